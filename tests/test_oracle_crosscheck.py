@@ -1,0 +1,169 @@
+"""Oracle vs the independent `transformers` ports (architecture cross-check, CPU).
+
+The reference's SuperPoint / LightGlue arithmetic is absent from /root/reference
+(empty submodules) and it ships no golden vectors, so the restatement in oracle/ is
+checked against the HF ports with identical seeded weights.  Known
+HF-vs-upstream deltas handled here: HF SuperPoint applies border removal against an
+8x too large image (only the low border is enforced) and returns relative coords.
+"""
+import pytest
+import torch
+
+from imcui_hip.synth import make_pair
+from oracle.lightglue import LightGlueOracle
+from oracle.superpoint import SuperPointOracle
+from oracle.weights import lightglue_state_dict, superpoint_state_dict
+
+transformers = pytest.importorskip("transformers")
+
+SP_MAP = {
+    "conv1a": "encoder.conv_blocks.0.conv_a",
+    "conv1b": "encoder.conv_blocks.0.conv_b",
+    "conv2a": "encoder.conv_blocks.1.conv_a",
+    "conv2b": "encoder.conv_blocks.1.conv_b",
+    "conv3a": "encoder.conv_blocks.2.conv_a",
+    "conv3b": "encoder.conv_blocks.2.conv_b",
+    "conv4a": "encoder.conv_blocks.3.conv_a",
+    "conv4b": "encoder.conv_blocks.3.conv_b",
+    "convPa": "keypoint_decoder.conv_score_a",
+    "convPb": "keypoint_decoder.conv_score_b",
+    "convDa": "descriptor_decoder.conv_descriptor_a",
+    "convDb": "descriptor_decoder.conv_descriptor_b",
+}
+
+
+def _hf_superpoint(sd, **kw):
+    from transformers import SuperPointConfig, SuperPointForKeypointDetection
+
+    hf = SuperPointForKeypointDetection(SuperPointConfig(**kw)).eval()
+    m = {}
+    for k, v in SP_MAP.items():
+        m[v + ".weight"] = sd[k + ".weight"]
+        m[v + ".bias"] = sd[k + ".bias"]
+    hf.load_state_dict(m, strict=True)
+    return hf
+
+
+@pytest.mark.parametrize("nms_radius,max_kpts", [(3, -1), (4, 300)])
+def test_superpoint_oracle_vs_hf(nms_radius, max_kpts):
+    torch.set_num_threads(4)
+    h, w = 240, 320
+    img0, _, _ = make_pair(3, h, w, n_blobs=500)
+    sd = superpoint_state_dict(0)
+    conf = dict(nms_radius=nms_radius, max_keypoints=max_kpts, keypoint_threshold=0.005, remove_borders=4)
+    out = SuperPointOracle(sd)({"image": img0}, conf)
+    hf = _hf_superpoint(
+        sd, keypoint_threshold=0.005, max_keypoints=max_kpts, nms_radius=nms_radius, border_removal_distance=4
+    )
+    with torch.no_grad():
+        ref = hf(img0.repeat(1, 3, 1, 1))
+    mask = ref.mask[0].bool()
+    k_hf = (ref.keypoints[0][mask] * torch.tensor([float(w), float(h)])).round()
+    s_hf, d_hf = ref.scores[0][mask], ref.descriptors[0][mask]
+    k_or, s_or, d_or = out["keypoints"][0], out["scores"][0], out["descriptors"][0].T
+    assert len(k_or) > 100
+    # HF keeps the high-border band the upstream code removes: compare on the interior
+    inner = (k_hf[:, 0] < w - 4) & (k_hf[:, 1] < h - 4)
+    if max_kpts < 0:
+        k_hf, s_hf, d_hf = k_hf[inner], s_hf[inner], d_hf[inner]
+        assert torch.equal(k_hf, k_or)
+        assert torch.equal(s_hf, s_or)
+        assert (d_hf - d_or).abs().max().item() < 1e-6
+    else:
+        # top-k is taken before/after a different border filter: compare the common points
+        key = lambda k: (k[:, 1] * w + k[:, 0]).long()  # noqa: E731
+        common = set(key(k_hf).tolist()) & set(key(k_or).tolist())
+        assert len(common) > 0.8 * len(k_or)
+        lut = {v: i for i, v in enumerate(key(k_hf).tolist())}
+        for i, v in enumerate(key(k_or).tolist()):
+            if v in lut:
+                assert s_or[i].item() == s_hf[lut[v]].item()
+                assert (d_or[i] - d_hf[lut[v]]).abs().max().item() < 1e-6
+
+
+def _hf_lightglue(lsd, dc, wc, th):
+    from transformers import LightGlueConfig, LightGlueForKeypointMatching, SuperPointConfig
+
+    cfg = LightGlueConfig(
+        keypoint_detector_config=SuperPointConfig(), depth_confidence=dc, width_confidence=wc, filter_threshold=th
+    )
+    hf = LightGlueForKeypointMatching(cfg).eval()
+    m = {k: v for k, v in hf.state_dict().items() if k.startswith("keypoint_detector")}
+    m["positional_encoder.projector.weight"] = lsd["posenc.Wr.weight"]
+    for i in range(9):
+        p, q = f"transformers.{i}.", f"transformer_layers.{i}."
+        W = lsd[p + "self_attn.Wqkv.weight"].view(4, 64, 3, 256)
+        B = lsd[p + "self_attn.Wqkv.bias"].view(4, 64, 3)
+        for t, nm in enumerate(["q_proj", "k_proj", "v_proj"]):
+            m[q + f"self_attention.{nm}.weight"] = W[:, :, t, :].reshape(256, 256)
+            m[q + f"self_attention.{nm}.bias"] = B[:, :, t].reshape(256)
+        m[q + "self_attention.o_proj.weight"] = lsd[p + "self_attn.out_proj.weight"]
+        m[q + "self_attention.o_proj.bias"] = lsd[p + "self_attn.out_proj.bias"]
+        for blk, src in [("self_mlp", "self_attn"), ("cross_mlp", "cross_attn")]:
+            for a, b in [("fc1", "ffn.0"), ("layer_norm", "ffn.1"), ("fc2", "ffn.3")]:
+                m[q + f"{blk}.{a}.weight"] = lsd[p + f"{src}.{b}.weight"]
+                m[q + f"{blk}.{a}.bias"] = lsd[p + f"{src}.{b}.bias"]
+        for nm in ["q_proj", "k_proj"]:
+            m[q + f"cross_attention.{nm}.weight"] = lsd[p + "cross_attn.to_qk.weight"]
+            m[q + f"cross_attention.{nm}.bias"] = lsd[p + "cross_attn.to_qk.bias"]
+        for a, b in [("v_proj", "to_v"), ("o_proj", "to_out")]:
+            m[q + f"cross_attention.{a}.weight"] = lsd[p + f"cross_attn.{b}.weight"]
+            m[q + f"cross_attention.{a}.bias"] = lsd[p + f"cross_attn.{b}.bias"]
+        a, b = f"log_assignment.{i}.", f"match_assignment_layers.{i}."
+        for x, y in [("final_projection", "final_proj"), ("matchability", "matchability")]:
+            m[b + x + ".weight"] = lsd[a + y + ".weight"]
+            m[b + x + ".bias"] = lsd[a + y + ".bias"]
+        if i < 8:
+            m[f"token_confidence.{i}.token.weight"] = lsd[f"token_confidence.{i}.token.0.weight"]
+            m[f"token_confidence.{i}.token.bias"] = lsd[f"token_confidence.{i}.token.0.bias"]
+    hf.load_state_dict(m, strict=True)
+    return hf
+
+
+def synthetic_matching_problem(seed, n, m, n_out, noise=0.05):
+    """Keypoints/descriptors with known correspondences (distinctive random descriptors)."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(seed)
+    k0 = torch.rand(n, 2, generator=g) * torch.tensor([632.0, 472.0]) + 4
+    perm = torch.randperm(n, generator=g)[:m]
+    k1 = k0[perm] + torch.randn(m, 2, generator=g)
+    d0 = F.normalize(torch.randn(n, 256, generator=g), dim=1)
+    d1 = F.normalize(d0[perm] + noise * torch.randn(m, 256, generator=g), dim=1)
+    d1[:n_out] = F.normalize(torch.randn(n_out, 256, generator=g), dim=1)
+    img = torch.zeros(1, 1, 480, 640)
+    return {
+        "image0": img,
+        "image1": img,
+        "keypoints0": k0[None],
+        "keypoints1": k1[None],
+        "descriptors0": d0.T[None].contiguous(),
+        "descriptors1": d1.T[None].contiguous(),
+    }
+
+
+# Only these two modes run in the HF port: it crashes when exactly one of early-stop / pruning is on.
+@pytest.mark.parametrize("dc,wc", [(-1.0, -1.0), (0.95, 0.99)])
+def test_lightglue_oracle_vs_hf(dc, wc):
+    torch.set_num_threads(4)
+    lsd = lightglue_state_dict(0)
+    data = synthetic_matching_problem(7, 400, 350, 100)
+    out = LightGlueOracle(lsd, dict(depth_confidence=dc, width_confidence=wc, filter_threshold=0.1))(data)
+    hf = _hf_lightglue(lsd, dc, wc, 0.1)
+    n0, n1 = data["keypoints0"].shape[1], data["keypoints1"].shape[1]
+    N = max(n0, n1)
+    kp = torch.zeros(1, 2, N, 2)
+    de = torch.zeros(1, 2, N, 256)
+    mask = torch.zeros(1, 2, N, dtype=torch.int)
+    kp[0, 0, :n0], kp[0, 1, :n1] = data["keypoints0"][0], data["keypoints1"][0]
+    de[0, 0, :n0], de[0, 1, :n1] = data["descriptors0"][0].T, data["descriptors1"][0].T
+    mask[0, 0, :n0] = 1
+    mask[0, 1, :n1] = 1
+    with torch.no_grad():
+        matches, mscores, prune, _, _ = hf._match_image_pair(kp, de, 480, 640, mask=mask)
+    matches, mscores, prune = matches.reshape(1, 2, -1), mscores.reshape(1, 2, -1), prune.reshape(1, 2, -1)
+    assert (out["matches0"] > -1).sum() > 50
+    assert torch.equal(matches[0, 0, :n0].long(), out["matches0"][0])
+    assert torch.equal(matches[0, 1, :n1].long(), out["matches1"][0])
+    assert (mscores[0, 0, :n0] - out["matching_scores0"][0]).abs().max().item() < 2e-5
+    assert torch.equal(prune[0, 0, :n0].long(), out["prune0"][0].long())
