@@ -1,0 +1,87 @@
+// Handle management, error reporting and the exported building-block entry points.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "attention.h"
+#include "conv.h"
+#include "gemm.h"
+#include "imcui_hip.h"
+
+int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...) {
+    if (h) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(h->err, sizeof h->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+extern "C" int imcui_hip_version(void) { return 100; }
+
+extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
+    if (!out) return IMCUI_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return IMCUI_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return IMCUI_ERR_HIP;
+    imcui_hip_s* h = (imcui_hip_s*)calloc(1, sizeof(imcui_hip_s));
+    if (!h) return IMCUI_ERR_ARG;
+    h->device = device;
+    h->num_cu = prop.multiProcessorCount;
+    h->err[0] = 0;
+    *out = h;
+    return IMCUI_OK;
+}
+
+extern "C" void imcui_hip_destroy(imcui_hip_t* h) { free(h); }
+
+extern "C" const char* imcui_hip_last_error(const imcui_hip_t* h) { return h ? h->err : "null handle"; }
+
+extern "C" int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float* W, const float* bias, float* C, int M, int N,
+                                    int K, int relu, void* stream) {
+    if (!h || !A || !W || !C) return imcui_set_err(h, IMCUI_ERR_ARG, "linear: null argument");
+    GemmP g;
+    g.epi = relu ? EPI_RELU : EPI_BIAS;
+    g.A = A;
+    g.lda = K;
+    g.W = W;
+    g.ldw = K;
+    g.bias = bias;
+    g.C = C;
+    g.ldc = N;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    return gemm_launch(h, g, (hipStream_t)stream);
+}
+
+extern "C" int imcui_hip_conv3x3_pack(const float* w_oihw, int Cout, int Cin, float* packed) {
+    if (!w_oihw || !packed || Cin % 32 || Cout % 64) return IMCUI_ERR_ARG;
+    pack_conv3x3(w_oihw, Cout, Cin, packed);
+    return IMCUI_OK;
+}
+
+extern "C" int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in, const float* wp, const float* bias, float* out, int B,
+                                     int H, int W, int Cin, int Cout, int relu, int pool, void* stream) {
+    if (!h || !in || !wp || !bias || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: null argument");
+    return conv3x3_launch(h, in, wp, bias, out, B, H, W, Cin, Cout, relu, pool, (hipStream_t)stream);
+}
+
+extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O,
+                                       const int* cnt, int S, int heads, int rows, int cross, void* stream) {
+    if (!h || !Q || !K || !V || !O || !cnt) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: null argument");
+    AttnP a;
+    a.Q = Q;
+    a.K = K;
+    a.V = V;
+    a.O = O;
+    a.cnt = cnt;
+    a.nseq = S;
+    a.heads = heads;
+    a.rows_per_seq = rows;
+    a.cross = cross;
+    return attention_launch(h, a, (hipStream_t)stream);
+}

@@ -1,0 +1,16 @@
+// Flash-style softmax(Q K^T) V on the f32 matrix cores for LightGlue (head_dim 64).
+#pragma once
+#include "common.h"
+
+struct AttnP {
+    // head-major operands: [seq][head][rows_per_seq][64]; Q is pre-scaled (and RoPE'd)
+    const float* Q = nullptr;
+    const float* K = nullptr;
+    const float* V = nullptr;
+    float* O = nullptr;         // token-major context [seq * rows_per_seq + i][heads * 64]
+    const int* cnt = nullptr;   // valid rows per sequence
+    const int* active = nullptr;  // per pair (seq >> 1), may be null
+    int nseq = 0, heads = 4, rows_per_seq = 0;
+    int cross = 0;  // 0: keys/values of the same sequence; 1: of the partner image (seq ^ 1)
+};
+int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);

@@ -1,0 +1,180 @@
+// Flash attention in exact f32 on v_mfma_f32_32x32x2_f32 (gfx950), head_dim = 64.
+//
+// A workgroup (4 waves) owns 128 queries of one (sequence, head); wave w owns 32 of them.
+// Both products are computed TRANSPOSED so that the soft-max statistics of a query are
+// lane-local and P never leaves registers:
+//   S^T[key, q] = K . Q^T      A = K tile rows (LDS, [d-quad][key][4]),  B = Q (32 registers)
+//   O^T[d,  q]  = V^T . P^T    A = V tile (LDS, [key][d]),              B = P = the S^T registers
+// In the C/D fragment layout column = lane & 31 = query, so max / sum / rescale of a query
+// touch only that lane (plus one cross-half exchange), and the S^T accumulator registers are
+// already the B operand of the second product (its k index = key = the register's row).
+// K/V tiles of 64 keys are prefetched through registers while the previous tile is multiplied.
+#include "attention.h"
+
+#define KT 64        // keys per tile
+#define KSTR 65      // padded key stride of the K image (float4 units)
+
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+    // one LDS object: K image [d-quad][key] (float4), then V [key][d]; the front of it is
+    // reused as the per-wave output transpose buffer after the last tile
+    __shared__ float4 smem4[16 * KSTR + KT * 16];
+    float4* Ks = smem4;
+    float* Vs = reinterpret_cast<float*>(smem4 + 16 * KSTR);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128;
+    const int nq = p.cnt[seq];
+    if (q0 >= nq) return;
+    if (p.active && p.active[seq >> 1] == 0) return;
+    const int kseq = p.cross ? (seq ^ 1) : seq;
+    const int nk = p.cnt[kseq];
+    const int R = p.rows_per_seq;
+
+    const float* Qb = p.Q + ((size_t)seq * p.heads + head) * R * 64;
+    const float* Kb = p.K + ((size_t)kseq * p.heads + head) * R * 64;
+    const float* Vb = p.V + ((size_t)kseq * p.heads + head) * R * 64;
+
+    // this lane's query row: 32 of its 64 dims (d = 32*hi + 0..31)
+    const int qrow = q0 + wid * 32 + lo;
+    float qreg[32];
+    {
+        const float4* qsrc = reinterpret_cast<const float4*>(Qb + (size_t)min(qrow, R - 1) * 64 + 32 * hi);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 v = qsrc[t];
+            qreg[4 * t + 0] = v.x;
+            qreg[4 * t + 1] = v.y;
+            qreg[4 * t + 2] = v.z;
+            qreg[4 * t + 3] = v.w;
+        }
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // staging: 64 keys x 16 float4 per operand = 1024 float4 -> 4 per thread
+    const int s_dq = tid & 15, s_key = tid >> 4;  // key + 16*it
+    float4 rk[4], rv[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int key = k0 + s_key + 16 * it;
+            if (key < nk) {
+                rk[it] = *reinterpret_cast<const float4*>(Kb + (size_t)key * 64 + s_dq * 4);
+                rv[it] = *reinterpret_cast<const float4*>(Vb + (size_t)key * 64 + s_dq * 4);
+            } else {  // rows past the sequence end may hold anything (even NaN): feed zeros
+                rk[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    const int ntile = (nk + KT - 1) / KT;
+    if (ntile > 0) load_tile(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int k0 = tile * KT;
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int key = s_key + 16 * it;
+            Ks[s_dq * KSTR + key] = rk[it];
+            *reinterpret_cast<float4*>(&Vs[key * 64 + s_dq * 4]) = rv[it];
+        }
+        __syncthreads();
+        if (tile + 1 < ntile) load_tile(k0 + KT);
+
+        // ---- S^T = K . Q^T  (two 32-key fragments)
+        f32x16 s[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[f][r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float4 a = Ks[(8 * hi + t) * KSTR + 32 * f + lo];
+                s[f] = mfma32(a.x, qreg[4 * t + 0], s[f]);
+                s[f] = mfma32(a.y, qreg[4 * t + 1], s[f]);
+                s[f] = mfma32(a.z, qreg[4 * t + 2], s[f]);
+                s[f] = mfma32(a.w, qreg[4 * t + 3], s[f]);
+            }
+        }
+        // ---- online soft-max for query `lo` (keys of this lane: 2 x 16 registers)
+        float m_t = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + 32 * f + frag_row(r, hi);
+                const float v = (key < nk) ? s[f][r] : -INFINITY;
+                s[f][r] = v;
+                m_t = fmaxf(m_t, v);
+            }
+        m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        const float m_new = fmaxf(m_run, m_t);  // finite: every tile holds >= 1 valid key
+        const float alpha = expf(m_run - m_new);
+        float l_t = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = expf(s[f][r] - m_new);
+                s[f][r] = pv;
+                l_t += pv;
+            }
+        l_run = l_run * alpha + l_t;
+        m_run = m_new;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * f + frag_row(r, hi);
+                const float pb = s[f][r];
+                o[0] = mfma32(Vs[key * 64 + lo], pb, o[0]);
+                o[1] = mfma32(Vs[key * 64 + 32 + lo], pb, o[1]);
+            }
+    }
+
+    // ---- normalise and write: transpose through LDS so each query row is stored contiguously
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (ntile > 0) ? 1.0f / l_tot : 0.0f;
+    __syncthreads();
+    float* Os = reinterpret_cast<float*>(smem4) + wid * (32 * 33);  // per wave [query][33]
+    const int H64 = p.heads * 64;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        // write O^T fragment f: element (d = frag_row(r,hi), q = lo) -> Os[q][d]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[lo * 33 + frag_row(r, hi)] = o[f][r] * inv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
+        __builtin_amdgcn_wave_barrier();
+        // read back: lane covers d = lo for query rows q = hi, hi+2, ...
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int q = 2 * qq + hi;
+            const int row = q0 + wid * 32 + q;
+            if (row < nq) p.O[((size_t)seq * R + row) * H64 + head * 64 + 32 * f + lo] = Os[q * 33 + lo];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
+    if (p.rows_per_seq % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
+    if (p.nseq <= 0) return IMCUI_OK;
+    dim3 grid(p.rows_per_seq / 128, p.heads, p.nseq);
+    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}

@@ -1,0 +1,99 @@
+// Common device/host helpers for the gfx950 (MI355X) kernels of libimcui_hip.
+//
+// All contractions use the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32
+// (64 FLOP/clk/SIMD, bitwise an fmaf chain) so that results stay within fp32
+// round-off of the PyTorch-CPU reference path (keypoint indices / match indices
+// must be bit-exact, tensors within 1e-4).
+//
+// Fragment conventions used everywhere (wave64, lane l, hi = l >> 5, lo = l & 31):
+//   A operand : one float per lane = A[row = lo][k = hi]
+//   B operand : one float per lane = B[k = hi][col = lo]
+//   C/D       : 16 floats per lane, reg r -> row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lo
+// A k-quad (4 consecutive k) is fetched with one 16-byte LDS read; the four MFMA
+// steps that consume it pair k = 4*q0 + j (hi = 0 lanes) with k = 4*q1 + j (hi = 1
+// lanes) -- any k order is legal as long as A and B agree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define IMCUI_WAVE 64
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row inside a 32x32 C/D fragment held by (reg r, half hi)
+__device__ __forceinline__ int frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))  (same form ATen uses)
+__device__ __forceinline__ float logsigmoidf_(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a
+// private 4 MiB L2).  Give every XCD a contiguous run of tile ids so that neighbouring tiles
+// (which share an operand panel) hit the same L2.  Bijective for any nwg.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// status codes of the C ABI
+#define IMCUI_OK 0
+#define IMCUI_ERR_ARG -1
+#define IMCUI_ERR_WS -2
+#define IMCUI_ERR_HIP -3
+#define IMCUI_ERR_UNSUPPORTED -4
+
+struct imcui_hip_s {
+    int device;
+    int num_cu;
+    char err[512];
+};
+
+int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...);
+
+#define IMCUI_CHECK_LAUNCH(h)                                                          \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess)                                                         \
+            return imcui_set_err(h, IMCUI_ERR_HIP, "%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+    } while (0)
+
+// bump allocator over the caller-provided workspace
+struct WsAlloc {
+    char* base;
+    size_t cap;
+    size_t off;
+    bool ok;
+    WsAlloc(void* p, size_t c) : base((char*)p), cap(c), off(0), ok(true) {}
+    template <typename T>
+    T* get(size_t n) {
+        size_t bytes = align_up(n * sizeof(T), 256);
+        if (base != nullptr && off + bytes > cap) ok = false;
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+};

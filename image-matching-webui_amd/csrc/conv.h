@@ -1,0 +1,18 @@
+// NHWC f32 convolutions for the SuperPoint VGG encoder / heads (gfx950).
+#pragma once
+#include "common.h"
+
+// 3x3, pad 1, stride 1, +bias, +ReLU, optional fused 2x2/2 max-pool.
+// in  : [B, H, W, Cin]  (NHWC), Cin % 32 == 0
+// wp  : packed weights  [Cin/32][9 taps][8 cq][Cout][4]   (see pack_conv3x3)
+// out : [B, H, W, Cout] or, with pool, [B, H/2, W/2, Cout];  Cout % 64 == 0
+int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float* bias, float* out, int B, int H, int W,
+                   int Cin, int Cout, int relu, int pool, hipStream_t stream);
+
+// first layer: 1 -> 64 channels, 3x3, pad 1, +bias, +ReLU.  in [B,H,W] ; w [9][64] ; out [B,H,W,64]
+int conv1a_launch(imcui_hip_s* h, const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
+                  hipStream_t stream);
+
+// host-side packers (OIHW -> device layouts above)
+void pack_conv3x3(const float* w_oihw, int Cout, int Cin, float* dst);
+void pack_conv1a(const float* w_oihw, float* dst);  // [64,1,3,3] -> [9][64]

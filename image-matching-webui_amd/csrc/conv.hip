@@ -1,0 +1,211 @@
+// Implicit-GEMM 3x3 convolution on the f32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC.
+//
+// One workgroup (4 waves) computes an 8x16 pixel tile x 64 output channels.  The K dimension
+// (9 taps x Cin) is walked as Cin/32 channel chunks x 9 taps: the (8+2)x(16+2) input patch of
+// a chunk is staged once into LDS as [channel-quad][pixel][4] (image tiles are read from HBM
+// in full 128-byte channel runs per pixel), the 32x64 weight slab of a tap is double-buffered
+// in LDS and prefetched through registers.  Wave w owns output rows 2w, 2w+1 (32 pixels, one
+// MFMA row fragment) and all 64 output channels (two column fragments).  ReLU and the 2x2
+// max-pool are applied in registers: the four pixels of a pooling window live in one lane.
+#include "conv.h"
+
+#define TH 8
+#define TW 16
+#define PW (TW + 2)
+#define PH (TH + 2)
+#define NPIX (PH * PW)  // 180
+#define PSTR 181        // padded pixel stride (float4 units) -> conflict-free staging writes
+#define WSTR 65         // padded cout stride (float4 units)
+
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                      int W, int Cin, int Cout, int tiles_x, int tiles_y, int relu,
+                                                      int pool) {
+    __shared__ float4 Ps[8 * PSTR];
+    __shared__ float4 Ws[2][8 * WSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int ncout = Cout >> 6;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = t % ncout;
+    int sp = t / ncout;
+    const int tx = sp % tiles_x;
+    sp /= tiles_x;
+    const int ty = sp % tiles_y;
+    const int b = sp / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, cout0 = ct * 64;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    const int nchunk = Cin >> 5;
+    const float4* wp4 = reinterpret_cast<const float4*>(wp);
+    // this lane's pixel inside the wave's 2x16 strip
+    const int py = 2 * wid + (lo >> 4), px = lo & 15;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();  // everybody is done with the previous patch
+        // ---- stage the input patch of this channel chunk: NPIX pixels x 8 channel quads
+        for (int idx = tid; idx < NPIX * 8; idx += 256) {
+            const int cq = idx & 7, pp = idx >> 3;
+            const int gy = y0 - 1 + pp / PW, gx = x0 - 1 + pp % PW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + cq * 4);
+            Ps[cq * PSTR + pp] = v;
+        }
+        // ---- weight slab prefetch for tap 0: 8 cq x 64 cout float4 = 512 -> 2 per thread
+        float4 rw[2];
+        auto wload = [&](int tap) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + 256 * it;
+                const int cq = idx >> 6, co = idx & 63;
+                rw[it] = wp4[((size_t)(ch * 9 + tap) * 8 + cq) * Cout + cout0 + co];
+            }
+        };
+        wload(0);
+        for (int tap = 0; tap < 9; ++tap) {
+            float4* wbuf = Ws[tap & 1];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + 256 * it;
+                wbuf[(idx >> 6) * WSTR + (idx & 63)] = rw[it];
+            }
+            __syncthreads();
+            if (tap + 1 < 9) wload(tap + 1);
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int pp = (py + dy) * PW + px + dx;
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                const int cq = 2 * tq + hi;
+                const float4 a = Ps[cq * PSTR + pp];
+                const float4 b0 = wbuf[cq * WSTR + lo];
+                const float4 b1 = wbuf[cq * WSTR + 32 + lo];
+                acc[0] = mfma32(a.x, b0.x, acc[0]);
+                acc[1] = mfma32(a.x, b1.x, acc[1]);
+                acc[0] = mfma32(a.y, b0.y, acc[0]);
+                acc[1] = mfma32(a.y, b1.y, acc[1]);
+                acc[0] = mfma32(a.z, b0.z, acc[0]);
+                acc[1] = mfma32(a.z, b1.z, acc[1]);
+                acc[0] = mfma32(a.w, b0.w, acc[0]);
+                acc[1] = mfma32(a.w, b1.w, acc[1]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, optional 2x2 max-pool (window = regs {r, r+1, r+8, r+9})
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = cout0 + n * 32 + lo;
+        const float bv = bias[co];
+        if (pool) {
+            const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                float v = fmaxf(fmaxf(acc[n][r], acc[n][r + 1]), fmaxf(acc[n][r + 8], acc[n][r + 9])) + bv;
+                if (relu) v = fmaxf(v, 0.0f);
+                const int p = frag_row(r, hi);  // < 16: first row of the strip
+                const int oy = (y0 >> 1) + wid, ox = (x0 >> 1) + (p >> 1);
+                if (oy < Ho && ox < Wo) out[(((size_t)b * Ho + oy) * Wo + ox) * Cout + co] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = frag_row(r, hi);
+                const int oy = y0 + 2 * wid + (p >> 4), ox = x0 + (p & 15);
+                float v = acc[n][r] + bv;
+                if (relu) v = fmaxf(v, 0.0f);
+                if (oy < H && ox < W) out[(((size_t)b * H + oy) * W + ox) * Cout + co] = v;
+            }
+        }
+    }
+}
+
+int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float* bias, float* out, int B, int H, int W,
+                   int Cin, int Cout, int relu, int pool, hipStream_t stream) {
+    if (Cin % 32 != 0 || Cout % 64 != 0)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
+    if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
+    const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
+    const long nwg = (long)tiles_x * tiles_y * (Cout / 64) * B;
+    if (nwg <= 0) return IMCUI_OK;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, in, wp, bias, out, H, W, Cin, Cout,
+                       tiles_x, tiles_y, relu, pool);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ conv1a (Cin = 1)
+// 16 lanes cover the 64 output channels of one pixel (4 channels each), so a wave stores
+// 4 pixels x 256 B = 1 KiB of contiguous NHWC output per instruction.
+__global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                     int W, long npix) {
+    const int cq = threadIdx.x & 15;
+    float4 wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const float4*>(w + t * 64 + cq * 4);
+    const float4 bv = *reinterpret_cast<const float4*>(bias + cq * 4);
+    const long stride = (long)gridDim.x * 16;
+    for (long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += stride) {
+        const int x = (int)(p % W);
+        const long q = p / W;
+        const int y = (int)(q % H);
+        const float* img = in + (q - y) * W;  // start of this image
+        float4 a = bv;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x + dx - 1;
+                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? img[(long)yy * W + xx] : 0.0f;
+                const float4 k = wk[dy * 3 + dx];
+                a.x = fmaf(v, k.x, a.x);
+                a.y = fmaf(v, k.y, a.y);
+                a.z = fmaf(v, k.z, a.z);
+                a.w = fmaf(v, k.w, a.w);
+            }
+        }
+        a.x = fmaxf(a.x, 0.f);
+        a.y = fmaxf(a.y, 0.f);
+        a.z = fmaxf(a.z, 0.f);
+        a.w = fmaxf(a.w, 0.f);
+        *reinterpret_cast<float4*>(out + p * 64 + cq * 4) = a;
+    }
+}
+
+int conv1a_launch(imcui_hip_s* h, const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
+                  hipStream_t stream) {
+    const long npix = (long)B * H * W;
+    if (npix <= 0) return IMCUI_OK;
+    long blocks = (npix + 15) / 16;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(conv1a_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, w, bias, out, H, W, npix);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ host packers
+void pack_conv3x3(const float* w, int Cout, int Cin, float* dst) {
+    // dst[((ch*9 + tap)*8 + cq)*Cout + co][j] = w[co][ch*32 + cq*4 + j][tap]
+    const int nchunk = Cin / 32;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int cq = 0; cq < 8; ++cq)
+                for (int co = 0; co < Cout; ++co)
+                    for (int j = 0; j < 4; ++j) {
+                        const int ci = ch * 32 + cq * 4 + j;
+                        dst[((((size_t)ch * 9 + tap) * 8 + cq) * Cout + co) * 4 + j] = w[((size_t)co * Cin + ci) * 9 + tap];
+                    }
+}
+
+void pack_conv1a(const float* w, float* dst) {
+    for (int tap = 0; tap < 9; ++tap)
+        for (int co = 0; co < 64; ++co) dst[tap * 64 + co] = w[co * 9 + tap];
+}

@@ -1,0 +1,52 @@
+// f32 MFMA GEMM with fused epilogues:  C = epi(A[M,K] * W[N,K]^T + bias).
+// Both operands are K-contiguous (nn.Linear weight layout / NHWC activations).
+#pragma once
+#include "common.h"
+
+enum GemmEpi {
+    EPI_BIAS = 0,   // C = (acc + bias) * alpha          (bias may be null)
+    EPI_RELU = 1,   // C = relu(acc + bias)
+    EPI_RESID = 2,  // C += acc + bias                  (in-place residual)
+    EPI_QKV = 3,    // LightGlue SelfBlock: bias, RoPE on q/k, q *= alpha, head-major split
+    EPI_CROSS = 4,  // LightGlue CrossBlock: [qk | v] = bias, qk *= alpha, head-major split
+};
+
+struct GemmP {
+    int epi = EPI_BIAS;
+    const float* A = nullptr;   // [M, K1] (or [M, K] when A2 == nullptr)
+    long lda = 0;
+    const float* A2 = nullptr;  // optional second K-slab: k >= K1 comes from A2[:, k - K1]
+    long lda2 = 0;
+    int K1 = 0;
+    const float* W = nullptr;  // [N, K]
+    long ldw = 0;
+    const float* bias = nullptr;  // [N] or null
+    float* C = nullptr;           // [M, N] (EPI_BIAS / RELU / RESID)
+    long ldc = 0;
+    int M = 0, N = 0, K = 0;
+    float alpha = 1.0f;
+    // ragged sequences: row tile r0 belongs to sequence r0 / rows_per_seq; tiles whose first
+    // row is >= cnt[seq] (or whose pair active[seq >> 1] == 0) are skipped.
+    const int* cnt = nullptr;
+    const int* active = nullptr;
+    int rows_per_seq = 0;
+    // per-pair weight selection: W += (wsel[seq >> 1] + wsel_off) * w_stride, bias likewise
+    const int* wsel = nullptr;
+    int wsel_off = 0;
+    long w_stride = 0, b_stride = 0;
+    // batched mode (blockIdx.z = batch): per-batch strides and dynamic M/N
+    int batch = 1;
+    long a_bs = 0, w_bs = 0, c_bs = 0;
+    const int* mcnt = nullptr;  // M for batch z = mcnt[z * cnt_stride]
+    const int* ncnt = nullptr;  // N for batch z = ncnt[z * cnt_stride]
+    int cnt_stride = 1;
+    // EPI_QKV / EPI_CROSS outputs, head-major [seq][head][row_in_seq][64]
+    float* Q = nullptr;
+    float* Kt = nullptr;
+    float* V = nullptr;
+    const float* rope_cos = nullptr;  // [rows, 32]
+    const float* rope_sin = nullptr;
+    int heads = 4;
+};
+
+int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);

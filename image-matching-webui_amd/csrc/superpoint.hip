@@ -1,0 +1,614 @@
+// SuperPoint forward on MI355X: VGG encoder + detector / descriptor heads + NMS + ordered
+// key-point selection + descriptor sampling.  Replaces the `self.net(data, self.conf)` call of
+// imcui/hloc/extractors/superpoint.py:56-57.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "conv.h"
+#include "gemm.h"
+#include "imcui_hip.h"
+
+// ------------------------------------------------------------------ packed weight layout
+struct SpLayout {
+    size_t w[12], b[12], total;
+};
+static const int SP_COUT[12] = {64, 64, 64, 64, 128, 128, 128, 128, 256, 65, 256, 256};
+static const int SP_CIN[12] = {1, 64, 64, 64, 64, 128, 128, 128, 128, 256, 128, 256};
+static const int SP_K[12] = {3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 3, 1};
+enum { L1A, L1B, L2A, L2B, L3A, L3B, L4A, L4B, LPA, LPB, LDA, LDB };
+
+static SpLayout sp_layout() {
+    SpLayout l;
+    size_t off = 0;
+    for (int i = 0; i < 12; ++i) {
+        l.w[i] = off;
+        off += align_up((size_t)SP_COUT[i] * SP_CIN[i] * SP_K[i] * SP_K[i], 64);
+        l.b[i] = off;
+        off += align_up((size_t)SP_COUT[i], 64);
+    }
+    l.total = off;
+    return l;
+}
+
+extern "C" size_t imcui_hip_superpoint_packed_floats(void) { return sp_layout().total; }
+
+extern "C" int imcui_hip_superpoint_pack_weights(const float* const* w, const float* const* b, float* packed) {
+    if (!w || !b || !packed) return IMCUI_ERR_ARG;
+    const SpLayout l = sp_layout();
+    memset(packed, 0, l.total * sizeof(float));
+    for (int i = 0; i < 12; ++i) {
+        if (!w[i] || !b[i]) return IMCUI_ERR_ARG;
+        if (i == L1A)
+            pack_conv1a(w[i], packed + l.w[i]);
+        else if (SP_K[i] == 3)
+            pack_conv3x3(w[i], SP_COUT[i], SP_CIN[i], packed + l.w[i]);
+        else  // 1x1: [Cout][Cin] is already the K-contiguous GEMM layout
+            memcpy(packed + l.w[i], w[i], (size_t)SP_COUT[i] * SP_CIN[i] * sizeof(float));
+        memcpy(packed + l.b[i], b[i], (size_t)SP_COUT[i] * sizeof(float));
+    }
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ detector soft-max + depth-to-space
+// One wave per coarse cell: lane l holds logit l, the dustbin (65th) logit is broadcast.
+__global__ __launch_bounds__(256) void sp_softmax_kernel(const float* __restrict__ logits, int ldl,
+                                                         float* __restrict__ scores, int Hc, int Wc, long ncell) {
+    const int lane = threadIdx.x & 63;
+    const long cell = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cell >= ncell) return;
+    const float* row = logits + cell * ldl;
+    const float x = row[lane];
+    const float dust = row[64];
+    const float m = fmaxf(wave_max(x), dust);
+    const float e = expf(x - m);
+    const float sum = wave_sum(e) + expf(dust - m);
+    const float pr = e / sum;
+    const int cx = (int)(cell % Wc);
+    const long t = cell / Wc;
+    const int cy = (int)(t % Hc);
+    const long b = t / Hc;
+    const int W = Wc * 8, H = Hc * 8;
+    scores[(b * H + cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)] = pr;
+}
+
+// ------------------------------------------------------------------ fused simple_nms
+// All five (2r+1)^2 max-pools of upstream `simple_nms` in one pass over an LDS tile with a
+// 5r halo; each pool is separable (row max then column max), and max is exact in any order, so
+// the result is bitwise the reference's.  Out-of-image = -inf (scores) / 0 (masks), i.e.
+// max_pool2d's implicit padding.
+#define NMS_T 32
+__global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
+                                                     int W, int r) {
+    extern __shared__ __attribute__((aligned(16))) char nms_smem[];
+    const int halo = 5 * r;
+    const int Rg = NMS_T + 2 * halo;
+    const int n = Rg * Rg;
+    float* S = reinterpret_cast<float*>(nms_smem);
+    float* T = S + n;
+    float* SS = T + n;
+    unsigned char* M = reinterpret_cast<unsigned char*>(SS + n);
+    unsigned char* U = M + n;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * NMS_T - halo, x0 = blockIdx.x * NMS_T - halo;
+    const float* img = in + (size_t)b * H * W;
+
+    for (int i = tid; i < n; i += 256) {
+        const int u = i / Rg, v = i - u * Rg;
+        const int y = y0 + u, x = x0 + v;
+        S[i] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : -INFINITY;
+    }
+    __syncthreads();
+
+    auto inimg = [&](int i) {
+        const int u = i / Rg, v = i - u * Rg;
+        const int y = y0 + u, x = x0 + v;
+        return y >= 0 && y < H && x >= 0 && x < W;
+    };
+    // T = row-max of src (float array) / of a byte mask
+    auto rowmax_f = [&](const float* src) {
+        for (int i = tid; i < n; i += 256) {
+            const int u = i / Rg, v = i - u * Rg;
+            const int lo = max(v - r, 0), hi = min(v + r, Rg - 1);
+            float m = -INFINITY;
+            for (int c = lo; c <= hi; ++c) m = fmaxf(m, src[u * Rg + c]);
+            T[i] = m;
+        }
+    };
+    auto rowmax_b = [&](const unsigned char* src) {
+        for (int i = tid; i < n; i += 256) {
+            const int u = i / Rg, v = i - u * Rg;
+            const int lo = max(v - r, 0), hi = min(v + r, Rg - 1);
+            unsigned char m = 0;
+            for (int c = lo; c <= hi; ++c) m |= src[u * Rg + c];
+            T[i] = (float)m;
+        }
+    };
+    auto colmax = [&](int i) {
+        const int u = i / Rg, v = i - u * Rg;
+        const int lo = max(u - r, 0), hi = min(u + r, Rg - 1);
+        float m = -INFINITY;
+        for (int c = lo; c <= hi; ++c) m = fmaxf(m, T[c * Rg + v]);
+        return m;
+    };
+
+    // max_mask = scores == max_pool(scores)
+    rowmax_f(S);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) M[i] = (inimg(i) && S[i] == colmax(i)) ? 1 : 0;
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        // supp_mask = max_pool(max_mask) > 0 ; supp_scores = where(supp_mask, 0, scores)
+        rowmax_b(M);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const bool supp = colmax(i) > 0.0f;
+            U[i] = supp ? 1 : 0;
+            SS[i] = inimg(i) ? (supp ? 0.0f : S[i]) : -INFINITY;
+        }
+        __syncthreads();
+        // new_max_mask = supp_scores == max_pool(supp_scores) ; max_mask |= new_max_mask & ~supp_mask
+        rowmax_f(SS);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const bool nm = inimg(i) && (SS[i] == colmax(i));
+            if (nm && !U[i]) M[i] = 1;
+        }
+        __syncthreads();
+    }
+    float* dst = out + (size_t)b * H * W;
+    for (int i = tid; i < NMS_T * NMS_T; i += 256) {
+        const int ty = i / NMS_T, tx = i - ty * NMS_T;
+        const int y = blockIdx.y * NMS_T + ty, x = blockIdx.x * NMS_T + tx;
+        if (y < H && x < W) {
+            const int j = (ty + halo) * Rg + tx + halo;
+            dst[(size_t)y * W + x] = M[j] ? S[j] : 0.0f;
+        }
+    }
+}
+
+static int nms_launch(imcui_hip_s* h, const float* in, float* out, int B, int H, int W, int r, hipStream_t stream) {
+    if (r < 0 || r > 4) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "nms_radius=%d not supported (0..4)", r);
+    const int Rg = NMS_T + 10 * r;
+    const size_t smem = (size_t)Rg * Rg * (3 * sizeof(float) + 2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(sp_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    dim3 grid(cdiv(W, NMS_T), cdiv(H, NMS_T), B);
+    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(256), smem, stream, in, out, H, W, r);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ ordered candidate compaction
+// candidate: nms score > thr and inside the border band.  Row-major order is preserved (the
+// reference returns `nonzero` order when no top-k is needed).
+#define SEL_CHUNK 4096  // pixels per block (16 consecutive per thread)
+
+__device__ __forceinline__ bool sp_is_cand(float s, int idx, int H, int W, float thr, int border) {
+    const int y = idx / W, x = idx - y * W;
+    return s > thr && y >= border && y < H - border && x >= border && x < W - border;
+}
+
+__global__ __launch_bounds__(256) void sp_count_kernel(const float* __restrict__ nms, int H, int W, float thr,
+                                                       int border, int* __restrict__ blkcnt, int nchunk) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int npix = H * W;
+    const float* img = nms + (size_t)b * npix;
+    const int base = chunk * SEL_CHUNK + threadIdx.x * 16;
+    int c = 0;
+    for (int j = 0; j < 16; ++j) {
+        const int idx = base + j;
+        if (idx < npix && sp_is_cand(img[idx], idx, H, W, thr, border)) ++c;
+    }
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[b * nchunk + chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the per-chunk counts (one block per image, serial over <= a few hundred chunks)
+__global__ void sp_scan_kernel(const int* __restrict__ blkcnt, int* __restrict__ blkoff, int* __restrict__ ncand,
+                               int nchunk) {
+    if (threadIdx.x != 0) return;
+    const int b = blockIdx.x;
+    int run = 0;
+    for (int i = 0; i < nchunk; ++i) {
+        blkoff[b * nchunk + i] = run;
+        run += blkcnt[b * nchunk + i];
+    }
+    ncand[b] = run;
+}
+
+__global__ __launch_bounds__(256) void sp_compact_kernel(const float* __restrict__ nms, int H, int W, float thr,
+                                                         int border, const int* __restrict__ blkoff, int nchunk,
+                                                         unsigned long long* __restrict__ cand, int cand_cap) {
+    __shared__ int tcnt[256];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int npix = H * W;
+    const float* img = nms + (size_t)b * npix;
+    const int base = chunk * SEL_CHUNK + threadIdx.x * 16;
+    float v[16];
+    unsigned flags = 0;
+    int c = 0;
+    for (int j = 0; j < 16; ++j) {
+        const int idx = base + j;
+        v[j] = (idx < npix) ? img[idx] : 0.0f;
+        if (idx < npix && sp_is_cand(v[j], idx, H, W, thr, border)) {
+            flags |= 1u << j;
+            ++c;
+        }
+    }
+    tcnt[threadIdx.x] = c;
+    __syncthreads();
+    // exclusive prefix over the 256 per-thread counts (Hillis-Steele)
+    for (int o = 1; o < 256; o <<= 1) {
+        int add = (threadIdx.x >= o) ? tcnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        tcnt[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int pos = blkoff[b * nchunk + chunk] + tcnt[threadIdx.x] - c;
+    unsigned long long* dst = cand + (size_t)b * cand_cap;
+    for (int j = 0; j < 16; ++j)
+        if (flags & (1u << j)) {
+            const unsigned idx = (unsigned)(base + j);
+            if (pos < cand_cap)
+                dst[pos] = ((unsigned long long)__float_as_uint(v[j]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+            ++pos;
+        }
+}
+
+// ------------------------------------------------------------------ top-k (score desc, index asc)
+// One block per image.  64-bit keys (score bits << 32 | ~index) are unique, so "the k largest
+// keys" is a well defined set: 8 rounds of 8-bit radix select find the k-th key, the winners are
+// gathered into LDS and bitonic-sorted descending.
+#define TOPK_MAX 8192
+__global__ __launch_bounds__(1024) void sp_topk_kernel(const unsigned long long* __restrict__ cand, int cand_cap,
+                                                       const int* __restrict__ ncand, int max_kpts, int kcap, int W,
+                                                       float* __restrict__ kpts, float* __restrict__ scores,
+                                                       int* __restrict__ nkpts, int* __restrict__ status) {
+    __shared__ unsigned long long sel[TOPK_MAX];
+    __shared__ int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k, s_nsel;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long* c = cand + (size_t)b * cand_cap;
+    int n = ncand[b];
+    if (n > cand_cap) {
+        if (tid == 0) atomicOr(status, 1);  // candidate buffer overflow
+        n = cand_cap;
+    }
+    int k = (max_kpts < 0) ? n : min(n, max_kpts);
+    float* kp = kpts + (size_t)b * kcap * 2;
+    float* sc = scores + (size_t)b * kcap;
+    if (k > kcap) {
+        if (tid == 0) atomicOr(status, 2);  // output capacity too small
+        k = kcap;
+    }
+    if (tid == 0) nkpts[b] = k;
+    if (n <= k || max_kpts < 0) {
+        // no top-k: keep `nonzero` (row-major) order
+        for (int i = tid; i < k; i += 1024) {
+            const unsigned long long key = c[i];
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            kp[2 * i + 0] = (float)(idx % W);
+            kp[2 * i + 1] = (float)(idx / W);
+            sc[i] = __uint_as_float((unsigned)(key >> 32));
+        }
+        return;
+    }
+    if (k > TOPK_MAX) {
+        if (tid == 0) {
+            atomicOr(status, 4);  // top-k larger than the LDS sorter supports
+            nkpts[b] = 0;
+        }
+        return;
+    }
+    // ---- radix select: find the k-th largest key
+    if (tid == 0) {
+        s_prefix = 0;
+        s_k = k;
+    }
+    __syncthreads();
+    for (int byte = 7; byte >= 0; --byte) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long himask = (byte == 7) ? 0ull : (~0ull << (8 * (byte + 1)));
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned long long key = c[i];
+            if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> (8 * byte)) & 0xFF)], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int kk = s_k, d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= kk) break;
+                kk -= hist[d];
+            }
+            s_prefix = prefix | ((unsigned long long)d << (8 * byte));
+            s_k = kk;
+        }
+        __syncthreads();
+    }
+    const unsigned long long kth = s_prefix;  // exactly k keys are >= kth
+    if (tid == 0) s_nsel = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long key = c[i];
+        if (key >= kth) {
+            const int pos = atomicAdd(&s_nsel, 1);
+            if (pos < TOPK_MAX) sel[pos] = key;
+        }
+    }
+    __syncthreads();
+    int np2 = 1;
+    while (np2 < k) np2 <<= 1;
+    for (int i = k + tid; i < np2; i += 1024) sel[i] = 0ull;
+    __syncthreads();
+    // ---- bitonic sort, descending
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < np2 / 2; i += 1024) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi2 = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = sel[lo], bb = sel[hi2];
+                if ((a < bb) == desc) {
+                    sel[lo] = bb;
+                    sel[hi2] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 1024) {
+        const unsigned long long key = sel[i];
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        kp[2 * i + 0] = (float)(idx % W);
+        kp[2 * i + 1] = (float)(idx / W);
+        sc[i] = __uint_as_float((unsigned)(key >> 32));
+    }
+}
+
+// ------------------------------------------------------------------ descriptor sampling
+// One wave per key-point: bilinear interpolation (grid_sample, align_corners=True, or the
+// reference's "fix_sampling" variant) of the L2-normalised dense descriptors, then L2 norm.
+// Lane l handles channels 4l..4l+3.  The dense normalisation is applied on the fly to the four
+// neighbour rows.
+__device__ __forceinline__ float4 sp_norm_row(const float* base, long row, int lane, bool valid) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(base + row * 256 + lane * 4);
+    const float nrm = sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w));
+    const float d = fmaxf(nrm, 1e-12f);
+    v.x /= d;
+    v.y /= d;
+    v.z /= d;
+    v.w /= d;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void sp_sample_kernel(const float* __restrict__ ddesc, const float* __restrict__ kpts,
+                                                        const int* __restrict__ nkpts, int kcap, int Hc, int Wc,
+                                                        int fix_sampling, float* __restrict__ desc) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nkpts[b]) return;
+    const float kx = kpts[((size_t)b * kcap + i) * 2 + 0];
+    const float ky = kpts[((size_t)b * kcap + i) * 2 + 1];
+    float ix, iy;
+    const float s = 8.0f;
+    if (!fix_sampling) {
+        // upstream: k = k - s/2 + 0.5 ; k /= [w*s - s/2 - 0.5, h*s - s/2 - 0.5] ; k = k*2 - 1
+        float gx = ((kx - s / 2) + 0.5f) / ((float)Wc * s - s / 2 - 0.5f);
+        float gy = ((ky - s / 2) + 0.5f) / ((float)Hc * s - s / 2 - 0.5f);
+        gx = gx * 2.0f - 1.0f;
+        gy = gy * 2.0f - 1.0f;
+        // grid_sample unnormalise, align_corners=True: (g + 1) * (size - 1) / 2
+        ix = (gx + 1.0f) * ((float)(Wc - 1) * 0.5f);
+        iy = (gy + 1.0f) * ((float)(Hc - 1) * 0.5f);
+    } else {
+        // imcui/hloc/extractors/superpoint.py:16-30: (k + 0.5) / (w*s), align_corners=False
+        float gx = (kx + 0.5f) / ((float)Wc * s);
+        float gy = (ky + 0.5f) / ((float)Hc * s);
+        gx = gx * 2.0f - 1.0f;
+        gy = gy * 2.0f - 1.0f;
+        ix = ((gx + 1.0f) * (float)Wc - 1.0f) * 0.5f;
+        iy = ((gy + 1.0f) * (float)Hc - 1.0f) * 0.5f;
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wnw = ((float)x1 - ix) * ((float)y1 - iy);
+    const float wne = (ix - (float)x0) * ((float)y1 - iy);
+    const float wsw = ((float)x1 - ix) * (iy - (float)y0);
+    const float wse = (ix - (float)x0) * (iy - (float)y0);
+    const float* base = ddesc + (size_t)b * Hc * Wc * 256;
+    const bool vx0 = x0 >= 0 && x0 < Wc, vx1 = x1 >= 0 && x1 < Wc;
+    const bool vy0 = y0 >= 0 && y0 < Hc, vy1 = y1 >= 0 && y1 < Hc;
+    const float4 nw = sp_norm_row(base, (long)y0 * Wc + x0, lane, vx0 && vy0);
+    const float4 ne = sp_norm_row(base, (long)y0 * Wc + x1, lane, vx1 && vy0);
+    const float4 sw = sp_norm_row(base, (long)y1 * Wc + x0, lane, vx0 && vy1);
+    const float4 se = sp_norm_row(base, (long)y1 * Wc + x1, lane, vx1 && vy1);
+    float4 o;
+    o.x = nw.x * wnw + ne.x * wne + sw.x * wsw + se.x * wse;
+    o.y = nw.y * wnw + ne.y * wne + sw.y * wsw + se.y * wse;
+    o.z = nw.z * wnw + ne.z * wne + sw.z * wsw + se.z * wse;
+    o.w = nw.w * wnw + ne.w * wne + sw.w * wsw + se.w * wse;
+    const float nrm = sqrtf(wave_sum(o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w));
+    const float d = fmaxf(nrm, 1e-12f);
+    o.x /= d;
+    o.y /= d;
+    o.z /= d;
+    o.w /= d;
+    *reinterpret_cast<float4*>(desc + ((size_t)b * kcap + i) * 256 + lane * 4) = o;
+}
+
+// ------------------------------------------------------------------ forward
+struct SpWs {
+    float *a1a, *p1, *a2a, *p2, *a3a, *p3, *a4a, *feat, *head, *logits, *dense, *nms, *ddesc;
+    int *blkcnt, *blkoff, *ncand, *status;
+    unsigned long long* cand;
+    size_t total;
+    bool ok;
+};
+
+static SpWs sp_carve(void* ws, size_t ws_bytes, int B, int H, int W, int cand_cap) {
+    WsAlloc a(ws, ws_bytes);
+    SpWs s;
+    const size_t hw = (size_t)B * H * W;
+    const size_t c = hw / 64;  // coarse cells
+    s.a1a = a.get<float>(hw * 64);
+    s.p1 = a.get<float>(hw / 4 * 64);
+    s.a2a = a.get<float>(hw / 4 * 64);
+    s.p2 = a.get<float>(hw / 16 * 64);
+    s.a3a = a.get<float>(hw / 16 * 128);
+    s.p3 = a.get<float>(c * 128);
+    s.a4a = a.get<float>(c * 128);
+    s.feat = a.get<float>(c * 128);
+    s.head = a.get<float>(c * 256);
+    s.logits = a.get<float>(c * 65 + 64);
+    s.dense = a.get<float>(hw);
+    s.nms = a.get<float>(hw);
+    s.ddesc = a.get<float>(c * 256);
+    const int nchunk = cdiv(H * W, SEL_CHUNK);
+    s.blkcnt = a.get<int>((size_t)B * nchunk);
+    s.blkoff = a.get<int>((size_t)B * nchunk);
+    s.ncand = a.get<int>(B);
+    s.status = a.get<int>(1);
+    s.cand = a.get<unsigned long long>((size_t)B * cand_cap);
+    s.total = a.off;
+    s.ok = a.ok;
+    return s;
+}
+
+// Every pixel can be a candidate when scores tie exactly (flat images), so the candidate list
+// is sized for the whole image (8 B per pixel).
+static int sp_cand_cap(int H, int W, int r) {
+    (void)r;
+    return H * W;
+}
+
+extern "C" size_t imcui_hip_superpoint_workspace_bytes(int B, int H, int W, int nms_radius) {
+    return sp_carve(nullptr, 0, B, H, W, sp_cand_cap(H, W, nms_radius)).total;
+}
+
+// Number of key-points a non-degenerate image can yield: NMS leaves at most one maximum per
+// (r+1)x(r+1) cell unless scores tie exactly.  Callers size `kcap` with it and retry with H*W
+// when imcui_hip_superpoint_status reports bit 1.
+extern "C" int imcui_hip_superpoint_max_keypoints_bound(int H, int W, int nms_radius) {
+    const int r = nms_radius < 0 ? 0 : nms_radius;
+    return cdiv(H, r + 1) * cdiv(W, r + 1);
+}
+
+extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed, const float* image, int B, int H, int W,
+                                            int nms_radius, float keypoint_threshold, int remove_borders,
+                                            int max_keypoints, int fix_sampling, int kcap, float* keypoints,
+                                            float* scores, float* descriptors, int* num_keypoints, float* score_map,
+                                            void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (B <= 0) return IMCUI_OK;
+    if (H % 8 || W % 8 || H < 8 || W < 8)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "superpoint: H=%d W=%d must be positive multiples of 8", H, W);
+    if (kcap <= 0 || !packed || !image || !keypoints || !scores || !descriptors || !num_keypoints)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "superpoint: null argument or kcap<=0");
+    const int cand_cap = sp_cand_cap(H, W, nms_radius);
+    SpWs s = sp_carve(ws, ws_bytes, B, H, W, cand_cap);
+    if (!ws || !s.ok) return imcui_set_err(h, IMCUI_ERR_WS, "superpoint: workspace too small (%zu < %zu)", ws_bytes, s.total);
+    const SpLayout l = sp_layout();
+    const float* P = packed;
+    int rc;
+#define SPRUN(x)              \
+    do {                      \
+        rc = (x);             \
+        if (rc != IMCUI_OK) return rc; \
+    } while (0)
+    const int Hc = H / 8, Wc = W / 8;
+    // a2: encoder
+    SPRUN(conv1a_launch(h, image, P + l.w[L1A], P + l.b[L1A], s.a1a, B, H, W, stream));
+    SPRUN(conv3x3_launch(h, s.a1a, P + l.w[L1B], P + l.b[L1B], s.p1, B, H, W, 64, 64, 1, 1, stream));
+    SPRUN(conv3x3_launch(h, s.p1, P + l.w[L2A], P + l.b[L2A], s.a2a, B, H / 2, W / 2, 64, 64, 1, 0, stream));
+    SPRUN(conv3x3_launch(h, s.a2a, P + l.w[L2B], P + l.b[L2B], s.p2, B, H / 2, W / 2, 64, 64, 1, 1, stream));
+    SPRUN(conv3x3_launch(h, s.p2, P + l.w[L3A], P + l.b[L3A], s.a3a, B, H / 4, W / 4, 64, 128, 1, 0, stream));
+    SPRUN(conv3x3_launch(h, s.a3a, P + l.w[L3B], P + l.b[L3B], s.p3, B, H / 4, W / 4, 128, 128, 1, 1, stream));
+    SPRUN(conv3x3_launch(h, s.p3, P + l.w[L4A], P + l.b[L4A], s.a4a, B, Hc, Wc, 128, 128, 1, 0, stream));
+    SPRUN(conv3x3_launch(h, s.a4a, P + l.w[L4B], P + l.b[L4B], s.feat, B, Hc, Wc, 128, 128, 1, 0, stream));
+    // a3: detector head -> dense score map
+    SPRUN(conv3x3_launch(h, s.feat, P + l.w[LPA], P + l.b[LPA], s.head, B, Hc, Wc, 128, 256, 1, 0, stream));
+    const long ncell = (long)B * Hc * Wc;
+    {
+        GemmP g;
+        g.epi = EPI_BIAS;
+        g.A = s.head;
+        g.lda = 256;
+        g.W = P + l.w[LPB];
+        g.ldw = 256;
+        g.bias = P + l.b[LPB];
+        g.C = s.logits;
+        g.ldc = 65;
+        g.M = (int)ncell;
+        g.N = 65;
+        g.K = 256;
+        SPRUN(gemm_launch(h, g, stream));
+    }
+    float* dense = score_map ? score_map : s.dense;
+    hipLaunchKernelGGL(sp_softmax_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, s.logits, 65, dense, Hc,
+                       Wc, ncell);
+    IMCUI_CHECK_LAUNCH(h);
+    // a4: NMS ; a5: select
+    SPRUN(nms_launch(h, dense, s.nms, B, H, W, nms_radius, stream));
+    const int nchunk = cdiv(H * W, SEL_CHUNK);
+    hipMemsetAsync(s.status, 0, sizeof(int), stream);
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nchunk, B), dim3(256), 0, stream, s.nms, H, W, keypoint_threshold,
+                       remove_borders, s.blkcnt, nchunk);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(64), 0, stream, s.blkcnt, s.blkoff, s.ncand, nchunk);
+    hipLaunchKernelGGL(sp_compact_kernel, dim3(nchunk, B), dim3(256), 0, stream, s.nms, H, W, keypoint_threshold,
+                       remove_borders, s.blkoff, nchunk, s.cand, cand_cap);
+    hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), 0, stream, s.cand, cand_cap, s.ncand, max_keypoints, kcap, W,
+                       keypoints, scores, num_keypoints, s.status);
+    IMCUI_CHECK_LAUNCH(h);
+    // a6: descriptor head + sampling
+    SPRUN(conv3x3_launch(h, s.feat, P + l.w[LDA], P + l.b[LDA], s.head, B, Hc, Wc, 128, 256, 1, 0, stream));
+    {
+        GemmP g;
+        g.epi = EPI_BIAS;
+        g.A = s.head;
+        g.lda = 256;
+        g.W = P + l.w[LDB];
+        g.ldw = 256;
+        g.bias = P + l.b[LDB];
+        g.C = s.ddesc;
+        g.ldc = 256;
+        g.M = (int)ncell;
+        g.N = 256;
+        g.K = 256;
+        SPRUN(gemm_launch(h, g, stream));
+    }
+    hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(kcap, 4), B), dim3(256), 0, stream, s.ddesc, keypoints, num_keypoints,
+                       kcap, Hc, Wc, fix_sampling, descriptors);
+    IMCUI_CHECK_LAUNCH(h);
+#undef SPRUN
+    return IMCUI_OK;
+}
+
+// status word of the last forward on this workspace (0 = fine; bit0 candidate overflow,
+// bit1 output capacity too small, bit2 top-k larger than the sorter supports). Synchronises.
+extern "C" int imcui_hip_superpoint_status(imcui_hip_t* h, int B, int H, int W, int nms_radius, void* ws, size_t ws_bytes,
+                                           void* stream_) {
+    SpWs s = sp_carve(ws, ws_bytes, B, H, W, sp_cand_cap(H, W, nms_radius));
+    if (!ws || !s.ok) return imcui_set_err(h, IMCUI_ERR_WS, "superpoint: workspace too small");
+    int st = 0;
+    if (hipMemcpyAsync(&st, s.status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_) != hipSuccess)
+        return imcui_set_err(h, IMCUI_ERR_HIP, "status copy failed");
+    hipStreamSynchronize((hipStream_t)stream_);
+    if (st) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "superpoint: selection status=%d (1 cand overflow, 2 kcap too small, 4 topk>%d)", st, TOPK_MAX);
+    return IMCUI_OK;
+}
+
+// stand-alone NMS entry (tests / reuse)
+extern "C" int imcui_hip_simple_nms(imcui_hip_t* h, const float* scores, float* out, int B, int H, int W, int nms_radius,
+                                    void* stream_) {
+    return nms_launch(h, scores, out, B, H, W, nms_radius, (hipStream_t)stream_);
+}

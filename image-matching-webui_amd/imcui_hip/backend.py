@@ -1,0 +1,316 @@
+"""Thin Python host layer over the C ABI: handles, weight packing, workspaces, launches.
+
+PyTorch-ROCm tensors in, tensors out.  Everything is enqueued on
+``torch.cuda.current_stream()``; nothing here synchronises except where the reference's
+ragged list outputs force a device->host read of the key-point counts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from .lib_loader import ImcuiHipError, load_library
+
+SP_ORDER = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convPb", "convDa", "convDb"]
+
+_handles: dict[int, "Handle"] = {}
+_hlock = threading.Lock()
+
+
+class Handle:
+    def __init__(self, device_index: int):
+        self.lib = load_library()
+        self.device_index = device_index
+        h = C.c_void_p()
+        rc = self.lib.imcui_hip_create(device_index, C.byref(h))
+        if rc != 0 or not h:
+            raise ImcuiHipError(f"imcui_hip_create(device={device_index}) failed with {rc} (no usable HIP device?)")
+        self.h = h
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            msg = self.lib.imcui_hip_last_error(self.h)
+            raise ImcuiHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def get_handle(device: torch.device) -> Handle:
+    if device.type != "cuda":
+        raise ImcuiHipError(f"the HIP backend needs a ROCm device tensor, got device '{device}' (no CPU fallback)")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _hlock:
+        if idx not in _handles:
+            _handles[idx] = Handle(idx)
+        return _handles[idx]
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _as_f32_host(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        t = t.detach().to("cpu", torch.float32).contiguous().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+class _Workspace:
+    """Grow-only byte buffer on one device (caller-provided scratch of the C ABI)."""
+
+    def __init__(self):
+        self.buf: torch.Tensor | None = None
+
+    def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+# ------------------------------------------------------------------ SuperPoint
+def pack_superpoint(state_dict: dict) -> torch.Tensor:
+    """Upstream SuperPoint state dict -> packed float32 buffer (host)."""
+    lib = load_library()
+    ws = [_as_f32_host(state_dict[f"{n}.weight"]) for n in SP_ORDER]
+    bs = [_as_f32_host(state_dict[f"{n}.bias"]) for n in SP_ORDER]
+    expect = {"conv1a": (64, 1, 3, 3), "convPb": (65, 256, 1, 1), "convDb": (256, 256, 1, 1)}
+    for n, shp in expect.items():
+        if tuple(state_dict[f"{n}.weight"].shape) != shp:
+            raise ImcuiHipError(f"unexpected shape for {n}.weight: {tuple(state_dict[f'{n}.weight'].shape)}")
+    packed = np.zeros(lib.imcui_hip_superpoint_packed_floats(), dtype=np.float32)
+    wp = (C.c_void_p * 12)(*[w.ctypes.data for w in ws])
+    bp = (C.c_void_p * 12)(*[b.ctypes.data for b in bs])
+    rc = lib.imcui_hip_superpoint_pack_weights(wp, bp, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_superpoint_pack_weights failed ({rc})")
+    return torch.from_numpy(packed)
+
+
+class SuperPointHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+
+    def forward(self, packed: torch.Tensor, image: torch.Tensor, conf: dict, want_score_map: bool = False):
+        """image [B,1,H,W] float32 on the GPU.  Returns dict of fixed-stride tensors + counts."""
+        hd = get_handle(image.device)
+        if packed.device != image.device:
+            raise ImcuiHipError("packed weights and image live on different devices")
+        lib = hd.lib
+        image = image.contiguous().float()
+        B, Cc, H, W = image.shape
+        if Cc != 1:
+            raise ImcuiHipError(f"SuperPoint expects a 1-channel image, got {Cc}")
+        nms = int(conf["nms_radius"])
+        maxk = int(conf["max_keypoints"])
+        bound = lib.imcui_hip_superpoint_max_keypoints_bound(H, W, nms)
+        kcap = bound if maxk < 0 else max(1, min(maxk, H * W))
+        dev = image.device
+        with self._lock:
+            for attempt in range(2):
+                kpts = torch.empty((B, kcap, 2), dtype=torch.float32, device=dev)
+                scores = torch.empty((B, kcap), dtype=torch.float32, device=dev)
+                desc = torch.empty((B, kcap, 256), dtype=torch.float32, device=dev)
+                nk = torch.empty((B,), dtype=torch.int32, device=dev)
+                smap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score_map else None
+                nbytes = lib.imcui_hip_superpoint_workspace_bytes(B, H, W, nms)
+                ws = self._ws.get(nbytes, dev)
+                with torch.cuda.device(dev):
+                    rc = lib.imcui_hip_superpoint_forward(
+                        hd.h, _ptr(packed), _ptr(image), B, H, W, nms, float(conf["keypoint_threshold"]),
+                        int(conf["remove_borders"]), maxk, int(bool(conf.get("fix_sampling", False))), kcap,
+                        _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(nk), _ptr(smap), _ptr(ws), ws.numel(), _stream_ptr(),
+                    )  # fmt: skip
+                    hd.check(rc, "imcui_hip_superpoint_forward")
+                    if maxk >= 0 or attempt == 1:
+                        break
+                    # max_keypoints = -1: the NMS bound can be exceeded only by exactly tied scores
+                    rc = lib.imcui_hip_superpoint_status(hd.h, B, H, W, nms, _ptr(ws), ws.numel(), _stream_ptr())
+                    if rc == 0:
+                        break
+                    kcap = H * W
+        out = {"keypoints": kpts, "scores": scores, "descriptors": desc, "num_keypoints": nk}
+        if want_score_map:
+            out["score_map"] = smap
+        return out
+
+
+# ------------------------------------------------------------------ LightGlue
+def lightglue_tensor_names() -> list[str]:
+    lib = load_library()
+    return [lib.imcui_hip_lightglue_tensor_name(i).decode() for i in range(lib.imcui_hip_lightglue_num_tensors())]
+
+
+def _rename_old_lightglue_keys(sd: dict) -> dict:
+    """Old checkpoints name blocks `self_attn.{i}...` / `cross_attn.{i}...` (renamed on load upstream)."""
+    out = {}
+    for k, v in sd.items():
+        for i in range(9):
+            for blk in ("self_attn", "cross_attn"):
+                old = f"{blk}.{i}"
+                if k.startswith(old + "."):
+                    k = f"transformers.{i}.{blk}" + k[len(old):]
+        out[k] = v
+    return out
+
+
+def pack_lightglue(state_dict: dict) -> torch.Tensor:
+    lib = load_library()
+    sd = _rename_old_lightglue_keys(state_dict)
+    names = lightglue_tensor_names()
+    arrs = []
+    for n in names:
+        if n not in sd:
+            raise ImcuiHipError(f"LightGlue state dict lacks '{n}'")
+        arrs.append(_as_f32_host(sd[n]))
+    if arrs[0].shape != (32, 2) or arrs[1].shape != (768, 256):
+        raise ImcuiHipError("only the 256-d / 4-head / 9-layer LightGlue (superpoint) is supported")
+    packed = np.zeros(lib.imcui_hip_lightglue_packed_floats(), dtype=np.float32)
+    tp = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    rc = lib.imcui_hip_lightglue_pack_weights(tp, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_lightglue_pack_weights failed ({rc})")
+    return torch.from_numpy(packed)
+
+
+class LightGlueHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+
+    def forward(self, packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, depth_confidence, width_confidence,
+                filter_threshold):  # fmt: skip
+        """kptsX [B,ncap,2], descX [B,ncap,256] (row per point), nX [B] int32 on the GPU; sizeX = (W, H)."""
+        dev = kpts0.device
+        hd = get_handle(dev)
+        lib = hd.lib
+        B, ncap0 = kpts0.shape[0], kpts0.shape[1]
+        ncap1 = kpts1.shape[1]
+        ncap = max(ncap0, ncap1, 1)
+
+        def pad(t, n):
+            if t.shape[1] == n:
+                return t.contiguous().float()
+            shape = list(t.shape)
+            shape[1] = n
+            o = torch.zeros(shape, dtype=torch.float32, device=dev)
+            o[:, : t.shape[1]] = t
+            return o
+
+        kpts0, kpts1, desc0, desc1 = pad(kpts0, ncap), pad(kpts1, ncap), pad(desc0, ncap), pad(desc1, ncap)
+        n0 = n0.to(device=dev, dtype=torch.int32).contiguous()
+        n1 = n1.to(device=dev, dtype=torch.int32).contiguous()
+        m0 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        m1 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        s0 = torch.empty((B, ncap), dtype=torch.float32, device=dev)
+        s1 = torch.empty((B, ncap), dtype=torch.float32, device=dev)
+        stop = torch.empty((B,), dtype=torch.int32, device=dev)
+        p0 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        p1 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        with self._lock:
+            ws = self._ws.get(lib.imcui_hip_lightglue_workspace_bytes(B, ncap), dev)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_lightglue_forward(
+                    hd.h, _ptr(packed), B, ncap, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(n0), _ptr(n1),
+                    float(size0[0]), float(size0[1]), float(size1[0]), float(size1[1]),
+                    float(depth_confidence), float(width_confidence), float(filter_threshold),
+                    _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(stop), _ptr(p0), _ptr(p1), _ptr(ws), ws.numel(), _stream_ptr(),
+                )  # fmt: skip
+                hd.check(rc, "imcui_hip_lightglue_forward")
+        return {
+            "matches0": m0[:, :ncap0], "matches1": m1[:, :ncap1], "matching_scores0": s0[:, :ncap0],
+            "matching_scores1": s1[:, :ncap1], "stop": stop, "prune0": p0[:, :ncap0], "prune1": p1[:, :ncap1],
+        }  # fmt: skip
+
+
+# ------------------------------------------------------------------ mutual NN
+_nn_ws = _Workspace()
+_nn_lock = threading.Lock()
+
+
+def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=None, distance_threshold=None,
+              do_mutual_check=True):  # fmt: skip
+    """desc0 [B,N,D], desc1 [B,M,D] (row per descriptor) -> matches0 [B,N] int32, scores0 [B,N]."""
+    dev = desc0_nd.device
+    hd = get_handle(dev)
+    lib = hd.lib
+    desc0_nd, desc1_md = desc0_nd.contiguous().float(), desc1_md.contiguous().float()
+    B, N, D = desc0_nd.shape
+    M = desc1_md.shape[1]
+    m0 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if D % 32:
+        raise ImcuiHipError(f"descriptor dim {D} must be a multiple of 32")
+    with _nn_lock:
+        ws = _nn_ws.get(lib.imcui_hip_mutual_nn_workspace_bytes(B, N, M), dev)
+        with torch.cuda.device(dev):
+            rc = lib.imcui_hip_mutual_nn(
+                hd.h, _ptr(desc0_nd), _ptr(desc1_md), B, N, M, D, float(ratio_threshold or 0.0),
+                float(distance_threshold or 0.0), int(bool(do_mutual_check)), _ptr(m0), _ptr(s0), _ptr(ws), ws.numel(),
+                _stream_ptr(),
+            )  # fmt: skip
+            hd.check(rc, "imcui_hip_mutual_nn")
+    return m0, s0
+
+
+# ------------------------------------------------------------------ building blocks (tests)
+def linear_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
+    hd = get_handle(a.device)
+    a, w = a.contiguous().float(), w.contiguous().float()
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        hd.check(hd.lib.imcui_hip_linear_f32(hd.h, _ptr(a), _ptr(w), _ptr(bias), _ptr(c), M, N, K, int(relu), _stream_ptr()), "linear")
+    return c
+
+
+def conv3x3_f32(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, relu=True, pool=False) -> torch.Tensor:
+    hd = get_handle(x_nhwc.device)
+    lib = hd.lib
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_oihw.shape[0]
+    wh = _as_f32_host(w_oihw)
+    packed = np.zeros(Cout * Cin * 9, dtype=np.float32)
+    if lib.imcui_hip_conv3x3_pack(wh.ctypes.data, Cout, Cin, packed.ctypes.data) != 0:
+        raise ImcuiHipError("conv3x3_pack failed")
+    wp = torch.from_numpy(packed).to(x_nhwc.device)
+    x_nhwc = x_nhwc.contiguous().float()
+    bias = bias.contiguous().float().to(x_nhwc.device)
+    out = torch.empty((B, H // 2, W // 2, Cout) if pool else (B, H, W, Cout), dtype=torch.float32, device=x_nhwc.device)
+    with torch.cuda.device(x_nhwc.device):
+        hd.check(
+            lib.imcui_hip_conv3x3_f32(hd.h, _ptr(x_nhwc), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, int(relu), int(pool), _stream_ptr()),
+            "conv3x3",
+        )
+    return out
+
+
+def attention_f32(q, k, v, cnt, cross=False):
+    """q,k,v [S,heads,rows,64] head-major (q pre-scaled); cnt [S] int32 -> [S*rows, heads*64]."""
+    hd = get_handle(q.device)
+    S, Hh, R, d = q.shape
+    assert d == 64
+    o = torch.zeros((S * R, Hh * 64), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        hd.check(
+            hd.lib.imcui_hip_attention_f32(hd.h, _ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), _ptr(cnt.to(torch.int32).contiguous()), S, Hh, R, int(cross), _stream_ptr()),
+            "attention",
+        )
+    return o
+
+
+def simple_nms(scores: torch.Tensor, radius: int) -> torch.Tensor:
+    hd = get_handle(scores.device)
+    scores = scores.contiguous().float()
+    B, H, W = scores.shape
+    out = torch.empty_like(scores)
+    with torch.cuda.device(scores.device):
+        hd.check(hd.lib.imcui_hip_simple_nms(hd.h, _ptr(scores), _ptr(out), B, H, W, int(radius), _stream_ptr()), "simple_nms")
+    return out

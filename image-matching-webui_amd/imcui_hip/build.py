@@ -1,0 +1,56 @@
+"""Build libimcui_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
+INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "..", "include"))
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
+SOURCES = ["api.hip", "gemm.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "nn.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def _newest_source_mtime() -> float:
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "imcui_hip.h")]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def needs_build() -> bool:
+    return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest_source_mtime()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source and link the shared library. Returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    if verbose:
+        print(f"[imcui_hip] built {LIB_PATH}", file=sys.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

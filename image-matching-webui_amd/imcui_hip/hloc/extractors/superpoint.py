@@ -1,0 +1,52 @@
+"""SuperPoint extractor plugin on the MI355X HIP backend.
+
+Drop-in for imcui/hloc/extractors/superpoint.py: same module name (`superpoint`), one BaseModel
+subclass, same `default_conf` (:34-41), `required_inputs` (:42), `detection_noise` (:43), and the
+runtime conf is re-read on every call like `self.net(data, self.conf)` (:57).  The arithmetic
+(:56-57 -> upstream SuperPoint.forward) runs in libimcui_hip (imcui_hip_superpoint_forward).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import backend
+from ..utils.base_model import BaseModel
+from ..utils.weights import resolve_state_dict
+
+
+class SuperPoint(BaseModel):
+    default_conf = {
+        "nms_radius": 4,
+        "model_name": "superpoint_v1.pth",
+        "keypoint_threshold": 0.005,
+        "max_keypoints": -1,
+        "remove_borders": 4,
+        "fix_sampling": False,
+    }
+    required_inputs = ["image"]
+    detection_noise = 2.0
+
+    def _init(self, conf):
+        sd = resolve_state_dict(conf, "superglue")
+        conf.pop("state_dict", None)  # keep self.conf small / printable
+        self.conf.pop("state_dict", None)
+        # registered buffer: counted by the UI model cache and moved by `.to(device)`
+        self.register_buffer("packed", backend.pack_superpoint(sd), persistent=False)
+        self._impl = backend.SuperPointHIP()
+
+    def forward_batched(self, image: torch.Tensor, want_score_map: bool = False) -> dict:
+        """Fixed-stride outputs, no host synchronisation: keypoints [B,K,2], scores [B,K],
+        descriptors [B,K,256] (row per key-point), num_keypoints [B] int32."""
+        if image.shape[1] == 3:  # RGB -> gray (upstream weights), the hloc path always feeds gray
+            scale = image.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)
+            image = (image * scale).sum(1, keepdim=True)
+        return self._impl.forward(self.packed, image, self.conf, want_score_map)
+
+    def _forward(self, data):
+        out = self.forward_batched(data["image"])
+        counts = out["num_keypoints"].tolist()  # ragged lists are the reference contract (one D2H)
+        kpts = [out["keypoints"][b, :n] for b, n in enumerate(counts)]
+        scores = [out["scores"][b, :n] for b, n in enumerate(counts)]
+        # reference layout is [256, N]: a transposed view of the row-per-keypoint buffer
+        desc = [out["descriptors"][b, :n].t() for b, n in enumerate(counts)]
+        return {"keypoints": kpts, "scores": scores, "descriptors": desc}

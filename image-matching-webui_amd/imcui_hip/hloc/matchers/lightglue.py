@@ -1,0 +1,91 @@
+"""LightGlue matcher plugin on the MI355X HIP backend.
+
+Drop-in for imcui/hloc/matchers/lightglue.py: module name `lightglue`, same `default_conf`
+(:15-25), `required_inputs` (:26-35), `filter_threshold = match_threshold` (:50) and flat input
+keys (:54-70: descriptors arrive [B,D,N] and are permuted to [B,N,D]).  The arithmetic (:75 ->
+upstream LightGlue.forward, CPU-path semantics) runs in libimcui_hip (imcui_hip_lightglue_forward).
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import backend
+from ..utils.base_model import BaseModel
+from ..utils.weights import resolve_state_dict
+
+
+class LightGlue(BaseModel):
+    default_conf = {
+        "match_threshold": 0.2,
+        "filter_threshold": 0.2,
+        "width_confidence": 0.99,  # for point pruning
+        "depth_confidence": 0.95,  # for early stopping
+        "features": "superpoint",
+        "model_name": "superpoint_lightglue.pth",
+        "flash": True,  # accepted for compatibility; the HIP kernels are always the fused path
+        "mp": False,
+        "add_scale_ori": False,
+    }
+    required_inputs = [
+        "image0",
+        "keypoints0",
+        "scores0",
+        "descriptors0",
+        "image1",
+        "keypoints1",
+        "scores1",
+        "descriptors1",
+    ]
+
+    def _init(self, conf):
+        if conf["features"] != "superpoint" or conf["add_scale_ori"]:
+            raise NotImplementedError("the HIP LightGlue backend covers the 256-d superpoint variant")
+        sd = resolve_state_dict(conf, "lightglue")
+        conf.pop("state_dict", None)
+        self.conf.pop("state_dict", None)
+        self.conf["filter_threshold"] = conf["match_threshold"]
+        self.register_buffer("packed", backend.pack_lightglue(sd), persistent=False)
+        self._impl = backend.LightGlueHIP()
+
+    def forward_batched(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1) -> dict:
+        """Row-per-point descriptors [B,N,256]; n0/n1 [B] int32 valid counts; sizes (W, H).
+        Fixed-stride int32 outputs, no host synchronisation."""
+        c = self.conf
+        # the UI mutates match_threshold at run time (imcui/ui/utils.py:921-922)
+        return self._impl.forward(
+            self.packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1,
+            c["depth_confidence"], c["width_confidence"], c["match_threshold"],
+        )  # fmt: skip
+
+    def _forward(self, data):
+        kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
+        desc0 = data["descriptors0"].permute(0, 2, 1)
+        desc1 = data["descriptors1"].permute(0, 2, 1)
+        B, m = kpts0.shape[0], kpts0.shape[1]
+        n = kpts1.shape[1]
+        dev = kpts0.device
+        size0 = tuple(data["image0"].shape[-2:][::-1])
+        size1 = tuple(data["image1"].shape[-2:][::-1])
+        n0 = torch.full((B,), m, dtype=torch.int32, device=dev)
+        n1 = torch.full((B,), n, dtype=torch.int32, device=dev)
+        out = self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1)
+        m0, m1 = out["matches0"].long(), out["matches1"].long()
+        ms0, ms1 = out["matching_scores0"], out["matching_scores1"]
+        matches, mscores = [], []
+        for k in range(B):
+            valid = m0[k] > -1
+            idx0 = torch.where(valid)[0]
+            matches.append(torch.stack([idx0, m0[k][valid]], -1))
+            mscores.append(ms0[k][valid])
+        stop = out["stop"]
+        return {
+            "matches0": m0,
+            "matches1": m1,
+            "matching_scores0": ms0,
+            "matching_scores1": ms1,
+            "stop": int(stop[0]) if B == 1 else stop,
+            "matches": matches,
+            "scores": mscores,
+            "prune0": out["prune0"].long(),
+            "prune1": out["prune1"].long(),
+        }

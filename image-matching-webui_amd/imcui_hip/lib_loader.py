@@ -1,0 +1,92 @@
+"""ctypes binding of libimcui_hip.so (the C ABI declared in include/imcui_hip.h).
+
+The product path fails loudly when the library is missing: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from .build import LIB_PATH
+
+_lock = threading.Lock()
+_lib = None
+
+
+class ImcuiHipError(RuntimeError):
+    pass
+
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol include/imcui_hip.h declares
+SIGNATURES = {
+    "imcui_hip_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "imcui_hip_destroy": (None, [C.c_void_p]),
+    "imcui_hip_last_error": (C.c_char_p, [C.c_void_p]),
+    "imcui_hip_version": (C.c_int, []),
+    "imcui_hip_superpoint_packed_floats": (C.c_size_t, []),
+    "imcui_hip_superpoint_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "imcui_hip_superpoint_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "imcui_hip_superpoint_max_keypoints_bound": (C.c_int, [C.c_int] * 3),
+    "imcui_hip_superpoint_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        + [C.c_void_p] * 5
+        + [C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "imcui_hip_superpoint_status": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "imcui_hip_simple_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "imcui_hip_lightglue_packed_floats": (C.c_size_t, []),
+    "imcui_hip_lightglue_num_tensors": (C.c_int, []),
+    "imcui_hip_lightglue_tensor_name": (C.c_char_p, [C.c_int]),
+    "imcui_hip_lightglue_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "imcui_hip_lightglue_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "imcui_hip_lightglue_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        + [C.c_void_p] * 6
+        + [C.c_float] * 4
+        + [C.c_double] * 3
+        + [C.c_void_p] * 7
+        + [C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "imcui_hip_mutual_nn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "imcui_hip_mutual_nn": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "imcui_hip_linear_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "imcui_hip_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "imcui_hip_conv3x3_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
+    "imcui_hip_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+}
+
+
+def load_library(path: str | None = None):
+    """dlopen the HIP backend; raises ImcuiHipError when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = path or os.environ.get("IMCUI_HIP_LIB", LIB_PATH)
+        if not os.path.exists(path):
+            raise ImcuiHipError(
+                f"{path} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        try:
+            lib = C.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise ImcuiHipError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise ImcuiHipError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib

@@ -1,0 +1,52 @@
+"""Batched SuperPoint + LightGlue pair pipeline (the unit of the throughput metric).
+
+One call = B image pairs: SuperPoint on the 2B images, LightGlue on the B pairs, all on the
+current stream with fixed-stride device tensors in between (no host synchronisation).  This is
+what `bench.py` times and what a batched hloc driver would call; the reference itself only ever
+runs batch 1 (imcui/hloc/match_features.py:172-174).
+"""
+from __future__ import annotations
+
+import torch
+
+from .hloc.extractors.superpoint import SuperPoint
+from .hloc.matchers.lightglue import LightGlue
+
+
+class SuperPointLightGluePipeline(torch.nn.Module):
+    def __init__(self, sp_conf: dict, lg_conf: dict):
+        super().__init__()
+        self.extractor = SuperPoint(sp_conf)
+        self.matcher = LightGlue(lg_conf)
+
+    @torch.no_grad()
+    def forward(self, image0: torch.Tensor, image1: torch.Tensor) -> dict:
+        """image0/image1 [B,1,H,W] in [0,1] -> fixed-stride match table (device tensors)."""
+        B = image0.shape[0]
+        same = image0.shape == image1.shape
+        if same:
+            f = self.extractor.forward_batched(torch.cat([image0, image1], 0))
+            k0, k1 = f["keypoints"][:B], f["keypoints"][B:]
+            d0, d1 = f["descriptors"][:B], f["descriptors"][B:]
+            n0, n1 = f["num_keypoints"][:B], f["num_keypoints"][B:]
+            s0, s1 = f["scores"][:B], f["scores"][B:]
+        else:
+            f0 = self.extractor.forward_batched(image0)
+            f1 = self.extractor.forward_batched(image1)
+            k0, k1, d0, d1 = f0["keypoints"], f1["keypoints"], f0["descriptors"], f1["descriptors"]
+            n0, n1, s0, s1 = f0["num_keypoints"], f1["num_keypoints"], f0["scores"], f1["scores"]
+        size0 = (image0.shape[-1], image0.shape[-2])
+        size1 = (image1.shape[-1], image1.shape[-2])
+        m = self.matcher.forward_batched(k0, k1, d0, d1, n0, n1, size0, size1)
+        return {
+            "keypoints0": k0, "keypoints1": k1, "scores0": s0, "scores1": s1, "descriptors0": d0, "descriptors1": d1,
+            "num_keypoints0": n0, "num_keypoints1": n1, **m,
+        }  # fmt: skip
+
+
+def match_table(out: dict) -> torch.Tensor:
+    """Fixed-stride per-pair record for the multi-GPU all-gather:
+    int32 [B, 3 + 2*K]: n0, n1, stop, matches0[K], bit-cast matching_scores0[K]."""
+    B, K = out["matches0"].shape
+    head = torch.stack([out["num_keypoints0"], out["num_keypoints1"], out["stop"]], 1).to(torch.int32)
+    return torch.cat([head, out["matches0"].to(torch.int32), out["matching_scores0"].contiguous().view(torch.int32)], 1)

@@ -1,0 +1,136 @@
+/* libimcui_hip -- C ABI of the MI355X (gfx950) extract/match backend for imcui.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: its hot path
+ * is the `_forward(data: dict) -> dict` of three `imcui.hloc` plugins, which delegate to
+ * PyTorch modules.  Each entry point below replaces the arithmetic behind one of those calls
+ * and is what a host-side binding (ctypes today) binds:
+ *
+ *   imcui_hip_superpoint_forward  <- imcui/hloc/extractors/superpoint.py:56-57  `self.net(data, self.conf)`
+ *   imcui_hip_lightglue_forward   <- imcui/hloc/matchers/lightglue.py:54-75     `self.net(input)`
+ *   imcui_hip_mutual_nn           <- imcui/hloc/matchers/nearest_neighbor.py:38-66 `_forward`
+ *   *_pack_weights                <- the `_init` weight loading (superpoint.py:48-53, lightglue.py:39-51)
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a device pointer owned by the caller (PyTorch-ROCm tensor
+ *     storage); the library never allocates or frees caller-visible memory.  Scratch comes from
+ *     a caller-provided workspace sized by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *     All work is enqueued on it; calls return without synchronising unless stated.
+ *   - return value: 0 = ok, < 0 = error (IMCUI_HIP_ERR_*); imcui_hip_last_error(h) has the text.
+ *     No exceptions cross the boundary.  The library is re-entrant per (handle, stream) and
+ *     holds no global mutable state.
+ *   - all tensors are float32 / int32, C-contiguous, batch-major.
+ */
+#ifndef IMCUI_HIP_H
+#define IMCUI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMCUI_HIP_OK 0
+#define IMCUI_HIP_ERR_ARG -1         /* bad argument */
+#define IMCUI_HIP_ERR_WS -2          /* workspace missing / too small */
+#define IMCUI_HIP_ERR_HIP -3         /* HIP runtime error */
+#define IMCUI_HIP_ERR_UNSUPPORTED -4 /* configuration outside what the kernels support */
+
+typedef struct imcui_hip_s imcui_hip_t;
+
+/* ---- handle ------------------------------------------------------------------------- */
+int imcui_hip_create(int device, imcui_hip_t** out);
+void imcui_hip_destroy(imcui_hip_t* h);
+const char* imcui_hip_last_error(const imcui_hip_t* h);
+int imcui_hip_version(void);
+
+/* ---- SuperPoint --------------------------------------------- */
+/* Weight packing runs on the HOST: `w[i]`, `b[i]` are the 12 conv weights (OIHW) / biases in the
+ * order conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa convPb convDa convDb
+ * (upstream state-dict keys `<name>.weight` / `<name>.bias`); `packed` receives
+ * imcui_hip_superpoint_packed_floats() floats which the caller uploads once. */
+size_t imcui_hip_superpoint_packed_floats(void);
+int imcui_hip_superpoint_pack_weights(const float* const* w, const float* const* b, float* packed);
+
+size_t imcui_hip_superpoint_workspace_bytes(int B, int H, int W, int nms_radius);
+/* Key-points a non-degenerate HxW image can yield after NMS (sizes `kcap` when max_keypoints < 0). */
+int imcui_hip_superpoint_max_keypoints_bound(int H, int W, int nms_radius);
+
+/* image [dev, B,1,H,W] in [0,1]; H, W multiples of 8.  Runtime conf (read per call, like the
+ * reference re-reads self.conf): nms_radius (0..4), keypoint_threshold, remove_borders,
+ * max_keypoints (-1 = all), fix_sampling (imcui/hloc/extractors/superpoint.py:16-30).
+ * Outputs, fixed stride `kcap` per image, first num_keypoints[b] entries valid:
+ *   keypoints   [dev, B,kcap,2]   (x, y) float pixel coordinates
+ *   scores      [dev, B,kcap]
+ *   descriptors [dev, B,kcap,256] row per key-point (the reference's [256,N] is its transpose view)
+ *   num_keypoints [dev, B] int32
+ *   score_map   [dev, B,H,W] optional (may be NULL): dense pre-NMS detector scores
+ * Order: score-descending (ties: lower flat index first) when top-k applies, row-major otherwise. */
+int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed, const float* image, int B, int H, int W,
+                                 int nms_radius, float keypoint_threshold, int remove_borders, int max_keypoints,
+                                 int fix_sampling, int kcap, float* keypoints, float* scores, float* descriptors,
+                                 int* num_keypoints, float* score_map, void* ws, size_t ws_bytes, void* stream);
+/* Synchronises `stream` and reports selection overflow of the last forward on `ws`
+ * (IMCUI_HIP_ERR_UNSUPPORTED + message) -- e.g. kcap too small for a max_keypoints = -1 call. */
+int imcui_hip_superpoint_status(imcui_hip_t* h, int B, int H, int W, int nms_radius, void* ws, size_t ws_bytes,
+                                void* stream);
+/* upstream `simple_nms` alone: scores/out [dev, B,H,W] */
+int imcui_hip_simple_nms(imcui_hip_t* h, const float* scores, float* out, int B, int H, int W, int nms_radius,
+                         void* stream);
+
+/* ---- LightGlue --------------------------------------------- */
+/* Host-side packing of the upstream state dict (9 layers, dim 256, 4 heads).  `tensors` holds the
+ * host pointers of imcui_hip_lightglue_num_tensors() tensors; tensor i is the upstream state-dict
+ * entry named imcui_hip_lightglue_tensor_name(i) (posenc.Wr.weight, transformers.{l}.*,
+ * log_assignment.{l}.*, token_confidence.{l}.token.0.*);
+ * `packed` receives imcui_hip_lightglue_packed_floats() floats. */
+size_t imcui_hip_lightglue_packed_floats(void);
+int imcui_hip_lightglue_num_tensors(void);
+const char* imcui_hip_lightglue_tensor_name(int i); /* upstream state-dict key of tensor i */
+int imcui_hip_lightglue_pack_weights(const float* const* tensors, float* packed);
+
+size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap);
+
+/* B pairs.  keypoints0/1 [dev, B,ncap,2] pixel (x,y); descriptors0/1 [dev, B,ncap,256];
+ * n0/n1 [dev, B] int32 valid counts (<= ncap).  size0/size1: (W,H) of the images the key-points
+ * live in (only used to normalise key-points, lightglue.py passes `image.shape`).
+ * depth_confidence / width_confidence <= 0 disable early stopping / point pruning;
+ * filter_threshold is conf["match_threshold"] (imcui/hloc/matchers/lightglue.py:50).  The three
+ * thresholds are doubles because the reference compares fp32 tensors against Python floats
+ * (e.g. `1 - width_confidence` is formed in double before the fp32 cast).
+ * Outputs [dev]: matches0/1 [B,ncap] int32 (-1 = unmatched), matching_scores0/1 [B,ncap],
+ * stop [B] int32 (layers run), prune0/1 [B,ncap] int32.  Entries >= n are -1 / 0. */
+int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
+                                const float* keypoints1, const float* descriptors0, const float* descriptors1,
+                                const int* n0, const int* n1, float w0, float h0, float w1, float h1,
+                                double depth_confidence, double width_confidence, double filter_threshold, int* matches0,
+                                int* matches1, float* matching_scores0, float* matching_scores1, int* stop, int* prune0,
+                                int* prune1, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
+size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
+/* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /
+ * distance_threshold <= 0 mean "None"; matches0 [dev, B,N] int32, scores0 [dev, B,N]. */
+int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,
+                        double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0,
+                        float* scores0, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- building blocks (exported for tests and for the LoFTR path to come) --------------------- */
+/* C[M,N] = A[M,K] * W[N,K]^T + bias ; relu optional ; K % 32 == 0 */
+int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+                         int relu, void* stream);
+/* NHWC 3x3 conv (pad 1) + bias (+ReLU) (+2x2 max-pool); weights OIHW on the HOST are packed with
+ * imcui_hip_conv3x3_pack (Cin % 32 == 0, Cout % 64 == 0) into Cout*Cin*9 floats. */
+int imcui_hip_conv3x3_pack(const float* w_oihw, int Cout, int Cin, float* packed);
+int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in_nhwc, const float* packed_w, const float* bias, float* out_nhwc,
+                          int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
+/* softmax(Q K^T) V, head_dim 64, operands head-major [S][heads][rows][64] (Q pre-scaled),
+ * output token-major [S*rows][heads*64]; cnt [dev, S] valid rows; cross: keys of sequence s^1. */
+int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,
+                            int heads, int rows, int cross, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMCUI_HIP_H */
