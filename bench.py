@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- image-pairs/s of the SuperPoint+LightGlue hot path on N MI355X (BASELINE.json).
+
+A step = one pass of the hot path over one batch of synthetic 640x480 pairs already resident in
+HBM: SuperPoint on 2B images (<= 2048 key-points, nms 3, thr 0.005) then LightGlue on the B
+pairs with early stopping and pruning DISABLED (depth = width = -1: all 9 layers on all points,
+the fixed-work worst case of SURVEY.md section 8d: 334 GF/pair -- nothing is skipped).  Weights are
+seeded random tensors of the real architecture (no checkpoints offline).  One process per GPU;
+pairs shard across ranks with no data-path dependency; each step ends with the RCCL all-gather of
+the fixed-stride match table.
+
+Prints ONE JSON line (rank 0).  `roofline` = attention kernel (the dominant kernel, 135 of 334
+GF/pair), algorithmic flops / HIP-event time measured live in the timed region; `cpu_baseline` =
+the torch-CPU oracle on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "image-matching-webui_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W, MAXK = 480, 640, 2048
+SP_GF_PER_IMAGE = 52.10
+LG_GF_PER_LAYER_PAIR = 25.23     # @N=M=2048, shared cross similarity
+ATTN_GF_PER_LAYER_PAIR = 15.03   # QK^T + PV, self (8.59) + cross with shared sim (6.44)
+PEAK_F32_MFMA_TF = 157.3         # MI355X_MICROARCH.md: dense f32 MFMA peak
+
+
+def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
+    """Oracle (= restated reference CPU path) timed on this host, same workload, batch 1."""
+    from imcui_hip.synth import make_pair
+    from oracle.lightglue import LightGlueOracle
+    from oracle.superpoint import SuperPointOracle
+    from oracle.weights import lightglue_state_dict, superpoint_state_dict
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sp = SuperPointOracle(superpoint_state_dict(0))
+    lg = LightGlueOracle(lightglue_state_dict(0), dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.1))
+    spc = dict(nms_radius=3, max_keypoints=MAXK, keypoint_threshold=0.005, remove_borders=4)
+
+    def one(seed):
+        i0, i1, _ = make_pair(seed, H, W)
+        f0, f1 = sp({"image": i0}, spc), sp({"image": i1}, spc)
+        lg({"image0": i0, "image1": i1, "keypoints0": f0["keypoints"][0][None], "keypoints1": f1["keypoints"][0][None],
+            "descriptors0": f0["descriptors"][0][None], "descriptors1": f1["descriptors"][0][None]})  # fmt: skip
+
+    one(0)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_pairs and (time.perf_counter() - t0) < max_seconds:
+        one(1 + n)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} synthetic 640x480 pairs, batch 1, fp32, SuperPoint(2048 kpts)+LightGlue(9 layers, no early exit), torch {torch.__version__} CPU"}  # fmt: skip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from imcui_hip import backend
+    from imcui_hip.pipeline import SuperPointLightGluePipeline, match_table
+    from imcui_hip.synth import make_pair_batch
+    from oracle.weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
+
+    B = args.batch
+    dc, wc = (0.95, 0.99) if args.adaptive else (-1.0, -1.0)
+    pipe = SuperPointLightGluePipeline(
+        {"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)},
+        {"depth_confidence": dc, "width_confidence": wc, "match_threshold": 0.1, "state_dict": lightglue_state_dict(0)},
+    ).eval().to(dev)
+    torch.manual_seed(1234 + rank)
+    img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
+    img0, img1 = img0.to(dev), img1.to(dev)
+    gathered = torch.empty((world * B, 3 + 2 * MAXK), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        out = pipe(img0, img1)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, match_table(out))
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    backend.profile_enable(dev, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    attn_ms, attn_n = backend.profile_read(dev, "attention")
+    conv_ms, conv_n = backend.profile_read(dev, "conv3x3")
+    gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
+    backend.profile_enable(dev, False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        nk0 = out["num_keypoints0"].float().mean().item()
+        nk1 = out["num_keypoints1"].float().mean().item()
+        stop = out["stop"].float().mean().item()
+        pairs = world * B * args.steps
+        ms_step = dt / args.steps * 1e3
+        # algorithmic flops of one attention launch: B pairs x 15.03 GF / 2 launches per layer
+        attn_flops = B * ATTN_GF_PER_LAYER_PAIR * 1e9 / 2 * (nk0 * nk1 / (MAXK * MAXK))
+        achieved = attn_flops / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
+        line = {
+            "metric": "image-pairs/sec @640x480 SuperPoint+LightGlue",
+            "value": pairs / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs resident in HBM",
+                "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, RCCL all-gather of match tables",
+                "lightglue_adaptive": bool(args.adaptive), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
+                "weights": "seeded random (oracle/weights.py), real architecture",
+            },
+            "roofline": {
+                "kernel": "attn_kernel (f32 MFMA flash attention)", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TF,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TF, "traffic": None,
+                "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n, "algorithmic_gflop_per_launch": attn_flops / 1e9,
+            },
+            "kernel_time_ms_per_step": {"attention": attn_ms / args.steps, "conv3x3": conv_ms / args.steps, "gemm": gemm_ms / args.steps},
+            "algorithmic_tflops_end_to_end": (2 * SP_GF_PER_IMAGE + 9 * LG_GF_PER_LAYER_PAIR + 2.7) * 1e9 * B / (ms_step * 1e-3) / 1e12,
+        }  # fmt: skip
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,54 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
     return IMCUI_OK;
 }
 
-extern "C" void imcui_hip_destroy(imcui_hip_t* h) { free(h); }
+extern "C" void imcui_hip_destroy(imcui_hip_t* h) {
+    if (!h) return;
+    for (int c = 0; c < PROF_NCLS; ++c) {
+        for (int i = 0; i < 2 * h->prof_alloc[c]; ++i) (void)hipEventDestroy(h->prof_ev[c][i]);
+        free(h->prof_ev[c]);
+    }
+    free(h);
+}
+
+// ---- optional HIP-event timing per kernel class ------------------------------------------
+void imcui_prof_begin(imcui_hip_s* h, int cls, hipStream_t s) {
+    if (!h->prof_on || h->prof_used[cls] >= PROF_MAX_EVENTS) return;
+    if (!h->prof_ev[cls]) h->prof_ev[cls] = (hipEvent_t*)calloc(2 * PROF_MAX_EVENTS, sizeof(hipEvent_t));
+    const int i = h->prof_used[cls];
+    if (i >= h->prof_alloc[cls]) {
+        (void)hipEventCreate(&h->prof_ev[cls][2 * i]);
+        (void)hipEventCreate(&h->prof_ev[cls][2 * i + 1]);
+        h->prof_alloc[cls] = i + 1;
+    }
+    (void)hipEventRecord(h->prof_ev[cls][2 * i], s);
+}
+void imcui_prof_end(imcui_hip_s* h, int cls, hipStream_t s) {
+    if (!h->prof_on || h->prof_used[cls] >= PROF_MAX_EVENTS) return;
+    (void)hipEventRecord(h->prof_ev[cls][2 * h->prof_used[cls] + 1], s);
+    h->prof_used[cls] += 1;
+}
+extern "C" int imcui_hip_profile_enable(imcui_hip_t* h, int on) {
+    if (!h) return IMCUI_ERR_ARG;
+    h->prof_on = on;
+    for (int c = 0; c < PROF_NCLS; ++c) h->prof_used[c] = 0;
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_profile_read(imcui_hip_t* h, int cls, double* total_ms, int* count) {
+    if (!h || cls < 0 || cls >= PROF_NCLS || !total_ms || !count) return IMCUI_ERR_ARG;
+    double tot = 0.0;
+    const int n = h->prof_used[cls];
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->prof_ev[cls][2 * i + 1]) != hipSuccess) return imcui_set_err(h, IMCUI_ERR_HIP, "profile: event sync failed");
+        if (hipEventElapsedTime(&ms, h->prof_ev[cls][2 * i], h->prof_ev[cls][2 * i + 1]) != hipSuccess)
+            return imcui_set_err(h, IMCUI_ERR_HIP, "profile: elapsed time failed");
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = n;
+    h->prof_used[cls] = 0;
+    return IMCUI_OK;
+}
 
 extern "C" const char* imcui_hip_last_error(const imcui_hip_t* h) { return h ? h->err : "null handle"; }
 

@@ -174,7 +174,9 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (p.rows_per_seq % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.nseq <= 0) return IMCUI_OK;
     dim3 grid(p.rows_per_seq / 128, p.heads, p.nseq);
+    imcui_prof_begin(h, PROF_ATTN, stream);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
+    imcui_prof_end(h, PROF_ATTN, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }

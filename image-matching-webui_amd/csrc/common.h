@@ -66,11 +66,20 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 #define IMCUI_ERR_HIP -3
 #define IMCUI_ERR_UNSUPPORTED -4
 
+// optional per-kernel-class HIP-event timing (bench.py's live roofline measurement)
+enum { PROF_ATTN = 0, PROF_CONV = 1, PROF_GEMM = 2, PROF_NCLS = 3 };
+#define PROF_MAX_EVENTS 4096
 struct imcui_hip_s {
     int device;
     int num_cu;
     char err[512];
+    int prof_on;
+    int prof_used[PROF_NCLS];
+    int prof_alloc[PROF_NCLS];
+    hipEvent_t* prof_ev[PROF_NCLS];  // pairs (start, stop)
 };
+void imcui_prof_begin(imcui_hip_s* h, int cls, hipStream_t s);
+void imcui_prof_end(imcui_hip_s* h, int cls, hipStream_t s);
 
 int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...);
 

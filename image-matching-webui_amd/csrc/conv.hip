@@ -134,8 +134,10 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
     const int tiles_x = cdiv(W, TW), tiles_y = cdiv(H, TH);
     const long nwg = (long)tiles_x * tiles_y * (Cout / 64) * B;
     if (nwg <= 0) return IMCUI_OK;
+    imcui_prof_begin(h, PROF_CONV, stream);
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, in, wp, bias, out, H, W, Cin, Cout,
                        tiles_x, tiles_y, relu, pool);
+    imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }

@@ -164,6 +164,7 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0) return IMCUI_OK;
     const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     dim3 grid(ntiles, 1, p.batch), block(256);
+    imcui_prof_begin(h, PROF_GEMM, stream);
     switch (p.epi) {
         case EPI_BIAS: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, 0, stream, p); break;
         case EPI_RELU: hipLaunchKernelGGL(gemm_kernel<EPI_RELU>, grid, block, 0, stream, p); break;
@@ -172,6 +173,7 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         case EPI_CROSS: hipLaunchKernelGGL(gemm_kernel<EPI_CROSS>, grid, block, 0, stream, p); break;
         default: return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: bad epilogue %d", p.epi);
     }
+    imcui_prof_end(h, PROF_GEMM, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }

@@ -259,6 +259,23 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
+# ------------------------------------------------------------------ live kernel timing
+KERNEL_CLASSES = {"attention": 0, "conv3x3": 1, "gemm": 2}
+
+
+def profile_enable(device: torch.device, on: bool = True):
+    hd = get_handle(device)
+    hd.check(hd.lib.imcui_hip_profile_enable(hd.h, int(on)), "profile_enable")
+
+
+def profile_read(device: torch.device, kernel_class: str):
+    """(total kernel ms, launches) of one class since the last read; HIP events on the launch stream."""
+    hd = get_handle(device)
+    tot, cnt = C.c_double(0.0), C.c_int(0)
+    hd.check(hd.lib.imcui_hip_profile_read(hd.h, KERNEL_CLASSES[kernel_class], C.byref(tot), C.byref(cnt)), "profile_read")
+    return tot.value, cnt.value
+
+
 # ------------------------------------------------------------------ building blocks (tests)
 def linear_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
     hd = get_handle(a.device)

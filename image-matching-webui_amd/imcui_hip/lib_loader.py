@@ -27,6 +27,8 @@ SIGNATURES = {
     "imcui_hip_destroy": (None, [C.c_void_p]),
     "imcui_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "imcui_hip_version": (C.c_int, []),
+    "imcui_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "imcui_hip_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imcui_hip_superpoint_packed_floats": (C.c_size_t, []),
     "imcui_hip_superpoint_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "imcui_hip_superpoint_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

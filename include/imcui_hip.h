@@ -45,6 +45,12 @@ void imcui_hip_destroy(imcui_hip_t* h);
 const char* imcui_hip_last_error(const imcui_hip_t* h);
 int imcui_hip_version(void);
 
+/* Optional HIP-event timing of the three heavy kernel classes on the launch stream
+ * (0 = attention, 1 = conv3x3, 2 = gemm): enable, run, then read (synchronises the events;
+ * returns the summed kernel time in ms and the number of launches, and resets the counters). */
+int imcui_hip_profile_enable(imcui_hip_t* h, int on);
+int imcui_hip_profile_read(imcui_hip_t* h, int kernel_class, double* total_ms, int* count);
+
 /* ---- SuperPoint --------------------------------------------- */
 /* Weight packing runs on the HOST: `w[i]`, `b[i]` are the 12 conv weights (OIHW) / biases in the
  * order conv1a conv1b conv2a conv2b conv3a conv3b conv4a conv4b convPa convPb convDa convDb

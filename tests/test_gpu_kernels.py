@@ -1,0 +1,106 @@
+"""Building-block kernels vs plain PyTorch fp32 (GPU box only, through the C ABI)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(256, 256, 256, False), (1000, 65, 256, False), (4800, 768, 256, True), (130, 130, 512, False)])
+def test_linear_f32(M, N, K, relu):
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    # asymmetric operands (row/col dependent) so a transposed write cannot pass
+    w = torch.randn(N, K, generator=g) + torch.arange(N).float()[:, None] * 0.01
+    b = torch.randn(N, generator=g)
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = (F.relu(ref) if relu else ref).float()
+    out = backend.linear_f32(a.to(_dev()), w.to(_dev()), b.to(_dev()), relu).cpu()
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [(2, 16, 32, 64, 64, False), (1, 24, 40, 64, 128, True), (2, 60, 80, 128, 256, False), (1, 15, 21, 32, 64, False)])
+def test_conv3x3_f32(B, H, W, Cin, Cout, pool):
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    ref = ref.float().permute(0, 2, 3, 1).contiguous()
+    out = backend.conv3x3_f32(x.permute(0, 2, 3, 1).contiguous().to(_dev()), w, b, relu=True, pool=pool).cpu()
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_f32(cross):
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(5)
+    S, Hh, R = 4, 4, 256
+    cnt = torch.tensor([256, 200, 77, 130], dtype=torch.int32)
+    q = torch.randn(S, Hh, R, 64, generator=g) * 0.5
+    k = torch.randn(S, Hh, R, 64, generator=g)
+    v = torch.randn(S, Hh, R, 64, generator=g)
+    # poison the padding rows: they must never leak into valid outputs
+    for s in range(S):
+        k[s, :, cnt[s]:] = float("nan")
+        v[s, :, cnt[s]:] = float("inf")
+    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), cross).cpu().view(S, R, Hh, 64)
+    for s in range(S):
+        ks = s ^ 1 if cross else s
+        nq, nk = int(cnt[s]), int(cnt[ks])
+        att = torch.softmax(q[s, :, :nq].double() @ k[ks, :, :nk].double().transpose(-1, -2), -1)
+        ref = (att @ v[ks, :, :nk].double()).float().permute(1, 0, 2)  # [nq, heads, 64]
+        got = out[s, :nq]
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_attention_sharp_softmax():
+    """Large logits: one key dominates; exercises the running-max rescale across tiles."""
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(6)
+    S, Hh, R = 2, 4, 384
+    cnt = torch.tensor([384, 300], dtype=torch.int32)
+    q = torch.randn(S, Hh, R, 64, generator=g) * 3.0
+    k = torch.randn(S, Hh, R, 64, generator=g) * 3.0
+    k[:, :, 290] *= 4.0  # spike in the last tile
+    v = torch.randn(S, Hh, R, 64, generator=g)
+    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), False).cpu().view(S, R, Hh, 64)
+    for s in range(S):
+        n = int(cnt[s])
+        att = torch.softmax(q[s, :, :n].double() @ k[s, :, :n].double().transpose(-1, -2), -1)
+        ref = (att @ v[s, :, :n].double()).float().permute(1, 0, 2)
+        assert (out[s, :n] - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("r", [0, 1, 3, 4])
+def test_simple_nms_bit_exact(r):
+    from imcui_hip import backend
+    from oracle.superpoint import simple_nms
+
+    g = torch.Generator().manual_seed(r)
+    s = torch.rand(2, 100, 141, generator=g)
+    s[0, 10:20, 10:30] = 0.5  # plateau of exact ties
+    s[1] = (s[1] * 8).round() / 8  # heavy quantisation -> many ties
+    ref = simple_nms(s, r)
+    out = backend.simple_nms(s.to(_dev()), r).cpu()
+    assert torch.equal(out, ref)

