@@ -1,0 +1,64 @@
+"""N>1 host logic on CPU: world_size-2 gloo, pair sharding + match-table all-gather."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from imcui_hip.distributed import gather_match_tables, padded_shard_size, run_sharded, shard_bounds
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 9, 100):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - s for s, e in spans) <= padded_shard_size(n, world) if n else True
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, num_pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K = 16
+
+    def fake_table(span):  # deterministic function of the global pair index, like a real matcher
+        s, e = span
+        idx = torch.arange(s, e, dtype=torch.int32)
+        return torch.stack([idx * 3 + j for j in range(3 + 2 * K)], 1)
+
+    out = run_sharded(lambda s, e: (s, e), num_pairs, fake_table)
+    expect = fake_table((0, num_pairs))
+    q.put((rank, bool(torch.equal(out, expect)), tuple(out.shape)))
+    # also the padded path explicitly
+    s, e = shard_bounds(num_pairs, rank, world)
+    out2 = gather_match_tables(fake_table((s, e)), num_pairs)
+    q.put((rank, bool(torch.equal(out2, expect)), tuple(out2.shape)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_pairs", [7, 8])
+def test_gloo_world2_allgather(num_pairs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, num_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (num_pairs, 3 + 32) for _, _, shape in res)

@@ -1,0 +1,107 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared
+symbol, weight packing is a pure permutation, plugins honour the reference seam."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.weights import lightglue_state_dict, superpoint_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from imcui_hip import build, load_library
+
+    build.build()
+    return load_library()
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    from imcui_hip.lib_loader import SIGNATURES
+
+    hdr = open(os.path.join(ROOT, "include", "imcui_hip.h")).read()
+    declared = set(re.findall(r"\b(imcui_hip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/imcui_hip.h but not exported"
+        assert name in SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.imcui_hip_version() >= 100
+
+
+def test_superpoint_packing_is_a_permutation(lib):
+    from imcui_hip import backend
+
+    sd = superpoint_state_dict(1)
+    packed = backend.pack_superpoint(sd).numpy()
+    total = sum(v.numel() for v in sd.values())
+    assert np.count_nonzero(packed) <= total
+    assert np.isclose(np.abs(packed).sum(dtype=np.float64), sum(v.abs().double().sum().item() for v in sd.values()), rtol=1e-9)
+    # spot-check the conv3x3 layout: [ch][tap][cq][cout][4]
+    w = sd["conv1b.weight"].numpy()
+    off = 9 * 64 + 64  # conv1a weights (576) + bias (64), both already 64-aligned
+    blk = packed[off : off + 64 * 64 * 9].reshape(2, 9, 8, 64, 4)
+    assert blk[1, 5, 3, 17, 2] == w[17, 32 + 3 * 4 + 2, 5 // 3, 5 % 3]
+
+
+def test_lightglue_packing_deinterleaves_qkv(lib):
+    from imcui_hip import backend
+
+    lsd = lightglue_state_dict(2)
+    names = backend.lightglue_tensor_names()
+    assert len(names) == 251 and names[0] == "posenc.Wr.weight" and set(names) <= set(lsd)
+    packed = backend.pack_lightglue(lsd).numpy()
+    assert np.isclose(np.abs(packed).sum(dtype=np.float64), sum(lsd[n].abs().double().sum().item() for n in names), rtol=1e-9)
+    # Wqkv rows of layer 0: packed row t*256 + h*64 + d  <-  upstream row h*192 + d*3 + t
+    w = lsd["transformers.0.self_attn.Wqkv.weight"].numpy()
+    base = 64
+    q_row = packed[base + (1 * 256 + 2 * 64 + 5) * 256 : base + (1 * 256 + 2 * 64 + 5) * 256 + 256]
+    assert np.array_equal(q_row, w[2 * 192 + 5 * 3 + 1])
+    # old-style checkpoint keys are accepted (renamed on load upstream)
+    old = {}
+    for k, v in lsd.items():
+        m = re.match(r"transformers\.(\d+)\.(self_attn|cross_attn)\.(.*)", k)
+        old[f"{m.group(2)}.{m.group(1)}.{m.group(3)}" if m else k] = v
+    assert np.array_equal(backend.pack_lightglue(old).numpy(), packed)
+
+
+def test_plugins_follow_the_reference_seam(lib):
+    import imcui_hip.hloc.extractors as extractors
+    import imcui_hip.hloc.matchers as matchers
+    from imcui_hip.hloc.utils.base_model import BaseModel, dynamic_load
+
+    SP = dynamic_load(extractors, "superpoint")
+    LG = dynamic_load(matchers, "lightglue")
+    NN = dynamic_load(matchers, "nearest_neighbor")
+    assert issubclass(SP, BaseModel) and issubclass(LG, BaseModel) and issubclass(NN, BaseModel)
+    # default_conf of the reference wrappers (superpoint.py:34-41, lightglue.py:15-25)
+    assert SP.default_conf["nms_radius"] == 4 and SP.default_conf["max_keypoints"] == -1 and SP.detection_noise == 2.0
+    assert LG.default_conf["depth_confidence"] == 0.95 and LG.default_conf["width_confidence"] == 0.99
+    sp = SP({"max_keypoints": 100, "state_dict": superpoint_state_dict(0)})
+    assert sp.conf["max_keypoints"] == 100 and sp.conf["nms_radius"] == 4 and "state_dict" not in sp.conf
+    # packed weights are a registered buffer (the UI model cache sums buffers and calls .to())
+    assert sum(b.numel() for b in sp.buffers()) >= 1300865
+    lg = LG({"match_threshold": 0.3, "state_dict": lightglue_state_dict(0)})
+    assert lg.conf["filter_threshold"] == 0.3
+    with pytest.raises(AssertionError):
+        lg({"image0": torch.zeros(1, 1, 8, 8)})  # missing required inputs
+    # no CPU fallback: the product path must fail loudly without a ROCm device tensor
+    from imcui_hip import ImcuiHipError
+
+    with pytest.raises(ImcuiHipError):
+        sp({"image": torch.zeros(1, 1, 64, 64)})
+    nn_model = NN({})
+    out = nn_model({"descriptors0": torch.zeros(1, 128, 5), "descriptors1": torch.zeros(1, 128, 0)})
+    assert (out["matches0"] == -1).all()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import imcui_hip.lib_loader as ll
+
+    monkeypatch.setattr(ll, "_lib", None)
+    with pytest.raises(ll.ImcuiHipError):
+        ll.load_library(str(tmp_path / "nope.so"))
