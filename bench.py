@@ -43,8 +43,6 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
     from oracle.superpoint import SuperPointOracle
     from oracle.weights import lightglue_state_dict, superpoint_state_dict
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     sp = SuperPointOracle(superpoint_state_dict(0))
     lg = LightGlueOracle(lightglue_state_dict(0), dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.1))
     spc = dict(nms_radius=3, max_keypoints=MAXK, keypoint_threshold=0.005, remove_borders=4)
@@ -55,6 +53,20 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
         lg({"image0": i0, "image1": i1, "keypoints0": f0["keypoints"][0][None], "keypoints1": f1["keypoints"][0][None],
             "descriptors0": f0["descriptors"][0][None], "descriptors1": f1["descriptors"][0][None]})  # fmt: skip
 
+    # pick the intra-op thread count that runs the oracle fastest on this host (oversubscribing a
+    # many-core box is catastrophically slow); the count used is reported as `cores`
+    ncpu = os.cpu_count() or 1
+    probe, _, _ = make_pair(99, H, W)
+    best_t, best_dt = 1, float("inf")
+    for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(t)
+        sp({"image": probe}, spc)
+        t0 = time.perf_counter()
+        sp({"image": probe}, spc)
+        d = time.perf_counter() - t0
+        if d < best_dt:
+            best_t, best_dt = t, d
+    torch.set_num_threads(best_t)
     one(0)  # warm-up
     t0 = time.perf_counter()
     n = 0

@@ -37,9 +37,12 @@ def synthetic_matching_problem(seed, n, m, n_out, noise=0.05, size=(640, 480)):
     g = torch.Generator().manual_seed(seed)
     W, H = size
     k0 = torch.rand(n, 2, generator=g) * torch.tensor([W - 8.0, H - 8.0]) + 4
-    perm = torch.randperm(n, generator=g)[:m]
+    perm = torch.randperm(n, generator=g)
+    perm = perm[torch.arange(m) % n]  # m > n: extra points of image 1 re-use partners (then become outliers)
     k1 = k0[perm] + torch.randn(m, 2, generator=g)
     d0 = F.normalize(torch.randn(n, 256, generator=g), dim=1)
     d1 = F.normalize(d0[perm] + noise * torch.randn(m, 256, generator=g), dim=1)
-    d1[:n_out] = F.normalize(torch.randn(n_out, 256, generator=g), dim=1)
+    n_out = max(n_out, m - n)
+    d1[m - n_out :] = F.normalize(torch.randn(n_out, 256, generator=g), dim=1)
+    k1[m - n_out :] = torch.rand(n_out, 2, generator=g) * torch.tensor([W - 8.0, H - 8.0]) + 4
     return k0, k1, d0, d1

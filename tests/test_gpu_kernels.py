@@ -89,7 +89,8 @@ def test_attention_sharp_softmax():
         n = int(cnt[s])
         att = torch.softmax(q[s, :, :n].double() @ k[s, :, :n].double().transpose(-1, -2), -1)
         ref = (att @ v[s, :, :n].double()).float().permute(1, 0, 2)
-        assert (out[s, :n] - ref).abs().max().item() < 5e-5
+        # logits reach several hundred: fp32 round-off of q.k alone is ~1e-4 relative in P
+        assert (out[s, :n] - ref).abs().max().item() < 5e-4
 
 
 @pytest.mark.parametrize("r", [0, 1, 3, 4])

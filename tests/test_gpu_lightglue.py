@@ -67,7 +67,7 @@ def test_lightglue_ragged_batch_vs_oracle(dc, wc):
 def test_lightglue_plugin_contract_and_empty():
     """Flat hloc dict in (descriptors [B,256,N]) -> reference keys out; empty side -> all -1."""
     a, c, e, f = synthetic_matching_problem(3, 300, 280, 60)
-    model = _model(0.95, 0.99)
+    model = _model(0.95, 0.99, th=0.2)
     img = torch.zeros(1, 1, 480, 640)
     data = {"image0": img, "image1": img, "keypoints0": a[None].cuda(), "keypoints1": c[None].cuda(),
             "scores0": torch.ones(1, 300).cuda(), "scores1": torch.ones(1, 280).cuda(),
