@@ -32,6 +32,7 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
     h->device = device;
     h->num_cu = prop.multiProcessorCount;
     h->err[0] = 0;
+    h->precision = 1;
     *out = h;
     return IMCUI_OK;
 }
@@ -85,6 +86,13 @@ extern "C" int imcui_hip_profile_read(imcui_hip_t* h, int cls, double* total_ms,
     return IMCUI_OK;
 }
 
+extern "C" int imcui_hip_set_precision(imcui_hip_t* h, int mode) {
+    if (!h || (mode != 0 && mode != 1)) return IMCUI_ERR_ARG;
+    h->precision = mode;
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_get_precision(const imcui_hip_t* h) { return h ? h->precision : -1; }
+
 extern "C" const char* imcui_hip_last_error(const imcui_hip_t* h) { return h ? h->err : "null handle"; }
 
 extern "C" int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float* W, const float* bias, float* C, int M, int N,
@@ -115,6 +123,18 @@ extern "C" int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in, const floa
                                      int H, int W, int Cin, int Cout, int relu, int pool, void* stream) {
     if (!h || !in || !wp || !bias || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: null argument");
     return conv3x3_launch(h, in, wp, bias, out, B, H, W, Cin, Cout, relu, pool, (hipStream_t)stream);
+}
+
+extern "C" float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo) {
+    if (!w_oihw || !hi || !lo || Cin % 32 || Cout % 64) return 0.0f;
+    return pack_conv3x3_split(w_oihw, Cout, Cin, hi, lo);
+}
+
+extern "C" int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in, const unsigned short* wh, const unsigned short* wl,
+                                           const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin,
+                                           int Cout, int relu, int pool, void* stream) {
+    if (!h || !in || !wh || !wl || !wscale || !bias || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3_split: null argument");
+    return conv3x3_split_launch(h, in, wh, wl, wscale, bias, out, B, H, W, Cin, Cout, relu, pool, (hipStream_t)stream);
 }
 
 extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O,

@@ -170,12 +170,215 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
 }
 
+// ------------------------------------------------------------------ 3 x f16 split variant
+// Same transposed flash structure on v_mfma_f32_32x32x16_f16: K, V^T tiles and Q are split into
+// f16 (hi, lo) pairs when they are staged, P is split in registers (scaled by 2^14 so that the
+// small probabilities keep their low part out of the f16 subnormal range), every product is
+// xh*yh + xh*yl + xl*yh with f32 accumulation.  V is consumed TRANSPOSED ([d][key], written that
+// way by the projection epilogue) because the P^T registers of a lane hold keys in groups of
+// four (C/D rows), so the matching A operand needs two 8-byte runs of consecutive keys per d.
+// V^T LDS image: row d = 4 groups of 16 keys, each group stored as two 16-byte halves
+// {keys 0-3, 8-11} and {keys 4-7, 12-15} (= what the hi = 0 / hi = 1 half-waves consume in one
+// MFMA step), + one 16-byte pad per row -> a fragment is ONE conflict-free ds_read_b128.
+#define VSTR 9  // V^T row stride in 16-byte units
+#define P_SCALE 16384.0f
+
+__global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
+    __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
+    uint4* Kh = smem4;  // [d-octet][key] 8 halves
+    uint4* Kl = smem4 + 8 * KSTR;
+    uint4* Vh = smem4 + 2 * 8 * KSTR;  // [d][VSTR]
+    uint4* Vl = Vh + 64 * VSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128;
+    const int nq = p.cnt[seq];
+    if (q0 >= nq) return;
+    if (p.active && p.active[seq >> 1] == 0) return;
+    const int kseq = p.cross ? (seq ^ 1) : seq;
+    const int nk = p.cnt[kseq];
+    const int R = p.rows_per_seq;
+
+    const float* Qb = p.Q + ((size_t)seq * p.heads + head) * R * 64;
+    const float* Kb = p.K + ((size_t)kseq * p.heads + head) * R * 64;
+    const float* Vb = p.V + ((size_t)kseq * p.heads + head) * 64 * R;  // V^T [64][R]
+
+    // Q fragment of this lane: query q0 + wid*32 + lo, dims 16s + 8hi .. +7, split once
+    uint4 qh[4], ql[4];
+    {
+        const int qrow = min(q0 + wid * 32 + lo, R - 1);
+        const float* qsrc = Qb + (size_t)qrow * 64 + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(qsrc + 16 * s);
+            const float4 b = *reinterpret_cast<const float4*>(qsrc + 16 * s + 4);
+            split8(a, b, qh[s], ql[s]);
+        }
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // staging: K 64 keys x 8 octets (2 items / thread), V^T 64 d x 16 key-quads (4 items / thread)
+    float4 rk[2][2], rv[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it;
+            const int key = k0 + (idx >> 3), oc = idx & 7;
+            // rows past the sequence end may hold anything (even NaN): they are zeroed when staged
+            const float* src = Kb + (size_t)min(key, R - 1) * 64 + oc * 8;
+            rk[it][0] = *reinterpret_cast<const float4*>(src);
+            rk[it][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            const int d = idx >> 4, kq = idx & 15;
+            const int key = k0 + kq * 4;
+            float4 v = *reinterpret_cast<const float4*>(Vb + (size_t)d * R + key);
+            // keys past the sequence end may hold anything (even NaN): feed zeros
+            if (key + 0 >= nk) v.x = 0.f;
+            if (key + 1 >= nk) v.y = 0.f;
+            if (key + 2 >= nk) v.z = 0.f;
+            if (key + 3 >= nk) v.w = 0.f;
+            rv[it] = v;
+        }
+    };
+
+    const int ntile = (nk + KT - 1) / KT;
+    if (ntile > 0) load_tile(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int k0 = tile * KT;
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 256 * it;
+            uint4 h, l;
+            split8(rk[it][0], rk[it][1], h, l);
+            if (k0 + (idx >> 3) >= nk) h = l = make_uint4(0u, 0u, 0u, 0u);
+            Kh[(idx & 7) * KSTR + (idx >> 3)] = h;
+            Kl[(idx & 7) * KSTR + (idx >> 3)] = l;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            const int d = idx >> 4, kq = idx & 15;
+            uint2 h, l;
+            split2(rv[it].x, rv[it].y, h.x, l.x);
+            split2(rv[it].z, rv[it].w, h.y, l.y);
+            // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
+            const int u = (d * VSTR + (kq >> 2) * 2 + (kq & 1)) * 2 + ((kq >> 1) & 1);
+            reinterpret_cast<uint2*>(Vh)[u] = h;
+            reinterpret_cast<uint2*>(Vl)[u] = l;
+        }
+        __syncthreads();
+        if (tile + 1 < ntile) load_tile(k0 + KT);
+
+        // ---- S^T = K . Q^T  (two 32-key fragments, K = 64 in four 16-wide steps)
+        f32x16 s[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[f][r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint4 ah = Kh[(2 * st + hi) * KSTR + 32 * f + lo];
+                const uint4 al = Kl[(2 * st + hi) * KSTR + 32 * f + lo];
+                s[f] = mfma16(al, qh[st], s[f]);
+                s[f] = mfma16(ah, ql[st], s[f]);
+                s[f] = mfma16(ah, qh[st], s[f]);
+            }
+        }
+        // ---- online soft-max for query `lo`
+        float m_t = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + 32 * f + frag_row(r, hi);
+                const float v = (key < nk) ? s[f][r] : -INFINITY;
+                s[f][r] = v;
+                m_t = fmaxf(m_t, v);
+            }
+        m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        const float m_new = fmaxf(m_run, m_t);
+        const float alpha = expf(m_run - m_new);
+        float l_t = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = expf(s[f][r] - m_new);
+                l_t += pv;
+                s[f][r] = pv * P_SCALE;
+            }
+        l_run = l_run * alpha + l_t;
+        m_run = m_new;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+        // ---- O^T += V^T . P^T : step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 ph, pl;
+                split2(s[f][8 * t + 0], s[f][8 * t + 1], ph.x, pl.x);
+                split2(s[f][8 * t + 2], s[f][8 * t + 3], ph.y, pl.y);
+                split2(s[f][8 * t + 4], s[f][8 * t + 5], ph.z, pl.z);
+                split2(s[f][8 * t + 6], s[f][8 * t + 7], ph.w, pl.w);
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const int vi = (32 * df + lo) * VSTR + (2 * f + t) * 2 + hi;
+                    const uint4 vh = Vh[vi];
+                    const uint4 vl = Vl[vi];
+                    o[df] = mfma16(vl, ph, o[df]);
+                    o[df] = mfma16(vh, pl, o[df]);
+                    o[df] = mfma16(vh, ph, o[df]);
+                }
+            }
+    }
+
+    // ---- normalise and write (transpose through LDS so each query row is stored contiguously)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (ntile > 0) ? (1.0f / P_SCALE) / l_tot : 0.0f;
+    __syncthreads();
+    float* Os = reinterpret_cast<float*>(smem4) + wid * (32 * 33);
+    const int H64 = p.heads * 64;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[lo * 33 + frag_row(r, hi)] = o[f][r] * inv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int q = 2 * qq + hi;
+            const int row = q0 + wid * 32 + q;
+            if (row < nq) p.O[((size_t)seq * R + row) * H64 + head * 64 + 32 * f + lo] = Os[q * 33 + lo];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (p.rows_per_seq % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.nseq <= 0) return IMCUI_OK;
     dim3 grid(p.rows_per_seq / 128, p.heads, p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
+    if (h->precision == 1)
+        hipLaunchKernelGGL(attn_split_kernel, grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
     imcui_prof_end(h, PROF_ATTN, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

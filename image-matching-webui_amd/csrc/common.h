@@ -25,6 +25,33 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-precision path: x = hi + lo with hi, lo in f16; a product a*b is evaluated as
+// ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 (products exact, f32 accumulate): ~fp32
+// accuracy (dropped al*bl term is 2^-22 relative) at 3/16 of the f32-MFMA cost.
+// f16 fragment layout (lane l, hi = l >> 5, lo = l & 31): A = 8 halves A[row = lo][k = 8*hi .. 8*hi+7],
+// B = 8 halves B[k = 8*hi .. 8*hi+7][col = lo]; C/D as for the f32 instruction.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// hi = round-toward-zero f16 pair (one instruction, saturates instead of overflowing to inf),
+// lo = round-to-nearest f16 of the exact remainders
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    split2(a.x, a.y, hi.x, lo.x);
+    split2(a.z, a.w, hi.y, lo.y);
+    split2(b.x, b.y, hi.z, lo.z);
+    split2(b.z, b.w, hi.w, lo.w);
+}
+
 // row inside a 32x32 C/D fragment held by (reg r, half hi)
 __device__ __forceinline__ int frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
@@ -73,6 +100,7 @@ struct imcui_hip_s {
     int device;
     int num_cu;
     char err[512];
+    int precision;  // 0 = exact f32 MFMA, 1 = 3 x f16 split MFMA (default)
     int prof_on;
     int prof_used[PROF_NCLS];
     int prof_alloc[PROF_NCLS];

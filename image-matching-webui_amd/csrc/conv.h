@@ -9,6 +9,14 @@
 int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float* bias, float* out, int B, int H, int W,
                    int Cin, int Cout, int relu, int pool, hipStream_t stream);
 
+// split-precision variant (imcui_hip_s::precision == 1): weights pre-split into f16 hi / lo planes
+//   wh/wl : [Cin/32][9 taps][4 octets][Cout][8 halves] of w * 2^e ; wscale -> 2^-e (device scalar)
+int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
+                         const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                         int relu, int pool, hipStream_t stream);
+// host: OIHW -> the split layout above; returns 2^-e
+float pack_conv3x3_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+
 // first layer: 1 -> 64 channels, 3x3, pad 1, +bias, +ReLU.  in [B,H,W] ; w [9][64] ; out [B,H,W,64]
 int conv1a_launch(imcui_hip_s* h, const float* in, const float* w, const float* bias, float* out, int B, int H, int W,
                   hipStream_t stream);

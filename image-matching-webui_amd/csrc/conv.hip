@@ -7,7 +7,10 @@
 // in LDS and prefetched through registers.  Wave w owns output rows 2w, 2w+1 (32 pixels, one
 // MFMA row fragment) and all 64 output channels (two column fragments).  ReLU and the 2x2
 // max-pool are applied in registers: the four pixels of a pooling window live in one lane.
+#include <stdlib.h>
+
 #include "conv.h"
+#include "gemm.h"
 
 #define TH 8
 #define TW 16
@@ -59,23 +62,16 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             Ps[cq * PSTR + pp] = v;
         }
         // ---- weight slab prefetch for tap 0: 8 cq x 64 cout float4 = 512 -> 2 per thread
-        float4 rw[2];
+        float4 rw0, rw1;
         auto wload = [&](int tap) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = tid + 256 * it;
-                const int cq = idx >> 6, co = idx & 63;
-                rw[it] = wp4[((size_t)(ch * 9 + tap) * 8 + cq) * Cout + cout0 + co];
-            }
+            rw0 = wp4[((size_t)(ch * 9 + tap) * 8 + (tid >> 6)) * Cout + cout0 + (tid & 63)];
+            rw1 = wp4[((size_t)(ch * 9 + tap) * 8 + 4 + (tid >> 6)) * Cout + cout0 + (tid & 63)];
         };
         wload(0);
         for (int tap = 0; tap < 9; ++tap) {
             float4* wbuf = Ws[tap & 1];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = tid + 256 * it;
-                wbuf[(idx >> 6) * WSTR + (idx & 63)] = rw[it];
-            }
+            wbuf[(tid >> 6) * WSTR + (tid & 63)] = rw0;
+            wbuf[(4 + (tid >> 6)) * WSTR + (tid & 63)] = rw1;
             __syncthreads();
             if (tap + 1 < 9) wload(tap + 1);
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -137,6 +133,161 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
     imcui_prof_begin(h, PROF_CONV, stream);
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, in, wp, bias, out, H, W, Cin, Cout,
                        tiles_x, tiles_y, relu, pool);
+    imcui_prof_end(h, PROF_CONV, stream);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ 3 x f16 split variant
+// 16x16 pixel tile x 64 output channels per workgroup; wave w owns rows 4w..4w+3 (two 32-pixel
+// row fragments) x 64 channels (two column fragments) = 64 accumulators.  The f32 input patch of
+// a 32-channel chunk is split into f16 (hi, lo) while it is staged into LDS as
+// [channel-octet][pixel][8 halves]; weights arrive pre-split.  Each tap = two 16-channel MFMA
+// steps of ah*bh + ah*bl + al*bh.
+#define STH 16
+#define STW 16
+#define SPW (STW + 2)
+#define SNPIX ((STH + 2) * SPW)  // 324
+#define SPSTR 330                // padded pixel stride (16-byte units): conflict-free staging writes
+
+__global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restrict__ in,
+                                                            const unsigned short* __restrict__ wh,
+                                                            const unsigned short* __restrict__ wl,
+                                                            const float* __restrict__ wscale,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
+                                                            int relu, int pool) {
+    __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSTR];
+    uint4* Ph = smem;
+    uint4* Pl = smem + 4 * SPSTR;
+    uint4* Wb = smem + 2 * 4 * SPSTR;  // [buf][plane][4 * WSTR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int ncout = Cout >> 6;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = t % ncout;
+    int sp = t / ncout;
+    const int tx = sp % tiles_x;
+    sp /= tiles_x;
+    const int ty = sp % tiles_y;
+    const int b = sp / tiles_y;
+    const int y0 = ty * STH, x0 = tx * STW, cout0 = ct * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nchunk = Cin >> 5;
+    const uint4* wh4 = reinterpret_cast<const uint4*>(wh);
+    const uint4* wl4 = reinterpret_cast<const uint4*>(wl);
+    const int px = lo & 15;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();  // everybody is done with the previous patch
+        for (int idx = tid; idx < SNPIX * 4; idx += 256) {
+            const int oc = idx & 3, pp = idx >> 2;
+            const int gy = y0 - 1 + pp / SPW, gx = x0 - 1 + pp % SPW;
+            uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                split8(a, c, hq, lq);
+            }
+            Ph[oc * SPSTR + pp] = hq;
+            Pl[oc * SPSTR + pp] = lq;
+        }
+        // weight slab of a tap: 4 octets x 64 cout per plane = 256 x 16 B -> one per thread per plane
+        uint4 rwh, rwl;
+        auto wload = [&](int tap) {
+            const size_t o = ((size_t)(ch * 9 + tap) * 4 + (tid >> 6)) * Cout + cout0 + (tid & 63);
+            rwh = wh4[o];
+            rwl = wl4[o];
+        };
+        wload(0);
+        for (int tap = 0; tap < 9; ++tap) {
+            uint4* wbh = Wb + (tap & 1) * (2 * 4 * WSTR);
+            uint4* wbl = wbh + 4 * WSTR;
+            wbh[(tid >> 6) * WSTR + (tid & 63)] = rwh;
+            wbl[(tid >> 6) * WSTR + (tid & 63)] = rwl;
+            __syncthreads();
+            if (tap + 1 < 9) wload(tap + 1);
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int oc = 2 * st + hi;
+                uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int pp = (4 * wid + 2 * m + (lo >> 4) + dy) * SPW + px + dx;
+                    ah[m] = Ph[oc * SPSTR + pp];
+                    al[m] = Pl[oc * SPSTR + pp];
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    bh[n] = wbh[oc * WSTR + n * 32 + lo];
+                    bl[n] = wbl[oc * WSTR + n * 32 + lo];
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = mfma16(al[m], bh[n], acc[m][n]);
+                        acc[m][n] = mfma16(ah[m], bl[n], acc[m][n]);
+                        acc[m][n] = mfma16(ah[m], bh[n], acc[m][n]);
+                    }
+            }
+        }
+    }
+
+    const float wsc = wscale[0];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int co = cout0 + n * 32 + lo;
+        const float bv = bias[co];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (pool) {
+                const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    float v = fmaxf(fmaxf(acc[m][n][r], acc[m][n][r + 1]), fmaxf(acc[m][n][r + 8], acc[m][n][r + 9])) * wsc + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    const int p = frag_row(r, hi);
+                    const int oy = (y0 >> 1) + 2 * wid + m, ox = (x0 >> 1) + (p >> 1);
+                    if (oy < Ho && ox < Wo) out[(((size_t)b * Ho + oy) * Wo + ox) * Cout + co] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = frag_row(r, hi);
+                    const int oy = y0 + 4 * wid + 2 * m + (p >> 4), ox = x0 + (p & 15);
+                    float v = acc[m][n][r] * wsc + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (oy < H && ox < W) out[(((size_t)b * H + oy) * W + ox) * Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
+                         const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                         int relu, int pool, hipStream_t stream) {
+    if (Cin % 32 != 0 || Cout % 64 != 0)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
+    if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
+    const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, STH);
+    const long nwg = (long)tiles_x * tiles_y * (Cout / 64) * B;
+    if (nwg <= 0) return IMCUI_OK;
+    imcui_prof_begin(h, PROF_CONV, stream);
+    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W,
+                       Cin, Cout, tiles_x, tiles_y, relu, pool);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -205,6 +356,24 @@ void pack_conv3x3(const float* w, int Cout, int Cin, float* dst) {
                         const int ci = ch * 32 + cq * 4 + j;
                         dst[((((size_t)ch * 9 + tap) * 8 + cq) * Cout + co) * 4 + j] = w[((size_t)co * Cin + ci) * 9 + tap];
                     }
+}
+
+float pack_conv3x3_split(const float* w, int Cout, int Cin, unsigned short* hi, unsigned short* lo) {
+    // value order: [((ch*9 + tap)*4 + oc)*Cout + co][j]  <-  w[co][ch*32 + oc*8 + j][tap]
+    const size_t n = (size_t)Cout * Cin * 9;
+    float* tmp = (float*)malloc(n * sizeof(float));
+    const int nchunk = Cin / 32;
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int oc = 0; oc < 4; ++oc)
+                for (int co = 0; co < Cout; ++co)
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = ch * 32 + oc * 8 + j;
+                        tmp[((((size_t)ch * 9 + tap) * 4 + oc) * Cout + co) * 8 + j] = w[((size_t)co * Cin + ci) * 9 + tap];
+                    }
+    const float sc = split_weights_host(tmp, n, hi, lo);
+    free(tmp);
+    return sc;
 }
 
 void pack_conv1a(const float* w, float* dst) {

@@ -1,5 +1,8 @@
-// f32 MFMA GEMM with fused epilogues:  C = epi(A[M,K] * W[N,K]^T + bias).
+// MFMA GEMM with fused epilogues:  C = epi(A[M,K] * W[N,K]^T + bias).
 // Both operands are K-contiguous (nn.Linear weight layout / NHWC activations).
+// Two arithmetic modes (imcui_hip_s::precision):
+//   0  exact f32 on v_mfma_f32_32x32x2_f32
+//   1  3 x f16 split (hi/lo) on v_mfma_f32_32x32x16_f16, f32 accumulate (~fp32 accuracy, ~5x rate)
 #pragma once
 #include "common.h"
 
@@ -18,8 +21,13 @@ struct GemmP {
     const float* A2 = nullptr;  // optional second K-slab: k >= K1 comes from A2[:, k - K1]
     long lda2 = 0;
     int K1 = 0;
-    const float* W = nullptr;  // [N, K]
+    const float* W = nullptr;  // [N, K] f32
     long ldw = 0;
+    // pre-split weights for precision 1 (optional; when null W is split on the fly):
+    // Wh/Wl [N, K] f16 planes of W * 2^e, wscale -> 2^-e
+    const unsigned short* Wh = nullptr;
+    const unsigned short* Wl = nullptr;
+    const float* wscale = nullptr;
     const float* bias = nullptr;  // [N] or null
     float* C = nullptr;           // [M, N] (EPI_BIAS / RELU / RESID)
     long ldc = 0;
@@ -44,9 +52,13 @@ struct GemmP {
     float* Q = nullptr;
     float* Kt = nullptr;
     float* V = nullptr;
+    int v_transposed = 0;  // 1: V is written as V^T [seq][head][64][rows_per_seq] (split attention)
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;
 };
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);
+
+// host: split an [n] f32 array into f16 hi / lo planes of w * 2^e; returns 2^-e
+float split_weights_host(const float* w, size_t n, unsigned short* hi, unsigned short* lo);

@@ -20,14 +20,19 @@
 #define LG_HEADS 4
 
 // ------------------------------------------------------------------ packed weights
+struct LgSplit {
+    size_t h, l, s;  // f16 hi / lo planes (float offsets) and 2^-e scale(s)
+};
 struct LgLayerOff {
     size_t wqkv, bqkv, wo, bo, w1s, b1s, gs, bs, w2s, b2s;
     size_t wx, bx, wto, bto, w1c, b1c, gc, bc, w2c, b2c;
+    LgSplit sqkv, so, s1s, s2s, sx, sto, s1c, s2c;
 };
 struct LgLayout {
     size_t wr;
     LgLayerOff L[LG_LAYERS];
     size_t wfinal, bfinal, wmatch, bmatch, wtoken, btoken;
+    LgSplit sfinal;  // [9] planes, scale array [9]
     size_t total;
 };
 
@@ -69,6 +74,25 @@ static LgLayout lg_layout() {
     l.bmatch = take(64);
     l.wtoken = take((size_t)(LG_LAYERS - 1) * 256);
     l.btoken = take(64);
+    auto take_split = [&](size_t n) {
+        LgSplit sp;
+        sp.h = take(n / 2);
+        sp.l = take(n / 2);
+        sp.s = take(64);
+        return sp;
+    };
+    for (int i = 0; i < LG_LAYERS; ++i) {
+        LgLayerOff& o = l.L[i];
+        o.sqkv = take_split(768 * 256);
+        o.so = take_split(256 * 256);
+        o.s1s = take_split(512 * 512);
+        o.s2s = take_split(256 * 512);
+        o.sx = take_split(512 * 256);
+        o.sto = take_split(256 * 256);
+        o.s1c = take_split(512 * 512);
+        o.s2c = take_split(256 * 512);
+    }
+    l.sfinal = take_split((size_t)LG_LAYERS * 256 * 256);
     l.total = off;
     return l;
 }
@@ -157,6 +181,23 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
     for (int i = 0; i < LG_LAYERS - 1; ++i) {
         cp(l.wtoken + (size_t)i * 256, tk[2 * i], 256);
         packed[l.btoken + i] = tk[2 * i + 1][0];
+    }
+    // split-precision copies of every GEMM weight (taken from the packed f32 layout)
+    auto sp = [&](const LgSplit& d, size_t src, size_t n, int slot) {
+        packed[d.s + slot] = split_weights_host(packed + src, n, reinterpret_cast<unsigned short*>(packed + d.h) + (size_t)slot * n,
+                                                reinterpret_cast<unsigned short*>(packed + d.l) + (size_t)slot * n);
+    };
+    for (int i = 0; i < LG_LAYERS; ++i) {
+        const LgLayerOff& o = l.L[i];
+        sp(o.sqkv, o.wqkv, 768 * 256, 0);
+        sp(o.so, o.wo, 256 * 256, 0);
+        sp(o.s1s, o.w1s, 512 * 512, 0);
+        sp(o.s2s, o.w2s, 256 * 512, 0);
+        sp(o.sx, o.wx, 512 * 256, 0);
+        sp(o.sto, o.wto, 256 * 256, 0);
+        sp(o.s1c, o.w1c, 512 * 512, 0);
+        sp(o.s2c, o.w2c, 256 * 512, 0);
+        sp(l.sfinal, l.wfinal + (size_t)i * 65536, 65536, i);
     }
     return IMCUI_OK;
 }
@@ -714,13 +755,23 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
                        matches1, mscores0, mscores1, prune0, prune1);
     IMCUI_CHECK_LAUNCH(h);
 
+    const bool split = h->precision == 1;
     auto base = [&](GemmP& g) {
         g.M = S * R;
         g.cnt = cnt_cur;
         g.active = w.active;
         g.rows_per_seq = R;
     };
-    auto ffn = [&](const float* msg, size_t w1, size_t b1, size_t gm, size_t bt, size_t w2, size_t b2) -> int {
+    auto wts = [&](GemmP& g, size_t wf32, const LgSplit& sp) {
+        g.W = P + wf32;
+        if (split) {
+            g.Wh = reinterpret_cast<const unsigned short*>(P + sp.h);
+            g.Wl = reinterpret_cast<const unsigned short*>(P + sp.l);
+            g.wscale = P + sp.s;
+        }
+    };
+    auto ffn = [&](const float* msg, size_t w1, const LgSplit& s1, size_t b1, size_t gm, size_t bt, size_t w2,
+                   const LgSplit& s2, size_t b2) -> int {
         GemmP g;
         base(g);
         g.epi = EPI_BIAS;
@@ -731,7 +782,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
         g.K1 = 256;
         g.K = 512;
         g.N = 512;
-        g.W = P + w1;
+        wts(g, w1, s1);
         g.ldw = 512;
         g.bias = P + b1;
         g.C = w.hbuf;
@@ -746,7 +797,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
         g2.lda = 512;
         g2.K = 512;
         g2.N = 256;
-        g2.W = P + w2;
+        wts(g2, w2, s2);
         g2.ldw = 512;
         g2.bias = P + b2;
         g2.C = w.x;
@@ -765,9 +816,10 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.lda = 256;
             g.K = 256;
             g.N = 768;
-            g.W = P + o.wqkv;
+            wts(g, o.wqkv, o.sqkv);
             g.ldw = 256;
             g.bias = P + o.bqkv;
+            g.v_transposed = split ? 1 : 0;
             g.Q = w.q;
             g.Kt = w.k;
             g.V = w.v;
@@ -795,13 +847,13 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g2.lda = 256;
             g2.K = 256;
             g2.N = 256;
-            g2.W = P + o.wo;
+            wts(g2, o.wo, o.so);
             g2.ldw = 256;
             g2.bias = P + o.bo;
             g2.C = w.msg;
             g2.ldc = 256;
             LGRUN(gemm_launch(h, g2, stream));
-            LGRUN(ffn(w.msg, o.w1s, o.b1s, o.gs, o.bs, o.w2s, o.b2s));
+            LGRUN(ffn(w.msg, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.b2s));
         }
         // ---- CrossBlock
         {
@@ -812,9 +864,10 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.lda = 256;
             g.K = 256;
             g.N = 512;
-            g.W = P + o.wx;
+            wts(g, o.wx, o.sx);
             g.ldw = 256;
             g.bias = P + o.bx;
+            g.v_transposed = split ? 1 : 0;
             g.Q = w.q;
             g.V = w.v;
             g.alpha = (float)0.35355339059327373;  // (64 ** -0.5) ** 0.5 applied to both sides
@@ -839,13 +892,13 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g2.lda = 256;
             g2.K = 256;
             g2.N = 256;
-            g2.W = P + o.wto;
+            wts(g2, o.wto, o.sto);
             g2.ldw = 256;
             g2.bias = P + o.bto;
             g2.C = w.msg;
             g2.ldc = 256;
             LGRUN(gemm_launch(h, g2, stream));
-            LGRUN(ffn(w.msg, o.w1c, o.b1c, o.gc, o.bc, o.w2c, o.b2c));
+            LGRUN(ffn(w.msg, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
         }
         if (layer == LG_LAYERS - 1) break;  // no early stopping or adaptive width at the last layer
         if (!do_stop && !do_prune) continue;
@@ -880,7 +933,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
         g.lda = 256;
         g.K = 256;
         g.N = 256;
-        g.W = P + l.wfinal;
+        wts(g, l.wfinal, l.sfinal);
         g.ldw = 256;
         g.bias = P + l.bfinal;
         g.wsel = stop;

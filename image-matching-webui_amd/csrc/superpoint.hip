@@ -11,7 +11,9 @@
 
 // ------------------------------------------------------------------ packed weight layout
 struct SpLayout {
-    size_t w[12], b[12], total;
+    size_t w[12], b[12];
+    size_t wh[12], wl[12], ws[12];  // split planes (f16 hi / lo, as float offsets) + 2^-e scale
+    size_t total;
 };
 static const int SP_COUT[12] = {64, 64, 64, 64, 128, 128, 128, 128, 256, 65, 256, 256};
 static const int SP_CIN[12] = {1, 64, 64, 64, 64, 128, 128, 128, 128, 256, 128, 256};
@@ -26,6 +28,15 @@ static SpLayout sp_layout() {
         off += align_up((size_t)SP_COUT[i] * SP_CIN[i] * SP_K[i] * SP_K[i], 64);
         l.b[i] = off;
         off += align_up((size_t)SP_COUT[i], 64);
+    }
+    for (int i = 1; i < 12; ++i) {  // conv1a (Cin = 1) stays on the VALU
+        const size_t n = (size_t)SP_COUT[i] * SP_CIN[i] * SP_K[i] * SP_K[i];
+        l.wh[i] = off;
+        off += align_up(n / 2 + 1, 64);
+        l.wl[i] = off;
+        off += align_up(n / 2 + 1, 64);
+        l.ws[i] = off;
+        off += 64;
     }
     l.total = off;
     return l;
@@ -46,6 +57,13 @@ extern "C" int imcui_hip_superpoint_pack_weights(const float* const* w, const fl
         else  // 1x1: [Cout][Cin] is already the K-contiguous GEMM layout
             memcpy(packed + l.w[i], w[i], (size_t)SP_COUT[i] * SP_CIN[i] * sizeof(float));
         memcpy(packed + l.b[i], b[i], (size_t)SP_COUT[i] * sizeof(float));
+        if (i == L1A) continue;
+        unsigned short* hp = reinterpret_cast<unsigned short*>(packed + l.wh[i]);
+        unsigned short* lp = reinterpret_cast<unsigned short*>(packed + l.wl[i]);
+        if (SP_K[i] == 3)
+            packed[l.ws[i]] = pack_conv3x3_split(w[i], SP_COUT[i], SP_CIN[i], hp, lp);
+        else
+            packed[l.ws[i]] = split_weights_host(w[i], (size_t)SP_COUT[i] * SP_CIN[i], hp, lp);
     }
     return IMCUI_OK;
 }
@@ -526,33 +544,47 @@ extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed,
         if (rc != IMCUI_OK) return rc; \
     } while (0)
     const int Hc = H / 8, Wc = W / 8;
-    // a2: encoder
-    SPRUN(conv1a_launch(h, image, P + l.w[L1A], P + l.b[L1A], s.a1a, B, H, W, stream));
-    SPRUN(conv3x3_launch(h, s.a1a, P + l.w[L1B], P + l.b[L1B], s.p1, B, H, W, 64, 64, 1, 1, stream));
-    SPRUN(conv3x3_launch(h, s.p1, P + l.w[L2A], P + l.b[L2A], s.a2a, B, H / 2, W / 2, 64, 64, 1, 0, stream));
-    SPRUN(conv3x3_launch(h, s.a2a, P + l.w[L2B], P + l.b[L2B], s.p2, B, H / 2, W / 2, 64, 64, 1, 1, stream));
-    SPRUN(conv3x3_launch(h, s.p2, P + l.w[L3A], P + l.b[L3A], s.a3a, B, H / 4, W / 4, 64, 128, 1, 0, stream));
-    SPRUN(conv3x3_launch(h, s.a3a, P + l.w[L3B], P + l.b[L3B], s.p3, B, H / 4, W / 4, 128, 128, 1, 1, stream));
-    SPRUN(conv3x3_launch(h, s.p3, P + l.w[L4A], P + l.b[L4A], s.a4a, B, Hc, Wc, 128, 128, 1, 0, stream));
-    SPRUN(conv3x3_launch(h, s.a4a, P + l.w[L4B], P + l.b[L4B], s.feat, B, Hc, Wc, 128, 128, 1, 0, stream));
-    // a3: detector head -> dense score map
-    SPRUN(conv3x3_launch(h, s.feat, P + l.w[LPA], P + l.b[LPA], s.head, B, Hc, Wc, 128, 256, 1, 0, stream));
-    const long ncell = (long)B * Hc * Wc;
-    {
+    const bool split = h->precision == 1;
+    auto conv = [&](int L, const float* src, float* dst, int hh, int ww, int pool) -> int {
+        if (split)
+            return conv3x3_split_launch(h, src, reinterpret_cast<const unsigned short*>(P + l.wh[L]),
+                                        reinterpret_cast<const unsigned short*>(P + l.wl[L]), P + l.ws[L], P + l.b[L], dst, B,
+                                        hh, ww, SP_CIN[L], SP_COUT[L], 1, pool, stream);
+        return conv3x3_launch(h, src, P + l.w[L], P + l.b[L], dst, B, hh, ww, SP_CIN[L], SP_COUT[L], 1, pool, stream);
+    };
+    auto lin = [&](int L, const float* src, float* dst, int ldc) -> int {
         GemmP g;
         g.epi = EPI_BIAS;
-        g.A = s.head;
-        g.lda = 256;
-        g.W = P + l.w[LPB];
-        g.ldw = 256;
-        g.bias = P + l.b[LPB];
-        g.C = s.logits;
-        g.ldc = 65;
-        g.M = (int)ncell;
-        g.N = 65;
-        g.K = 256;
-        SPRUN(gemm_launch(h, g, stream));
-    }
+        g.A = src;
+        g.lda = SP_CIN[L];
+        g.W = P + l.w[L];
+        g.ldw = SP_CIN[L];
+        if (split) {
+            g.Wh = reinterpret_cast<const unsigned short*>(P + l.wh[L]);
+            g.Wl = reinterpret_cast<const unsigned short*>(P + l.wl[L]);
+            g.wscale = P + l.ws[L];
+        }
+        g.bias = P + l.b[L];
+        g.C = dst;
+        g.ldc = ldc;
+        g.M = B * Hc * Wc;
+        g.N = SP_COUT[L];
+        g.K = SP_CIN[L];
+        return gemm_launch(h, g, stream);
+    };
+    // a2: encoder
+    SPRUN(conv1a_launch(h, image, P + l.w[L1A], P + l.b[L1A], s.a1a, B, H, W, stream));
+    SPRUN(conv(L1B, s.a1a, s.p1, H, W, 1));
+    SPRUN(conv(L2A, s.p1, s.a2a, H / 2, W / 2, 0));
+    SPRUN(conv(L2B, s.a2a, s.p2, H / 2, W / 2, 1));
+    SPRUN(conv(L3A, s.p2, s.a3a, H / 4, W / 4, 0));
+    SPRUN(conv(L3B, s.a3a, s.p3, H / 4, W / 4, 1));
+    SPRUN(conv(L4A, s.p3, s.a4a, Hc, Wc, 0));
+    SPRUN(conv(L4B, s.a4a, s.feat, Hc, Wc, 0));
+    // a3: detector head -> dense score map
+    SPRUN(conv(LPA, s.feat, s.head, Hc, Wc, 0));
+    const long ncell = (long)B * Hc * Wc;
+    SPRUN(lin(LPB, s.head, s.logits, 65));
     float* dense = score_map ? score_map : s.dense;
     hipLaunchKernelGGL(sp_softmax_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, s.logits, 65, dense, Hc,
                        Wc, ncell);
@@ -570,22 +602,8 @@ extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed,
                        keypoints, scores, num_keypoints, s.status);
     IMCUI_CHECK_LAUNCH(h);
     // a6: descriptor head + sampling
-    SPRUN(conv3x3_launch(h, s.feat, P + l.w[LDA], P + l.b[LDA], s.head, B, Hc, Wc, 128, 256, 1, 0, stream));
-    {
-        GemmP g;
-        g.epi = EPI_BIAS;
-        g.A = s.head;
-        g.lda = 256;
-        g.W = P + l.w[LDB];
-        g.ldw = 256;
-        g.bias = P + l.b[LDB];
-        g.C = s.ddesc;
-        g.ldc = 256;
-        g.M = (int)ncell;
-        g.N = 256;
-        g.K = 256;
-        SPRUN(gemm_launch(h, g, stream));
-    }
+    SPRUN(conv(LDA, s.feat, s.head, Hc, Wc, 0));
+    SPRUN(lin(LDB, s.head, s.ddesc, 256));
     hipLaunchKernelGGL(sp_sample_kernel, dim3(cdiv(kcap, 4), B), dim3(256), 0, stream, s.ddesc, keypoints, num_keypoints,
                        kcap, Hc, Wc, fix_sampling, descriptors);
     IMCUI_CHECK_LAUNCH(h);

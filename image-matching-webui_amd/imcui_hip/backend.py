@@ -259,6 +259,18 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
+# ------------------------------------------------------------------ arithmetic mode
+def set_precision(device: torch.device, mode: int):
+    """0 = exact f32 MFMA, 1 = 3 x f16 split MFMA (default; ~fp32 accuracy at ~5x the matrix rate)."""
+    hd = get_handle(device)
+    hd.check(hd.lib.imcui_hip_set_precision(hd.h, int(mode)), "set_precision")
+
+
+def get_precision(device: torch.device) -> int:
+    hd = get_handle(device)
+    return hd.lib.imcui_hip_get_precision(hd.h)
+
+
 # ------------------------------------------------------------------ live kernel timing
 KERNEL_CLASSES = {"attention": 0, "conv3x3": 1, "gemm": 2}
 
@@ -294,13 +306,28 @@ def conv3x3_f32(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, 
     B, H, W, Cin = x_nhwc.shape
     Cout = w_oihw.shape[0]
     wh = _as_f32_host(w_oihw)
+    x_nhwc = x_nhwc.contiguous().float()
+    bias = bias.contiguous().float().to(x_nhwc.device)
+    out = torch.empty((B, H // 2, W // 2, Cout) if pool else (B, H, W, Cout), dtype=torch.float32, device=x_nhwc.device)
+    if lib.imcui_hip_get_precision(hd.h) == 1:
+        hi = np.zeros(Cout * Cin * 9, dtype=np.uint16)
+        lo = np.zeros(Cout * Cin * 9, dtype=np.uint16)
+        sc = lib.imcui_hip_conv3x3_pack_split(wh.ctypes.data, Cout, Cin, hi.ctypes.data, lo.ctypes.data)
+        if sc == 0.0:
+            raise ImcuiHipError("conv3x3_pack_split failed")
+        dh = torch.from_numpy(hi.view(np.int16)).to(x_nhwc.device)
+        dl = torch.from_numpy(lo.view(np.int16)).to(x_nhwc.device)
+        ds = torch.tensor([sc], dtype=torch.float32, device=x_nhwc.device)
+        with torch.cuda.device(x_nhwc.device):
+            hd.check(
+                lib.imcui_hip_conv3x3_split_f32(hd.h, _ptr(x_nhwc), _ptr(dh), _ptr(dl), _ptr(ds), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, int(relu), int(pool), _stream_ptr()),
+                "conv3x3_split",
+            )
+        return out
     packed = np.zeros(Cout * Cin * 9, dtype=np.float32)
     if lib.imcui_hip_conv3x3_pack(wh.ctypes.data, Cout, Cin, packed.ctypes.data) != 0:
         raise ImcuiHipError("conv3x3_pack failed")
     wp = torch.from_numpy(packed).to(x_nhwc.device)
-    x_nhwc = x_nhwc.contiguous().float()
-    bias = bias.contiguous().float().to(x_nhwc.device)
-    out = torch.empty((B, H // 2, W // 2, Cout) if pool else (B, H, W, Cout), dtype=torch.float32, device=x_nhwc.device)
     with torch.cuda.device(x_nhwc.device):
         hd.check(
             lib.imcui_hip_conv3x3_f32(hd.h, _ptr(x_nhwc), _ptr(wp), _ptr(bias), _ptr(out), B, H, W, Cin, Cout, int(relu), int(pool), _stream_ptr()),
@@ -314,6 +341,8 @@ def attention_f32(q, k, v, cnt, cross=False):
     hd = get_handle(q.device)
     S, Hh, R, d = q.shape
     assert d == 64
+    if hd.lib.imcui_hip_get_precision(hd.h) == 1:
+        v = v.transpose(2, 3)  # the split kernel consumes V^T [S,heads,64,rows]
     o = torch.zeros((S * R, Hh * 64), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         hd.check(

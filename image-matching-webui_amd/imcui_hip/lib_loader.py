@@ -27,6 +27,10 @@ SIGNATURES = {
     "imcui_hip_destroy": (None, [C.c_void_p]),
     "imcui_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "imcui_hip_version": (C.c_int, []),
+    "imcui_hip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "imcui_hip_get_precision": (C.c_int, [C.c_void_p]),
+    "imcui_hip_conv3x3_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "imcui_hip_conv3x3_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]),
     "imcui_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "imcui_hip_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imcui_hip_superpoint_packed_floats": (C.c_size_t, []),

@@ -45,6 +45,15 @@ void imcui_hip_destroy(imcui_hip_t* h);
 const char* imcui_hip_last_error(const imcui_hip_t* h);
 int imcui_hip_version(void);
 
+/* Arithmetic mode of the matrix-core kernels (default 1):
+ *   0  exact f32: v_mfma_f32_32x32x2_f32, bitwise an fmaf chain
+ *   1  3 x f16 split: every f32 operand is split into f16 (hi, lo) and a product is evaluated as
+ *      ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with f32 accumulation (~fp32 accuracy,
+ *      ~5x the f32 matrix rate).  Attention then consumes V transposed (internal detail).
+ * For imcui_hip_attention_f32 in mode 1 the caller passes V as V^T [S][heads][64][rows]. */
+int imcui_hip_set_precision(imcui_hip_t* h, int mode);
+int imcui_hip_get_precision(const imcui_hip_t* h);
+
 /* Optional HIP-event timing of the three heavy kernel classes on the launch stream
  * (0 = attention, 1 = conv3x3, 2 = gemm): enable, run, then read (synchronises the events;
  * returns the summed kernel time in ms and the number of launches, and resets the counters). */
@@ -131,6 +140,11 @@ int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float* W, const f
 int imcui_hip_conv3x3_pack(const float* w_oihw, int Cout, int Cin, float* packed);
 int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in_nhwc, const float* packed_w, const float* bias, float* out_nhwc,
                           int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
+/* split-precision variants of the conv building block (mode 1 packing / launch) */
+float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
+                                const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,
+                                int Cout, int relu, int pool, void* stream);
 /* softmax(Q K^T) V, head_dim 64, operands head-major [S][heads][rows][64] (Q pre-scaled),
  * output token-major [S*rows][heads*64]; cnt [dev, S] valid rows; cross: keys of sequence s^1. */
 int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,

@@ -17,3 +17,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=[1, 0], ids=["split-f16x3", "exact-f32"])
+def precision(request):
+    """Run a GPU test in both arithmetic modes of the matrix-core kernels."""
+    import torch
+
+    from imcui_hip import backend
+
+    dev = torch.device("cuda:0")
+    backend.set_precision(dev, request.param)
+    yield request.param
+    backend.set_precision(dev, 1)

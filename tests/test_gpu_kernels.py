@@ -16,7 +16,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(256, 256, 256, False), (1000, 65, 256, False), (4800, 768, 256, True), (130, 130, 512, False)])
-def test_linear_f32(M, N, K, relu):
+def test_linear_f32(M, N, K, relu, precision):
     from imcui_hip import backend
 
     g = torch.Generator().manual_seed(M + N)
@@ -28,11 +28,11 @@ def test_linear_f32(M, N, K, relu):
     ref = (F.relu(ref) if relu else ref).float()
     out = backend.linear_f32(a.to(_dev()), w.to(_dev()), b.to(_dev()), relu).cpu()
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 2e-6
+    assert _rel(out, ref) < (2e-6 if precision == 0 else 4e-6)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [(2, 16, 32, 64, 64, False), (1, 24, 40, 64, 128, True), (2, 60, 80, 128, 256, False), (1, 15, 21, 32, 64, False)])
-def test_conv3x3_f32(B, H, W, Cin, Cout, pool):
+def test_conv3x3_f32(B, H, W, Cin, Cout, pool, precision):
     from imcui_hip import backend
 
     g = torch.Generator().manual_seed(H * W)
@@ -45,11 +45,11 @@ def test_conv3x3_f32(B, H, W, Cin, Cout, pool):
     ref = ref.float().permute(0, 2, 3, 1).contiguous()
     out = backend.conv3x3_f32(x.permute(0, 2, 3, 1).contiguous().to(_dev()), w, b, relu=True, pool=pool).cpu()
     assert out.shape == ref.shape
-    assert _rel(out, ref) < 2e-6
+    assert _rel(out, ref) < (2e-6 if precision == 0 else 4e-6)
 
 
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_f32(cross):
+def test_attention_f32(cross, precision):
     from imcui_hip import backend
 
     g = torch.Generator().manual_seed(5)
@@ -73,7 +73,7 @@ def test_attention_f32(cross):
         assert (got - ref).abs().max().item() < 2e-5
 
 
-def test_attention_sharp_softmax():
+def test_attention_sharp_softmax(precision):
     """Large logits: one key dominates; exercises the running-max rescale across tiles."""
     from imcui_hip import backend
 

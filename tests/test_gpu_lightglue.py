@@ -38,7 +38,7 @@ def _batch(problems):
 
 
 @pytest.mark.parametrize("dc,wc", [(-1, -1), (0.95, 0.99), (0.95, -1), (-1, 0.99)])
-def test_lightglue_ragged_batch_vs_oracle(dc, wc):
+def test_lightglue_ragged_batch_vs_oracle(dc, wc, precision):
     torch.set_num_threads(8)
     problems = [synthetic_matching_problem(20 + i, n, m, o) for i, (n, m, o) in enumerate(SIZES)]
     k0, k1, d0, d1, n0, n1 = _batch(problems)
@@ -93,7 +93,7 @@ def test_lightglue_plugin_contract_and_empty():
     assert (pred["matches0"] == -1).all() and pred["matches1"].shape == (1, 0) and pred["stop"] == 1
 
 
-def test_superpoint_lightglue_end_to_end():
+def test_superpoint_lightglue_end_to_end(precision):
     """Images in -> match table out through the batched pipeline, vs the oracle chain."""
     from imcui_hip.pipeline import SuperPointLightGluePipeline
     from imcui_hip.synth import make_pair_batch

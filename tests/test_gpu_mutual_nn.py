@@ -18,7 +18,7 @@ def _conf(z):
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "nn_*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
-def test_nn_plugin_vs_reference_golden(path):
+def test_nn_plugin_vs_reference_golden(path, precision):
     from imcui_hip.hloc.matchers.nearest_neighbor import NearestNeighbor
 
     z = np.load(path)
@@ -42,7 +42,7 @@ def test_nn_plugin_vs_reference_golden(path):
     assert np.abs(s0 - z["matching_scores0"]).max() < 1e-5 or z["matching_scores0"].size == 0
 
 
-def test_nn_large_vs_oracle():
+def test_nn_large_vs_oracle(precision):
     from imcui_hip import backend
     from oracle.mutual_nn import mutual_nn
 

@@ -33,7 +33,7 @@ def _model(conf):
         (120, 200, dict(nms_radius=2, max_keypoints=300, keypoint_threshold=0.02, remove_borders=6, fix_sampling=True)),
     ],
 )
-def test_superpoint_vs_oracle(h, w, conf):
+def test_superpoint_vs_oracle(h, w, conf, precision):
     torch.set_num_threads(8)
     img0, img1, _ = make_pair(11, h, w, n_blobs=max(200, h * w // 150))
     images = torch.cat([img0, img1], 0)

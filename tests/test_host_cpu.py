@@ -38,9 +38,8 @@ def test_superpoint_packing_is_a_permutation(lib):
 
     sd = superpoint_state_dict(1)
     packed = backend.pack_superpoint(sd).numpy()
-    total = sum(v.numel() for v in sd.values())
-    assert np.count_nonzero(packed) <= total
-    assert np.isclose(np.abs(packed).sum(dtype=np.float64), sum(v.abs().double().sum().item() for v in sd.values()), rtol=1e-9)
+    n32 = 1300928  # f32 region (weights + biases, 64-float aligned); f16 split planes follow
+    assert np.isclose(np.abs(packed[:n32]).sum(dtype=np.float64), sum(v.abs().double().sum().item() for v in sd.values()), rtol=1e-9)
     # spot-check the conv3x3 layout: [ch][tap][cq][cout][4]
     w = sd["conv1b.weight"].numpy()
     off = 9 * 64 + 64  # conv1a weights (576) + bias (64), both already 64-aligned
@@ -55,7 +54,8 @@ def test_lightglue_packing_deinterleaves_qkv(lib):
     names = backend.lightglue_tensor_names()
     assert len(names) == 251 and names[0] == "posenc.Wr.weight" and set(names) <= set(lsd)
     packed = backend.pack_lightglue(lsd).numpy()
-    assert np.isclose(np.abs(packed).sum(dtype=np.float64), sum(lsd[n].abs().double().sum().item() for n in names), rtol=1e-9)
+    n32 = 11851712  # f32 region; f16 split planes follow
+    assert np.isclose(np.abs(packed[:n32]).sum(dtype=np.float64), sum(lsd[n].abs().double().sum().item() for n in names), rtol=1e-9)
     # Wqkv rows of layer 0: packed row t*256 + h*64 + d  <-  upstream row h*192 + d*3 + t
     w = lsd["transformers.0.self_attn.Wqkv.weight"].numpy()
     base = 64
@@ -67,6 +67,21 @@ def test_lightglue_packing_deinterleaves_qkv(lib):
         m = re.match(r"transformers\.(\d+)\.(self_attn|cross_attn)\.(.*)", k)
         old[f"{m.group(2)}.{m.group(1)}.{m.group(3)}" if m else k] = v
     assert np.array_equal(backend.pack_lightglue(old).numpy(), packed)
+
+
+def test_host_weight_split_is_accurate(lib):
+    """w * 2^e == hi + lo to ~2^-22 relative, hi/lo valid f16, scale a power of two."""
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(64, 32, 3, 3, generator=g) * 0.07).numpy()
+    hi = np.zeros(w.size, dtype=np.uint16)
+    lo = np.zeros(w.size, dtype=np.uint16)
+    inv = lib.imcui_hip_conv3x3_pack_split(w.ctypes.data, 64, 32, hi.ctypes.data, lo.ctypes.data)
+    assert inv > 0 and np.log2(inv) == np.round(np.log2(inv))
+    rec = (hi.view(np.float16).astype(np.float64) + lo.view(np.float16).astype(np.float64)) * inv
+    # layout [(ch*9+tap)*4+oc][cout][8]  <-  w[co][oc*8+j][tap]
+    ref = w.reshape(64, 1, 4, 8, 9).transpose(1, 4, 2, 0, 3).reshape(-1).astype(np.float64)
+    assert np.abs(rec - ref).max() <= np.abs(ref).max() * 2.0**-21
+    assert np.isfinite(hi.view(np.float16)).all() and np.isfinite(lo.view(np.float16)).all()
 
 
 def test_plugins_follow_the_reference_seam(lib):
