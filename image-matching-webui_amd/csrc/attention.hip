@@ -23,8 +23,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
-    const int seq = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, so the nqb query blocks of one
+    // (sequence, head) are given ids that share b % 8 and read their K/V through ONE L2.
+    const int nqb = p.rows_per_seq >> 7;
+    const int bid = blockIdx.x;
+    const int grp = (bid / (8 * nqb)) * 8 + (bid & 7);
+    const int seq = grp / p.heads, head = grp - seq * p.heads;
+    const int q0 = ((bid >> 3) % nqb) * 128;
     const int nq = p.cnt[seq];
     if (q0 >= nq) return;
     if (p.active && p.active[seq >> 1] == 0) return;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     // staging: 64 keys x 16 float4 per operand = 1024 float4 -> 4 per thread
     const int s_dq = tid & 15, s_key = tid >> 4;  // key + 16*it
     float4 rk[4], rv[4];
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int key = k0 + s_key + 16 * it;
@@ -105,16 +110,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         }
         // ---- online soft-max for query `lo` (keys of this lane: 2 x 16 registers)
+        if (k0 + KT > nk) {  // only the last tile can hold keys past the sequence end
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + 32 * f + frag_row(r, hi) >= nk) s[f][r] = -INFINITY;
+        }
         float m_t = -INFINITY;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + 32 * f + frag_row(r, hi);
-                const float v = (key < nk) ? s[f][r] : -INFINITY;
-                s[f][r] = v;
-                m_t = fmaxf(m_t, v);
-            }
+            for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
         const float m_new = fmaxf(m_run, m_t);  // finite: every tile holds >= 1 valid key
         const float alpha = expf(m_run - m_new);
@@ -129,10 +136,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
             }
         l_run = l_run * alpha + l_t;
         m_run = m_new;
+        if (__ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+        }
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -159,11 +168,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
         __builtin_amdgcn_wave_barrier();
         // read back: lane covers d = lo for query rows q = hi, hi+2, ...
+        // read back: 8 lanes cover the 32 dims of one query -> one 16-byte store per lane
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            const int q = 2 * qq + hi;
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = 8 * qq + (lane >> 3), d4 = (lane & 7) * 4;
             const int row = q0 + wid * 32 + q;
-            if (row < nq) p.O[((size_t)seq * R + row) * H64 + head * 64 + 32 * f + lo] = Os[q * 33 + lo];
+            const float4 v = make_float4(Os[q * 33 + d4], Os[q * 33 + d4 + 1], Os[q * 33 + d4 + 2], Os[q * 33 + d4 + 3]);
+            if (row < nq) *reinterpret_cast<float4*>(p.O + ((size_t)seq * R + row) * H64 + head * 64 + 32 * f + d4) = v;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -181,7 +192,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 // {keys 0-3, 8-11} and {keys 4-7, 12-15} (= what the hi = 0 / hi = 1 half-waves consume in one
 // MFMA step), + one 16-byte pad per row -> a fragment is ONE conflict-free ds_read_b128.
 #define VSTR 9  // V^T row stride in 16-byte units
-#define P_SCALE 16384.0f
+#define P_SHIFT 14.0f
+#define LOG2E 1.44269504088896340736f
 
 __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
@@ -192,8 +204,13 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
-    const int seq = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, so the nqb query blocks of one
+    // (sequence, head) are given ids that share b % 8 and read their K/V through ONE L2.
+    const int nqb = p.rows_per_seq >> 7;
+    const int bid = blockIdx.x;
+    const int grp = (bid / (8 * nqb)) * 8 + (bid & 7);
+    const int seq = grp / p.heads, head = grp - seq * p.heads;
+    const int q0 = ((bid >> 3) % nqb) * 128;
     const int nq = p.cnt[seq];
     if (q0 >= nq) return;
     if (p.active && p.active[seq >> 1] == 0) return;
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 
     // staging: K 64 keys x 8 octets (2 items / thread), V^T 64 d x 16 key-quads (4 items / thread)
     float4 rk[2][2], rv[4];
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = tid + 256 * it;
@@ -297,34 +314,41 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
             }
         }
         // ---- online soft-max for query `lo`
+        if (k0 + KT > nk) {  // only the last tile can hold keys past the sequence end
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + 32 * f + frag_row(r, hi) >= nk) s[f][r] = -INFINITY;
+        }
         float m_t = -INFINITY;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + 32 * f + frag_row(r, hi);
-                const float v = (key < nk) ? s[f][r] : -INFINITY;
-                s[f][r] = v;
-                m_t = fmaxf(m_t, v);
-            }
+            for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
         const float m_new = fmaxf(m_run, m_t);
-        const float alpha = expf(m_run - m_new);
+        // p * 2^14 = exp2(s*log2e - m*log2e + 14): one fma + one v_exp_f32 per element; the 2^14
+        // (which keeps the f16 low parts of small probabilities normal) cancels in O / l.
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float bias = P_SHIFT - m_new * LOG2E;
         float l_t = 0.0f;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = expf(s[f][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[f][r], LOG2E, bias));
                 l_t += pv;
-                s[f][r] = pv * P_SCALE;
+                s[f][r] = pv;
             }
         l_run = l_run * alpha + l_t;
         m_run = m_new;
+        if (__ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+        }
         // ---- O^T += V^T . P^T : step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -349,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 
     // ---- normalise and write (transpose through LDS so each query row is stored contiguously)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (ntile > 0) ? (1.0f / P_SCALE) / l_tot : 0.0f;
+    const float inv = (ntile > 0) ? 1.0f / l_tot : 0.0f;  // l carries the same 2^14 as O
     __syncthreads();
     float* Os = reinterpret_cast<float*>(smem4) + wid * (32 * 33);
     const int H64 = p.heads * 64;
@@ -359,11 +383,13 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) Os[lo * 33 + frag_row(r, hi)] = o[f][r] * inv;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        // read back: 8 lanes cover the 32 dims of one query -> one 16-byte store per lane
 #pragma unroll
-        for (int qq = 0; qq < 16; ++qq) {
-            const int q = 2 * qq + hi;
+        for (int qq = 0; qq < 4; ++qq) {
+            const int q = 8 * qq + (lane >> 3), d4 = (lane & 7) * 4;
             const int row = q0 + wid * 32 + q;
-            if (row < nq) p.O[((size_t)seq * R + row) * H64 + head * 64 + 32 * f + lo] = Os[q * 33 + lo];
+            const float4 v = make_float4(Os[q * 33 + d4], Os[q * 33 + d4 + 1], Os[q * 33 + d4 + 2], Os[q * 33 + d4 + 3]);
+            if (row < nq) *reinterpret_cast<float4*>(p.O + ((size_t)seq * R + row) * H64 + head * 64 + 32 * f + d4) = v;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -373,7 +399,8 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (p.rows_per_seq % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.nseq <= 0) return IMCUI_OK;
-    dim3 grid(p.rows_per_seq / 128, p.heads, p.nseq);
+    if ((p.heads * p.nseq) % 8 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: heads*nseq=%d must be a multiple of 8", p.heads * p.nseq);
+    dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
     if (h->precision == 1)
         hipLaunchKernelGGL(attn_split_kernel, grid, dim3(256), 0, stream, p);

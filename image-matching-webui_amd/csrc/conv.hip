@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         }
         // ---- weight slab prefetch for tap 0: 8 cq x 64 cout float4 = 512 -> 2 per thread
         float4 rw0, rw1;
-        auto wload = [&](int tap) {
+        auto wload = [&](int tap) __attribute__((always_inline)) {
             rw0 = wp4[((size_t)(ch * 9 + tap) * 8 + (tid >> 6)) * Cout + cout0 + (tid & 63)];
             rw1 = wp4[((size_t)(ch * 9 + tap) * 8 + 4 + (tid >> 6)) * Cout + cout0 + (tid & 63)];
         };
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
         }
         // weight slab of a tap: 4 octets x 64 cout per plane = 256 x 16 B -> one per thread per plane
         uint4 rwh, rwl;
-        auto wload = [&](int tap) {
+        auto wload = [&](int tap) __attribute__((always_inline)) {
             const size_t o = ((size_t)(ch * 9 + tap) * 4 + (tid >> 6)) * Cout + cout0 + (tid & 63);
             rwh = wh4[o];
             rwl = wl4[o];

@@ -49,55 +49,105 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c) {
     return true;
 }
 
+// Epilogue.  The products are issued with the WEIGHT fragment as the MFMA A operand and the
+// activation fragment as B, i.e. the accumulators hold C^T: column (lane & 31) = token row,
+// fragment row = output feature.  A lane therefore owns 4 CONSECUTIVE features of one token per
+// register quad (r & 3), which makes every store a 16-byte store (a 64-dword-store epilogue is
+// store-issue bound and was 10x the matrix time), puts RoPE pairs in one lane, and lets V^T be
+// written with lanes running along the token axis.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
                                               int wn, int lo, int hi) {
     float* C = p.C ? p.C + (size_t)c.z * p.c_bs : nullptr;
+    const bool vec_ok = ((p.ldc & 3) == 0);
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = c.col0 + wn * 64 + n * 32 + lo;
-        const bool colok = col < c.N;
-        const float bv = (c.bias != nullptr && colok) ? c.bias[col] : 0.0f;
+    for (int m = 0; m < 2; ++m) {
+        const int row = c.row0 + wm * 64 + m * 32 + lo;  // token
+        const bool rowok = row < c.M;
+        const int i = row - c.seq * p.rows_per_seq;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int n = 0; n < 2; ++n) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = c.row0 + wm * 64 + m * 32 + frag_row(r, hi);
-                const bool ok = colok && row < c.M;
-                float v = acc[m][n][r] * wsc + bv;
-                if (EPI == EPI_BIAS) {
-                    if (ok) C[(size_t)row * p.ldc + col] = v * p.alpha;
-                } else if (EPI == EPI_RELU) {
-                    if (ok) C[(size_t)row * p.ldc + col] = fmaxf(v, 0.0f);
-                } else if (EPI == EPI_RESID) {
-                    if (ok) C[(size_t)row * p.ldc + col] += v;
-                } else if (EPI == EPI_QKV || EPI == EPI_CROSS) {
-                    // col = t*256 + head*64 + d (weights were de-interleaved at pack time)
-                    const int t = col >> 8, hd = (col >> 6) & 3, d = col & 63;
-                    const int i = row - c.seq * p.rows_per_seq;
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = c.col0 + wn * 64 + n * 32 + 8 * q + 4 * hi;  // first of 4 features
+                if (!rowok || f0 >= c.N) continue;
+                float v[4] = {acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                              acc[m][n][4 * q + 3] * wsc};
+                const bool full = (f0 + 3 < c.N);
+                if (c.bias != nullptr) {
+                    if (full) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+                        v[0] += b4.x;
+                        v[1] += b4.y;
+                        v[2] += b4.z;
+                        v[3] += b4.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < c.N) v[j] += c.bias[f0 + j];
+                    }
+                }
+                if (EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_RESID) {
+                    float* dst = C + (size_t)row * p.ldc + f0;
+                    if (EPI == EPI_BIAS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                    } else if (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    }
+                    if (full && vec_ok) {
+                        if (EPI == EPI_RESID) {
+                            const float4 o4 = *reinterpret_cast<const float4*>(dst);
+                            v[0] += o4.x;
+                            v[1] += o4.y;
+                            v[2] += o4.z;
+                            v[3] += o4.w;
+                        }
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < c.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
+                    }
+                } else {
+                    // f0 = t*256 + head*64 + d0 (weights were de-interleaved at pack time); N % 4 == 0
+                    const int t = f0 >> 8, hd = (f0 >> 6) & 3, d0 = f0 & 63;
                     float* dst;
-                    bool vt = false;
+                    bool vt;
                     if (EPI == EPI_QKV) {
-                        const float partner = __shfl_xor(v, 1, 64);  // (d ^ 1) of the same row
                         if (t < 2) {
-                            const float cs = p.rope_cos[(size_t)row * 32 + (d >> 1)];
-                            const float sn = p.rope_sin[(size_t)row * 32 + (d >> 1)];
                             // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
-                            v = v * cs + ((d & 1) ? partner : -partner) * sn;
-                            if (t == 0) v *= p.alpha;
+                            const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
+                            const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                            const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                            v[0] = a0 * cs.x + (-a1) * sn.x;
+                            v[1] = a1 * cs.x + a0 * sn.x;
+                            v[2] = a2 * cs.y + (-a3) * sn.y;
+                            v[3] = a3 * cs.y + a2 * sn.y;
+                            if (t == 0) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                            }
                         }
                         dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
                         vt = (t == 2);
                     } else {
-                        if (t == 0) v *= p.alpha;
+                        if (t == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                        }
                         dst = (t == 0) ? p.Q : p.V;
                         vt = (t == 1);
                     }
-                    if (ok) {
-                        if (vt && p.v_transposed)
-                            dst[(((size_t)c.seq * p.heads + hd) * 64 + d) * p.rows_per_seq + i] = v;
-                        else
-                            dst[(((size_t)c.seq * p.heads + hd) * p.rows_per_seq + i) * 64 + d] = v;
+                    if (vt && p.v_transposed) {
+                        // V^T [seq][head][64][rows]: lanes run along the token axis -> coalesced
+                        float* o = dst + (((size_t)c.seq * p.heads + hd) * 64 + d0) * p.rows_per_seq + i;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[(size_t)j * p.rows_per_seq] = v[j];
+                    } else {
+                        *reinterpret_cast<float4*>(dst + (((size_t)c.seq * p.heads + hd) * p.rows_per_seq + i) * 64 + d0) =
+                            make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
@@ -132,33 +182,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     // staging: 128 rows x 8 k-quads per operand = 1024 float4, 4 per thread
     const int s_kq = tid & 7;
     const int s_r = tid >> 3;  // 0..31, +32 per iteration
-    float4 ra[4], rb[4];
+    // named registers, not arrays: a register array that is only copied global -> LDS is kept in
+    // scratch by the compiler (it is turned into a private-memory copy)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const int nkt = p.K / BK32;
-
-    auto load_tile = [&](int kt) {
+#define FOR4(X) X(0) X(1) X(2) X(3)
+#define LD32(it)                                                                     \
+    {                                                                                \
+        const int r = s_r + 32 * it;                                                 \
+        const int ar = min(c.row0 + r, c.M - 1);                                     \
+        const int br = min(c.col0 + r, c.N - 1);                                     \
+        const float* src = (p.A2 != nullptr && k >= p.K1) ? p.A2 + (size_t)ar * p.lda2 + (k - p.K1) \
+                                                          : A + (size_t)ar * p.lda + k; \
+        ra##it = *reinterpret_cast<const float4*>(src);                              \
+        rb##it = *reinterpret_cast<const float4*>(W + (size_t)br * p.ldw + k);       \
+    }
+#define ST32(it)                                    \
+    As[s_kq * LDS_ROWS + s_r + 32 * it] = ra##it;   \
+    Bs[s_kq * LDS_ROWS + s_r + 32 * it] = rb##it;
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         const int k = kt * BK32 + s_kq * 4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = s_r + 32 * it;
-            const int ar = min(c.row0 + r, c.M - 1);
-            const int br = min(c.col0 + r, c.N - 1);
-            const float* src;
-            if (p.A2 != nullptr && k >= p.K1)
-                src = p.A2 + (size_t)ar * p.lda2 + (k - p.K1);
-            else
-                src = A + (size_t)ar * p.lda + k;
-            ra[it] = *reinterpret_cast<const float4*>(src);
-            rb[it] = *reinterpret_cast<const float4*>(W + (size_t)br * p.ldw + k);
-        }
+        FOR4(LD32)
     };
 
     load_tile(0);
     for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            As[s_kq * LDS_ROWS + s_r + 32 * it] = ra[it];
-            Bs[s_kq * LDS_ROWS + s_r + 32 * it] = rb[it];
-        }
+        FOR4(ST32)
         __syncthreads();
         if (kt + 1 < nkt) load_tile(kt + 1);
 #pragma unroll
@@ -173,10 +222,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = mfma32(a[m].x, b[n].x, acc[m][n]);
-                    acc[m][n] = mfma32(a[m].y, b[n].y, acc[m][n]);
-                    acc[m][n] = mfma32(a[m].z, b[n].z, acc[m][n]);
-                    acc[m][n] = mfma32(a[m].w, b[n].w, acc[m][n]);
+                    // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
+                    acc[m][n] = mfma32(b[n].x, a[m].x, acc[m][n]);
+                    acc[m][n] = mfma32(b[n].y, a[m].y, acc[m][n]);
+                    acc[m][n] = mfma32(b[n].z, a[m].z, acc[m][n]);
+                    acc[m][n] = mfma32(b[n].w, a[m].w, acc[m][n]);
                 }
         }
         __syncthreads();
@@ -219,54 +269,53 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
     // staging: 128 rows x 8 k-octets per operand = 1024 items of 8 values, 4 per thread
     const int s_ko = tid & 7;
     const int s_r = tid >> 3;
-    float4 ra[4][2];
-    float4 rbf[PRESPLIT ? 1 : 4][2];
-    uint4 rbh[PRESPLIT ? 4 : 1], rbl[PRESPLIT ? 4 : 1];
+    // A: two float4 per item (split while staged); B: hi/lo planes (pre-split weights, pure copy)
+    // or two float4 (activations, split while staged) held as raw bits in the same registers
+    float4 ra0a, ra0b, ra1a, ra1b, ra2a, ra2b, ra3a, ra3b;
+    uint4 rb0a, rb0b, rb1a, rb1b, rb2a, rb2b, rb3a, rb3b;
     const int nkt = p.K / BK64;
-
-    auto load_tile = [&](int kt) {
+#define LD64(it)                                                                     \
+    {                                                                                \
+        const int r = s_r + 32 * it;                                                 \
+        const int ar = min(c.row0 + r, c.M - 1);                                     \
+        const int br = min(c.col0 + r, c.N - 1);                                     \
+        const float* src = (p.A2 != nullptr && k >= p.K1) ? p.A2 + (size_t)ar * p.lda2 + (k - p.K1) \
+                                                          : A + (size_t)ar * p.lda + k; \
+        ra##it##a = *reinterpret_cast<const float4*>(src);                           \
+        ra##it##b = *reinterpret_cast<const float4*>(src + 4);                       \
+        if (PRESPLIT) {                                                              \
+            rb##it##a = *reinterpret_cast<const uint4*>(Wh + (size_t)br * p.ldw + k); \
+            rb##it##b = *reinterpret_cast<const uint4*>(Wl + (size_t)br * p.ldw + k); \
+        } else {                                                                     \
+            const float* ws = W + (size_t)br * p.ldw + k;                            \
+            rb##it##a = *reinterpret_cast<const uint4*>(ws);                         \
+            rb##it##b = *reinterpret_cast<const uint4*>(ws + 4);                     \
+        }                                                                            \
+    }
+#define ST64(it)                                                                     \
+    {                                                                                \
+        const int o = s_ko * LDS_ROWS + s_r + 32 * it;                               \
+        uint4 h, l;                                                                  \
+        split8(ra##it##a, ra##it##b, h, l);                                          \
+        Ah[o] = h;                                                                   \
+        Al[o] = l;                                                                   \
+        if (PRESPLIT) {                                                              \
+            Bh[o] = rb##it##a;                                                       \
+            Bl[o] = rb##it##b;                                                       \
+        } else {                                                                     \
+            split8(__builtin_bit_cast(float4, rb##it##a), __builtin_bit_cast(float4, rb##it##b), h, l); \
+            Bh[o] = h;                                                               \
+            Bl[o] = l;                                                               \
+        }                                                                            \
+    }
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         const int k = kt * BK64 + s_ko * 8;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = s_r + 32 * it;
-            const int ar = min(c.row0 + r, c.M - 1);
-            const int br = min(c.col0 + r, c.N - 1);
-            const float* src;
-            if (p.A2 != nullptr && k >= p.K1)
-                src = p.A2 + (size_t)ar * p.lda2 + (k - p.K1);
-            else
-                src = A + (size_t)ar * p.lda + k;
-            ra[it][0] = *reinterpret_cast<const float4*>(src);
-            ra[it][1] = *reinterpret_cast<const float4*>(src + 4);
-            if (PRESPLIT) {
-                rbh[it] = *reinterpret_cast<const uint4*>(Wh + (size_t)br * p.ldw + k);
-                rbl[it] = *reinterpret_cast<const uint4*>(Wl + (size_t)br * p.ldw + k);
-            } else {
-                const float* ws = W + (size_t)br * p.ldw + k;
-                rbf[it][0] = *reinterpret_cast<const float4*>(ws);
-                rbf[it][1] = *reinterpret_cast<const float4*>(ws + 4);
-            }
-        }
+        FOR4(LD64)
     };
 
     load_tile(0);
     for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int o = s_ko * LDS_ROWS + s_r + 32 * it;
-            uint4 h, l;
-            split8(ra[it][0], ra[it][1], h, l);
-            Ah[o] = h;
-            Al[o] = l;
-            if (PRESPLIT) {
-                Bh[o] = rbh[it];
-                Bl[o] = rbl[it];
-            } else {
-                split8(rbf[it][0], rbf[it][1], h, l);
-                Bh[o] = h;
-                Bl[o] = l;
-            }
-        }
+        FOR4(ST64)
         __syncthreads();
         if (kt + 1 < nkt) load_tile(kt + 1);
 #pragma unroll
@@ -287,9 +336,10 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    acc[m][n] = mfma16(al[m], bh[n], acc[m][n]);
-                    acc[m][n] = mfma16(ah[m], bl[n], acc[m][n]);
-                    acc[m][n] = mfma16(ah[m], bh[n], acc[m][n]);
+                    // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
+                    acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                    acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                    acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
                 }
         }
         __syncthreads();

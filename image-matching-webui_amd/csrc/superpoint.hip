@@ -94,85 +94,101 @@ __global__ __launch_bounds__(256) void sp_softmax_kernel(const float* __restrict
 // All five (2r+1)^2 max-pools of upstream `simple_nms` in one pass over an LDS tile with a
 // 5r halo; each pool is separable (row max then column max), and max is exact in any order, so
 // the result is bitwise the reference's.  Out-of-image = -inf (scores) / 0 (masks), i.e.
-// max_pool2d's implicit padding.
+// max_pool2d's implicit padding.  Every thread produces runs of 8 outputs from a register window
+// (8 + 2r LDS reads instead of 8 * (2r+1)); the LDS row stride is odd so both the row pass
+// (lanes along rows) and the column pass (lanes along columns) are bank-conflict free.
 #define NMS_T 32
+template <int R>
 __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
-                                                     int W, int r) {
+                                                     int W) {
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
-    const int halo = 5 * r;
-    const int Rg = NMS_T + 2 * halo;
-    const int n = Rg * Rg;
-    float* S = reinterpret_cast<float*>(nms_smem);
-    float* T = S + n;
-    float* SS = T + n;
-    unsigned char* M = reinterpret_cast<unsigned char*>(SS + n);
-    unsigned char* U = M + n;
+    constexpr int halo = 5 * R;
+    constexpr int Rg = NMS_T + 2 * halo;
+    constexpr int RS = Rg | 1;  // odd row stride
+    constexpr int n = Rg * RS;
+    constexpr int NCH = (Rg + 7) / 8;  // chunks of 8 along one axis
+    float* S = reinterpret_cast<float*>(nms_smem);  // scores (-inf outside the image)
+    float* T = S + n;                               // row-pass temporary
+    float* X = T + n;                               // pool input: mask (0/1) or suppressed scores
+    float* M = X + n;                               // max_mask (0/1)
+    float* U = M + n;                               // supp_mask (0/1)
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * NMS_T - halo, x0 = blockIdx.x * NMS_T - halo;
     const float* img = in + (size_t)b * H * W;
 
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < Rg * Rg; i += 256) {
         const int u = i / Rg, v = i - u * Rg;
         const int y = y0 + u, x = x0 + v;
-        S[i] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : -INFINITY;
+        S[u * RS + v] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : -INFINITY;
     }
     __syncthreads();
 
-    auto inimg = [&](int i) {
-        const int u = i / Rg, v = i - u * Rg;
+    // T = max over [v-R, v+R] of src (row pass).  work item = (row u, chunk c); lanes run along u.
+    auto rowpass = [&](const float* src) __attribute__((always_inline)) {
+        for (int it = tid; it < Rg * NCH; it += 256) {
+            const int u = it % Rg, v0 = (it / Rg) * 8;
+            float w[8 + 2 * R];
+#pragma unroll
+            for (int j = 0; j < 8 + 2 * R; ++j) {
+                const int v = v0 - R + j;
+                w[j] = (v >= 0 && v < Rg) ? src[u * RS + v] : -INFINITY;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float m = w[j];
+#pragma unroll
+                for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
+                if (v0 + j < Rg) T[u * RS + v0 + j] = m;
+            }
+        }
+    };
+    // column pass over T; calls f(u, v, pooled value).  work item = (chunk c, column v); lanes along v.
+    auto colpass = [&](auto&& f) __attribute__((always_inline)) {
+        for (int it = tid; it < Rg * NCH; it += 256) {
+            const int v = it % Rg, u0 = (it / Rg) * 8;
+            float w[8 + 2 * R];
+#pragma unroll
+            for (int j = 0; j < 8 + 2 * R; ++j) {
+                const int u = u0 - R + j;
+                w[j] = (u >= 0 && u < Rg) ? T[u * RS + v] : -INFINITY;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float m = w[j];
+#pragma unroll
+                for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
+                if (u0 + j < Rg) f(u0 + j, v, m);
+            }
+        }
+    };
+    auto inimg = [&](int u, int v) __attribute__((always_inline)) {
         const int y = y0 + u, x = x0 + v;
         return y >= 0 && y < H && x >= 0 && x < W;
     };
-    // T = row-max of src (float array) / of a byte mask
-    auto rowmax_f = [&](const float* src) {
-        for (int i = tid; i < n; i += 256) {
-            const int u = i / Rg, v = i - u * Rg;
-            const int lo = max(v - r, 0), hi = min(v + r, Rg - 1);
-            float m = -INFINITY;
-            for (int c = lo; c <= hi; ++c) m = fmaxf(m, src[u * Rg + c]);
-            T[i] = m;
-        }
-    };
-    auto rowmax_b = [&](const unsigned char* src) {
-        for (int i = tid; i < n; i += 256) {
-            const int u = i / Rg, v = i - u * Rg;
-            const int lo = max(v - r, 0), hi = min(v + r, Rg - 1);
-            unsigned char m = 0;
-            for (int c = lo; c <= hi; ++c) m |= src[u * Rg + c];
-            T[i] = (float)m;
-        }
-    };
-    auto colmax = [&](int i) {
-        const int u = i / Rg, v = i - u * Rg;
-        const int lo = max(u - r, 0), hi = min(u + r, Rg - 1);
-        float m = -INFINITY;
-        for (int c = lo; c <= hi; ++c) m = fmaxf(m, T[c * Rg + v]);
-        return m;
-    };
 
     // max_mask = scores == max_pool(scores)
-    rowmax_f(S);
+    rowpass(S);
     __syncthreads();
-    for (int i = tid; i < n; i += 256) M[i] = (inimg(i) && S[i] == colmax(i)) ? 1 : 0;
+    colpass([&](int u, int v, float pm) { M[u * RS + v] = (inimg(u, v) && S[u * RS + v] == pm) ? 1.0f : 0.0f; });
     __syncthreads();
-    for (int it = 0; it < 2; ++it) {
+#pragma unroll 1
+    for (int iter = 0; iter < 2; ++iter) {
         // supp_mask = max_pool(max_mask) > 0 ; supp_scores = where(supp_mask, 0, scores)
-        rowmax_b(M);
+        rowpass(M);
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const bool supp = colmax(i) > 0.0f;
-            U[i] = supp ? 1 : 0;
-            SS[i] = inimg(i) ? (supp ? 0.0f : S[i]) : -INFINITY;
-        }
+        colpass([&](int u, int v, float pm) {
+            const bool supp = pm > 0.0f;
+            U[u * RS + v] = supp ? 1.0f : 0.0f;
+            X[u * RS + v] = inimg(u, v) ? (supp ? 0.0f : S[u * RS + v]) : -INFINITY;
+        });
         __syncthreads();
         // new_max_mask = supp_scores == max_pool(supp_scores) ; max_mask |= new_max_mask & ~supp_mask
-        rowmax_f(SS);
+        rowpass(X);
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const bool nm = inimg(i) && (SS[i] == colmax(i));
-            if (nm && !U[i]) M[i] = 1;
-        }
+        colpass([&](int u, int v, float pm) {
+            if (inimg(u, v) && X[u * RS + v] == pm && U[u * RS + v] == 0.0f) M[u * RS + v] = 1.0f;
+        });
         __syncthreads();
     }
     float* dst = out + (size_t)b * H * W;
@@ -180,19 +196,30 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
         const int ty = i / NMS_T, tx = i - ty * NMS_T;
         const int y = blockIdx.y * NMS_T + ty, x = blockIdx.x * NMS_T + tx;
         if (y < H && x < W) {
-            const int j = (ty + halo) * Rg + tx + halo;
-            dst[(size_t)y * W + x] = M[j] ? S[j] : 0.0f;
+            const int j = (ty + halo) * RS + tx + halo;
+            dst[(size_t)y * W + x] = (M[j] != 0.0f) ? S[j] : 0.0f;
         }
     }
 }
 
-static int nms_launch(imcui_hip_s* h, const float* in, float* out, int B, int H, int W, int r, hipStream_t stream) {
-    if (r < 0 || r > 4) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "nms_radius=%d not supported (0..4)", r);
-    const int Rg = NMS_T + 10 * r;
-    const size_t smem = (size_t)Rg * Rg * (3 * sizeof(float) + 2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(sp_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+template <int R>
+static void nms_launch_r(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
+    constexpr int Rg = NMS_T + 10 * R;
+    constexpr size_t smem = (size_t)Rg * (Rg | 1) * 5 * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_nms_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     dim3 grid(cdiv(W, NMS_T), cdiv(H, NMS_T), B);
-    hipLaunchKernelGGL(sp_nms_kernel, grid, dim3(256), smem, stream, in, out, H, W, r);
+    hipLaunchKernelGGL(sp_nms_kernel<R>, grid, dim3(256), smem, stream, in, out, H, W);
+}
+
+static int nms_launch(imcui_hip_s* h, const float* in, float* out, int B, int H, int W, int r, hipStream_t stream) {
+    switch (r) {
+        case 0: nms_launch_r<0>(in, out, B, H, W, stream); break;
+        case 1: nms_launch_r<1>(in, out, B, H, W, stream); break;
+        case 2: nms_launch_r<2>(in, out, B, H, W, stream); break;
+        case 3: nms_launch_r<3>(in, out, B, H, W, stream); break;
+        case 4: nms_launch_r<4>(in, out, B, H, W, stream); break;
+        default: return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "nms_radius=%d not supported (0..4)", r);
+    }
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }
