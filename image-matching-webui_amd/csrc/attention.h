@@ -6,7 +6,10 @@ struct AttnP {
     // head-major operands: [seq][head][rows_per_seq][64]; Q is pre-scaled (and RoPE'd)
     const float* Q = nullptr;
     const float* K = nullptr;
-    const float* V = nullptr;  // precision 0: [seq][head][rows][64]; precision 1: V^T [seq][head][64][rows]
+    // precision 0: Q, K, V f32 [seq][head][rows][64].
+    // precision 1: each buffer holds two f16 planes (hi, then lo at +nseq*heads*rows*64 halves) of
+    //              Q / K [seq][head][rows][64] and of V^T [seq][head][64][rows]  (see gemm.hip split_out)
+    const float* V = nullptr;
     float* O = nullptr;         // token-major context [seq * rows_per_seq + i][heads * 64]
     const int* cnt = nullptr;   // valid rows per sequence
     const int* active = nullptr;  // per pair (seq >> 1), may be null

@@ -9,6 +9,8 @@
 // touch only that lane (plus one cross-half exchange), and the S^T accumulator registers are
 // already the B operand of the second product (its k index = key = the register's row).
 // K/V tiles of 64 keys are prefetched through registers while the previous tile is multiplied.
+#include <type_traits>
+
 #include "attention.h"
 
 #define KT 64        // keys per tile
@@ -195,6 +197,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #define P_SHIFT 14.0f
 #define LOG2E 1.44269504088896340736f
 
+// Operands arrive PRE-SPLIT from the projection epilogue (gemm.hip, split_out): each of Q, K,
+// V^T is two f16 planes (hi then lo) in the buffer that holds the f32 tensor in exact mode, so a
+// K/V element is split once instead of once per query block and staging is a pure copy.
 __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
@@ -217,21 +222,21 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
     const int kseq = p.cross ? (seq ^ 1) : seq;
     const int nk = p.cnt[kseq];
     const int R = p.rows_per_seq;
+    const size_t plane = (size_t)p.nseq * p.heads * R * 64;  // halves per plane
 
-    const float* Qb = p.Q + ((size_t)seq * p.heads + head) * R * 64;
-    const float* Kb = p.K + ((size_t)kseq * p.heads + head) * R * 64;
-    const float* Vb = p.V + ((size_t)kseq * p.heads + head) * 64 * R;  // V^T [64][R]
+    const unsigned short* Qh = reinterpret_cast<const unsigned short*>(p.Q) + ((size_t)seq * p.heads + head) * R * 64;
+    const unsigned short* Kg = reinterpret_cast<const unsigned short*>(p.K) + ((size_t)kseq * p.heads + head) * R * 64;
+    const unsigned short* Vg = reinterpret_cast<const unsigned short*>(p.V) + ((size_t)kseq * p.heads + head) * 64 * R;
 
-    // Q fragment of this lane: query q0 + wid*32 + lo, dims 16s + 8hi .. +7, split once
+    // Q fragment of this lane: query q0 + wid*32 + lo, dims 16s + 8hi .. +7
     uint4 qh[4], ql[4];
     {
         const int qrow = min(q0 + wid * 32 + lo, R - 1);
-        const float* qsrc = Qb + (size_t)qrow * 64 + 8 * hi;
+        const unsigned short* qsrc = Qh + (size_t)qrow * 64 + 8 * hi;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(qsrc + 16 * s);
-            const float4 b = *reinterpret_cast<const float4*>(qsrc + 16 * s + 4);
-            split8(a, b, qh[s], ql[s]);
+            qh[s] = *reinterpret_cast<const uint4*>(qsrc + 16 * s);
+            ql[s] = *reinterpret_cast<const uint4*>(qsrc + plane + 16 * s);
         }
     }
 
@@ -242,63 +247,60 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
 
-    // staging: K 64 keys x 8 octets (2 items / thread), V^T 64 d x 16 key-quads (4 items / thread)
-    float4 rk[2][2], rv[4];
+    // staging registers (named, see gemm.hip): K 64 keys x 8 octets x 2 planes = 4 x 16 B per thread,
+    // V^T 64 d x 16 key-quads x 2 planes = 8 x 8 B per thread
+    uint4 rk0, rk1, rk2, rk3;
+    uint2 rv0, rv1, rv2, rv3, rv4, rv5, rv6, rv7;
+    const int k_key = tid >> 3, k_oc = tid & 7;  // + 32 keys for the second item
+    const int v_d = tid >> 4, v_kq = tid & 15;   // + 16 d per item
     auto load_tile = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + 256 * it;
-            const int key = k0 + (idx >> 3), oc = idx & 7;
-            // rows past the sequence end may hold anything (even NaN): they are zeroed when staged
-            const float* src = Kb + (size_t)min(key, R - 1) * 64 + oc * 8;
-            rk[it][0] = *reinterpret_cast<const float4*>(src);
-            rk[it][1] = *reinterpret_cast<const float4*>(src + 4);
+        const unsigned short* ks = Kg + (size_t)(k0 + k_key) * 64 + k_oc * 8;
+        rk0 = *reinterpret_cast<const uint4*>(ks);
+        rk1 = *reinterpret_cast<const uint4*>(ks + plane);
+        rk2 = *reinterpret_cast<const uint4*>(ks + 32 * 64);
+        rk3 = *reinterpret_cast<const uint4*>(ks + 32 * 64 + plane);
+        const unsigned short* vs = Vg + (size_t)v_d * R + k0 + v_kq * 4;
+        rv0 = *reinterpret_cast<const uint2*>(vs);
+        rv1 = *reinterpret_cast<const uint2*>(vs + plane);
+        rv2 = *reinterpret_cast<const uint2*>(vs + (size_t)16 * R);
+        rv3 = *reinterpret_cast<const uint2*>(vs + (size_t)16 * R + plane);
+        rv4 = *reinterpret_cast<const uint2*>(vs + (size_t)32 * R);
+        rv5 = *reinterpret_cast<const uint2*>(vs + (size_t)32 * R + plane);
+        rv6 = *reinterpret_cast<const uint2*>(vs + (size_t)48 * R);
+        rv7 = *reinterpret_cast<const uint2*>(vs + (size_t)48 * R + plane);
+    };
+    // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
+    const int v_u = ((v_kq >> 2) * 2 + (v_kq & 1)) * 2 + ((v_kq >> 1) & 1);
+    auto store_tile = [&](int k0, auto tail) __attribute__((always_inline)) {
+        if (decltype(tail)::value) {
+            // keys past the sequence end may hold anything (even NaN bit patterns): zero them
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            if (k0 + k_key >= nk) rk0 = rk1 = z4;
+            if (k0 + k_key + 32 >= nk) rk2 = rk3 = z4;
+            const int kk = k0 + v_kq * 4;
+            const unsigned mx = (kk + 0 < nk ? 0x0000FFFFu : 0u) | (kk + 1 < nk ? 0xFFFF0000u : 0u);
+            const unsigned my = (kk + 2 < nk ? 0x0000FFFFu : 0u) | (kk + 3 < nk ? 0xFFFF0000u : 0u);
+            rv0.x &= mx; rv0.y &= my; rv1.x &= mx; rv1.y &= my; rv2.x &= mx; rv2.y &= my; rv3.x &= mx; rv3.y &= my;
+            rv4.x &= mx; rv4.y &= my; rv5.x &= mx; rv5.y &= my; rv6.x &= mx; rv6.y &= my; rv7.x &= mx; rv7.y &= my;
         }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 256 * it;
-            const int d = idx >> 4, kq = idx & 15;
-            const int key = k0 + kq * 4;
-            float4 v = *reinterpret_cast<const float4*>(Vb + (size_t)d * R + key);
-            // keys past the sequence end may hold anything (even NaN): feed zeros
-            if (key + 0 >= nk) v.x = 0.f;
-            if (key + 1 >= nk) v.y = 0.f;
-            if (key + 2 >= nk) v.z = 0.f;
-            if (key + 3 >= nk) v.w = 0.f;
-            rv[it] = v;
-        }
+        Kh[k_oc * KSTR + k_key] = rk0;
+        Kl[k_oc * KSTR + k_key] = rk1;
+        Kh[k_oc * KSTR + k_key + 32] = rk2;
+        Kl[k_oc * KSTR + k_key + 32] = rk3;
+        uint2* vh2 = reinterpret_cast<uint2*>(Vh);
+        uint2* vl2 = reinterpret_cast<uint2*>(Vl);
+        vh2[(v_d * VSTR) * 2 + v_u] = rv0;
+        vl2[(v_d * VSTR) * 2 + v_u] = rv1;
+        vh2[((v_d + 16) * VSTR) * 2 + v_u] = rv2;
+        vl2[((v_d + 16) * VSTR) * 2 + v_u] = rv3;
+        vh2[((v_d + 32) * VSTR) * 2 + v_u] = rv4;
+        vl2[((v_d + 32) * VSTR) * 2 + v_u] = rv5;
+        vh2[((v_d + 48) * VSTR) * 2 + v_u] = rv6;
+        vl2[((v_d + 48) * VSTR) * 2 + v_u] = rv7;
     };
 
-    const int ntile = (nk + KT - 1) / KT;
-    if (ntile > 0) load_tile(0);
-    for (int tile = 0; tile < ntile; ++tile) {
-        const int k0 = tile * KT;
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + 256 * it;
-            uint4 h, l;
-            split8(rk[it][0], rk[it][1], h, l);
-            if (k0 + (idx >> 3) >= nk) h = l = make_uint4(0u, 0u, 0u, 0u);
-            Kh[(idx & 7) * KSTR + (idx >> 3)] = h;
-            Kl[(idx & 7) * KSTR + (idx >> 3)] = l;
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 256 * it;
-            const int d = idx >> 4, kq = idx & 15;
-            uint2 h, l;
-            split2(rv[it].x, rv[it].y, h.x, l.x);
-            split2(rv[it].z, rv[it].w, h.y, l.y);
-            // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
-            const int u = (d * VSTR + (kq >> 2) * 2 + (kq & 1)) * 2 + ((kq >> 1) & 1);
-            reinterpret_cast<uint2*>(Vh)[u] = h;
-            reinterpret_cast<uint2*>(Vl)[u] = l;
-        }
-        __syncthreads();
-        if (tile + 1 < ntile) load_tile(k0 + KT);
-
-        // ---- S^T = K . Q^T  (two 32-key fragments, K = 64 in four 16-wide steps)
+    // one 64-key tile: S^T = K.Q^T, online soft-max, O^T += V^T.P^T
+    auto compute_tile = [&](int k0, auto tail) __attribute__((always_inline)) {
         f32x16 s[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -313,8 +315,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
                 s[f] = mfma16(ah, qh[st], s[f]);
             }
         }
-        // ---- online soft-max for query `lo`
-        if (k0 + KT > nk) {  // only the last tile can hold keys past the sequence end
+        if (decltype(tail)::value) {  // only the last tile can hold keys past the sequence end
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
         }
-        // ---- O^T += V^T . P^T : step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
+        // step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -369,6 +370,22 @@ __global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
                     o[df] = mfma16(vh, ph, o[df]);
                 }
             }
+    };
+
+    const int ntile = (nk + KT - 1) / KT;
+    if (ntile > 0) load_tile(0);
+    for (int tile = 0; tile + 1 < ntile; ++tile) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile(tile * KT, std::false_type{});
+        __syncthreads();
+        load_tile((tile + 1) * KT);
+        compute_tile(tile * KT, std::false_type{});
+    }
+    if (ntile > 0) {
+        __syncthreads();
+        store_tile((ntile - 1) * KT, std::true_type{});
+        __syncthreads();
+        compute_tile((ntile - 1) * KT, std::true_type{});
     }
 
     // ---- normalise and write (transpose through LDS so each query row is stored contiguously)

@@ -53,6 +53,8 @@ struct GemmP {
     float* Kt = nullptr;
     float* V = nullptr;
     int v_transposed = 0;  // 1: V is written as V^T [seq][head][64][rows_per_seq] (split attention)
+    int split_out = 0;     // 1: Q / K / V^T are written as f16 hi / lo planes (lo plane at +plane_halves)
+    size_t plane_halves = 0;
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;

@@ -140,7 +140,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, 
                         dst = (t == 0) ? p.Q : p.V;
                         vt = (t == 1);
                     }
-                    if (vt && p.v_transposed) {
+                    if (p.split_out) {
+                        // pre-split operands for attn_split_kernel: f16 hi plane, lo plane
+                        unsigned h01, l01, h23, l23;
+                        split2(v[0], v[1], h01, l01);
+                        split2(v[2], v[3], h23, l23);
+                        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+                        if (vt) {
+                            unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * 64 + d0) * p.rows_per_seq + i;
+                            const size_t rs = p.rows_per_seq;
+                            o[0] = (unsigned short)(h01 & 0xFFFFu);
+                            o[rs] = (unsigned short)(h01 >> 16);
+                            o[2 * rs] = (unsigned short)(h23 & 0xFFFFu);
+                            o[3 * rs] = (unsigned short)(h23 >> 16);
+                            o += p.plane_halves;
+                            o[0] = (unsigned short)(l01 & 0xFFFFu);
+                            o[rs] = (unsigned short)(l01 >> 16);
+                            o[2 * rs] = (unsigned short)(l23 & 0xFFFFu);
+                            o[3 * rs] = (unsigned short)(l23 >> 16);
+                        } else {
+                            unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * p.rows_per_seq + i) * 64 + d0;
+                            *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
+                            *reinterpret_cast<uint2*>(o + p.plane_halves) = make_uint2(l01, l23);
+                        }
+                    } else if (vt && p.v_transposed) {
                         // V^T [seq][head][64][rows]: lanes run along the token axis -> coalesced
                         float* o = dst + (((size_t)c.seq * p.heads + hd) * 64 + d0) * p.rows_per_seq + i;
 #pragma unroll

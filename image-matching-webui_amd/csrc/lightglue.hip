@@ -820,6 +820,8 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.ldw = 256;
             g.bias = P + o.bqkv;
             g.v_transposed = split ? 1 : 0;
+            g.split_out = split ? 1 : 0;
+            g.plane_halves = (size_t)S * R * 256;
             g.Q = w.q;
             g.Kt = w.k;
             g.V = w.v;
@@ -868,6 +870,8 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.ldw = 256;
             g.bias = P + o.bx;
             g.v_transposed = split ? 1 : 0;
+            g.split_out = split ? 1 : 0;
+            g.plane_halves = (size_t)S * R * 256;
             g.Q = w.q;
             g.V = w.v;
             g.alpha = (float)0.35355339059327373;  // (64 ** -0.5) ** 0.5 applied to both sides

@@ -336,17 +336,28 @@ def conv3x3_f32(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
+def _split_planes(t: torch.Tensor) -> torch.Tensor:
+    """f32 tensor -> [2, ...] f16 (hi, lo) planes, the operand format of the split attention kernel."""
+    hi = t.half()
+    lo = (t - hi.float()).half()
+    return torch.stack([hi, lo], 0).contiguous()
+
+
 def attention_f32(q, k, v, cnt, cross=False):
     """q,k,v [S,heads,rows,64] head-major (q pre-scaled); cnt [S] int32 -> [S*rows, heads*64]."""
     hd = get_handle(q.device)
     S, Hh, R, d = q.shape
     assert d == 64
     if hd.lib.imcui_hip_get_precision(hd.h) == 1:
-        v = v.transpose(2, 3)  # the split kernel consumes V^T [S,heads,64,rows]
+        # the split kernel consumes pre-split f16 planes of Q, K and V^T [S,heads,64,rows]
+        q, k, v = _split_planes(q.float()), _split_planes(k.float()), _split_planes(v.float().transpose(2, 3).contiguous())
+    else:
+        q, k, v = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
     o = torch.zeros((S * R, Hh * 64), dtype=torch.float32, device=q.device)
+    cnt = cnt.to(torch.int32).contiguous()
     with torch.cuda.device(q.device):
         hd.check(
-            hd.lib.imcui_hip_attention_f32(hd.h, _ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(v.contiguous()), _ptr(o), _ptr(cnt.to(torch.int32).contiguous()), S, Hh, R, int(cross), _stream_ptr()),
+            hd.lib.imcui_hip_attention_f32(hd.h, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(cnt), S, Hh, R, int(cross), _stream_ptr()),
             "attention",
         )
     return o

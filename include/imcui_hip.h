@@ -50,7 +50,8 @@ int imcui_hip_version(void);
  *   1  3 x f16 split: every f32 operand is split into f16 (hi, lo) and a product is evaluated as
  *      ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with f32 accumulation (~fp32 accuracy,
  *      ~5x the f32 matrix rate).  Attention then consumes V transposed (internal detail).
- * For imcui_hip_attention_f32 in mode 1 the caller passes V as V^T [S][heads][64][rows]. */
+ * For imcui_hip_attention_f32 in mode 1 the caller passes pre-split operands: each of Q, K
+ * [S][heads][rows][64] and V^T [S][heads][64][rows] as two f16 planes (hi, then lo). */
 int imcui_hip_set_precision(imcui_hip_t* h, int mode);
 int imcui_hip_get_precision(const imcui_hip_t* h);
 
