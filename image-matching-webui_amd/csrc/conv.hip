@@ -139,16 +139,19 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 }
 
 // ------------------------------------------------------------------ 3 x f16 split variant
-// 16x16 pixel tile x 64 output channels per workgroup; wave w owns rows 4w..4w+3 (two 32-pixel
-// row fragments) x 64 channels (two column fragments) = 64 accumulators.  The f32 input patch of
-// a 32-channel chunk is split into f16 (hi, lo) while it is staged into LDS as
+// 8x32 pixel tile x 64 output channels per workgroup; wave w owns image rows 2w, 2w+1 (two
+// 32-pixel row fragments: a fragment is ONE image row, so its 16-byte LDS reads are consecutive
+// and bank-conflict free) x 64 channels (two fragments) = 64 accumulators.  The f32 input patch
+// of a 32-channel chunk is split into f16 (hi, lo) while it is staged into LDS as
 // [channel-octet][pixel][8 halves]; weights arrive pre-split.  Each tap = two 16-channel MFMA
-// steps of ah*bh + ah*bl + al*bh.
-#define STH 16
-#define STW 16
+// steps of wh*ah + wl*ah + wh*al with the WEIGHT fragment as the A operand, so a lane ends up
+// with 4 consecutive output channels of one pixel per register quad: the NHWC store is 16 bytes
+// per lane, and the 2x2 max-pool is one register max (rows) + one neighbour-lane max (columns).
+#define STH 8
+#define STW 32
 #define SPW (STW + 2)
-#define SNPIX ((STH + 2) * SPW)  // 324
-#define SPSTR 330                // padded pixel stride (16-byte units): conflict-free staging writes
+#define SNPIX ((STH + 2) * SPW)  // 340
+#define SPSTR 346                // padded pixel stride (16-byte units): conflict-free staging writes
 
 __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restrict__ in,
                                                             const unsigned short* __restrict__ wh,
@@ -185,7 +188,6 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
     const int nchunk = Cin >> 5;
     const uint4* wh4 = reinterpret_cast<const uint4*>(wh);
     const uint4* wl4 = reinterpret_cast<const uint4*>(wl);
-    const int px = lo & 15;
 
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // everybody is done with the previous patch
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                 uint4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int pp = (4 * wid + 2 * m + (lo >> 4) + dy) * SPW + px + dx;
+                    const int pp = (2 * wid + m + dy) * SPW + lo + dx;
                     ah[m] = Ph[oc * SPSTR + pp];
                     al[m] = Pl[oc * SPSTR + pp];
                 }
@@ -237,39 +239,58 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = mfma16(al[m], bh[n], acc[m][n]);
-                        acc[m][n] = mfma16(ah[m], bl[n], acc[m][n]);
-                        acc[m][n] = mfma16(ah[m], bh[n], acc[m][n]);
+                        // weights = MFMA A operand (rows = output channels), pixels = B (columns)
+                        acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                        acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                        acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
                     }
             }
         }
     }
 
+    // ---- epilogue: lane = pixel column x0 + lo; register quad q of fragment n = channels
+    //      cout0 + 32n + 8q + 4hi .. +3
     const float wsc = wscale[0];
+    const int ox = x0 + lo;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int co = cout0 + n * 32 + lo;
-        const float bv = bias[co];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int q = 0; q < 4; ++q) {
+            const int co = cout0 + n * 32 + 8 * q + 4 * hi;
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
             if (pool) {
                 const int Ho = H >> 1, Wo = W >> 1;
+                float v[4];
 #pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    float v = fmaxf(fmaxf(acc[m][n][r], acc[m][n][r + 1]), fmaxf(acc[m][n][r + 8], acc[m][n][r + 9])) * wsc + bv;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    const int p = frag_row(r, hi);
-                    const int oy = (y0 >> 1) + 2 * wid + m, ox = (x0 >> 1) + (p >> 1);
-                    if (oy < Ho && ox < Wo) out[(((size_t)b * Ho + oy) * Wo + ox) * Cout + co] = v;
+                for (int j = 0; j < 4; ++j) {
+                    float tv = fmaxf(acc[0][n][4 * q + j], acc[1][n][4 * q + j]);  // rows 2w, 2w+1
+                    tv = fmaxf(tv, __shfl_xor(tv, 1, 64));                          // columns x, x^1
+                    v[j] = tv * wsc;
                 }
+                v[0] += b4.x;
+                v[1] += b4.y;
+                v[2] += b4.z;
+                v[3] += b4.w;
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                }
+                const int oy = (y0 >> 1) + wid, pxo = ox >> 1;
+                if ((lo & 1) == 0 && oy < Ho && pxo < Wo)
+                    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = frag_row(r, hi);
-                    const int oy = y0 + 4 * wid + 2 * m + (p >> 4), ox = x0 + (p & 15);
-                    float v = acc[m][n][r] * wsc + bv;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    if (oy < H && ox < W) out[(((size_t)b * H + oy) * W + ox) * Cout + co] = v;
+                for (int m = 0; m < 2; ++m) {
+                    const int oy = y0 + 2 * wid + m;
+                    float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y,
+                                           acc[m][n][4 * q + 2] * wsc + b4.z, acc[m][n][4 * q + 3] * wsc + b4.w);
+                    if (relu) {
+                        v.x = fmaxf(v.x, 0.0f);
+                        v.y = fmaxf(v.y, 0.0f);
+                        v.z = fmaxf(v.z, 0.0f);
+                        v.w = fmaxf(v.w, 0.0f);
+                    }
+                    if (oy < H && ox < W) *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * Cout + co) = v;
                 }
             }
         }

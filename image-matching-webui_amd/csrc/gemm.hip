@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // PRESPLIT: B operand comes from pre-split f16 planes (network weights); otherwise it is an
 // f32 activation matrix split on the fly like A (similarity products).
 template <int EPI, bool PRESPLIT>
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
     __shared__ uint4 smem[4 * (BK64 / 8) * LDS_ROWS];  // A_hi | A_lo | B_hi | B_lo, 16512 B each
     uint4* Ah = smem;
     uint4* Al = smem + (BK64 / 8) * LDS_ROWS;
@@ -293,19 +293,24 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
     const int s_ko = tid & 7;
     const int s_r = tid >> 3;
     // A: two float4 per item (split while staged); B: hi/lo planes (pre-split weights, pure copy)
-    // or two float4 (activations, split while staged) held as raw bits in the same registers
-    float4 ra0a, ra0b, ra1a, ra1b, ra2a, ra2b, ra3a, ra3b;
+    // or two float4 (activations, split while staged) held as raw bits in the same registers.
+    // The A operand (activations streamed from HBM / MALL) has TWO register sets (X, Y): tile kt+2
+    // is requested before tile kt is multiplied, so its load has a whole stage + multiply phase
+    // (> 3k cycles) to land.  The B operand (weights, L2-resident) is fetched one tile ahead.
+    float4 raX0a, raX0b, raX1a, raX1b, raX2a, raX2b, raX3a, raX3b, raY0a, raY0b, raY1a, raY1b, raY2a, raY2b, raY3a, raY3b;
     uint4 rb0a, rb0b, rb1a, rb1b, rb2a, rb2b, rb3a, rb3b;
     const int nkt = p.K / BK64;
-#define LD64(it)                                                                     \
+#define LDA64(S, it)                                                                 \
     {                                                                                \
-        const int r = s_r + 32 * it;                                                 \
-        const int ar = min(c.row0 + r, c.M - 1);                                     \
-        const int br = min(c.col0 + r, c.N - 1);                                     \
+        const int ar = min(c.row0 + s_r + 32 * it, c.M - 1);                         \
         const float* src = (p.A2 != nullptr && k >= p.K1) ? p.A2 + (size_t)ar * p.lda2 + (k - p.K1) \
                                                           : A + (size_t)ar * p.lda + k; \
-        ra##it##a = *reinterpret_cast<const float4*>(src);                           \
-        ra##it##b = *reinterpret_cast<const float4*>(src + 4);                       \
+        ra##S##it##a = *reinterpret_cast<const float4*>(src);                        \
+        ra##S##it##b = *reinterpret_cast<const float4*>(src + 4);                    \
+    }
+#define LDB64(it)                                                                    \
+    {                                                                                \
+        const int br = min(c.col0 + s_r + 32 * it, c.N - 1);                         \
         if (PRESPLIT) {                                                              \
             rb##it##a = *reinterpret_cast<const uint4*>(Wh + (size_t)br * p.ldw + k); \
             rb##it##b = *reinterpret_cast<const uint4*>(Wl + (size_t)br * p.ldw + k); \
@@ -315,11 +320,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
             rb##it##b = *reinterpret_cast<const uint4*>(ws + 4);                     \
         }                                                                            \
     }
-#define ST64(it)                                                                     \
+#define ST64(S, it)                                                                  \
     {                                                                                \
         const int o = s_ko * LDS_ROWS + s_r + 32 * it;                               \
         uint4 h, l;                                                                  \
-        split8(ra##it##a, ra##it##b, h, l);                                          \
+        split8(ra##S##it##a, ra##S##it##b, h, l);                                    \
         Ah[o] = h;                                                                   \
         Al[o] = l;                                                                   \
         if (PRESPLIT) {                                                              \
@@ -331,41 +336,63 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmP p) {
             Bl[o] = l;                                                               \
         }                                                                            \
     }
-    auto load_tile = [&](int kt) __attribute__((always_inline)) {
-        const int k = kt * BK64 + s_ko * 8;
-        FOR4(LD64)
-    };
+#define LOADA(S, kt_)                                    \
+    {                                                    \
+        const int k = (kt_) * BK64 + s_ko * 8;           \
+        LDA64(S, 0) LDA64(S, 1) LDA64(S, 2) LDA64(S, 3)  \
+    }
+#define LOADB(kt_)                               \
+    {                                            \
+        const int k = (kt_) * BK64 + s_ko * 8;   \
+        LDB64(0) LDB64(1) LDB64(2) LDB64(3)      \
+    }
+#define STORESET(S) ST64(S, 0) ST64(S, 1) ST64(S, 2) ST64(S, 3)
 
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        FOR4(ST64)
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+    auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < BK64 / 16; ++s) {
-            const int ko = 2 * s + hi;
-            uint4 ah[2], al[2], bh[2], bl[2];
+    for (int s = 0; s < BK64 / 16; ++s) {
+        const int ko = 2 * s + hi;
+        uint4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ah[m] = Ah[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
-                al[m] = Al[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
-            }
+        for (int m = 0; m < 2; ++m) {
+            ah[m] = Ah[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
+            al[m] = Al[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bh[n] = Bh[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
+            bl[n] = Bl[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                bh[n] = Bh[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
-                bl[n] = Bl[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
+                // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
+                acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
             }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
-                    acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
-                    acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
-                    acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
-                }
-        }
+    }
+    };
+
+    LOADA(X, 0)
+    LOADB(0)
+    if (nkt > 1) LOADA(Y, 1)
+    for (int kt = 0; kt < nkt; kt += 2) {
+        STORESET(X)
         __syncthreads();
+        if (kt + 1 < nkt) LOADB(kt + 1)
+        if (kt + 2 < nkt) LOADA(X, kt + 2)
+        compute();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            STORESET(Y)
+            __syncthreads();
+            if (kt + 2 < nkt) LOADB(kt + 2)
+            if (kt + 3 < nkt) LOADA(Y, kt + 3)
+            compute();
+            __syncthreads();
+        }
     }
     gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi);
 }
