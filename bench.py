@@ -82,8 +82,8 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,6 +163,14 @@ def main():
         # executed matrix flops: both cross directions recompute QK^T (8.59 + 8.59 vs 15.03 GF) and the
         # split mode issues 3 f16 MFMAs per product
         executed = achieved * (17.18 / 15.03) * (3.0 if split else 1.0)
+        # HBM-side bytes per attention launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs, FETCH doubled per MI355X_MICROARCH.md); scales with the batch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
+        if split and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj["traffic_bytes_per_launch"] * B / tj["batch_pairs"]
         line = {
             "metric": "image-pairs/sec @640x480 SuperPoint+LightGlue",
             "value": pairs / dt,
@@ -184,7 +192,7 @@ def main():
             },
             "roofline": {
                 "kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel (f32 MFMA flash attention)",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "executed_tflops": executed, "executed_frac": executed / peak,
                 "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n, "algorithmic_gflop_per_launch": attn_flops / 1e9,
             },
