@@ -14,6 +14,11 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
                          int relu, int pool, hipStream_t stream);
+// SuperPoint conv1a (1->64, VALU, evaluated on the fly for the patch) fused into conv1b (64->64, split MFMA):
+// image [B,H,W] -> relu(conv1b(relu(conv1a(image)))) (+2x2 max-pool), NHWC out
+int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* w1a, const float* b1a,
+                               const unsigned short* wh, const unsigned short* wl, const float* wscale, const float* bias,
+                               float* out, int B, int H, int W, int pool, hipStream_t stream);
 // host: OIHW -> the split layout above; returns 2^-e
 float pack_conv3x3_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
 

@@ -153,17 +153,27 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 #define SNPIX ((STH + 2) * SPW)  // 340
 #define SPSTR 346                // padded pixel stride (16-byte units): conflict-free staging writes
 
+// FUSE1A: `in` is the 1-channel image [B,H,W] and the 64-channel input of this layer is
+// relu(conv1a(image)) evaluated on the fly for the patch (SuperPoint conv1a -> conv1b): the
+// 79 MB/image conv1a activation never goes to HBM.  The arithmetic of conv1a is the same fmaf chain
+// as conv1a_kernel, so the fused and unfused paths agree bit for bit.
+#define ITW (STW + 4)  // image tile: patch + 1-pixel halo of the first conv
+#define ITH (STH + 4)
+template <bool FUSE1A>
 __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restrict__ in,
                                                             const unsigned short* __restrict__ wh,
                                                             const unsigned short* __restrict__ wl,
                                                             const float* __restrict__ wscale,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
-                                                            int relu, int pool) {
-    __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSTR];
+                                                            int relu, int pool, const float* __restrict__ w1a,
+                                                            const float* __restrict__ b1a) {
+    __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSTR + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
     uint4* Ph = smem;
     uint4* Pl = smem + 4 * SPSTR;
     uint4* Wb = smem + 2 * 4 * SPSTR;  // [buf][plane][4 * WSTR]
+    float* img = reinterpret_cast<float*>(smem + 2 * 4 * SPSTR + 2 * 2 * 4 * WSTR);  // [ITH][ITW] (FUSE1A)
+    float* w1 = img + ITH * ITW;                                                       // [9][64] + bias [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
@@ -189,16 +199,51 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
     const uint4* wh4 = reinterpret_cast<const uint4*>(wh);
     const uint4* wl4 = reinterpret_cast<const uint4*>(wl);
 
+    if (FUSE1A) {
+        // image tile (zero outside the image = conv1a's padding) and the first layer's weights
+        for (int i = tid; i < ITH * ITW; i += 256) {
+            const int gy = y0 - 2 + i / ITW, gx = x0 - 2 + i % ITW;
+            img[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in[((size_t)b * H + gy) * W + gx] : 0.0f;
+        }
+        for (int i = tid; i < 9 * 64; i += 256) w1[i] = w1a[i];
+        if (tid < 64) w1[9 * 64 + tid] = b1a[tid];
+    }
+
     for (int ch = 0; ch < nchunk; ++ch) {
-        __syncthreads();  // everybody is done with the previous patch
+        __syncthreads();  // everybody is done with the previous patch (and the image tile is visible)
         for (int idx = tid; idx < SNPIX * 4; idx += 256) {
             const int oc = idx & 3, pp = idx >> 2;
-            const int gy = y0 - 1 + pp / SPW, gx = x0 - 1 + pp % SPW;
+            const int py = pp / SPW, px = pp - py * SPW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
-                const float4 a = *reinterpret_cast<const float4*>(src);
-                const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                float4 a, c;
+                if (FUSE1A) {
+                    // relu(conv1a) for channels ch*32 + oc*8 .. +7 of this pixel (tap-major fmaf chain)
+                    const int c0 = ch * 32 + oc * 8;
+                    a = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0);
+                    c = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0 + 4);
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) {
+                        const float v = img[(py + t9 / 3) * ITW + px + t9 % 3];
+                        const float4 k0 = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0);
+                        const float4 k1 = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0 + 4);
+                        a.x = fmaf(v, k0.x, a.x);
+                        a.y = fmaf(v, k0.y, a.y);
+                        a.z = fmaf(v, k0.z, a.z);
+                        a.w = fmaf(v, k0.w, a.w);
+                        c.x = fmaf(v, k1.x, c.x);
+                        c.y = fmaf(v, k1.y, c.y);
+                        c.z = fmaf(v, k1.z, c.z);
+                        c.w = fmaf(v, k1.w, c.w);
+                    }
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                } else {
+                    const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
+                    a = *reinterpret_cast<const float4*>(src);
+                    c = *reinterpret_cast<const float4*>(src + 4);
+                }
                 split8(a, c, hq, lq);
             }
             Ph[oc * SPSTR + pp] = hq;
@@ -307,8 +352,23 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     const long nwg = (long)tiles_x * tiles_y * (Cout / 64) * B;
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
-    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W,
-                       Cin, Cout, tiles_x, tiles_y, relu, pool);
+    hipLaunchKernelGGL(conv3x3_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H,
+                       W, Cin, Cout, tiles_x, tiles_y, relu, pool, (const float*)nullptr, (const float*)nullptr);
+    imcui_prof_end(h, PROF_CONV, stream);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* w1a, const float* b1a,
+                               const unsigned short* wh, const unsigned short* wl, const float* wscale, const float* bias,
+                               float* out, int B, int H, int W, int pool, hipStream_t stream) {
+    if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv1ab: pooled layer needs even H,W (%dx%d)", H, W);
+    const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, STH);
+    const long nwg = (long)tiles_x * tiles_y * B;
+    if (nwg <= 0) return IMCUI_OK;
+    imcui_prof_begin(h, PROF_CONV, stream);
+    hipLaunchKernelGGL(conv3x3_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
+                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

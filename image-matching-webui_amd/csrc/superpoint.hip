@@ -600,8 +600,17 @@ extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed,
         return gemm_launch(h, g, stream);
     };
     // a2: encoder
-    SPRUN(conv1a_launch(h, image, P + l.w[L1A], P + l.b[L1A], s.a1a, B, H, W, stream));
-    SPRUN(conv(L1B, s.a1a, s.p1, H, W, 1));
+    if (split) {
+        // conv1a is evaluated inside conv1b's patch staging: its 64-channel full-resolution output
+        // (79 MB / image) never reaches HBM
+        SPRUN(conv1ab_fused_split_launch(h, image, P + l.w[L1A], P + l.b[L1A],
+                                         reinterpret_cast<const unsigned short*>(P + l.wh[L1B]),
+                                         reinterpret_cast<const unsigned short*>(P + l.wl[L1B]), P + l.ws[L1B], P + l.b[L1B],
+                                         s.p1, B, H, W, 1, stream));
+    } else {
+        SPRUN(conv1a_launch(h, image, P + l.w[L1A], P + l.b[L1A], s.a1a, B, H, W, stream));
+        SPRUN(conv(L1B, s.a1a, s.p1, H, W, 1));
+    }
     SPRUN(conv(L2A, s.p1, s.a2a, H / 2, W / 2, 0));
     SPRUN(conv(L2B, s.a2a, s.p2, H / 2, W / 2, 1));
     SPRUN(conv(L3A, s.p2, s.a3a, H / 4, W / 4, 0));
