@@ -52,7 +52,7 @@ def superpoint_state_dict(seed: int = 0, peaky: bool = True) -> dict:
         # ReLU features have a large positive mean; centre the descriptor projection over
         # its inputs so descriptors are not dominated by one common direction.
         w = sd["convDb.weight"]
-        sd["convDb.weight"] = (w - w.mean(dim=1, keepdim=True)) * 2.0
+        sd["convDb.weight"] = (w - w.mean(dim=1, keepdim=True)) * 3.0
         sd["convDb.bias"] = -_mean_descriptor_logits(sd, g)
     return sd
 
@@ -139,4 +139,89 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
                 sd[t + ".bias"] = sd[t + ".bias"] + 1.2 + 0.4 * i
             else:
                 sd.update(lin(1, dim, scale=2.0, prefix=t))
+    return sd
+
+
+def loftr_state_dict(seed: int = 0, structured: bool = True) -> dict:
+    """Random LoFTR weights in kornia's state-dict layout (ResNetFPN_8_2 + coarse/fine transformers).
+
+    backbone.{conv1,bn1,layer{1,2,3}.{0,1}.{conv1,bn1,conv2,bn2[,downsample.{0,1}]},layer3_outconv,
+    layer2_outconv,layer2_outconv2.{0,1,3},layer1_outconv,layer1_outconv2.{0,1,3}},
+    loftr_coarse.layers.{0..7}.{q_proj,k_proj,v_proj,merge,mlp.0,mlp.2,norm1,norm2},
+    fine_preprocess.{down_proj,merge_feat}, loftr_fine.layers.{0,1}.*
+    `structured` damps the transformer updates so coarse features stay image-dependent and the
+    dual soft-max produces confident mutual matches with random weights.
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k, gain=1.0):
+        sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k)) * gain
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    b = "backbone."
+    conv(b + "conv1", 128, 1, 7)
+    bn(b + "bn1", 128)
+    dims = [128, 128, 196, 256]
+    for li in range(1, 4):
+        cin, cout = dims[li - 1], dims[li]
+        for bi in range(2):
+            p = f"{b}layer{li}.{bi}"
+            c_in = cin if bi == 0 else cout
+            conv(p + ".conv1", cout, c_in, 3)
+            bn(p + ".bn1", cout)
+            conv(p + ".conv2", cout, cout, 3, gain=0.5)
+            bn(p + ".bn2", cout)
+            if bi == 0 and li > 1:
+                conv(p + ".downsample.0", cout, c_in, 1)
+                bn(p + ".downsample.1", cout)
+    conv(b + "layer3_outconv", 256, 256, 1)
+    if structured:
+        # x3 is post-ReLU and dominated by one common direction: project the mean feature of a small
+        # calibration image out of every row, then apply a gain, so that the coarse dual soft-max is
+        # driven by image content and produces confident mutual matches with random weights
+        from oracle.loftr import LoFTROracle
+
+        with torch.no_grad():
+            _, _, x3 = LoFTROracle(sd).encoder_stages(torch.rand(1, 1, 96, 128, generator=g))
+        m = x3.mean(dim=(0, 2, 3))
+        m = m / m.norm()
+        wc = sd[b + "layer3_outconv.weight"][:, :, 0, 0]
+        wc = wc - (wc @ m)[:, None] * m[None, :]
+        sd[b + "layer3_outconv.weight"] = (wc * 4.0)[:, :, None, None].contiguous()
+    conv(b + "layer2_outconv", 256, 196, 1)
+    conv(b + "layer2_outconv2.0", 256, 256, 3)
+    bn(b + "layer2_outconv2.1", 256)
+    conv(b + "layer2_outconv2.3", 196, 256, 3)
+    conv(b + "layer1_outconv", 196, 128, 1)
+    conv(b + "layer1_outconv2.0", 196, 196, 3)
+    bn(b + "layer1_outconv2.1", 196)
+    conv(b + "layer1_outconv2.3", 128, 196, 3)
+
+    def lin(name, out_f, in_f, gain=1.0, bias=False):
+        sd[name + ".weight"] = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * math.sqrt(3.0 / in_f) * gain
+        if bias:
+            sd[name + ".bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * 0.1
+
+    def encoder(prefix, n_layers, d):
+        for i in range(n_layers):
+            p = f"{prefix}.layers.{i}"
+            for nm in ("q_proj", "k_proj", "v_proj", "merge"):
+                lin(f"{p}.{nm}", d, d)
+            lin(f"{p}.mlp.0", 2 * d, 2 * d)
+            lin(f"{p}.mlp.2", d, 2 * d)
+            for nm in ("norm1", "norm2"):
+                sd[f"{p}.{nm}.weight"] = (0.25 if (structured and nm == "norm2") else 1.0) + 0.05 * torch.randn(d, generator=g)
+                sd[f"{p}.{nm}.bias"] = 0.02 * torch.randn(d, generator=g)
+
+    encoder("loftr_coarse", 8, 256)
+    lin("fine_preprocess.down_proj", 128, 256, bias=True)
+    lin("fine_preprocess.merge_feat", 128, 256, bias=True)
+    encoder("loftr_fine", 2, 128)
     return sd
