@@ -137,6 +137,37 @@ extern "C" int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in, cons
     return conv3x3_split_launch(h, in, wh, wl, wscale, bias, out, B, H, W, Cin, Cout, relu, pool, (hipStream_t)stream);
 }
 
+extern "C" int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in, const float* w, const float* bias, const float* resid,
+                                       float* out, int B, int Hin, int Win, int Cin, int Cout, int ks, int stride, int act,
+                                       void* stream) {
+    if (!h || !in || !w || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv_gemm: null argument");
+    GemmP g;
+    g.epi = EPI_CONV;
+    const int pad = ks / 2;
+    const int hout = (Hin + 2 * pad - ks) / stride + 1, wout = (Win + 2 * pad - ks) / stride + 1;
+    g.A = in;
+    g.conv_k = ks;
+    g.conv_stride = stride;
+    g.conv_pad = pad;
+    g.conv_hin = Hin;
+    g.conv_win = Win;
+    g.conv_hout = hout;
+    g.conv_wout = wout;
+    g.conv_cin = Cin;
+    g.W = w;
+    g.K = ks * ks * Cin;
+    g.ldw = g.K;
+    g.bias = bias;
+    g.N = Cout;
+    g.M = B * hout * wout;
+    g.C = out;
+    g.ldc = Cout;
+    g.resid = resid;
+    g.ldr = Cout;
+    g.act = act;
+    return gemm_launch(h, g, (hipStream_t)stream);
+}
+
 extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O,
                                        const int* cnt, int S, int heads, int rows, int cross, void* stream) {
     if (!h || !Q || !K || !V || !O || !cnt) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: null argument");

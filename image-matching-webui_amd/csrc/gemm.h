@@ -12,6 +12,7 @@ enum GemmEpi {
     EPI_RESID = 2,  // C += acc + bias                  (in-place residual)
     EPI_QKV = 3,    // LightGlue SelfBlock: bias, RoPE on q/k, q *= alpha, head-major split
     EPI_CROSS = 4,  // LightGlue CrossBlock: [qk | v] = bias, qk *= alpha, head-major split
+    EPI_CONV = 5,   // C = act(acc + bias + resid): act 0 none / 1 ReLU / 2 LeakyReLU(0.01)
 };
 
 struct GemmP {
@@ -55,6 +56,13 @@ struct GemmP {
     int v_transposed = 0;  // 1: V is written as V^T [seq][head][64][rows_per_seq] (split attention)
     int split_out = 0;     // 1: Q / K / V^T are written as f16 hi / lo planes (lo plane at +plane_halves)
     size_t plane_halves = 0;
+    // implicit im2col (enabled when conv_k > 0): A is an NHWC image [B, hin, win, cin], row m of the
+    // GEMM is output pixel m of a conv_k x conv_k convolution (stride, zero padding), K = conv_k^2 * cin
+    // ordered (tap, channel) -- the layout of pack_conv_gemm(); cin % 64 == 0
+    int conv_k = 0, conv_stride = 1, conv_pad = 0, conv_hin = 0, conv_win = 0, conv_hout = 0, conv_wout = 0, conv_cin = 0;
+    const float* resid = nullptr;  // EPI_CONV: [M, N] added before the activation (may alias C)
+    long ldr = 0;
+    int act = 0;
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;
@@ -62,5 +70,7 @@ struct GemmP {
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);
 
+// host: OIHW conv weight -> GEMM weight [Cout][tap][Cin] (K order of the implicit im2col)
+void pack_conv_gemm(const float* w_oihw, int Cout, int Cin, int ksize, int Cin_pad, float* dst);
 // host: split an [n] f32 array into f16 hi / lo planes of w * 2^e; returns 2^-e
 float split_weights_host(const float* w, size_t n, unsigned short* hi, unsigned short* lo);

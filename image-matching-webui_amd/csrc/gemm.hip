@@ -87,9 +87,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, 
                             if (f0 + j < c.N) v[j] += c.bias[f0 + j];
                     }
                 }
-                if (EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_RESID) {
+                if (EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_RESID || EPI == EPI_CONV) {
                     float* dst = C + (size_t)row * p.ldc + f0;
-                    if (EPI == EPI_BIAS) {
+                    if (EPI == EPI_CONV) {
+                        if (p.resid != nullptr) {
+                            const float* rs = p.resid + (size_t)row * p.ldr + f0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (f0 + j < c.N) v[j] += rs[j];
+                        }
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                        } else if (p.act == 2) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];
+                        }
+                    } else if (EPI == EPI_BIAS) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
                     } else if (EPI == EPI_RELU) {
@@ -178,6 +192,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, 
     }
 }
 
+// Source of `n` consecutive K elements starting at k for GEMM row `ar` (nullptr = zeros):
+// plain / concatenated matrix, or implicit im2col of an NHWC convolution.
+__device__ __forceinline__ const float* gemm_a_src(const GemmP& p, const float* A, int ar, int k) {
+    if (p.conv_k > 0) {
+        const int tap = k / p.conv_cin, c0 = k - tap * p.conv_cin;
+        const int ky = tap / p.conv_k, kx = tap - ky * p.conv_k;
+        const int ox = ar % p.conv_wout;
+        const int t = ar / p.conv_wout;
+        const int oy = t % p.conv_hout, b = t / p.conv_hout;
+        const int iy = oy * p.conv_stride - p.conv_pad + ky, ix = ox * p.conv_stride - p.conv_pad + kx;
+        if (iy < 0 || iy >= p.conv_hin || ix < 0 || ix >= p.conv_win) return nullptr;
+        return A + (((size_t)b * p.conv_hin + iy) * p.conv_win + ix) * p.conv_cin + c0;
+    }
+    if (p.A2 != nullptr && k >= p.K1) return p.A2 + (size_t)ar * p.lda2 + (k - p.K1);
+    return A + (size_t)ar * p.lda + k;
+}
+
 // ------------------------------------------------------------------ exact f32 kernel
 #define BK32 32
 template <int EPI>
@@ -215,9 +246,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int r = s_r + 32 * it;                                                 \
         const int ar = min(c.row0 + r, c.M - 1);                                     \
         const int br = min(c.col0 + r, c.N - 1);                                     \
-        const float* src = (p.A2 != nullptr && k >= p.K1) ? p.A2 + (size_t)ar * p.lda2 + (k - p.K1) \
-                                                          : A + (size_t)ar * p.lda + k; \
-        ra##it = *reinterpret_cast<const float4*>(src);                              \
+        const float* src = gemm_a_src(p, A, ar, k);                                  \
+        ra##it = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f); \
         rb##it = *reinterpret_cast<const float4*>(W + (size_t)br * p.ldw + k);       \
     }
 #define ST32(it)                                    \
@@ -303,10 +333,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
 #define LDA64(S, it)                                                                 \
     {                                                                                \
         const int ar = min(c.row0 + s_r + 32 * it, c.M - 1);                         \
-        const float* src = (p.A2 != nullptr && k >= p.K1) ? p.A2 + (size_t)ar * p.lda2 + (k - p.K1) \
-                                                          : A + (size_t)ar * p.lda + k; \
-        ra##S##it##a = *reinterpret_cast<const float4*>(src);                        \
-        ra##S##it##b = *reinterpret_cast<const float4*>(src + 4);                    \
+        const float* src = gemm_a_src(p, A, ar, k);                                  \
+        ra##S##it##a = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);     \
+        ra##S##it##b = src ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
     }
 #define LDB64(it)                                                                    \
     {                                                                                \
@@ -413,6 +442,8 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.rows_per_seq > 0 && p.rows_per_seq % BM != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: rows_per_seq=%d must be a multiple of %d", p.rows_per_seq, BM);
     if (p.M <= 0 || p.N <= 0) return IMCUI_OK;
+    if (p.conv_k > 0 && (p.conv_cin % BK64 != 0 || p.K != p.conv_k * p.conv_k * p.conv_cin))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm(conv): cin=%d must be a multiple of %d and K=%d == k*k*cin", p.conv_cin, BK64, p.K);
     const bool split = h->precision == 1 && (p.K % BK64 == 0);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");
     const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -424,6 +455,7 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         case EPI_RESID: launch_one<EPI_RESID>(p, split, grid, stream); break;
         case EPI_QKV: launch_one<EPI_QKV>(p, split, grid, stream); break;
         case EPI_CROSS: launch_one<EPI_CROSS>(p, split, grid, stream); break;
+        case EPI_CONV: launch_one<EPI_CONV>(p, split, grid, stream); break;
         default: return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: bad epilogue %d", p.epi);
     }
     imcui_prof_end(h, PROF_GEMM, stream);
@@ -481,6 +513,15 @@ static unsigned short f32_to_f16_rtn(float f) {
     if (dt < du) return t;
     if (du < dt) return u;
     return (t & 1) ? u : t;
+}
+
+void pack_conv_gemm(const float* w, int Cout, int Cin, int ks, int Cin_pad, float* dst) {
+    // dst[co][tap][ci] = w[co][ci][tap], channels ci >= Cin are zero
+    const int taps = ks * ks;
+    for (int co = 0; co < Cout; ++co)
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < Cin_pad; ++ci)
+                dst[((size_t)co * taps + t) * Cin_pad + ci] = (ci < Cin) ? w[((size_t)co * Cin + ci) * taps + t] : 0.0f;
 }
 
 float split_weights_host(const float* w, size_t n, unsigned short* hi, unsigned short* lo) {

@@ -1,0 +1,495 @@
+// LoFTR forward on MI355X (kornia.feature.LoFTR semantics, called by
+// imcui/hloc/matchers/loftr.py:54).
+//
+// Every convolution of the ResNet-FPN backbone and every Linear of the two transformers is one
+// "linear layer" W[N][K] (+bias) run by the MFMA GEMM kernel of gemm.hip: 3x3 / 1x1 / strided
+// convolutions through its implicit-im2col addressing on NHWC activations (BatchNorm folded into
+// W and bias on the host, residual add + ReLU / LeakyReLU fused in the epilogue), the 196-channel
+// stage padded to 256 channels with zero weights.  Linear attention, LayerNorm, the dual-softmax
+// coarse matching and the fine 5x5-window stage are the small kernels of loftr_kernels.h.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gemm.h"
+#include "imcui_hip.h"
+#include "loftr_kernels.h"
+
+// ------------------------------------------------------------------ layer table
+enum {
+    LF_L1_0_C1 = 0, LF_L1_0_C2, LF_L1_1_C1, LF_L1_1_C2,
+    LF_L2_0_C1, LF_L2_0_C2, LF_L2_0_DS, LF_L2_1_C1, LF_L2_1_C2,
+    LF_L3_0_C1, LF_L3_0_C2, LF_L3_0_DS, LF_L3_1_C1, LF_L3_1_C2,
+    LF_OUT3, LF_OUT2, LF_OUT2B_0, LF_OUT2B_3, LF_OUT1, LF_OUT1B_0, LF_OUT1B_3,
+    LF_COARSE0,                       // 8 layers x {q, k, v, merge, mlp0, mlp2}
+    LF_DOWN = LF_COARSE0 + 48, LF_MERGEF,
+    LF_FINE0,                         // 2 layers x {q, k, v, merge, mlp0, mlp2}
+    LF_NLAYERS = LF_FINE0 + 12
+};
+#define CP 256  // the 196-channel stage, padded
+
+static void lf_shape(int i, int* N, int* K) {
+    static const int tab[21][2] = {
+        {128, 9 * 128}, {128, 9 * 128}, {128, 9 * 128}, {128, 9 * 128},
+        {CP, 9 * 128},  {CP, 9 * CP},   {CP, 128},      {CP, 9 * CP},   {CP, 9 * CP},
+        {256, 9 * CP},  {256, 9 * 256}, {256, CP},      {256, 9 * 256}, {256, 9 * 256},
+        {256, 256},     {256, CP},      {256, 9 * 256}, {CP, 9 * 256},  {CP, 128},      {CP, 9 * CP}, {128, 9 * CP},
+    };
+    if (i < LF_COARSE0) {
+        *N = tab[i][0];
+        *K = tab[i][1];
+        return;
+    }
+    if (i == LF_DOWN || i == LF_MERGEF) {
+        *N = 128;
+        *K = 256;
+        return;
+    }
+    const bool fine = i >= LF_FINE0;
+    const int d = fine ? 128 : 256;
+    const int j = (i - (fine ? LF_FINE0 : LF_COARSE0)) % 6;
+    *N = (j == 4) ? 2 * d : d;
+    *K = (j >= 4) ? 2 * d : d;
+}
+// norm vectors: coarse layer l: 4l + {norm1.w, norm1.b, norm2.w, norm2.b} (256), then fine (128)
+#define LF_NNORMS (8 * 4 + 2 * 4)
+static int lf_norm_dim(int i) { return i < 32 ? 256 : 128; }
+
+struct LfLayout {
+    size_t conv1_w, conv1_b;  // [49][128], [128]
+    size_t w[LF_NLAYERS], b[LF_NLAYERS], wh[LF_NLAYERS], wl[LF_NLAYERS], ws[LF_NLAYERS];
+    size_t norm[LF_NNORMS];
+    size_t total;
+};
+static LfLayout lf_layout() {
+    LfLayout l;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t r = off;
+        off += align_up(n, 64);
+        return r;
+    };
+    l.conv1_w = take(49 * 128);
+    l.conv1_b = take(128);
+    for (int i = 0; i < LF_NLAYERS; ++i) {
+        int N, K;
+        lf_shape(i, &N, &K);
+        l.w[i] = take((size_t)N * K);
+        l.b[i] = take(N);
+        l.wh[i] = take((size_t)N * K / 2);
+        l.wl[i] = take((size_t)N * K / 2);
+        l.ws[i] = take(64);
+    }
+    for (int i = 0; i < LF_NNORMS; ++i) l.norm[i] = take(lf_norm_dim(i));
+    l.total = off;
+    return l;
+}
+
+extern "C" size_t imcui_hip_loftr_packed_floats(void) { return lf_layout().total; }
+extern "C" int imcui_hip_loftr_num_layers(void) { return LF_NLAYERS; }
+extern "C" int imcui_hip_loftr_layer_shape(int i, int* N, int* K) {
+    if (i < 0 || i >= LF_NLAYERS || !N || !K) return IMCUI_ERR_ARG;
+    lf_shape(i, N, K);
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_loftr_num_norms(void) { return LF_NNORMS; }
+extern "C" int imcui_hip_loftr_norm_dim(int i) { return (i < 0 || i >= LF_NNORMS) ? -1 : lf_norm_dim(i); }
+
+// conv1: [49][128] tap-major weights + bias (BN folded by the caller); layers: W[N][K] / bias[N]
+// already in GEMM layout (convolutions as [Cout][tap][Cin_pad], BN folded, padded channels zero)
+extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* conv1_b, const float* const* w,
+                                            const float* const* b, const float* const* norms, float* packed) {
+    if (!conv1_w || !conv1_b || !w || !b || !norms || !packed) return IMCUI_ERR_ARG;
+    const LfLayout l = lf_layout();
+    memset(packed, 0, l.total * sizeof(float));
+    memcpy(packed + l.conv1_w, conv1_w, 49 * 128 * sizeof(float));
+    memcpy(packed + l.conv1_b, conv1_b, 128 * sizeof(float));
+    for (int i = 0; i < LF_NLAYERS; ++i) {
+        int N, K;
+        lf_shape(i, &N, &K);
+        if (!w[i]) return IMCUI_ERR_ARG;
+        memcpy(packed + l.w[i], w[i], (size_t)N * K * sizeof(float));
+        if (b[i]) memcpy(packed + l.b[i], b[i], (size_t)N * sizeof(float));
+        packed[l.ws[i]] = split_weights_host(w[i], (size_t)N * K, reinterpret_cast<unsigned short*>(packed + l.wh[i]),
+                                             reinterpret_cast<unsigned short*>(packed + l.wl[i]));
+    }
+    for (int i = 0; i < LF_NNORMS; ++i) {
+        if (!norms[i]) return IMCUI_ERR_ARG;
+        memcpy(packed + l.norm[i], norms[i], lf_norm_dim(i) * sizeof(float));
+    }
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+struct LfWs {
+    float *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *fc, *up3, *x2o, *y2, *x2out, *up2, *x1o, *y1, *ff;
+    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest;
+    float *X, *CG, *CW, *F, *fq, *fk, *fv, *fatt, *fm, *fh, *fo, *mconf;
+    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2;
+    size_t total;
+    bool ok;
+};
+static LfWs lf_carve(void* ws, size_t bytes, int B, int H, int W) {
+    WsAlloc a(ws, bytes);
+    LfWs w;
+    const size_t n2 = 2 * (size_t)B;
+    const size_t p2 = n2 * (H / 2) * (W / 2), p4 = n2 * (H / 4) * (W / 4), p8 = n2 * (H / 8) * (W / 8);
+    const size_t L = (size_t)(H / 8) * (W / 8);
+    const size_t cap = (size_t)B * L;
+    w.x0 = a.get<float>(p2 * 128);
+    w.t1 = a.get<float>(p2 * 128);
+    w.x1a = a.get<float>(p2 * 128);
+    w.x1 = a.get<float>(p2 * 128);
+    w.t2 = a.get<float>(p4 * CP);
+    w.ds2 = a.get<float>(p4 * CP);
+    w.x2a = a.get<float>(p4 * CP);
+    w.x2 = a.get<float>(p4 * CP);
+    w.t3 = a.get<float>(p8 * 256);
+    w.ds3 = a.get<float>(p8 * 256);
+    w.x3a = a.get<float>(p8 * 256);
+    w.x3 = a.get<float>(p8 * 256);
+    w.fc = a.get<float>(p8 * 256);
+    w.up3 = a.get<float>(p4 * 256);
+    w.x2o = a.get<float>(p4 * 256);
+    w.y2 = a.get<float>(p4 * 256);
+    w.x2out = a.get<float>(p4 * CP);
+    w.up2 = a.get<float>(p2 * CP);
+    w.x1o = a.get<float>(p2 * CP);
+    w.y1 = a.get<float>(p2 * CP);
+    w.ff = a.get<float>(p2 * 128);
+    w.q = a.get<float>(p8 * 256);
+    w.k = a.get<float>(p8 * 256);
+    w.v = a.get<float>(p8 * 256);
+    w.att = a.get<float>(p8 * 256);
+    w.m = a.get<float>(p8 * 256);
+    w.hb = a.get<float>(p8 * 512);
+    w.ob = a.get<float>(p8 * 256);
+    const size_t nchunk = (L + LA_CHUNK - 1) / LA_CHUNK;
+    w.kvpart = a.get<float>(n2 * 8 * nchunk * (32 * 32 + 32));
+    w.kv = a.get<float>(n2 * 8 * (32 * 32 + 32));
+    w.sim = a.get<float>((size_t)B * L * L);
+    w.rmax = a.get<float>(cap);
+    w.rsum = a.get<float>(cap);
+    w.cmax = a.get<float>(cap);
+    w.csum = a.get<float>(cap);
+    w.best = a.get<float>(cap);
+    w.cbest = a.get<float>(cap);
+    w.X = a.get<float>(2 * cap * 25 * 256);
+    w.CG = a.get<float>(2 * cap * 256);
+    w.CW = a.get<float>(2 * cap * 128);
+    w.F = a.get<float>(2 * cap * 25 * 128);
+    w.fq = a.get<float>(2 * cap * 25 * 128);
+    w.fk = a.get<float>(2 * cap * 25 * 128);
+    w.fv = a.get<float>(2 * cap * 25 * 128);
+    w.fatt = a.get<float>(2 * cap * 25 * 128);
+    w.fm = a.get<float>(2 * cap * 25 * 128);
+    w.fh = a.get<float>(2 * cap * 25 * 256);
+    w.fo = a.get<float>(2 * cap * 25 * 128);
+    w.mconf = a.get<float>(cap);
+    w.bestj = a.get<int>(cap);
+    w.flag = a.get<int>(cap);
+    w.mb = a.get<int>(cap);
+    w.mi = a.get<int>(cap);
+    w.mj = a.get<int>(cap);
+    w.nmatch = a.get<int>(4);
+    w.cnt2 = a.get<int>(4);
+    w.total = a.off;
+    w.ok = a.ok;
+    return w;
+}
+extern "C" size_t imcui_hip_loftr_workspace_bytes(int B, int H, int W) { return lf_carve(nullptr, 0, B, H, W).total; }
+
+// byte offsets of a few workspace buffers, for the parity tests: 0 = coarse features after the
+// transformer [2B, L, 256], 1 = fine features [2B, H/2, W/2, 128], 2 = sim [B, L, L], 3 = fine windows F
+extern "C" size_t imcui_hip_loftr_debug_offset(int which, int B, int H, int W) {
+    LfWs w = lf_carve((void*)256, (size_t)-1 >> 1, B, H, W);
+    const char* base = (const char*)256;
+    switch (which) {
+        case 0: return (const char*)w.fc - base;
+        case 1: return (const char*)w.ff - base;
+        case 2: return (const char*)w.sim - base;
+        case 3: return (const char*)w.F - base;
+        default: return 0;
+    }
+}
+
+__global__ void lf_counts_kernel(const int* nmatch, int* cnt2) {
+    cnt2[0] = *nmatch;       // rows of the per-match GEMMs
+    cnt2[1] = *nmatch * 25;  // rows of the per-window-token GEMMs
+}
+__global__ void lf_copy_int_kernel(const int* src, int* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------ forward
+extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B,
+                                       int H, int W, double match_threshold, int temp_bug_fix, float* keypoints0,
+                                       float* keypoints1, float* confidence, int* batch_indexes, int* num_matches,
+                                       void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (B <= 0) return IMCUI_OK;
+    if (H % 8 || W % 8 || H < 32 || W < 32) return imcui_set_err(h, IMCUI_ERR_ARG, "loftr: H=%d W=%d must be multiples of 8 (>= 32)", H, W);
+    if (!packed || !image0 || !image1 || !keypoints0 || !keypoints1 || !confidence || !batch_indexes || !num_matches)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "loftr: null argument");
+    const int hc = H / 8, wc = W / 8;
+    if (hc > 256 || wc > 256) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "loftr: coarse map %dx%d exceeds the 256x256 positional encoding", hc, wc);
+    LfWs w = lf_carve(ws, ws_bytes, B, H, W);
+    if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "loftr: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const LfLayout l = lf_layout();
+    const float* P = packed;
+    const bool split = h->precision == 1;
+    const int n2 = 2 * B;
+    const int L = hc * wc;
+    const int cap = B * L;
+    int rc;
+#define LFRUN(x)                       \
+    do {                               \
+        rc = (x);                      \
+        if (rc != IMCUI_OK) return rc; \
+    } while (0)
+
+    auto wts = [&](GemmP& g, int li) {
+        int N, K;
+        lf_shape(li, &N, &K);
+        g.N = N;
+        g.K = K;
+        g.ldw = K;
+        g.W = P + l.w[li];
+        g.bias = P + l.b[li];
+        if (split) {
+            g.Wh = reinterpret_cast<const unsigned short*>(P + l.wh[li]);
+            g.Wl = reinterpret_cast<const unsigned short*>(P + l.wl[li]);
+            g.wscale = P + l.ws[li];
+        }
+    };
+    // conv as GEMM over NHWC: in [n2, hin, win, cin] -> out [n2, hout, wout, N]
+    auto conv = [&](int li, const float* in, float* out, int hin, int win, int cin, int ks, int stride, const float* resid,
+                    int act) -> int {
+        GemmP g;
+        wts(g, li);
+        g.epi = EPI_CONV;
+        const int pad = ks / 2;
+        const int hout = (hin + 2 * pad - ks) / stride + 1, wout = (win + 2 * pad - ks) / stride + 1;
+        g.A = in;
+        g.conv_k = ks;
+        g.conv_stride = stride;
+        g.conv_pad = pad;
+        g.conv_hin = hin;
+        g.conv_win = win;
+        g.conv_hout = hout;
+        g.conv_wout = wout;
+        g.conv_cin = cin;
+        g.M = n2 * hout * wout;
+        g.C = out;
+        g.ldc = g.N;
+        g.resid = resid;
+        g.ldr = g.N;
+        g.act = act;
+        return gemm_launch(h, g, stream);
+    };
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    // ---- a13: ResNetFPN_8_2
+    {
+        const long npix = (long)B * H2 * W2;
+        long blocks = min((npix + 15) / 16, (long)256 * 32);
+        hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, image0, P + l.conv1_w, P + l.conv1_b,
+                           w.x0, H, W, H2, W2, npix);
+        hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, image1, P + l.conv1_w, P + l.conv1_b,
+                           w.x0 + (size_t)npix * 128, H, W, H2, W2, npix);
+        IMCUI_CHECK_LAUNCH(h);
+    }
+    LFRUN(conv(LF_L1_0_C1, w.x0, w.t1, H2, W2, 128, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L1_0_C2, w.t1, w.x1a, H2, W2, 128, 3, 1, w.x0, 1));
+    LFRUN(conv(LF_L1_1_C1, w.x1a, w.t1, H2, W2, 128, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L1_1_C2, w.t1, w.x1, H2, W2, 128, 3, 1, w.x1a, 1));
+    LFRUN(conv(LF_L2_0_C1, w.x1, w.t2, H2, W2, 128, 3, 2, nullptr, 1));
+    LFRUN(conv(LF_L2_0_DS, w.x1, w.ds2, H2, W2, 128, 1, 2, nullptr, 0));
+    LFRUN(conv(LF_L2_0_C2, w.t2, w.x2a, H4, W4, CP, 3, 1, w.ds2, 1));
+    LFRUN(conv(LF_L2_1_C1, w.x2a, w.t2, H4, W4, CP, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L2_1_C2, w.t2, w.x2, H4, W4, CP, 3, 1, w.x2a, 1));
+    LFRUN(conv(LF_L3_0_C1, w.x2, w.t3, H4, W4, CP, 3, 2, nullptr, 1));
+    LFRUN(conv(LF_L3_0_DS, w.x2, w.ds3, H4, W4, CP, 1, 2, nullptr, 0));
+    LFRUN(conv(LF_L3_0_C2, w.t3, w.x3a, hc, wc, 256, 3, 1, w.ds3, 1));
+    LFRUN(conv(LF_L3_1_C1, w.x3a, w.t3, hc, wc, 256, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L3_1_C2, w.t3, w.x3, hc, wc, 256, 3, 1, w.x3a, 1));
+    LFRUN(conv(LF_OUT3, w.x3, w.fc, hc, wc, 256, 1, 1, nullptr, 0));
+    auto upsample = [&](const float* in, float* out, int hh, int ww, int C) {
+        const long n4 = (long)n2 * (2 * hh) * (2 * ww) * (C / 4);
+        hipLaunchKernelGGL(lf_upsample2_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), dim3(256), 0, stream, in,
+                           out, hh, ww, C, n4);
+    };
+    upsample(w.fc, w.up3, hc, wc, 256);
+    LFRUN(conv(LF_OUT2, w.x2, w.x2o, H4, W4, CP, 1, 1, w.up3, 0));
+    LFRUN(conv(LF_OUT2B_0, w.x2o, w.y2, H4, W4, 256, 3, 1, nullptr, 2));
+    LFRUN(conv(LF_OUT2B_3, w.y2, w.x2out, H4, W4, 256, 3, 1, nullptr, 0));
+    upsample(w.x2out, w.up2, H4, W4, CP);
+    LFRUN(conv(LF_OUT1, w.x1, w.x1o, H2, W2, 128, 1, 1, w.up2, 0));
+    LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, H2, W2, CP, 3, 1, nullptr, 2));
+    LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, H2, W2, CP, 3, 1, nullptr, 0));
+
+    // ---- a14: positional encoding + coarse LocalFeatureTransformer (linear attention)
+    {
+        const long n = (long)n2 * L * 256;
+        hipLaunchKernelGGL(lf_posenc_kernel, dim3((unsigned)min((n + 255) / 256, (long)65536)), dim3(256), 0, stream, w.fc, hc,
+                           wc, 256, n, temp_bug_fix);
+    }
+    auto lin = [&](int li, const float* A, long lda, const float* A2, float* C, long rows, int relu, const int* mcnt) -> int {
+        GemmP g;
+        wts(g, li);
+        g.bias = nullptr;  // transformer Linears have no bias
+        g.epi = relu ? EPI_RELU : EPI_BIAS;
+        g.A = A;
+        g.lda = lda;
+        if (A2) {
+            g.A2 = A2;
+            g.lda2 = lda;
+            g.K1 = (int)lda;
+        }
+        g.C = C;
+        g.ldc = g.N;
+        g.M = (int)rows;
+        g.mcnt = mcnt;
+        g.cnt_stride = 0;
+        return gemm_launch(h, g, stream);
+    };
+    const int nchunk = cdiv(L, LA_CHUNK);
+    // encoder layer on query sequences [qs0, qs0+ns) with source sequences [ss0, ss0+ns)
+    auto coarse_layer = [&](int layer, int qs0, int ss0, int ns) -> int {
+        const int base = LF_COARSE0 + layer * 6;
+        const size_t qo = (size_t)qs0 * L * 256, so = (size_t)ss0 * L * 256;
+        const long rows = (long)ns * L;
+        int r;
+        if ((r = lin(base + 0, w.fc + qo, 256, nullptr, w.q + qo, rows, 0, nullptr))) return r;
+        if ((r = lin(base + 1, w.fc + so, 256, nullptr, w.k + so, rows, 0, nullptr))) return r;
+        if ((r = lin(base + 2, w.fc + so, 256, nullptr, w.v + so, rows, 0, nullptr))) return r;
+        hipLaunchKernelGGL(lf_la_kv_partial_kernel<32>, dim3(nchunk, 8, ns), dim3(256), 0, stream, w.k + so, w.v + so, L, 8,
+                           w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk);
+        hipLaunchKernelGGL(lf_la_kv_reduce_kernel<32>, dim3(ns * 8), dim3(256), 0, stream,
+                           w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk, w.kv + (size_t)ss0 * 8 * 1056);
+        const size_t smem = (8 * 1056 + 4 * 256) * sizeof(float);
+        hipLaunchKernelGGL(lf_la_apply_kernel<32>, dim3(cdiv(L, 64), ns), dim3(256), smem, stream, w.q, w.kv, qs0, ss0, L, L, 8,
+                           w.att);
+        if ((r = lin(base + 3, w.att + qo, 256, nullptr, w.m + qo, rows, 0, nullptr))) return r;
+        const float* n1w = P + l.norm[layer * 4 + 0];
+        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.m + qo, n1w,
+                           P + l.norm[layer * 4 + 1], (const float*)nullptr, w.m + qo, rows, 0);
+        if ((r = lin(base + 4, w.fc + qo, 256, w.m + qo, w.hb + (size_t)qs0 * L * 512, rows, 1, nullptr))) return r;
+        if ((r = lin(base + 5, w.hb + (size_t)qs0 * L * 512, 512, nullptr, w.ob + qo, rows, 0, nullptr))) return r;
+        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.ob + qo,
+                           P + l.norm[layer * 4 + 2], P + l.norm[layer * 4 + 3], w.fc + qo, w.fc + qo, rows, 1);
+        return IMCUI_OK;
+    };
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lf_la_apply_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (8 * 1056 + 4 * 256) * (int)sizeof(float));
+    for (int layer = 0; layer < 8; ++layer) {
+        if ((layer & 1) == 0) {
+            LFRUN(coarse_layer(layer, 0, 0, n2));  // self: both images, sources = themselves
+        } else {
+            LFRUN(coarse_layer(layer, 0, B, B));  // feat0 <- layer(feat0, feat1)
+            LFRUN(coarse_layer(layer, B, 0, B));  // feat1 <- layer(feat1, updated feat0)
+        }
+    }
+    IMCUI_CHECK_LAUNCH(h);
+
+    // ---- a15: dual-softmax coarse matching
+    {
+        GemmP g;  // sim = (f0 / 16) . (f1 / 16)^T / 0.1
+        g.epi = EPI_BIAS;
+        g.batch = B;
+        g.A = w.fc;
+        g.lda = 256;
+        g.a_bs = (long)L * 256;
+        g.W = w.fc + (size_t)B * L * 256;
+        g.ldw = 256;
+        g.w_bs = (long)L * 256;
+        g.C = w.sim;
+        g.ldc = L;
+        g.c_bs = (long)L * L;
+        g.M = L;
+        g.N = L;
+        g.K = 256;
+        g.alpha = 0.00390625f / 0.1f;
+        LFRUN(gemm_launch(h, g, stream));
+    }
+    const dim3 rg(cdiv(L, 4), B), cg(cdiv(L, 64), B), blk(256);
+    hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum);
+    hipLaunchKernelGGL(lf_colstat_kernel, cg, blk, 0, stream, w.sim, L, L, w.cmax, w.csum);
+    // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
+    hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
+    hipLaunchKernelGGL(lf_colbest_kernel, cg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.cbest);
+    hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, L, wc, hc, wc, hc, 2,
+                       (float)match_threshold, w.flag, (long)cap);
+    hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi,
+                       w.mj, w.mconf, w.nmatch);
+    hipLaunchKernelGGL(lf_counts_kernel, dim3(1), dim3(1), 0, stream, w.nmatch, w.cnt2);
+    IMCUI_CHECK_LAUNCH(h);
+
+    // ---- a16: fine level on the 5x5 windows of the matches
+    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap, H2, W2,
+                       hc, wc, 4, w.X, w.CG);
+    auto lin_b = [&](int li, const float* A, long lda, const float* A2, float* C, long side_rows_cap, int relu, int per_token,
+                     int side0, int nsides, bool with_bias) -> int {
+        // rows of side s start at s * side_rows_cap; valid rows = nmatch (* 25)
+        GemmP g;
+        wts(g, li);
+        if (!with_bias) g.bias = nullptr;
+        g.epi = relu ? EPI_RELU : EPI_BIAS;
+        g.batch = nsides;
+        g.A = A + (size_t)side0 * side_rows_cap * lda;
+        g.lda = lda;
+        g.a_bs = side_rows_cap * lda;
+        if (A2) {
+            g.A2 = A2 + (size_t)side0 * side_rows_cap * lda;
+            g.lda2 = lda;
+            g.K1 = (int)lda;
+        }
+        g.C = C + (size_t)side0 * side_rows_cap * g.N;
+        g.ldc = g.N;
+        g.c_bs = side_rows_cap * g.N;
+        g.M = (int)side_rows_cap;
+        g.mcnt = w.cnt2 + (per_token ? 1 : 0);
+        g.cnt_stride = 0;
+        return gemm_launch(h, g, stream);
+    };
+    LFRUN(lin_b(LF_DOWN, w.CG, 256, nullptr, w.CW, cap, 0, 0, 0, 2, true));
+    hipLaunchKernelGGL(lf_fine_fill_kernel, dim3(cap, 2), blk, 0, stream, w.CW, w.nmatch, cap, w.X);
+    const long wcap = (long)cap * 25;
+    LFRUN(lin_b(LF_MERGEF, w.X, 256, nullptr, w.F, wcap, 0, 1, 0, 2, true));
+    auto fine_layer = [&](int layer, int side0, int nsides, int cross) -> int {
+        const int base = LF_FINE0 + layer * 6;
+        const int src0 = cross ? 1 - side0 : side0;
+        int r;
+        if ((r = lin_b(base + 0, w.F, 128, nullptr, w.fq, wcap, 0, 1, side0, nsides, false))) return r;
+        if ((r = lin_b(base + 1, w.F, 128, nullptr, w.fk, wcap, 0, 1, src0, nsides, false))) return r;
+        if ((r = lin_b(base + 2, w.F, 128, nullptr, w.fv, wcap, 0, 1, src0, nsides, false))) return r;
+        hipLaunchKernelGGL(lf_la_window_kernel, dim3(cap, nsides), blk, 0, stream, w.fq, w.fk, w.fv, w.nmatch, cap, side0, cross,
+                           w.fatt);
+        if ((r = lin_b(base + 3, w.fatt, 128, nullptr, w.fm, wcap, 0, 1, side0, nsides, false))) return r;
+        const int nl = 32 + layer * 4;
+        // LayerNorm over every (capacity) row of the processed sides: rows past nmatch*25 hold stale data and are never read
+        const long rows = (long)nsides * wcap;
+        float* fm0 = w.fm + (size_t)side0 * wcap * 128;
+        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, fm0, P + l.norm[nl + 0],
+                           P + l.norm[nl + 1], (const float*)nullptr, fm0, rows, 0);
+        if ((r = lin_b(base + 4, w.F, 128, w.fm, w.fh, wcap, 1, 1, side0, nsides, false))) return r;
+        if ((r = lin_b(base + 5, w.fh, 256, nullptr, w.fo, wcap, 0, 1, side0, nsides, false))) return r;
+        float* fo0 = w.fo + (size_t)side0 * wcap * 128;
+        float* f0 = w.F + (size_t)side0 * wcap * 128;
+        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, fo0, P + l.norm[nl + 2],
+                           P + l.norm[nl + 3], f0, f0, rows, 1);
+        return IMCUI_OK;
+    };
+    LFRUN(fine_layer(0, 0, 2, 0));  // self on both windows
+    LFRUN(fine_layer(1, 0, 1, 1));  // cross: window0 <- (window0, window1)
+    LFRUN(fine_layer(1, 1, 1, 1));  //        window1 <- (window1, updated window0)
+    hipLaunchKernelGGL(lf_fine_match_kernel, dim3(cdiv(cap, 4)), blk, 0, stream, w.F, w.mi, w.mj, w.nmatch, cap, wc, wc,
+                       (float)H / (float)hc, (float)H / (float)H2, keypoints0, keypoints1);
+    hipMemcpyAsync(confidence, w.mconf, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    hipLaunchKernelGGL(lf_copy_int_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.mb, batch_indexes, cap);
+    hipLaunchKernelGGL(lf_copy_int_kernel, dim3(1), dim3(64), 0, stream, w.nmatch, num_matches, 1);
+    IMCUI_CHECK_LAUNCH(h);
+#undef LFRUN
+    return IMCUI_OK;
+}

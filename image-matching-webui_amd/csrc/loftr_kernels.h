@@ -1,0 +1,505 @@
+// Device kernels of the LoFTR path that are not GEMM-shaped:
+// first 7x7 conv, bilinear up-sampling, positional encoding, linear attention, LayerNorm,
+// dual-softmax coarse matching, fine window gather and fine matching.  Included by loftr.hip only.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------ conv1: 7x7 stride 2 pad 3, 1 -> 128 (+folded BN, ReLU)
+// 16 lanes x 8 channels cover the 128 output channels of one pixel; a wave stores 4 pixels
+// (4 x 512 B contiguous NHWC).  w: [49][128], bias [128].
+__global__ __launch_bounds__(256) void lf_conv7_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                       int W, int Ho, int Wo, long npix) {
+    const int c8 = (threadIdx.x & 15) * 8;
+    const long stride = (long)gridDim.x * 16;
+    for (long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += stride) {
+        const int ox = (int)(p % Wo);
+        const long q = p / Wo;
+        const int oy = (int)(q % Ho);
+        const float* img = in + (q / Ho) * (long)H * W;
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = bias[c8 + j];
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = oy * 2 - 3 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const int ix = ox * 2 - 3 + kx;
+                const float v = (ix >= 0 && ix < W) ? img[(long)iy * W + ix] : 0.0f;
+                const float4 k0 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * 128 + c8);
+                const float4 k1 = *reinterpret_cast<const float4*>(w + (ky * 7 + kx) * 128 + c8 + 4);
+                a[0] = fmaf(v, k0.x, a[0]);
+                a[1] = fmaf(v, k0.y, a[1]);
+                a[2] = fmaf(v, k0.z, a[2]);
+                a[3] = fmaf(v, k0.w, a[3]);
+                a[4] = fmaf(v, k1.x, a[4]);
+                a[5] = fmaf(v, k1.y, a[5]);
+                a[6] = fmaf(v, k1.z, a[6]);
+                a[7] = fmaf(v, k1.w, a[7]);
+            }
+        }
+        float* o = out + p * 128 + c8;
+        *reinterpret_cast<float4*>(o) = make_float4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        *reinterpret_cast<float4*>(o + 4) = make_float4(fmaxf(a[4], 0.f), fmaxf(a[5], 0.f), fmaxf(a[6], 0.f), fmaxf(a[7], 0.f));
+    }
+}
+
+// ------------------------------------------------------------------ bilinear x2, align_corners=True (NHWC)
+// out[b, oy, ox, :] = interp(in[b], oy * (h-1)/(2h-1), ox * (w-1)/(2w-1))
+__global__ __launch_bounds__(256) void lf_upsample2_kernel(const float* __restrict__ in, float* __restrict__ out, int h,
+                                                           int w, int C, long nout4) {
+    const int C4 = C >> 2;
+    const int Ho = 2 * h, Wo = 2 * w;
+    const float sy = (Ho > 1) ? (float)(h - 1) / (float)(Ho - 1) : 0.0f;
+    const float sx = (Wo > 1) ? (float)(w - 1) / (float)(Wo - 1) : 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nout4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        long t = i / C4;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long b = t / Ho;
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* base = in + b * (long)h * w * C + c4 * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x0) * C);
+        const float4 v01 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x1) * C);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x0) * C);
+        const float4 v11 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x1) * C);
+        float4 o;
+        // ATen upsample_bilinear2d: h0lambda * (w0lambda * v00 + w1lambda * v01) + h1lambda * (w0lambda * v10 + w1lambda * v11)
+        o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        *reinterpret_cast<float4*>(out + i * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------ PositionEncodingSine (added in place, NHWC tokens)
+// channel 4g+0 = sin(x*div_g), 4g+1 = cos(x*div_g), 4g+2 = sin(y*div_g), 4g+3 = cos(y*div_g); x, y 1-based.
+__global__ __launch_bounds__(256) void lf_posenc_kernel(float* __restrict__ feat, int hc, int wc, int C, long n,
+                                                        int temp_bug_fix) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long t = i / C;
+        const int x = (int)(t % wc), y = (int)((t / wc) % hc);
+        const int g = c >> 2;
+        // div_term = exp(arange(0, C/2, 2) * (-ln(1e4) / (C/2)))   [fixed]
+        //          = exp(arange(0, C/2, 2) * (-ln(1e4) / C // 2))   [released weights: == -1.0 for C = 256]
+        const float kf = (float)(2 * g);
+        const float coef = temp_bug_fix ? (-9.210340371976184f / (float)(C / 2)) : floorf((-9.210340371976184f / (float)C) / 2.0f);
+        const float div = expf(kf * coef);
+        const float pos = (float)(((c & 2) ? y : x) + 1);
+        const float arg = pos * div;
+        feat[i] += (c & 1) ? cosf(arg) : sinf(arg);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm over D = 64 * VEC features, one wave per row
+// mode 0: y = LN(x)   mode 1: y = res + LN(x)   (y may alias res)
+template <int VEC>
+__global__ __launch_bounds__(256) void lf_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* res,
+                                                           float* y, long rows, int mode) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int D = 64 * VEC;
+    float v[VEC];
+    const float* xr = x + row * D + lane * VEC;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        v[j] = xr[j];
+        s += v[j];
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        v[j] -= mean;
+        q += v[j] * v[j];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        float o = v[j] * rstd * gamma[lane * VEC + j] + beta[lane * VEC + j];
+        if (mode == 1) o += res[row * D + lane * VEC + j];
+        y[row * D + lane * VEC + j] = o;
+    }
+}
+
+#define LA_CHUNK 128
+__device__ __forceinline__ float lf_elu1(float x) { return x > 0.0f ? x + 1.0f : (expf(x) - 1.0f) + 1.0f; }
+
+// ------------------------------------------------------------------ linear attention, long sequences (coarse level)
+// K, V: [nseq * L, heads * HD] rows of the SOURCE sequences.  Pass 1 reduces chunks of 128 tokens to
+// partial KV[d][v] (K' = elu(k)+1, values pre-divided by L) and Ksum[d]; pass 2 adds the partials in a
+// fixed order (deterministic, no atomics).
+template <int HD>
+__global__ __launch_bounds__(256) void lf_la_kv_partial_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                               int L, int heads, float* __restrict__ part, int nchunk) {
+    __shared__ float Ks[LA_CHUNK * HD], Vs[LA_CHUNK * HD];
+    const int chunk = blockIdx.x, h = blockIdx.y, seq = blockIdx.z;
+    const int D = heads * HD;
+    const int t0 = chunk * LA_CHUNK;
+    const int nt = min(LA_CHUNK, L - t0);
+    for (int i = threadIdx.x; i < LA_CHUNK * HD; i += 256) {
+        const int t = i / HD, d = i - t * HD;
+        float kv = 0.0f, vv = 0.0f;
+        if (t < nt) {
+            const size_t o = ((size_t)seq * L + t0 + t) * D + h * HD + d;
+            kv = lf_elu1(K[o]);
+            vv = V[o] / (float)L;
+        }
+        Ks[i] = kv;
+        Vs[i] = vv;
+    }
+    __syncthreads();
+    // HD*HD outputs (+ HD sums): thread -> (d, group of v)
+    constexpr int NV = HD * HD / 256;  // outputs per thread: 4 (HD 32) or 1 (HD 16)
+    const int d = threadIdx.x / (HD / NV), v0 = (threadIdx.x % (HD / NV)) * NV;
+    float acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = 0.0f;
+    float ks = 0.0f;
+    for (int t = 0; t < nt; ++t) {
+        const float kk = Ks[t * HD + d];
+        ks += kk;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] = fmaf(kk, Vs[t * HD + v0 + j], acc[j]);
+    }
+    float* o = part + (((size_t)seq * heads + h) * nchunk + chunk) * (HD * HD + HD);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) o[d * HD + v0 + j] = acc[j];
+    if (v0 == 0) o[HD * HD + d] = ks;
+}
+
+template <int HD>
+__global__ void lf_la_kv_reduce_kernel(const float* __restrict__ part, int nchunk, float* __restrict__ kv) {
+    const int gh = blockIdx.x;  // seq * heads + h
+    constexpr int N = HD * HD + HD;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float s = 0.0f;
+        for (int c = 0; c < nchunk; ++c) s += part[((size_t)gh * nchunk + c) * N + i];
+        kv[(size_t)gh * N + i] = s;
+    }
+}
+
+// message[l, h, v] = (sum_d Q'[l,h,d] KV[h][d][v]) * Z[l,h] * L,  Z = 1 / (Q'[l,h,:] . Ksum[h] + 1e-6)
+// one wave per token; lane -> HD/ (64/heads) ... generic: lane handles D/64 consecutive outputs
+template <int HD>
+__global__ __launch_bounds__(256) void lf_la_apply_kernel(const float* __restrict__ Q, const float* __restrict__ kv,
+                                                          int seq0, int src_seq0, int L, int Lsrc, int heads,
+                                                          float* __restrict__ out) {
+    extern __shared__ float la_smem[];  // [heads][HD*HD + HD] of this block's source sequence, then 4 x D query rows
+    const int D = heads * HD;
+    constexpr int N = HD * HD + HD;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // 64 tokens of one query sequence per block; Q / out are indexed by absolute token row
+    const int seq = seq0 + blockIdx.y;
+    const int sseq = src_seq0 + blockIdx.y;
+    const long row0 = (long)seq * L + (long)blockIdx.x * 64;
+    float* kvs = la_smem;
+    float* qs = la_smem + heads * N + wv * D;
+    for (int i = threadIdx.x; i < heads * N; i += 256) kvs[i] = kv[(size_t)sseq * heads * N + i];
+    __syncthreads();
+    const int per = D / 64;  // outputs per lane (4 for D = 256, 2 for D = 128)
+    for (int tt = wv; tt < 64; tt += 4) {
+        const long row = row0 + tt;
+        if (row >= (long)(seq + 1) * L) break;
+        for (int i = lane; i < D; i += 64) qs[i] = lf_elu1(Q[row * D + i]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int c0 = lane * per;
+        const int h = c0 / HD, v0 = c0 - h * HD;
+        const float* kh = kvs + h * N;
+        float z = 0.0f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < HD; ++d) {
+            const float qd = qs[h * HD + d];
+            z = fmaf(qd, kh[HD * HD + d], z);
+            for (int j = 0; j < per; ++j) acc[j] = fmaf(qd, kh[d * HD + v0 + j], acc[j]);
+        }
+        const float Z = 1.0f / (z + 1e-6f);
+        for (int j = 0; j < per; ++j) out[row * D + c0 + j] = acc[j] * Z * (float)Lsrc;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ dual-softmax coarse matching on sim [B, L, S]
+// row / column statistics (max, sum of exp) -> conf(i,j) = softmax_col(i,j) * softmax_row(i,j)
+__global__ __launch_bounds__(256) void lf_rowstat_kernel(const float* __restrict__ sim, int L, int S,
+                                                         float* __restrict__ rmax, float* __restrict__ rsum) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= L) return;
+    const float* row = sim + ((size_t)b * L + i) * S;
+    float m = -INFINITY;
+    for (int j = lane; j < S; j += 64) m = fmaxf(m, row[j]);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int j = lane; j < S; j += 64) s += expf(row[j] - m);
+    s = wave_sum(s);
+    if (lane == 0) {
+        rmax[(size_t)b * L + i] = m;
+        rsum[(size_t)b * L + i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void lf_colstat_kernel(const float* __restrict__ sim, int L, int S,
+                                                         float* __restrict__ cmax, float* __restrict__ csum) {
+    __shared__ float sm[4][64], ss[4][64];
+    const int b = blockIdx.y;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const float* base = sim + (size_t)b * L * S;
+    float m = -INFINITY;
+    if (j < S)
+        for (int i = g; i < L; i += 4) m = fmaxf(m, base[(size_t)i * S + j]);
+    sm[g][c] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+    float s = 0.0f;
+    if (j < S)
+        for (int i = g; i < L; i += 4) s += expf(base[(size_t)i * S + j] - m);
+    ss[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < S) {
+        cmax[(size_t)b * S + j] = m;
+        csum[(size_t)b * S + j] = ss[0][c] + ss[1][c] + ss[2][c] + ss[3][c];
+    }
+}
+// conf = softmax(sim, dim=1)[i,j] * softmax(sim, dim=2)[i,j]   (dim 1 = over i / L, dim 2 = over j / S)
+__device__ __forceinline__ float lf_conf(float s, float cm, float cs, float rm, float rs) {
+    return (expf(s - cm) / cs) * (expf(s - rm) / rs);
+}
+// per row: max_j conf and the first j attaining it
+__global__ __launch_bounds__(256) void lf_rowbest_kernel(const float* __restrict__ sim, int L, int S,
+                                                         const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                         const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                         float* __restrict__ best, int* __restrict__ bestj) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= L) return;
+    const float* row = sim + ((size_t)b * L + i) * S;
+    const float rm = rmax[(size_t)b * L + i], rs = rsum[(size_t)b * L + i];
+    float bv = -1.0f;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < S; j += 64) {
+        const float v = lf_conf(row[j], cmax[(size_t)b * S + j], csum[(size_t)b * S + j], rm, rs);
+        if (v > bv) {
+            bv = v;
+            bj = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oj = __shfl_xor(bj, o, 64);
+        if (ov > bv || (ov == bv && oj < bj)) {
+            bv = ov;
+            bj = oj;
+        }
+    }
+    if (lane == 0) {
+        best[(size_t)b * L + i] = bv;
+        bestj[(size_t)b * L + i] = bj;
+    }
+}
+// per column: max_i conf
+__global__ __launch_bounds__(256) void lf_colbest_kernel(const float* __restrict__ sim, int L, int S,
+                                                         const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                         const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                         float* __restrict__ cbest) {
+    __shared__ float sv[4][64];
+    const int b = blockIdx.y;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const float* base = sim + (size_t)b * L * S;
+    float bv = -1.0f;
+    if (j < S) {
+        const float cm = cmax[(size_t)b * S + j], cs = csum[(size_t)b * S + j];
+        for (int i = g; i < L; i += 4)
+            bv = fmaxf(bv, lf_conf(base[(size_t)i * S + j], cm, cs, rmax[(size_t)b * L + i], rsum[(size_t)b * L + i]));
+    }
+    sv[g][c] = bv;
+    __syncthreads();
+    if (g == 0 && j < S) cbest[(size_t)b * S + j] = fmaxf(fmaxf(sv[0][c], sv[1][c]), fmaxf(sv[2][c], sv[3][c]));
+}
+// per row decision: conf > thr, border, mutual; flag[b*L+i] = 1/0
+__global__ void lf_decide_kernel(const float* __restrict__ best, const int* __restrict__ bestj,
+                                 const float* __restrict__ cbest, int L, int S, int w0c, int h0c, int w1c, int h1c, int bd,
+                                 float thr, int* __restrict__ flag, long n) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int b = (int)(t / L), i = (int)(t - (long)b * L);
+    const int j = bestj[t];
+    const float v = best[t];
+    const int y0 = i / w0c, x0 = i - y0 * w0c, y1 = j / w1c, x1 = j - y1 * w1c;
+    bool ok = v > thr && v == cbest[(size_t)b * S + j];
+    ok = ok && y0 >= bd && y0 < h0c - bd && x0 >= bd && x0 < w0c - bd && y1 >= bd && y1 < h1c - bd && x1 >= bd && x1 < w1c - bd;
+    flag[t] = ok ? 1 : 0;
+}
+// ordered compaction of the flagged rows (torch.where order: batch-major, i ascending); single block
+__global__ __launch_bounds__(1024) void lf_compact_kernel(const int* __restrict__ flag, const float* __restrict__ best,
+                                                          const int* __restrict__ bestj, int L, long n, int cap,
+                                                          int* __restrict__ mb, int* __restrict__ mi, int* __restrict__ mj,
+                                                          float* __restrict__ mconf, int* __restrict__ nmatch) {
+    __shared__ int wsum[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (long base = 0; base < n; base += 1024) {
+        const long t = base + tid;
+        const bool f = (t < n) && flag[t] != 0;
+        const unsigned long long bal = __ballot(f);
+        const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wv) woff += wsum[w];
+            tot += wsum[w];
+        }
+        const int pos = s_run + woff + wrank;
+        if (f && pos < cap) {
+            mb[pos] = (int)(t / L);
+            mi[pos] = (int)(t % L);
+            mj[pos] = bestj[t];
+            mconf[pos] = best[t];
+        }
+        __syncthreads();
+        if (tid == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *nmatch = min(s_run, cap);
+}
+
+// ------------------------------------------------------------------ fine level
+// gather: row (side, m, ww) of X [2*cap*25, 256] = [ unfold 5x5 window of feat_f (128) | coarse feature (128, filled later) ]
+// also gathers the coarse transformer features of the match into CG [2*cap, 256]
+__global__ __launch_bounds__(256) void lf_fine_gather_kernel(const float* __restrict__ feat_f, const float* __restrict__ feat_c,
+                                                             const int* __restrict__ mb, const int* __restrict__ mi,
+                                                             const int* __restrict__ mj, const int* __restrict__ nmatch,
+                                                             int B, int cap, int hf, int wf, int hc, int wc, int stride,
+                                                             float* __restrict__ X, float* __restrict__ CG) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x, side = blockIdx.y;
+    if (m >= *nmatch) return;
+    const int b = mb[m];
+    const int cell = side ? mj[m] : mi[m];
+    const int img = side * B + b;  // image index in the concatenated batch
+    const int cy = cell / wc, cx = cell - cy * wc;
+    const size_t wrow0 = ((size_t)side * cap + m) * 25;
+    for (int ww = threadIdx.x >> 6; ww < 25; ww += 4) {
+        const int fy = cy * stride + ww / 5 - 2, fx = cx * stride + ww % 5 - 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (fy >= 0 && fy < hf && fx >= 0 && fx < wf)
+            v = *reinterpret_cast<const float2*>(feat_f + (((size_t)img * hf + fy) * wf + fx) * 128 + lane * 2);
+        *reinterpret_cast<float2*>(X + (wrow0 + ww) * 256 + lane * 2) = v;
+    }
+    if (threadIdx.x < 64) {
+        const float4 c = *reinterpret_cast<const float4*>(feat_c + ((size_t)img * hc * wc + cell) * 256 + lane * 4);
+        *reinterpret_cast<float4*>(CG + ((size_t)side * cap + m) * 256 + lane * 4) = c;
+    }
+}
+// broadcast the projected coarse feature CW [2*cap, 128] into columns 128..255 of every window row
+__global__ __launch_bounds__(256) void lf_fine_fill_kernel(const float* __restrict__ CW, const int* __restrict__ nmatch,
+                                                           int cap, float* __restrict__ X) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x, side = blockIdx.y;
+    if (m >= *nmatch) return;
+    const float2 c = *reinterpret_cast<const float2*>(CW + ((size_t)side * cap + m) * 128 + lane * 2);
+    for (int ww = threadIdx.x >> 6; ww < 25; ww += 4)
+        *reinterpret_cast<float2*>(X + (((size_t)side * cap + m) * 25 + ww) * 256 + 128 + lane * 2) = c;
+}
+
+// linear attention on 25-token windows, D = 128, 8 heads x 16: one block per (match, side)
+__global__ __launch_bounds__(256) void lf_la_window_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                           const float* __restrict__ V, const int* __restrict__ nmatch,
+                                                           int cap, int side0, int cross, float* __restrict__ out) {
+    __shared__ float Ks[25 * 128], Vs[25 * 128], Qs[25 * 128], KV[8 * 16 * 16], KS[128];
+    const int m = blockIdx.x, side = side0 + blockIdx.y;  // absolute side; all pointers are un-offset
+    if (m >= *nmatch) return;
+    const size_t qrow0 = ((size_t)side * cap + m) * 25;
+    const size_t srow0 = ((size_t)(cross ? 1 - side : side) * cap + m) * 25;
+    for (int i = threadIdx.x; i < 25 * 128; i += 256) {
+        Ks[i] = lf_elu1(K[srow0 * 128 + i]);
+        Vs[i] = V[srow0 * 128 + i] / 25.0f;
+        Qs[i] = lf_elu1(Q[qrow0 * 128 + i]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 8 * 16 * 16; e += 256) {
+        const int h = e >> 8, d = (e >> 4) & 15, v = e & 15;
+        float a = 0.0f;
+        for (int t = 0; t < 25; ++t) a = fmaf(Ks[t * 128 + h * 16 + d], Vs[t * 128 + h * 16 + v], a);
+        KV[e] = a;
+    }
+    if (threadIdx.x < 128) {
+        float a = 0.0f;
+        for (int t = 0; t < 25; ++t) a += Ks[t * 128 + threadIdx.x];
+        KS[threadIdx.x] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 25 * 128; i += 256) {
+        const int t = i >> 7, c = i & 127, h = c >> 4, v = c & 15;
+        float z = 0.0f, a = 0.0f;
+        for (int d = 0; d < 16; ++d) {
+            const float qd = Qs[t * 128 + h * 16 + d];
+            z = fmaf(qd, KS[h * 16 + d], z);
+            a = fmaf(qd, KV[(h * 16 + d) * 16 + v], a);
+        }
+        out[qrow0 * 128 + i] = a * (1.0f / (z + 1e-6f)) * 25.0f;
+    }
+}
+
+// fine matching: heat = softmax(<f0[center], f1[r]> / sqrt(128)) over the 25 cells, expectation of the
+// normalised grid, key-points in image pixels.  One wave per match.
+__global__ __launch_bounds__(256) void lf_fine_match_kernel(const float* __restrict__ F, const int* __restrict__ mi,
+                                                            const int* __restrict__ mj, const int* __restrict__ nmatch,
+                                                            int cap, int w0c, int w1c, float scale_c, float scale_f,
+                                                            float* __restrict__ kp0, float* __restrict__ kp1) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= *nmatch) return;
+    const float* f0 = F + (((size_t)0 * cap + m) * 25 + 12) * 128;
+    const float* f1 = F + ((size_t)1 * cap + m) * 25 * 128;
+    const float2 c = *reinterpret_cast<const float2*>(f0 + lane * 2);
+    float sim[25];
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+        const float2 v = *reinterpret_cast<const float2*>(f1 + r * 128 + lane * 2);
+        sim[r] = wave_sum(c.x * v.x + c.y * v.y) * 0.08838834764831845f;  // 1 / sqrt(128)
+    }
+    float mx = sim[0];
+#pragma unroll
+    for (int r = 1; r < 25; ++r) mx = fmaxf(mx, sim[r]);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+        sim[r] = expf(sim[r] - mx);
+        sum += sim[r];
+    }
+    float ex = 0.0f, ey = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+        const float hv = sim[r] / sum;
+        ex += (-1.0f + 0.5f * (float)(r % 5)) * hv;  // linspace(-1, 1, 5)
+        ey += (-1.0f + 0.5f * (float)(r / 5)) * hv;
+    }
+    if (lane == 0) {
+        const int i = mi[m], j = mj[m];
+        kp0[2 * m + 0] = (float)(i % w0c) * scale_c;
+        kp0[2 * m + 1] = (float)(i / w0c) * scale_c;
+        kp1[2 * m + 0] = (float)(j % w1c) * scale_c + ex * 2.0f * scale_f;  // coords * (W // 2) * scale
+        kp1[2 * m + 1] = (float)(j / w1c) * scale_c + ey * 2.0f * scale_f;
+    }
+}

@@ -229,6 +229,151 @@ class LightGlueHIP:
         }  # fmt: skip
 
 
+# ------------------------------------------------------------------ LoFTR
+def _fold_bn(w: torch.Tensor, sd: dict, bn: str | None, eps: float = 1e-5):
+    """conv (no bias) followed by eval-mode BatchNorm -> (w', b')."""
+    cout = w.shape[0]
+    if bn is None:
+        return w, torch.zeros(cout)
+    g = sd[bn + ".weight"].float() / torch.sqrt(sd[bn + ".running_var"].float() + eps)
+    return w * g.view(-1, 1, 1, 1), sd[bn + ".bias"].float() - sd[bn + ".running_mean"].float() * g
+
+
+def _conv_gemm_layout(w: torch.Tensor, b: torch.Tensor, n_pad: int, cin_pad: int):
+    """OIHW -> [Cout_pad][tap][Cin_pad] (K order of the implicit im2col), zero padded."""
+    cout, cin, kh, kw = w.shape
+    out = torch.zeros(n_pad, kh * kw, cin_pad)
+    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    bo = torch.zeros(n_pad)
+    bo[:cout] = b
+    return out.reshape(n_pad, kh * kw * cin_pad).contiguous(), bo
+
+
+def pack_loftr(state_dict: dict) -> torch.Tensor:
+    """kornia LoFTR state dict -> packed float32 buffer (host): BN folding, GEMM layouts, 196 -> 256 padding."""
+    lib = load_library()
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
+    bb = "backbone."
+    w1, b1 = _fold_bn(sd[bb + "conv1.weight"], sd, bb + "bn1")
+    conv1_w = w1[:, 0].reshape(128, 49).t().contiguous().numpy()  # [tap][cout]
+    conv1_b = b1.contiguous().numpy()
+    P = lambda c: 256 if c == 196 else c  # noqa: E731
+    convs = [  # (weight key, bn key or None) in the order of the C layer table
+        ("layer1.0.conv1", "layer1.0.bn1"), ("layer1.0.conv2", "layer1.0.bn2"), ("layer1.1.conv1", "layer1.1.bn1"), ("layer1.1.conv2", "layer1.1.bn2"),
+        ("layer2.0.conv1", "layer2.0.bn1"), ("layer2.0.conv2", "layer2.0.bn2"), ("layer2.0.downsample.0", "layer2.0.downsample.1"),
+        ("layer2.1.conv1", "layer2.1.bn1"), ("layer2.1.conv2", "layer2.1.bn2"),
+        ("layer3.0.conv1", "layer3.0.bn1"), ("layer3.0.conv2", "layer3.0.bn2"), ("layer3.0.downsample.0", "layer3.0.downsample.1"),
+        ("layer3.1.conv1", "layer3.1.bn1"), ("layer3.1.conv2", "layer3.1.bn2"),
+        ("layer3_outconv", None), ("layer2_outconv", None), ("layer2_outconv2.0", "layer2_outconv2.1"), ("layer2_outconv2.3", None),
+        ("layer1_outconv", None), ("layer1_outconv2.0", "layer1_outconv2.1"), ("layer1_outconv2.3", None),
+    ]  # fmt: skip
+    ws, bs = [], []
+    for wk, bk in convs:
+        w, b = _fold_bn(sd[bb + wk + ".weight"], sd, bb + bk if bk else None)
+        wg, bg = _conv_gemm_layout(w, b, P(w.shape[0]), P(w.shape[1]))
+        ws.append(wg)
+        bs.append(bg)
+    lin_names = ["q_proj", "k_proj", "v_proj", "merge", "mlp.0", "mlp.2"]
+    for i in range(8):
+        for n in lin_names:
+            ws.append(sd[f"loftr_coarse.layers.{i}.{n}.weight"].contiguous())
+            bs.append(None)
+    for n in ("down_proj", "merge_feat"):
+        ws.append(sd[f"fine_preprocess.{n}.weight"].contiguous())
+        bs.append(sd[f"fine_preprocess.{n}.bias"].contiguous())
+    for i in range(2):
+        for n in lin_names:
+            ws.append(sd[f"loftr_fine.layers.{i}.{n}.weight"].contiguous())
+            bs.append(None)
+    norms = []
+    for pre, nl in (("loftr_coarse", 8), ("loftr_fine", 2)):
+        for i in range(nl):
+            for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"):
+                norms.append(sd[f"{pre}.layers.{i}.{n}"].contiguous())
+    nl = lib.imcui_hip_loftr_num_layers()
+    assert len(ws) == nl and len(norms) == lib.imcui_hip_loftr_num_norms(), (len(ws), nl)
+    N, K = C.c_int(), C.c_int()
+    w_np, b_np = [], []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        lib.imcui_hip_loftr_layer_shape(i, C.byref(N), C.byref(K))
+        if tuple(w.shape) != (N.value, K.value):
+            raise ImcuiHipError(f"LoFTR layer {i}: expected {(N.value, K.value)}, got {tuple(w.shape)}")
+        w_np.append(_as_f32_host(w))
+        b_np.append(None if b is None else _as_f32_host(b))
+    n_np = [_as_f32_host(n) for n in norms]
+    packed = np.zeros(lib.imcui_hip_loftr_packed_floats(), dtype=np.float32)
+    wp = (C.c_void_p * nl)(*[a.ctypes.data for a in w_np])
+    bp = (C.c_void_p * nl)(*[(0 if a is None else a.ctypes.data) for a in b_np])
+    npp = (C.c_void_p * len(n_np))(*[a.ctypes.data for a in n_np])
+    c1w, c1b = np.ascontiguousarray(conv1_w, dtype=np.float32), np.ascontiguousarray(conv1_b, dtype=np.float32)
+    rc = lib.imcui_hip_loftr_pack_weights(c1w.ctypes.data, c1b.ctypes.data, wp, bp, npp, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_loftr_pack_weights failed ({rc})")
+    return torch.from_numpy(packed)
+
+
+class LoFTRHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+        self.last_ws = None
+
+    def forward(self, packed, image0, image1, match_threshold, temp_bug_fix=False):
+        """kornia LoFTR.forward on [B,1,H,W] pairs; fixed-capacity outputs + device match count."""
+        dev = image0.device
+        hd = get_handle(dev)
+        lib = hd.lib
+        if image0.shape != image1.shape:
+            raise ImcuiHipError("the HIP LoFTR path needs image0 and image1 of the same size (the reference config force-resizes both)")
+        image0, image1 = image0.contiguous().float(), image1.contiguous().float()
+        B, Cc, H, W = image0.shape
+        if Cc != 1:
+            raise ImcuiHipError("LoFTR expects 1-channel images")
+        cap = B * (H // 8) * (W // 8)
+        kp0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        kp1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        conf = torch.empty((cap,), dtype=torch.float32, device=dev)
+        bidx = torch.empty((cap,), dtype=torch.int32, device=dev)
+        nm = torch.zeros((1,), dtype=torch.int32, device=dev)
+        with self._lock:
+            ws = self._ws.get(lib.imcui_hip_loftr_workspace_bytes(B, H, W), dev)
+            self.last_ws = ws
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_loftr_forward(
+                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H, W, float(match_threshold), int(bool(temp_bug_fix)),
+                    _ptr(kp0), _ptr(kp1), _ptr(conf), _ptr(bidx), _ptr(nm), _ptr(ws), ws.numel(), _stream_ptr(),
+                )  # fmt: skip
+                hd.check(rc, "imcui_hip_loftr_forward")
+        return {"keypoints0": kp0, "keypoints1": kp1, "confidence": conf, "batch_indexes": bidx, "num_matches": nm}
+
+    def debug_buffer(self, which: int, B: int, H: int, W: int, shape) -> torch.Tensor:
+        lib = load_library()
+        off = lib.imcui_hip_loftr_debug_offset(which, B, H, W)
+        n = int(np.prod(shape))
+        return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
+
+
+def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):
+    """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 64 == 0)."""
+    hd = get_handle(x_nhwc.device)
+    B, H, W, Cin = x_nhwc.shape
+    Cout, _, ks, _ = w_oihw.shape
+    wg, bg = _conv_gemm_layout(w_oihw.float().cpu(), bias.float().cpu(), Cout, Cin)
+    pad = ks // 2
+    ho, wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    out = torch.empty((B, ho, wo, Cout), dtype=torch.float32, device=x_nhwc.device)
+    wd, bd = wg.to(x_nhwc.device), bg.to(x_nhwc.device)
+    x_nhwc = x_nhwc.contiguous().float()
+    if resid is not None:
+        resid = resid.contiguous().float()
+    with torch.cuda.device(x_nhwc.device):
+        hd.check(
+            hd.lib.imcui_hip_conv_gemm_f32(hd.h, _ptr(x_nhwc), _ptr(wd), _ptr(bd), _ptr(resid), _ptr(out), B, H, W, Cin, Cout, ks, stride, act, _stream_ptr()),
+            "conv_gemm",
+        )
+    return out
+
+
 # ------------------------------------------------------------------ mutual NN
 _nn_ws = _Workspace()
 _nn_lock = threading.Lock()

@@ -1,0 +1,55 @@
+"""LoFTR dense matcher plugin on the MI355X HIP backend.
+
+Drop-in for imcui/hloc/matchers/loftr.py: module name `loftr`, same `default_conf` (:13-18) and
+`required_inputs` (:19); `_forward` keeps the wrapper's semantics -- image0 <-> image1 are swapped
+before the net ("we refine kpts in image0", :42-51), the top-k matches by confidence are kept with
+`argsort(descending)[:k]` (:58-65), key names are swapped back and `confidence` is renamed `scores`
+(:67-70).  The model itself (kornia.feature.LoFTR.forward, :54) runs in libimcui_hip
+(imcui_hip_loftr_forward).  Weights: kornia's `outdoor` checkpoint state dict (or the MINIMA variant,
+which sets temp_bug_fix, :27-36), given as conf["state_dict"] / conf["weights_path"].
+"""
+from __future__ import annotations
+
+import torch
+
+from ... import backend
+from ..utils.base_model import BaseModel
+from ..utils.weights import resolve_state_dict
+
+
+class LoFTR(BaseModel):
+    default_conf = {
+        "weights": "outdoor",
+        "match_threshold": 0.2,
+        "sinkhorn_iterations": 20,
+        "max_keypoints": -1,
+    }
+    required_inputs = ["image0", "image1"]
+
+    def _init(self, conf):
+        model_name = conf.get("model_name", None)
+        self.temp_bug_fix = model_name is not None and "minima" in model_name
+        if conf.get("state_dict") is None and not conf.get("weights_path"):
+            conf = {**conf, "model_name": model_name or f"loftr_{conf['weights']}.ckpt"}
+        sd = resolve_state_dict(conf, "loftr")
+        if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+            sd = sd["state_dict"]
+        self.conf.pop("state_dict", None)
+        self.register_buffer("packed", backend.pack_loftr(sd), persistent=False)
+        self._impl = backend.LoFTRHIP()
+
+    def forward_batched(self, image0: torch.Tensor, image1: torch.Tensor) -> dict:
+        """kornia LoFTR.forward(image0, image1) on a batch: fixed-capacity outputs, no host sync."""
+        return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], self.temp_bug_fix)
+
+    def _forward(self, data):
+        # For consistency with hloc pairs the reference refines key-points in image0: swap the images
+        out = self.forward_batched(data["image1"], data["image0"])
+        n = int(out["num_matches"][0])  # ragged outputs are the reference contract (one D2H)
+        kp0, kp1, scores = out["keypoints0"][:n], out["keypoints1"][:n], out["confidence"][:n]
+        top_k = self.conf["max_keypoints"]
+        if top_k is not None and len(scores) > top_k:
+            keep = torch.argsort(scores, descending=True)[:top_k]
+            kp0, kp1, scores = kp0[keep], kp1[keep], scores[keep]
+        # switch the indices back
+        return {"keypoints0": kp1, "keypoints1": kp0, "scores": scores, "batch_indexes": out["batch_indexes"][:n] if top_k is None else None}

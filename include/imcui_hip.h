@@ -8,6 +8,7 @@
  *   imcui_hip_superpoint_forward  <- imcui/hloc/extractors/superpoint.py:56-57  `self.net(data, self.conf)`
  *   imcui_hip_lightglue_forward   <- imcui/hloc/matchers/lightglue.py:54-75     `self.net(input)`
  *   imcui_hip_mutual_nn           <- imcui/hloc/matchers/nearest_neighbor.py:38-66 `_forward`
+ *   imcui_hip_loftr_forward       <- imcui/hloc/matchers/loftr.py:54            `self.net(data_)`
  *   *_pack_weights                <- the `_init` weight loading (superpoint.py:48-53, lightglue.py:39-51)
  *
  * Conventions
@@ -124,6 +125,34 @@ int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int 
                                 int* matches1, float* matching_scores0, float* matching_scores1, int* stop, int* prune0,
                                 int* prune1, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- LoFTR (kornia.feature.LoFTR behind imcui/hloc/matchers/loftr.py:54) ---- */
+/* Host-side packing.  Every convolution / Linear is one layer W[N][K] (+ bias[N], may be NULL) in GEMM
+ * layout: imcui_hip_loftr_num_layers() layers of imcui_hip_loftr_layer_shape(i); convolutions as
+ * [Cout][tap][Cin] with BatchNorm folded and the 196-channel stage zero-padded to 256 channels (the
+ * Python host layer imcui_hip/backend.py:pack_loftr builds them from the kornia state dict).
+ * conv1_w [49][128] / conv1_b [128]: the first 7x7 convolution (BN folded).  norms: LayerNorm weight /
+ * bias vectors, imcui_hip_loftr_num_norms() of imcui_hip_loftr_norm_dim(i) floats. */
+size_t imcui_hip_loftr_packed_floats(void);
+int imcui_hip_loftr_num_layers(void);
+int imcui_hip_loftr_layer_shape(int i, int* N, int* K);
+int imcui_hip_loftr_num_norms(void);
+int imcui_hip_loftr_norm_dim(int i);
+int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* conv1_b, const float* const* w, const float* const* b,
+                                 const float* const* norms, float* packed);
+size_t imcui_hip_loftr_workspace_bytes(int B, int H, int W);
+/* kornia LoFTR.forward on B pairs: image0 / image1 [dev, B,1,H,W] (same size, multiples of 8).
+ * Outputs with capacity B*(H/8)*(W/8) rows, first num_matches[0] valid, ordered like torch.where
+ * (batch-major, coarse cell of image0 ascending): keypoints0/1 [dev, cap,2] pixel (x,y),
+ * confidence [dev, cap], batch_indexes [dev, cap] int32, num_matches [dev, 1] int32.
+ * match_threshold = conf["match_threshold"] (loftr.py:23); temp_bug_fix = 1 only for MINIMA weights (:28). */
+int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H,
+                            int W, double match_threshold, int temp_bug_fix, float* keypoints0, float* keypoints1,
+                            float* confidence, int* batch_indexes, int* num_matches, void* ws, size_t ws_bytes, void* stream);
+
+/* byte offset inside the LoFTR workspace of: 0 coarse features after the transformer [2B,L,256],
+ * 1 fine features [2B,H/2,W/2,128], 2 sim [B,L,L], 3 fine windows [2,B*L,25,128]  (parity tests) */
+size_t imcui_hip_loftr_debug_offset(int which, int B, int H, int W);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /
@@ -146,6 +175,11 @@ float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsig
 int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
                                 const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,
                                 int Cout, int relu, int pool, void* stream);
+/* NHWC convolution as an implicit-im2col GEMM: weights [Cout][k*k*Cin] (tap-major), Cin % 64 == 0,
+ * optional residual [B,Hout,Wout,Cout] added before the activation (0 none, 1 ReLU, 2 LeakyReLU 0.01) */
+int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in_nhwc, const float* w_gemm, const float* bias, const float* resid,
+                            float* out_nhwc, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int act,
+                            void* stream);
 /* softmax(Q K^T) V, head_dim 64, operands head-major [S][heads][rows][64] (Q pre-scaled),
  * output token-major [S*rows][heads*64]; cnt [dev, S] valid rows; cross: keys of sequence s^1. */
 int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,

@@ -1,0 +1,95 @@
+"""LoFTR HIP path vs the CPU oracle on identical seeded inputs (GPU box only).
+
+Bar: coarse match index pairs bit-exact, confidences / fine key-points within 1e-4 (px: 1e-3).
+The pair is two crops of one synthetic image offset by (16, 8) px, so true coarse correspondences
+exist and the dual soft-max produces a few hundred confident mutual matches with random weights.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from imcui_hip.synth import make_pair
+from oracle.loftr import LoFTROracle
+from oracle.weights import loftr_state_dict
+
+pytestmark = pytest.mark.gpu
+SD = loftr_state_dict(0)
+
+
+def crops(seed, h, w):
+    base, _, _ = make_pair(seed, h + 16, w + 16, n_blobs=max(300, h * w // 130))
+    return base[..., 0:h, 0:w].contiguous(), base[..., 8 : h + 8, 16 : w + 16].contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,act,use_res", [(128, 128, 3, 1, 1, True), (128, 256, 3, 2, 1, False), (128, 256, 1, 2, 0, False), (256, 256, 1, 1, 0, True), (256, 128, 3, 1, 2, False)])
+def test_conv_gemm_vs_torch(cin, cout, ks, stride, act, use_res, precision):
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(cin + cout + ks)
+    B, H, W = 2, 24, 40
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = F.relu(ref) if act == 1 else F.leaky_relu(ref, 0.01) if act == 2 else ref
+    ref = ref.float().permute(0, 2, 3, 1).contiguous()
+    out = backend.conv_gemm_f32(
+        x.permute(0, 2, 3, 1).contiguous().cuda(), w, b, None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda(), stride, act
+    ).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() / ref.abs().max().item() < 4e-6
+
+
+@pytest.mark.parametrize("h,w,B", [(240, 320, 1), (96, 160, 2)])
+def test_loftr_vs_oracle(h, w, B, precision):
+    from imcui_hip.hloc.matchers.loftr import LoFTR
+
+    torch.set_num_threads(8)
+    pairs = [crops(3 + b, h, w) for b in range(B)]
+    img0 = torch.cat([p[0] for p in pairs], 0)
+    img1 = torch.cat([p[1] for p in pairs], 0)
+    thr = 0.01
+    model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": SD}).eval().to("cuda:0")
+    out = model.forward_batched(img0.cuda(), img1.cuda())
+    torch.cuda.synchronize()
+    n = int(out["num_matches"][0])
+    hc, wc = h // 8, w // 8
+    L = hc * wc
+    ora = LoFTROracle(SD, {"match_threshold": thr, "max_keypoints": None})
+    ref = ora.net(img0, img1, return_intermediates=True)
+    # intermediates: coarse features after the transformer, fine features, similarity
+    fc = model._impl.debug_buffer(0, B, h, w, (2 * B, L, 256)).cpu()
+    ff = model._impl.debug_buffer(1, B, h, w, (2 * B, h // 2, w // 2, 128)).cpu()
+    fc_ref = torch.cat([ref["_feat_c0"], ref["_feat_c1"]], 0)
+    assert (ff[:B] - ref["_feat_f0"].permute(0, 2, 3, 1)).abs().max().item() < 2e-4 * ref["_feat_f0"].abs().max().item(), "fine backbone features"
+    assert (fc - fc_ref).abs().max().item() < 2e-4 * fc_ref.abs().max().item(), "coarse features after the transformer"
+    # coarse matches: same (b, i, j) triplets in the same order
+    mi = (out["keypoints0"][:n, 1] / 8 * wc + out["keypoints0"][:n, 0] / 8).round().long().cpu()
+    assert n == len(ref["confidence"]) and n > 20, (n, len(ref["confidence"]))
+    assert torch.equal(out["batch_indexes"][:n].cpu().long(), ref["batch_indexes"])
+    assert torch.equal(mi, ref["_i_ids"])
+    assert torch.equal(out["keypoints0"][:n].cpu(), ref["keypoints0"].float())
+    assert (out["confidence"][:n].cpu() - ref["confidence"]).abs().max().item() < 1e-4
+    # fine refinement: sub-pixel key-points of image1
+    assert (out["keypoints1"][:n].cpu() - ref["keypoints1"]).abs().max().item() < 2e-3
+
+
+def test_loftr_plugin_contract():
+    """Reference wrapper semantics: image swap, top-k by confidence, key rename (loftr.py:41-71)."""
+    from imcui_hip.hloc.matchers.loftr import LoFTR
+
+    img0, img1 = crops(9, 240, 320)
+    model = LoFTR({"match_threshold": 0.01, "max_keypoints": 50, "state_dict": SD}).eval().to("cuda:0")
+    with torch.no_grad():
+        pred = model({"image0": img0.cuda(), "image1": img1.cuda()})
+    ref = LoFTROracle(SD, {"match_threshold": 0.01, "max_keypoints": 50})({"image0": img0, "image1": img1})
+    assert set(("keypoints0", "keypoints1", "scores")) <= set(pred)
+    assert pred["keypoints0"].shape == (50, 2) and pred["scores"].shape == (50,)
+    assert (pred["scores"].cpu() - ref["scores"]).abs().max().item() < 1e-4
+    assert (pred["keypoints0"].cpu() - ref["keypoints0"]).abs().max().item() < 2e-3
+    assert (pred["keypoints1"].cpu() - ref["keypoints1"]).abs().max().item() < 2e-3
+    # image0 was refined (the reference swaps): its key-points are sub-pixel, image1's sit on the 8-px grid
+    assert (pred["keypoints1"].cpu() % 8 == 0).all()
