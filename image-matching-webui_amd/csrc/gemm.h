@@ -45,7 +45,7 @@ struct GemmP {
     long w_stride = 0, b_stride = 0;
     // batched mode (blockIdx.z = batch): per-batch strides and dynamic M/N
     int batch = 1;
-    long a_bs = 0, w_bs = 0, c_bs = 0;
+    long a_bs = 0, a2_bs = 0, w_bs = 0, c_bs = 0;
     const int* mcnt = nullptr;  // M for batch z = mcnt[z * cnt_stride]
     const int* ncnt = nullptr;  // N for batch z = ncnt[z * cnt_stride]
     int cnt_stride = 1;

@@ -194,7 +194,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, 
 
 // Source of `n` consecutive K elements starting at k for GEMM row `ar` (nullptr = zeros):
 // plain / concatenated matrix, or implicit im2col of an NHWC convolution.
-__device__ __forceinline__ const float* gemm_a_src(const GemmP& p, const float* A, int ar, int k) {
+__device__ __forceinline__ const float* gemm_a_src(const GemmP& p, const float* A, const float* A2, int ar, int k) {
     if (p.conv_k > 0) {
         const int tap = k / p.conv_cin, c0 = k - tap * p.conv_cin;
         const int ky = tap / p.conv_k, kx = tap - ky * p.conv_k;
@@ -205,7 +205,7 @@ __device__ __forceinline__ const float* gemm_a_src(const GemmP& p, const float* 
         if (iy < 0 || iy >= p.conv_hin || ix < 0 || ix >= p.conv_win) return nullptr;
         return A + (((size_t)b * p.conv_hin + iy) * p.conv_win + ix) * p.conv_cin + c0;
     }
-    if (p.A2 != nullptr && k >= p.K1) return p.A2 + (size_t)ar * p.lda2 + (k - p.K1);
+    if (A2 != nullptr && k >= p.K1) return A2 + (size_t)ar * p.lda2 + (k - p.K1);
     return A + (size_t)ar * p.lda + k;
 }
 
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     if (!gemm_tile_setup(p, c)) return;
     const float* W = p.W + (size_t)c.z * p.w_bs + (size_t)c.wsel * p.w_stride;
     const float* A = p.A + (size_t)c.z * p.a_bs;
+    const float* A2 = p.A2 ? p.A2 + (size_t)c.z * p.a2_bs : nullptr;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int r = s_r + 32 * it;                                                 \
         const int ar = min(c.row0 + r, c.M - 1);                                     \
         const int br = min(c.col0 + r, c.N - 1);                                     \
-        const float* src = gemm_a_src(p, A, ar, k);                                  \
+        const float* src = gemm_a_src(p, A, A2, ar, k);                                  \
         ra##it = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f); \
         rb##it = *reinterpret_cast<const float4*>(W + (size_t)br * p.ldw + k);       \
     }
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
     TileCtx c;
     if (!gemm_tile_setup(p, c)) return;
     const float* A = p.A + (size_t)c.z * p.a_bs;
+    const float* A2 = p.A2 ? p.A2 + (size_t)c.z * p.a2_bs : nullptr;
     const float* W = PRESPLIT ? nullptr : p.W + (size_t)c.z * p.w_bs + (size_t)c.wsel * p.w_stride;
     const unsigned short* Wh = PRESPLIT ? p.Wh + (size_t)c.wsel * p.w_stride : nullptr;
     const unsigned short* Wl = PRESPLIT ? p.Wl + (size_t)c.wsel * p.w_stride : nullptr;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
 #define LDA64(S, it)                                                                 \
     {                                                                                \
         const int ar = min(c.row0 + s_r + 32 * it, c.M - 1);                         \
-        const float* src = gemm_a_src(p, A, ar, k);                                  \
+        const float* src = gemm_a_src(p, A, A2, ar, k);                                  \
         ra##S##it##a = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);     \
         ra##S##it##b = src ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
     }

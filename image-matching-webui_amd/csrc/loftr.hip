@@ -443,6 +443,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         if (A2) {
             g.A2 = A2 + (size_t)side0 * side_rows_cap * lda;
             g.lda2 = lda;
+            g.a2_bs = side_rows_cap * lda;
             g.K1 = (int)lda;
         }
         g.C = C + (size_t)side0 * side_rows_cap * g.N;
