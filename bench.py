@@ -79,6 +79,61 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
             "sample": f"{n} synthetic 640x480 pairs, batch 1, fp32, SuperPoint(2048 kpts)+LightGlue(9 layers, no early exit), torch {torch.__version__} CPU"}  # fmt: skip
 
 
+def bench_loftr(args, dev, rank, world):
+    """configs[3]: LoFTR dense matcher (coarse 1/8 + fine) on synthetic pairs; pairs/s, weak scaling."""
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.loftr import LoFTR
+    from imcui_hip.synth import make_pair
+    from oracle.weights import loftr_state_dict  # seeded weights only
+
+    Hh, Ww = args.size if args.size else (1024, 1024)
+    B = args.batch if args.batch != 16 else 1
+    model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
+    base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
+    img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
+    img1 = base[..., 8 : Hh + 8, 16 : Ww + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
+    for _ in range(args.warmup):
+        out = model.forward_batched(img0, img1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    backend.profile_enable(dev, True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.forward_batched(img0, img1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
+    backend.profile_enable(dev, False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        # algorithmic work (SURVEY.md section 8d): 2.55 TF / pair at 1024^2, scaled by area (coarse sim by area^2)
+        area = Hh * Ww / (1024.0 * 1024.0)
+        tf_pair = (2.03 + 0.35 + 0.03) * area + 0.14 * area * area
+        split = args.precision == 1
+        line = {
+            "metric": "image-pairs/sec LoFTR dense matcher", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
+            "config": {"workload": f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM",
+                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), "weights": "seeded random (oracle/weights.py), kornia LoFTR architecture"},
+            "roofline": {"kernel": "gemm_split_kernel (convolutions as implicit-im2col GEMM)" if split else "gemm_kernel", "bound": "mfma",
+                         "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
+                         "unit": "TFLOP/s", "frac": (tf_pair * B * args.steps / (gemm_ms * 1e-3) / (PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF)) if gemm_ms else 0.0,
+                         "traffic": None, "gemm_ms_per_step": gemm_ms / args.steps, "launches_per_step": gemm_n / args.steps,
+                         "note": "achieved = algorithmic TFLOP of a pair / summed GEMM-class kernel time (HIP events)"},
+            "algorithmic_tflops_end_to_end": tf_pair * B / (dt / args.steps),
+        }  # fmt: skip
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +142,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr"],
+                    help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher")
+    ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
@@ -108,6 +166,8 @@ def main():
     from oracle.weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
 
     backend.set_precision(dev, args.precision)
+    if args.workload == "loftr":
+        return bench_loftr(args, dev, rank, world)
     B = args.batch
     dc, wc = (0.95, 0.99) if args.adaptive else (-1.0, -1.0)
     pipe = SuperPointLightGluePipeline(
