@@ -123,7 +123,7 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
 // ------------------------------------------------------------------ workspace
 struct LfWs {
     float *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *fc, *up3, *x2o, *y2, *x2out, *up2, *x1o, *y1, *ff;
-    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest;
+    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1;
     float *X, *CG, *CW, *F, *fq, *fk, *fv, *fatt, *fm, *fh, *fo, *mconf;
     int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2;
     size_t total;
@@ -174,6 +174,8 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H, int W) {
     w.csum = a.get<float>(cap);
     w.best = a.get<float>(cap);
     w.cbest = a.get<float>(cap);
+    w.pc0 = a.get<float>(cap * LF_RCH);
+    w.pc1 = a.get<float>(cap * LF_RCH);
     w.X = a.get<float>(2 * cap * 25 * 256);
     w.CG = a.get<float>(2 * cap * 256);
     w.CW = a.get<float>(2 * cap * 128);
@@ -366,7 +368,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         if ((r = lin(base + 2, w.fc + so, 256, nullptr, w.v + so, rows, 0, nullptr))) return r;
         hipLaunchKernelGGL(lf_la_kv_partial_kernel<32>, dim3(nchunk, 8, ns), dim3(256), 0, stream, w.k + so, w.v + so, L, 8,
                            w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk);
-        hipLaunchKernelGGL(lf_la_kv_reduce_kernel<32>, dim3(ns * 8), dim3(256), 0, stream,
+        hipLaunchKernelGGL(lf_la_kv_reduce_kernel<32>, dim3(ns * 8, cdiv(1056, 256)), dim3(256), 0, stream,
                            w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk, w.kv + (size_t)ss0 * 8 * 1056);
         const size_t smem = (8 * 1056 + 4 * 256) * sizeof(float);
         hipLaunchKernelGGL(lf_la_apply_kernel<32>, dim3(cdiv(L, 64), ns), dim3(256), smem, stream, w.q, w.kv, qs0, ss0, L, L, 8,
@@ -413,12 +415,15 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.alpha = 0.00390625f / 0.1f;
         LFRUN(gemm_launch(h, g, stream));
     }
-    const dim3 rg(cdiv(L, 4), B), cg(cdiv(L, 64), B), blk(256);
+    const dim3 rg(cdiv(L, 4), B), blk(256);
     hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum);
-    hipLaunchKernelGGL(lf_colstat_kernel, cg, blk, 0, stream, w.sim, L, L, w.cmax, w.csum);
+    const dim3 cgz(cdiv(L, 64), B, LF_RCH), cg1(cdiv(L, 256), B);
+    hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, L, w.pc0, w.pc1);
+    hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, L, w.cmax, w.csum);
     // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
     hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
-    hipLaunchKernelGGL(lf_colbest_kernel, cg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.cbest);
+    hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
+    hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, L, w.cbest);
     hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, L, wc, hc, wc, hc, 2,
                        (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi,

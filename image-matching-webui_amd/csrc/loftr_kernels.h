@@ -184,11 +184,11 @@ template <int HD>
 __global__ void lf_la_kv_reduce_kernel(const float* __restrict__ part, int nchunk, float* __restrict__ kv) {
     const int gh = blockIdx.x;  // seq * heads + h
     constexpr int N = HD * HD + HD;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        float s = 0.0f;
-        for (int c = 0; c < nchunk; ++c) s += part[((size_t)gh * nchunk + c) * N + i];
-        kv[(size_t)gh * N + i] = s;
-    }
+    const int i = blockIdx.y * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float s = 0.0f;
+    for (int c = 0; c < nchunk; ++c) s += part[((size_t)gh * nchunk + c) * N + i];  // fixed order: deterministic
+    kv[(size_t)gh * N + i] = s;
 }
 
 // message[l, h, v] = (sum_d Q'[l,h,d] KV[h][d][v]) * Z[l,h] * L,  Z = 1 / (Q'[l,h,:] . Ksum[h] + 1e-6)
@@ -252,28 +252,48 @@ __global__ __launch_bounds__(256) void lf_rowstat_kernel(const float* __restrict
         rsum[(size_t)b * L + i] = s;
     }
 }
+// column pass, split over LF_RCH row chunks (blockIdx.z): partial (max, sum) per chunk, combined in a
+// fixed order by lf_colstat_combine_kernel
+#define LF_RCH 32
 __global__ __launch_bounds__(256) void lf_colstat_kernel(const float* __restrict__ sim, int L, int S,
-                                                         float* __restrict__ cmax, float* __restrict__ csum) {
+                                                         float* __restrict__ pmax, float* __restrict__ psum) {
     __shared__ float sm[4][64], ss[4][64];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, ch = blockIdx.z;
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + c;
+    const int rows = (L + LF_RCH - 1) / LF_RCH;
+    const int i0 = ch * rows, i1 = min(L, i0 + rows);
     const float* base = sim + (size_t)b * L * S;
     float m = -INFINITY;
     if (j < S)
-        for (int i = g; i < L; i += 4) m = fmaxf(m, base[(size_t)i * S + j]);
+        for (int i = i0 + g; i < i1; i += 4) m = fmaxf(m, base[(size_t)i * S + j]);
     sm[g][c] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
     float s = 0.0f;
-    if (j < S)
-        for (int i = g; i < L; i += 4) s += expf(base[(size_t)i * S + j] - m);
+    if (j < S && m > -INFINITY)
+        for (int i = i0 + g; i < i1; i += 4) s += expf(base[(size_t)i * S + j] - m);
     ss[g][c] = s;
     __syncthreads();
     if (g == 0 && j < S) {
-        cmax[(size_t)b * S + j] = m;
-        csum[(size_t)b * S + j] = ss[0][c] + ss[1][c] + ss[2][c] + ss[3][c];
+        pmax[((size_t)b * LF_RCH + ch) * S + j] = m;
+        psum[((size_t)b * LF_RCH + ch) * S + j] = ss[0][c] + ss[1][c] + ss[2][c] + ss[3][c];
     }
+}
+__global__ void lf_colstat_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int S,
+                                          float* __restrict__ cmax, float* __restrict__ csum) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    float m = -INFINITY;
+    for (int ch = 0; ch < LF_RCH; ++ch) m = fmaxf(m, pmax[((size_t)b * LF_RCH + ch) * S + j]);
+    float s = 0.0f;
+    for (int ch = 0; ch < LF_RCH; ++ch) {
+        const float pm = pmax[((size_t)b * LF_RCH + ch) * S + j];
+        if (pm > -INFINITY) s += psum[((size_t)b * LF_RCH + ch) * S + j] * expf(pm - m);
+    }
+    cmax[(size_t)b * S + j] = m;
+    csum[(size_t)b * S + j] = s;
 }
 // conf = softmax(sim, dim=1)[i,j] * softmax(sim, dim=2)[i,j]   (dim 1 = over i / L, dim 2 = over j / S)
 __device__ __forceinline__ float lf_conf(float s, float cm, float cs, float rm, float rs) {
@@ -313,25 +333,35 @@ __global__ __launch_bounds__(256) void lf_rowbest_kernel(const float* __restrict
         bestj[(size_t)b * L + i] = bj;
     }
 }
-// per column: max_i conf
+// per column: max_i conf, split over LF_RCH row chunks (partials), then lf_colmax_combine_kernel
 __global__ __launch_bounds__(256) void lf_colbest_kernel(const float* __restrict__ sim, int L, int S,
                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                          const float* __restrict__ cmax, const float* __restrict__ csum,
-                                                         float* __restrict__ cbest) {
+                                                         float* __restrict__ pbest) {
     __shared__ float sv[4][64];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, ch = blockIdx.z;
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + c;
+    const int rows = (L + LF_RCH - 1) / LF_RCH;
+    const int i0 = ch * rows, i1 = min(L, i0 + rows);
     const float* base = sim + (size_t)b * L * S;
     float bv = -1.0f;
     if (j < S) {
         const float cm = cmax[(size_t)b * S + j], cs = csum[(size_t)b * S + j];
-        for (int i = g; i < L; i += 4)
+        for (int i = i0 + g; i < i1; i += 4)
             bv = fmaxf(bv, lf_conf(base[(size_t)i * S + j], cm, cs, rmax[(size_t)b * L + i], rsum[(size_t)b * L + i]));
     }
     sv[g][c] = bv;
     __syncthreads();
-    if (g == 0 && j < S) cbest[(size_t)b * S + j] = fmaxf(fmaxf(sv[0][c], sv[1][c]), fmaxf(sv[2][c], sv[3][c]));
+    if (g == 0 && j < S) pbest[((size_t)b * LF_RCH + ch) * S + j] = fmaxf(fmaxf(sv[0][c], sv[1][c]), fmaxf(sv[2][c], sv[3][c]));
+}
+__global__ void lf_colmax_combine_kernel(const float* __restrict__ pbest, int S, float* __restrict__ cbest) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    float m = -1.0f;
+    for (int ch = 0; ch < LF_RCH; ++ch) m = fmaxf(m, pbest[((size_t)b * LF_RCH + ch) * S + j]);
+    cbest[(size_t)b * S + j] = m;
 }
 // per row decision: conf > thr, border, mutual; flag[b*L+i] = 1/0
 __global__ void lf_decide_kernel(const float* __restrict__ best, const int* __restrict__ bestj,
