@@ -55,9 +55,128 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c) {
 // register quad (r & 3), which makes every store a 16-byte store (a 64-dword-store epilogue is
 // store-issue bound and was 10x the matrix time), puts RoPE pairs in one lane, and lets V^T be
 // written with lanes running along the token axis.
+//
+// split_out projections (Q / K / V^T as f16 hi + lo planes for attn_split_kernel) go through LDS
+// (`stage`, >= 73728 B, the GEMM's operand buffers): written straight from the fragments they are
+// 8-byte (Q/K) or 2-byte (V^T) scattered stores and the kernel was store-bound at 15 % of the matrix
+// rate; staged, the 128x128 tile leaves as 16-byte stores of fully contiguous 16 KiB (Q/K) or
+// 256-byte (V^T) runs.
+#define STAGE_QK_ROW 144    // bytes per staged [token][64 halves] row (128 + 16 pad)
+#define STAGE_QK_PLANE (2 * 128 * STAGE_QK_ROW)
+#define STAGE_VT_ROW 272    // bytes per staged [feature][128 token halves] row (256 + 16 pad)
+#define STAGE_VT_PLANE (128 * STAGE_VT_ROW)
+#define STAGE_BYTES 73728
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
-                                              int wn, int lo, int hi) {
+                                              int wn, int lo, int hi, uint4* stage = nullptr) {
+    if ((EPI == EPI_QKV || EPI == EPI_CROSS) && stage != nullptr && p.split_out) {
+        // the 128 columns of a tile are two heads of ONE of q / k / v (256 features each)
+        const int t = c.col0 >> 8, hd0 = (c.col0 >> 6) & 3;
+        float* dst;
+        bool vt, rope, scale;
+        if (EPI == EPI_QKV) {
+            dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
+            vt = (t == 2);
+            rope = (t < 2);
+            scale = (t == 0);
+        } else {
+            dst = (t == 0) ? p.Q : p.V;
+            vt = (t == 1);
+            rope = false;
+            scale = (t == 0);
+        }
+        char* sb = reinterpret_cast<char*>(stage);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int tl = wm * 64 + m * 32 + lo;  // token within the tile
+            const int row = c.row0 + tl;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int fl = wn * 64 + n * 32 + 8 * q + 4 * hi;  // first of 4 features within the tile
+                    const int f0 = c.col0 + fl;
+                    float v[4] = {acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                                  acc[m][n][4 * q + 3] * wsc};
+                    if (c.bias != nullptr) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+                        v[0] += b4.x;
+                        v[1] += b4.y;
+                        v[2] += b4.z;
+                        v[3] += b4.w;
+                    }
+                    if (rope) {
+                        const int d0 = fl & 63;
+                        const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
+                        const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                        const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                        v[0] = a0 * cs.x + (-a1) * sn.x;
+                        v[1] = a1 * cs.x + a0 * sn.x;
+                        v[2] = a2 * cs.y + (-a3) * sn.y;
+                        v[3] = a3 * cs.y + a2 * sn.y;
+                    }
+                    if (scale) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                    }
+                    unsigned h01, l01, h23, l23;
+                    split2(v[0], v[1], h01, l01);
+                    split2(v[2], v[3], h23, l23);
+                    if (!vt) {
+                        char* o = sb + ((fl >> 6) * 128 + tl) * STAGE_QK_ROW + (fl & 63) * 2;
+                        *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(o + STAGE_QK_PLANE) = make_uint2(l01, l23);
+                    } else {
+                        // pair lanes (tokens 2u, 2u+1): the even lane ends up with features f, f+1 of both
+                        // tokens, the odd lane with f+2, f+3 -> 4-byte [feature][token pair] words
+                        const bool odd = (lo & 1) != 0;
+                        const unsigned rh = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h01 : h23), 0xB1, 0xF, 0xF, true);
+                        const unsigned rl = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? l01 : l23), 0xB1, 0xF, 0xF, true);
+                        unsigned wh0, wh1, wl0, wl1;
+                        if (!odd) {
+                            wh0 = (h01 & 0xFFFFu) | (rh << 16);
+                            wh1 = (h01 >> 16) | (rh & 0xFFFF0000u);
+                            wl0 = (l01 & 0xFFFFu) | (rl << 16);
+                            wl1 = (l01 >> 16) | (rl & 0xFFFF0000u);
+                        } else {
+                            wh0 = (rh & 0xFFFFu) | (h23 << 16);
+                            wh1 = (rh >> 16) | (h23 & 0xFFFF0000u);
+                            wl0 = (rl & 0xFFFFu) | (l23 << 16);
+                            wl1 = (rl >> 16) | (l23 & 0xFFFF0000u);
+                        }
+                        char* o = sb + (fl + (odd ? 2 : 0)) * STAGE_VT_ROW + (tl >> 1) * 4;
+                        *reinterpret_cast<unsigned*>(o) = wh0;
+                        *reinterpret_cast<unsigned*>(o + STAGE_VT_ROW) = wh1;
+                        *reinterpret_cast<unsigned*>(o + STAGE_VT_PLANE) = wl0;
+                        *reinterpret_cast<unsigned*>(o + STAGE_VT_PLANE + STAGE_VT_ROW) = wl1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        const int i0 = c.row0 - c.seq * p.rows_per_seq;
+        const int tid = threadIdx.x;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int g = it * 256 + tid;  // 16-byte granule: 2 planes x 2048
+            const int plane = g >> 11, rem = g & 2047;
+            if (!vt) {
+                const int hh = rem >> 10, tok = (rem >> 3) & 127, gr = rem & 7;
+                const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STAGE_QK_PLANE + (hh * 128 + tok) * STAGE_QK_ROW + gr * 16);
+                unsigned short* o = d16 + (size_t)plane * p.plane_halves +
+                                    (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + tok) * 64 + gr * 8;
+                *reinterpret_cast<uint4*>(o) = val;
+            } else {
+                const int feat = rem >> 4, gr = rem & 15;
+                const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STAGE_VT_PLANE + feat * STAGE_VT_ROW + gr * 16);
+                unsigned short* o = d16 + (size_t)plane * p.plane_halves +
+                                    (((size_t)c.seq * p.heads + hd0 + (feat >> 6)) * 64 + (feat & 63)) * p.rows_per_seq + i0 + gr * 8;
+                *reinterpret_cast<uint4*>(o) = val;
+            }
+        }
+        return;
+    }
     float* C = p.C ? p.C + (size_t)c.z * p.c_bs : nullptr;
     const bool vec_ok = ((p.ldc & 3) == 0);
 #pragma unroll
@@ -294,7 +413,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // f32 activation matrix split on the fly like A (similarity products).
 template <int EPI, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
-    __shared__ uint4 smem[4 * (BK64 / 8) * LDS_ROWS];  // A_hi | A_lo | B_hi | B_lo, 16512 B each
+    // A_hi | A_lo | B_hi | B_lo, 16512 B each; the split_out epilogues restage the tile in it (73728 B)
+    constexpr int SMEM_U4 = (EPI == EPI_QKV || EPI == EPI_CROSS) ? STAGE_BYTES / 16 : 4 * (BK64 / 8) * LDS_ROWS;
+    __shared__ uint4 smem[SMEM_U4];
     uint4* Ah = smem;
     uint4* Al = smem + (BK64 / 8) * LDS_ROWS;
     uint4* Bh = smem + 2 * (BK64 / 8) * LDS_ROWS;
@@ -425,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
             __syncthreads();
         }
     }
-    gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi);
+    gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi, smem);
 }
 
 template <int EPI>
@@ -447,6 +568,8 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.conv_k > 0 && (p.conv_cin % BK64 != 0 || p.K != p.conv_k * p.conv_k * p.conv_cin))
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm(conv): cin=%d must be a multiple of %d and K=%d == k*k*cin", p.conv_cin, BK64, p.K);
     const bool split = h->precision == 1 && (p.K % BK64 == 0);
+    if (p.split_out && (!split || p.rows_per_seq <= 0 || p.N % BN != 0 || p.M % BM != 0 || p.batch != 1))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: split_out needs the split mode and whole 128x128 tiles (M=%d N=%d)", p.M, p.N);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");
     const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     dim3 grid(ntiles, 1, p.batch);
