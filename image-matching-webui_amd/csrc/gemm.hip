@@ -66,6 +66,8 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c) {
 #define STAGE_VT_ROW 272    // bytes per staged [feature][128 token halves] row (256 + 16 pad)
 #define STAGE_VT_PLANE (128 * STAGE_VT_ROW)
 #define STAGE_BYTES 73728
+#define STAGE_C_ROW 132     // floats per staged [token][128 features] row of the f32 outputs
+#define STAGE_C_BYTES (128 * STAGE_C_ROW * 4)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
                                               int wn, int lo, int hi, uint4* stage = nullptr) {
@@ -179,6 +181,89 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, 
     }
     float* C = p.C ? p.C + (size_t)c.z * p.c_bs : nullptr;
     const bool vec_ok = ((p.ldc & 3) == 0);
+    if ((EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_RESID || EPI == EPI_CONV) && stage != nullptr) {
+        // Row-major outputs: a fragment store touches 32 token rows x 32 B, which the memory system
+        // serves at a third of the rate of whole lines (the epilogue was a third of the kernel).
+        // Transpose the tile through LDS instead ([token][feature], 132-float rows: conflict-free
+        // both ways) and let every wave write whole 512-byte rows.
+        float* st = reinterpret_cast<float*>(stage);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tl = wm * 64 + m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
+                    *reinterpret_cast<float4*>(st + tl * STAGE_C_ROW + fl) =
+                        make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                                    acc[m][n][4 * q + 3] * wsc);
+                }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        const int f0 = c.col0 + 4 * (tid & 31);
+        if (f0 >= c.N) return;
+        const bool full = (f0 + 3 < c.N) && vec_ok;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c.bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < c.N) b[j] = c.bias[f0 + j];
+        }
+        const bool res_vec = (EPI == EPI_CONV) && p.resid != nullptr && ((p.ldr & 3) == 0);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int tl = (tid >> 5) + 8 * it;
+            const int row = c.row0 + tl;
+            if (row >= c.M) break;
+            const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STAGE_C_ROW + 4 * (tid & 31));
+            float v[4] = {t4.x + b[0], t4.y + b[1], t4.z + b[2], t4.w + b[3]};
+            float* dst = C + (size_t)row * p.ldc + f0;
+            if (EPI == EPI_CONV) {
+                if (p.resid != nullptr) {
+                    const float* rs = p.resid + (size_t)row * p.ldr + f0;
+                    if (full && res_vec) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(rs);
+                        v[0] += r4.x;
+                        v[1] += r4.y;
+                        v[2] += r4.z;
+                        v[3] += r4.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < c.N) v[j] += rs[j];
+                    }
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];
+                }
+            } else if (EPI == EPI_BIAS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+            } else if (EPI == EPI_RELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            }
+            if (full) {
+                if (EPI == EPI_RESID) {
+                    const float4 o4 = *reinterpret_cast<const float4*>(dst);
+                    v[0] += o4.x;
+                    v[1] += o4.y;
+                    v[2] += o4.z;
+                    v[3] += o4.w;
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (f0 + j < c.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int row = c.row0 + wm * 64 + m * 32 + lo;  // token
@@ -414,7 +499,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 template <int EPI, bool PRESPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
     // A_hi | A_lo | B_hi | B_lo, 16512 B each; the split_out epilogues restage the tile in it (73728 B)
-    constexpr int SMEM_U4 = (EPI == EPI_QKV || EPI == EPI_CROSS) ? STAGE_BYTES / 16 : 4 * (BK64 / 8) * LDS_ROWS;
+    constexpr int SMEM_U4 = (EPI == EPI_QKV || EPI == EPI_CROSS) ? STAGE_BYTES / 16 : STAGE_C_BYTES / 16;
+    static_assert(SMEM_U4 >= 4 * (BK64 / 8) * LDS_ROWS, "operand buffers must fit");
     __shared__ uint4 smem[SMEM_U4];
     uint4* Ah = smem;
     uint4* Al = smem + (BK64 / 8) * LDS_ROWS;
