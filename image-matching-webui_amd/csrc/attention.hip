@@ -16,7 +16,7 @@
 #define KT 64        // keys per tile
 #define KSTR 65      // padded key stride of the K image (float4 units)
 
-__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // one LDS object: K image [d-quad][key] (float4), then V [key][d]; the front of it is
     // reused as the per-wave output transpose buffer after the last tile
     __shared__ float4 smem4[16 * KSTR + KT * 16];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 // Operands arrive PRE-SPLIT from the projection epilogue (gemm.hip, split_out): each of Q, K,
 // V^T is two f16 planes (hi then lo) in the buffer that holds the f32 tensor in exact mode, so a
 // K/V element is split once instead of once per query block and staging is a pure copy.
-__global__ __launch_bounds__(256) void attn_split_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
     uint4* Kl = smem4 + 8 * KSTR;

@@ -85,9 +85,16 @@ __global__ __launch_bounds__(256, 2) void lab_kernel(GemmP p) {
 #define SINK4(v) sink ^= __builtin_bit_cast(unsigned, (v).x) ^ __builtin_bit_cast(unsigned, (v).y) ^ __builtin_bit_cast(unsigned, (v).z) ^ __builtin_bit_cast(unsigned, (v).w);
 #define CONSUME(S) { SINK4(ra##S##0a) SINK4(ra##S##0b) SINK4(ra##S##1a) SINK4(ra##S##1b) SINK4(ra##S##2a) SINK4(ra##S##2b) SINK4(ra##S##3a) SINK4(ra##S##3b) \
                      SINK4(rb0a) SINK4(rb0b) SINK4(rb1a) SINK4(rb1b) SINK4(rb2a) SINK4(rb2b) SINK4(rb3a) SINK4(rb3b) }
-    LOADA(X, 0)
-    LOADB(0)
-    if (nkt > 1) LOADA(Y, 1)
+    if (KO & 512) {
+        raX0a = raX0b = raX1a = raX1b = raX2a = raX2b = raX3a = raX3b = make_float4(1.f, 2.f, 3.f, 4.f);
+        raY0a = raY0b = raY1a = raY1b = raY2a = raY2b = raY3a = raY3b = make_float4(1.f, 2.f, 3.f, 4.f);
+        rb0a = rb0b = rb1a = rb1b = rb2a = rb2b = rb3a = rb3b = make_uint4(1, 2, 3, 4);
+    } else {
+        LOADA(X, 0)
+        LOADB(0)
+        if (nkt > 1) LOADA(Y, 1)
+    }
+    if (KO & 1024) return;
     if (KO & 4) {
         STORESET(X)
         __syncthreads();
@@ -210,6 +217,11 @@ int main(int argc, char** argv) {
         RUN(14, "mfma+ldsread only")
         RUN(15, "ldsread only")
         RUN(9, "no mfma, no epi")
+        RUN(15 | 512, "ldsread, no prologue ld")
+        RUN(15 | 512 | 64, "ldsread, no prol, nosync")
+        RUN(14 | 512, "mfma+ldsrd, no prol")
+        RUN(14 | 512 | 64, "mfma+ldsrd,noprol,nosync")
+        RUN(512 | 1024, "empty kernel")
         RUN(8 | 16 | 32 | 64, "loads only")
         RUN(8 | 16 | 32 | 64 | 128, "B loads only")
         RUN(8 | 16 | 32 | 64 | 256, "A loads only")
