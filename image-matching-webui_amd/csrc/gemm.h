@@ -24,8 +24,9 @@ struct GemmP {
     int K1 = 0;
     const float* W = nullptr;  // [N, K] f32
     long ldw = 0;
-    // pre-split weights for precision 1 (optional; when null W is split on the fly):
-    // Wh/Wl [N, K] f16 planes of W * 2^e, wscale -> 2^-e
+    // pre-split weights for precision 1 (optional; when null W is split on the fly): f16 planes of
+    // W * 2^e in FRAGMENT-MAJOR order [ceil(N/32)][K/16][64 lanes][8 halves] (split_weights_frag_host),
+    // wscale -> 2^-e
     const unsigned short* Wh = nullptr;
     const unsigned short* Wl = nullptr;
     const float* wscale = nullptr;
@@ -58,7 +59,7 @@ struct GemmP {
     size_t plane_halves = 0;
     // implicit im2col (enabled when conv_k > 0): A is an NHWC image [B, hin, win, cin], row m of the
     // GEMM is output pixel m of a conv_k x conv_k convolution (stride, zero padding), K = conv_k^2 * cin
-    // ordered (tap, channel) -- the layout of pack_conv_gemm(); cin % 64 == 0
+    // ordered (tap, channel) -- the layout of pack_conv_gemm(); cin % 32 == 0
     int conv_k = 0, conv_stride = 1, conv_pad = 0, conv_hin = 0, conv_win = 0, conv_hout = 0, conv_wout = 0, conv_cin = 0;
     const float* resid = nullptr;  // EPI_CONV: [M, N] added before the activation (may alias C)
     long ldr = 0;
@@ -74,3 +75,5 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);
 void pack_conv_gemm(const float* w_oihw, int Cout, int Cin, int ksize, int Cin_pad, float* dst);
 // host: split an [n] f32 array into f16 hi / lo planes of w * 2^e; returns 2^-e
 float split_weights_host(const float* w, size_t n, unsigned short* hi, unsigned short* lo);
+// host: the same for a GEMM weight [N][K], planes written fragment-major with rows padded to 32
+float split_weights_frag_host(const float* w, int N, int K, unsigned short* hi, unsigned short* lo);

@@ -1,14 +1,14 @@
 // MFMA GEMM for MI355X / gfx950 in two arithmetic modes.
 //
 // f32 mode: tile 128x128x32, v_mfma_f32_32x32x2_f32, operands staged global -> registers -> LDS
-// as [k-quad][row][4 floats].  Split mode: tile 128x128x64, every f32 operand value is split into
-// an f16 (hi, lo) pair while it is staged (3 VALU per element), LDS holds [k-octet][row][8 halves]
-// images of hi and lo, and each 32x32x16 step issues ah*bh + ah*bl + al*bh.  Weights of the
-// networks are pre-split (and pre-scaled by a power of two) at pack time.  In both modes the row
-// stride of the LDS image is padded to 129 granules of 16 B, which makes the staging writes and
-// the fragment reads bank-conflict free, and the next K tile is prefetched into registers while
-// the current one is multiplied.  4 waves (2x2), each wave a 64x64 output tile (64 accumulators).
+// as [k-quad][row][4 floats] (row stride padded to 129 granules: conflict-free).
+// Split mode (default): every f32 value is an f16 (hi, lo) pair and each 32x32x16 step issues
+// ah*bh + ah*bl + al*bh; see gemm_split_kernel below.  In both modes 4 waves (2x2) each own a 64x64
+// output tile (64 accumulators) and the products are issued with the weight fragment as the MFMA A
+// operand (C^T accumulation, see gemm_epilogue).
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gemm.h"
@@ -55,215 +55,11 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c) {
 // register quad (r & 3), which makes every store a 16-byte store (a 64-dword-store epilogue is
 // store-issue bound and was 10x the matrix time), puts RoPE pairs in one lane, and lets V^T be
 // written with lanes running along the token axis.
-//
-// split_out projections (Q / K / V^T as f16 hi + lo planes for attn_split_kernel) go through LDS
-// (`stage`, >= 73728 B, the GEMM's operand buffers): written straight from the fragments they are
-// 8-byte (Q/K) or 2-byte (V^T) scattered stores and the kernel was store-bound at 15 % of the matrix
-// rate; staged, the 128x128 tile leaves as 16-byte stores of fully contiguous 16 KiB (Q/K) or
-// 256-byte (V^T) runs.
-#define STAGE_QK_ROW 144    // bytes per staged [token][64 halves] row (128 + 16 pad)
-#define STAGE_QK_PLANE (2 * 128 * STAGE_QK_ROW)
-#define STAGE_VT_ROW 272    // bytes per staged [feature][128 token halves] row (256 + 16 pad)
-#define STAGE_VT_PLANE (128 * STAGE_VT_ROW)
-#define STAGE_BYTES 73728
-#define STAGE_C_ROW 132     // floats per staged [token][128 features] row of the f32 outputs
-#define STAGE_C_BYTES (128 * STAGE_C_ROW * 4)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
-                                              int wn, int lo, int hi, uint4* stage = nullptr) {
-    if ((EPI == EPI_QKV || EPI == EPI_CROSS) && stage != nullptr && p.split_out) {
-        // the 128 columns of a tile are two heads of ONE of q / k / v (256 features each)
-        const int t = c.col0 >> 8, hd0 = (c.col0 >> 6) & 3;
-        float* dst;
-        bool vt, rope, scale;
-        if (EPI == EPI_QKV) {
-            dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
-            vt = (t == 2);
-            rope = (t < 2);
-            scale = (t == 0);
-        } else {
-            dst = (t == 0) ? p.Q : p.V;
-            vt = (t == 1);
-            rope = false;
-            scale = (t == 0);
-        }
-        char* sb = reinterpret_cast<char*>(stage);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int tl = wm * 64 + m * 32 + lo;  // token within the tile
-            const int row = c.row0 + tl;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int fl = wn * 64 + n * 32 + 8 * q + 4 * hi;  // first of 4 features within the tile
-                    const int f0 = c.col0 + fl;
-                    float v[4] = {acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
-                                  acc[m][n][4 * q + 3] * wsc};
-                    if (c.bias != nullptr) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(c.bias + f0);
-                        v[0] += b4.x;
-                        v[1] += b4.y;
-                        v[2] += b4.z;
-                        v[3] += b4.w;
-                    }
-                    if (rope) {
-                        const int d0 = fl & 63;
-                        const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
-                        const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
-                        const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-                        v[0] = a0 * cs.x + (-a1) * sn.x;
-                        v[1] = a1 * cs.x + a0 * sn.x;
-                        v[2] = a2 * cs.y + (-a3) * sn.y;
-                        v[3] = a3 * cs.y + a2 * sn.y;
-                    }
-                    if (scale) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-                    }
-                    unsigned h01, l01, h23, l23;
-                    split2(v[0], v[1], h01, l01);
-                    split2(v[2], v[3], h23, l23);
-                    if (!vt) {
-                        char* o = sb + ((fl >> 6) * 128 + tl) * STAGE_QK_ROW + (fl & 63) * 2;
-                        *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
-                        *reinterpret_cast<uint2*>(o + STAGE_QK_PLANE) = make_uint2(l01, l23);
-                    } else {
-                        // pair lanes (tokens 2u, 2u+1): the even lane ends up with features f, f+1 of both
-                        // tokens, the odd lane with f+2, f+3 -> 4-byte [feature][token pair] words
-                        const bool odd = (lo & 1) != 0;
-                        const unsigned rh = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h01 : h23), 0xB1, 0xF, 0xF, true);
-                        const unsigned rl = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? l01 : l23), 0xB1, 0xF, 0xF, true);
-                        unsigned wh0, wh1, wl0, wl1;
-                        if (!odd) {
-                            wh0 = (h01 & 0xFFFFu) | (rh << 16);
-                            wh1 = (h01 >> 16) | (rh & 0xFFFF0000u);
-                            wl0 = (l01 & 0xFFFFu) | (rl << 16);
-                            wl1 = (l01 >> 16) | (rl & 0xFFFF0000u);
-                        } else {
-                            wh0 = (rh & 0xFFFFu) | (h23 << 16);
-                            wh1 = (rh >> 16) | (h23 & 0xFFFF0000u);
-                            wl0 = (rl & 0xFFFFu) | (l23 << 16);
-                            wl1 = (rl >> 16) | (l23 & 0xFFFF0000u);
-                        }
-                        char* o = sb + (fl + (odd ? 2 : 0)) * STAGE_VT_ROW + (tl >> 1) * 4;
-                        *reinterpret_cast<unsigned*>(o) = wh0;
-                        *reinterpret_cast<unsigned*>(o + STAGE_VT_ROW) = wh1;
-                        *reinterpret_cast<unsigned*>(o + STAGE_VT_PLANE) = wl0;
-                        *reinterpret_cast<unsigned*>(o + STAGE_VT_PLANE + STAGE_VT_ROW) = wl1;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
-        const int i0 = c.row0 - c.seq * p.rows_per_seq;
-        const int tid = threadIdx.x;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int g = it * 256 + tid;  // 16-byte granule: 2 planes x 2048
-            const int plane = g >> 11, rem = g & 2047;
-            if (!vt) {
-                const int hh = rem >> 10, tok = (rem >> 3) & 127, gr = rem & 7;
-                const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STAGE_QK_PLANE + (hh * 128 + tok) * STAGE_QK_ROW + gr * 16);
-                unsigned short* o = d16 + (size_t)plane * p.plane_halves +
-                                    (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + tok) * 64 + gr * 8;
-                *reinterpret_cast<uint4*>(o) = val;
-            } else {
-                const int feat = rem >> 4, gr = rem & 15;
-                const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STAGE_VT_PLANE + feat * STAGE_VT_ROW + gr * 16);
-                unsigned short* o = d16 + (size_t)plane * p.plane_halves +
-                                    (((size_t)c.seq * p.heads + hd0 + (feat >> 6)) * 64 + (feat & 63)) * p.rows_per_seq + i0 + gr * 8;
-                *reinterpret_cast<uint4*>(o) = val;
-            }
-        }
-        return;
-    }
+                                              int wn, int lo, int hi) {
     float* C = p.C ? p.C + (size_t)c.z * p.c_bs : nullptr;
     const bool vec_ok = ((p.ldc & 3) == 0);
-    if ((EPI == EPI_BIAS || EPI == EPI_RELU || EPI == EPI_RESID || EPI == EPI_CONV) && stage != nullptr) {
-        // Row-major outputs: a fragment store touches 32 token rows x 32 B, which the memory system
-        // serves at a third of the rate of whole lines (the epilogue was a third of the kernel).
-        // Transpose the tile through LDS instead ([token][feature], 132-float rows: conflict-free
-        // both ways) and let every wave write whole 512-byte rows.
-        float* st = reinterpret_cast<float*>(stage);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int tl = wm * 64 + m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
-                    *reinterpret_cast<float4*>(st + tl * STAGE_C_ROW + fl) =
-                        make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
-                                    acc[m][n][4 * q + 3] * wsc);
-                }
-        __syncthreads();
-        const int tid = threadIdx.x;
-        const int f0 = c.col0 + 4 * (tid & 31);
-        if (f0 >= c.N) return;
-        const bool full = (f0 + 3 < c.N) && vec_ok;
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (c.bias != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (f0 + j < c.N) b[j] = c.bias[f0 + j];
-        }
-        const bool res_vec = (EPI == EPI_CONV) && p.resid != nullptr && ((p.ldr & 3) == 0);
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int tl = (tid >> 5) + 8 * it;
-            const int row = c.row0 + tl;
-            if (row >= c.M) break;
-            const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STAGE_C_ROW + 4 * (tid & 31));
-            float v[4] = {t4.x + b[0], t4.y + b[1], t4.z + b[2], t4.w + b[3]};
-            float* dst = C + (size_t)row * p.ldc + f0;
-            if (EPI == EPI_CONV) {
-                if (p.resid != nullptr) {
-                    const float* rs = p.resid + (size_t)row * p.ldr + f0;
-                    if (full && res_vec) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(rs);
-                        v[0] += r4.x;
-                        v[1] += r4.y;
-                        v[2] += r4.z;
-                        v[3] += r4.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (f0 + j < c.N) v[j] += rs[j];
-                    }
-                }
-                if (p.act == 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-                } else if (p.act == 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];
-                }
-            } else if (EPI == EPI_BIAS) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-            } else if (EPI == EPI_RELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-            }
-            if (full) {
-                if (EPI == EPI_RESID) {
-                    const float4 o4 = *reinterpret_cast<const float4*>(dst);
-                    v[0] += o4.x;
-                    v[1] += o4.y;
-                    v[2] += o4.z;
-                    v[3] += o4.w;
-                }
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (f0 + j < c.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int row = c.row0 + wm * 64 + m * 32 + lo;  // token
@@ -492,21 +288,257 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     gemm_epilogue<EPI>(p, c, acc, 1.0f, wm, wn, lo, hi);
 }
 
-// ------------------------------------------------------------------ 3 x f16 split kernel
-#define BK64 64
-// PRESPLIT: B operand comes from pre-split f16 planes (network weights); otherwise it is an
-// f32 activation matrix split on the fly like A (similarity products).
-template <int EPI, bool PRESPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
-    // A_hi | A_lo | B_hi | B_lo, 16512 B each; the split_out epilogues restage the tile in it (73728 B)
-    constexpr int SMEM_U4 = (EPI == EPI_QKV || EPI == EPI_CROSS) ? STAGE_BYTES / 16 : STAGE_C_BYTES / 16;
-    static_assert(SMEM_U4 >= 4 * (BK64 / 8) * LDS_ROWS, "operand buffers must fit");
-    __shared__ uint4 smem[SMEM_U4];
-    uint4* Ah = smem;
-    uint4* Al = smem + (BK64 / 8) * LDS_ROWS;
-    uint4* Bh = smem + 2 * (BK64 / 8) * LDS_ROWS;
-    uint4* Bl = smem + 3 * (BK64 / 8) * LDS_ROWS;
+// ------------------------------------------------------------------ staged epilogues of the split kernel
+// Written straight from the C^T fragments, a store instruction touches 32 token rows x 32 B (row-major
+// outputs) or is an 8- / 2-byte scatter (Q / K / V^T planes); the memory system serves that at a
+// third of the rate of whole lines and the epilogue was a third of the kernel.  The tile therefore
+// leaves through LDS, one 64-token half at a time (<= 36.9 KB, so three workgroups fit a CU):
+// the waves that own the half park it, then all 256 threads write whole rows.
+#define STG_C_ROW 132   // floats per parked [token][128 features] row (conflict-free both ways)
+#define STG_H_ROW 144   // bytes per parked row of 64 halves (128 + 16 pad)
+#define STG_H_PLANE 18432
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
+                                                     int wn, int lo, int hi, char* sb) {
+    const int tid = threadIdx.x;
+    if (EPI == EPI_QKV || EPI == EPI_CROSS) {
+        if (!p.split_out) {
+            gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi);
+            return;
+        }
+        // the 128 columns of a tile are two heads of ONE of q / k / v (256 features each)
+        const int t = c.col0 >> 8, hd0 = (c.col0 >> 6) & 3;
+        float* dst;
+        bool vt, rope, scale;
+        if (EPI == EPI_QKV) {
+            dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
+            vt = (t == 2);
+            rope = (t < 2);
+            scale = (t == 0);
+        } else {
+            dst = (t == 0) ? p.Q : p.V;
+            vt = (t == 1);
+            rope = false;
+            scale = (t == 0);
+        }
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        const int i0 = c.row0 - c.seq * p.rows_per_seq;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (wm == h) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int tl = m * 32 + lo;  // token within the half
+                    const int row = c.row0 + h * 64 + tl;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int fl = wn * 64 + n * 32 + 8 * q + 4 * hi;  // first of 4 features within the tile
+                            const int f0 = c.col0 + fl;
+                            float v[4] = {acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                                          acc[m][n][4 * q + 3] * wsc};
+                            if (c.bias != nullptr) {
+                                const float4 b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+                                v[0] += b4.x;
+                                v[1] += b4.y;
+                                v[2] += b4.z;
+                                v[3] += b4.w;
+                            }
+                            if (rope) {
+                                // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
+                                const int d0 = fl & 63;
+                                const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
+                                const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                                const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+                                v[0] = a0 * cs.x + (-a1) * sn.x;
+                                v[1] = a1 * cs.x + a0 * sn.x;
+                                v[2] = a2 * cs.y + (-a3) * sn.y;
+                                v[3] = a3 * cs.y + a2 * sn.y;
+                            }
+                            if (scale) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                            }
+                            unsigned h01, l01, h23, l23;
+                            split2(v[0], v[1], h01, l01);
+                            split2(v[2], v[3], h23, l23);
+                            if (!vt) {
+                                char* o = sb + ((fl >> 6) * 64 + tl) * STG_H_ROW + (fl & 63) * 2;
+                                *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
+                                *reinterpret_cast<uint2*>(o + STG_H_PLANE) = make_uint2(l01, l23);
+                            } else {
+                                // pair lanes (tokens 2u, 2u+1): the even lane ends up with features f, f+1 of
+                                // both tokens, the odd lane with f+2, f+3 -> 4-byte [feature][token pair] words
+                                const bool odd = (lo & 1) != 0;
+                                const unsigned rh = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h01 : h23), 0xB1, 0xF, 0xF, true);
+                                const unsigned rl = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? l01 : l23), 0xB1, 0xF, 0xF, true);
+                                unsigned wh0, wh1, wl0, wl1;
+                                if (!odd) {
+                                    wh0 = (h01 & 0xFFFFu) | (rh << 16);
+                                    wh1 = (h01 >> 16) | (rh & 0xFFFF0000u);
+                                    wl0 = (l01 & 0xFFFFu) | (rl << 16);
+                                    wl1 = (l01 >> 16) | (rl & 0xFFFF0000u);
+                                } else {
+                                    wh0 = (rh & 0xFFFFu) | (h23 << 16);
+                                    wh1 = (rh >> 16) | (h23 & 0xFFFF0000u);
+                                    wl0 = (rl & 0xFFFFu) | (l23 << 16);
+                                    wl1 = (rl >> 16) | (l23 & 0xFFFF0000u);
+                                }
+                                char* o = sb + (fl + (odd ? 2 : 0)) * STG_H_ROW + (tl >> 1) * 4;
+                                *reinterpret_cast<unsigned*>(o) = wh0;
+                                *reinterpret_cast<unsigned*>(o + STG_H_ROW) = wh1;
+                                *reinterpret_cast<unsigned*>(o + STG_H_PLANE) = wl0;
+                                *reinterpret_cast<unsigned*>(o + STG_H_PLANE + STG_H_ROW) = wl1;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int g = it * 256 + tid;  // 16-byte granule: 2 planes x 1024
+                const int plane = g >> 10, rem = g & 1023;
+                if (!vt) {
+                    // per (plane, head): 64 tokens x 128 B = one contiguous 8 KiB run
+                    const int hh = rem >> 9, tok = (rem >> 3) & 63, gr = rem & 7;
+                    const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STG_H_PLANE + (hh * 64 + tok) * STG_H_ROW + gr * 16);
+                    unsigned short* o = d16 + (size_t)plane * p.plane_halves +
+                                        (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tok) * 64 + gr * 8;
+                    *reinterpret_cast<uint4*>(o) = val;
+                } else {
+                    // V^T [seq][head][64][rows]: one whole 128-byte line per (plane, feature)
+                    const int feat = rem >> 3, gr = rem & 7;
+                    const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STG_H_PLANE + feat * STG_H_ROW + gr * 16);
+                    unsigned short* o = d16 + (size_t)plane * p.plane_halves +
+                                        (((size_t)c.seq * p.heads + hd0 + (feat >> 6)) * 64 + (feat & 63)) * p.rows_per_seq + i0 + h * 64 +
+                                        gr * 8;
+                    *reinterpret_cast<uint4*>(o) = val;
+                }
+            }
+            if (h == 0) __syncthreads();
+        }
+        return;
+    }
+    // ---- row-major f32 outputs
+    float* C = p.C + (size_t)c.z * p.c_bs;
+    float* st = reinterpret_cast<float*>(sb);
+    const int f0 = c.col0 + 4 * (tid & 31);
+    const bool colok = f0 < c.N;
+    const bool full = (f0 + 3 < c.N) && ((p.ldc & 3) == 0);
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c.bias != nullptr && colok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (f0 + j < c.N) b[j] = c.bias[f0 + j];
+    }
+    const bool res_vec = (EPI == EPI_CONV) && p.resid != nullptr && ((p.ldr & 3) == 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int tl = m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
+                        *reinterpret_cast<float4*>(st + tl * STG_C_ROW + fl) =
+                            make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                                        acc[m][n][4 * q + 3] * wsc);
+                    }
+        }
+        __syncthreads();
+        if (colok) {
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int tl = (tid >> 5) + 8 * it;
+                const int row = c.row0 + h * 64 + tl;
+                if (row >= c.M) break;
+                const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + 4 * (tid & 31));
+                float v[4] = {t4.x + b[0], t4.y + b[1], t4.z + b[2], t4.w + b[3]};
+                float* dst = C + (size_t)row * p.ldc + f0;
+                if (EPI == EPI_CONV) {
+                    if (p.resid != nullptr) {
+                        const float* rs = p.resid + (size_t)row * p.ldr + f0;
+                        if (full && res_vec) {
+                            const float4 r4 = *reinterpret_cast<const float4*>(rs);
+                            v[0] += r4.x;
+                            v[1] += r4.y;
+                            v[2] += r4.z;
+                            v[3] += r4.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (f0 + j < c.N) v[j] += rs[j];
+                        }
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];
+                    }
+                } else if (EPI == EPI_BIAS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                } else if (EPI == EPI_RELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                }
+                if (full) {
+                    if (EPI == EPI_RESID) {
+                        const float4 o4 = *reinterpret_cast<const float4*>(dst);
+                        v[0] += o4.x;
+                        v[1] += o4.y;
+                        v[2] += o4.z;
+                        v[3] += o4.w;
+                    }
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (f0 + j < c.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
+                }
+            }
+        }
+        if (h == 0) __syncthreads();
+    }
+}
 
+// ------------------------------------------------------------------ 3 x f16 split kernel
+// Tile 128 x 128 x 32, 4 waves (2 x 2), three workgroups per CU (48 KB LDS, <= 168 VGPRs).
+//  * Weights (WDMA): packed at load time as FRAGMENT-MAJOR f16 hi / lo planes
+//    [N/32][K/16][64 lanes][8 halves], so one `global_load_lds_dwordx4` moves a ready-to-use 1 KiB MFMA
+//    fragment L2 -> LDS with no registers, no ds_write and no bank conflicts; double-buffered, the tile
+//    for step kt+1 streams in while step kt is multiplied.
+//  * Activations: fetched two tiles ahead into registers, split into (hi, lo) f16 and written to a
+//    single LDS buffer in the same fragment order with the granule position XOR-swizzled by 2*(k-octet)
+//    (both the ds_write_b128 of 8 lanes = 2 rows x 4 octets and the fragment ds_read_b128 are then
+//    conflict-free).
+//  * The LDS-DMA is issued from inline asm and retired with a hand-counted `s_waitcnt vmcnt(4)`: a
+//    DMA the compiler knows about makes it drain vmcnt to 0 at the next use of any loaded register,
+//    i.e. exposes the full memory latency once per K step.  (Hiding the register loads in asm as well
+//    is NOT safe: the allocator may copy a destination register before the load has landed.)
+#define BK3 32
+#define GLDS16(gptr, ldsaddr)                                                                                              \
+    {                                                                                                                     \
+        unsigned keep__;                                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep__)                                                                                      \
+                     : "v"(gptr), "s"(ldsaddr)                                                                            \
+                     : "memory");                                                                                         \
+    }
+// ASRC: 0 = matrix (optionally two K slabs), 1 = implicit im2col of an NHWC image
+// WDMA: weights by LDS-DMA from fragment-major planes; otherwise B is an f32 matrix [N][K] (activations,
+//       e.g. similarity products) staged like A
+template <int EPI, int ASRC, bool WDMA>
+__global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) {
+    // A_hi 8K | A_lo 8K | B stage 0 (hi 8K, lo 8K) | B stage 1 ; reused by the epilogue
+    __shared__ uint4 smem[49152 / 16];
+    char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
@@ -515,10 +547,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
     if (!gemm_tile_setup(p, c)) return;
     const float* A = p.A + (size_t)c.z * p.a_bs;
     const float* A2 = p.A2 ? p.A2 + (size_t)c.z * p.a2_bs : nullptr;
-    const float* W = PRESPLIT ? nullptr : p.W + (size_t)c.z * p.w_bs + (size_t)c.wsel * p.w_stride;
-    const unsigned short* Wh = PRESPLIT ? p.Wh + (size_t)c.wsel * p.w_stride : nullptr;
-    const unsigned short* Wl = PRESPLIT ? p.Wl + (size_t)c.wsel * p.w_stride : nullptr;
-    const float wsc = (PRESPLIT && p.wscale) ? p.wscale[c.wsel] : 1.0f;
+    const float wsc = (WDMA && p.wscale) ? p.wscale[c.wsel] : 1.0f;
+    const int nkt = p.K / BK3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -528,111 +558,203 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-    // staging: 128 rows x 8 k-octets per operand = 1024 items of 8 values, 4 per thread
-    const int s_ko = tid & 7;
-    const int s_r = tid >> 3;
-    // A: two float4 per item (split while staged); B: hi/lo planes (pre-split weights, pure copy)
-    // or two float4 (activations, split while staged) held as raw bits in the same registers.
-    // The A operand (activations streamed from HBM / MALL) has TWO register sets (X, Y): tile kt+2
-    // is requested before tile kt is multiplied, so its load has a whole stage + multiply phase
-    // (> 3k cycles) to land.  The B operand (weights, L2-resident) is fetched one tile ahead.
-    float4 raX0a, raX0b, raX1a, raX1b, raX2a, raX2b, raX3a, raX3b, raY0a, raY0b, raY1a, raY1b, raY2a, raY2b, raY3a, raY3b;
-    uint4 rb0a, rb0b, rb1a, rb1b, rb2a, rb2b, rb3a, rb3b;
-    const int nkt = p.K / BK64;
-#define LDA64(S, it)                                                                 \
-    {                                                                                \
-        const int ar = min(c.row0 + s_r + 32 * it, c.M - 1);                         \
-        const float* src = gemm_a_src(p, A, A2, ar, k);                                  \
-        ra##S##it##a = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);     \
-        ra##S##it##b = src ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.f, 0.f, 0.f, 0.f); \
-    }
-#define LDB64(it)                                                                    \
-    {                                                                                \
-        const int br = min(c.col0 + s_r + 32 * it, c.N - 1);                         \
-        if (PRESPLIT) {                                                              \
-            rb##it##a = *reinterpret_cast<const uint4*>(Wh + (size_t)br * p.ldw + k); \
-            rb##it##b = *reinterpret_cast<const uint4*>(Wl + (size_t)br * p.ldw + k); \
-        } else {                                                                     \
-            const float* ws = W + (size_t)br * p.ldw + k;                            \
-            rb##it##a = *reinterpret_cast<const uint4*>(ws);                         \
-            rb##it##b = *reinterpret_cast<const uint4*>(ws + 4);                     \
-        }                                                                            \
-    }
-#define ST64(S, it)                                                                  \
-    {                                                                                \
-        const int o = s_ko * LDS_ROWS + s_r + 32 * it;                               \
-        uint4 h, l;                                                                  \
-        split8(ra##S##it##a, ra##S##it##b, h, l);                                    \
-        Ah[o] = h;                                                                   \
-        Al[o] = l;                                                                   \
-        if (PRESPLIT) {                                                              \
-            Bh[o] = rb##it##a;                                                       \
-            Bl[o] = rb##it##b;                                                       \
-        } else {                                                                     \
-            split8(__builtin_bit_cast(float4, rb##it##a), __builtin_bit_cast(float4, rb##it##b), h, l); \
-            Bh[o] = h;                                                               \
-            Bl[o] = l;                                                               \
-        }                                                                            \
-    }
-#define LOADA(S, kt_)                                    \
-    {                                                    \
-        const int k = (kt_) * BK64 + s_ko * 8;           \
-        LDA64(S, 0) LDA64(S, 1) LDA64(S, 2) LDA64(S, 3)  \
-    }
-#define LOADB(kt_)                               \
-    {                                            \
-        const int k = (kt_) * BK64 + s_ko * 8;   \
-        LDB64(0) LDB64(1) LDB64(2) LDB64(3)      \
-    }
-#define STORESET(S) ST64(S, 0) ST64(S, 1) ST64(S, 2) ST64(S, 3)
-
-    auto compute = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int s = 0; s < BK64 / 16; ++s) {
-        const int ko = 2 * s + hi;
-        uint4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ah[m] = Ah[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
-            al[m] = Al[ko * LDS_ROWS + wm * 64 + m * 32 + lo];
+    // ---- staging geometry: thread -> k-octet g = tid & 3 (8 consecutive k) of rows tid >> 2 and + 64
+    const int g = tid & 3;
+    const int rl0 = tid >> 2, rl1 = 64 + (tid >> 2);
+    // LDS byte offset of the granule: fragment (ks = g >> 1, rf = row >> 5), half g & 1, position (row & 31) ^ 2g
+    const int wo0 = (((g >> 1) * 4 + (rl0 >> 5)) * 64 + (g & 1) * 32 + ((rl0 & 31) ^ (2 * g))) * 16;
+    const int wo1 = (((g >> 1) * 4 + (rl1 >> 5)) * 64 + (g & 1) * 32 + ((rl1 & 31) ^ (2 * g))) * 16;
+    const int ar0 = min(c.row0 + rl0, c.M - 1), ar1 = min(c.row0 + rl1, c.M - 1);
+    const float *pa0, *pa1, *pb0 = nullptr, *pb1 = nullptr;
+    int iy0 = 0, ix0 = 0, iy1 = 0, ix1 = 0;  // conv: top-left input pixel of the two rows
+    if (ASRC == 1) {
+        const int ox0 = ar0 % p.conv_wout, t0 = ar0 / p.conv_wout, ox1 = ar1 % p.conv_wout, t1 = ar1 / p.conv_wout;
+        const int oy0 = t0 % p.conv_hout, b0 = t0 / p.conv_hout, oy1 = t1 % p.conv_hout, b1 = t1 / p.conv_hout;
+        iy0 = oy0 * p.conv_stride - p.conv_pad;
+        ix0 = ox0 * p.conv_stride - p.conv_pad;
+        iy1 = oy1 * p.conv_stride - p.conv_pad;
+        ix1 = ox1 * p.conv_stride - p.conv_pad;
+        pa0 = A + (((long)b0 * p.conv_hin + iy0) * p.conv_win + ix0) * p.conv_cin + g * 8;
+        pa1 = A + (((long)b1 * p.conv_hin + iy1) * p.conv_win + ix1) * p.conv_cin + g * 8;
+    } else {
+        pa0 = A + (size_t)ar0 * p.lda + g * 8;
+        pa1 = A + (size_t)ar1 * p.lda + g * 8;
+        if (A2 != nullptr) {
+            pb0 = A2 + (size_t)ar0 * p.lda2 + g * 8 - p.K1;
+            pb1 = A2 + (size_t)ar1 * p.lda2 + g * 8 - p.K1;
         }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            bh[n] = Bh[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
-            bl[n] = Bl[ko * LDS_ROWS + wn * 64 + n * 32 + lo];
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
-                acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
-                acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
-                acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
+    }
+    f32x4 xa0, xb0, xa1, xb1, ya0, yb0, ya1, yb1;
+    bool xv0 = true, xv1 = true, yv0 = true, yv1 = true;  // conv: row inside the image for this tap
+    int cv_c0 = 0, cv_ky = 0, cv_kx = 0;                    // conv: running (tap, channel) of the next tile
+    // tiles are requested strictly in order kt = 0, 1, 2, ...
+    auto issue_a = [&](int kt, f32x4& a0, f32x4& b0, f32x4& a1, f32x4& b1, bool& v0, bool& v1) __attribute__((always_inline)) {
+        const float *q0, *q1;
+        if (ASRC == 1) {
+            const int off = (cv_ky * p.conv_win + cv_kx) * p.conv_cin + cv_c0;
+            v0 = (unsigned)(iy0 + cv_ky) < (unsigned)p.conv_hin && (unsigned)(ix0 + cv_kx) < (unsigned)p.conv_win;
+            v1 = (unsigned)(iy1 + cv_ky) < (unsigned)p.conv_hin && (unsigned)(ix1 + cv_kx) < (unsigned)p.conv_win;
+            q0 = v0 ? pa0 + off : A;
+            q1 = v1 ? pa1 + off : A;
+            cv_c0 += BK3;
+            if (cv_c0 == p.conv_cin) {
+                cv_c0 = 0;
+                if (++cv_kx == p.conv_k) {
+                    cv_kx = 0;
+                    ++cv_ky;
+                }
             }
-    }
+        } else {
+            const int k = kt * BK3;
+            if (A2 != nullptr && k >= p.K1) {
+                q0 = pb0 + k;
+                q1 = pb1 + k;
+            } else {
+                q0 = pa0 + k;
+                q1 = pa1 + k;
+            }
+        }
+        a0 = *reinterpret_cast<const f32x4*>(q0);
+        b0 = *reinterpret_cast<const f32x4*>(q0 + 4);
+        a1 = *reinterpret_cast<const f32x4*>(q1);
+        b1 = *reinterpret_cast<const f32x4*>(q1 + 4);
+    };
+    auto store_a = [&](f32x4& a0, f32x4& b0, f32x4& a1, f32x4& b1, bool v0, bool v1) __attribute__((always_inline)) {
+        uint4 h, l;
+        float4 fa = __builtin_bit_cast(float4, a0), fb = __builtin_bit_cast(float4, b0);
+        if (ASRC == 1 && !v0) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        split8(fa, fb, h, l);
+        *reinterpret_cast<uint4*>(sm + wo0) = h;
+        *reinterpret_cast<uint4*>(sm + 8192 + wo0) = l;
+        fa = __builtin_bit_cast(float4, a1);
+        fb = __builtin_bit_cast(float4, b1);
+        if (ASRC == 1 && !v1) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        split8(fa, fb, h, l);
+        *reinterpret_cast<uint4*>(sm + wo1) = h;
+        *reinterpret_cast<uint4*>(sm + 8192 + wo1) = l;
     };
 
-    LOADA(X, 0)
-    LOADB(0)
-    if (nkt > 1) LOADA(Y, 1)
+    // ---- B operand
+    // WDMA: wave w moves the fragments of column block nf = w (all planes / k-steps) of every tile
+    const int nks = p.K >> 4;
+    const int nfr = (p.N + 31) >> 5;
+    const uint4 *wh = nullptr, *wl = nullptr;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
+    if (WDMA) {
+        const int nfg = min((c.col0 >> 5) + wid, nfr - 1);
+        wh = reinterpret_cast<const uint4*>(p.Wh + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
+        wl = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
+    }
+    auto dma_b = [&](int kt, int stg) __attribute__((always_inline)) {
+        const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + 16384 + stg * 16384 + wid * 1024);
+        GLDS16(wh + (size_t)(kt * 2 + 0) * 64, d);
+        GLDS16(wh + (size_t)(kt * 2 + 1) * 64, d + 4096);
+        GLDS16(wl + (size_t)(kt * 2 + 0) * 64, d + 8192);
+        GLDS16(wl + (size_t)(kt * 2 + 1) * 64, d + 8192 + 4096);
+    };
+    // !WDMA: B rows staged like A (single buffer = stage 0)
+    f32x4 xc0, xd0, xc1, xd1, yc0, yd0, yc1, yd1;
+    const float *pw0 = nullptr, *pw1 = nullptr;
+    if (!WDMA) {
+        const float* W = p.W + (size_t)c.z * p.w_bs + (size_t)c.wsel * p.w_stride;
+        pw0 = W + (size_t)min(c.col0 + rl0, c.N - 1) * p.ldw + g * 8;
+        pw1 = W + (size_t)min(c.col0 + rl1, c.N - 1) * p.ldw + g * 8;
+    }
+    auto issue_b = [&](int kt, f32x4& a0, f32x4& b0, f32x4& a1, f32x4& b1) __attribute__((always_inline)) {
+        const float *q0 = pw0 + kt * BK3, *q1 = pw1 + kt * BK3;
+        a0 = *reinterpret_cast<const f32x4*>(q0);
+        b0 = *reinterpret_cast<const f32x4*>(q0 + 4);
+        a1 = *reinterpret_cast<const f32x4*>(q1);
+        b1 = *reinterpret_cast<const f32x4*>(q1 + 4);
+    };
+    auto store_b = [&](f32x4& a0, f32x4& b0, f32x4& a1, f32x4& b1) __attribute__((always_inline)) {
+        uint4 h, l;
+        split8(__builtin_bit_cast(float4, a0), __builtin_bit_cast(float4, b0), h, l);
+        *reinterpret_cast<uint4*>(sm + 16384 + wo0) = h;
+        *reinterpret_cast<uint4*>(sm + 24576 + wo0) = l;
+        split8(__builtin_bit_cast(float4, a1), __builtin_bit_cast(float4, b1), h, l);
+        *reinterpret_cast<uint4*>(sm + 16384 + wo1) = h;
+        *reinterpret_cast<uint4*>(sm + 24576 + wo1) = l;
+    };
+
+    auto compute = [&](int stg) __attribute__((always_inline)) {
+        const char* sbt = sm + 16384 + (WDMA ? stg * 16384 : 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 ah[2], al[2], bh[2], bl[2];
+            const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int fo = (ks * 4 + wm * 2 + m) * 1024 + apos;
+                ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
+                al[m] = *reinterpret_cast<const uint4*>(sm + 8192 + fo);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int fo = (ks * 4 + wn * 2 + n) * 1024 + (WDMA ? lane * 16 : apos);
+                bh[n] = *reinterpret_cast<const uint4*>(sbt + fo);
+                bl[n] = *reinterpret_cast<const uint4*>(sbt + 8192 + fo);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
+                    acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                    acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                    acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
+                }
+        }
+    };
+    // The register loads are ordinary loads (the compiler counts its own vmcnt for them); only the
+    // LDS-DMA is invisible to it and is retired by hand before the barrier that publishes the tile.
+    // No order is assumed between DMA and register loads: the wait is for everything.
+#define DMA_LANDED(pend) \
+    if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // prologue: tile 0 -> LDS, tile 1 in flight
+    issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
+    if (WDMA) dma_b(0, 0); else issue_b(0, xc0, xd0, xc1, xd1);
+    if (nkt > 1) {
+        issue_a(1, ya0, yb0, ya1, yb1, yv0, yv1);
+        if (!WDMA) issue_b(1, yc0, yd0, yc1, yd1);
+    }
+    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+    if (!WDMA) store_b(xc0, xd0, xc1, xd1);
+    DMA_LANDED(nkt > 1)
+    __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
-        STORESET(X)
-        __syncthreads();
-        if (kt + 1 < nkt) LOADB(kt + 1)
-        if (kt + 2 < nkt) LOADA(X, kt + 2)
-        compute();
+        // tile kt is in LDS (weights in stage 0); y holds tile kt+1 (in flight)
+        if (kt + 2 < nkt) {
+            issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
+            if (!WDMA) issue_b(kt + 2, xc0, xd0, xc1, xd1);
+        }
+        if (WDMA && kt + 1 < nkt) dma_b(kt + 1, 1);
+        compute(0);
         __syncthreads();
         if (kt + 1 < nkt) {
-            STORESET(Y)
+            store_a(ya0, yb0, ya1, yb1, yv0, yv1);
+            if (!WDMA) store_b(yc0, yd0, yc1, yd1);
+            DMA_LANDED(kt + 2 < nkt)
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            if (kt + 3 < nkt) {
+                issue_a(kt + 3, ya0, yb0, ya1, yb1, yv0, yv1);
+                if (!WDMA) issue_b(kt + 3, yc0, yd0, yc1, yd1);
+            }
+            if (WDMA && kt + 2 < nkt) dma_b(kt + 2, 0);
+            compute(1);
             __syncthreads();
-            if (kt + 2 < nkt) LOADB(kt + 2)
-            if (kt + 3 < nkt) LOADA(Y, kt + 3)
-            compute();
+            if (kt + 2 < nkt) {
+                store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+                if (!WDMA) store_b(xc0, xd0, xc1, xd1);
+                DMA_LANDED(kt + 3 < nkt)
+            }
             __syncthreads();
         }
     }
-    gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi, smem);
+    gemm_epilogue_staged<EPI>(p, c, acc, wsc, wm, wn, lo, hi, sm);
 }
 
 template <int EPI>
@@ -640,25 +762,41 @@ static void launch_one(const GemmP& p, bool split, dim3 grid, hipStream_t stream
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI>, grid, dim3(256), 0, stream, p);
     else if (p.Wh != nullptr)
-        hipLaunchKernelGGL((gemm_split_kernel<EPI, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true>), grid, dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<EPI, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, false>), grid, dim3(256), 0, stream, p);
+}
+static void launch_conv(const GemmP& p, bool split, dim3 grid, hipStream_t stream) {
+    if (!split)
+        hipLaunchKernelGGL(gemm_kernel<EPI_CONV>, grid, dim3(256), 0, stream, p);
+    else if (p.Wh != nullptr)
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, false>), grid, dim3(256), 0, stream, p);
 }
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.K % BK32 != 0 || p.K <= 0) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: K=%d must be a positive multiple of %d", p.K, BK32);
-    if (p.A2 && (p.K1 % BK64 != 0)) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: K1=%d must be a multiple of %d", p.K1, BK64);
+    if (p.A2 && (p.K1 % BK32 != 0)) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: K1=%d must be a multiple of %d", p.K1, BK32);
     if (p.rows_per_seq > 0 && p.rows_per_seq % BM != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: rows_per_seq=%d must be a multiple of %d", p.rows_per_seq, BM);
     if (p.M <= 0 || p.N <= 0) return IMCUI_OK;
-    if (p.conv_k > 0 && (p.conv_cin % BK64 != 0 || p.K != p.conv_k * p.conv_k * p.conv_cin))
-        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm(conv): cin=%d must be a multiple of %d and K=%d == k*k*cin", p.conv_cin, BK64, p.K);
-    const bool split = h->precision == 1 && (p.K % BK64 == 0);
+    if (p.conv_k > 0 && (p.conv_cin % BK32 != 0 || p.K != p.conv_k * p.conv_k * p.conv_cin || p.epi != EPI_CONV || p.A2))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm(conv): cin=%d must be a multiple of %d, K=%d == k*k*cin, epilogue EPI_CONV", p.conv_cin,
+                             BK32, p.K);
+    const bool split = h->precision == 1;
     if (p.split_out && (!split || p.rows_per_seq <= 0 || p.N % BN != 0 || p.M % BM != 0 || p.batch != 1))
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: split_out needs the split mode and whole 128x128 tiles (M=%d N=%d)", p.M, p.N);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");
     const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
     dim3 grid(ntiles, 1, p.batch);
+    static const bool dbg = getenv("IMCUI_HIP_GEMM_DEBUG") != nullptr;
+    if (dbg) {
+        hipStreamSynchronize(stream);
+        fprintf(stderr, "[gemm] epi=%d M=%d N=%d K=%d K1=%d batch=%d split=%d wdma=%d conv=%d rows_per_seq=%d split_out=%d\n", p.epi, p.M, p.N,
+                p.K, p.K1, p.batch, (int)split, p.Wh != nullptr, p.conv_k, p.rows_per_seq, p.split_out);
+        fflush(stderr);
+    }
     imcui_prof_begin(h, PROF_GEMM, stream);
     switch (p.epi) {
         case EPI_BIAS: launch_one<EPI_BIAS>(p, split, grid, stream); break;
@@ -666,10 +804,20 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         case EPI_RESID: launch_one<EPI_RESID>(p, split, grid, stream); break;
         case EPI_QKV: launch_one<EPI_QKV>(p, split, grid, stream); break;
         case EPI_CROSS: launch_one<EPI_CROSS>(p, split, grid, stream); break;
-        case EPI_CONV: launch_one<EPI_CONV>(p, split, grid, stream); break;
+        case EPI_CONV:
+            if (p.conv_k > 0)
+                launch_conv(p, split, grid, stream);
+            else
+                launch_one<EPI_CONV>(p, split, grid, stream);
+            break;
         default: return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: bad epilogue %d", p.epi);
     }
     imcui_prof_end(h, PROF_GEMM, stream);
+    if (dbg) {
+        const hipError_t e = hipStreamSynchronize(stream);
+        fprintf(stderr, "[gemm] done: %s\n", hipGetErrorString(e));
+        fflush(stderr);
+    }
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }
@@ -724,6 +872,30 @@ static unsigned short f32_to_f16_rtn(float f) {
     if (dt < du) return t;
     if (du < dt) return u;
     return (t & 1) ? u : t;
+}
+
+float split_weights_frag_host(const float* w, int N, int K, unsigned short* hi, unsigned short* lo) {
+    // planes [ceil(N/32)][K/16][2][32][8]: element (nf, ks, h, r, j) = W[nf*32 + r][ks*16 + h*8 + j]
+    const size_t n = (size_t)N * K;
+    unsigned short* th = (unsigned short*)malloc(n * sizeof(unsigned short));
+    unsigned short* tl = (unsigned short*)malloc(n * sizeof(unsigned short));
+    const float sc = split_weights_host(w, n, th, tl);
+    const int nfr = (N + 31) / 32, nks = K / 16;
+    for (int nf = 0; nf < nfr; ++nf)
+        for (int ks = 0; ks < nks; ++ks)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 32; ++r) {
+                    const int row = nf * 32 + r;
+                    const size_t dst = ((((size_t)nf * nks + ks) * 2 + hh) * 32 + r) * 8;
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t src = (size_t)row * K + ks * 16 + hh * 8 + j;
+                        hi[dst + j] = row < N ? th[src] : 0;
+                        lo[dst + j] = row < N ? tl[src] : 0;
+                    }
+                }
+    free(th);
+    free(tl);
+    return sc;
 }
 
 void pack_conv_gemm(const float* w, int Cout, int Cin, int ks, int Cin_pad, float* dst) {

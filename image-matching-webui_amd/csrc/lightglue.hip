@@ -183,21 +183,22 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
         packed[l.btoken + i] = tk[2 * i + 1][0];
     }
     // split-precision copies of every GEMM weight (taken from the packed f32 layout)
-    auto sp = [&](const LgSplit& d, size_t src, size_t n, int slot) {
-        packed[d.s + slot] = split_weights_host(packed + src, n, reinterpret_cast<unsigned short*>(packed + d.h) + (size_t)slot * n,
-                                                reinterpret_cast<unsigned short*>(packed + d.l) + (size_t)slot * n);
+    auto sp = [&](const LgSplit& d, size_t src, int N, int K, int slot) {
+        const size_t n = (size_t)N * K;
+        packed[d.s + slot] = split_weights_frag_host(packed + src, N, K, reinterpret_cast<unsigned short*>(packed + d.h) + (size_t)slot * n,
+                                                     reinterpret_cast<unsigned short*>(packed + d.l) + (size_t)slot * n);
     };
     for (int i = 0; i < LG_LAYERS; ++i) {
         const LgLayerOff& o = l.L[i];
-        sp(o.sqkv, o.wqkv, 768 * 256, 0);
-        sp(o.so, o.wo, 256 * 256, 0);
-        sp(o.s1s, o.w1s, 512 * 512, 0);
-        sp(o.s2s, o.w2s, 256 * 512, 0);
-        sp(o.sx, o.wx, 512 * 256, 0);
-        sp(o.sto, o.wto, 256 * 256, 0);
-        sp(o.s1c, o.w1c, 512 * 512, 0);
-        sp(o.s2c, o.w2c, 256 * 512, 0);
-        sp(l.sfinal, l.wfinal + (size_t)i * 65536, 65536, i);
+        sp(o.sqkv, o.wqkv, 768, 256, 0);
+        sp(o.so, o.wo, 256, 256, 0);
+        sp(o.s1s, o.w1s, 512, 512, 0);
+        sp(o.s2s, o.w2s, 256, 512, 0);
+        sp(o.sx, o.wx, 512, 256, 0);
+        sp(o.sto, o.wto, 256, 256, 0);
+        sp(o.s1c, o.w1c, 512, 512, 0);
+        sp(o.s2c, o.w2c, 256, 512, 0);
+        sp(l.sfinal, l.wfinal + (size_t)i * 65536, 256, 256, i);
     }
     return IMCUI_OK;
 }

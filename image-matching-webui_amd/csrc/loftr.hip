@@ -110,8 +110,8 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
         if (!w[i]) return IMCUI_ERR_ARG;
         memcpy(packed + l.w[i], w[i], (size_t)N * K * sizeof(float));
         if (b[i]) memcpy(packed + l.b[i], b[i], (size_t)N * sizeof(float));
-        packed[l.ws[i]] = split_weights_host(w[i], (size_t)N * K, reinterpret_cast<unsigned short*>(packed + l.wh[i]),
-                                             reinterpret_cast<unsigned short*>(packed + l.wl[i]));
+        packed[l.ws[i]] = split_weights_frag_host(w[i], N, K, reinterpret_cast<unsigned short*>(packed + l.wh[i]),
+                                                  reinterpret_cast<unsigned short*>(packed + l.wl[i]));
     }
     for (int i = 0; i < LF_NNORMS; ++i) {
         if (!norms[i]) return IMCUI_ERR_ARG;

@@ -30,7 +30,8 @@ static SpLayout sp_layout() {
         off += align_up((size_t)SP_COUT[i], 64);
     }
     for (int i = 1; i < 12; ++i) {  // conv1a (Cin = 1) stays on the VALU
-        const size_t n = (size_t)SP_COUT[i] * SP_CIN[i] * SP_K[i] * SP_K[i];
+        // 1x1 layers are stored fragment-major with rows padded to a multiple of 32 (convPb: 65 -> 96)
+        const size_t n = (size_t)(SP_K[i] == 1 ? align_up(SP_COUT[i], 32) : SP_COUT[i]) * SP_CIN[i] * SP_K[i] * SP_K[i];
         l.wh[i] = off;
         off += align_up(n / 2 + 1, 64);
         l.wl[i] = off;
@@ -63,7 +64,7 @@ extern "C" int imcui_hip_superpoint_pack_weights(const float* const* w, const fl
         if (SP_K[i] == 3)
             packed[l.ws[i]] = pack_conv3x3_split(w[i], SP_COUT[i], SP_CIN[i], hp, lp);
         else
-            packed[l.ws[i]] = split_weights_host(w[i], (size_t)SP_COUT[i] * SP_CIN[i], hp, lp);
+            packed[l.ws[i]] = split_weights_frag_host(w[i], SP_COUT[i], SP_CIN[i], hp, lp);
     }
     return IMCUI_OK;
 }
