@@ -757,12 +757,19 @@ __global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) 
     gemm_epilogue_staged<EPI>(p, c, acc, wsc, wm, wn, lo, hi, sm);
 }
 
+// The weight-DMA kernel fits three workgroups per CU (768 slots); a launch whose tile count leaves the
+// last round mostly empty is faster with two (512 slots, less sharing per workgroup).  Extra dynamic
+// LDS is the occupancy knob: 48 KB static + 32 KB dynamic -> two workgroups per CU.
+static unsigned occupancy_pad(long nblocks) {
+    const long r3 = (nblocks + 767) / 768, r2 = (nblocks + 511) / 512;
+    return (r2 * 4 <= r3 * 5) ? 32768u : 0u;  // a round at 3/CU costs ~1.25x a round at 2/CU
+}
 template <int EPI>
 static void launch_one(const GemmP& p, bool split, dim3 grid, hipStream_t stream) {
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI>, grid, dim3(256), 0, stream, p);
     else if (p.Wh != nullptr)
-        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else
         hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, false>), grid, dim3(256), 0, stream, p);
 }
@@ -770,7 +777,7 @@ static void launch_conv(const GemmP& p, bool split, dim3 grid, hipStream_t strea
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI_CONV>, grid, dim3(256), 0, stream, p);
     else if (p.Wh != nullptr)
-        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else
         hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, false>), grid, dim3(256), 0, stream, p);
 }
