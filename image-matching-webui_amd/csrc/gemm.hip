@@ -323,13 +323,72 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
         }
         unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
         const int i0 = c.row0 - c.seq * p.rows_per_seq;
+        if (rope) {
+            // q / k of the self block.  RoPE from the fragments means 32 scattered 8-byte table loads per
+            // lane; parked as f32 [token][128] instead, a thread finishes 8 consecutive features of one
+            // token (bias, RoPE with one float4 of cos and of sin, scale, split) and 8 lanes write one whole
+            // 128-byte row of each plane.
+            float* st = reinterpret_cast<float*>(sb);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (wm == h) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int tl = m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
+                                *reinterpret_cast<float4*>(st + tl * STG_C_ROW + fl) =
+                                    make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
+                                                acc[m][n][4 * q + 3] * wsc);
+                            }
+                }
+                __syncthreads();
+                const int ch = tid & 15;  // 8-feature chunk of the 128 columns
+                const int fl = ch * 8, d0 = fl & 63, hh = fl >> 6;
+                float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+                if (c.bias != nullptr) {
+                    ba = *reinterpret_cast<const float4*>(c.bias + c.col0 + fl);
+                    bb = *reinterpret_cast<const float4*>(c.bias + c.col0 + fl + 4);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int tl = (tid >> 4) + 16 * it;
+                    const int row = c.row0 + h * 64 + tl;
+                    const float4 va = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + fl);
+                    const float4 vb = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + fl + 4);
+                    const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
+                    const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                    float v[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
+                    const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
+                        const float a0 = v[2 * j], a1 = v[2 * j + 1];
+                        v[2 * j] = a0 * cc[j] + (-a1) * ss[j];
+                        v[2 * j + 1] = a1 * cc[j] + a0 * ss[j];
+                    }
+                    if (scale) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+                    }
+                    uint4 hv, lv;
+                    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
+                    unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tl) * 64 + d0;
+                    *reinterpret_cast<uint4*>(o) = hv;
+                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                }
+                if (h == 0) __syncthreads();
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (wm == h) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int tl = m * 32 + lo;  // token within the half
-                    const int row = c.row0 + h * 64 + tl;
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -344,17 +403,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                                 v[1] += b4.y;
                                 v[2] += b4.z;
                                 v[3] += b4.w;
-                            }
-                            if (rope) {
-                                // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
-                                const int d0 = fl & 63;
-                                const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
-                                const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
-                                const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-                                v[0] = a0 * cs.x + (-a1) * sn.x;
-                                v[1] = a1 * cs.x + a0 * sn.x;
-                                v[2] = a2 * cs.y + (-a3) * sn.y;
-                                v[3] = a3 * cs.y + a2 * sn.y;
                             }
                             if (scale) {
 #pragma unroll
