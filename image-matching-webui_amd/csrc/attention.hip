@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 // V^T LDS image: row d = 4 groups of 16 keys, each group stored as two 16-byte halves
 // {keys 0-3, 8-11} and {keys 4-7, 12-15} (= what the hi = 0 / hi = 1 half-waves consume in one
 // MFMA step), + one 16-byte pad per row -> a fragment is ONE conflict-free ds_read_b128.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define VSTR 9  // V^T row stride in 16-byte units
 #define P_SHIFT 14.0f
 #define LOG2E 1.44269504088896340736f
@@ -333,15 +334,23 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         // (which keeps the f16 low parts of small probabilities normal) cancels in O / l.
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         const float bias = P_SHIFT - m_new * LOG2E;
-        float l_t = 0.0f;
+        // two elements per instruction where the ISA has packed f32 forms (v_pk_fma_f32, v_pk_add_f32): on a
+        // SIMD the VALU and matrix instructions of co-resident waves serialise, so every VALU slot saved is
+        // matrix time gained
+        f32x2 l2 = {0.0f, 0.0f};
+        const f32x2 k2 = {LOG2E, LOG2E}, b2 = {bias, bias};
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[f][r], LOG2E, bias));
-                l_t += pv;
-                s[f][r] = pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x = {s[f][r], s[f][r + 1]};
+                const f32x2 a = __builtin_elementwise_fma(x, k2, b2);
+                const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                l2 += e;
+                s[f][r] = e[0];
+                s[f][r + 1] = e[1];
             }
+        const float l_t = l2[0] + l2[1];
         l_run = l_run * alpha + l_t;
         m_run = m_new;
         if (__ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved

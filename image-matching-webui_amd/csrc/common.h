@@ -39,11 +39,16 @@ __device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
 }
 // hi = round-toward-zero f16 pair (one instruction, saturates instead of overflowing to inf),
 // lo = round-to-nearest f16 of the exact remainders
+// lo = f16(x - hi) is ONE mixed-precision FMA per element (fma(hi_f16, -1, x_f32) rounded to f16: the
+// difference is exact in f32, so this is the same value as subtract-then-convert); the compiler's own
+// lowering of the C expression is convert, convert, packed subtract, packed convert.
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     hi = __builtin_bit_cast(unsigned, h);
-    const f16x2 l = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
-    lo = __builtin_bit_cast(unsigned, l);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
 }
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
     split2(a.x, a.y, hi.x, lo.x);

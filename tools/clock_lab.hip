@@ -37,15 +37,18 @@ int main() {
     unsigned long long* c;
     hipMalloc(&d, 1 << 20);
     hipMalloc(&c, 64);
+    for (int nacc = 1; nacc <= 4; nacc *= 2)
     for (int wavesPerSimd = 1; wavesPerSimd <= 2; ++wavesPerSimd)
         for (unsigned seed = 0; seed < 2; ++seed)
-            for (int rep = 0; rep < 3; ++rep) {
+            for (int rep = 0; rep < 2; ++rep) {
                 const int blocks = 256 * wavesPerSimd, iters = 4000;
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0);
                 hipEventCreate(&e1);
                 hipEventRecord(e0, 0);
-                hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, d, c, iters, seed);
+                if (nacc == 1) hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, d, c, iters * 4, seed);
+                else if (nacc == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(blocks), dim3(256), 0, 0, d, c, iters * 2, seed);
+                else hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, d, c, iters, seed);
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
                 float ms;
@@ -53,7 +56,7 @@ int main() {
                 unsigned long long h[2];
                 hipMemcpy(h, c, 16, hipMemcpyDeviceToHost);
                 const double flops = (double)blocks * 4 * iters * 4 * 32768.0;
-                printf("waves/SIMD=%d data=%s  %.1f us  %.0f TF/s   core clk %.0f MHz (memtime %llu / realtime %llu)\n", wavesPerSimd,
+                printf("chains=%d waves/SIMD=%d data=%s  %.1f us  %.0f TF/s   core clk %.0f MHz (memtime %llu / realtime %llu)\n", nacc, wavesPerSimd,
                        seed ? "random" : "zero", ms * 1e3, flops / (ms * 1e-3) * 1e-12, (double)h[0] / h[1] * 100.0, h[0], h[1]);
             }
     return 0;
