@@ -354,7 +354,7 @@ class LoFTRHIP:
 
 
 def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):
-    """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 64 == 0)."""
+    """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 32 == 0)."""
     hd = get_handle(x_nhwc.device)
     B, H, W, Cin = x_nhwc.shape
     Cout, _, ks, _ = w_oihw.shape

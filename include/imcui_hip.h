@@ -175,7 +175,7 @@ float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsig
 int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
                                 const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,
                                 int Cout, int relu, int pool, void* stream);
-/* NHWC convolution as an implicit-im2col GEMM: weights [Cout][k*k*Cin] (tap-major), Cin % 64 == 0,
+/* NHWC convolution as an implicit-im2col GEMM: weights [Cout][k*k*Cin] (tap-major), Cin % 32 == 0,
  * optional residual [B,Hout,Wout,Cout] added before the activation (0 none, 1 ReLU, 2 LeakyReLU 0.01) */
 int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in_nhwc, const float* w_gemm, const float* bias, const float* resid,
                             float* out_nhwc, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int act,

@@ -124,3 +124,34 @@ def test_superpoint_lightglue_end_to_end(precision):
         m_h, m_r = out["matches0"][b, :n0].cpu().long(), ref["matches0"][0]
         assert (m_h != m_r).sum().item() <= max(1, n0 // 200), (m_h != m_r).sum().item()
         assert (out["matching_scores0"][b, :n0].cpu() - ref["matching_scores0"][0]).abs().max().item() < 2e-3 or (m_h != m_r).any()
+
+
+def test_pipeline_full_batch_replicas_are_identical():
+    """BASELINE configs[2] at the bench batch (16 pairs, 640x480, 2048 key-points): size-independent
+    property -- the batch holds 4 distinct pairs replicated 4x, and every replica must produce the SAME
+    key-points, matches and scores (bit for bit): the result of a pair may not depend on its slot in the
+    batch, on which CU / XCD ran it, or on timing (this caught a load-ordering race in the GEMM)."""
+    from imcui_hip.pipeline import SuperPointLightGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from oracle.weights import superpoint_state_dict
+
+    B = 16
+    pipe = SuperPointLightGluePipeline(
+        {"nms_radius": 3, "max_keypoints": 2048, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)},
+        {"depth_confidence": -1.0, "width_confidence": -1.0, "match_threshold": 0.1, "state_dict": LSD},
+    ).eval().to("cuda:0")
+    img0, img1, _ = make_pair_batch(1234, B, 480, 640, distinct=4)
+    out = pipe(img0.to("cuda:0"), img1.to("cuda:0"))
+    torch.cuda.synchronize()
+    assert int(out["num_keypoints0"].min()) > 1000  # the synthetic pairs are feature rich
+    assert int((out["matches0"] >= 0).sum()) > 0
+    for key in ("keypoints0", "keypoints1", "num_keypoints0", "matches0", "matches1", "matching_scores0", "stop"):
+        v = out[key]
+        assert not torch.isnan(v.float()).any(), key
+        for i in range(4, B):
+            assert torch.equal(v[i], v[i % 4]), f"{key}: replica {i} differs from pair {i % 4}"
+    # sortedness / consistency of the match table at full size
+    m0, m1 = out["matches0"], out["matches1"]
+    for b in range(B):
+        idx = torch.nonzero(m0[b] >= 0).flatten()
+        assert torch.equal(m1[b][m0[b][idx]], idx), "matches0 / matches1 are not mutual"

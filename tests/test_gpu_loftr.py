@@ -21,7 +21,7 @@ def crops(seed, h, w):
     return base[..., 0:h, 0:w].contiguous(), base[..., 8 : h + 8, 16 : w + 16].contiguous()
 
 
-@pytest.mark.parametrize("cin,cout,ks,stride,act,use_res", [(128, 128, 3, 1, 1, True), (128, 256, 3, 2, 1, False), (128, 256, 1, 2, 0, False), (256, 256, 1, 1, 0, True), (256, 128, 3, 1, 2, False)])
+@pytest.mark.parametrize("cin,cout,ks,stride,act,use_res", [(128, 128, 3, 1, 1, True), (128, 256, 3, 2, 1, False), (128, 256, 1, 2, 0, False), (256, 256, 1, 1, 0, True), (256, 128, 3, 1, 2, False), (96, 64, 3, 1, 1, False), (32, 192, 3, 2, 0, False)])
 def test_conv_gemm_vs_torch(cin, cout, ks, stride, act, use_res, precision):
     from imcui_hip import backend
 
