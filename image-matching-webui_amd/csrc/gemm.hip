@@ -24,14 +24,14 @@ struct TileCtx {
 };
 
 // returns false when the workgroup has nothing to do
-__device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c) {
+__device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int bn = BN) {
     c.z = blockIdx.z;
     c.M = p.mcnt ? p.mcnt[c.z * p.cnt_stride] : p.M;
     c.N = p.ncnt ? p.ncnt[c.z * p.cnt_stride] : p.N;
-    const int ncol = (p.N + BN - 1) / BN;
+    const int ncol = (p.N + bn - 1) / bn;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     c.row0 = (tile / ncol) * BM;
-    c.col0 = (tile % ncol) * BN;
+    c.col0 = (tile % ncol) * bn;
     if (c.row0 >= c.M || c.col0 >= c.N) return false;
     c.bias = p.bias;
     c.seq = 0;
@@ -297,17 +297,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #define STG_C_ROW 132   // floats per parked [token][128 features] row (conflict-free both ways)
 #define STG_H_ROW 144   // bytes per parked row of 64 halves (128 + 16 pad)
 #define STG_H_PLANE 18432
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileCtx& c, f32x16 (&acc)[2][2], float wsc, int wm,
+// NW = 32-column fragments per wave: 2 -> 128-column tile (both wn waves park a half), 4 -> 256-column tile
+// (processed as two 128-column sub-tiles, each owned by the waves of one wn).
+template <int EPI, int NW>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileCtx& cc, f32x16 (&acc)[2][NW], float wsc, int wm,
                                                      int wn, int lo, int hi, char* sb) {
     const int tid = threadIdx.x;
+    constexpr int NPASS = NW;  // (token half) x (128-column sub-tile)
+#define PASS_H(ps) ((ps) & 1)
+#define PASS_C2(ps) ((ps) >> 1)
+#define PARKS(ps) (wm == PASS_H(ps) && (NW == 2 || wn == PASS_C2(ps)))
+#define FRAG_COL(n) ((NW == 2 ? wn * 64 : 0) + (n) * 32)
     if (EPI == EPI_QKV || EPI == EPI_CROSS) {
         if (!p.split_out) {
-            gemm_epilogue<EPI>(p, c, acc, wsc, wm, wn, lo, hi);
+            if constexpr (NW == 2) gemm_epilogue<EPI>(p, cc, acc, wsc, wm, wn, lo, hi);
             return;
         }
-        // the 128 columns of a tile are two heads of ONE of q / k / v (256 features each)
-        const int t = c.col0 >> 8, hd0 = (c.col0 >> 6) & 3;
+        // the 128 columns of a sub-tile are two heads of ONE of q / k / v (256 features each)
+        const int t = cc.col0 >> 8;
         float* dst;
         bool vt, rope, scale;
         if (EPI == EPI_QKV) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
             scale = (t == 0);
         }
         unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
-        const int i0 = c.row0 - c.seq * p.rows_per_seq;
+        const int i0 = cc.row0 - cc.seq * p.rows_per_seq;
         if (rope) {
             // q / k of the self block.  RoPE from the fragments means 32 scattered 8-byte table loads per
             // lane; parked as f32 [token][128] instead, a thread finishes 8 consecutive features of one
@@ -330,15 +337,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
             // 128-byte row of each plane.
             float* st = reinterpret_cast<float*>(sb);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (wm == h) {
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int h = PASS_H(ps);
+                const int col0 = cc.col0 + PASS_C2(ps) * 128, hd0 = (col0 >> 6) & 3;
+                if (PARKS(ps)) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int n = 0; n < 2; ++n)
+                        for (int n = 0; n < NW; ++n)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const int tl = m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
+                                const int tl = m * 32 + lo, fl = FRAG_COL(n) + 8 * q + 4 * hi;
                                 *reinterpret_cast<float4*>(st + tl * STG_C_ROW + fl) =
                                     make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
                                                 acc[m][n][4 * q + 3] * wsc);
@@ -348,26 +357,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                 const int ch = tid & 15;  // 8-feature chunk of the 128 columns
                 const int fl = ch * 8, d0 = fl & 63, hh = fl >> 6;
                 float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
-                if (c.bias != nullptr) {
-                    ba = *reinterpret_cast<const float4*>(c.bias + c.col0 + fl);
-                    bb = *reinterpret_cast<const float4*>(c.bias + c.col0 + fl + 4);
+                if (cc.bias != nullptr) {
+                    ba = *reinterpret_cast<const float4*>(cc.bias + col0 + fl);
+                    bb = *reinterpret_cast<const float4*>(cc.bias + col0 + fl + 4);
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int tl = (tid >> 4) + 16 * it;
-                    const int row = c.row0 + h * 64 + tl;
+                    const int row = cc.row0 + h * 64 + tl;
                     const float4 va = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + fl);
                     const float4 vb = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + fl + 4);
                     const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
                     const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
                     float v[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
-                    const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+                    const float cw[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)
                         const float a0 = v[2 * j], a1 = v[2 * j + 1];
-                        v[2 * j] = a0 * cc[j] + (-a1) * ss[j];
-                        v[2 * j + 1] = a1 * cc[j] + a0 * ss[j];
+                        v[2 * j] = a0 * cw[j] + (-a1) * ss[j];
+                        v[2 * j + 1] = a1 * cw[j] + a0 * ss[j];
                     }
                     if (scale) {
 #pragma unroll
@@ -375,30 +384,32 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                     }
                     uint4 hv, lv;
                     split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
-                    unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tl) * 64 + d0;
+                    unsigned short* o = d16 + (((size_t)cc.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tl) * 64 + d0;
                     *reinterpret_cast<uint4*>(o) = hv;
                     *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
                 }
-                if (h == 0) __syncthreads();
+                if (ps + 1 < NPASS) __syncthreads();
             }
             return;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (wm == h) {
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int h = PASS_H(ps);
+            const int col0 = cc.col0 + PASS_C2(ps) * 128, hd0 = (col0 >> 6) & 3;
+            if (PARKS(ps)) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int tl = m * 32 + lo;  // token within the half
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NW; ++n) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int fl = wn * 64 + n * 32 + 8 * q + 4 * hi;  // first of 4 features within the tile
-                            const int f0 = c.col0 + fl;
+                            const int fl = FRAG_COL(n) + 8 * q + 4 * hi;  // first of 4 features within the sub-tile
+                            const int f0 = col0 + fl;
                             float v[4] = {acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
                                           acc[m][n][4 * q + 3] * wsc};
-                            if (c.bias != nullptr) {
-                                const float4 b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+                            if (cc.bias != nullptr) {
+                                const float4 b4 = *reinterpret_cast<const float4*>(cc.bias + f0);
                                 v[0] += b4.x;
                                 v[1] += b4.y;
                                 v[2] += b4.z;
@@ -453,45 +464,46 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                     const int hh = rem >> 9, tok = (rem >> 3) & 63, gr = rem & 7;
                     const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STG_H_PLANE + (hh * 64 + tok) * STG_H_ROW + gr * 16);
                     unsigned short* o = d16 + (size_t)plane * p.plane_halves +
-                                        (((size_t)c.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tok) * 64 + gr * 8;
+                                        (((size_t)cc.seq * p.heads + hd0 + hh) * p.rows_per_seq + i0 + h * 64 + tok) * 64 + gr * 8;
                     *reinterpret_cast<uint4*>(o) = val;
                 } else {
                     // V^T [seq][head][64][rows]: one whole 128-byte line per (plane, feature)
                     const int feat = rem >> 3, gr = rem & 7;
                     const uint4 val = *reinterpret_cast<const uint4*>(sb + plane * STG_H_PLANE + feat * STG_H_ROW + gr * 16);
                     unsigned short* o = d16 + (size_t)plane * p.plane_halves +
-                                        (((size_t)c.seq * p.heads + hd0 + (feat >> 6)) * 64 + (feat & 63)) * p.rows_per_seq + i0 + h * 64 +
+                                        (((size_t)cc.seq * p.heads + hd0 + (feat >> 6)) * 64 + (feat & 63)) * p.rows_per_seq + i0 + h * 64 +
                                         gr * 8;
                     *reinterpret_cast<uint4*>(o) = val;
                 }
             }
-            if (h == 0) __syncthreads();
+            if (ps + 1 < NPASS) __syncthreads();
         }
         return;
     }
     // ---- row-major f32 outputs
-    float* C = p.C + (size_t)c.z * p.c_bs;
+    float* C = p.C + (size_t)cc.z * p.c_bs;
     float* st = reinterpret_cast<float*>(sb);
-    const int f0 = c.col0 + 4 * (tid & 31);
-    const bool colok = f0 < c.N;
-    const bool full = (f0 + 3 < c.N) && ((p.ldc & 3) == 0);
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c.bias != nullptr && colok) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (f0 + j < c.N) b[j] = c.bias[f0 + j];
-    }
     const bool res_vec = (EPI == EPI_CONV) && p.resid != nullptr && ((p.ldr & 3) == 0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (wm == h) {
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int h = PASS_H(ps);
+        const int f0 = cc.col0 + PASS_C2(ps) * 128 + 4 * (tid & 31);
+        const bool colok = f0 < cc.N;
+        const bool full = (f0 + 3 < cc.N) && ((p.ldc & 3) == 0);
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cc.bias != nullptr && colok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (f0 + j < cc.N) b[j] = cc.bias[f0 + j];
+        }
+        if (PARKS(ps)) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < NW; ++n)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int tl = m * 32 + lo, fl = wn * 64 + n * 32 + 8 * q + 4 * hi;
+                        const int tl = m * 32 + lo, fl = FRAG_COL(n) + 8 * q + 4 * hi;
                         *reinterpret_cast<float4*>(st + tl * STG_C_ROW + fl) =
                             make_float4(acc[m][n][4 * q + 0] * wsc, acc[m][n][4 * q + 1] * wsc, acc[m][n][4 * q + 2] * wsc,
                                         acc[m][n][4 * q + 3] * wsc);
@@ -502,8 +514,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 #pragma unroll 4
             for (int it = 0; it < 8; ++it) {
                 const int tl = (tid >> 5) + 8 * it;
-                const int row = c.row0 + h * 64 + tl;
-                if (row >= c.M) break;
+                const int row = cc.row0 + h * 64 + tl;
+                if (row >= cc.M) break;
                 const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + 4 * (tid & 31));
                 float v[4] = {t4.x + b[0], t4.y + b[1], t4.z + b[2], t4.w + b[3]};
                 float* dst = C + (size_t)row * p.ldc + f0;
@@ -519,7 +531,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (f0 + j < c.N) v[j] += rs[j];
+                                if (f0 + j < cc.N) v[j] += rs[j];
                         }
                     }
                     if (p.act == 1) {
@@ -548,12 +560,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (f0 + j < c.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
+                        if (f0 + j < cc.N) dst[j] = (EPI == EPI_RESID) ? dst[j] + v[j] : v[j];
                 }
             }
         }
-        if (h == 0) __syncthreads();
+        if (ps + 1 < NPASS) __syncthreads();
     }
+#undef PASS_H
+#undef PASS_C2
+#undef PARKS
+#undef FRAG_COL
 }
 
 // ------------------------------------------------------------------ 3 x f16 split kernel
@@ -582,27 +598,32 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 // ASRC: 0 = matrix (optionally two K slabs), 1 = implicit im2col of an NHWC image
 // WDMA: weights by LDS-DMA from fragment-major planes; otherwise B is an f32 matrix [N][K] (activations,
 //       e.g. similarity products) staged like A
-template <int EPI, int ASRC, bool WDMA>
-__global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) {
-    // A_hi 8K | A_lo 8K | B stage 0 (hi 8K, lo 8K) | B stage 1 ; reused by the epilogue
-    __shared__ uint4 smem[49152 / 16];
+// NW:   32-column fragments per wave: 2 -> tile 128 x 128 (three workgroups per CU), 4 -> tile 128 x 256 (two per
+//       CU, 80 KB LDS): per MFMA half the LDS fragment reads, half the activation staging and half the DMA issue
+//       -- on a SIMD the matrix pipe and everything else serialise, so the wave tile is the efficiency lever
+template <int EPI, int ASRC, bool WDMA, int NW>
+__global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_kernel(GemmP p) {
+    static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need the weight DMA path");
+    constexpr int BPL = 4 * NW * 1024;  // bytes per B plane per stage: [ks 2][nf 2 NW] fragments of 1 KiB
+    // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 ; reused by the epilogue
+    __shared__ uint4 smem[(16384 + 4 * BPL) / 16];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     TileCtx c;
-    if (!gemm_tile_setup(p, c)) return;
+    if (!gemm_tile_setup(p, c, 64 * NW)) return;
     const float* A = p.A + (size_t)c.z * p.a_bs;
     const float* A2 = p.A2 ? p.A2 + (size_t)c.z * p.a2_bs : nullptr;
     const float wsc = (WDMA && p.wscale) ? p.wscale[c.wsel] : 1.0f;
     const int nkt = p.K / BK3;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NW];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NW; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
@@ -683,22 +704,29 @@ __global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) 
     };
 
     // ---- B operand
-    // WDMA: wave w moves the fragments of column block nf = w (all planes / k-steps) of every tile
+    // WDMA: wave w moves the fragments of column blocks nf = w (+ 4 for 256-column tiles), all planes / k-steps
     const int nks = p.K >> 4;
     const int nfr = (p.N + 31) >> 5;
-    const uint4 *wh = nullptr, *wl = nullptr;
+    const uint4 *wh[NW / 2], *wl[NW / 2];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
-    if (WDMA) {
-        const int nfg = min((c.col0 >> 5) + wid, nfr - 1);
-        wh = reinterpret_cast<const uint4*>(p.Wh + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
-        wl = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < NW / 2; ++u) {
+        wh[u] = wl[u] = nullptr;
+        if (WDMA) {
+            const int nfg = min((c.col0 >> 5) + wid + 4 * u, nfr - 1);
+            wh[u] = reinterpret_cast<const uint4*>(p.Wh + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
+            wl[u] = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
+        }
     }
     auto dma_b = [&](int kt, int stg) __attribute__((always_inline)) {
-        const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + 16384 + stg * 16384 + wid * 1024);
-        GLDS16(wh + (size_t)(kt * 2 + 0) * 64, d);
-        GLDS16(wh + (size_t)(kt * 2 + 1) * 64, d + 4096);
-        GLDS16(wl + (size_t)(kt * 2 + 0) * 64, d + 8192);
-        GLDS16(wl + (size_t)(kt * 2 + 1) * 64, d + 8192 + 4096);
+#pragma unroll
+        for (int u = 0; u < NW / 2; ++u) {
+            const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + 16384 + stg * 2 * BPL + (wid + 4 * u) * 1024);
+            GLDS16(wh[u] + (size_t)(kt * 2 + 0) * 64, d);
+            GLDS16(wh[u] + (size_t)(kt * 2 + 1) * 64, d + BPL / 2);
+            GLDS16(wl[u] + (size_t)(kt * 2 + 0) * 64, d + BPL);
+            GLDS16(wl[u] + (size_t)(kt * 2 + 1) * 64, d + BPL + BPL / 2);
+        }
     };
     // !WDMA: B rows staged like A (single buffer = stage 0)
     f32x4 xc0, xd0, xc1, xd1, yc0, yd0, yc1, yd1;
@@ -726,10 +754,10 @@ __global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) 
     };
 
     auto compute = [&](int stg) __attribute__((always_inline)) {
-        const char* sbt = sm + 16384 + (WDMA ? stg * 16384 : 0);
+        const char* sbt = sm + 16384 + (WDMA ? stg * 2 * BPL : 0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 ah[2], al[2], bh[2], bl[2];
+            uint4 ah[2], al[2], bh[NW], bl[NW];
             const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -738,15 +766,15 @@ __global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) 
                 al[m] = *reinterpret_cast<const uint4*>(sm + 8192 + fo);
             }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int fo = (ks * 4 + wn * 2 + n) * 1024 + (WDMA ? lane * 16 : apos);
+            for (int n = 0; n < NW; ++n) {
+                const int fo = (ks * 2 * NW + wn * NW + n) * 1024 + (WDMA ? lane * 16 : apos);
                 bh[n] = *reinterpret_cast<const uint4*>(sbt + fo);
-                bl[n] = *reinterpret_cast<const uint4*>(sbt + 8192 + fo);
+                bl[n] = *reinterpret_cast<const uint4*>(sbt + BPL + fo);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
+                for (int n = 0; n < NW; ++n) {
                     // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
                     acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
                     acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
@@ -802,7 +830,7 @@ __global__ __launch_bounds__(256, WDMA ? 3 : 2) void gemm_split_kernel(GemmP p) 
             __syncthreads();
         }
     }
-    gemm_epilogue_staged<EPI>(p, c, acc, wsc, wm, wn, lo, hi, sm);
+    gemm_epilogue_staged<EPI, NW>(p, c, acc, wsc, wm, wn, lo, hi, sm);
 }
 
 // The weight-DMA kernel fits three workgroups per CU (768 slots); a launch whose tile count leaves the
@@ -812,22 +840,36 @@ static unsigned occupancy_pad(long nblocks) {
     const long r3 = (nblocks + 767) / 768, r2 = (nblocks + 511) / 512;
     return (r2 * 4 <= r3 * 5) ? 32768u : 0u;  // a round at 3/CU costs ~1.25x a round at 2/CU
 }
+// 256-column tiles whenever the weights are DMA-able and N is a multiple of 256, for the row-major epilogues
+// (measured: type BIAS / RESID -4..6 %; the QKV / CROSS plane epilogues lose more in their four single-wave
+// parking passes than the main loop gains, so they stay on 128-column tiles).
+static bool wide_ok(const GemmP& p) { return p.Wh != nullptr && p.N % 256 == 0 && p.epi != EPI_QKV && p.epi != EPI_CROSS; }
 template <int EPI>
-static void launch_one(const GemmP& p, bool split, dim3 grid, hipStream_t stream) {
+static void launch_one(const GemmP& p, bool split, hipStream_t stream) {
+    const bool wide = split && wide_ok(p);
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, wide ? 256 : BN), 1, p.batch);
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI>, grid, dim3(256), 0, stream, p);
+    else if (wide) {
+        if constexpr (EPI != EPI_QKV && EPI != EPI_CROSS)
+            hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 4>), grid, dim3(256), 0, stream, p);
+    }
     else if (p.Wh != nullptr)
-        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 2>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, false, 2>), grid, dim3(256), 0, stream, p);
 }
-static void launch_conv(const GemmP& p, bool split, dim3 grid, hipStream_t stream) {
+static void launch_conv(const GemmP& p, bool split, hipStream_t stream) {
+    const bool wide = split && wide_ok(p);
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, wide ? 256 : BN), 1, p.batch);
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI_CONV>, grid, dim3(256), 0, stream, p);
+    else if (wide)
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 4>), grid, dim3(256), 0, stream, p);
     else if (p.Wh != nullptr)
-        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 2>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, false, 2>), grid, dim3(256), 0, stream, p);
 }
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
@@ -843,8 +885,6 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.split_out && (!split || p.rows_per_seq <= 0 || p.N % BN != 0 || p.M % BM != 0 || p.batch != 1))
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: split_out needs the split mode and whole 128x128 tiles (M=%d N=%d)", p.M, p.N);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");
-    const int ntiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-    dim3 grid(ntiles, 1, p.batch);
     static const bool dbg = getenv("IMCUI_HIP_GEMM_DEBUG") != nullptr;
     if (dbg) {
         hipStreamSynchronize(stream);
@@ -854,16 +894,16 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     }
     imcui_prof_begin(h, PROF_GEMM, stream);
     switch (p.epi) {
-        case EPI_BIAS: launch_one<EPI_BIAS>(p, split, grid, stream); break;
-        case EPI_RELU: launch_one<EPI_RELU>(p, split, grid, stream); break;
-        case EPI_RESID: launch_one<EPI_RESID>(p, split, grid, stream); break;
-        case EPI_QKV: launch_one<EPI_QKV>(p, split, grid, stream); break;
-        case EPI_CROSS: launch_one<EPI_CROSS>(p, split, grid, stream); break;
+        case EPI_BIAS: launch_one<EPI_BIAS>(p, split, stream); break;
+        case EPI_RELU: launch_one<EPI_RELU>(p, split, stream); break;
+        case EPI_RESID: launch_one<EPI_RESID>(p, split, stream); break;
+        case EPI_QKV: launch_one<EPI_QKV>(p, split, stream); break;
+        case EPI_CROSS: launch_one<EPI_CROSS>(p, split, stream); break;
         case EPI_CONV:
             if (p.conv_k > 0)
-                launch_conv(p, split, grid, stream);
+                launch_conv(p, split, stream);
             else
-                launch_one<EPI_CONV>(p, split, grid, stream);
+                launch_one<EPI_CONV>(p, split, stream);
             break;
         default: return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: bad epilogue %d", p.epi);
     }
