@@ -35,6 +35,8 @@ LG_GF_PER_LAYER_PAIR = 25.23     # @N=M=2048, shared cross similarity
 ATTN_GF_PER_LAYER_PAIR = 15.03   # QK^T + PV, self (8.59) + cross with shared sim (6.44)
 PEAK_F32_MFMA_TF = 157.3         # MI355X_MICROARCH.md: dense f32 MFMA peak
 PEAK_F16_MFMA_TF = 2500.0        # dense f16/bf16 MFMA peak (split mode executes 3 f16 MFMAs per product)
+SUSTAINED_F16_MFMA_TF = 1800.0   # tools/clock_lab.hip on this chip: register-resident MFMA loop, random operands,
+                                 # power-limited to ~1.82 GHz (2200 TF/s at 2.18 GHz with zero operands)
 
 
 def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
@@ -254,6 +256,7 @@ def main():
                 "kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel (f32 MFMA flash attention)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "executed_tflops": executed, "executed_frac": executed / peak,
+                "executed_frac_of_sustained_peak": (executed / SUSTAINED_F16_MFMA_TF) if split else None,
                 "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n, "algorithmic_gflop_per_launch": attn_flops / 1e9,
             },
             "kernel_time_ms_per_step": {"attention": attn_ms / args.steps, "conv3x3": conv_ms / args.steps, "gemm": gemm_ms / args.steps},
