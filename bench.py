@@ -89,7 +89,7 @@ def bench_loftr(args, dev, rank, world):
     from oracle.weights import loftr_state_dict  # seeded weights only
 
     Hh, Ww = args.size if args.size else (1024, 1024)
-    B = args.batch if args.batch != 16 else 1
+    B = args.batch if args.batch != 32 else 1
     model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
     base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="splg", choices=["splg", "loftr"],
