@@ -567,15 +567,30 @@ __global__ __launch_bounds__(256) void lg_colstat_kernel(const float* __restrict
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
     if (blockIdx.x * 64 >= n1) return;
     const float* base = sim + (size_t)b * R * R;
+    // 8 independent loads per trip (a column walk is a dependent 256-byte-per-wave load chain otherwise:
+    // latency bound at 4x the HBM time); values are folded in the original row order
     float m = -INFINITY;
     if (j < n1)
-        for (int i = g; i < n0; i += 4) m = fmaxf(m, base[(size_t)i * R + j]);
+        for (int i = g; i < n0; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < n0) ? base[(size_t)(i + 4 * u) * R + j] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+        }
     sm[g][c] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
     float s = 0.0f;
     if (j < n1)
-        for (int i = g; i < n0; i += 4) s += expf(base[(size_t)i * R + j] - m);
+        for (int i = g; i < n0; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < n0) ? base[(size_t)(i + 4 * u) * R + j] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + 4 * u < n0) s += expf(v[u] - m);
+        }
     ss[g][c] = s;
     __syncthreads();
     if (g == 0 && j < n1) {
@@ -650,11 +665,20 @@ __global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict_
     if (j < n1) {
         const float cmj = cmax[(size_t)b * R + j], clj = cls[(size_t)b * R + j];
         const float l1 = ls[((size_t)2 * b + 1) * R + j];
-        for (int i = g; i < n0; i += 4) {
-            const float v = lg_score(base[(size_t)i * R + j], rm[i], rl[i], cmj, clj, l0[i], l1);
-            if (v > best) {
-                best = v;
-                bi = i;
+        for (int i0 = g; i0 < n0; i0 += 32) {
+            float sv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv8[u] = (i0 + 4 * u < n0) ? base[(size_t)(i0 + 4 * u) * R + j] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 4 * u;
+                if (i < n0) {
+                    const float v = lg_score(sv8[u], rm[i], rl[i], cmj, clj, l0[i], l1);
+                    if (v > best) {
+                        best = v;
+                        bi = i;
+                    }
+                }
             }
         }
     }
