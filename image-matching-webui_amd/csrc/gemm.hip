@@ -788,46 +788,82 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
 #define DMA_LANDED(pend) \
     if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // prologue: tile 0 -> LDS, tile 1 in flight
-    issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
-    if (WDMA) dma_b(0, 0); else issue_b(0, xc0, xd0, xc1, xd1);
-    if (nkt > 1) {
-        issue_a(1, ya0, yb0, ya1, yb1, yv0, yv1);
-        if (!WDMA) issue_b(1, yc0, yd0, yc1, yd1);
-    }
-    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-    if (!WDMA) store_b(xc0, xd0, xc1, xd1);
-    DMA_LANDED(nkt > 1)
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        // tile kt is in LDS (weights in stage 0); y holds tile kt+1 (in flight)
-        if (kt + 2 < nkt) {
-            issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
-            if (!WDMA) issue_b(kt + 2, xc0, xd0, xc1, xd1);
-        }
-        if (WDMA && kt + 1 < nkt) dma_b(kt + 1, 1);
-        compute(0);
+    if constexpr (WDMA) {
+        // The hand-placed vmcnt(0) that publishes a weight tile also retires every register load in flight
+        // (no order is assumed between LDS-DMA and register loads), so the activation loads of tile kt+2 are
+        // issued right AFTER it: they then have a whole iteration (barrier, DMA issue, 24-48 MFMAs, barrier)
+        // to land before the next drain instead of one matrix phase.  One register set.
+        issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
+        dma_b(0, 0);
+        store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+        DMA_LANDED(false)
+        if (nkt > 1) issue_a(1, xa0, xb0, xa1, xb1, xv0, xv1);
         __syncthreads();
-        if (kt + 1 < nkt) {
-            store_a(ya0, yb0, ya1, yb1, yv0, yv1);
-            if (!WDMA) store_b(yc0, yd0, yc1, yd1);
-            DMA_LANDED(kt + 2 < nkt)
-        }
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            if (kt + 3 < nkt) {
-                issue_a(kt + 3, ya0, yb0, ya1, yb1, yv0, yv1);
-                if (!WDMA) issue_b(kt + 3, yc0, yd0, yc1, yd1);
-            }
-            if (WDMA && kt + 2 < nkt) dma_b(kt + 2, 0);
-            compute(1);
+        for (int kt = 0; kt < nkt; kt += 2) {
+            // tile kt: activations in LDS, weights in stage 0; x holds tile kt+1 (in flight)
+            if (kt + 1 < nkt) dma_b(kt + 1, 1);
+            compute(0);
             __syncthreads();
-            if (kt + 2 < nkt) {
+            if (kt + 1 < nkt) {
                 store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-                if (!WDMA) store_b(xc0, xd0, xc1, xd1);
-                DMA_LANDED(kt + 3 < nkt)
+                DMA_LANDED(false)
+                if (kt + 2 < nkt) issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
             }
             __syncthreads();
+            if (kt + 1 < nkt) {
+                if (kt + 2 < nkt) dma_b(kt + 2, 0);
+                compute(1);
+                __syncthreads();
+                if (kt + 2 < nkt) {
+                    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+                    DMA_LANDED(false)
+                    if (kt + 3 < nkt) issue_a(kt + 3, xa0, xb0, xa1, xb1, xv0, xv1);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+    // prologue: tile 0 -> LDS, tile 1 in flight
+        issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
+        if (WDMA) dma_b(0, 0); else issue_b(0, xc0, xd0, xc1, xd1);
+        if (nkt > 1) {
+            issue_a(1, ya0, yb0, ya1, yb1, yv0, yv1);
+            if (!WDMA) issue_b(1, yc0, yd0, yc1, yd1);
+        }
+        store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+        if (!WDMA) store_b(xc0, xd0, xc1, xd1);
+        DMA_LANDED(nkt > 1)
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            // tile kt is in LDS (weights in stage 0); y holds tile kt+1 (in flight)
+            if (kt + 2 < nkt) {
+                issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
+                if (!WDMA) issue_b(kt + 2, xc0, xd0, xc1, xd1);
+            }
+            if (WDMA && kt + 1 < nkt) dma_b(kt + 1, 1);
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                store_a(ya0, yb0, ya1, yb1, yv0, yv1);
+                if (!WDMA) store_b(yc0, yd0, yc1, yd1);
+                DMA_LANDED(kt + 2 < nkt)
+            }
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                if (kt + 3 < nkt) {
+                    issue_a(kt + 3, ya0, yb0, ya1, yb1, yv0, yv1);
+                    if (!WDMA) issue_b(kt + 3, yc0, yd0, yc1, yd1);
+                }
+                if (WDMA && kt + 2 < nkt) dma_b(kt + 2, 0);
+                compute(1);
+                __syncthreads();
+                if (kt + 2 < nkt) {
+                    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+                    if (!WDMA) store_b(xc0, xd0, xc1, xd1);
+                    DMA_LANDED(kt + 3 < nkt)
+                }
+                __syncthreads();
+            }
         }
     }
     gemm_epilogue_staged<EPI, NW>(p, c, acc, wsc, wm, wn, lo, hi, sm);
