@@ -209,9 +209,49 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
         if (tid < 64) w1[9 * 64 + tid] = b1a[tid];
     }
 
+    // Input patch of a 32-channel chunk: 340 pixels x 4 channel octets = 1360 granules, <= 6 per thread.  For
+    // the plain layers the granules of chunk ch+1 are fetched into registers while the nine taps of chunk ch
+    // are multiplied (the fetch used to sit, latency exposed, between two chunks).
+    constexpr int NPG = (SNPIX * 4 + 255) / 256;
+    float4 pa[NPG], pc[NPG];
+    unsigned pvalid = 0;
+    auto patch_fetch = [&](int ch) __attribute__((always_inline)) {
+        pvalid = 0;
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int idx = tid + 256 * k;
+            const int oc = idx & 3, pp = idx >> 2;
+            const int py = pp / SPW, px = pp - py * SPW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            if (idx < SNPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
+                pa[k] = *reinterpret_cast<const float4*>(src);
+                pc[k] = *reinterpret_cast<const float4*>(src + 4);
+                pvalid |= 1u << k;
+            }
+        }
+    };
+    auto patch_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < SNPIX * 4) {
+                uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
+                if ((pvalid >> k) & 1u) split8(pa[k], pc[k], hq, lq);
+                Ph[(idx & 3) * SPSTR + (idx >> 2)] = hq;
+                Pl[(idx & 3) * SPSTR + (idx >> 2)] = lq;
+            }
+        }
+    };
+    if (!FUSE1A) patch_fetch(0);
+
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();  // everybody is done with the previous patch (and the image tile is visible)
-        for (int idx = tid; idx < SNPIX * 4; idx += 256) {
+        if (!FUSE1A) {
+            patch_store();
+            if (ch + 1 < nchunk) patch_fetch(ch + 1);
+        }
+        for (int idx = tid; FUSE1A && idx < SNPIX * 4; idx += 256) {
             const int oc = idx & 3, pp = idx >> 2;
             const int py = pp / SPW, px = pp - py * SPW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
