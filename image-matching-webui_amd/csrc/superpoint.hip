@@ -125,41 +125,50 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
     }
     __syncthreads();
 
-    // T = max over [v-R, v+R] of src (row pass).  work item = (row u, chunk c); lanes run along u.
-    auto rowpass = [&](const float* src) __attribute__((always_inline)) {
-        for (int it = tid; it < Rg * NCH; it += 256) {
-            const int u = it % Rg, v0 = (it / Rg) * 8;
+    // Each pool only has to be right where a later stage still reads it: pool p (1..5) is evaluated on the
+    // tile plus a halo of (5 - p) R, i.e. with a margin of m = p R from the staged region (the last pool
+    // exactly on the 32 x 32 core).  That halves the work of evaluating all five on the full 5R-halo region.
+    // T = max over [v-R, v+R] of src (row pass) for rows [m-R, Rg-m+R) x columns [m, Rg-m).
+    // work item = (row u, chunk of 8 columns); lanes run along u.
+    auto rowpass = [&](const float* src, auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int nu = Rg - 2 * (m - R), nv = Rg - 2 * m, nch = (nv + 7) / 8;
+        for (int it = tid; it < nu * nch; it += 256) {
+            const int u = (m - R) + it % nu, v0 = m + (it / nu) * 8;
             float w[8 + 2 * R];
 #pragma unroll
             for (int j = 0; j < 8 + 2 * R; ++j) {
                 const int v = v0 - R + j;
-                w[j] = (v >= 0 && v < Rg) ? src[u * RS + v] : -INFINITY;
+                w[j] = (v < Rg) ? src[u * RS + v] : -INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float m = w[j];
+                float mx = w[j];
 #pragma unroll
-                for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
-                if (v0 + j < Rg) T[u * RS + v0 + j] = m;
+                for (int k = 1; k <= 2 * R; ++k) mx = fmaxf(mx, w[j + k]);
+                if (v0 + j < Rg - m) T[u * RS + v0 + j] = mx;
             }
         }
     };
-    // column pass over T; calls f(u, v, pooled value).  work item = (chunk c, column v); lanes along v.
-    auto colpass = [&](auto&& f) __attribute__((always_inline)) {
-        for (int it = tid; it < Rg * NCH; it += 256) {
-            const int v = it % Rg, u0 = (it / Rg) * 8;
+    // column pass over T on [m, Rg-m)^2; calls f(u, v, pooled value).  work item = (chunk of 8 rows, column v);
+    // lanes along v.
+    auto colpass = [&](auto mc, auto&& f) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int nv = Rg - 2 * m, nch = (nv + 7) / 8;
+        for (int it = tid; it < nv * nch; it += 256) {
+            const int v = m + it % nv, u0 = m + (it / nv) * 8;
             float w[8 + 2 * R];
 #pragma unroll
             for (int j = 0; j < 8 + 2 * R; ++j) {
                 const int u = u0 - R + j;
-                w[j] = (u >= 0 && u < Rg) ? T[u * RS + v] : -INFINITY;
+                w[j] = (u < Rg) ? T[u * RS + v] : -INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float m = w[j];
+                float mx = w[j];
 #pragma unroll
-                for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
-                if (u0 + j < Rg) f(u0 + j, v, m);
+                for (int k = 1; k <= 2 * R; ++k) mx = fmaxf(mx, w[j + k]);
+                if (u0 + j < Rg - m) f(u0 + j, v, mx);
             }
         }
     };
@@ -167,31 +176,37 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
         const int y = y0 + u, x = x0 + v;
         return y >= 0 && y < H && x >= 0 && x < W;
     };
+    using M1 = std::integral_constant<int, 1 * R>;
+    using M2 = std::integral_constant<int, 2 * R>;
+    using M3 = std::integral_constant<int, 3 * R>;
+    using M4 = std::integral_constant<int, 4 * R>;
+    using M5 = std::integral_constant<int, 5 * R>;
 
     // max_mask = scores == max_pool(scores)
-    rowpass(S);
+    rowpass(S, M1{});
     __syncthreads();
-    colpass([&](int u, int v, float pm) { M[u * RS + v] = (inimg(u, v) && S[u * RS + v] == pm) ? 1.0f : 0.0f; });
+    colpass(M1{}, [&](int u, int v, float pm) { M[u * RS + v] = (inimg(u, v) && S[u * RS + v] == pm) ? 1.0f : 0.0f; });
     __syncthreads();
-#pragma unroll 1
-    for (int iter = 0; iter < 2; ++iter) {
+    auto iteration = [&](auto ma, auto mb) __attribute__((always_inline)) {
         // supp_mask = max_pool(max_mask) > 0 ; supp_scores = where(supp_mask, 0, scores)
-        rowpass(M);
+        rowpass(M, ma);
         __syncthreads();
-        colpass([&](int u, int v, float pm) {
+        colpass(ma, [&](int u, int v, float pm) {
             const bool supp = pm > 0.0f;
             U[u * RS + v] = supp ? 1.0f : 0.0f;
             X[u * RS + v] = inimg(u, v) ? (supp ? 0.0f : S[u * RS + v]) : -INFINITY;
         });
         __syncthreads();
         // new_max_mask = supp_scores == max_pool(supp_scores) ; max_mask |= new_max_mask & ~supp_mask
-        rowpass(X);
+        rowpass(X, mb);
         __syncthreads();
-        colpass([&](int u, int v, float pm) {
+        colpass(mb, [&](int u, int v, float pm) {
             if (inimg(u, v) && X[u * RS + v] == pm && U[u * RS + v] == 0.0f) M[u * RS + v] = 1.0f;
         });
         __syncthreads();
-    }
+    };
+    iteration(M2{}, M3{});
+    iteration(M4{}, M5{});
     float* dst = out + (size_t)b * H * W;
     for (int i = tid; i < NMS_T * NMS_T; i += 256) {
         const int ty = i / NMS_T, tx = i - ty * NMS_T;
