@@ -251,6 +251,19 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
             patch_store();
             if (ch + 1 < nchunk) patch_fetch(ch + 1);
         }
+        // fused first layer: a thread always works on the same channel octet (256 % 4 == 0), so the 9 x 8 weights
+        // and the bias of that octet are fetched from LDS once per chunk, not once per granule
+        float4 kw0[9], kw1[9], kb0, kb1;
+        if (FUSE1A) {
+            const int c0 = ch * 32 + (tid & 3) * 8;
+            kb0 = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0);
+            kb1 = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0 + 4);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                kw0[t9] = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0);
+                kw1[t9] = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0 + 4);
+            }
+        }
         for (int idx = tid; FUSE1A && idx < SNPIX * 4; idx += 256) {
             const int oc = idx & 3, pp = idx >> 2;
             const int py = pp / SPW, px = pp - py * SPW;
@@ -260,14 +273,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                 float4 a, c;
                 if (FUSE1A) {
                     // relu(conv1a) for channels ch*32 + oc*8 .. +7 of this pixel (tap-major fmaf chain)
-                    const int c0 = ch * 32 + oc * 8;
-                    a = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0);
-                    c = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0 + 4);
+                    a = kb0;
+                    c = kb1;
 #pragma unroll
                     for (int t9 = 0; t9 < 9; ++t9) {
                         const float v = img[(py + t9 / 3) * ITW + px + t9 % 3];
-                        const float4 k0 = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0);
-                        const float4 k1 = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0 + 4);
+                        const float4 k0 = kw0[t9];
+                        const float4 k1 = kw1[t9];
                         a.x = fmaf(v, k0.x, a.x);
                         a.y = fmaf(v, k0.y, a.y);
                         a.z = fmaf(v, k0.z, a.z);

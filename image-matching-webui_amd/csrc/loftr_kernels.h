@@ -261,11 +261,25 @@ __global__ __launch_bounds__(256) void lf_rowstat_kernel(const float* __restrict
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= L) return;
     const float* row = sim + ((size_t)b * L + i) * S;
+    // 8 independent loads per trip, folded in the original order (a one-load-per-trip walk is latency bound)
     float m = -INFINITY;
-    for (int j = lane; j < S; j += 64) m = fmaxf(m, row[j]);
+    for (int j = lane; j < S; j += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j + 64 * u < S) ? row[j + 64 * u] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    }
     m = wave_max(m);
     float s = 0.0f;
-    for (int j = lane; j < S; j += 64) s += expf(row[j] - m);
+    for (int j = lane; j < S; j += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j + 64 * u < S) ? row[j + 64 * u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + 64 * u < S) s += expf(v[u] - m);
+    }
     s = wave_sum(s);
     if (lane == 0) {
         rmax[(size_t)b * L + i] = m;
@@ -286,13 +300,26 @@ __global__ __launch_bounds__(256) void lf_colstat_kernel(const float* __restrict
     const float* base = sim + (size_t)b * L * S;
     float m = -INFINITY;
     if (j < S)
-        for (int i = i0 + g; i < i1; i += 4) m = fmaxf(m, base[(size_t)i * S + j]);
+        for (int i = i0 + g; i < i1; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < i1) ? base[(size_t)(i + 4 * u) * S + j] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+        }
     sm[g][c] = m;
     __syncthreads();
     m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
     float s = 0.0f;
     if (j < S && m > -INFINITY)
-        for (int i = i0 + g; i < i1; i += 4) s += expf(base[(size_t)i * S + j] - m);
+        for (int i = i0 + g; i < i1; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < i1) ? base[(size_t)(i + 4 * u) * S + j] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + 4 * u < i1) s += expf(v[u] - m);
+        }
     ss[g][c] = s;
     __syncthreads();
     if (g == 0 && j < S) {
@@ -332,11 +359,25 @@ __global__ __launch_bounds__(256) void lf_rowbest_kernel(const float* __restrict
     const float rm = rmax[(size_t)b * L + i], rs = rsum[(size_t)b * L + i];
     float bv = -1.0f;
     int bj = 0x7fffffff;
-    for (int j = lane; j < S; j += 64) {
-        const float v = lf_conf(row[j], cmax[(size_t)b * S + j], csum[(size_t)b * S + j], rm, rs);
-        if (v > bv) {
-            bv = v;
-            bj = j;
+    for (int j0 = lane; j0 < S; j0 += 512) {
+        float sv[8], cm[8], cs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = min(j0 + 64 * u, S - 1);
+            sv[u] = row[j];
+            cm[u] = cmax[(size_t)b * S + j];
+            cs[u] = csum[(size_t)b * S + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < S) {
+                const float v = lf_conf(sv[u], cm[u], cs[u], rm, rs);
+                if (v > bv) {
+                    bv = v;
+                    bj = j;
+                }
+            }
         }
     }
 #pragma unroll
@@ -368,8 +409,19 @@ __global__ __launch_bounds__(256) void lf_colbest_kernel(const float* __restrict
     float bv = -1.0f;
     if (j < S) {
         const float cm = cmax[(size_t)b * S + j], cs = csum[(size_t)b * S + j];
-        for (int i = i0 + g; i < i1; i += 4)
-            bv = fmaxf(bv, lf_conf(base[(size_t)i * S + j], cm, cs, rmax[(size_t)b * L + i], rsum[(size_t)b * L + i]));
+        for (int ia = i0 + g; ia < i1; ia += 32) {
+            float sv8[8], rm8[8], rs8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(ia + 4 * u, i1 - 1);
+                sv8[u] = base[(size_t)i * S + j];
+                rm8[u] = rmax[(size_t)b * L + i];
+                rs8[u] = rsum[(size_t)b * L + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (ia + 4 * u < i1) bv = fmaxf(bv, lf_conf(sv8[u], cm, cs, rm8[u], rs8[u]));
+        }
     }
     sv[g][c] = bv;
     __syncthreads();
