@@ -575,9 +575,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 // ------------------------------------------------------------------ 3 x f16 split kernel
 // Tile 128 x 128 x 32, 4 waves (2 x 2), three workgroups per CU (48 KB LDS, <= 168 VGPRs).
 //  * Weights (WDMA): packed at load time as FRAGMENT-MAJOR f16 hi / lo planes
-//    [N/32][K/16][64 lanes][8 halves], so one `global_load_lds_dwordx4` moves a ready-to-use 1 KiB MFMA
-//    fragment L2 -> LDS with no registers, no ds_write and no bank conflicts; double-buffered, the tile
-//    for step kt+1 streams in while step kt is multiplied.
+//    [N/32][K/16][64 lanes][8 halves]: a wave instruction moves a ready-to-use, conflict-free 1 KiB MFMA
+//    fragment -- by `global_load_lds_dwordx4` (L2 -> LDS, no registers, 256-column tiles) or as one coalesced
+//    16-byte load + ds_write_b128 per lane (128-column tiles); double-buffered, the tile for step kt+1 streams
+//    in while step kt is multiplied.
 //  * Activations: fetched two tiles ahead into registers, split into (hi, lo) f16 and written to a
 //    single LDS buffer in the same fragment order with the granule position XOR-swizzled by 2*(k-octet)
 //    (both the ds_write_b128 of 8 lanes = 2 rows x 4 octets and the fragment ds_read_b128 are then
@@ -603,6 +604,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 //       -- on a SIMD the matrix pipe and everything else serialise, so the wave tile is the efficiency lever
 template <int EPI, int ASRC, bool WDMA, int NW>
 __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_kernel(GemmP p) {
+    // 128-column tiles take the weight fragments through registers (4 x 16 B per lane per tile, waits counted by
+    // the compiler): measured 3-5 % faster than the DMA there.  256-column tiles have no registers to spare
+    // (128 accumulators) and use the LDS-DMA.
+    constexpr bool WREGP = WDMA && NW == 2;
     static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need the weight DMA path");
     constexpr int BPL = 4 * NW * 1024;  // bytes per B plane per stage: [ks 2][nf 2 NW] fragments of 1 KiB
     // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 ; reused by the epilogue
@@ -718,6 +723,21 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
             wl[u] = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nfg * nks) * 64 + lane;
         }
     }
+    // WREGP: the fragment-major planes through registers
+    uint4 bq0, bq1, bq2, bq3;
+    auto load_bp = [&](int kt) __attribute__((always_inline)) {
+        bq0 = wh[0][(size_t)(kt * 2 + 0) * 64];
+        bq1 = wh[0][(size_t)(kt * 2 + 1) * 64];
+        bq2 = wl[0][(size_t)(kt * 2 + 0) * 64];
+        bq3 = wl[0][(size_t)(kt * 2 + 1) * 64];
+    };
+    auto store_bp = [&](int stg) __attribute__((always_inline)) {
+        char* d = sm + 16384 + stg * 2 * BPL + wid * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(d) = bq0;
+        *reinterpret_cast<uint4*>(d + BPL / 2) = bq1;
+        *reinterpret_cast<uint4*>(d + BPL) = bq2;
+        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = bq3;
+    };
     auto dma_b = [&](int kt, int stg) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NW / 2; ++u) {
@@ -788,7 +808,43 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
 #define DMA_LANDED(pend) \
     if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    if constexpr (WDMA) {
+    if constexpr (WREGP) {
+        issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
+        load_bp(0);
+        store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+        store_bp(0);
+        if (nkt > 1) {
+            issue_a(1, xa0, xb0, xa1, xb1, xv0, xv1);
+            load_bp(1);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+                store_bp(1);
+                if (kt + 2 < nkt) {
+                    issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
+                    load_bp(kt + 2);
+                }
+            }
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                compute(1);
+                __syncthreads();
+                if (kt + 2 < nkt) {
+                    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
+                    store_bp(0);
+                    if (kt + 3 < nkt) {
+                        issue_a(kt + 3, xa0, xb0, xa1, xb1, xv0, xv1);
+                        load_bp(kt + 3);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else if constexpr (WDMA) {
         // The hand-placed vmcnt(0) that publishes a weight tile also retires every register load in flight
         // (no order is assumed between LDS-DMA and register loads), so the activation loads of tile kt+2 are
         // issued right AFTER it: they then have a whole iteration (barrier, DMA issue, 24-48 MFMAs, barrier)
