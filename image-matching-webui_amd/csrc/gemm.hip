@@ -610,8 +610,8 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     constexpr bool WREGP = WDMA && NW == 2;
     static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need the weight DMA path");
     constexpr int BPL = 4 * NW * 1024;  // bytes per B plane per stage: [ks 2][nf 2 NW] fragments of 1 KiB
-    // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 ; reused by the epilogue
-    __shared__ uint4 smem[(16384 + 4 * BPL) / 16];
+    // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 (DMA path only) ; reused by the epilogue (<= 36864 B)
+    __shared__ uint4 smem[((WDMA && NW == 2) ? 36864 : 16384 + 4 * BPL) / 16];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -725,19 +725,22 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     }
     // WREGP: the fragment-major planes through registers
     uint4 bq0, bq1, bq2, bq3;
-    auto load_bp = [&](int kt) __attribute__((always_inline)) {
-        bq0 = wh[0][(size_t)(kt * 2 + 0) * 64];
-        bq1 = wh[0][(size_t)(kt * 2 + 1) * 64];
-        bq2 = wl[0][(size_t)(kt * 2 + 0) * 64];
-        bq3 = wl[0][(size_t)(kt * 2 + 1) * 64];
+    auto load_bp2 = [&](int kt, uint4& q0, uint4& q1, uint4& q2, uint4& q3) __attribute__((always_inline)) {
+        q0 = wh[0][(size_t)(kt * 2 + 0) * 64];
+        q1 = wh[0][(size_t)(kt * 2 + 1) * 64];
+        q2 = wl[0][(size_t)(kt * 2 + 0) * 64];
+        q3 = wl[0][(size_t)(kt * 2 + 1) * 64];
     };
-    auto store_bp = [&](int stg) __attribute__((always_inline)) {
-        char* d = sm + 16384 + stg * 2 * BPL + wid * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(d) = bq0;
-        *reinterpret_cast<uint4*>(d + BPL / 2) = bq1;
-        *reinterpret_cast<uint4*>(d + BPL) = bq2;
-        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = bq3;
+    auto store_bp2 = [&](int stg, uint4& q0, uint4& q1, uint4& q2, uint4& q3) __attribute__((always_inline)) {
+        char* d = sm + 16384 + wid * 1024 + lane * 16;  // single buffer: written between the two barriers, like A
+        (void)stg;
+        *reinterpret_cast<uint4*>(d) = q0;
+        *reinterpret_cast<uint4*>(d + BPL / 2) = q1;
+        *reinterpret_cast<uint4*>(d + BPL) = q2;
+        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = q3;
     };
+    auto load_bp = [&](int kt) __attribute__((always_inline)) { load_bp2(kt, bq0, bq1, bq2, bq3); };
+    auto store_bp = [&](int stg) __attribute__((always_inline)) { store_bp2(stg, bq0, bq1, bq2, bq3); };
     auto dma_b = [&](int kt, int stg) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NW / 2; ++u) {
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     };
 
     auto compute = [&](int stg) __attribute__((always_inline)) {
-        const char* sbt = sm + 16384 + (WDMA ? stg * 2 * BPL : 0);
+        const char* sbt = sm + 16384 + ((WDMA && !WREGP) ? stg * 2 * BPL : 0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 ah[2], al[2], bh[NW], bl[NW];
@@ -925,9 +928,10 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     gemm_epilogue_staged<EPI, NW>(p, c, acc, wsc, wm, wn, lo, hi, sm);
 }
 
-// The weight-DMA kernel fits three workgroups per CU (768 slots); a launch whose tile count leaves the
-// last round mostly empty is faster with two (512 slots, less sharing per workgroup).  Extra dynamic
-// LDS is the occupancy knob: 48 KB static + 32 KB dynamic -> two workgroups per CU.
+// The 128-column kernel runs three workgroups per CU (768 slots, register-limited: a 128-VGPR build for four
+// was 40 % slower and mis-compiled); a launch whose tile count leaves the last round mostly empty is faster
+// with two (512 slots, less sharing per workgroup).  Extra dynamic LDS is the occupancy knob:
+// 36 KB static + 32 KB dynamic -> two workgroups per CU.
 static unsigned occupancy_pad(long nblocks) {
     const long r3 = (nblocks + 767) / 768, r2 = (nblocks + 511) / 512;
     return (r2 * 4 <= r3 * 5) ? 32768u : 0u;  // a round at 3/CU costs ~1.25x a round at 2/CU
