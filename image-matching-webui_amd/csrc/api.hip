@@ -113,6 +113,33 @@ extern "C" int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float*
     return gemm_launch(h, g, (hipStream_t)stream);
 }
 
+extern "C" float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* hi, unsigned short* lo) {
+    if (!w || !hi || !lo || N <= 0 || K <= 0 || K % 16) return 0.0f;
+    return split_weights_frag_host(w, N, K, hi, lo);
+}
+
+extern "C" int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned short* wh, const unsigned short* wl,
+                                          const float* wscale, const float* bias, float* C, int M, int N, int K, int relu,
+                                          void* stream) {
+    if (!h || !A || !wh || !wl || !wscale || !C) return imcui_set_err(h, IMCUI_ERR_ARG, "linear_split: null argument");
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "linear_split: needs precision 1 (3 x f16 split)");
+    GemmP g;
+    g.epi = relu ? EPI_RELU : EPI_BIAS;
+    g.A = A;
+    g.lda = K;
+    g.Wh = wh;
+    g.Wl = wl;
+    g.wscale = wscale;
+    g.ldw = K;
+    g.bias = bias;
+    g.C = C;
+    g.ldc = N;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    return gemm_launch(h, g, (hipStream_t)stream);
+}
+
 extern "C" int imcui_hip_conv3x3_pack(const float* w_oihw, int Cout, int Cin, float* packed) {
     if (!w_oihw || !packed || Cin % 32 || Cout % 64) return IMCUI_ERR_ARG;
     pack_conv3x3(w_oihw, Cout, Cin, packed);

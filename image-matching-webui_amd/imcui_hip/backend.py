@@ -445,6 +445,40 @@ def linear_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, relu
     return c
 
 
+def pack_linear_split(w: torch.Tensor):
+    """Host: nn.Linear weight [N, K] -> (hi, lo) uint16 fragment-major planes and the inverse scale 2^-e."""
+    from .lib_loader import load_library
+
+    lib = load_library()
+    wh = _as_f32_host(w)
+    N, K = wh.shape
+    npad = (N + 31) // 32 * 32
+    hi = np.zeros(npad * K, dtype=np.uint16)
+    lo = np.zeros(npad * K, dtype=np.uint16)
+    sc = lib.imcui_hip_linear_pack_split(wh.ctypes.data, N, K, hi.ctypes.data, lo.ctypes.data)
+    if sc <= 0:
+        raise ImcuiHipError("linear_pack_split failed (K must be a multiple of 16)")
+    return hi, lo, float(sc)
+
+
+def linear_split_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, relu: bool = False) -> torch.Tensor:
+    """Building block: a projection with PRE-SPLIT weights, i.e. the GEMM path every network layer takes in the split
+    mode (fragment-major planes, 128- or 256-column tiles by N)."""
+    hd = get_handle(a.device)
+    a = a.contiguous().float()
+    M, K = a.shape
+    N = w.shape[0]
+    hi, lo, sc = pack_linear_split(w)
+    dh = torch.from_numpy(hi.view(np.int16)).to(a.device)
+    dl = torch.from_numpy(lo.view(np.int16)).to(a.device)
+    ds = torch.tensor([sc], dtype=torch.float32, device=a.device)
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        hd.check(hd.lib.imcui_hip_linear_split_f32(hd.h, _ptr(a), _ptr(dh), _ptr(dl), _ptr(ds), _ptr(bias), _ptr(c), M, N, K, int(relu), _stream_ptr()),
+                 "linear_split")
+    return c
+
+
 def conv3x3_f32(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, relu=True, pool=False) -> torch.Tensor:
     hd = get_handle(x_nhwc.device)
     lib = hd.lib

@@ -172,6 +172,16 @@ int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in_nhwc, const float* pac
                           int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
 /* split-precision variants of the conv building block (mode 1 packing / launch) */
 float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+/* nn.Linear weight [N][K] (K % 16 == 0) -> f16 hi / lo planes of w * 2^e in the FRAGMENT-MAJOR order the split GEMM
+ * streams ([ceil(N/32)][K/16][2][32][8] halves per plane, rows >= N zero: each 1 KiB block is one MFMA operand
+ * fragment of a wave); returns 2^-e (0 on bad arguments).  Planes hold roundup(N,32) * K halves each. */
+float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* hi, unsigned short* lo);
+/* C = act(A[M,K] * W^T + bias) with pre-split weights (device planes from imcui_hip_linear_pack_split, wscale = device
+ * float holding the returned 2^-e).  Building block of every network projection in the split mode
+ * (imcui/hloc/matchers/lightglue.py:75 -> upstream nn.Linear); precision 1 only, K % 32 == 0. */
+int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned short* wh, const unsigned short* wl,
+                               const float* wscale, const float* bias, float* C, int M, int N, int K, int relu, void* stream);
+
 int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
                                 const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,
                                 int Cout, int relu, int pool, void* stream);

@@ -31,6 +31,29 @@ def test_linear_f32(M, N, K, relu, precision):
     assert _rel(out, ref) < (2e-6 if precision == 0 else 4e-6)
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(300, 65, 256, False), (4800, 768, 256, True), (1000, 512, 512, False), (130, 256, 32, False),
+                                       (2048, 128, 96, True), (129, 1024, 64, False), (5000, 256, 1152, False)])
+def test_linear_split_prepacked_weights(M, N, K, relu):
+    """The GEMM path of every network projection in the split mode: fragment-major pre-split weights, 128-column
+    tiles (registers) for N % 256 != 0 and 256-column tiles (LDS-DMA) otherwise, odd and single K-tile counts,
+    ragged M / N edges."""
+    from imcui_hip import backend
+
+    dev = torch.device("cuda:0")
+    backend.set_precision(dev, 1)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * (1.0 / K**0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    ref = a.double() @ w.double().t() + b.double()
+    ref = torch.relu(ref) if relu else ref
+    out = backend.linear_split_f32(a.to(dev), w, b.to(dev), relu).cpu()
+    assert out.shape == ref.shape
+    assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 4e-6
+    out2 = backend.linear_split_f32(a.to(dev), w, b.to(dev), relu).cpu()
+    assert torch.equal(out, out2)  # bitwise repeatable
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [(2, 16, 32, 64, 64, False), (1, 24, 40, 64, 128, True), (2, 60, 80, 128, 256, False), (1, 15, 21, 32, 64, False)])
 def test_conv3x3_f32(B, H, W, Cin, Cout, pool, precision):
     from imcui_hip import backend

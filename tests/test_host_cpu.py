@@ -84,6 +84,26 @@ def test_host_weight_split_is_accurate(lib):
     assert np.isfinite(hi.view(np.float16)).all() and np.isfinite(lo.view(np.float16)).all()
 
 
+def test_linear_split_planes_are_fragment_major(lib):
+    """imcui_hip_linear_pack_split: element (nf, ks, h, r, j) of a plane is W[32 nf + r][16 ks + 8 h + j] (one 1 KiB
+    block = the 64-lane MFMA operand fragment of a wave), rows >= N are zero, hi + lo reconstructs w * 2^e."""
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(3)
+    N, K = 65, 96  # three row fragments (the last one holds a single row), six k-steps
+    w = torch.randn(N, K, generator=g) * 0.3
+    hi, lo, inv = backend.pack_linear_split(w)
+    assert inv > 0 and np.log2(inv) == np.round(np.log2(inv))
+    rec = (hi.view(np.float16).astype(np.float64) + lo.view(np.float16).astype(np.float64)) * inv
+    rec = rec.reshape(3, K // 16, 2, 32, 8)  # [nf][ks][h][r][j]
+    full = rec.transpose(0, 3, 1, 2, 4).reshape(96, K)  # rows 32 nf + r, columns 16 ks + 8 h + j
+    assert np.abs(full[:N] - w.numpy().astype(np.float64)).max() <= np.abs(w.numpy()).max() * 2.0**-21
+    assert np.all(full[N:] == 0.0)
+    assert np.isfinite(hi.view(np.float16)).all() and np.isfinite(lo.view(np.float16)).all()
+    with pytest.raises(Exception):
+        backend.pack_linear_split(torch.zeros(8, 24))  # K % 16 != 0
+
+
 def test_plugins_follow_the_reference_seam(lib):
     import imcui_hip.hloc.extractors as extractors
     import imcui_hip.hloc.matchers as matchers
