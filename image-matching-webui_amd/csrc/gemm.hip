@@ -573,44 +573,35 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 }
 
 // ------------------------------------------------------------------ 3 x f16 split kernel
-// Tile 128 x 128 x 32, 4 waves (2 x 2), three workgroups per CU (48 KB LDS, <= 168 VGPRs).
-//  * Weights (WDMA): packed at load time as FRAGMENT-MAJOR f16 hi / lo planes
-//    [N/32][K/16][64 lanes][8 halves]: a wave instruction moves a ready-to-use, conflict-free 1 KiB MFMA
-//    fragment -- by `global_load_lds_dwordx4` (L2 -> LDS, no registers, 256-column tiles) or as one coalesced
-//    16-byte load + ds_write_b128 per lane (128-column tiles); double-buffered, the tile for step kt+1 streams
-//    in while step kt is multiplied.
-//  * Activations: fetched two tiles ahead into registers, split into (hi, lo) f16 and written to a
+// Tile 128 x 128 x 32 (three workgroups per CU: 36 KB LDS, <= 168 VGPRs) or 128 x 256 x 32, 4 waves (2 x 2).
+//  * Weights (WDMA = pre-split planes): packed at load time as FRAGMENT-MAJOR f16 hi / lo planes
+//    [N/32][K/16][64 lanes][8 halves]: one coalesced 16-byte load + ds_write_b128 per lane moves a
+//    ready-to-use, conflict-free 1 KiB MFMA fragment (no VALU on the weight side); the fragments of tile kt+1
+//    are requested while tile kt is multiplied.  (An LDS-DMA version -- `global_load_lds_dwordx4` from inline
+//    asm with a hand-placed vmcnt drain, because a compiler-visible DMA makes hipcc drain vmcnt to 0 at every
+//    register-load use -- measured 3-5 % slower on 128-column tiles and equal on 256-column ones, and hiding
+//    register loads in asm to count waits by hand is NOT safe: the allocator may copy a destination register
+//    before the load has landed.  Everything is ordinary loads now; the compiler counts the waits.)
+//  * Activations: fetched one tile ahead into registers, split into (hi, lo) f16 and written to a
 //    single LDS buffer in the same fragment order with the granule position XOR-swizzled by 2*(k-octet)
 //    (both the ds_write_b128 of 8 lanes = 2 rows x 4 octets and the fragment ds_read_b128 are then
 //    conflict-free).
-//  * The LDS-DMA is issued from inline asm and retired with a hand-counted `s_waitcnt vmcnt(4)`: a
-//    DMA the compiler knows about makes it drain vmcnt to 0 at the next use of any loaded register,
-//    i.e. exposes the full memory latency once per K step.  (Hiding the register loads in asm as well
-//    is NOT safe: the allocator may copy a destination register before the load has landed.)
 #define BK3 32
-#define GLDS16(gptr, ldsaddr)                                                                                              \
-    {                                                                                                                     \
-        unsigned keep__;                                                                                                  \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep__)                                                                                      \
-                     : "v"(gptr), "s"(ldsaddr)                                                                            \
-                     : "memory");                                                                                         \
-    }
 // ASRC: 0 = matrix (optionally two K slabs), 1 = implicit im2col of an NHWC image
-// WDMA: weights by LDS-DMA from fragment-major planes; otherwise B is an f32 matrix [N][K] (activations,
+// WDMA: weights are pre-split fragment-major planes; otherwise B is an f32 matrix [N][K] (activations,
 //       e.g. similarity products) staged like A
 // NW:   32-column fragments per wave: 2 -> tile 128 x 128 (three workgroups per CU), 4 -> tile 128 x 256 (two per
-//       CU, 80 KB LDS): per MFMA half the LDS fragment reads, half the activation staging and half the DMA issue
-//       -- on a SIMD the matrix pipe and everything else serialise, so the wave tile is the efficiency lever
+//       CU, 80 KB LDS): per MFMA half the LDS fragment reads and half the activation staging -- on a SIMD the
+//       matrix pipe and everything else serialise, so the wave tile is the efficiency lever
 template <int EPI, int ASRC, bool WDMA, int NW>
 __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_kernel(GemmP p) {
-    // 128-column tiles take the weight fragments through registers (4 x 16 B per lane per tile, waits counted by
-    // the compiler): measured 3-5 % faster than the DMA there.  256-column tiles have no registers to spare
-    // (128 accumulators) and use the LDS-DMA.
+    // 128-column tiles: the four weight fragments of a wave in four registers, single LDS buffer (written between
+    // the two barriers like the activations).  256-column tiles: eight fragments, four registers, two halves,
+    // double-buffered in LDS (parked while the current tile is multiplied).
     constexpr bool WREGP = WDMA && NW == 2;
-    static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need the weight DMA path");
+    static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need pre-split weight planes");
     constexpr int BPL = 4 * NW * 1024;  // bytes per B plane per stage: [ks 2][nf 2 NW] fragments of 1 KiB
-    // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 (DMA path only) ; reused by the epilogue (<= 36864 B)
+    // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 (256-column tiles) ; reused by the epilogue (<= 36864 B)
     __shared__ uint4 smem[((WDMA && NW == 2) ? 36864 : 16384 + 4 * BPL) / 16];
     char* sm = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
@@ -713,7 +704,6 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     const int nks = p.K >> 4;
     const int nfr = (p.N + 31) >> 5;
     const uint4 *wh[NW / 2], *wl[NW / 2];
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
 #pragma unroll
     for (int u = 0; u < NW / 2; ++u) {
         wh[u] = wl[u] = nullptr;
@@ -739,18 +729,22 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
         *reinterpret_cast<uint4*>(d + BPL) = q2;
         *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = q3;
     };
+    // 256-column tiles: the wave's two column blocks (u = 0, 1) go through the same four registers one after the other
+    auto load_bu = [&](int kt, int u) __attribute__((always_inline)) {
+        bq0 = wh[u][(size_t)(kt * 2 + 0) * 64];
+        bq1 = wh[u][(size_t)(kt * 2 + 1) * 64];
+        bq2 = wl[u][(size_t)(kt * 2 + 0) * 64];
+        bq3 = wl[u][(size_t)(kt * 2 + 1) * 64];
+    };
+    auto store_bu = [&](int stg, int u) __attribute__((always_inline)) {
+        char* d = sm + 16384 + stg * 2 * BPL + (wid + 4 * u) * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(d) = bq0;
+        *reinterpret_cast<uint4*>(d + BPL / 2) = bq1;
+        *reinterpret_cast<uint4*>(d + BPL) = bq2;
+        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = bq3;
+    };
     auto load_bp = [&](int kt) __attribute__((always_inline)) { load_bp2(kt, bq0, bq1, bq2, bq3); };
     auto store_bp = [&](int stg) __attribute__((always_inline)) { store_bp2(stg, bq0, bq1, bq2, bq3); };
-    auto dma_b = [&](int kt, int stg) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < NW / 2; ++u) {
-            const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + 16384 + stg * 2 * BPL + (wid + 4 * u) * 1024);
-            GLDS16(wh[u] + (size_t)(kt * 2 + 0) * 64, d);
-            GLDS16(wh[u] + (size_t)(kt * 2 + 1) * 64, d + BPL / 2);
-            GLDS16(wl[u] + (size_t)(kt * 2 + 0) * 64, d + BPL);
-            GLDS16(wl[u] + (size_t)(kt * 2 + 1) * 64, d + BPL + BPL / 2);
-        }
-    };
     // !WDMA: B rows staged like A (single buffer = stage 0)
     f32x4 xc0, xd0, xc1, xd1, yc0, yd0, yc1, yd1;
     const float *pw0 = nullptr, *pw1 = nullptr;
@@ -776,10 +770,9 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
         *reinterpret_cast<uint4*>(sm + 24576 + wo1) = l;
     };
 
-    auto compute = [&](int stg) __attribute__((always_inline)) {
+    auto compute_ks = [&](int stg, int ks) __attribute__((always_inline)) {
         const char* sbt = sm + 16384 + ((WDMA && !WREGP) ? stg * 2 * BPL : 0);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        {
             uint4 ah[2], al[2], bh[NW], bl[NW];
             const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
 #pragma unroll
@@ -805,12 +798,10 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
                 }
         }
     };
-    // The register loads are ordinary loads (the compiler counts its own vmcnt for them); only the
-    // LDS-DMA is invisible to it and is retired by hand before the barrier that publishes the tile.
-    // No order is assumed between DMA and register loads: the wait is for everything.
-#define DMA_LANDED(pend) \
-    if (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
+    auto compute = [&](int stg) __attribute__((always_inline)) {
+        compute_ks(stg, 0);
+        compute_ks(stg, 1);
+    };
     if constexpr (WREGP) {
         issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
         load_bp(0);
@@ -848,78 +839,75 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
             }
         }
     } else if constexpr (WDMA) {
-        // The hand-placed vmcnt(0) that publishes a weight tile also retires every register load in flight
-        // (no order is assumed between LDS-DMA and register loads), so the activation loads of tile kt+2 are
-        // issued right AFTER it: they then have a whole iteration (barrier, DMA issue, 24-48 MFMAs, barrier)
-        // to land before the next drain instead of one matrix phase.  One register set.
+        // 256-column tiles: weights through four registers per lane, half a tile at a time -- the first column
+        // block of tile kt+1 is requested before the first k-step of tile kt and parked in the other LDS stage
+        // after it, the second around the second k-step.  Every load is an ordinary load: the compiler counts
+        // the waits (an LDS-DMA version needed a hand-placed vmcnt(0) drain per tile and was 3-5 % slower).
         issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
-        dma_b(0, 0);
+        load_bu(0, 0);
+        store_bu(0, 0);
+        load_bu(0, 1);
+        store_bu(0, 1);
         store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-        DMA_LANDED(false)
         if (nkt > 1) issue_a(1, xa0, xb0, xa1, xb1, xv0, xv1);
         __syncthreads();
+#define WIDE_STEP(kt_, stg_)                                                                  \
+    {                                                                                         \
+        const bool nxt__ = (kt_) + 1 < nkt;                                                   \
+        if (nxt__) load_bu((kt_) + 1, 0);                                                     \
+        compute_ks(stg_, 0);                                                                  \
+        if (nxt__) {                                                                          \
+            store_bu((stg_) ^ 1, 0);                                                          \
+            load_bu((kt_) + 1, 1);                                                            \
+        }                                                                                     \
+        compute_ks(stg_, 1);                                                                  \
+        __syncthreads();                                                                      \
+        if (nxt__) {                                                                          \
+            store_bu((stg_) ^ 1, 1);                                                          \
+            store_a(xa0, xb0, xa1, xb1, xv0, xv1);                                            \
+            if ((kt_) + 2 < nkt) issue_a((kt_) + 2, xa0, xb0, xa1, xb1, xv0, xv1);            \
+        }                                                                                     \
+        __syncthreads();                                                                      \
+    }
         for (int kt = 0; kt < nkt; kt += 2) {
-            // tile kt: activations in LDS, weights in stage 0; x holds tile kt+1 (in flight)
-            if (kt + 1 < nkt) dma_b(kt + 1, 1);
-            compute(0);
-            __syncthreads();
-            if (kt + 1 < nkt) {
-                store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-                DMA_LANDED(false)
-                if (kt + 2 < nkt) issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
-            }
-            __syncthreads();
-            if (kt + 1 < nkt) {
-                if (kt + 2 < nkt) dma_b(kt + 2, 0);
-                compute(1);
-                __syncthreads();
-                if (kt + 2 < nkt) {
-                    store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-                    DMA_LANDED(false)
-                    if (kt + 3 < nkt) issue_a(kt + 3, xa0, xb0, xa1, xb1, xv0, xv1);
-                }
-                __syncthreads();
-            }
+            WIDE_STEP(kt, 0)
+            if (kt + 1 < nkt) WIDE_STEP(kt + 1, 1)
         }
+#undef WIDE_STEP
     } else {
     // prologue: tile 0 -> LDS, tile 1 in flight
         issue_a(0, xa0, xb0, xa1, xb1, xv0, xv1);
-        if (WDMA) dma_b(0, 0); else issue_b(0, xc0, xd0, xc1, xd1);
+        issue_b(0, xc0, xd0, xc1, xd1);
         if (nkt > 1) {
             issue_a(1, ya0, yb0, ya1, yb1, yv0, yv1);
-            if (!WDMA) issue_b(1, yc0, yd0, yc1, yd1);
+            issue_b(1, yc0, yd0, yc1, yd1);
         }
         store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-        if (!WDMA) store_b(xc0, xd0, xc1, xd1);
-        DMA_LANDED(nkt > 1)
+        store_b(xc0, xd0, xc1, xd1);
         __syncthreads();
         for (int kt = 0; kt < nkt; kt += 2) {
             // tile kt is in LDS (weights in stage 0); y holds tile kt+1 (in flight)
             if (kt + 2 < nkt) {
                 issue_a(kt + 2, xa0, xb0, xa1, xb1, xv0, xv1);
-                if (!WDMA) issue_b(kt + 2, xc0, xd0, xc1, xd1);
+                issue_b(kt + 2, xc0, xd0, xc1, xd1);
             }
-            if (WDMA && kt + 1 < nkt) dma_b(kt + 1, 1);
             compute(0);
             __syncthreads();
             if (kt + 1 < nkt) {
                 store_a(ya0, yb0, ya1, yb1, yv0, yv1);
-                if (!WDMA) store_b(yc0, yd0, yc1, yd1);
-                DMA_LANDED(kt + 2 < nkt)
+                store_b(yc0, yd0, yc1, yd1);
             }
             __syncthreads();
             if (kt + 1 < nkt) {
                 if (kt + 3 < nkt) {
                     issue_a(kt + 3, ya0, yb0, ya1, yb1, yv0, yv1);
-                    if (!WDMA) issue_b(kt + 3, yc0, yd0, yc1, yd1);
+                    issue_b(kt + 3, yc0, yd0, yc1, yd1);
                 }
-                if (WDMA && kt + 2 < nkt) dma_b(kt + 2, 0);
                 compute(1);
                 __syncthreads();
                 if (kt + 2 < nkt) {
                     store_a(xa0, xb0, xa1, xb1, xv0, xv1);
-                    if (!WDMA) store_b(xc0, xd0, xc1, xd1);
-                    DMA_LANDED(kt + 3 < nkt)
+                    store_b(xc0, xd0, xc1, xd1);
                 }
                 __syncthreads();
             }
