@@ -104,6 +104,21 @@ def test_linear_split_planes_are_fragment_major(lib):
         backend.pack_linear_split(torch.zeros(8, 24))  # K % 16 != 0
 
 
+def test_header_is_c99_and_library_binds_from_plain_c(lib, tmp_path):
+    """The boundary is a C ABI (plain pointers and sizes): a C99 program compiled against include/imcui_hip.h
+    dlopens the library and calls the entry points that need no GPU."""
+    import subprocess
+
+    from imcui_hip.build import LIB_PATH
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_smoke.c"),
+                    "-o", str(exe), "-ldl"], check=True)  # fmt: skip
+    out = subprocess.run([str(exe), LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "version=100" in out and "lg_tensors=251" in out and "first=posenc.Wr.weight" in out, out
+
+
 def test_plugins_follow_the_reference_seam(lib):
     import imcui_hip.hloc.extractors as extractors
     import imcui_hip.hloc.matchers as matchers
