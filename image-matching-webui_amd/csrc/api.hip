@@ -113,6 +113,33 @@ extern "C" int imcui_hip_linear_f32(imcui_hip_t* h, const float* A, const float*
     return gemm_launch(h, g, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------ device-side preprocessing (step before the path)
+// 4 pixels per thread: 12 bytes in (three dwords), 16 bytes out; HBM-bound byte work (7 B / pixel).
+__global__ __launch_bounds__(256) void rgb_to_gray_kernel(const unsigned* __restrict__ rgb, float4* __restrict__ out, long nquad) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nquad) return;
+    const unsigned w0 = rgb[3 * q], w1 = rgb[3 * q + 1], w2 = rgb[3 * q + 2];
+    // bytes: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    const unsigned r0 = w0 & 255u, g0 = (w0 >> 8) & 255u, b0 = (w0 >> 16) & 255u, r1 = w0 >> 24;
+    const unsigned g1 = w1 & 255u, b1 = (w1 >> 8) & 255u, r2 = (w1 >> 16) & 255u, g2 = w1 >> 24;
+    const unsigned b2 = w2 & 255u, r3 = (w2 >> 8) & 255u, g3 = (w2 >> 16) & 255u, b3 = w2 >> 24;
+    auto gray = [](unsigned r, unsigned g, unsigned b) { return (float)((9798u * r + 19235u * g + 3735u * b + 16384u) >> 15) / 255.0f; };
+    out[q] = make_float4(gray(r0, g0, b0), gray(r1, g1, b1), gray(r2, g2, b2), gray(r3, g3, b3));
+}
+
+extern "C" int imcui_hip_rgb_to_gray_f32(imcui_hip_t* h, const unsigned char* rgb_hwc, float* out, int B, int H, int W, void* stream) {
+    if (!h || !rgb_hwc || !out || B < 0 || H <= 0 || W <= 0) return imcui_set_err(h, IMCUI_ERR_ARG, "rgb_to_gray: bad argument");
+    const long npix = (long)B * H * W;
+    if (((long)H * W) % 4 != 0 || ((size_t)rgb_hwc & 3) != 0)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "rgb_to_gray: H*W=%ld must be a multiple of 4 and the image 4-byte aligned", (long)H * W);
+    if (npix == 0) return IMCUI_OK;
+    const long nquad = npix / 4;
+    hipLaunchKernelGGL(rgb_to_gray_kernel, dim3((unsigned)((nquad + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned*>(rgb_hwc), reinterpret_cast<float4*>(out), nquad);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
 extern "C" float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* hi, unsigned short* lo) {
     if (!w || !hi || !lo || N <= 0 || K <= 0 || K % 16) return 0.0f;
     return split_weights_frag_host(w, N, K, hi, lo);

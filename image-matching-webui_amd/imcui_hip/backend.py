@@ -445,6 +445,20 @@ def linear_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, relu
     return c
 
 
+def rgb_to_gray(rgb_u8: torch.Tensor) -> torch.Tensor:
+    """Device-side `cv2.cvtColor(RGB2GRAY)` + `astype(float32) / 255` (extract_features.py:120-160) for decoded
+    uint8 images [B,H,W,3] already on the device -> [B,1,H,W] float32 in [0,1]."""
+    if rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 4 or rgb_u8.shape[-1] != 3:
+        raise ImcuiHipError("rgb_to_gray expects uint8 [B,H,W,3]")
+    hd = get_handle(rgb_u8.device)
+    rgb_u8 = rgb_u8.contiguous()
+    B, H, W, _ = rgb_u8.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=rgb_u8.device)
+    with torch.cuda.device(rgb_u8.device):
+        hd.check(hd.lib.imcui_hip_rgb_to_gray_f32(hd.h, _ptr(rgb_u8), _ptr(out), B, H, W, _stream_ptr()), "rgb_to_gray")
+    return out
+
+
 def pack_linear_split(w: torch.Tensor):
     """Host: nn.Linear weight [N, K] -> (hi, lo) uint16 fragment-major planes and the inverse scale 2^-e."""
     from .lib_loader import load_library

@@ -172,6 +172,12 @@ int imcui_hip_conv3x3_f32(imcui_hip_t* h, const float* in_nhwc, const float* pac
                           int B, int H, int W, int Cin, int Cout, int relu, int pool, void* stream);
 /* split-precision variants of the conv building block (mode 1 packing / launch) */
 float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+/* Step before the path: the host preprocessing of imcui/hloc/extract_features.py:120-160 for
+ * images that need no resize -- cv2.cvtColor(RGB2GRAY) on 8-bit pixels (OpenCV 4.x fixed point:
+ * (9798 R + 19235 G + 3735 B + 16384) >> 15), astype(float32), / 255.0 -- on the device.
+ * rgb: uint8 [B,H,W,3] (interleaved, as decoded), out: float32 [B,1,H,W].  H*W % 4 == 0. */
+int imcui_hip_rgb_to_gray_f32(imcui_hip_t* h, const unsigned char* rgb_hwc, float* out, int B, int H, int W, void* stream);
+
 /* nn.Linear weight [N][K] (K % 16 == 0) -> f16 hi / lo planes of w * 2^e in the FRAGMENT-MAJOR order the split GEMM
  * streams ([ceil(N/32)][K/16][2][32][8] halves per plane, rows >= N zero: each 1 KiB block is one MFMA operand
  * fragment of a wave); returns 2^-e (0 on bad arguments).  Planes hold roundup(N,32) * K halves each. */

@@ -128,3 +128,19 @@ def test_simple_nms_bit_exact(r):
     ref = simple_nms(s, r)
     out = backend.simple_nms(s.to(_dev()), r).cpu()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 480, 640), (3, 30, 44), (2, 1, 4)])
+def test_rgb_to_gray_bit_exact(B, H, W):
+    """Step before the path: device grey conversion + /255 vs the CPU restatement, bit for bit."""
+    import numpy as np
+
+    from imcui_hip import backend
+    from oracle.preprocess import preprocess_gray
+
+    rng = np.random.default_rng(B * 1000 + H + W)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    img[0, 0, :4] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 0, 255]][: min(4, W)]
+    out = backend.rgb_to_gray(torch.from_numpy(img).cuda()).cpu().numpy()
+    ref = preprocess_gray(img)
+    assert out.shape == ref.shape and np.array_equal(out, ref)
