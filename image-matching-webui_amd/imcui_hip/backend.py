@@ -404,6 +404,25 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
+def dual_softmax(desc0: torch.Tensor, desc1: torch.Tensor, threshold: float = 0.2, inv_temperature: float = 20.0, normalize: bool = True):
+    """desc0 [B,C,N], desc1 [B,C,M] (channels-first, as the plugin receives them) -> matches0 [B,N] int32, scores0 [B,N]."""
+    dev = desc0.device
+    hd = get_handle(dev)
+    lib = hd.lib
+    desc0, desc1 = desc0.contiguous().float(), desc1.contiguous().float()
+    B, C, N = desc0.shape
+    M = desc1.shape[2]
+    m0 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with _nn_lock:
+        ws = _nn_ws.get(lib.imcui_hip_dual_softmax_workspace_bytes(B, C, N, M), dev)
+        with torch.cuda.device(dev):
+            rc = lib.imcui_hip_dual_softmax(hd.h, _ptr(desc0), _ptr(desc1), B, C, N, M, float(threshold), float(inv_temperature),
+                                            int(bool(normalize)), _ptr(m0), _ptr(s0), _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
+            hd.check(rc, "imcui_hip_dual_softmax")
+    return m0, s0
+
+
 # ------------------------------------------------------------------ arithmetic mode
 def set_precision(device: torch.device, mode: int):
     """0 = exact f32 MFMA, 1 = 3 x f16 split MFMA (default; ~fp32 accuracy at ~5x the matrix rate)."""

@@ -9,6 +9,7 @@
  *   imcui_hip_lightglue_forward   <- imcui/hloc/matchers/lightglue.py:54-75     `self.net(input)`
  *   imcui_hip_mutual_nn           <- imcui/hloc/matchers/nearest_neighbor.py:38-66 `_forward`
  *   imcui_hip_loftr_forward       <- imcui/hloc/matchers/loftr.py:54            `self.net(data_)`
+ *   imcui_hip_dual_softmax        <- imcui/hloc/matchers/dual_softmax.py:62-75  `dual_softmax_matcher(...)`
  *   *_pack_weights                <- the `_init` weight loading (superpoint.py:48-53, lightglue.py:39-51)
  *
  * Conventions
@@ -160,6 +161,17 @@ size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,
                         double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0,
                         float* scores0, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- dual-softmax matcher (imcui/hloc/matchers/dual_softmax.py; zoo entries disk+dualsoftmax, superpoint+dualsoftmax) */
+size_t imcui_hip_dual_softmax_workspace_bytes(int B, int C, int N, int M);
+/* desc0 [dev, B,C,N], desc1 [dev, B,C,M] channels-first as the plugin receives them (any C >= 1); the matcher
+ * L2-normalises over C when `normalize` (dual_softmax.py:20-22), sim = D0^T D1 * inv_temperature,
+ * P = softmax(sim, rows) * softmax(sim, columns); matches0 [dev, B,N] int32 = the last column that is the row
+ * maximum, the column maximum and > threshold (-1 = none), scores0 [dev, B,N] = P there (0 otherwise).
+ * Per batch item (the reference is only ever driven with B = 1). */
+int imcui_hip_dual_softmax(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int C, int N, int M, double threshold,
+                           double inv_temperature, int normalize, int* matches0, float* scores0, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ---- building blocks (exported for tests and for the LoFTR path to come) --------------------- */
 /* C[M,N] = A[M,K] * W[N,K]^T + bias ; relu optional ; K % 32 == 0 */

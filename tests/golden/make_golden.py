@@ -2,8 +2,8 @@
 
 /root/reference is importable only where it is mounted; this script is committed
 together with its outputs (tests/golden/nn_*.npz) so the GPU box never needs it.
-Only `imcui.hloc.matchers.nearest_neighbor` can run: the
-SuperPoint / LightGlue / LoFTR arithmetic lives in absent submodules.
+Only `imcui.hloc.matchers.nearest_neighbor` and `imcui.hloc.matchers.dual_softmax` can run (SURVEY.md
+section 8c): the SuperPoint / LightGlue / LoFTR arithmetic lives in absent submodules.
 
 Run from a scratch CWD (importing imcui.hloc truncates ./log.txt):
     cd /tmp && python /root/repo/tests/golden/make_golden.py
@@ -17,6 +17,7 @@ import torch
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, "/root/reference")
 
+from imcui.hloc.matchers.dual_softmax import DualSoftMax  # noqa: E402
 from imcui.hloc.matchers.nearest_neighbor import NearestNeighbor  # noqa: E402
 
 
@@ -54,6 +55,38 @@ if __name__ == "__main__":
             descriptors1=d1.numpy(),
             matches0=out["matches0"].numpy(),
             matching_scores0=out["matching_scores0"].numpy().astype(np.float32),
+            conf_keys=np.array(list(conf.keys())),
+            conf_vals=np.array([float(v) for v in conf.values()]),
+        )
+        print(name, "matches", int((out["matches0"] > -1).sum()), "of", n)
+
+    # ---- dual-softmax matcher (imcui/hloc/matchers/dual_softmax.py; batch 1 as hloc drives it)
+    DS_CASES = {
+        # name: (D, N, M, noise, conf)
+        "ds_default": (256, 300, 280, 0.25, {}),
+        "ds_disk128": (128, 257, 333, 0.35, {"match_threshold": 0.1}),
+        "ds_temp": (64, 129, 65, 0.2, {"match_threshold": 0.3, "inv_temperature": 10}),
+        "ds_unnormalised_inputs": (128, 200, 190, 0.3, {"match_threshold": 0.05}),
+        "ds_single": (128, 50, 1, 0.1, {}),
+        "ds_empty": (128, 40, 0, 0.0, {}),
+    }
+    for i, (name, (d, n, m, noise, conf)) in enumerate(DS_CASES.items()):
+        g = torch.Generator().manual_seed(500 + i)
+        d0 = unit(g, 1, d, n)
+        perm = torch.randperm(max(n, 1), generator=g)[:m] if m <= n else torch.arange(m) % max(n, 1)
+        d1 = d0[:, :, perm] + noise * torch.randn(1, d, m, generator=g) if m > 0 else torch.zeros(1, d, 0)
+        if name == "ds_unnormalised_inputs":  # the matcher normalises itself
+            d0 = d0 * (0.5 + torch.rand(1, 1, n, generator=g))
+            d1 = d1 * (0.5 + torch.rand(1, 1, m, generator=g))
+        model = DualSoftMax(conf).eval()
+        with torch.no_grad():
+            out = model({"descriptors0": d0, "descriptors1": d1})
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            descriptors0=d0.numpy(),
+            descriptors1=d1.numpy(),
+            matches0=out["matches0"].numpy().astype(np.int64),
+            matching_scores0=out["matching_scores0"].numpy().astype(np.float64),
             conf_keys=np.array(list(conf.keys())),
             conf_vals=np.array([float(v) for v in conf.values()]),
         )

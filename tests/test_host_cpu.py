@@ -127,7 +127,11 @@ def test_plugins_follow_the_reference_seam(lib):
     SP = dynamic_load(extractors, "superpoint")
     LG = dynamic_load(matchers, "lightglue")
     NN = dynamic_load(matchers, "nearest_neighbor")
-    assert issubclass(SP, BaseModel) and issubclass(LG, BaseModel) and issubclass(NN, BaseModel)
+    DS = dynamic_load(matchers, "dual_softmax")
+    assert issubclass(SP, BaseModel) and issubclass(LG, BaseModel) and issubclass(NN, BaseModel) and issubclass(DS, BaseModel)
+    assert DS.default_conf == {"match_threshold": 0.2, "inv_temperature": 20} and DS.required_inputs == ["descriptors0", "descriptors1"]
+    empty = DS({})({"descriptors0": torch.zeros(1, 128, 5), "descriptors1": torch.zeros(1, 128, 0)})  # no GPU needed
+    assert empty["matches0"].shape == (1, 128) and int(empty["matches0"].max()) == -1  # the reference's (B, C) quirk
     # default_conf of the reference wrappers (superpoint.py:34-41, lightglue.py:15-25)
     assert SP.default_conf["nms_radius"] == 4 and SP.default_conf["max_keypoints"] == -1 and SP.detection_noise == 2.0
     assert LG.default_conf["depth_confidence"] == 0.95 and LG.default_conf["width_confidence"] == 0.99
