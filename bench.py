@@ -81,6 +81,63 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
             "sample": f"{n} synthetic 640x480 pairs, batch 1, fp32, SuperPoint(2048 kpts)+LightGlue(9 layers, no early exit), torch {torch.__version__} CPU"}  # fmt: skip
 
 
+def bench_superpoint(args, dev, rank, world):
+    """configs[1]: SuperPoint extractor (max 2048 key-points) on 640x480 batches; images/s, weak scaling."""
+    from imcui_hip import backend
+    from imcui_hip.hloc.extractors.superpoint import SuperPoint
+    from imcui_hip.synth import make_pair_batch
+    from oracle.weights import superpoint_state_dict  # seeded weights only
+
+    B = 2 * args.batch  # images per step per GPU (the pairs workload extracts 2 images per pair)
+    model = SuperPoint({"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4,
+                        "state_dict": superpoint_state_dict(0)}).eval().to(dev)  # fmt: skip
+    img0, img1, _ = make_pair_batch(1234 + rank, B // 2, H, W, distinct=min(B // 2, 4))
+    img = torch.cat([img0, img1], 0).to(dev)
+    for _ in range(args.warmup):
+        out = model.forward_batched(img)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    backend.profile_enable(dev, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.forward_batched(img)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n = backend.profile_read(dev, "conv3x3")
+    backend.profile_enable(dev, False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        split = args.precision == 1
+        peak = PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF
+        conv_gf = 45.65 - 0.35 + 2.83 + 2.83  # 3x3 layers on the MFMA conv kernel: encoder minus conv1a, convPa, convDa (SURVEY.md 8a)
+        achieved = conv_gf * 1e9 * B * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
+        line = {
+            "metric": "images/sec @640x480 SuperPoint extractor", "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: SuperPoint (max 2048 kpts, nms 3, thr 0.005) on synthetic 640x480 images resident in HBM",
+                       "images_per_step_per_gpu": B, "mean_keypoints": float(out["num_keypoints"].float().mean()),
+                       "weights": "seeded random (oracle/weights.py), real architecture"},
+            "roofline": {"kernel": "conv3x3_split_kernel (implicit-GEMM 3x3 convolutions)" if split else "conv3x3_kernel", "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "executed_tflops": achieved * (3.0 if split else 1.0),
+                         "executed_frac_of_sustained_peak": achieved * 3.0 / SUSTAINED_F16_MFMA_TF if split else None,
+                         "conv_ms_per_step": conv_ms / args.steps, "launches_per_step": conv_n / args.steps,
+                         "note": "achieved = algorithmic TFLOP of the 3x3 layers / summed conv kernel time (HIP events)"},
+            "algorithmic_tflops_end_to_end": SP_GF_PER_IMAGE * 1e9 * B / (dt / args.steps) / 1e12,
+        }  # fmt: skip
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_loftr(args, dev, rank, world):
     """configs[3]: LoFTR dense matcher (coarse 1/8 + fine) on synthetic pairs; pairs/s, weak scaling."""
     from imcui_hip import backend
@@ -144,8 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr"],
-                    help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher")
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint"],
+                    help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
+                         "superpoint = configs[1] extractor only (images/s)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
@@ -170,6 +228,8 @@ def main():
     backend.set_precision(dev, args.precision)
     if args.workload == "loftr":
         return bench_loftr(args, dev, rank, world)
+    if args.workload == "superpoint":
+        return bench_superpoint(args, dev, rank, world)
     B = args.batch
     dc, wc = (0.95, 0.99) if args.adaptive else (-1.0, -1.0)
     pipe = SuperPointLightGluePipeline(

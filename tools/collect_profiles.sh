@@ -7,6 +7,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ( cd $R && timeout 300 python bench.py > $O/bench_splg.json.log 2>&1; tail -1 $O/bench_splg.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024.json.log 2>&1; tail -1 $O/bench_loftr_1024.json.log | cut -c1-160 )
+( cd $R && timeout 200 python bench.py --workload superpoint > $O/bench_superpoint.json.log 2>&1; tail -1 $O/bench_superpoint.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python bench.py --precision 0 --no-cpu-baseline > $O/bench_splg_f32.json.log 2>&1; tail -1 $O/bench_splg_f32.json.log | cut -c1-160 )
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 > $O/rocprof_loftr.log 2>&1

@@ -43,6 +43,7 @@ json.dump({"kernel": "attn_split_kernel", "source": f"profiles/{tag}_pmc_traffic
           open(os.path.join(P, "r01_attention_traffic.json"), "w"), indent=1)
 for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_loftr_1024.json.log", f"{tag}_bench_loftr_1024.json.log"),
                  ("bench_splg_f32.json.log", f"{tag}_bench_splg_f32.json.log"),
+                 ("bench_superpoint.json.log", f"{tag}_bench_superpoint.json.log"),
                  ("stats_splg/splg_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg.csv"),
                  ("stats_loftr/loftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_loftr_1024.csv"),
                  ("lab_clock.txt", "r01_lab_mfma_clock.txt"), ("lab_overlap.txt", "r01_lab_mfma_valu_overlap.txt"),
