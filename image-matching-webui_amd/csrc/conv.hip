@@ -345,18 +345,21 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
         }
     }
 
-    // ---- epilogue: lane = pixel column x0 + lo; register quad q of fragment n = channels
-    //      cout0 + 32n + 8q + 4hi .. +3
+    // ---- epilogue: lane = pixel column x0 + lo; register quad q of fragment n = channels cout0 + 32n + 8q + 4hi .. +3.
+    // Written straight from the fragments a store touches 32 pixels x 32 B; the finished values are parked in LDS
+    // ([pixel][64 channels], 68-float rows: conflict-free both ways) and leave as whole 256-byte channel runs.
     const float wsc = wscale[0];
-    const int ox = x0 + lo;
+    __syncthreads();  // every wave is done with the patch / weight buffers
+    float* st = reinterpret_cast<float*>(smem);
+    constexpr int SROW = 68;
+    if (pool) {
+        const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int co = cout0 + n * 32 + 8 * q + 4 * hi;
-            const float4 b4 = *reinterpret_cast<const float4*>(bias + co);
-            if (pool) {
-                const int Ho = H >> 1, Wo = W >> 1;
+            for (int q = 0; q < 4; ++q) {
+                const int cl = n * 32 + 8 * q + 4 * hi;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -372,24 +375,51 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
                 }
-                const int oy = (y0 >> 1) + wid, pxo = ox >> 1;
-                if ((lo & 1) == 0 && oy < Ho && pxo < Wo)
-                    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int oy = y0 + 2 * wid + m;
-                    float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y,
-                                           acc[m][n][4 * q + 2] * wsc + b4.z, acc[m][n][4 * q + 3] * wsc + b4.w);
-                    if (relu) {
-                        v.x = fmaxf(v.x, 0.0f);
-                        v.y = fmaxf(v.y, 0.0f);
-                        v.z = fmaxf(v.z, 0.0f);
-                        v.w = fmaxf(v.w, 0.0f);
-                    }
-                    if (oy < H && ox < W) *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * Cout + co) = v;
-                }
+                if ((lo & 1) == 0) *reinterpret_cast<float4*>(st + (wid * 16 + (lo >> 1)) * SROW + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // 64 pooled pixels x 16 channel quads
+            const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
+            const int oy = (y0 >> 1) + (px >> 4), pxo = (x0 >> 1) + (px & 15);
+            if (oy < Ho && pxo < Wo)
+                *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + cout0 + 4 * c4) =
+                    *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+        }
+    } else {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {  // image rows 4 h2 .. 4 h2 + 3 of the tile (waves 2 h2, 2 h2 + 1)
+            if ((wid >> 1) == h2) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = n * 32 + 8 * q + 4 * hi;
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y,
+                                                   acc[m][n][4 * q + 2] * wsc + b4.z, acc[m][n][4 * q + 3] * wsc + b4.w);
+                            if (relu) {
+                                v.x = fmaxf(v.x, 0.0f);
+                                v.y = fmaxf(v.y, 0.0f);
+                                v.z = fmaxf(v.z, 0.0f);
+                                v.w = fmaxf(v.w, 0.0f);
+                            }
+                            *reinterpret_cast<float4*>(st + (((wid & 1) * 2 + m) * 32 + lo) * SROW + cl) = v;
+                        }
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
+                const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
+                const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
+                if (oy < H && ox < W)
+                    *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4) =
+                        *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+            }
+            if (h2 == 0) __syncthreads();
         }
     }
 }
