@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -25,6 +26,23 @@ def needs_build() -> bool:
     return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest_source_mtime()
 
 
+# MFMA kernels whose register budget is part of the design: a build that spills them to scratch is rejected (two
+# experimental builds of the split GEMM that spilled -- 128-VGPR and 168-VGPR-with-20-B-scratch variants -- were
+# slower AND failed the parity / determinism tests on the GPU; hipcc is not to be trusted with spills around them).
+NO_SPILL_KERNELS = ("gemm_split_kernel", "gemm_kernel", "attn_split_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_kernel")
+
+
+def _check_no_spills(src: str, remarks: str) -> None:
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and int(m.group(1)) > 0 and any(k in name for k in NO_SPILL_KERNELS):
+            raise RuntimeError(f"{src}: kernel {name} spills {m.group(1)} bytes/lane to scratch -- reduce its register pressure")
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source and link the shared library. Returns its path."""
     if not force and not needs_build():
@@ -35,10 +53,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        _check_no_spills(src, r.stderr)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
