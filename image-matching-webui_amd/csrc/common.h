@@ -45,10 +45,15 @@ __device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     hi = __builtin_bit_cast(unsigned, h);
+#ifdef IMCUI_SPLIT_NO_ASM
+    const f16x2 l2 = {(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    lo = __builtin_bit_cast(unsigned, l2);
+#else
     unsigned l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
     lo = l;
+#endif
 }
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
     split2(a.x, a.y, hi.x, lo.x);
