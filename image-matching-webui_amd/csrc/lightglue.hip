@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "attention.h"
 #include "gemm.h"
 #include "imcui_hip.h"
@@ -181,6 +183,31 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
     for (int i = 0; i < LG_LAYERS - 1; ++i) {
         cp(l.wtoken + (size_t)i * 256, tk[2 * i], 256);
         packed[l.btoken + i] = tk[2 * i + 1][0];
+    }
+    // out_proj / to_out are folded into ffn.0 (reference lightglue.py SelfBlock/CrossBlock.forward:
+    // ffn(cat[x, out_proj(ctx)])):  cat[x, Wo ctx + bo] W1^T + b1 = cat[x, ctx] [W1a | W1b Wo]^T + (b1 + W1b bo).
+    // The fold is done once here in double, so the forward reads the attention context directly and runs
+    // two GEMMs fewer per layer.  The wo/bo/wto/bto slots keep the unfused tensors for inspection.
+    auto fold = [&](size_t w1, size_t b1, size_t wo, size_t bo) {
+        std::vector<double> row(256);
+        for (int n = 0; n < 512; ++n) {
+            float* w1b = packed + w1 + (size_t)n * 512 + 256;
+            double bacc = packed[b1 + n];
+            for (int k = 0; k < 256; ++k) row[k] = 0.0;
+            for (int j = 0; j < 256; ++j) {
+                const double c = w1b[j];
+                const float* wor = packed + wo + (size_t)j * 256;
+                for (int k = 0; k < 256; ++k) row[k] += c * (double)wor[k];
+                bacc += c * (double)packed[bo + j];
+            }
+            for (int k = 0; k < 256; ++k) w1b[k] = (float)row[k];
+            packed[b1 + n] = (float)bacc;
+        }
+    };
+    for (int i = 0; i < LG_LAYERS; ++i) {
+        const LgLayerOff& o = l.L[i];
+        fold(o.w1s, o.b1s, o.wo, o.bo);
+        fold(o.w1c, o.b1c, o.wto, o.bto);
     }
     // split-precision copies of every GEMM weight (taken from the packed f32 layout)
     auto sp = [&](const LgSplit& d, size_t src, int N, int K, int slot) {
@@ -795,14 +822,14 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.wscale = P + sp.s;
         }
     };
-    auto ffn = [&](const float* msg, size_t w1, const LgSplit& s1, size_t b1, size_t gm, size_t bt, size_t w2,
+    auto ffn = [&](const float* ctx, size_t w1, const LgSplit& s1, size_t b1, size_t gm, size_t bt, size_t w2,
                    const LgSplit& s2, size_t b2) -> int {
         GemmP g;
         base(g);
         g.epi = EPI_BIAS;
         g.A = w.x;
         g.lda = 256;
-        g.A2 = msg;
+        g.A2 = ctx;  // out_proj is folded into W1 at pack time
         g.lda2 = 256;
         g.K1 = 256;
         g.K = 512;
@@ -867,20 +894,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.rows_per_seq = R;
             a.cross = 0;
             LGRUN(attention_launch(h, a, stream));
-            GemmP g2;
-            base(g2);
-            g2.epi = EPI_BIAS;
-            g2.A = w.ctx;
-            g2.lda = 256;
-            g2.K = 256;
-            g2.N = 256;
-            wts(g2, o.wo, o.so);
-            g2.ldw = 256;
-            g2.bias = P + o.bo;
-            g2.C = w.msg;
-            g2.ldc = 256;
-            LGRUN(gemm_launch(h, g2, stream));
-            LGRUN(ffn(w.msg, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.b2s));
+            LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.b2s));
         }
         // ---- CrossBlock
         {
@@ -914,20 +928,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.rows_per_seq = R;
             a.cross = 1;
             LGRUN(attention_launch(h, a, stream));
-            GemmP g2;
-            base(g2);
-            g2.epi = EPI_BIAS;
-            g2.A = w.ctx;
-            g2.lda = 256;
-            g2.K = 256;
-            g2.N = 256;
-            wts(g2, o.wto, o.sto);
-            g2.ldw = 256;
-            g2.bias = P + o.bto;
-            g2.C = w.msg;
-            g2.ldc = 256;
-            LGRUN(gemm_launch(h, g2, stream));
-            LGRUN(ffn(w.msg, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
+            LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
         }
         if (layer == LG_LAYERS - 1) break;  // no early stopping or adaptive width at the last layer
         if (!do_stop && !do_prune) continue;

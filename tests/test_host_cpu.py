@@ -55,7 +55,16 @@ def test_lightglue_packing_deinterleaves_qkv(lib):
     assert len(names) == 251 and names[0] == "posenc.Wr.weight" and set(names) <= set(lsd)
     packed = backend.pack_lightglue(lsd).numpy()
     n32 = 11851712  # f32 region; f16 split planes follow
-    assert np.isclose(np.abs(packed[:n32]).sum(dtype=np.float64), sum(lsd[n].abs().double().sum().item() for n in names), rtol=1e-9)
+    # out_proj / to_out are folded into the right half of ffn.0 at pack time: W1b' = W1b @ Wo, b1' = b1 + W1b @ bo
+    expect = dict(lsd)
+    for i in range(9):
+        for blk, proj in (("self_attn", "out_proj"), ("cross_attn", "to_out")):
+            pre = f"transformers.{i}.{blk}."
+            w1, b1 = lsd[pre + "ffn.0.weight"].double(), lsd[pre + "ffn.0.bias"].double()
+            wo, bo = lsd[pre + proj + ".weight"].double(), lsd[pre + proj + ".bias"].double()
+            expect[pre + "ffn.0.weight"] = torch.cat([w1[:, :256], w1[:, 256:] @ wo], 1).float()
+            expect[pre + "ffn.0.bias"] = (b1 + w1[:, 256:] @ bo).float()
+    assert np.isclose(np.abs(packed[:n32]).sum(dtype=np.float64), sum(expect[n].abs().double().sum().item() for n in names), rtol=1e-9)
     # Wqkv rows of layer 0: packed row t*256 + h*64 + d  <-  upstream row h*192 + d*3 + t
     w = lsd["transformers.0.self_attn.Wqkv.weight"].numpy()
     base = 64
