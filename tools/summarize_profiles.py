@@ -41,6 +41,9 @@ json.dump({"kernel": "attn_split_kernel", "source": f"profiles/{tag}_pmc_traffic
            "note": "Q, K, V^T planes read once + O written once per launch; the XCD-aware grid keeps the K/V of a (sequence, head) in one L2 "
                    "(traffic == compulsory bytes; it was 4.5x that before the remap)"},
           open(os.path.join(P, "r01_attention_traffic.json"), "w"), indent=1)
+for opt in ("adaptive", "b1"):  # operating points beside the headline line (collected when present)
+    if os.path.exists(os.path.join(F, f"bench_splg_{opt}.json.log")):
+        shutil.copy(os.path.join(F, f"bench_splg_{opt}.json.log"), os.path.join(P, f"{tag}_bench_splg_{opt}.json.log"))
 for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_loftr_1024.json.log", f"{tag}_bench_loftr_1024.json.log"),
                  ("bench_splg_f32.json.log", f"{tag}_bench_splg_f32.json.log"),
                  ("bench_superpoint.json.log", f"{tag}_bench_superpoint.json.log"),
