@@ -193,6 +193,78 @@ def bench_loftr(args, dev, rank, world):
         dist.destroy_process_group()
 
 
+def bench_superglue(args, dev, rank, world):
+    """SuperPoint + SuperGlue (matcher zoo entry `superglue`, imcui/hloc/configs/matchers.py:10-24: 50 Sinkhorn rounds) on
+    640x480 pairs; pairs/s, weak scaling (pairs are independent, no data-path collective)."""
+    from imcui_hip import backend
+    from imcui_hip.pipeline import SuperPointSuperGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from oracle.weights import superglue_state_dict, superpoint_state_dict  # seeded weights only
+
+    B = args.batch
+    spc = {"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)}
+    pipe = SuperPointSuperGluePipeline(spc, {"sinkhorn_iterations": args.sinkhorn, "match_threshold": 0.2, "state_dict": superglue_state_dict(0)}).eval().to(dev)
+    img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
+    img0, img1 = img0.to(dev), img1.to(dev)
+
+    def timed(steps):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = pipe(img0, img1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, out
+
+    for _ in range(args.warmup):
+        pipe(img0, img1)
+    backend.profile_enable(dev, True)
+    dt, out = timed(args.steps)
+    attn_ms, attn_n = backend.profile_read(dev, "attention")
+    conv_ms, _ = backend.profile_read(dev, "conv3x3")
+    gemm_ms, _ = backend.profile_read(dev, "gemm")
+    backend.profile_enable(dev, False)
+    # the optimal transport alone: the same step without Sinkhorn rounds (outside the timed region)
+    pipe.matcher.conf["sinkhorn_iterations"] = 0
+    pipe(img0, img1)
+    dt0, _ = timed(max(2, args.steps // 2))
+    dt0 *= args.steps / max(2, args.steps // 2)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        nk0, nk1 = out["num_keypoints0"].float().mean().item(), out["num_keypoints1"].float().mean().item()
+        split = args.precision == 1
+        peak = PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF
+        attn_flops = B * 8.59e9 * (nk0 * nk1 / (MAXK * MAXK))  # one launch: 2 images x 4 heads x (QK^T + PV) at 2048 x 2048 x 64
+        achieved = attn_flops / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
+        sk_ms = max(dt - dt0, 0.0) / args.steps * 1e3
+        sk_bytes = 2.0 * args.sinkhorn * 4.0 * nk0 * nk1 * B  # one row pass + one column pass over the score matrix per round
+        line = {
+            "metric": "image-pairs/sec @640x480 SuperPoint+SuperGlue", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
+            "config": {"workload": "SuperPoint(max 2048 kpts, nms 3)+SuperGlue(18 layers, Sinkhorn) on synthetic 640x480 pairs resident in HBM",
+                       "pairs_per_step_per_gpu": B, "sinkhorn_iterations": args.sinkhorn, "mean_keypoints": [nk0, nk1],
+                       "mean_matches": float((out["matches0"] > -1).sum(1).float().mean()),
+                       "weights": "seeded random (oracle/weights.py), real architecture"},
+            "roofline": {"kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel", "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n},
+            "sinkhorn": {"bound": "hbm", "ms_per_step": sk_ms, "algorithmic_bytes_per_step": sk_bytes,
+                         "achieved": sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                         "note": "step time minus the same step with 0 Sinkhorn rounds; 2 * rounds * 4 * n0 * n1 bytes per pair"},
+            "kernel_time_ms_per_step": {"attention": attn_ms / args.steps, "conv3x3": conv_ms / args.steps, "gemm": gemm_ms / args.steps},
+        }  # fmt: skip
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,9 +273,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint"],
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint", "superglue"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
-                         "superpoint = configs[1] extractor only (images/s)")
+                         "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
+    ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
@@ -230,6 +303,8 @@ def main():
         return bench_loftr(args, dev, rank, world)
     if args.workload == "superpoint":
         return bench_superpoint(args, dev, rank, world)
+    if args.workload == "superglue":
+        return bench_superglue(args, dev, rank, world)
     B = args.batch
     dc, wc = (0.95, 0.99) if args.adaptive else (-1.0, -1.0)
     pipe = SuperPointLightGluePipeline(

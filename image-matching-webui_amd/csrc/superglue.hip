@@ -1,0 +1,723 @@
+// SuperGlue: what imcui/hloc/matchers/superglue.py:42-43 `self.net(data)` computes
+// (upstream Vincentqyw/SuperGluePretrainedNetwork models/superglue.py), for B pairs at once.
+//
+// Same data layout as LightGlue: 2B sequences (image 0/1 of each pair) of R = roundup(ncap,128) token rows,
+// x [2B*R,256] token-major, attention operands head-major, per-sequence counts on the device.  Every layer is
+//   QKV GEMM (three 256->256 projections as one N=768 launch, heads de-interleaved at pack time)
+//   -> flash attention (self: own keys; cross: keys/values of the partner sequence)
+//   -> GEMM 512->512 + ReLU on cat[x, context] (attn.merge and the BatchNorm are folded into it at pack time)
+//   -> GEMM 512->256 with the residual add.
+// The optimal transport runs on the materialised score matrix [B,R,R] (dust-bin row / column are never stored:
+// they are the constant bin_score): per Sinkhorn round one row pass and one column pass, each reading the matrix
+// once -- HBM bound, 2 * iterations * 4*n0*n1 bytes per pair.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "attention.h"
+#include "gemm.h"
+#include "imcui_hip.h"
+
+#define SG_LAYERS 18
+#define SG_HEADS 4
+#define SG_BN_EPS 1e-5  // nn.BatchNorm1d default
+
+// ------------------------------------------------------------------ packed weights
+struct SgSplit {
+    size_t h, l, s;  // f16 hi / lo planes (float offsets) and the 2^-e scale
+};
+struct SgLayerOff {
+    size_t wqkv, bqkv, w1, b1, w2, b2;
+    SgSplit sqkv, s1, s2;
+};
+struct SgLayout {
+    size_t k0;                  // [32][4]: wx, wy, wscore, bias of the first key-point encoder layer (BN folded)
+    size_t kw[4], kb[4];        // encoder layers 1..4: 32->64, 64->128, 128->256 (BN folded), 256->256
+    SgSplit ks[4];
+    SgLayerOff L[SG_LAYERS];
+    size_t wfinal, bfinal, bin;
+    SgSplit sfinal;
+    size_t total;
+};
+static const int SG_KENC[6] = {3, 32, 64, 128, 256, 256};
+
+static SgLayout sg_layout() {
+    SgLayout l;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t r = off;
+        off += align_up(n, 64);
+        return r;
+    };
+    auto take_split = [&](size_t n) {
+        SgSplit sp;
+        sp.h = take(n / 2);
+        sp.l = take(n / 2);
+        sp.s = take(64);
+        return sp;
+    };
+    l.k0 = take(32 * 4);
+    for (int i = 0; i < 4; ++i) {
+        l.kw[i] = take((size_t)SG_KENC[i + 2] * SG_KENC[i + 1]);
+        l.kb[i] = take(SG_KENC[i + 2]);
+    }
+    for (int i = 0; i < SG_LAYERS; ++i) {
+        SgLayerOff& o = l.L[i];
+        o.wqkv = take(768 * 256);
+        o.bqkv = take(768);
+        o.w1 = take(512 * 512);
+        o.b1 = take(512);
+        o.w2 = take(256 * 512);
+        o.b2 = take(256);
+    }
+    l.wfinal = take(256 * 256);
+    l.bfinal = take(256);
+    l.bin = take(64);
+    for (int i = 0; i < 4; ++i) l.ks[i] = take_split((size_t)SG_KENC[i + 2] * SG_KENC[i + 1]);
+    for (int i = 0; i < SG_LAYERS; ++i) {
+        SgLayerOff& o = l.L[i];
+        o.sqkv = take_split(768 * 256);
+        o.s1 = take_split(512 * 512);
+        o.s2 = take_split(256 * 512);
+    }
+    l.sfinal = take_split(256 * 256);
+    l.total = off;
+    return l;
+}
+
+// tensor order of the host-side packer = upstream state-dict keys
+//   0..9    kenc.encoder.{0,3,6,9,12}.{weight,bias}
+//   10..25  kenc.encoder.{1,4,7,10}.{weight,bias,running_mean,running_var}
+//   26 + 16*i + j   gnn.layers.i.<SG_LAYER_KEYS[j]>
+//   26 + 16*18 ..   final_proj.weight, final_proj.bias, bin_score
+enum { SG_T_KENC = 26, SG_T_PER_LAYER = 16 };
+static const char* const SG_LAYER_KEYS[SG_T_PER_LAYER] = {
+    "attn.proj.0.weight", "attn.proj.0.bias",  "attn.proj.1.weight", "attn.proj.1.bias",   "attn.proj.2.weight", "attn.proj.2.bias",
+    "attn.merge.weight",  "attn.merge.bias",   "mlp.0.weight",       "mlp.0.bias",         "mlp.1.weight",       "mlp.1.bias",
+    "mlp.1.running_mean", "mlp.1.running_var", "mlp.3.weight",       "mlp.3.bias",
+};
+static const char* const SG_BN_FIELDS[4] = {"weight", "bias", "running_mean", "running_var"};
+static const int SG_NUM_TENSORS = SG_T_KENC + SG_T_PER_LAYER * SG_LAYERS + 3;
+
+extern "C" size_t imcui_hip_superglue_packed_floats(void) { return sg_layout().total; }
+extern "C" int imcui_hip_superglue_num_tensors(void) { return SG_NUM_TENSORS; }
+extern "C" const char* imcui_hip_superglue_tensor_name(int i) {
+    static thread_local char buf[96];
+    if (i < 0 || i >= SG_NUM_TENSORS) return nullptr;
+    if (i < 10) {
+        snprintf(buf, sizeof buf, "kenc.encoder.%d.%s", 3 * (i / 2), (i & 1) ? "bias" : "weight");
+    } else if (i < SG_T_KENC) {
+        snprintf(buf, sizeof buf, "kenc.encoder.%d.%s", 3 * ((i - 10) / 4) + 1, SG_BN_FIELDS[(i - 10) % 4]);
+    } else if (i < SG_T_KENC + SG_T_PER_LAYER * SG_LAYERS) {
+        const int j = i - SG_T_KENC;
+        snprintf(buf, sizeof buf, "gnn.layers.%d.%s", j / SG_T_PER_LAYER, SG_LAYER_KEYS[j % SG_T_PER_LAYER]);
+    } else {
+        const int j = i - SG_T_KENC - SG_T_PER_LAYER * SG_LAYERS;
+        return j == 0 ? "final_proj.weight" : j == 1 ? "final_proj.bias" : "bin_score";
+    }
+    return buf;
+}
+
+// Host-side packing.  Everything that is affine at inference time is folded in double here:
+//   BatchNorm (eval):  y = (x - mean) * gamma / sqrt(var + eps) + beta  ->  scale and shift of the preceding conv
+//   attn.merge:        mlp.0(cat[x, Wm ctx + bm]) = cat[x, ctx] [W0a | W0b Wm]^T + (b0 + W0b bm)
+// Heads: upstream views the 256 projection channels as (64, 4): channel = d * 4 + head.  The packed q / k / v rows and
+// the merge input columns are re-ordered to head * 64 + d, the head-major layout of the attention kernel.
+extern "C" int imcui_hip_superglue_pack_weights(const float* const* t, float* packed) {
+    if (!t || !packed) return IMCUI_ERR_ARG;
+    for (int i = 0; i < SG_NUM_TENSORS; ++i)
+        if (!t[i]) return IMCUI_ERR_ARG;
+    const SgLayout l = sg_layout();
+    memset(packed, 0, l.total * sizeof(float));
+    // ---- key-point encoder
+    for (int i = 0; i < 5; ++i) {
+        const int cin = SG_KENC[i], cout = SG_KENC[i + 1];
+        const float* w = t[2 * i];
+        const float* b = t[2 * i + 1];
+        for (int o = 0; o < cout; ++o) {
+            double sc = 1.0, sh = 0.0;
+            if (i < 4) {
+                const float* const* bn = t + 10 + 4 * i;
+                sc = (double)bn[0][o] / sqrt((double)bn[3][o] + SG_BN_EPS);
+                sh = (double)bn[1][o] - (double)bn[2][o] * sc;
+            }
+            float* dw = (i == 0) ? packed + l.k0 + (size_t)o * 4 : packed + l.kw[i - 1] + (size_t)o * cin;
+            for (int k = 0; k < cin; ++k) dw[k] = (float)((double)w[(size_t)o * cin + k] * sc);
+            const float bias = (float)((double)b[o] * sc + sh);
+            if (i == 0)
+                dw[3] = bias;
+            else
+                packed[l.kb[i - 1] + o] = bias;
+        }
+    }
+    // ---- attentional propagation layers
+    std::vector<double> row(256);
+    for (int i = 0; i < SG_LAYERS; ++i) {
+        const float* const* s = t + SG_T_KENC + SG_T_PER_LAYER * i;
+        const SgLayerOff& o = l.L[i];
+        for (int tt = 0; tt < 3; ++tt)
+            for (int hh = 0; hh < 4; ++hh)
+                for (int d = 0; d < 64; ++d) {
+                    const int src = d * 4 + hh, dst = tt * 256 + hh * 64 + d;
+                    memcpy(packed + o.wqkv + (size_t)dst * 256, s[2 * tt] + (size_t)src * 256, 256 * sizeof(float));
+                    packed[o.bqkv + dst] = s[2 * tt + 1][src];
+                }
+        const float *wm = s[6], *bm = s[7], *w0 = s[8], *b0 = s[9];
+        for (int n = 0; n < 512; ++n) {
+            const double sc = (double)s[10][n] / sqrt((double)s[13][n] + SG_BN_EPS);
+            const double sh = (double)s[11][n] - (double)s[12][n] * sc;
+            const float* w0r = w0 + (size_t)n * 512;
+            float* dst = packed + o.w1 + (size_t)n * 512;
+            for (int k = 0; k < 256; ++k) dst[k] = (float)((double)w0r[k] * sc);
+            double bacc = b0[n];
+            for (int k = 0; k < 256; ++k) row[k] = 0.0;
+            for (int j = 0; j < 256; ++j) {
+                const double c = w0r[256 + j];
+                const float* wmr = wm + (size_t)j * 256;
+                for (int k = 0; k < 256; ++k) row[k] += c * (double)wmr[k];
+                bacc += c * (double)bm[j];
+            }
+            // context channel head*64 + d  <-  upstream merge input channel d*4 + head
+            for (int hh = 0; hh < 4; ++hh)
+                for (int d = 0; d < 64; ++d) dst[256 + hh * 64 + d] = (float)(row[d * 4 + hh] * sc);
+            packed[o.b1 + n] = (float)(bacc * sc + sh);
+        }
+        memcpy(packed + o.w2, s[14], (size_t)256 * 512 * sizeof(float));
+        memcpy(packed + o.b2, s[15], 256 * sizeof(float));
+    }
+    const float* const* f = t + SG_T_KENC + SG_T_PER_LAYER * SG_LAYERS;
+    memcpy(packed + l.wfinal, f[0], (size_t)256 * 256 * sizeof(float));
+    memcpy(packed + l.bfinal, f[1], 256 * sizeof(float));
+    packed[l.bin] = f[2][0];
+    // split-precision copies of every GEMM weight (taken from the packed f32 layout)
+    auto sp = [&](const SgSplit& d, size_t src, int N, int K) {
+        packed[d.s] = split_weights_frag_host(packed + src, N, K, reinterpret_cast<unsigned short*>(packed + d.h),
+                                              reinterpret_cast<unsigned short*>(packed + d.l));
+    };
+    for (int i = 0; i < 4; ++i) sp(l.ks[i], l.kw[i], SG_KENC[i + 2], SG_KENC[i + 1]);
+    for (int i = 0; i < SG_LAYERS; ++i) {
+        const SgLayerOff& o = l.L[i];
+        sp(o.sqkv, o.wqkv, 768, 256);
+        sp(o.s1, o.w1, 512, 512);
+        sp(o.s2, o.w2, 256, 512);
+    }
+    sp(l.sfinal, l.wfinal, 256, 256);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+struct SgWs {
+    float *x, *ctx, *hbuf, *q, *k, *v, *one, *zero, *md, *sim, *u, *vv, *max0;
+    int *cnt, *active, *m0, *m1;
+    size_t total;
+    bool ok;
+};
+
+static SgWs sg_carve(void* ws, size_t bytes, int B, int R) {
+    WsAlloc a(ws, bytes);
+    SgWs w;
+    const size_t rows = (size_t)2 * B * R;
+    w.x = a.get<float>(rows * 256);
+    w.ctx = a.get<float>(rows * 256);
+    w.hbuf = a.get<float>(rows * 512);
+    w.q = a.get<float>(rows * 256);
+    w.k = a.get<float>(rows * 256);
+    w.v = a.get<float>(rows * 256);
+    w.one = a.get<float>(rows * 32);   // identity rotation for the shared QKV epilogue (cos = 1, sin = 0)
+    w.zero = a.get<float>(rows * 32);
+    w.md = a.get<float>(rows * 256);
+    w.sim = a.get<float>((size_t)B * R * R);
+    w.u = a.get<float>((size_t)B * (R + 64));
+    w.vv = a.get<float>((size_t)B * (R + 64));
+    w.max0 = a.get<float>((size_t)B * R);
+    w.cnt = a.get<int>(2 * B);
+    w.active = a.get<int>(B);
+    w.m0 = a.get<int>((size_t)B * R);
+    w.m1 = a.get<int>((size_t)B * R);
+    w.total = a.off;
+    w.ok = a.ok;
+    return w;
+}
+
+extern "C" size_t imcui_hip_superglue_workspace_bytes(int B, int ncap) {
+    const int R = (int)align_up((size_t)(ncap > 0 ? ncap : 1), 128);
+    return sg_carve(nullptr, 0, B, R).total;
+}
+
+// ------------------------------------------------------------------ kernels
+__global__ void sg_init_pairs_kernel(const int* __restrict__ n0, const int* __restrict__ n1, int B, int* __restrict__ cnt,
+                                     int* __restrict__ active) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int a = n0[b], c = n1[b];
+    const int act = (a > 0 && c > 0) ? 1 : 0;  // upstream returns all -1 / 0 when either image has no key-points
+    active[b] = act;
+    cnt[2 * b] = act ? a : 0;
+    cnt[2 * b + 1] = act ? c : 0;
+}
+
+// one wave per row: output defaults, x = descriptor, first encoder layer relu(W0' [kx, ky, score] + b0') -> e32,
+// identity rotation tables, Sinkhorn potentials u = v = 0
+__global__ __launch_bounds__(256) void sg_init_kernel(const float* __restrict__ kp0, const float* __restrict__ kp1,
+                                                      const float* __restrict__ sc0, const float* __restrict__ sc1,
+                                                      const float* __restrict__ d0, const float* __restrict__ d1,
+                                                      const int* __restrict__ cnt, int ncap, int R, float w0, float h0, float w1,
+                                                      float h1, const float* __restrict__ k0w, float* __restrict__ x,
+                                                      float* __restrict__ e32, float* __restrict__ one, float* __restrict__ zero,
+                                                      float* __restrict__ u, float* __restrict__ v, int* __restrict__ matches0,
+                                                      int* __restrict__ matches1, float* __restrict__ ms0,
+                                                      float* __restrict__ ms1) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.y, b = seq >> 1, img = seq & 1;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= R) return;
+    const int n = cnt[seq];
+    const size_t row = (size_t)seq * R + i;
+    if (lane == 0) {
+        if (i < ncap) {
+            (img ? matches1 : matches0)[(size_t)b * ncap + i] = -1;
+            (img ? ms1 : ms0)[(size_t)b * ncap + i] = 0.0f;
+        }
+        (img ? v : u)[(size_t)b * (R + 64) + i] = 0.0f;
+        if (i == 0) (img ? v : u)[(size_t)b * (R + 64) + R] = 0.0f;
+    }
+    if (lane < 32) {
+        one[row * 32 + lane] = 1.0f;
+        zero[row * 32 + lane] = 0.0f;
+    }
+    if (i >= n) return;
+    const float* d = (img ? d1 : d0) + ((size_t)b * ncap + i) * 256;
+    *reinterpret_cast<float4*>(x + row * 256 + lane * 4) = *reinterpret_cast<const float4*>(d + lane * 4);
+    if (lane < 32) {
+        const float* kp = (img ? kp1 : kp0) + ((size_t)b * ncap + i) * 2;
+        const float W = img ? w1 : w0, H = img ? h1 : h0;
+        // normalize_keypoints: (k - size/2) / (max(size) * 0.7)
+        const float scaling = fmaxf(W, H) * 0.7f;
+        const float kx = (kp[0] - W / 2.0f) / scaling, ky = (kp[1] - H / 2.0f) / scaling;
+        const float s = (img ? sc1 : sc0)[(size_t)b * ncap + i];
+        const float4 w4 = *reinterpret_cast<const float4*>(k0w + lane * 4);
+        e32[row * 32 + lane] = fmaxf(((kx * w4.x + ky * w4.y) + s * w4.z) + w4.w, 0.0f);
+    }
+}
+
+// streaming log-sum-exp: running maximum m, sum s of exp(x - m)
+struct Lse {
+    float m, s;
+};
+__device__ __forceinline__ void lse_add4(Lse& a, float x0, float x1, float x2, float x3) {
+    const float cm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    if (cm == -INFINITY) return;
+    const float mn = fmaxf(a.m, cm);
+    a.s = a.s * expf(a.m - mn) + ((expf(x0 - mn) + expf(x1 - mn)) + (expf(x2 - mn) + expf(x3 - mn)));
+    a.m = mn;
+}
+__device__ __forceinline__ void lse_merge(Lse& a, float m, float s) {
+    if (m == -INFINITY) return;
+    const float mn = fmaxf(a.m, m);
+    a.s = a.s * expf(a.m - mn) + s * expf(m - mn);
+    a.m = mn;
+}
+
+// Sinkhorn row pass: u_i = log_mu_i - logsumexp_j(Z_ij + v_j), j over the n1 columns and the dust-bin column.
+// One wave per row; row n0 is the dust-bin row (Z = bin_score everywhere).
+__global__ __launch_bounds__(256) void sg_row_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                     const int* __restrict__ active, int R, const float* __restrict__ binp,
+                                                     const float* __restrict__ v, float* __restrict__ u) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    if (!active[b]) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    if (i > n0) return;
+    const float alpha = binp[0];
+    const float* vb = v + (size_t)b * (R + 64);
+    const float* row = sim + ((size_t)b * R + (i < n0 ? i : 0)) * R;
+    const bool bin = (i == n0);
+    Lse a = {-INFINITY, 0.0f};
+#pragma unroll 2
+    for (int j = lane * 4; j < n1; j += 256) {
+        const float4 z = bin ? make_float4(alpha, alpha, alpha, alpha) : *reinterpret_cast<const float4*>(row + j);
+        const float4 vj = *reinterpret_cast<const float4*>(vb + j);
+        lse_add4(a, z.x + vj.x, (j + 1 < n1) ? z.y + vj.y : -INFINITY, (j + 2 < n1) ? z.z + vj.z : -INFINITY,
+                 (j + 3 < n1) ? z.w + vj.w : -INFINITY);
+    }
+    const float M = wave_max(a.m);
+    float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
+    s = wave_sum(s);
+    if (lane == 0) {
+        Lse t = {M, s};
+        lse_merge(t, alpha + vb[n1], 1.0f);  // dust-bin column
+        const float norm = -logf((float)n0 + (float)n1);
+        const float log_mu = bin ? logf((float)n1) + norm : norm;
+        u[(size_t)b * (R + 64) + i] = log_mu - (t.m + logf(t.s));
+    }
+}
+
+// Sinkhorn column pass: v_j = log_nu_j - logsumexp_i(Z_ij + u_i).  Block = 64 columns x 4 row groups; the last block
+// column (blockIdx.x == R / 64) is the dust-bin column.
+__global__ __launch_bounds__(256) void sg_col_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                     const int* __restrict__ active, int R, const float* __restrict__ binp,
+                                                     const float* __restrict__ u, float* __restrict__ v) {
+    __shared__ float sm[4][64], ss[4][64];
+    const int b = blockIdx.y;
+    if (!active[b]) return;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    const float alpha = binp[0];
+    const float* ub = u + (size_t)b * (R + 64);
+    const float norm = -logf((float)n0 + (float)n1);
+    if (blockIdx.x == R / 64) {
+        // dust-bin column: logsumexp_i(alpha + u_i) over the n0 rows and the dust-bin row
+        Lse a = {-INFINITY, 0.0f};
+        for (int i = threadIdx.x * 4; i <= n0; i += 1024)
+            lse_add4(a, alpha + ub[i], (i + 1 <= n0) ? alpha + ub[i + 1] : -INFINITY, (i + 2 <= n0) ? alpha + ub[i + 2] : -INFINITY,
+                     (i + 3 <= n0) ? alpha + ub[i + 3] : -INFINITY);
+        const float M = wave_max(a.m);
+        float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
+        s = wave_sum(s);
+        if (c == 0) {
+            sm[g][0] = M;
+            ss[g][0] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Lse t = {sm[0][0], ss[0][0]};
+            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][0], ss[gg][0]);
+            v[(size_t)b * (R + 64) + n1] = (logf((float)n0) + norm) - (t.m + logf(t.s));
+        }
+        return;
+    }
+    if (blockIdx.x * 64 >= n1) return;
+    const int j = blockIdx.x * 64 + c;
+    const float* base = sim + (size_t)b * R * R;
+    Lse a = {-INFINITY, 0.0f};
+    if (j < n1)
+        for (int i = g; i < n0; i += 32) {
+            // 8 independent loads per trip (a column walk is a dependent load chain otherwise)
+            float z[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) z[t] = (i + 4 * t < n0) ? base[(size_t)(i + 4 * t) * R + j] + ub[i + 4 * t] : -INFINITY;
+            lse_add4(a, z[0], z[1], z[2], z[3]);
+            lse_add4(a, z[4], z[5], z[6], z[7]);
+        }
+    sm[g][c] = a.m;
+    ss[g][c] = a.s;
+    __syncthreads();
+    if (g == 0 && j < n1) {
+        Lse t = {sm[0][c], ss[0][c]};
+        for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][c], ss[gg][c]);
+        lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
+        v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
+    }
+}
+
+// final log assignment of (i, j) exactly as the reference associates it: ((Z + u_i) + v_j) - norm
+__device__ __forceinline__ float sg_score(float z, float ui, float vj, float norm) { return ((z + ui) + vj) - norm; }
+
+__global__ __launch_bounds__(256) void sg_rowarg_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                        const int* __restrict__ active, int R, const float* __restrict__ u,
+                                                        const float* __restrict__ v, float* __restrict__ max0,
+                                                        int* __restrict__ m0) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    if (!active[b]) return;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    if (i >= n0) return;
+    const float* row = sim + ((size_t)b * R + i) * R;
+    const float* vb = v + (size_t)b * (R + 64);
+    const float ui = u[(size_t)b * (R + 64) + i];
+    const float norm = -logf((float)n0 + (float)n1);
+    float best = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = lane; j < n1; j += 64) {
+        const float val = sg_score(row[j], ui, vb[j], norm);
+        if (val > best) {
+            best = val;
+            bj = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oj = __shfl_xor(bj, o, 64);
+        if (ov > best || (ov == best && oj < bj)) {
+            best = ov;
+            bj = oj;
+        }
+    }
+    if (lane == 0) {
+        max0[(size_t)b * R + i] = best;
+        m0[(size_t)b * R + i] = bj;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_colarg_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                        const int* __restrict__ active, int R, const float* __restrict__ u,
+                                                        const float* __restrict__ v, int* __restrict__ m1) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int b = blockIdx.y;
+    if (!active[b]) return;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    if (blockIdx.x * 64 >= n1) return;
+    const float* base = sim + (size_t)b * R * R;
+    const float* ub = u + (size_t)b * (R + 64);
+    const float norm = -logf((float)n0 + (float)n1);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (j < n1) {
+        const float vj = v[(size_t)b * (R + 64) + j];
+        for (int i0 = g; i0 < n0; i0 += 32) {
+            float z[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) z[t] = (i0 + 4 * t < n0) ? base[(size_t)(i0 + 4 * t) * R + j] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int i = i0 + 4 * t;
+                if (i < n0) {
+                    const float val = sg_score(z[t], ub[i], vj, norm);
+                    if (val > best) {
+                        best = val;
+                        bi = i;
+                    }
+                }
+            }
+        }
+    }
+    sv[g][c] = best;
+    si[g][c] = bi;
+    __syncthreads();
+    if (g == 0 && j < n1) {
+        for (int gg = 1; gg < 4; ++gg) {
+            const float ov = sv[gg][c];
+            const int oi = si[gg][c];
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        m1[(size_t)b * R + j] = bi;
+    }
+}
+
+// mutual check + threshold, one block per pair
+__global__ __launch_bounds__(256) void sg_filter_kernel(const int* __restrict__ cnt, const int* __restrict__ active, int R, int ncap,
+                                                        const int* __restrict__ m0, const int* __restrict__ m1,
+                                                        const float* __restrict__ max0, float thr, int* __restrict__ matches0,
+                                                        int* __restrict__ matches1, float* __restrict__ mscores0,
+                                                        float* __restrict__ mscores1) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!active[b]) return;
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    const size_t pb = (size_t)b * R, ob = (size_t)b * ncap;
+    for (int i = tid; i < n0; i += 256) {
+        const int j = m0[pb + i];
+        const bool mutual = (m1[pb + j] == i);
+        const float ms = mutual ? expf(max0[pb + i]) : 0.0f;
+        matches0[ob + i] = (mutual && ms > thr) ? j : -1;
+        mscores0[ob + i] = ms;
+    }
+    for (int j = tid; j < n1; j += 256) {
+        const int i = m1[pb + j];
+        const bool mutual = (m0[pb + i] == j);
+        const float ms = mutual ? expf(max0[pb + i]) : 0.0f;  // = mscores0[i] (i is mutual with j)
+        matches1[ob + j] = (mutual && ms > thr) ? i : -1;
+        mscores1[ob + j] = ms;
+    }
+}
+
+// ------------------------------------------------------------------ forward
+extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
+                                           const float* keypoints1, const float* scores0, const float* scores1,
+                                           const float* descriptors0, const float* descriptors1, const int* n0, const int* n1,
+                                           float w0, float h0, float w1, float h1, int sinkhorn_iterations, double match_threshold,
+                                           int* matches0, int* matches1, float* mscores0, float* mscores1, void* ws,
+                                           size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (B <= 0) return IMCUI_OK;
+    if (ncap <= 0) return imcui_set_err(h, IMCUI_ERR_ARG, "superglue: ncap=%d must be positive", ncap);
+    if (sinkhorn_iterations < 0) return imcui_set_err(h, IMCUI_ERR_ARG, "superglue: sinkhorn_iterations=%d", sinkhorn_iterations);
+    if (!packed || !keypoints0 || !keypoints1 || !scores0 || !scores1 || !descriptors0 || !descriptors1 || !n0 || !n1 ||
+        !matches0 || !matches1 || !mscores0 || !mscores1)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "superglue: null argument");
+    const int R = (int)align_up((size_t)ncap, 128);
+    SgWs w = sg_carve(ws, ws_bytes, B, R);
+    if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "superglue: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const SgLayout l = sg_layout();
+    const float* P = packed;
+    const int S = 2 * B;
+    const dim3 rowgrid(R / 4, S), blk(256);
+    int rc;
+#define SGRUN(x)                       \
+    do {                               \
+        rc = (x);                      \
+        if (rc != IMCUI_OK) return rc; \
+    } while (0)
+
+    hipLaunchKernelGGL(sg_init_pairs_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, n0, n1, B, w.cnt, w.active);
+    hipLaunchKernelGGL(sg_init_kernel, rowgrid, blk, 0, stream, keypoints0, keypoints1, scores0, scores1, descriptors0, descriptors1,
+                       w.cnt, ncap, R, w0, h0, w1, h1, P + l.k0, w.x, w.ctx, w.one, w.zero, w.u, w.vv, matches0, matches1, mscores0,
+                       mscores1);
+    IMCUI_CHECK_LAUNCH(h);
+
+    const bool split = h->precision == 1;
+    auto base = [&](GemmP& g) {
+        g.M = S * R;
+        g.cnt = w.cnt;
+        g.active = w.active;
+        g.rows_per_seq = R;
+    };
+    auto wts = [&](GemmP& g, size_t wf32, const SgSplit& sp) {
+        g.W = P + wf32;
+        if (split) {
+            g.Wh = reinterpret_cast<const unsigned short*>(P + sp.h);
+            g.Wl = reinterpret_cast<const unsigned short*>(P + sp.l);
+            g.wscale = P + sp.s;
+        }
+    };
+    // ---- key-point encoder layers 1..4 (layer 0 ran in sg_init_kernel): e32 -> e64 -> e128 -> e256 -> x += e
+    {
+        const float* src = w.ctx;
+        float* bufs[2] = {w.hbuf, w.ctx};
+        for (int i = 0; i < 4; ++i) {
+            const int K = SG_KENC[i + 1], N = SG_KENC[i + 2];
+            GemmP g;
+            base(g);
+            g.epi = (i < 3) ? EPI_RELU : EPI_RESID;
+            g.A = src;
+            g.lda = K;
+            g.K = K;
+            g.N = N;
+            wts(g, l.kw[i], l.ks[i]);
+            g.ldw = K;
+            g.bias = P + l.kb[i];
+            g.C = (i < 3) ? bufs[i & 1] : w.x;
+            g.ldc = (i < 3) ? N : 256;
+            SGRUN(gemm_launch(h, g, stream));
+            src = bufs[i & 1];
+        }
+    }
+    // ---- attentional GNN: ['self', 'cross'] * 9
+    for (int layer = 0; layer < SG_LAYERS; ++layer) {
+        const SgLayerOff& o = l.L[layer];
+        GemmP g;
+        base(g);
+        g.epi = EPI_QKV;
+        g.A = w.x;
+        g.lda = 256;
+        g.K = 256;
+        g.N = 768;
+        wts(g, o.wqkv, o.sqkv);
+        g.ldw = 256;
+        g.bias = P + o.bqkv;
+        g.v_transposed = split ? 1 : 0;
+        g.split_out = split ? 1 : 0;
+        g.plane_halves = (size_t)S * R * 256;
+        g.Q = w.q;
+        g.Kt = w.k;
+        g.V = w.v;
+        g.rope_cos = w.one;  // no rotary encoding in SuperGlue: q * 1 + rotate_half(q) * 0
+        g.rope_sin = w.zero;
+        g.alpha = 0.125f;  // scores / 64 ** .5, folded into q (exact power of two)
+        g.heads = SG_HEADS;
+        SGRUN(gemm_launch(h, g, stream));
+        AttnP a;
+        a.Q = w.q;
+        a.K = w.k;
+        a.V = w.v;
+        a.O = w.ctx;
+        a.cnt = w.cnt;
+        a.active = w.active;
+        a.nseq = S;
+        a.heads = SG_HEADS;
+        a.rows_per_seq = R;
+        a.cross = layer & 1;
+        SGRUN(attention_launch(h, a, stream));
+        GemmP f1;  // relu(bn(mlp.0(cat[x, merge(ctx)]))) with merge and bn folded into the weights
+        base(f1);
+        f1.epi = EPI_RELU;
+        f1.A = w.x;
+        f1.lda = 256;
+        f1.A2 = w.ctx;
+        f1.lda2 = 256;
+        f1.K1 = 256;
+        f1.K = 512;
+        f1.N = 512;
+        wts(f1, o.w1, o.s1);
+        f1.ldw = 512;
+        f1.bias = P + o.b1;
+        f1.C = w.hbuf;
+        f1.ldc = 512;
+        SGRUN(gemm_launch(h, f1, stream));
+        GemmP f2;  // x += mlp.3(h)
+        base(f2);
+        f2.epi = EPI_RESID;
+        f2.A = w.hbuf;
+        f2.lda = 512;
+        f2.K = 512;
+        f2.N = 256;
+        wts(f2, o.w2, o.s2);
+        f2.ldw = 512;
+        f2.bias = P + o.b2;
+        f2.C = w.x;
+        f2.ldc = 256;
+        SGRUN(gemm_launch(h, f2, stream));
+    }
+    {
+        GemmP g;  // md = final_proj(x) / 256^(1/4): md0 . md1 = scores / 256 ** .5 (exact power of two)
+        base(g);
+        g.epi = EPI_BIAS;
+        g.A = w.x;
+        g.lda = 256;
+        g.K = 256;
+        g.N = 256;
+        wts(g, l.wfinal, l.sfinal);
+        g.ldw = 256;
+        g.bias = P + l.bfinal;
+        g.alpha = 0.25f;
+        g.C = w.md;
+        g.ldc = 256;
+        SGRUN(gemm_launch(h, g, stream));
+    }
+    {
+        GemmP g;  // sim[b] = md0[b] . md1[b]^T
+        g.epi = EPI_BIAS;
+        g.batch = B;
+        g.A = w.md;
+        g.lda = 256;
+        g.a_bs = (long)2 * R * 256;
+        g.W = w.md + (size_t)R * 256;
+        g.ldw = 256;
+        g.w_bs = (long)2 * R * 256;
+        g.C = w.sim;
+        g.ldc = R;
+        g.c_bs = (long)R * R;
+        g.M = R;
+        g.N = R;
+        g.K = 256;
+        g.mcnt = w.cnt;
+        g.ncnt = w.cnt + 1;
+        g.cnt_stride = 2;
+        SGRUN(gemm_launch(h, g, stream));
+    }
+    // ---- log-domain Sinkhorn with dust-bins, then mutual arg-max + threshold
+    const dim3 rg(R / 4 + 1, B), cg(R / 64 + 1, B);
+    for (int it = 0; it < sinkhorn_iterations; ++it) {
+        hipLaunchKernelGGL(sg_row_kernel, rg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u);
+        hipLaunchKernelGGL(sg_col_kernel, cg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.u, w.vv);
+    }
+    hipLaunchKernelGGL(sg_rowarg_kernel, dim3(R / 4, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.max0, w.m0);
+    hipLaunchKernelGGL(sg_colarg_kernel, dim3(R / 64, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.m1);
+    hipLaunchKernelGGL(sg_filter_kernel, dim3(B), blk, 0, stream, w.cnt, w.active, R, ncap, w.m0, w.m1, w.max0, (float)match_threshold,
+                       matches0, matches1, mscores0, mscores1);
+    IMCUI_CHECK_LAUNCH(h);
+#undef SGRUN
+    return IMCUI_OK;
+}

@@ -229,6 +229,79 @@ class LightGlueHIP:
         }  # fmt: skip
 
 
+# ------------------------------------------------------------------ SuperGlue
+def superglue_tensor_names() -> list[str]:
+    lib = load_library()
+    return [lib.imcui_hip_superglue_tensor_name(i).decode() for i in range(lib.imcui_hip_superglue_num_tensors())]
+
+
+def pack_superglue(state_dict: dict) -> torch.Tensor:
+    """Upstream SuperGlue state dict (Conv1d weights [out,in,1]) -> packed float32 buffer (host)."""
+    lib = load_library()
+    names = superglue_tensor_names()
+    arrs = []
+    for n in names:
+        if n not in state_dict:
+            raise ImcuiHipError(f"SuperGlue state dict lacks '{n}'")
+        arrs.append(_as_f32_host(state_dict[n]).reshape(-1) if n == "bin_score" else _as_f32_host(state_dict[n]))
+    if arrs[0].size != 32 * 3 or arrs[names.index("gnn.layers.17.mlp.3.weight")].size != 256 * 512:
+        raise ImcuiHipError("only the 256-d / 4-head / 18-layer SuperGlue with the [32,64,128,256] key-point encoder is supported")
+    packed = np.zeros(lib.imcui_hip_superglue_packed_floats(), dtype=np.float32)
+    tp = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    rc = lib.imcui_hip_superglue_pack_weights(tp, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_superglue_pack_weights failed ({rc})")
+    return torch.from_numpy(packed)
+
+
+class SuperGlueHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+
+    def forward(self, packed, kpts0, kpts1, scores0, scores1, desc0, desc1, n0, n1, size0, size1, sinkhorn_iterations,
+                match_threshold):  # fmt: skip
+        """kptsX [B,ncap,2], scoresX [B,ncap], descX [B,ncap,256] (row per point), nX [B] int32 on the GPU; sizeX = (W, H)."""
+        dev = kpts0.device
+        hd = get_handle(dev)
+        lib = hd.lib
+        B, ncap0 = kpts0.shape[0], kpts0.shape[1]
+        ncap1 = kpts1.shape[1]
+        ncap = max(ncap0, ncap1, 1)
+
+        def pad(t, n):
+            if t.shape[1] == n:
+                return t.contiguous().float()
+            shape = list(t.shape)
+            shape[1] = n
+            o = torch.zeros(shape, dtype=torch.float32, device=dev)
+            o[:, : t.shape[1]] = t
+            return o
+
+        kpts0, kpts1, desc0, desc1 = pad(kpts0, ncap), pad(kpts1, ncap), pad(desc0, ncap), pad(desc1, ncap)
+        scores0, scores1 = pad(scores0, ncap), pad(scores1, ncap)
+        n0 = n0.to(device=dev, dtype=torch.int32).contiguous()
+        n1 = n1.to(device=dev, dtype=torch.int32).contiguous()
+        m0 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        m1 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        s0 = torch.empty((B, ncap), dtype=torch.float32, device=dev)
+        s1 = torch.empty((B, ncap), dtype=torch.float32, device=dev)
+        with self._lock:
+            ws = self._ws.get(lib.imcui_hip_superglue_workspace_bytes(B, ncap), dev)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_superglue_forward(
+                    hd.h, _ptr(packed), B, ncap, _ptr(kpts0), _ptr(kpts1), _ptr(scores0), _ptr(scores1), _ptr(desc0), _ptr(desc1),
+                    _ptr(n0), _ptr(n1), float(size0[0]), float(size0[1]), float(size1[0]), float(size1[1]),
+                    int(sinkhorn_iterations), float(match_threshold),
+                    _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(ws), ws.numel(), _stream_ptr(),
+                )  # fmt: skip
+                hd.check(rc, "imcui_hip_superglue_forward")
+        return {
+            "matches0": m0[:, :ncap0], "matches1": m1[:, :ncap1], "matching_scores0": s0[:, :ncap0],
+            "matching_scores1": s1[:, :ncap1],
+        }  # fmt: skip
+
+
 # ------------------------------------------------------------------ LoFTR
 def _fold_bn(w: torch.Tensor, sd: dict, bn: str | None, eps: float = 1e-5):
     """conv (no bias) followed by eval-mode BatchNorm -> (w', b')."""

@@ -62,6 +62,20 @@ SIGNATURES = {
         + [C.c_void_p] * 7
         + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "imcui_hip_superglue_packed_floats": (C.c_size_t, []),
+    "imcui_hip_superglue_num_tensors": (C.c_int, []),
+    "imcui_hip_superglue_tensor_name": (C.c_char_p, [C.c_int]),
+    "imcui_hip_superglue_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "imcui_hip_superglue_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "imcui_hip_superglue_forward": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        + [C.c_void_p] * 8
+        + [C.c_float] * 4
+        + [C.c_int, C.c_double]
+        + [C.c_void_p] * 4
+        + [C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "imcui_hip_loftr_packed_floats": (C.c_size_t, []),
     "imcui_hip_loftr_num_layers": (C.c_int, []),
     "imcui_hip_loftr_layer_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -44,6 +44,38 @@ class SuperPointLightGluePipeline(torch.nn.Module):
         }  # fmt: skip
 
 
+class SuperPointSuperGluePipeline(torch.nn.Module):
+    """SuperPoint -> SuperGlue on B pairs (the `superpoint_max` + `superglue` entry of the matcher zoo,
+    imcui/hloc/configs/matchers.py:10-24): images in, fixed-stride match table out, no host synchronisation."""
+
+    def __init__(self, sp_conf: dict, sg_conf: dict):
+        super().__init__()
+        from .hloc.matchers.superglue import SuperGlue
+
+        self.extractor = SuperPoint(sp_conf)
+        self.matcher = SuperGlue(sg_conf)
+
+    @torch.no_grad()
+    def forward(self, image0: torch.Tensor, image1: torch.Tensor) -> dict:
+        B = image0.shape[0]
+        if image0.shape == image1.shape:
+            f = self.extractor.forward_batched(torch.cat([image0, image1], 0))
+            f0 = {k: v[:B] for k, v in f.items() if k in ("keypoints", "descriptors", "num_keypoints", "scores")}
+            f1 = {k: v[B:] for k, v in f.items() if k in ("keypoints", "descriptors", "num_keypoints", "scores")}
+        else:
+            f0 = self.extractor.forward_batched(image0)
+            f1 = self.extractor.forward_batched(image1)
+        size0 = (image0.shape[-1], image0.shape[-2])
+        size1 = (image1.shape[-1], image1.shape[-2])
+        m = self.matcher.forward_batched(f0["keypoints"], f1["keypoints"], f0["scores"], f1["scores"], f0["descriptors"],
+                                         f1["descriptors"], f0["num_keypoints"], f1["num_keypoints"], size0, size1)  # fmt: skip
+        return {
+            "keypoints0": f0["keypoints"], "keypoints1": f1["keypoints"], "scores0": f0["scores"], "scores1": f1["scores"],
+            "descriptors0": f0["descriptors"], "descriptors1": f1["descriptors"], "num_keypoints0": f0["num_keypoints"],
+            "num_keypoints1": f1["num_keypoints"], **m,
+        }  # fmt: skip
+
+
 def match_table(out: dict) -> torch.Tensor:
     """Fixed-stride per-pair record for the multi-GPU all-gather:
     int32 [B, 3 + 2*K]: n0, n1, stop, matches0[K], bit-cast matching_scores0[K]."""

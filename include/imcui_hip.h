@@ -10,6 +10,7 @@
  *   imcui_hip_mutual_nn           <- imcui/hloc/matchers/nearest_neighbor.py:38-66 `_forward`
  *   imcui_hip_loftr_forward       <- imcui/hloc/matchers/loftr.py:54            `self.net(data_)`
  *   imcui_hip_dual_softmax        <- imcui/hloc/matchers/dual_softmax.py:62-75  `dual_softmax_matcher(...)`
+ *   imcui_hip_superglue_forward   <- imcui/hloc/matchers/superglue.py:42-43     `self.net(data)`
  *   *_pack_weights                <- the `_init` weight loading (superpoint.py:48-53, lightglue.py:39-51)
  *
  * Conventions
@@ -125,6 +126,29 @@ int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int 
                                 double depth_confidence, double width_confidence, double filter_threshold, int* matches0,
                                 int* matches1, float* matching_scores0, float* matching_scores1, int* stop, int* prune0,
                                 int* prune1, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- SuperGlue (imcui/hloc/matchers/superglue.py:42-43 `self.net(data)`) ---------- */
+/* Host-side packing of the upstream state dict (Vincentqyw/SuperGluePretrainedNetwork models/superglue.py:
+ * kenc.encoder.*, gnn.layers.{0..17}.{attn.proj.{0,1,2},attn.merge,mlp.{0,1,3}}, final_proj, bin_score).
+ * `tensors` holds the host pointers of imcui_hip_superglue_num_tensors() tensors, tensor i being the state-dict entry
+ * imcui_hip_superglue_tensor_name(i) (Conv1d weights [out,in,1] are passed as [out,in]).  Eval-mode BatchNorm and
+ * attn.merge are folded into the neighbouring layers; heads are de-interleaved. */
+size_t imcui_hip_superglue_packed_floats(void);
+int imcui_hip_superglue_num_tensors(void);
+const char* imcui_hip_superglue_tensor_name(int i);
+int imcui_hip_superglue_pack_weights(const float* const* tensors, float* packed);
+size_t imcui_hip_superglue_workspace_bytes(int B, int ncap);
+/* B pairs.  keypoints0/1 [dev, B,ncap,2] pixel (x,y); scores0/1 [dev, B,ncap] detector scores; descriptors0/1
+ * [dev, B,ncap,256] (row per key-point); n0/n1 [dev, B] int32 valid counts (<= ncap); (w0,h0)/(w1,h1): size of the
+ * images (superglue.py passes `data["image0"].shape`, only used to normalise key-points).
+ * sinkhorn_iterations / match_threshold = conf (superglue.py:17-18; configs/matchers.py:15-16,30-31).
+ * Outputs [dev]: matches0/1 [B,ncap] int32 (-1 = unmatched), matching_scores0/1 [B,ncap]; a pair with an empty
+ * image gets all -1 / 0 (upstream early return).  Entries >= n are -1 / 0. */
+int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
+                                const float* keypoints1, const float* scores0, const float* scores1, const float* descriptors0,
+                                const float* descriptors1, const int* n0, const int* n1, float w0, float h0, float w1, float h1,
+                                int sinkhorn_iterations, double match_threshold, int* matches0, int* matches1,
+                                float* matching_scores0, float* matching_scores1, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- LoFTR (kornia.feature.LoFTR behind imcui/hloc/matchers/loftr.py:54) ---- */
 /* Host-side packing.  Every convolution / Linear is one layer W[N][K] (+ bias[N], may be NULL) in GEMM

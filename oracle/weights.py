@@ -225,3 +225,59 @@ def loftr_state_dict(seed: int = 0, structured: bool = True) -> dict:
     lin("fine_preprocess.merge_feat", 128, 256, bias=True)
     encoder("loftr_fine", 2, 128)
     return sd
+
+
+def superglue_state_dict(seed: int = 0, structured: bool = True) -> dict:
+    """Random SuperGlue weights in the upstream (magicleap / Vincentqyw fork) state-dict layout:
+
+    kenc.encoder.{0,3,6,9,12}.{weight[out,in,1],bias}, kenc.encoder.{1,4,7,10}.{weight,bias,running_mean,
+    running_var,num_batches_tracked}, gnn.layers.{i}.attn.{merge,proj.0,proj.1,proj.2}.{weight,bias},
+    gnn.layers.{i}.mlp.{0,3}.{weight,bias}, gnn.layers.{i}.mlp.1.<BatchNorm>, final_proj.{weight,bias}, bin_score.
+
+    `structured` damps the residual updates and makes `final_proj` a scaled identity + noise, so the optimal
+    transport of random-weight features still resolves the true correspondences of distinctive descriptors
+    (mutual matches above `match_threshold`, the rest in the dust-bins).
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, scale=1.0, bias_scale=0.1):
+        bound = scale * math.sqrt(3.0 / cin)
+        sd[name + ".weight"] = (torch.rand(cout, cin, 1, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bias_scale
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    chans = [3, 32, 64, 128, 256, 256]
+    for i in range(1, len(chans)):
+        last = i == len(chans) - 1
+        conv(f"kenc.encoder.{3 * (i - 1)}", chans[i], chans[i - 1], scale=(0.05 if structured else 1.0) if last else 1.4)
+        if last:
+            sd[f"kenc.encoder.{3 * (i - 1)}.bias"].zero_()  # nn.init.constant_(encoder[-1].bias, 0)
+            if structured:  # ReLU features have a positive mean: zero-mean rows avoid a common-mode offset
+                w = sd[f"kenc.encoder.{3 * (i - 1)}.weight"]
+                sd[f"kenc.encoder.{3 * (i - 1)}.weight"] = w - w.mean(dim=1, keepdim=True)
+        else:
+            bn(f"kenc.encoder.{3 * (i - 1) + 1}", chans[i])
+    for i in range(18):
+        p = f"gnn.layers.{i}."
+        conv(p + "attn.merge", 256, 256)
+        for j in range(3):
+            conv(p + f"attn.proj.{j}", 256, 256, scale=6.0 if (structured and j < 2) else 1.0)
+        conv(p + "mlp.0", 512, 512, scale=1.4)
+        bn(p + "mlp.1", 512)
+        conv(p + "mlp.3", 256, 512, scale=0.08 if structured else 1.0)
+        if structured:
+            w = sd[p + "mlp.3.weight"]
+            sd[p + "mlp.3.weight"] = w - w.mean(dim=1, keepdim=True)
+        sd[p + "mlp.3.bias"].zero_()  # nn.init.constant_(mlp[-1].bias, 0)
+    conv("final_proj", 256, 256, scale=2.0 if structured else 4.0)
+    if structured:
+        sd["final_proj.weight"] = sd["final_proj.weight"] + 4.0 * math.sqrt(60.0) * torch.eye(256)[:, :, None]
+    sd["bin_score"] = torch.tensor(35.0 if structured else 1.0)  # above the best random-column score of an outlier
+    return sd

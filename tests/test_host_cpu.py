@@ -168,3 +168,90 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(ll, "_lib", None)
     with pytest.raises(ll.ImcuiHipError):
         ll.load_library(str(tmp_path / "nope.so"))
+
+
+def _sg_layout_offsets():
+    """Python mirror of csrc/superglue.hip sg_layout() (f32 region only)."""
+    off = 0
+
+    def take(n):
+        nonlocal off
+        r = off
+        off += (n + 63) // 64 * 64
+        return r
+
+    kenc = [3, 32, 64, 128, 256, 256]
+    lay = {"k0": take(32 * 4), "kw": [], "kb": [], "L": []}
+    for i in range(4):
+        lay["kw"].append(take(kenc[i + 2] * kenc[i + 1]))
+        lay["kb"].append(take(kenc[i + 2]))
+    for _ in range(18):
+        lay["L"].append({k: take(n) for k, n in [("wqkv", 768 * 256), ("bqkv", 768), ("w1", 512 * 512), ("b1", 512), ("w2", 256 * 512), ("b2", 256)]})
+    lay["wfinal"], lay["bfinal"], lay["bin"] = take(256 * 256), take(256), take(64)
+    return lay
+
+
+def test_superglue_packing_folds_bn_merge_and_heads(lib):
+    """The packed SuperGlue weights (BatchNorm and attn.merge folded, heads de-interleaved) evaluated with plain
+    torch reproduce the oracle: checks the host packer without a GPU."""
+    from imcui_hip import backend
+    from oracle.superglue import SuperGlueOracle, log_optimal_transport, normalize_keypoints
+    from oracle.weights import superglue_state_dict
+
+    torch.set_num_threads(4)
+    sd = superglue_state_dict(3)
+    names = backend.superglue_tensor_names()
+    assert len(names) == 26 + 16 * 18 + 3 and names[0] == "kenc.encoder.0.weight" and names[-1] == "bin_score"
+    assert set(names) == {k for k in sd if not k.endswith("num_batches_tracked")}
+    P = backend.pack_superglue(sd)
+    lay = _sg_layout_offsets()
+    g = torch.Generator().manual_seed(0)
+    n0, n1 = 150, 170
+    k0 = torch.rand(1, n0, 2, generator=g) * torch.tensor([640.0, 480.0])
+    k1 = torch.rand(1, n1, 2, generator=g) * torch.tensor([640.0, 480.0])
+    d0 = torch.nn.functional.normalize(torch.randn(1, 256, n0, generator=g), dim=1)
+    d1 = torch.nn.functional.normalize(torch.cat([d0[:, :, :100] + 0.05 * torch.randn(1, 256, 100, generator=g), torch.randn(1, 256, n1 - 100, generator=g)], 2), dim=1)
+    s0, s1 = torch.rand(1, n0, generator=g), torch.rand(1, n1, generator=g)
+    img = torch.zeros(1, 1, 480, 640)
+    data = {"image0": img, "image1": img, "keypoints0": k0, "keypoints1": k1, "scores0": s0, "scores1": s1, "descriptors0": d0, "descriptors1": d1}
+    ref = SuperGlueOracle(sd, {"sinkhorn_iterations": 20})(data)
+
+    def mat(off, n, k):
+        return P[off : off + n * k].view(n, k).double()
+
+    def vec(off, n):
+        return P[off : off + n].double()
+
+    def enc(kp, sc, dsc):
+        kn = normalize_keypoints(kp, img.shape)[0].double()
+        w0 = mat(lay["k0"], 32, 4)
+        e = torch.relu(kn @ w0[:, :2].T + sc[0].double()[:, None] * w0[:, 2] + w0[:, 3])
+        dims = [32, 64, 128, 256, 256]
+        for i in range(4):
+            e = e @ mat(lay["kw"][i], dims[i + 1], dims[i]).T + vec(lay["kb"][i], dims[i + 1])
+            if i < 3:
+                e = torch.relu(e)
+        return dsc[0].T.double() + e
+
+    x = [enc(k0, s0, d0), enc(k1, s1, d1)]
+    for li, L in enumerate(lay["L"]):
+        qkv = [(xi @ mat(L["wqkv"], 768, 256).T + vec(L["bqkv"], 768)).view(-1, 3, 4, 64) for xi in x]
+        new = []
+        for a in range(2):
+            src = a ^ (li & 1)
+            q, k, v = qkv[a][:, 0], qkv[src][:, 1], qkv[src][:, 2]
+            att = torch.softmax(torch.einsum("nhd,mhd->hnm", q, k) / 8.0, -1)
+            ctx = torch.einsum("hnm,mhd->nhd", att, v).reshape(-1, 256)
+            hid = torch.relu(torch.cat([x[a], ctx], 1) @ mat(L["w1"], 512, 512).T + vec(L["b1"], 512))
+            new.append(x[a] + hid @ mat(L["w2"], 256, 512).T + vec(L["b2"], 256))
+        x = new
+    md = [xi @ mat(lay["wfinal"], 256, 256).T + vec(lay["bfinal"], 256) for xi in x]
+    scores = (md[0] @ md[1].T / 16.0)[None].float()
+    Z = log_optimal_transport(scores, P[lay["bin"]], 20)
+    mx = Z[:, :-1, :-1].max(2)
+    mutual = torch.arange(n0)[None] == Z[:, :-1, :-1].max(1).indices.gather(1, mx.indices)
+    ms = torch.where(mutual, mx.values.exp(), torch.zeros(()))
+    m0 = torch.where(mutual & (ms > 0.2), mx.indices, torch.tensor(-1))
+    assert (ref["matches0"] > -1).sum() > 60
+    assert torch.equal(m0, ref["matches0"])
+    assert (ms - ref["matching_scores0"]).abs().max().item() < 1e-4

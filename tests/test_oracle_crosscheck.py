@@ -167,3 +167,61 @@ def test_lightglue_oracle_vs_hf(dc, wc):
     assert torch.equal(matches[0, 1, :n1].long(), out["matches1"][0])
     assert (mscores[0, 0, :n0] - out["matching_scores0"][0]).abs().max().item() < 2e-5
     assert torch.equal(prune[0, 0, :n0].long(), out["prune0"][0].long())
+
+
+def _hf_superglue(sd, iters):
+    """HF keeps the heads contiguous (channel = head * 64 + d); upstream interleaves them (d * 4 + head)."""
+    from transformers import SuperGlueConfig, SuperGlueForKeypointMatching
+
+    hf = SuperGlueForKeypointMatching(SuperGlueConfig(sinkhorn_iterations=iters, matching_threshold=0.0)).eval()
+    m = {k: v for k, v in hf.state_dict().items() if k.startswith("keypoint_detector")}
+    perm = torch.tensor([d * 4 + h for h in range(4) for d in range(64)])  # HF channel -> upstream channel
+    for i in range(5):
+        src = f"kenc.encoder.{3 * i}"
+        dst = f"keypoint_encoder.encoder.{i}" + (".linear" if i < 4 else "")
+        m[dst + ".weight"], m[dst + ".bias"] = sd[src + ".weight"][:, :, 0], sd[src + ".bias"]
+        if i < 4:
+            for f in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+                m[f"keypoint_encoder.encoder.{i}.batch_norm.{f}"] = sd[f"kenc.encoder.{3 * i + 1}.{f}"]
+    for i in range(18):
+        p, q = f"gnn.layers.{i}.", f"gnn.layers.{i}."
+        for j, nm in enumerate(["query", "key", "value"]):
+            m[q + f"attention.self.{nm}.weight"] = sd[p + f"attn.proj.{j}.weight"][:, :, 0][perm]
+            m[q + f"attention.self.{nm}.bias"] = sd[p + f"attn.proj.{j}.bias"][perm]
+        m[q + "attention.output.dense.weight"] = sd[p + "attn.merge.weight"][:, :, 0][:, perm]
+        m[q + "attention.output.dense.bias"] = sd[p + "attn.merge.bias"]
+        m[q + "mlp.0.linear.weight"], m[q + "mlp.0.linear.bias"] = sd[p + "mlp.0.weight"][:, :, 0], sd[p + "mlp.0.bias"]
+        for f in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            m[q + f"mlp.0.batch_norm.{f}"] = sd[p + f"mlp.1.{f}"]
+        m[q + "mlp.1.weight"], m[q + "mlp.1.bias"] = sd[p + "mlp.3.weight"][:, :, 0], sd[p + "mlp.3.bias"]
+    m["final_projection.final_proj.weight"] = sd["final_proj.weight"][:, :, 0]
+    m["final_projection.final_proj.bias"] = sd["final_proj.bias"]
+    m["bin_score"] = sd["bin_score"]
+    hf.load_state_dict(m, strict=True)
+    return hf
+
+
+@pytest.mark.parametrize("iters", [5, 50])
+def test_superglue_oracle_vs_hf(iters):
+    """Same seeded weights through the restatement and through the independent HF port (equal key-point
+    counts: the HF port stacks the two images)."""
+    from oracle.superglue import SuperGlueOracle
+    from oracle.weights import superglue_state_dict
+
+    torch.set_num_threads(4)
+    sd = superglue_state_dict(0)
+    data = synthetic_matching_problem(11, 300, 300, 80)
+    g = torch.Generator().manual_seed(5)
+    data["scores0"], data["scores1"] = torch.rand(1, 300, generator=g), torch.rand(1, 300, generator=g)
+    out = SuperGlueOracle(sd, {"sinkhorn_iterations": iters, "match_threshold": 0.0})(data)
+    hf = _hf_superglue(sd, iters)
+    kp = torch.stack([data["keypoints0"], data["keypoints1"]], 1)
+    de = torch.stack([data["descriptors0"].transpose(1, 2), data["descriptors1"].transpose(1, 2)], 1)
+    sc = torch.stack([data["scores0"], data["scores1"]], 1)
+    with torch.no_grad():
+        matches, mscores, _, _ = hf._match_image_pair(kp, de, sc, 480, 640)
+    assert (out["matches0"][0] > -1).sum() > 150
+    assert torch.equal(matches[0, 0].long(), out["matches0"][0].long())
+    assert torch.equal(matches[0, 1].long(), out["matches1"][0].long())
+    assert (mscores[0, 0] - out["matching_scores0"][0]).abs().max().item() < 2e-5
+    assert (mscores[0, 1] - out["matching_scores1"][0]).abs().max().item() < 2e-5
