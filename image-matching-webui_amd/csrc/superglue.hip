@@ -24,6 +24,7 @@
 #define SG_LAYERS 18
 #define SG_HEADS 4
 #define SG_BN_EPS 1e-5  // nn.BatchNorm1d default
+#define SG_RBANDS 8     // row bands of the Sinkhorn column pass
 
 // ------------------------------------------------------------------ packed weights
 struct SgSplit {
@@ -210,7 +211,7 @@ extern "C" int imcui_hip_superglue_pack_weights(const float* const* t, float* pa
 
 // ------------------------------------------------------------------ workspace
 struct SgWs {
-    float *x, *ctx, *hbuf, *q, *k, *v, *one, *zero, *md, *sim, *u, *vv, *max0;
+    float *x, *ctx, *hbuf, *q, *k, *v, *one, *zero, *md, *sim, *u, *vv, *max0, *pm, *ps;
     int *cnt, *active, *m0, *m1;
     size_t total;
     bool ok;
@@ -233,6 +234,8 @@ static SgWs sg_carve(void* ws, size_t bytes, int B, int R) {
     w.u = a.get<float>((size_t)B * (R + 64));
     w.vv = a.get<float>((size_t)B * (R + 64));
     w.max0 = a.get<float>((size_t)B * R);
+    w.pm = a.get<float>((size_t)B * SG_RBANDS * R);  // column-pass partials (max, sum) per row band
+    w.ps = a.get<float>((size_t)B * SG_RBANDS * R);
     w.cnt = a.get<int>(2 * B);
     w.active = a.get<int>(B);
     w.m0 = a.get<int>((size_t)B * R);
@@ -356,21 +359,90 @@ __global__ __launch_bounds__(256) void sg_row_kernel(const float* __restrict__ s
     }
 }
 
-// Sinkhorn column pass: v_j = log_nu_j - logsumexp_i(Z_ij + u_i).  Block = 64 columns x 4 row groups; the last block
-// column (blockIdx.x == R / 64) is the dust-bin column.
-__global__ __launch_bounds__(256) void sg_col_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
-                                                     const int* __restrict__ active, int R, const float* __restrict__ binp,
-                                                     const float* __restrict__ u, float* __restrict__ v) {
-    __shared__ float sm[4][64], ss[4][64];
+// Sinkhorn column pass: v_j = log_nu_j - logsumexp_i(Z_ij + u_i), in two launches.
+// (1) partial statistics: block = 256 columns (one float4 per lane, a wave reads 1 KB of a row) x one band of rows,
+//     the four waves take interleaved rows, 8 rows in flight per lane.  A walk down 64-column strips (one 256-byte
+//     segment per row and wave) measured 0.8 - 2.1 TB/s; this shape streams like the row pass.
+// (2) merge of the SG_RBANDS band partials and the dust-bin row; the last block is the dust-bin column.
+__device__ __forceinline__ void lse_add8(Lse& a, const float (&x)[8]) {
+    const float cm = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+    if (cm == -INFINITY) return;
+    const float mn = fmaxf(a.m, cm);
+    a.s = a.s * expf(a.m - mn) + (((expf(x[0] - mn) + expf(x[1] - mn)) + (expf(x[2] - mn) + expf(x[3] - mn))) +
+                                  ((expf(x[4] - mn) + expf(x[5] - mn)) + (expf(x[6] - mn) + expf(x[7] - mn))));
+    a.m = mn;
+}
+__device__ __forceinline__ int sg_band_rows(int n0) { return (n0 + SG_RBANDS - 1) / SG_RBANDS; }
+
+__global__ __launch_bounds__(256) void sg_colpart_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                         const int* __restrict__ active, int R, const float* __restrict__ u,
+                                                         float* __restrict__ pm, float* __restrict__ ps) {
+    __shared__ float sm[4][256], ss[4][256];
+    const int b = blockIdx.z;
+    if (!active[b]) return;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    const int j0 = blockIdx.x * 256;
+    const int rb = sg_band_rows(n0), r0 = blockIdx.y * rb, r1 = min(n0, r0 + rb);
+    if (j0 >= n1 || r0 >= n0) return;
+    const int j = j0 + lane * 4;
+    const float* base = sim + (size_t)b * R * R + j;
+    const float* ub = u + (size_t)b * (R + 64);
+    Lse a[4] = {{-INFINITY, 0.0f}, {-INFINITY, 0.0f}, {-INFINITY, 0.0f}, {-INFINITY, 0.0f}};
+    if (j < n1)
+        for (int i = r0 + g; i < r1; i += 32) {
+            float4 z[8];
+            float uu[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool ok = i + 4 * t < r1;
+                z[t] = ok ? *reinterpret_cast<const float4*>(base + (size_t)(i + 4 * t) * R) : make_float4(0.f, 0.f, 0.f, 0.f);
+                uu[t] = ok ? ub[i + 4 * t] : -INFINITY;
+            }
+            float x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = z[t].x + uu[t];
+            lse_add8(a[0], x);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = z[t].y + uu[t];
+            lse_add8(a[1], x);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = z[t].z + uu[t];
+            lse_add8(a[2], x);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = z[t].w + uu[t];
+            lse_add8(a[3], x);
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sm[g][lane * 4 + c] = a[c].m;
+        ss[g][lane * 4 + c] = a[c].s;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (j0 + t < n1) {
+        Lse r = {sm[0][t], ss[0][t]};
+        for (int gg = 1; gg < 4; ++gg) lse_merge(r, sm[gg][t], ss[gg][t]);
+        const size_t o = ((size_t)b * SG_RBANDS + blockIdx.y) * R + j0 + t;
+        pm[o] = r.m;
+        ps[o] = r.s;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict__ cnt, const int* __restrict__ active, int R,
+                                                          const float* __restrict__ binp, const float* __restrict__ u,
+                                                          const float* __restrict__ pm, const float* __restrict__ ps,
+                                                          float* __restrict__ v) {
+    __shared__ float sm[4], ss[4];
     const int b = blockIdx.y;
     if (!active[b]) return;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
     const float alpha = binp[0];
     const float* ub = u + (size_t)b * (R + 64);
     const float norm = -logf((float)n0 + (float)n1);
-    if (blockIdx.x == R / 64) {
+    if (blockIdx.x == gridDim.x - 1) {
         // dust-bin column: logsumexp_i(alpha + u_i) over the n0 rows and the dust-bin row
+        const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
         Lse a = {-INFINITY, 0.0f};
         for (int i = threadIdx.x * 4; i <= n0; i += 1024)
             lse_add4(a, alpha + ub[i], (i + 1 <= n0) ? alpha + ub[i + 1] : -INFINITY, (i + 2 <= n0) ? alpha + ub[i + 2] : -INFINITY,
@@ -378,40 +450,28 @@ __global__ __launch_bounds__(256) void sg_col_kernel(const float* __restrict__ s
         const float M = wave_max(a.m);
         float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
         s = wave_sum(s);
-        if (c == 0) {
-            sm[g][0] = M;
-            ss[g][0] = s;
+        if (lane == 0) {
+            sm[g] = M;
+            ss[g] = s;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            Lse t = {sm[0][0], ss[0][0]};
-            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][0], ss[gg][0]);
+            Lse t = {sm[0], ss[0]};
+            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg], ss[gg]);
             v[(size_t)b * (R + 64) + n1] = (logf((float)n0) + norm) - (t.m + logf(t.s));
         }
         return;
     }
-    if (blockIdx.x * 64 >= n1) return;
-    const int j = blockIdx.x * 64 + c;
-    const float* base = sim + (size_t)b * R * R;
-    Lse a = {-INFINITY, 0.0f};
-    if (j < n1)
-        for (int i = g; i < n0; i += 32) {
-            // 8 independent loads per trip (a column walk is a dependent load chain otherwise)
-            float z[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) z[t] = (i + 4 * t < n0) ? base[(size_t)(i + 4 * t) * R + j] + ub[i + 4 * t] : -INFINITY;
-            lse_add4(a, z[0], z[1], z[2], z[3]);
-            lse_add4(a, z[4], z[5], z[6], z[7]);
-        }
-    sm[g][c] = a.m;
-    ss[g][c] = a.s;
-    __syncthreads();
-    if (g == 0 && j < n1) {
-        Lse t = {sm[0][c], ss[0][c]};
-        for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][c], ss[gg][c]);
-        lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
-        v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n1) return;
+    const int nbands = (n0 + sg_band_rows(n0) - 1) / sg_band_rows(n0);
+    Lse t = {-INFINITY, 0.0f};
+    for (int k = 0; k < nbands; ++k) {
+        const size_t o = ((size_t)b * SG_RBANDS + k) * R + j;
+        lse_merge(t, pm[o], ps[o]);
     }
+    lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
+    v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
 }
 
 // final log assignment of (i, j) exactly as the reference associates it: ((Z + u_i) + v_j) - norm
@@ -708,10 +768,13 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
         SGRUN(gemm_launch(h, g, stream));
     }
     // ---- log-domain Sinkhorn with dust-bins, then mutual arg-max + threshold
-    const dim3 rg(R / 4 + 1, B), cg(R / 64 + 1, B);
+    // (Running the rounds chunk-wise so that a chunk's matrices fit the 256 MB memory-side cache measured slower
+    // at every chunk size: the passes stream at HBM rate either way and small launches lose occupancy.)
+    const dim3 rg(R / 4 + 1, B), cpg(cdiv(R, 256), SG_RBANDS, B), cmg(cdiv(R, 256) + 1, B);
     for (int it = 0; it < sinkhorn_iterations; ++it) {
         hipLaunchKernelGGL(sg_row_kernel, rg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u);
-        hipLaunchKernelGGL(sg_col_kernel, cg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.u, w.vv);
+        hipLaunchKernelGGL(sg_colpart_kernel, cpg, blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.pm, w.ps);
+        hipLaunchKernelGGL(sg_colmerge_kernel, cmg, blk, 0, stream, w.cnt, w.active, R, P + l.bin, w.u, w.pm, w.ps, w.vv);
     }
     hipLaunchKernelGGL(sg_rowarg_kernel, dim3(R / 4, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.max0, w.m0);
     hipLaunchKernelGGL(sg_colarg_kernel, dim3(R / 64, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.m1);
