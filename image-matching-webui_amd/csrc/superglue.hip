@@ -24,7 +24,9 @@
 #define SG_LAYERS 18
 #define SG_HEADS 4
 #define SG_BN_EPS 1e-5  // nn.BatchNorm1d default
-#define SG_RBANDS 8     // row bands of the Sinkhorn column pass
+#define SG_RBANDS 8     // row bands of the Sinkhorn column pass (R > 2048)
+#define SGF_ROWS 16     // rows per block of the fused Sinkhorn round (R <= 2048)
+#define SGF_COLS 2048
 
 // ------------------------------------------------------------------ packed weights
 struct SgSplit {
@@ -234,8 +236,9 @@ static SgWs sg_carve(void* ws, size_t bytes, int B, int R) {
     w.u = a.get<float>((size_t)B * (R + 64));
     w.vv = a.get<float>((size_t)B * (R + 64));
     w.max0 = a.get<float>((size_t)B * R);
-    w.pm = a.get<float>((size_t)B * SG_RBANDS * R);  // column-pass partials (max, sum) per row band
-    w.ps = a.get<float>((size_t)B * SG_RBANDS * R);
+    const size_t nbmax = (R <= SGF_COLS) ? (size_t)R / SGF_ROWS : (size_t)SG_RBANDS;
+    w.pm = a.get<float>((size_t)B * nbmax * R);  // column-pass partials (max, sum) per row band
+    w.ps = a.get<float>((size_t)B * nbmax * R);
     w.cnt = a.get<int>(2 * B);
     w.active = a.get<int>(B);
     w.m0 = a.get<int>((size_t)B * R);
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void sg_row_kernel(const float* __restrict__ s
 // (1) partial statistics: block = 256 columns (one float4 per lane, a wave reads 1 KB of a row) x one band of rows,
 //     the four waves take interleaved rows, 8 rows in flight per lane.  A walk down 64-column strips (one 256-byte
 //     segment per row and wave) measured 0.8 - 2.1 TB/s; this shape streams like the row pass.
-// (2) merge of the SG_RBANDS band partials and the dust-bin row; the last block is the dust-bin column.
+// (2) merge of the band partials and the dust-bin row; the last block is the dust-bin column.
 __device__ __forceinline__ void lse_add8(Lse& a, const float (&x)[8]) {
     const float cm = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
     if (cm == -INFINITY) return;
@@ -429,20 +432,21 @@ __global__ __launch_bounds__(256) void sg_colpart_kernel(const float* __restrict
     }
 }
 
+// (2) merge: block = 64 columns x 4 groups of bands (fixed order inside a group and across groups)
 __global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict__ cnt, const int* __restrict__ active, int R,
                                                           const float* __restrict__ binp, const float* __restrict__ u,
                                                           const float* __restrict__ pm, const float* __restrict__ ps,
-                                                          float* __restrict__ v) {
-    __shared__ float sm[4], ss[4];
+                                                          float* __restrict__ v, int fused) {
+    __shared__ float sm[4][64], ss[4][64];
     const int b = blockIdx.y;
     if (!active[b]) return;
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const float alpha = binp[0];
     const float* ub = u + (size_t)b * (R + 64);
     const float norm = -logf((float)n0 + (float)n1);
     if (blockIdx.x == gridDim.x - 1) {
         // dust-bin column: logsumexp_i(alpha + u_i) over the n0 rows and the dust-bin row
-        const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
         Lse a = {-INFINITY, 0.0f};
         for (int i = threadIdx.x * 4; i <= n0; i += 1024)
             lse_add4(a, alpha + ub[i], (i + 1 <= n0) ? alpha + ub[i + 1] : -INFINITY, (i + 2 <= n0) ? alpha + ub[i + 2] : -INFINITY,
@@ -450,28 +454,164 @@ __global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict_
         const float M = wave_max(a.m);
         float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
         s = wave_sum(s);
-        if (lane == 0) {
-            sm[g] = M;
-            ss[g] = s;
+        if (c == 0) {
+            sm[g][0] = M;
+            ss[g][0] = s;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            Lse t = {sm[0], ss[0]};
-            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg], ss[gg]);
+            Lse t = {sm[0][0], ss[0][0]};
+            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][0], ss[gg][0]);
             v[(size_t)b * (R + 64) + n1] = (logf((float)n0) + norm) - (t.m + logf(t.s));
         }
         return;
     }
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n1) return;
-    const int nbands = (n0 + sg_band_rows(n0) - 1) / sg_band_rows(n0);
+    if (blockIdx.x * 64 >= n1) return;
+    const int j = blockIdx.x * 64 + c;
+    const int nbands = fused ? (n0 + SGF_ROWS - 1) / SGF_ROWS : (n0 + sg_band_rows(n0) - 1) / sg_band_rows(n0);
+    const size_t stride = fused ? (size_t)(R / SGF_ROWS) : (size_t)SG_RBANDS;
     Lse t = {-INFINITY, 0.0f};
-    for (int k = 0; k < nbands; ++k) {
-        const size_t o = ((size_t)b * SG_RBANDS + k) * R + j;
-        lse_merge(t, pm[o], ps[o]);
+    if (j < n1) {
+#pragma unroll 4
+        for (int k = g; k < nbands; k += 4) {
+            const size_t o = ((size_t)b * stride + k) * R + j;
+            lse_merge(t, pm[o], ps[o]);
+        }
     }
-    lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
-    v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
+    sm[g][c] = t.m;
+    ss[g][c] = t.s;
+    __syncthreads();
+    if (g == 0 && j < n1) {
+        for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][c], ss[gg][c]);
+        lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
+        v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
+    }
+}
+
+// Fused Sinkhorn round for R <= 2048 (one launch + the merge): a block owns SGF_ROWS rows of one pair, keeps them in
+// registers (2 rows x 32 columns per lane), computes its u_i from the staged v (row pass) and straight away the
+// column statistics of its band with the new u (column pass): the matrix is read from HBM once per round instead
+// of twice.  The last block of a pair (blockIdx.x == number of bands) is the dust-bin row.
+__global__ __launch_bounds__(512, 4) void sg_band_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
+                                                         const int* __restrict__ active, int R, const float* __restrict__ binp,
+                                                         const float* __restrict__ v, float* __restrict__ u,
+                                                         float* __restrict__ pm, float* __restrict__ ps) {
+    __shared__ float4 lds4[(8 * SGF_COLS + SGF_COLS + 64) / 4];
+    float* lm = reinterpret_cast<float*>(lds4);  // [8 waves][2048]: column maxima of a wave's rows, then its rescaled sums
+    float* lv = lm + 8 * SGF_COLS;               // [2048 + 64]: staged v (row pass), then the block's column maxima
+    const int b = blockIdx.y;
+    if (!active[b]) return;
+    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
+    const int nbands = (n0 + SGF_ROWS - 1) / SGF_ROWS;
+    if ((int)blockIdx.x > nbands) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float alpha = binp[0];
+    const float* vb = v + (size_t)b * (R + 64);
+    float* ub = u + (size_t)b * (R + 64);
+    const float norm = -logf((float)n0 + (float)n1);
+    for (int j = tid; j < SGF_COLS + 64; j += 512) lv[j] = (j <= n1) ? vb[j] : 0.0f;
+    __syncthreads();
+    if ((int)blockIdx.x == nbands) {
+        // dust-bin row: u = (log n1 + norm) - logsumexp_j(alpha + v_j), j = 0 .. n1 (dust-bin column included)
+        float mx = -INFINITY;
+        for (int j = tid; j <= n1; j += 512) mx = fmaxf(mx, alpha + lv[j]);
+        mx = wave_max(mx);
+        if (lane == 0) lm[w] = mx;
+        __syncthreads();
+        float M = lm[0];
+        for (int k = 1; k < 8; ++k) M = fmaxf(M, lm[k]);
+        float s = 0.0f;
+        for (int j = tid; j <= n1; j += 512) s += expf((alpha + lv[j]) - M);
+        s = wave_sum(s);
+        __syncthreads();
+        if (lane == 0) lm[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float S = lm[0];
+            for (int k = 1; k < 8; ++k) S += lm[k];
+            ub[n0] = (logf((float)n1) + norm) - (M + logf(S));
+        }
+        return;
+    }
+    const int i0 = blockIdx.x * SGF_ROWS + 2 * w;
+    const bool ok0 = i0 < n0, ok1 = i0 + 1 < n0;
+    const int nch = (n1 + 255) >> 8;
+    const float* p0 = sim + ((size_t)b * R + i0) * R + lane * 4;
+    const float NI = -INFINITY;
+    float4 z0[8], z1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k * 256 + lane * 4;
+        const bool in = (k < nch) && (j < R);
+        z0[k] = (in && ok0) ? *reinterpret_cast<const float4*>(p0 + k * 256) : make_float4(NI, NI, NI, NI);
+        z1[k] = (in && ok1) ? *reinterpret_cast<const float4*>(p0 + R + k * 256) : make_float4(NI, NI, NI, NI);
+        if (j + 0 >= n1) z0[k].x = NI, z1[k].x = NI;
+        if (j + 1 >= n1) z0[k].y = NI, z1[k].y = NI;
+        if (j + 2 >= n1) z0[k].z = NI, z1[k].z = NI;
+        if (j + 3 >= n1) z0[k].w = NI, z1[k].w = NI;
+    }
+    // ---- row pass: u_i = norm - logsumexp_j(Z_ij + v_j) (max, then sum of exp, like torch.logsumexp)
+    auto row_u = [&](const float4(&z)[8], int i) -> float {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(z[k].x + vj.x, z[k].y + vj.y), fmaxf(z[k].z + vj.z, z[k].w + vj.w)));
+        }
+        const float M = wave_max(mx);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
+            s += (expf((z[k].x + vj.x) - M) + expf((z[k].y + vj.y) - M)) + (expf((z[k].z + vj.z) - M) + expf((z[k].w + vj.w) - M));
+        }
+        s = wave_sum(s);
+        const float xb = alpha + lv[n1];  // dust-bin column
+        const float M2 = fmaxf(M, xb);
+        const float ui = norm - (M2 + logf(s * expf(M - M2) + expf(xb - M2)));
+        if (lane == 0) ub[i] = ui;
+        return ui;
+    };
+    const float u0 = ok0 ? row_u(z0, i0) : 0.0f;
+    const float u1 = ok1 ? row_u(z1, i0 + 1) : 0.0f;
+    // ---- column pass over the band: block maximum per column first (through LDS), then the sum of exp(x - max)
+    float* lmw = lm + w * SGF_COLS + lane * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<float4*>(lmw + k * 256) =
+            make_float4(fmaxf(z0[k].x + u0, z1[k].x + u1), fmaxf(z0[k].y + u0, z1[k].y + u1), fmaxf(z0[k].z + u0, z1[k].z + u1),
+                        fmaxf(z0[k].w + u0, z1[k].w + u1));
+    __syncthreads();  // every wave is also done with the staged v
+    float4 M4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
+#pragma unroll
+    for (int ww = 1; ww < 8; ++ww) {
+        const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
+        M4 = make_float4(fmaxf(M4.x, t.x), fmaxf(M4.y, t.y), fmaxf(M4.z, t.z), fmaxf(M4.w, t.w));
+    }
+    *reinterpret_cast<float4*>(lv + 4 * tid) = M4;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 MM = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
+        float4 r;  // a masked row / column is -inf: exp(-inf - MM) = 0; MM = -inf only for a masked column
+        r.x = (MM.x == NI) ? 0.0f : expf((z0[k].x + u0) - MM.x) + expf((z1[k].x + u1) - MM.x);
+        r.y = (MM.y == NI) ? 0.0f : expf((z0[k].y + u0) - MM.y) + expf((z1[k].y + u1) - MM.y);
+        r.z = (MM.z == NI) ? 0.0f : expf((z0[k].z + u0) - MM.z) + expf((z1[k].z + u1) - MM.z);
+        r.w = (MM.w == NI) ? 0.0f : expf((z0[k].w + u0) - MM.w) + expf((z1[k].w + u1) - MM.w);
+        *reinterpret_cast<float4*>(lmw + k * 256) = r;
+    }
+    __syncthreads();
+    float4 S4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
+#pragma unroll
+    for (int ww = 1; ww < 8; ++ww) {
+        const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
+        S4 = make_float4(S4.x + t.x, S4.y + t.y, S4.z + t.z, S4.w + t.w);
+    }
+    if (4 * tid < R) {
+        const size_t o = ((size_t)b * (R / SGF_ROWS) + blockIdx.x) * R + 4 * tid;
+        *reinterpret_cast<float4*>(pm + o) = M4;
+        *reinterpret_cast<float4*>(ps + o) = S4;
+    }
 }
 
 // final log assignment of (i, j) exactly as the reference associates it: ((Z + u_i) + v_j) - norm
@@ -770,11 +910,16 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
     // ---- log-domain Sinkhorn with dust-bins, then mutual arg-max + threshold
     // (Running the rounds chunk-wise so that a chunk's matrices fit the 256 MB memory-side cache measured slower
     // at every chunk size: the passes stream at HBM rate either way and small launches lose occupancy.)
-    const dim3 rg(R / 4 + 1, B), cpg(cdiv(R, 256), SG_RBANDS, B), cmg(cdiv(R, 256) + 1, B);
+    const bool fused = R <= SGF_COLS;
+    const dim3 rg(R / 4 + 1, B), cpg(cdiv(R, 256), SG_RBANDS, B), cmg(R / 64 + 1, B), bg(R / SGF_ROWS + 1, B);
     for (int it = 0; it < sinkhorn_iterations; ++it) {
-        hipLaunchKernelGGL(sg_row_kernel, rg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u);
-        hipLaunchKernelGGL(sg_colpart_kernel, cpg, blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.pm, w.ps);
-        hipLaunchKernelGGL(sg_colmerge_kernel, cmg, blk, 0, stream, w.cnt, w.active, R, P + l.bin, w.u, w.pm, w.ps, w.vv);
+        if (fused) {
+            hipLaunchKernelGGL(sg_band_kernel, bg, dim3(512), 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u, w.pm, w.ps);
+        } else {
+            hipLaunchKernelGGL(sg_row_kernel, rg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u);
+            hipLaunchKernelGGL(sg_colpart_kernel, cpg, blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.pm, w.ps);
+        }
+        hipLaunchKernelGGL(sg_colmerge_kernel, cmg, blk, 0, stream, w.cnt, w.active, R, P + l.bin, w.u, w.pm, w.ps, w.vv, fused ? 1 : 0);
     }
     hipLaunchKernelGGL(sg_rowarg_kernel, dim3(R / 4, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.max0, w.m0);
     hipLaunchKernelGGL(sg_colarg_kernel, dim3(R / 64, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.m1);

@@ -147,3 +147,20 @@ def test_superglue_full_size_replicas_are_identical():
         idx = torch.where(m0[b] > -1)[0]
         assert torch.equal(m1[b][v.long()].long(), idx)  # mutual consistency
         assert (ms0[b][idx] > 0.2).all() and (ms0[b] <= 1.0 + 1e-5).all()
+
+
+def test_superglue_more_than_2048_keypoints_uses_the_streaming_rounds():
+    """Above 2048 key-points per image the Sinkhorn rounds run as separate row / column passes (the fused
+    register-resident round covers R <= 2048): same parity bar."""
+    torch.set_num_threads(16)
+    p = _problem(77, 2100, 2060, 400)
+    k0, k1, s0, s1, d0, d1, n0, n1 = _batch([p])
+    model = _model(5)
+    out = model.forward_batched(k0.cuda(), k1.cuda(), s0.cuda(), s1.cuda(), d0.cuda(), d1.cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480))
+    torch.cuda.synchronize()
+    out = {k: v.cpu() for k, v in out.items()}
+    ref = _oracle(SuperGlueOracle(SSD, {"sinkhorn_iterations": 5, "match_threshold": 0.2}), p)
+    assert (ref["matches0"] > -1).sum() > 1000
+    assert (out["matching_scores0"][0, :2100] - ref["matching_scores0"][0]).abs().max().item() < 1e-4
+    assert torch.equal(out["matches0"][0, :2100].long(), ref["matches0"][0])
+    assert torch.equal(out["matches1"][0, :2060].long(), ref["matches1"][0])
