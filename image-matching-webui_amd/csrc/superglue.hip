@@ -309,6 +309,11 @@ __global__ __launch_bounds__(256) void sg_init_kernel(const float* __restrict__ 
     }
 }
 
+// exp() of the Sinkhorn passes: arguments are x - max <= 0, the terms that matter have |x| of a few units, so the
+// hardware 2^x (v_exp_f32 of x * log2 e, ~1e-6 relative here) replaces the ~12-instruction library expf: with two
+// exponentials per matrix element and round the library version made the fused round VALU-bound (200 us vs 100 us of
+// HBM time).
+__device__ __forceinline__ float sg_exp(float x) { return __expf(x); }
 // streaming log-sum-exp: running maximum m, sum s of exp(x - m)
 struct Lse {
     float m, s;
@@ -317,13 +322,13 @@ __device__ __forceinline__ void lse_add4(Lse& a, float x0, float x1, float x2, f
     const float cm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
     if (cm == -INFINITY) return;
     const float mn = fmaxf(a.m, cm);
-    a.s = a.s * expf(a.m - mn) + ((expf(x0 - mn) + expf(x1 - mn)) + (expf(x2 - mn) + expf(x3 - mn)));
+    a.s = a.s * sg_exp(a.m - mn) + ((sg_exp(x0 - mn) + sg_exp(x1 - mn)) + (sg_exp(x2 - mn) + sg_exp(x3 - mn)));
     a.m = mn;
 }
 __device__ __forceinline__ void lse_merge(Lse& a, float m, float s) {
     if (m == -INFINITY) return;
     const float mn = fmaxf(a.m, m);
-    a.s = a.s * expf(a.m - mn) + s * expf(m - mn);
+    a.s = a.s * sg_exp(a.m - mn) + s * sg_exp(m - mn);
     a.m = mn;
 }
 
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256) void sg_row_kernel(const float* __restrict__ s
                  (j + 3 < n1) ? z.w + vj.w : -INFINITY);
     }
     const float M = wave_max(a.m);
-    float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
+    float s = (a.m == -INFINITY) ? 0.0f : a.s * sg_exp(a.m - M);
     s = wave_sum(s);
     if (lane == 0) {
         Lse t = {M, s};
@@ -371,8 +376,8 @@ __device__ __forceinline__ void lse_add8(Lse& a, const float (&x)[8]) {
     const float cm = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
     if (cm == -INFINITY) return;
     const float mn = fmaxf(a.m, cm);
-    a.s = a.s * expf(a.m - mn) + (((expf(x[0] - mn) + expf(x[1] - mn)) + (expf(x[2] - mn) + expf(x[3] - mn))) +
-                                  ((expf(x[4] - mn) + expf(x[5] - mn)) + (expf(x[6] - mn) + expf(x[7] - mn))));
+    a.s = a.s * sg_exp(a.m - mn) + (((sg_exp(x[0] - mn) + sg_exp(x[1] - mn)) + (sg_exp(x[2] - mn) + sg_exp(x[3] - mn))) +
+                                  ((sg_exp(x[4] - mn) + sg_exp(x[5] - mn)) + (sg_exp(x[6] - mn) + sg_exp(x[7] - mn))));
     a.m = mn;
 }
 __device__ __forceinline__ int sg_band_rows(int n0) { return (n0 + SG_RBANDS - 1) / SG_RBANDS; }
@@ -432,12 +437,13 @@ __global__ __launch_bounds__(256) void sg_colpart_kernel(const float* __restrict
     }
 }
 
-// (2) merge: block = 64 columns x 4 groups of bands (fixed order inside a group and across groups)
-__global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict__ cnt, const int* __restrict__ active, int R,
+// (2) merge: block = 256 columns (float4 per thread) x 16 groups of bands (fixed order inside a group and across groups)
+#define SG_MG 16
+__global__ __launch_bounds__(64 * SG_MG) void sg_colmerge_kernel(const int* __restrict__ cnt, const int* __restrict__ active, int R,
                                                           const float* __restrict__ binp, const float* __restrict__ u,
                                                           const float* __restrict__ pm, const float* __restrict__ ps,
                                                           float* __restrict__ v, int fused) {
-    __shared__ float sm[4][64], ss[4][64];
+    __shared__ float sm[SG_MG][256], ss[SG_MG][256];
     const int b = blockIdx.y;
     if (!active[b]) return;
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
@@ -448,11 +454,11 @@ __global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict_
     if (blockIdx.x == gridDim.x - 1) {
         // dust-bin column: logsumexp_i(alpha + u_i) over the n0 rows and the dust-bin row
         Lse a = {-INFINITY, 0.0f};
-        for (int i = threadIdx.x * 4; i <= n0; i += 1024)
+        for (int i = threadIdx.x * 4; i <= n0; i += 256 * SG_MG)
             lse_add4(a, alpha + ub[i], (i + 1 <= n0) ? alpha + ub[i + 1] : -INFINITY, (i + 2 <= n0) ? alpha + ub[i + 2] : -INFINITY,
                      (i + 3 <= n0) ? alpha + ub[i + 3] : -INFINITY);
         const float M = wave_max(a.m);
-        float s = (a.m == -INFINITY) ? 0.0f : a.s * expf(a.m - M);
+        float s = (a.m == -INFINITY) ? 0.0f : a.s * sg_exp(a.m - M);
         s = wave_sum(s);
         if (c == 0) {
             sm[g][0] = M;
@@ -461,44 +467,76 @@ __global__ __launch_bounds__(256) void sg_colmerge_kernel(const int* __restrict_
         __syncthreads();
         if (threadIdx.x == 0) {
             Lse t = {sm[0][0], ss[0][0]};
-            for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][0], ss[gg][0]);
+            for (int gg = 1; gg < SG_MG; ++gg) lse_merge(t, sm[gg][0], ss[gg][0]);
             v[(size_t)b * (R + 64) + n1] = (logf((float)n0) + norm) - (t.m + logf(t.s));
         }
         return;
     }
-    if (blockIdx.x * 64 >= n1) return;
-    const int j = blockIdx.x * 64 + c;
+    if (blockIdx.x * 256 >= n1) return;
+    const int j = blockIdx.x * 256 + c * 4;  // four columns per thread
     const int nbands = fused ? (n0 + SGF_ROWS - 1) / SGF_ROWS : (n0 + sg_band_rows(n0) - 1) / sg_band_rows(n0);
     const size_t stride = fused ? (size_t)(R / SGF_ROWS) : (size_t)SG_RBANDS;
-    Lse t = {-INFINITY, 0.0f};
+    Lse t[4] = {{-INFINITY, 0.0f}, {-INFINITY, 0.0f}, {-INFINITY, 0.0f}, {-INFINITY, 0.0f}};
     if (j < n1) {
 #pragma unroll 4
-        for (int k = g; k < nbands; k += 4) {
+        for (int k = g; k < nbands; k += SG_MG) {
             const size_t o = ((size_t)b * stride + k) * R + j;
-            lse_merge(t, pm[o], ps[o]);
+            const float4 m4 = *reinterpret_cast<const float4*>(pm + o);
+            const float4 s4 = *reinterpret_cast<const float4*>(ps + o);
+            lse_merge(t[0], m4.x, s4.x);
+            lse_merge(t[1], m4.y, s4.y);
+            lse_merge(t[2], m4.z, s4.z);
+            lse_merge(t[3], m4.w, s4.w);
         }
     }
-    sm[g][c] = t.m;
-    ss[g][c] = t.s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sm[g][c * 4 + q] = t[q].m;
+        ss[g][c * 4 + q] = t[q].s;
+    }
     __syncthreads();
-    if (g == 0 && j < n1) {
-        for (int gg = 1; gg < 4; ++gg) lse_merge(t, sm[gg][c], ss[gg][c]);
-        lse_merge(t, alpha + ub[n0], 1.0f);  // dust-bin row
-        v[(size_t)b * (R + 64) + j] = norm - (t.m + logf(t.s));
+    const int jj = blockIdx.x * 256 + threadIdx.x;  // one column per thread for the final combine
+    if (threadIdx.x < 256 && jj < n1) {
+        Lse r = {sm[0][threadIdx.x], ss[0][threadIdx.x]};
+        for (int gg = 1; gg < SG_MG; ++gg) lse_merge(r, sm[gg][threadIdx.x], ss[gg][threadIdx.x]);
+        lse_merge(r, alpha + ub[n0], 1.0f);  // dust-bin row
+        v[(size_t)b * (R + 64) + jj] = norm - (r.m + logf(r.s));
     }
 }
 
-// Fused Sinkhorn round for R <= 2048 (one launch + the merge): a block owns SGF_ROWS rows of one pair, keeps them in
-// registers (2 rows x 32 columns per lane), computes its u_i from the staged v (row pass) and straight away the
-// column statistics of its band with the new u (column pass): the matrix is read from HBM once per round instead
-// of twice.  The last block of a pair (blockIdx.x == number of bands) is the dust-bin row.
+// Fused Sinkhorn round for R <= 2048 (one launch + the merge): a block owns SGF_ROWS rows of one pair at a time, keeps
+// them in registers (2 rows x 32 columns per lane), computes its u_i from the staged v (row pass) and straight away
+// the column statistics of the band with the new u (column pass): the matrix is read from HBM once per round
+// instead of twice.  One band per block, two 512-thread blocks per CU (124 VGPRs, 74 KB LDS); a persistent variant
+// that prefetched the next band into a second register set (194 VGPRs, one block per CU) measured 20 % slower.
+// Block index == number of bands is the dust-bin row.
+struct SgBandRows {
+    float4 z0[8], z1[8];
+};
+__device__ __forceinline__ void sg_band_load(SgBandRows& t, const float* __restrict__ simb, int R, int band, int w, int lane, int n0,
+                                             int n1) {
+    const float NI = -INFINITY;
+    const int i0 = band * SGF_ROWS + 2 * w;
+    const bool ok0 = i0 < n0, ok1 = i0 + 1 < n0;
+    const int nch = (n1 + 255) >> 8;
+    const float* p0 = simb + (size_t)i0 * R + lane * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k * 256 + lane * 4;
+        const bool in = (k < nch) && (j < R);
+        t.z0[k] = (in && ok0) ? *reinterpret_cast<const float4*>(p0 + k * 256) : make_float4(NI, NI, NI, NI);
+        t.z1[k] = (in && ok1) ? *reinterpret_cast<const float4*>(p0 + R + k * 256) : make_float4(NI, NI, NI, NI);
+    }
+}
+
 __global__ __launch_bounds__(512, 4) void sg_band_kernel(const float* __restrict__ sim, const int* __restrict__ cnt,
                                                          const int* __restrict__ active, int R, const float* __restrict__ binp,
                                                          const float* __restrict__ v, float* __restrict__ u,
                                                          float* __restrict__ pm, float* __restrict__ ps) {
     __shared__ float4 lds4[(8 * SGF_COLS + SGF_COLS + 64) / 4];
-    float* lm = reinterpret_cast<float*>(lds4);  // [8 waves][2048]: column maxima of a wave's rows, then its rescaled sums
+    float* lm = reinterpret_cast<float*>(lds4);  // [8 waves][2048]: column maxima of a wave's rows, then its sums
     float* lv = lm + 8 * SGF_COLS;               // [2048 + 64]: staged v (row pass), then the block's column maxima
+    float* lM = lv;
     const int b = blockIdx.y;
     if (!active[b]) return;
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
@@ -506,111 +544,113 @@ __global__ __launch_bounds__(512, 4) void sg_band_kernel(const float* __restrict
     if ((int)blockIdx.x > nbands) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float alpha = binp[0];
+    const float NI = -INFINITY;
+    const float* simb = sim + (size_t)b * R * R;
     const float* vb = v + (size_t)b * (R + 64);
     float* ub = u + (size_t)b * (R + 64);
     const float norm = -logf((float)n0 + (float)n1);
+    SgBandRows cur;
     for (int j = tid; j < SGF_COLS + 64; j += 512) lv[j] = (j <= n1) ? vb[j] : 0.0f;
     __syncthreads();
-    if ((int)blockIdx.x == nbands) {
-        // dust-bin row: u = (log n1 + norm) - logsumexp_j(alpha + v_j), j = 0 .. n1 (dust-bin column included)
-        float mx = -INFINITY;
-        for (int j = tid; j <= n1; j += 512) mx = fmaxf(mx, alpha + lv[j]);
-        mx = wave_max(mx);
-        if (lane == 0) lm[w] = mx;
-        __syncthreads();
-        float M = lm[0];
-        for (int k = 1; k < 8; ++k) M = fmaxf(M, lm[k]);
-        float s = 0.0f;
-        for (int j = tid; j <= n1; j += 512) s += expf((alpha + lv[j]) - M);
-        s = wave_sum(s);
-        __syncthreads();
-        if (lane == 0) lm[w] = s;
-        __syncthreads();
-        if (tid == 0) {
-            float S = lm[0];
-            for (int k = 1; k < 8; ++k) S += lm[k];
-            ub[n0] = (logf((float)n1) + norm) - (M + logf(S));
+    {
+        const int band = blockIdx.x;
+        if (band == nbands) {
+            // dust-bin row: u = (log n1 + norm) - logsumexp_j(alpha + v_j), j = 0 .. n1 (dust-bin column included)
+            float mx = -INFINITY;
+            for (int j = tid; j <= n1; j += 512) mx = fmaxf(mx, alpha + lv[j]);
+            mx = wave_max(mx);
+            if (lane == 0) lm[w] = mx;
+            __syncthreads();
+            float M = lm[0];
+            for (int k = 1; k < 8; ++k) M = fmaxf(M, lm[k]);
+            float s = 0.0f;
+            for (int j = tid; j <= n1; j += 512) s += sg_exp((alpha + lv[j]) - M);
+            s = wave_sum(s);
+            __syncthreads();
+            if (lane == 0) lm[w] = s;
+            __syncthreads();
+            if (tid == 0) {
+                float S = lm[0];
+                for (int k = 1; k < 8; ++k) S += lm[k];
+                ub[n0] = (logf((float)n1) + norm) - (M + logf(S));
+            }
+            return;
         }
-        return;
-    }
-    const int i0 = blockIdx.x * SGF_ROWS + 2 * w;
-    const bool ok0 = i0 < n0, ok1 = i0 + 1 < n0;
-    const int nch = (n1 + 255) >> 8;
-    const float* p0 = sim + ((size_t)b * R + i0) * R + lane * 4;
-    const float NI = -INFINITY;
-    float4 z0[8], z1[8];
+        sg_band_load(cur, simb, R, band, w, lane, n0, n1);
+        const int i0 = band * SGF_ROWS + 2 * w;
+        const bool ok0 = i0 < n0, ok1 = i0 + 1 < n0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int j = k * 256 + lane * 4;
-        const bool in = (k < nch) && (j < R);
-        z0[k] = (in && ok0) ? *reinterpret_cast<const float4*>(p0 + k * 256) : make_float4(NI, NI, NI, NI);
-        z1[k] = (in && ok1) ? *reinterpret_cast<const float4*>(p0 + R + k * 256) : make_float4(NI, NI, NI, NI);
-        if (j + 0 >= n1) z0[k].x = NI, z1[k].x = NI;
-        if (j + 1 >= n1) z0[k].y = NI, z1[k].y = NI;
-        if (j + 2 >= n1) z0[k].z = NI, z1[k].z = NI;
-        if (j + 3 >= n1) z0[k].w = NI, z1[k].w = NI;
-    }
-    // ---- row pass: u_i = norm - logsumexp_j(Z_ij + v_j) (max, then sum of exp, like torch.logsumexp)
-    auto row_u = [&](const float4(&z)[8], int i) -> float {
-        float mx = -INFINITY;
+        for (int k = 0; k < 8; ++k) {  // columns >= n1 do not exist
+            const int j = k * 256 + lane * 4;
+            if (j + 0 >= n1) cur.z0[k].x = NI, cur.z1[k].x = NI;
+            if (j + 1 >= n1) cur.z0[k].y = NI, cur.z1[k].y = NI;
+            if (j + 2 >= n1) cur.z0[k].z = NI, cur.z1[k].z = NI;
+            if (j + 3 >= n1) cur.z0[k].w = NI, cur.z1[k].w = NI;
+        }
+        // ---- row pass: u_i = norm - logsumexp_j(Z_ij + v_j) (max, then sum of exp, like torch.logsumexp)
+        auto row_u = [&](const float4(&z)[8], int i) -> float {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
+                mx = fmaxf(mx, fmaxf(fmaxf(z[k].x + vj.x, z[k].y + vj.y), fmaxf(z[k].z + vj.z, z[k].w + vj.w)));
+            }
+            const float M = wave_max(mx);
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
+                s += (sg_exp((z[k].x + vj.x) - M) + sg_exp((z[k].y + vj.y) - M)) + (sg_exp((z[k].z + vj.z) - M) + sg_exp((z[k].w + vj.w) - M));
+            }
+            s = wave_sum(s);
+            const float xb = alpha + lv[n1];  // dust-bin column
+            const float M2 = fmaxf(M, xb);
+            const float ui = norm - (M2 + logf(s * sg_exp(M - M2) + sg_exp(xb - M2)));
+            if (lane == 0) ub[i] = ui;
+            return ui;
+        };
+        const float u0 = ok0 ? row_u(cur.z0, i0) : 0.0f;
+        const float u1 = ok1 ? row_u(cur.z1, i0 + 1) : 0.0f;
+        // ---- column pass over the band: block maximum per column first (through LDS), then the sum of exp(x - max)
+        float* lmw = lm + w * SGF_COLS + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // x = Z + u_i in place (a masked row / column stays -inf)
+            cur.z0[k].x += u0, cur.z0[k].y += u0, cur.z0[k].z += u0, cur.z0[k].w += u0;
+            cur.z1[k].x += u1, cur.z1[k].y += u1, cur.z1[k].z += u1, cur.z1[k].w += u1;
+            *reinterpret_cast<float4*>(lmw + k * 256) = make_float4(fmaxf(cur.z0[k].x, cur.z1[k].x), fmaxf(cur.z0[k].y, cur.z1[k].y),
+                                                                    fmaxf(cur.z0[k].z, cur.z1[k].z), fmaxf(cur.z0[k].w, cur.z1[k].w));
+        }
+        __syncthreads();
+        float4 M4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) {
+            const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
+            M4 = make_float4(fmaxf(M4.x, t.x), fmaxf(M4.y, t.y), fmaxf(M4.z, t.z), fmaxf(M4.w, t.w));
+        }
+        *reinterpret_cast<float4*>(lM + 4 * tid) = M4;
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
-            mx = fmaxf(mx, fmaxf(fmaxf(z[k].x + vj.x, z[k].y + vj.y), fmaxf(z[k].z + vj.z, z[k].w + vj.w)));
+            const float4 MM = *reinterpret_cast<const float4*>(lM + k * 256 + lane * 4);
+            float4 r;  // exp(-inf - MM) = 0 for a masked row; MM = -inf only for a masked column
+            r.x = (MM.x == NI) ? 0.0f : sg_exp(cur.z0[k].x - MM.x) + sg_exp(cur.z1[k].x - MM.x);
+            r.y = (MM.y == NI) ? 0.0f : sg_exp(cur.z0[k].y - MM.y) + sg_exp(cur.z1[k].y - MM.y);
+            r.z = (MM.z == NI) ? 0.0f : sg_exp(cur.z0[k].z - MM.z) + sg_exp(cur.z1[k].z - MM.z);
+            r.w = (MM.w == NI) ? 0.0f : sg_exp(cur.z0[k].w - MM.w) + sg_exp(cur.z1[k].w - MM.w);
+            *reinterpret_cast<float4*>(lmw + k * 256) = r;
         }
-        const float M = wave_max(mx);
-        float s = 0.0f;
+        __syncthreads();
+        float4 S4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 vj = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
-            s += (expf((z[k].x + vj.x) - M) + expf((z[k].y + vj.y) - M)) + (expf((z[k].z + vj.z) - M) + expf((z[k].w + vj.w) - M));
+        for (int ww = 1; ww < 8; ++ww) {
+            const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
+            S4 = make_float4(S4.x + t.x, S4.y + t.y, S4.z + t.z, S4.w + t.w);
         }
-        s = wave_sum(s);
-        const float xb = alpha + lv[n1];  // dust-bin column
-        const float M2 = fmaxf(M, xb);
-        const float ui = norm - (M2 + logf(s * expf(M - M2) + expf(xb - M2)));
-        if (lane == 0) ub[i] = ui;
-        return ui;
-    };
-    const float u0 = ok0 ? row_u(z0, i0) : 0.0f;
-    const float u1 = ok1 ? row_u(z1, i0 + 1) : 0.0f;
-    // ---- column pass over the band: block maximum per column first (through LDS), then the sum of exp(x - max)
-    float* lmw = lm + w * SGF_COLS + lane * 4;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        *reinterpret_cast<float4*>(lmw + k * 256) =
-            make_float4(fmaxf(z0[k].x + u0, z1[k].x + u1), fmaxf(z0[k].y + u0, z1[k].y + u1), fmaxf(z0[k].z + u0, z1[k].z + u1),
-                        fmaxf(z0[k].w + u0, z1[k].w + u1));
-    __syncthreads();  // every wave is also done with the staged v
-    float4 M4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
-#pragma unroll
-    for (int ww = 1; ww < 8; ++ww) {
-        const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
-        M4 = make_float4(fmaxf(M4.x, t.x), fmaxf(M4.y, t.y), fmaxf(M4.z, t.z), fmaxf(M4.w, t.w));
-    }
-    *reinterpret_cast<float4*>(lv + 4 * tid) = M4;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float4 MM = *reinterpret_cast<const float4*>(lv + k * 256 + lane * 4);
-        float4 r;  // a masked row / column is -inf: exp(-inf - MM) = 0; MM = -inf only for a masked column
-        r.x = (MM.x == NI) ? 0.0f : expf((z0[k].x + u0) - MM.x) + expf((z1[k].x + u1) - MM.x);
-        r.y = (MM.y == NI) ? 0.0f : expf((z0[k].y + u0) - MM.y) + expf((z1[k].y + u1) - MM.y);
-        r.z = (MM.z == NI) ? 0.0f : expf((z0[k].z + u0) - MM.z) + expf((z1[k].z + u1) - MM.z);
-        r.w = (MM.w == NI) ? 0.0f : expf((z0[k].w + u0) - MM.w) + expf((z1[k].w + u1) - MM.w);
-        *reinterpret_cast<float4*>(lmw + k * 256) = r;
-    }
-    __syncthreads();
-    float4 S4 = *reinterpret_cast<const float4*>(lm + 4 * tid);
-#pragma unroll
-    for (int ww = 1; ww < 8; ++ww) {
-        const float4 t = *reinterpret_cast<const float4*>(lm + ww * SGF_COLS + 4 * tid);
-        S4 = make_float4(S4.x + t.x, S4.y + t.y, S4.z + t.z, S4.w + t.w);
-    }
-    if (4 * tid < R) {
-        const size_t o = ((size_t)b * (R / SGF_ROWS) + blockIdx.x) * R + 4 * tid;
-        *reinterpret_cast<float4*>(pm + o) = M4;
-        *reinterpret_cast<float4*>(ps + o) = S4;
+        if (4 * tid < R) {
+            const size_t o = ((size_t)b * (R / SGF_ROWS) + band) * R + 4 * tid;
+            *reinterpret_cast<float4*>(pm + o) = M4;
+            *reinterpret_cast<float4*>(ps + o) = S4;
+        }
     }
 }
 
@@ -911,7 +951,7 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
     // (Running the rounds chunk-wise so that a chunk's matrices fit the 256 MB memory-side cache measured slower
     // at every chunk size: the passes stream at HBM rate either way and small launches lose occupancy.)
     const bool fused = R <= SGF_COLS;
-    const dim3 rg(R / 4 + 1, B), cpg(cdiv(R, 256), SG_RBANDS, B), cmg(R / 64 + 1, B), bg(R / SGF_ROWS + 1, B);
+    const dim3 rg(R / 4 + 1, B), cpg(cdiv(R, 256), SG_RBANDS, B), cmg(cdiv(R, 256) + 1, B), bg(R / SGF_ROWS + 1, B);
     for (int it = 0; it < sinkhorn_iterations; ++it) {
         if (fused) {
             hipLaunchKernelGGL(sg_band_kernel, bg, dim3(512), 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u, w.pm, w.ps);
@@ -919,7 +959,7 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
             hipLaunchKernelGGL(sg_row_kernel, rg, blk, 0, stream, w.sim, w.cnt, w.active, R, P + l.bin, w.vv, w.u);
             hipLaunchKernelGGL(sg_colpart_kernel, cpg, blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.pm, w.ps);
         }
-        hipLaunchKernelGGL(sg_colmerge_kernel, cmg, blk, 0, stream, w.cnt, w.active, R, P + l.bin, w.u, w.pm, w.ps, w.vv, fused ? 1 : 0);
+        hipLaunchKernelGGL(sg_colmerge_kernel, cmg, dim3(64 * SG_MG), 0, stream, w.cnt, w.active, R, P + l.bin, w.u, w.pm, w.ps, w.vv, fused ? 1 : 0);
     }
     hipLaunchKernelGGL(sg_rowarg_kernel, dim3(R / 4, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.max0, w.m0);
     hipLaunchKernelGGL(sg_colarg_kernel, dim3(R / 64, B), blk, 0, stream, w.sim, w.cnt, w.active, R, w.u, w.vv, w.m1);
