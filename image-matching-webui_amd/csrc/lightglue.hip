@@ -28,7 +28,7 @@ struct LgSplit {
 struct LgLayerOff {
     size_t wqkv, bqkv, wo, bo, w1s, b1s, gs, bs, w2s, b2s;
     size_t wx, bx, wto, bto, w1c, b1c, gc, bc, w2c, b2c;
-    LgSplit sqkv, so, s1s, s2s, sx, sto, s1c, s2c;
+    LgSplit sqkv, s1s, s2s, sx, s1c, s2c;  // out_proj / to_out are folded into ffn.0: no planes of their own
 };
 struct LgLayout {
     size_t wr;
@@ -86,11 +86,9 @@ static LgLayout lg_layout() {
     for (int i = 0; i < LG_LAYERS; ++i) {
         LgLayerOff& o = l.L[i];
         o.sqkv = take_split(768 * 256);
-        o.so = take_split(256 * 256);
         o.s1s = take_split(512 * 512);
         o.s2s = take_split(256 * 512);
         o.sx = take_split(512 * 256);
-        o.sto = take_split(256 * 256);
         o.s1c = take_split(512 * 512);
         o.s2c = take_split(256 * 512);
     }
@@ -218,11 +216,9 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
     for (int i = 0; i < LG_LAYERS; ++i) {
         const LgLayerOff& o = l.L[i];
         sp(o.sqkv, o.wqkv, 768, 256, 0);
-        sp(o.so, o.wo, 256, 256, 0);
         sp(o.s1s, o.w1s, 512, 512, 0);
         sp(o.s2s, o.w2s, 256, 512, 0);
         sp(o.sx, o.wx, 512, 256, 0);
-        sp(o.sto, o.wto, 256, 256, 0);
         sp(o.s1c, o.w1c, 512, 512, 0);
         sp(o.s2c, o.w2c, 256, 512, 0);
         sp(l.sfinal, l.wfinal + (size_t)i * 65536, 256, 256, i);
@@ -232,7 +228,7 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
 
 // ------------------------------------------------------------------ workspace
 struct LgWs {
-    float *x, *xt, *ctx, *msg, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls, *sim;
+    float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls, *sim;
     float *rmax, *rls, *cmax, *cls, *max0, *ms0;
     int *cntA, *cntB, *active, *ind, *indt, *pos, *prune, *m0, *m1, *valid0, *norig;
     size_t total;
@@ -246,7 +242,6 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.x = a.get<float>(rows * 256);
     w.xt = a.get<float>(rows * 256);
     w.ctx = a.get<float>(rows * 256);
-    w.msg = a.get<float>(rows * 256);
     w.hbuf = a.get<float>(rows * 512);
     w.q = a.get<float>(rows * 256);
     w.k = a.get<float>(rows * 256);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void lf_rowstat_kernel(const float* __restrict
         for (int u = 0; u < 8; ++u) v[u] = (j + 64 * u < S) ? row[j + 64 * u] : 0.0f;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (j + 64 * u < S) s += expf(v[u] - m);
+            if (j + 64 * u < S) s += __expf(v[u] - m);
     }
     s = wave_sum(s);
     if (lane == 0) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void lf_colstat_kernel(const float* __restrict
             for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < i1) ? base[(size_t)(i + 4 * u) * S + j] : 0.0f;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (i + 4 * u < i1) s += expf(v[u] - m);
+                if (i + 4 * u < i1) s += __expf(v[u] - m);
         }
     ss[g][c] = s;
     __syncthreads();
@@ -337,14 +337,18 @@ __global__ void lf_colstat_combine_kernel(const float* __restrict__ pmax, const 
     float s = 0.0f;
     for (int ch = 0; ch < LF_RCH; ++ch) {
         const float pm = pmax[((size_t)b * LF_RCH + ch) * S + j];
-        if (pm > -INFINITY) s += psum[((size_t)b * LF_RCH + ch) * S + j] * expf(pm - m);
+        if (pm > -INFINITY) s += psum[((size_t)b * LF_RCH + ch) * S + j] * __expf(pm - m);
     }
     cmax[(size_t)b * S + j] = m;
     csum[(size_t)b * S + j] = s;
 }
 // conf = softmax(sim, dim=1)[i,j] * softmax(sim, dim=2)[i,j]   (dim 1 = over i / L, dim 2 = over j / S)
+// The four passes over the 1.07 GB matrix evaluate one or two exponentials (and here two divisions) per element: with
+// the library expf and IEEE division they were VALU-bound at 2.3 - 3.2 TB/s.  Arguments are s - max <= 0, so the
+// hardware 2^x (v_exp_f32 of x * log2 e) and v_rcp_f32 (1 ulp each, ~1e-6 relative on conf) are used instead; every
+// pass calls this one function, so the mutual-maximum equality tests stay bit-consistent.
 __device__ __forceinline__ float lf_conf(float s, float cm, float cs, float rm, float rs) {
-    return (expf(s - cm) / cs) * (expf(s - rm) / rs);
+    return (__expf(s - cm) * __builtin_amdgcn_rcpf(cs)) * (__expf(s - rm) * __builtin_amdgcn_rcpf(rs));
 }
 // per row: max_j conf and the first j attaining it
 __global__ __launch_bounds__(256) void lf_rowbest_kernel(const float* __restrict__ sim, int L, int S,

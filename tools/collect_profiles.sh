@@ -4,22 +4,26 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
-# LG_ONLY=1: only the SuperPoint+LightGlue legs (use after a change that cannot affect LoFTR / the lab binaries)
+# LG_ONLY=1: only the SuperPoint+LightGlue legs (use after a change that cannot affect LoFTR / SuperGlue / the lab binaries)
+# SKIP_LABS=1: everything except the stand-alone lab programs (their output does not depend on the library)
 L=${LG_ONLY:-0}
+K=${SKIP_LABS:-$L}
 cd /tmp && export TMPDIR=/tmp
 ( cd $R && timeout 300 python bench.py > $O/bench_splg.json.log 2>&1; tail -1 $O/bench_splg.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024.json.log 2>&1; tail -1 $O/bench_loftr_1024.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload superpoint > $O/bench_superpoint.json.log 2>&1; tail -1 $O/bench_superpoint.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python bench.py --precision 0 --no-cpu-baseline > $O/bench_splg_f32.json.log 2>&1; tail -1 $O/bench_splg_f32.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload superglue > $O/bench_superglue.json.log 2>&1; tail -1 $O/bench_superglue.json.log | cut -c1-160 )
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_superglue -o superglue -- python $R/bench.py --workload superglue --steps 3 --warmup 1 > $O/rocprof_superglue.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 > $O/rocprof_loftr.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   echo pmc $c rc $?
 done
-[ $L = 1 ] || timeout 60 $R/tools/clock_lab > $O/lab_clock.txt 2>&1
-[ $L = 1 ] || timeout 60 $R/tools/overlap_lab > $O/lab_overlap.txt 2>&1
-[ $L = 1 ] || timeout 60 $R/tools/launch_lab > $O/lab_launch.txt 2>&1
+[ $K = 1 ] || timeout 60 $R/tools/clock_lab > $O/lab_clock.txt 2>&1
+[ $K = 1 ] || timeout 60 $R/tools/overlap_lab > $O/lab_overlap.txt 2>&1
+[ $K = 1 ] || timeout 60 $R/tools/launch_lab > $O/lab_launch.txt 2>&1
 ( cd $R && timeout 100 python bench.py --adaptive --no-cpu-baseline > $O/bench_splg_adaptive.json.log 2>&1; tail -1 $O/bench_splg_adaptive.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python bench.py --batch 1 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_splg_b1.json.log 2>&1; tail -1 $O/bench_splg_b1.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )

@@ -44,6 +44,10 @@ json.dump({"kernel": "attn_split_kernel", "source": f"profiles/{tag}_pmc_traffic
 for opt in ("adaptive", "b1"):  # operating points beside the headline line (collected when present)
     if os.path.exists(os.path.join(F, f"bench_splg_{opt}.json.log")):
         shutil.copy(os.path.join(F, f"bench_splg_{opt}.json.log"), os.path.join(P, f"{tag}_bench_splg_{opt}.json.log"))
+for src, dst in [("bench_superglue.json.log", f"{tag}_bench_superglue.json.log"),
+                 ("stats_superglue/superglue_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_superglue.csv")]:
+    if os.path.exists(os.path.join(F, src)):
+        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
 for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_loftr_1024.json.log", f"{tag}_bench_loftr_1024.json.log"),
                  ("bench_splg_f32.json.log", f"{tag}_bench_splg_f32.json.log"),
                  ("bench_superpoint.json.log", f"{tag}_bench_superpoint.json.log"),
