@@ -6,7 +6,7 @@
 // R = roundup(ncap, 128) rows: token row = seq * R + i.  Per-sequence valid counts live on the
 // device (`cnt`), per-pair `active` flags implement early stopping, and point pruning physically
 // compacts rows, so every kernel is launched for the worst case and skips dead tiles without any
-// host synchronisation.  All contractions run on the exact-f32 matrix instruction.
+// host synchronisation.  All contractions run on the matrix cores (gemm.h: exact f32 or 3 x f16 split).
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
