@@ -160,6 +160,24 @@ def test_plugins_follow_the_reference_seam(lib):
     nn_model = NN({})
     out = nn_model({"descriptors0": torch.zeros(1, 128, 5), "descriptors1": torch.zeros(1, 128, 0)})
     assert (out["matches0"] == -1).all()
+    # SuperGlue wrapper (imcui/hloc/matchers/superglue.py:14-29)
+    from oracle.weights import superglue_state_dict
+
+    SG = dynamic_load(matchers, "superglue")
+    assert issubclass(SG, BaseModel)
+    assert SG.default_conf == {"weights": "outdoor", "model_name": "superglue_outdoor.pth", "sinkhorn_iterations": 100, "match_threshold": 0.2}
+    assert SG.required_inputs == ["image0", "keypoints0", "scores0", "descriptors0", "image1", "keypoints1", "scores1", "descriptors1"]
+    sg = SG({"sinkhorn_iterations": 50, "state_dict": superglue_state_dict(0)})
+    assert sg.conf["sinkhorn_iterations"] == 50 and sg.conf["match_threshold"] == 0.2 and "state_dict" not in sg.conf
+    assert sum(b.numel() for b in sg.buffers()) >= 12_000_000  # ~12 M parameters + their split planes
+    img = torch.zeros(1, 1, 48, 64)
+    data = {"image0": img, "image1": img, "keypoints0": torch.zeros(1, 5, 2), "keypoints1": torch.zeros(1, 0, 2), "scores0": torch.zeros(1, 5),
+            "scores1": torch.zeros(1, 0), "descriptors0": torch.zeros(1, 256, 5), "descriptors1": torch.zeros(1, 256, 0)}  # fmt: skip
+    out = sg(data)  # no key-points: the upstream early return needs no GPU
+    assert out["matches0"].dtype == torch.int32 and (out["matches0"] == -1).all() and out["matches1"].shape == (1, 0)
+    data["keypoints1"], data["scores1"], data["descriptors1"] = torch.zeros(1, 4, 2), torch.zeros(1, 4), torch.zeros(1, 256, 4)
+    with pytest.raises(ImcuiHipError):
+        sg(data)  # CPU tensors: no fallback
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
