@@ -195,9 +195,9 @@ def bench_loftr(args, dev, rank, world):
 
 def bench_superglue(args, dev, rank, world):
     """SuperPoint + SuperGlue (matcher zoo entry `superglue`, imcui/hloc/configs/matchers.py:10-24: 50 Sinkhorn rounds) on
-    640x480 pairs; pairs/s, weak scaling (pairs are independent, no data-path collective)."""
+    640x480 pairs; pairs/s, weak scaling (pairs are independent; one all-gather of the match tables per step)."""
     from imcui_hip import backend
-    from imcui_hip.pipeline import SuperPointSuperGluePipeline
+    from imcui_hip.pipeline import SuperPointSuperGluePipeline, match_table
     from imcui_hip.synth import make_pair_batch
     from oracle.weights import superglue_state_dict, superpoint_state_dict  # seeded weights only
 
@@ -207,20 +207,28 @@ def bench_superglue(args, dev, rank, world):
     img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
     img0, img1 = img0.to(dev), img1.to(dev)
 
+    gathered = torch.empty((world * B, 3 + 2 * MAXK), dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        out = pipe(img0, img1)
+        if world > 1:  # the one exchange step of the path: all-gather of the match tables
+            dist.all_gather_into_tensor(gathered, match_table(out))
+        return out
+
     def timed(steps):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = pipe(img0, img1)
+            out = step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         return time.perf_counter() - t0, out
 
     for _ in range(args.warmup):
-        pipe(img0, img1)
+        step()
     backend.profile_enable(dev, True)
     dt, out = timed(args.steps)
     attn_ms, attn_n = backend.profile_read(dev, "attention")

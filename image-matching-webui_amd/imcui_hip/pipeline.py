@@ -80,5 +80,6 @@ def match_table(out: dict) -> torch.Tensor:
     """Fixed-stride per-pair record for the multi-GPU all-gather:
     int32 [B, 3 + 2*K]: n0, n1, stop, matches0[K], bit-cast matching_scores0[K]."""
     B, K = out["matches0"].shape
-    head = torch.stack([out["num_keypoints0"], out["num_keypoints1"], out["stop"]], 1).to(torch.int32)
+    stop = out["stop"] if "stop" in out else torch.zeros_like(out["num_keypoints0"])  # SuperGlue has no early exit
+    head = torch.stack([out["num_keypoints0"], out["num_keypoints1"], stop], 1).to(torch.int32)
     return torch.cat([head, out["matches0"].to(torch.int32), out["matching_scores0"].contiguous().view(torch.int32)], 1)

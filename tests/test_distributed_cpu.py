@@ -62,3 +62,20 @@ def test_gloo_world2_allgather(num_pairs):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (num_pairs, 3 + 32) for _, _, shape in res)
+
+
+def test_match_table_layout_with_and_without_stop():
+    """pipeline.match_table: int32 [B, 3 + 2K] = n0, n1, stop, matches0[K], bit-cast scores[K]; SuperGlue has no
+    early exit, its record carries stop = 0."""
+    import torch
+
+    from imcui_hip.pipeline import match_table
+
+    out = {"matches0": torch.tensor([[1, -1, 0], [2, 2, -1]], dtype=torch.int32), "matching_scores0": torch.tensor([[0.5, 0.0, 0.25], [1.0, 0.125, 0.0]]),
+           "num_keypoints0": torch.tensor([3, 2], dtype=torch.int32), "num_keypoints1": torch.tensor([2, 3], dtype=torch.int32)}  # fmt: skip
+    t = match_table(out)
+    assert t.dtype == torch.int32 and t.shape == (2, 9)
+    assert t[:, :3].tolist() == [[3, 2, 0], [2, 3, 0]] and t[:, 3:6].tolist() == [[1, -1, 0], [2, 2, -1]]
+    assert torch.equal(t[:, 6:].contiguous().view(torch.float32), out["matching_scores0"])
+    out["stop"] = torch.tensor([9, 4], dtype=torch.int32)
+    assert match_table(out)[:, 2].tolist() == [9, 4]
