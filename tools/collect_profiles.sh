@@ -24,6 +24,7 @@ done
 [ $K = 1 ] || timeout 60 $R/tools/clock_lab > $O/lab_clock.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/overlap_lab > $O/lab_overlap.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/launch_lab > $O/lab_launch.txt 2>&1
+[ $K = 1 ] || timeout 60 $R/tools/gridsync_lab > $O/lab_gridsync.txt 2>&1
 ( cd $R && timeout 100 python bench.py --adaptive --no-cpu-baseline > $O/bench_splg_adaptive.json.log 2>&1; tail -1 $O/bench_splg_adaptive.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python bench.py --batch 1 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_splg_b1.json.log 2>&1; tail -1 $O/bench_splg_b1.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )

@@ -54,7 +54,9 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("stats_splg/splg_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg.csv"),
                  ("stats_loftr/loftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_loftr_1024.csv"),
                  ("lab_clock.txt", "r01_lab_mfma_clock.txt"), ("lab_overlap.txt", "r01_lab_mfma_valu_overlap.txt"),
-                 ("lab_launch.txt", "r01_lab_workgroup_launch.txt")]:
+                 ("lab_launch.txt", "r01_lab_workgroup_launch.txt"), ("lab_gridsync.txt", "r01_lab_gridsync_barrier.txt")]:
+    if not os.path.exists(os.path.join(F, src)):
+        continue
     shutil.copy(os.path.join(F, src), os.path.join(P, dst))
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["fetch_bytes_per_launch"] * kv[1]["launches"])[:8]:
     print(f"{k[:50]:50s} n={v['launches']:4d} fetch {v['fetch_bytes_per_launch'] / 1e6:9.1f} MB write {v['write_bytes_per_launch'] / 1e6:9.1f} MB")
