@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
     ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint", "superglue"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
@@ -325,8 +326,14 @@ def main():
     img0, img1 = img0.to(dev), img1.to(dev)
     gathered = torch.empty((world * B, 3 + 2 * MAXK), dtype=torch.int32, device=dev) if world > 1 else None
 
+    run = pipe
+    if args.graph:
+        from imcui_hip.pipeline import GraphedPipeline
+
+        run = GraphedPipeline(pipe, img0, img1)
+
     def step():
-        out = pipe(img0, img1)
+        out = run(img0, img1)
         if world > 1:
             dist.all_gather_into_tensor(gathered, match_table(out))
         return out
@@ -393,7 +400,7 @@ def main():
             "config": {
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs resident in HBM",
                 "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, RCCL all-gather of match tables",
-                "lightglue_adaptive": bool(args.adaptive), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
+                "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
                 "weights": "seeded random (oracle/weights.py), real architecture",
             },
             "roofline": {

@@ -76,6 +76,39 @@ class SuperPointSuperGluePipeline(torch.nn.Module):
         }  # fmt: skip
 
 
+class GraphedPipeline:
+    """One forward of a pipeline captured in a HIP graph and replayed (fixed image shapes and batch size).
+
+    The batched path never synchronises with the host -- key-point counts, early stopping and point pruning live on
+    the device and every kernel is launched for the worst case -- so the whole extract + match step (~250 launches)
+    is capturable.  This is for the latency-bound small-batch case (the UI / API match one pair at a time); at the
+    bench batch the launches are already hidden.  The returned tensors are the graph's static outputs: consume or
+    copy them before the next call."""
+
+    def __init__(self, pipe: torch.nn.Module, image0: torch.Tensor, image1: torch.Tensor, warmup: int = 3):
+        self.pipe = pipe
+        self.image0, self.image1 = image0.clone(), image1.clone()
+        side = torch.cuda.Stream(device=image0.device)
+        side.wait_stream(torch.cuda.current_stream(image0.device))
+        with torch.cuda.stream(side):  # warm-up off the capture: workspaces reach their final size
+            for _ in range(warmup):
+                pipe(self.image0, self.image1)
+        torch.cuda.current_stream(image0.device).wait_stream(side)
+        torch.cuda.synchronize(image0.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = pipe(self.image0, self.image1)
+
+    @torch.no_grad()
+    def __call__(self, image0: torch.Tensor, image1: torch.Tensor) -> dict:
+        if image0.shape != self.image0.shape or image1.shape != self.image1.shape:
+            raise ValueError(f"graph was captured for {tuple(self.image0.shape)} / {tuple(self.image1.shape)}")
+        self.image0.copy_(image0)
+        self.image1.copy_(image1)
+        self.graph.replay()
+        return self.out
+
+
 def match_table(out: dict) -> torch.Tensor:
     """Fixed-stride per-pair record for the multi-GPU all-gather:
     int32 [B, 3 + 2*K]: n0, n1, stop, matches0[K], bit-cast matching_scores0[K]."""

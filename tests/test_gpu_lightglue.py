@@ -155,3 +155,30 @@ def test_pipeline_full_batch_replicas_are_identical():
     for b in range(B):
         idx = torch.nonzero(m0[b] >= 0).flatten()
         assert torch.equal(m1[b][m0[b][idx]], idx), "matches0 / matches1 are not mutual"
+
+
+def test_graph_replay_equals_eager_launches():
+    """The batched step has no host synchronisation (counts, early stop and pruning live on the device), so it can be
+    captured in a HIP graph; a replay on new inputs must reproduce the eager result bit for bit."""
+    from imcui_hip.pipeline import GraphedPipeline, SuperPointLightGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from oracle.weights import superpoint_state_dict
+
+    pipe = SuperPointLightGluePipeline(
+        {"nms_radius": 3, "max_keypoints": 512, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)},
+        {"depth_confidence": 0.95, "width_confidence": 0.99, "match_threshold": 0.1, "state_dict": LSD},
+    ).eval().to("cuda:0")
+    a0, a1, _ = make_pair_batch(5, 2, 240, 320, n_blobs=600)
+    b0, b1, _ = make_pair_batch(6, 2, 240, 320, n_blobs=600)
+    a0, a1, b0, b1 = a0.cuda(), a1.cuda(), b0.cuda(), b1.cuda()
+    eager_a = {k: v.clone() for k, v in pipe(a0, a1).items()}
+    eager_b = {k: v.clone() for k, v in pipe(b0, b1).items()}
+    g = GraphedPipeline(pipe, a0, a1)
+    for inp, ref in (((b0, b1), eager_b), ((a0, a1), eager_a)):
+        out = g(*inp)
+        torch.cuda.synchronize()
+        for k in ("num_keypoints0", "keypoints1", "descriptors0", "matches0", "matches1", "matching_scores0", "stop", "prune0"):
+            assert torch.equal(out[k], ref[k]), k
+    assert (eager_a["matches0"] > -1).sum() > 20
+    with pytest.raises(ValueError):
+        g(a0[:1], a1[:1])
