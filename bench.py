@@ -44,7 +44,7 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
     from imcui_hip.synth import make_pair
     from oracle.lightglue import LightGlueOracle
     from oracle.superpoint import SuperPointOracle
-    from oracle.weights import lightglue_state_dict, superpoint_state_dict
+    from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
 
     sp = SuperPointOracle(superpoint_state_dict(0))
     lg = LightGlueOracle(lightglue_state_dict(0), dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.1))
@@ -86,7 +86,7 @@ def bench_superpoint(args, dev, rank, world):
     from imcui_hip import backend
     from imcui_hip.hloc.extractors.superpoint import SuperPoint
     from imcui_hip.synth import make_pair_batch
-    from oracle.weights import superpoint_state_dict  # seeded weights only
+    from imcui_hip.synth_weights import superpoint_state_dict  # seeded weights only
 
     B = 2 * args.batch  # images per step per GPU (the pairs workload extracts 2 images per pair)
     model = SuperPoint({"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4,
@@ -124,7 +124,7 @@ def bench_superpoint(args, dev, rank, world):
             "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: SuperPoint (max 2048 kpts, nms 3, thr 0.005) on synthetic 640x480 images resident in HBM",
                        "images_per_step_per_gpu": B, "mean_keypoints": float(out["num_keypoints"].float().mean()),
-                       "weights": "seeded random (oracle/weights.py), real architecture"},
+                       "weights": "seeded random (imcui_hip/synth_weights.py), real architecture"},
             "roofline": {"kernel": "conv3x3_split_kernel (implicit-GEMM 3x3 convolutions)" if split else "conv3x3_kernel", "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                          "executed_tflops": achieved * (3.0 if split else 1.0),
@@ -143,7 +143,7 @@ def bench_loftr(args, dev, rank, world):
     from imcui_hip import backend
     from imcui_hip.hloc.matchers.loftr import LoFTR
     from imcui_hip.synth import make_pair
-    from oracle.weights import loftr_state_dict  # seeded weights only
+    from imcui_hip.synth_weights import loftr_state_dict  # seeded weights only
 
     Hh, Ww = args.size if args.size else (1024, 1024)
     B = args.batch if args.batch != 32 else 1
@@ -180,7 +180,7 @@ def bench_loftr(args, dev, rank, world):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
             "config": {"workload": f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM",
-                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), "weights": "seeded random (oracle/weights.py), kornia LoFTR architecture"},
+                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), "weights": "seeded random (imcui_hip/synth_weights.py), kornia LoFTR architecture"},
             "roofline": {"kernel": "gemm_split_kernel (convolutions as implicit-im2col GEMM)" if split else "gemm_kernel", "bound": "mfma",
                          "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": (tf_pair * B * args.steps / (gemm_ms * 1e-3) / (PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF)) if gemm_ms else 0.0,
@@ -199,7 +199,7 @@ def bench_superglue(args, dev, rank, world):
     from imcui_hip import backend
     from imcui_hip.pipeline import SuperPointSuperGluePipeline, match_table
     from imcui_hip.synth import make_pair_batch
-    from oracle.weights import superglue_state_dict, superpoint_state_dict  # seeded weights only
+    from imcui_hip.synth_weights import superglue_state_dict, superpoint_state_dict  # seeded weights only
 
     B = args.batch
     spc = {"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)}
@@ -259,7 +259,7 @@ def bench_superglue(args, dev, rank, world):
             "config": {"workload": "SuperPoint(max 2048 kpts, nms 3)+SuperGlue(18 layers, Sinkhorn) on synthetic 640x480 pairs resident in HBM",
                        "pairs_per_step_per_gpu": B, "sinkhorn_iterations": args.sinkhorn, "mean_keypoints": [nk0, nk1],
                        "mean_matches": float((out["matches0"] > -1).sum(1).float().mean()),
-                       "weights": "seeded random (oracle/weights.py), real architecture"},
+                       "weights": "seeded random (imcui_hip/synth_weights.py), real architecture"},
             "roofline": {"kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel", "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                          "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n},
@@ -306,7 +306,7 @@ def main():
     from imcui_hip import backend
     from imcui_hip.pipeline import SuperPointLightGluePipeline, match_table
     from imcui_hip.synth import make_pair_batch
-    from oracle.weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
+    from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
 
     backend.set_precision(dev, args.precision)
     if args.workload == "loftr":
@@ -401,7 +401,7 @@ def main():
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs resident in HBM",
                 "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, RCCL all-gather of match tables",
                 "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
-                "weights": "seeded random (oracle/weights.py), real architecture",
+                "weights": "seeded random (imcui_hip/synth_weights.py), real architecture",
             },
             "roofline": {
                 "kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel (f32 MFMA flash attention)",

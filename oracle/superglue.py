@@ -71,7 +71,7 @@ def log_optimal_transport(scores, alpha, iters: int):
 
 
 class SuperGlueOracle:
-    """state dict in the upstream layout (oracle/weights.py superglue_state_dict) -> callable(hloc dict)."""
+    """state dict in the upstream layout (imcui_hip/synth_weights.py superglue_state_dict) -> callable(hloc dict)."""
 
     def __init__(self, sd: dict, conf: dict | None = None):
         self.sd = {k: v.detach().float() if v.is_floating_point() else v for k, v in sd.items()}

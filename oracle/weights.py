@@ -1,283 +1,9 @@
-"""Seeded synthetic weights in the upstream state-dict layouts (oracle side).
-
-No checkpoint exists offline (weights come from the HF hub
-at `_init` time, imcui/hloc/extractors/superpoint.py:48-53,
-imcui/hloc/matchers/lightglue.py:39-51), so parity runs load the SAME seeded
-tensors into the oracle and into the HIP backend.  Key names/shapes follow
-SURVEY.md Appendix A.1 / A.2, so a real `superpoint_v1.pth` /
-`superpoint_lightglue.pth` state dict drops in unchanged.
-"""
-from __future__ import annotations
-
-import math
-
-import torch
-
-SP_LAYERS = [
-    # name, cout, cin, k
-    ("conv1a", 64, 1, 3),
-    ("conv1b", 64, 64, 3),
-    ("conv2a", 64, 64, 3),
-    ("conv2b", 64, 64, 3),
-    ("conv3a", 128, 64, 3),
-    ("conv3b", 128, 128, 3),
-    ("conv4a", 128, 128, 3),
-    ("conv4b", 128, 128, 3),
-    ("convPa", 256, 128, 3),
-    ("convPb", 65, 256, 1),
-    ("convDa", 256, 128, 3),
-    ("convDb", 256, 256, 1),
-]
-
-
-def superpoint_state_dict(seed: int = 0, peaky: bool = True) -> dict:
-    """Kaiming-scaled random SuperPoint weights (1 300 865 params).
-
-    `peaky=True` scales the detector logits (convPb) up and biases the dustbin
-    channel so the soft-max heat-map has many well separated peaks above the
-    0.005 threshold -- random heads otherwise give a near-uniform 1/65 map and
-    NMS / top-k are exercised degenerately (golden data (i)).
-    """
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-    for name, cout, cin, k in SP_LAYERS:
-        fan_in = cin * k * k
-        w = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / fan_in)
-        b = torch.randn(cout, generator=g) * 0.05
-        sd[f"{name}.weight"] = w
-        sd[f"{name}.bias"] = b
-    if peaky:
-        sd["convPb.weight"] = sd["convPb.weight"] * 6.0
-        sd["convPb.bias"][-1] += 2.0
-        # ReLU features have a large positive mean; centre the descriptor projection over
-        # its inputs so descriptors are not dominated by one common direction.
-        w = sd["convDb.weight"]
-        sd["convDb.weight"] = (w - w.mean(dim=1, keepdim=True)) * 3.0
-        sd["convDb.bias"] = -_mean_descriptor_logits(sd, g)
-    return sd
-
-
-def _mean_descriptor_logits(sd: dict, g: torch.Generator) -> torch.Tensor:
-    """Mean convDb pre-activation over a small noise image (used to centre descriptors)."""
-    import torch.nn.functional as F
-
-    x = torch.rand(1, 1, 96, 128, generator=g)
-    with torch.no_grad():
-        for name in ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convDa"):
-            x = F.relu(F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], padding=1))
-            if name in ("conv1b", "conv2b", "conv3b"):
-                x = F.max_pool2d(x, 2, 2)
-        y = F.conv2d(x, sd["convDb.weight"], None)
-    return y.mean(dim=(0, 2, 3))
-
-
-def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads: int = 4, structured: bool = True) -> dict:
-    """Random LightGlue weights in the upstream (new-style) key layout.
-
-    transformers.{i}.self_attn.{Wqkv,out_proj,ffn.0,ffn.1,ffn.3}
-    transformers.{i}.cross_attn.{to_qk,to_v,to_out,ffn.0,ffn.1,ffn.3}
-    log_assignment.{i}.{matchability,final_proj}, token_confidence.{i}.token.0,
-    posenc.Wr.weight
-
-    `structured=True` shapes the heads so the data-dependent control flow is
-    exercised non-degenerately with random transformer weights: residual updates are
-    damped, `final_proj` is a scaled identity + noise (true correspondences of
-    SuperPoint descriptors then win the dual soft-max), matchability logits spread
-    around +1 (a few points fall below the 1 - width_confidence prune threshold) and
-    the token-confidence bias rises with depth (pairs early-stop at varying layers).
-    """
-    g = torch.Generator().manual_seed(seed)
-
-    def lin(out_f, in_f, scale=1.0, bias=True, prefix=""):
-        bound = scale / math.sqrt(in_f)
-        d = {prefix + ".weight": (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound * math.sqrt(3.0)}
-        if bias:
-            d[prefix + ".bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * 0.1
-        return d
-
-    sd = {}
-    head_dim = dim // heads
-    # gamma = 1 -> std 1 upstream (nn.init.normal_(std=gamma**-2))
-    sd["posenc.Wr.weight"] = torch.randn(head_dim // 2, 2, generator=g)
-    damp = 0.03 if structured else 1.0
-    for i in range(n_layers):
-        p = f"transformers.{i}."
-        sd.update(lin(3 * dim, dim, scale=10.0 if structured else 1.0, prefix=p + "self_attn.Wqkv"))
-        sd.update(lin(dim, dim, prefix=p + "self_attn.out_proj"))
-        sd.update(lin(2 * dim, 2 * dim, prefix=p + "self_attn.ffn.0"))
-        sd[p + "self_attn.ffn.1.weight"] = 1.0 + (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd[p + "self_attn.ffn.1.bias"] = (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd.update(lin(dim, 2 * dim, scale=damp, prefix=p + "self_attn.ffn.3"))
-        if structured:  # zero-mean rows: no common-mode drift of the residual stream
-            w = sd[p + "self_attn.ffn.3.weight"]
-            sd[p + "self_attn.ffn.3.weight"] = w - w.mean(dim=1, keepdim=True)
-            sd[p + "self_attn.ffn.3.bias"] = sd[p + "self_attn.ffn.3.bias"] * 0.05
-        sd.update(lin(dim, dim, scale=10.0 if structured else 1.0, prefix=p + "cross_attn.to_qk"))
-        sd.update(lin(dim, dim, prefix=p + "cross_attn.to_v"))
-        sd.update(lin(dim, dim, prefix=p + "cross_attn.to_out"))
-        sd.update(lin(2 * dim, 2 * dim, prefix=p + "cross_attn.ffn.0"))
-        sd[p + "cross_attn.ffn.1.weight"] = 1.0 + (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd[p + "cross_attn.ffn.1.bias"] = (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd.update(lin(dim, 2 * dim, scale=damp, prefix=p + "cross_attn.ffn.3"))
-        if structured:
-            w = sd[p + "cross_attn.ffn.3.weight"]
-            sd[p + "cross_attn.ffn.3.weight"] = w - w.mean(dim=1, keepdim=True)
-            sd[p + "cross_attn.ffn.3.bias"] = sd[p + "cross_attn.ffn.3.bias"] * 0.05
-        q = f"log_assignment.{i}."
-        if structured:
-            sd.update(lin(1, dim, scale=48.0, prefix=q + "matchability"))  # logit std ~2.5 per unit |x|
-            sd[q + "matchability.bias"] = sd[q + "matchability.bias"] + 2.0
-            sd.update(lin(dim, dim, scale=2.0, prefix=q + "final_proj"))
-            sd[q + "final_proj.weight"] = sd[q + "final_proj.weight"] + 4.0 * math.sqrt(60.0) * torch.eye(dim)
-        else:
-            sd.update(lin(1, dim, prefix=q + "matchability"))
-            sd.update(lin(dim, dim, scale=4.0, prefix=q + "final_proj"))
-        if i < n_layers - 1:
-            t = f"token_confidence.{i}.token.0"
-            if structured:
-                sd.update(lin(1, dim, scale=12.0, prefix=t))  # logit std ~1 per unit |x|
-                sd[t + ".bias"] = sd[t + ".bias"] + 1.2 + 0.4 * i
-            else:
-                sd.update(lin(1, dim, scale=2.0, prefix=t))
-    return sd
-
-
-def loftr_state_dict(seed: int = 0, structured: bool = True) -> dict:
-    """Random LoFTR weights in kornia's state-dict layout (ResNetFPN_8_2 + coarse/fine transformers).
-
-    backbone.{conv1,bn1,layer{1,2,3}.{0,1}.{conv1,bn1,conv2,bn2[,downsample.{0,1}]},layer3_outconv,
-    layer2_outconv,layer2_outconv2.{0,1,3},layer1_outconv,layer1_outconv2.{0,1,3}},
-    loftr_coarse.layers.{0..7}.{q_proj,k_proj,v_proj,merge,mlp.0,mlp.2,norm1,norm2},
-    fine_preprocess.{down_proj,merge_feat}, loftr_fine.layers.{0,1}.*
-    `structured` damps the transformer updates so coarse features stay image-dependent and the
-    dual soft-max produces confident mutual matches with random weights.
-    """
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def conv(name, cout, cin, k, gain=1.0):
-        sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k)) * gain
-
-    def bn(name, c):
-        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
-        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
-        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
-        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
-        sd[name + ".num_batches_tracked"] = torch.tensor(0)
-
-    b = "backbone."
-    conv(b + "conv1", 128, 1, 7)
-    bn(b + "bn1", 128)
-    dims = [128, 128, 196, 256]
-    for li in range(1, 4):
-        cin, cout = dims[li - 1], dims[li]
-        for bi in range(2):
-            p = f"{b}layer{li}.{bi}"
-            c_in = cin if bi == 0 else cout
-            conv(p + ".conv1", cout, c_in, 3)
-            bn(p + ".bn1", cout)
-            conv(p + ".conv2", cout, cout, 3, gain=0.5)
-            bn(p + ".bn2", cout)
-            if bi == 0 and li > 1:
-                conv(p + ".downsample.0", cout, c_in, 1)
-                bn(p + ".downsample.1", cout)
-    conv(b + "layer3_outconv", 256, 256, 1)
-    if structured:
-        # x3 is post-ReLU and dominated by one common direction: project the mean feature of a small
-        # calibration image out of every row, then apply a gain, so that the coarse dual soft-max is
-        # driven by image content and produces confident mutual matches with random weights
-        from oracle.loftr import LoFTROracle
-
-        with torch.no_grad():
-            _, _, x3 = LoFTROracle(sd).encoder_stages(torch.rand(1, 1, 96, 128, generator=g))
-        m = x3.mean(dim=(0, 2, 3))
-        m = m / m.norm()
-        wc = sd[b + "layer3_outconv.weight"][:, :, 0, 0]
-        wc = wc - (wc @ m)[:, None] * m[None, :]
-        sd[b + "layer3_outconv.weight"] = (wc * 4.0)[:, :, None, None].contiguous()
-    conv(b + "layer2_outconv", 256, 196, 1)
-    conv(b + "layer2_outconv2.0", 256, 256, 3)
-    bn(b + "layer2_outconv2.1", 256)
-    conv(b + "layer2_outconv2.3", 196, 256, 3)
-    conv(b + "layer1_outconv", 196, 128, 1)
-    conv(b + "layer1_outconv2.0", 196, 196, 3)
-    bn(b + "layer1_outconv2.1", 196)
-    conv(b + "layer1_outconv2.3", 128, 196, 3)
-
-    def lin(name, out_f, in_f, gain=1.0, bias=False):
-        sd[name + ".weight"] = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * math.sqrt(3.0 / in_f) * gain
-        if bias:
-            sd[name + ".bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * 0.1
-
-    def encoder(prefix, n_layers, d):
-        for i in range(n_layers):
-            p = f"{prefix}.layers.{i}"
-            for nm in ("q_proj", "k_proj", "v_proj", "merge"):
-                lin(f"{p}.{nm}", d, d)
-            lin(f"{p}.mlp.0", 2 * d, 2 * d)
-            lin(f"{p}.mlp.2", d, 2 * d)
-            for nm in ("norm1", "norm2"):
-                sd[f"{p}.{nm}.weight"] = (0.25 if (structured and nm == "norm2") else 1.0) + 0.05 * torch.randn(d, generator=g)
-                sd[f"{p}.{nm}.bias"] = 0.02 * torch.randn(d, generator=g)
-
-    encoder("loftr_coarse", 8, 256)
-    lin("fine_preprocess.down_proj", 128, 256, bias=True)
-    lin("fine_preprocess.merge_feat", 128, 256, bias=True)
-    encoder("loftr_fine", 2, 128)
-    return sd
-
-
-def superglue_state_dict(seed: int = 0, structured: bool = True) -> dict:
-    """Random SuperGlue weights in the upstream (magicleap / Vincentqyw fork) state-dict layout:
-
-    kenc.encoder.{0,3,6,9,12}.{weight[out,in,1],bias}, kenc.encoder.{1,4,7,10}.{weight,bias,running_mean,
-    running_var,num_batches_tracked}, gnn.layers.{i}.attn.{merge,proj.0,proj.1,proj.2}.{weight,bias},
-    gnn.layers.{i}.mlp.{0,3}.{weight,bias}, gnn.layers.{i}.mlp.1.<BatchNorm>, final_proj.{weight,bias}, bin_score.
-
-    `structured` damps the residual updates and makes `final_proj` a scaled identity + noise, so the optimal
-    transport of random-weight features still resolves the true correspondences of distinctive descriptors
-    (mutual matches above `match_threshold`, the rest in the dust-bins).
-    """
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def conv(name, cout, cin, scale=1.0, bias_scale=0.1):
-        bound = scale * math.sqrt(3.0 / cin)
-        sd[name + ".weight"] = (torch.rand(cout, cin, 1, generator=g) * 2 - 1) * bound
-        sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bias_scale
-
-    def bn(name, c):
-        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
-        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
-        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
-        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
-        sd[name + ".num_batches_tracked"] = torch.tensor(0)
-
-    chans = [3, 32, 64, 128, 256, 256]
-    for i in range(1, len(chans)):
-        last = i == len(chans) - 1
-        conv(f"kenc.encoder.{3 * (i - 1)}", chans[i], chans[i - 1], scale=(0.05 if structured else 1.0) if last else 1.4)
-        if last:
-            sd[f"kenc.encoder.{3 * (i - 1)}.bias"].zero_()  # nn.init.constant_(encoder[-1].bias, 0)
-            if structured:  # ReLU features have a positive mean: zero-mean rows avoid a common-mode offset
-                w = sd[f"kenc.encoder.{3 * (i - 1)}.weight"]
-                sd[f"kenc.encoder.{3 * (i - 1)}.weight"] = w - w.mean(dim=1, keepdim=True)
-        else:
-            bn(f"kenc.encoder.{3 * (i - 1) + 1}", chans[i])
-    for i in range(18):
-        p = f"gnn.layers.{i}."
-        conv(p + "attn.merge", 256, 256)
-        for j in range(3):
-            conv(p + f"attn.proj.{j}", 256, 256, scale=6.0 if (structured and j < 2) else 1.0)
-        conv(p + "mlp.0", 512, 512, scale=1.4)
-        bn(p + "mlp.1", 512)
-        conv(p + "mlp.3", 256, 512, scale=0.08 if structured else 1.0)
-        if structured:
-            w = sd[p + "mlp.3.weight"]
-            sd[p + "mlp.3.weight"] = w - w.mean(dim=1, keepdim=True)
-        sd[p + "mlp.3.bias"].zero_()  # nn.init.constant_(mlp[-1].bias, 0)
-    conv("final_proj", 256, 256, scale=2.0 if structured else 4.0)
-    if structured:
-        sd["final_proj.weight"] = sd["final_proj.weight"] + 4.0 * math.sqrt(60.0) * torch.eye(256)[:, :, None]
-    sd["bin_score"] = torch.tensor(35.0 if structured else 1.0)  # above the best random-column score of an outlier
-    return sd
+"""Seeded synthetic weights for the oracle side: the generators live in imcui_hip/synth_weights.py (pure data
+generation, shared with bench.py / smoke so that checker and HIP path load identical tensors)."""
+from imcui_hip.synth_weights import (  # noqa: F401
+    SP_LAYERS,
+    lightglue_state_dict,
+    loftr_state_dict,
+    superglue_state_dict,
+    superpoint_state_dict,
+)

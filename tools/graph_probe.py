@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "image-matching-webui_amd"))
 from imcui_hip.pipeline import GraphedPipeline, SuperPointLightGluePipeline  # noqa: E402
 from imcui_hip.synth import make_pair_batch  # noqa: E402
-from oracle.weights import lightglue_state_dict, superpoint_state_dict  # noqa: E402  (seeded weights only)
+from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict  # noqa: E402  (seeded weights only)
 
 dev = torch.device("cuda:0")
 pipe = SuperPointLightGluePipeline(
