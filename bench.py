@@ -39,8 +39,13 @@ SUSTAINED_F16_MFMA_TF = 1800.0   # tools/clock_lab.hip on this chip: register-re
                                  # power-limited to ~1.82 GHz (2200 TF/s at 2.18 GHz with zero operands)
 
 
-def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
-    """Oracle (= restated reference CPU path) timed on this host, same workload, batch 1."""
+def cpu_baseline(max_seconds: float = 28.0, min_pairs: int = 10, max_pairs: int = 12):
+    """Oracle (= restated reference CPU path) timed on this host's cores, same workload.
+
+    Leg 1 is the reference's own operating point -- one pair per call (imcui/hloc/match_features.py:172-174 never
+    batches): median over >= 10 pairs after 2 warm-ups.  Leg 2 batches the extractor over 8 images (SURVEY.md section 8d
+    asks for it "for fairness"; LightGlue key-point sets are ragged, the oracle matches them pair by pair).  Bounded to
+    about half a minute of CPU work."""
     from imcui_hip.synth import make_pair
     from oracle.lightglue import LightGlueOracle
     from oracle.superpoint import SuperPointOracle
@@ -50,35 +55,53 @@ def cpu_baseline(max_seconds: float = 25.0, max_pairs: int = 6):
     lg = LightGlueOracle(lightglue_state_dict(0), dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.1))
     spc = dict(nms_radius=3, max_keypoints=MAXK, keypoint_threshold=0.005, remove_borders=4)
 
-    def one(seed):
-        i0, i1, _ = make_pair(seed, H, W)
-        f0, f1 = sp({"image": i0}, spc), sp({"image": i1}, spc)
-        lg({"image0": i0, "image1": i1, "keypoints0": f0["keypoints"][0][None], "keypoints1": f1["keypoints"][0][None],
-            "descriptors0": f0["descriptors"][0][None], "descriptors1": f1["descriptors"][0][None]})  # fmt: skip
+    def match(i0, i1, f0, f1, b0=0, b1=0):
+        lg({"image0": i0, "image1": i1, "keypoints0": f0["keypoints"][b0][None], "keypoints1": f1["keypoints"][b1][None],
+            "descriptors0": f0["descriptors"][b0][None], "descriptors1": f1["descriptors"][b1][None]})  # fmt: skip
+
+    def one(pair):
+        i0, i1 = pair
+        match(i0, i1, sp({"image": i0}, spc), sp({"image": i1}, spc))
 
     # pick the intra-op thread count that runs the oracle fastest on this host (oversubscribing a
     # many-core box is catastrophically slow); the count used is reported as `cores`
     ncpu = os.cpu_count() or 1
-    probe, _, _ = make_pair(99, H, W)
+    pairs = [make_pair(99 + i, H, W)[:2] for i in range(4)]
     best_t, best_dt = 1, float("inf")
     for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(t)
-        sp({"image": probe}, spc)
+        sp({"image": pairs[0][0]}, spc)
         t0 = time.perf_counter()
-        sp({"image": probe}, spc)
+        sp({"image": pairs[0][0]}, spc)
         d = time.perf_counter() - t0
         if d < best_dt:
             best_t, best_dt = t, d
     torch.set_num_threads(best_t)
-    one(0)  # warm-up
+    one(pairs[0])  # two warm-ups
+    one(pairs[1])
+    t_start = time.perf_counter()
+    times = []
+    while len(times) < max_pairs and (len(times) < min_pairs or (time.perf_counter() - t_start) < 0.6 * max_seconds):
+        t0 = time.perf_counter()
+        one(pairs[len(times) % 4])
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > max_seconds:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    # leg 2: the extractor on a batch of 8 images (4 pairs), matcher pair by pair
+    i0 = torch.cat([p[0] for p in pairs], 0)
+    i1 = torch.cat([p[1] for p in pairs], 0)
     t0 = time.perf_counter()
-    n = 0
-    while n < max_pairs and (time.perf_counter() - t0) < max_seconds:
-        one(1 + n)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} synthetic 640x480 pairs, batch 1, fp32, SuperPoint(2048 kpts)+LightGlue(9 layers, no early exit), torch {torch.__version__} CPU"}  # fmt: skip
+    f = sp({"image": torch.cat([i0, i1], 0)}, spc)
+    for b in range(4):
+        match(i0[b : b + 1], i1[b : b + 1], f, f, b, 4 + b)
+    b8 = 4 / (time.perf_counter() - t0)
+    return {"value": 1.0 / med, "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
+            "batched_extractor_value": b8,
+            "sample": f"median of {len(times)} synthetic 640x480 pairs after 2 warm-ups, one pair per call (the reference never batches), fp32, "
+                      f"SuperPoint(2048 kpts)+LightGlue(9 layers, no early exit), torch {torch.__version__} CPU, {torch.get_num_threads()} of {ncpu} host "
+                      f"CPUs (fastest of 8/16/32/64/128 threads); batched_extractor_value = same with SuperPoint on a batch of 8 images"}  # fmt: skip
 
 
 def bench_superpoint(args, dev, rank, world):
@@ -151,15 +174,27 @@ def bench_loftr(args, dev, rank, world):
     base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
     img1 = base[..., 8 : Hh + 8, 16 : Ww + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
-    for _ in range(args.warmup):
+    cap = B * (Hh // 8) * (Ww // 8)
+    gather = TableGather(world, cap + 1, 6, torch.float32, dev)
+
+    def step():
         out = model.forward_batched(img0, img1)
+        if world > 1:  # fixed-capacity match table of this rank's pairs: rows (x0, y0, x1, y1, conf, pair), last row = count
+            rows = torch.cat([out["keypoints0"], out["keypoints1"], out["confidence"][:, None], out["batch_indexes"].float()[:, None]], 1)
+            gather(torch.cat([rows, out["num_matches"].float().expand(1, 6)], 0))
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    gather.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     backend.profile_enable(dev, True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model.forward_batched(img0, img1)
+        out = step()
+    gather.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -207,12 +242,12 @@ def bench_superglue(args, dev, rank, world):
     img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
     img0, img1 = img0.to(dev), img1.to(dev)
 
-    gathered = torch.empty((world * B, 3 + 2 * MAXK), dtype=torch.int32, device=dev) if world > 1 else None
+    gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev)
 
     def step():
         out = pipe(img0, img1)
         if world > 1:  # the one exchange step of the path: all-gather of the match tables
-            dist.all_gather_into_tensor(gathered, match_table(out))
+            gather(match_table(out))
         return out
 
     def timed(steps):
@@ -222,6 +257,7 @@ def bench_superglue(args, dev, rank, world):
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
+        gather.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -274,6 +310,97 @@ def bench_superglue(args, dev, rank, world):
         dist.destroy_process_group()
 
 
+def rank_env(args):
+    """(rank, local_rank, world) from the launcher's environment; the rank count must be what --gpus asked for."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    return rank, local_rank, world
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run with one rank per
+    GPU (exactly the command line the driver uses for N > 1), forwarding every argument.  Rank 0 of the child job
+    prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]  # fmt: skip
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class TableGather:
+    """The one exchange step of the path: RCCL all-gather of the per-rank match tables, issued
+    asynchronously -- PyTorch runs the collective on its own communication stream behind the producing kernels, so the
+    compute stream goes straight on to the next batch; two receive buffers alternate and a buffer is only reused after
+    the collective that last wrote it has completed."""
+
+    def __init__(self, world: int, rows: int, stride: int, dtype, device):
+        self.world = world
+        self.bufs = [torch.empty((world * rows, stride), dtype=dtype, device=device) for _ in range(2)] if world > 1 else []
+        self.work = [None, None]
+        self.i = 0
+
+    def __call__(self, table: torch.Tensor):
+        if self.world == 1:
+            return table
+        j = self.i & 1
+        if self.work[j] is not None:
+            self.work[j].wait()
+        self.work[j] = dist.all_gather_into_tensor(self.bufs[j], table.contiguous(), async_op=True)
+        self.i += 1
+        return self.bufs[j]
+
+    def finish(self):
+        for w in self.work:
+            if w is not None:
+                w.wait()
+        self.work = [None, None]
+
+
+def launchcheck(args) -> None:
+    """CPU check of the launch / sharding / timing scaffold (tests/test_distributed_cpu.py): the same self-launch,
+    rank environment, barrier-bracketed timing, MAX-over-ranks and match-table all-gather as the GPU workloads, on the
+    gloo backend with a synthetic match table instead of HIP kernels.  Not a benchmark."""
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    rank, _, world = rank_env(args)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    B, K = 4, 64
+    gather = TableGather(world, B, 3 + 2 * K, torch.int32, "cpu")
+    table = torch.full((B, 3 + 2 * K), rank, dtype=torch.int32)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = gather(table)
+    gather.finish()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        assert got.shape[0] == world * B and all(int(got[r * B, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "launchcheck (no HIP work)", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "config": {"workload": "launchcheck", "parallelism": f"gloo x{world}"}}), flush=True)  # fmt: skip
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +410,7 @@ def main():
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint", "superglue"],
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
@@ -292,9 +419,11 @@ def main():
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload == "launchcheck":
+        return launchcheck(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    rank, local_rank, world = rank_env(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -302,6 +431,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from imcui_hip import backend
     from imcui_hip.pipeline import SuperPointLightGluePipeline, match_table
@@ -324,7 +454,7 @@ def main():
     torch.manual_seed(1234 + rank)
     img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
     img0, img1 = img0.to(dev), img1.to(dev)
-    gathered = torch.empty((world * B, 3 + 2 * MAXK), dtype=torch.int32, device=dev) if world > 1 else None
+    gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev)
 
     run = pipe
     if args.graph:
@@ -335,7 +465,7 @@ def main():
     def step():
         out = run(img0, img1)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, match_table(out))
+            gather(match_table(out))
         return out
 
     for _ in range(args.warmup):
@@ -348,6 +478,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    gather.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -399,7 +530,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs resident in HBM",
-                "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded x{world}, RCCL all-gather of match tables",
+                "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), async all-gather of match tables",
                 "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
                 "weights": "seeded random (imcui_hip/synth_weights.py), real architecture",
             },

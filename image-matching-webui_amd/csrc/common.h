@@ -115,6 +115,8 @@ struct imcui_hip_s {
     int prof_used[PROF_NCLS];
     int prof_alloc[PROF_NCLS];
     hipEvent_t* prof_ev[PROF_NCLS];  // pairs (start, stop)
+    float* lg_dump;  // parity-test hook (imcui_hip_lightglue_set_layer_dump): per-layer token states
+    size_t lg_dump_floats;
 };
 void imcui_prof_begin(imcui_hip_s* h, int cls, hipStream_t s);
 void imcui_prof_end(imcui_hip_s* h, int cls, hipStream_t s);

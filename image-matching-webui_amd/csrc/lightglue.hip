@@ -230,7 +230,7 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
 struct LgWs {
     float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls, *sim;
     float *rmax, *rls, *cmax, *cls, *max0, *ms0;
-    int *cntA, *cntB, *active, *ind, *indt, *pos, *prune, *m0, *m1, *valid0, *norig;
+    int *cntA, *cntB, *active, *ind, *indt, *pos, *prune, *m0, *m1, *valid0, *norig, *pflag;
     size_t total;
     bool ok;
 };
@@ -272,9 +272,17 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.m1 = a.get<int>((size_t)B * R);
     w.valid0 = a.get<int>((size_t)B * R);
     w.norig = a.get<int>(2 * B);
+    w.pflag = a.get<int>(2 * B);
     w.total = a.off;
     w.ok = a.ok;
     return w;
+}
+
+extern "C" int imcui_hip_lightglue_set_layer_dump(imcui_hip_t* h, float* dump, size_t floats) {
+    if (!h) return IMCUI_ERR_ARG;
+    h->lg_dump = dump;
+    h->lg_dump_floats = dump ? floats : 0;
+    return IMCUI_OK;
 }
 
 extern "C" size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap) {
@@ -398,8 +406,10 @@ __global__ __launch_bounds__(256) void lg_conf_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void lg_decide_kernel(const float* __restrict__ conf, const float* __restrict__ mtch,
                                                         const int* __restrict__ cnt_cur, int* __restrict__ cnt_next,
                                                         const int* __restrict__ norig, int* __restrict__ active,
-                                                        int* __restrict__ stop, int* __restrict__ pos, int R, int layer,
-                                                        int do_stop, int do_prune, float tau, float depth_conf,
+                                                        int* __restrict__ stop, int* __restrict__ pos,
+                                                        const int* __restrict__ ind, int* __restrict__ prune,
+                                                        int* __restrict__ pflag, int R, int layer, int do_stop,
+                                                        int do_prune, int prune_min, float tau, float depth_conf,
                                                         float keep_thr) {
     __shared__ int red[4];
     __shared__ int s_flag;
@@ -446,10 +456,19 @@ __global__ __launch_bounds__(256) void lg_decide_kernel(const float* __restrict_
         }
         return;
     }
+    // upstream prunes a side only while it holds more than pruning_keypoint_thresholds[device] points
+    // (cpu -1: always; cuda 1024; flash 1536): `if do_point_pruning and desc0.shape[-2] > pruning_th`
     int newc[2];
+    bool pruned[2];
     for (int s = 0; s < 2; ++s) {
         const int c = s ? c1 : c0;
         const size_t base = ((size_t)(2 * b + s)) * R;
+        pruned[s] = c > prune_min;
+        if (tid == 0) pflag[2 * b + s] = pruned[s] ? 1 : 0;
+        if (!pruned[s]) {
+            newc[s] = c;
+            continue;
+        }
         int run = 0;
         for (int i0 = 0; i0 < c; i0 += 256) {
             const int i = i0 + tid;
@@ -471,10 +490,21 @@ __global__ __launch_bounds__(256) void lg_decide_kernel(const float* __restrict_
         }
         newc[s] = run;
     }
+    if (newc[0] == 0 || newc[1] == 0) {
+        // a side lost all its points: upstream still bumps the prune counters of the rows each side kept
+        // (`prune0[:, ind0] += 1` runs before the loop breaks at the top of the next layer); the
+        // gather / copy-back kernels skip inactive pairs, so do it here (a thread re-reads its own pos[])
+        for (int s = 0; s < 2; ++s) {
+            if (!pruned[s]) continue;
+            const int c = s ? c1 : c0;
+            const size_t base = ((size_t)(2 * b + s)) * R;
+            for (int i = tid; i < c; i += 256)
+                if (pos[base + i] >= 0) prune[base + ind[base + i]] += 1;
+        }
+    }
     if (tid == 0) {
         if (newc[0] == 0 || newc[1] == 0) {
-            // a side lost all its points: upstream breaks at the top of the next layer
-            // ("no keypoints" result, stop = (layer + 1) + 1)
+            // upstream breaks at the top of the next layer ("no keypoints" result, stop = (layer + 1) + 1)
             active[b] = 0;
             stop[b] = layer + 2;
             cnt_next[2 * b] = 0;
@@ -515,11 +545,12 @@ __global__ __launch_bounds__(256) void lg_copyback_kernel(float* __restrict__ x,
                                                           int* __restrict__ ind, const int* __restrict__ indt,
                                                           int* __restrict__ prune, const int* __restrict__ cnt_cur,
                                                           const int* __restrict__ cnt_next,
-                                                          const int* __restrict__ active, int R, int do_prune) {
+                                                          const int* __restrict__ active,
+                                                          const int* __restrict__ pflag, int R, int do_prune) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.y;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (!do_prune || active[seq >> 1] == 0 || i >= cnt_next[seq]) return;
+    if (!do_prune || active[seq >> 1] == 0 || pflag[seq] == 0 || i >= cnt_next[seq]) return;
     const size_t row = (size_t)seq * R + i;
     const bool moved = cnt_next[seq] != cnt_cur[seq];
     if (moved) {
@@ -764,7 +795,8 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
                                            const float* keypoints1, const float* descriptors0,
                                            const float* descriptors1, const int* n0, const int* n1, float w0, float h0,
                                            float w1, float h1, double depth_confidence, double width_confidence,
-                                           double filter_threshold, int* matches0, int* matches1, float* mscores0,
+                                           int pruning_threshold, double filter_threshold, int* matches0, int* matches1,
+                                           float* mscores0,
                                            float* mscores1, int* stop, int* prune0, int* prune1, void* ws,
                                            size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -925,6 +957,14 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
         }
+        if (h->lg_dump) {  // parity-test hook: token states after this layer (rows in their current, pruned order)
+            const size_t nf = (size_t)S * R * 256;
+            if ((size_t)(layer + 1) * nf > h->lg_dump_floats)
+                return imcui_set_err(h, IMCUI_ERR_ARG, "lightglue: layer dump buffer too small (%zu < %zu floats)", h->lg_dump_floats,
+                                     (size_t)LG_LAYERS * nf);
+            if (hipMemcpyAsync(h->lg_dump + (size_t)layer * nf, w.x, nf * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return imcui_set_err(h, IMCUI_ERR_HIP, "lightglue: layer dump copy failed");
+        }
         if (layer == LG_LAYERS - 1) break;  // no early stopping or adaptive width at the last layer
         if (!do_stop && !do_prune) continue;
         // ---- a10: confidence, early stop, point pruning
@@ -933,12 +973,13 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
                            P + l.btoken + layer, P + l.wmatch + (size_t)layer * 256, P + l.bmatch + layer, cnt_cur, w.active,
                            R, w.conf, w.mtch);
         hipLaunchKernelGGL(lg_decide_kernel, dim3(B), blk, 0, stream, w.conf, w.mtch, cnt_cur, cnt_next, w.norig, w.active,
-                           stop, w.pos, R, layer, do_stop, do_prune, tau, depth_f, keep_thr);
+                           stop, w.pos, w.ind, w.prune, w.pflag, R, layer, do_stop, do_prune, pruning_threshold, tau, depth_f,
+                           keep_thr);
         if (do_prune) {
             hipLaunchKernelGGL(lg_gather_kernel, rowgrid, blk, 0, stream, w.x, w.xt, w.cs, w.sn, w.cst, w.snt, w.ind, w.indt,
                                w.prune, w.pos, cnt_cur, cnt_next, w.active, R);
             hipLaunchKernelGGL(lg_copyback_kernel, rowgrid, blk, 0, stream, w.x, w.xt, w.cs, w.sn, w.cst, w.snt, w.ind,
-                               w.indt, w.prune, cnt_cur, cnt_next, w.active, R, do_prune);
+                               w.indt, w.prune, cnt_cur, cnt_next, w.active, w.pflag, R, do_prune);
         }
         IMCUI_CHECK_LAUNCH(h);
         int* t = cnt_cur;

@@ -324,12 +324,14 @@ __global__ __launch_bounds__(256) void sp_compact_kernel(const float* __restrict
 // One block per image.  64-bit keys (score bits << 32 | ~index) are unique, so "the k largest
 // keys" is a well defined set: 8 rounds of 8-bit radix select find the k-th key, the winners are
 // gathered into LDS and bitonic-sorted descending.
-#define TOPK_MAX 8192
+// TOPK_MAX keys of 8 bytes = 128 KiB of the CU's 160 KiB LDS (dynamic allocation; the UI's max_keypoints slider
+// ends at 10000, imcui/ui/app_class.py).  Larger k is rejected on the host before the launch.
+#define TOPK_MAX 16384
 __global__ __launch_bounds__(1024) void sp_topk_kernel(const unsigned long long* __restrict__ cand, int cand_cap,
                                                        const int* __restrict__ ncand, int max_kpts, int kcap, int W,
                                                        float* __restrict__ kpts, float* __restrict__ scores,
                                                        int* __restrict__ nkpts, int* __restrict__ status) {
-    __shared__ unsigned long long sel[TOPK_MAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sel[];  // [roundup_pow2(min(max_kpts, TOPK_MAX))]
     __shared__ int hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k, s_nsel;
@@ -566,8 +568,8 @@ extern "C" int imcui_hip_superpoint_max_keypoints_bound(int H, int W, int nms_ra
 extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed, const float* image, int B, int H, int W,
                                             int nms_radius, float keypoint_threshold, int remove_borders,
                                             int max_keypoints, int fix_sampling, int kcap, float* keypoints,
-                                            float* scores, float* descriptors, int* num_keypoints, float* score_map,
-                                            void* ws, size_t ws_bytes, void* stream_) {
+                                            float* scores, float* descriptors, int* num_keypoints, int* status,
+                                            float* score_map, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!h) return IMCUI_ERR_ARG;
     if (B <= 0) return IMCUI_OK;
@@ -575,6 +577,9 @@ extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed,
         return imcui_set_err(h, IMCUI_ERR_ARG, "superpoint: H=%d W=%d must be positive multiples of 8", H, W);
     if (kcap <= 0 || !packed || !image || !keypoints || !scores || !descriptors || !num_keypoints)
         return imcui_set_err(h, IMCUI_ERR_ARG, "superpoint: null argument or kcap<=0");
+    if (max_keypoints > TOPK_MAX && (long)H * W > TOPK_MAX)
+        return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "superpoint: max_keypoints=%d exceeds the on-chip top-k sorter (%d); use -1 for all key-points",
+                             max_keypoints, TOPK_MAX);
     const int cand_cap = sp_cand_cap(H, W, nms_radius);
     SpWs s = sp_carve(ws, ws_bytes, B, H, W, cand_cap);
     if (!ws || !s.ok) return imcui_set_err(h, IMCUI_ERR_WS, "superpoint: workspace too small (%zu < %zu)", ws_bytes, s.total);
@@ -644,14 +649,23 @@ extern "C" int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed,
     // a4: NMS ; a5: select
     SPRUN(nms_launch(h, dense, s.nms, B, H, W, nms_radius, stream));
     const int nchunk = cdiv(H * W, SEL_CHUNK);
-    hipMemsetAsync(s.status, 0, sizeof(int), stream);
+    int* st = status ? status : s.status;
+    hipMemsetAsync(st, 0, sizeof(int), stream);
     hipLaunchKernelGGL(sp_count_kernel, dim3(nchunk, B), dim3(256), 0, stream, s.nms, H, W, keypoint_threshold,
                        remove_borders, s.blkcnt, nchunk);
     hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(64), 0, stream, s.blkcnt, s.blkoff, s.ncand, nchunk);
     hipLaunchKernelGGL(sp_compact_kernel, dim3(nchunk, B), dim3(256), 0, stream, s.nms, H, W, keypoint_threshold,
                        remove_borders, s.blkoff, nchunk, s.cand, cand_cap);
-    hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), 0, stream, s.cand, cand_cap, s.ncand, max_keypoints, kcap, W,
-                       keypoints, scores, num_keypoints, s.status);
+    {
+        int np2 = 1;
+        const int kmax = max_keypoints < 0 ? 1 : (max_keypoints < TOPK_MAX ? max_keypoints : TOPK_MAX);
+        while (np2 < kmax) np2 <<= 1;
+        const size_t smem = (size_t)np2 * sizeof(unsigned long long);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(TOPK_MAX * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), smem, stream, s.cand, cand_cap, s.ncand, max_keypoints, kcap, W,
+                           keypoints, scores, num_keypoints, st);
+    }
     IMCUI_CHECK_LAUNCH(h);
     // a6: descriptor head + sampling
     SPRUN(conv(LDA, s.feat, s.head, Hc, Wc, 0));

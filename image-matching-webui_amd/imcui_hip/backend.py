@@ -61,16 +61,36 @@ def _as_f32_host(t) -> np.ndarray:
 
 
 class _Workspace:
-    """Grow-only byte buffer on one device (caller-provided scratch of the C ABI)."""
+    """Caller-provided scratch of the C ABI: one grow-only byte buffer per (device, stream).
+
+    Kernels of one stream execute in order, so a buffer is only ever shared by launches that are ordered
+    anyway; two streams (two Gradio worker threads, a side stream) get separate buffers and cannot overwrite
+    each other's scratch while kernels are in flight.  A buffer that was handed out during a HIP-graph capture
+    is baked into that graph: it is pinned, and a later request that would have to re-allocate it raises
+    instead of freeing memory the graph still replays on."""
 
     def __init__(self):
-        self.buf: torch.Tensor | None = None
+        self._bufs: dict[tuple[int, int], torch.Tensor] = {}
+        self._pinned: set[tuple[int, int]] = set()
 
     def get(self, nbytes: int, device: torch.device) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
-            self.buf = None
-            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self.buf
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, torch.cuda.current_stream(device).cuda_stream)
+        capturing = torch.cuda.is_current_stream_capturing()
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if key in self._pinned:
+                raise ImcuiHipError(
+                    f"workspace of stream {key[1]:#x} is referenced by a captured HIP graph ({buf.numel()} B) and cannot grow to "
+                    f"{int(nbytes)} B: capture the graph after a warm-up at the largest shape, or run the larger call on another stream"
+                )
+            buf = None
+            self._bufs.pop(key, None)
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        if capturing:
+            self._pinned.add(key)
+        return buf
 
 
 # ------------------------------------------------------------------ SuperPoint
@@ -92,13 +112,20 @@ def pack_superpoint(state_dict: dict) -> torch.Tensor:
     return torch.from_numpy(packed)
 
 
+SP_TOPK_MAX = 16384  # on-chip top-k sorter of sp_topk_kernel (csrc/superpoint.hip)
+
+
 class SuperPointHIP:
     def __init__(self):
         self._ws = _Workspace()
         self._lock = threading.Lock()
 
-    def forward(self, packed: torch.Tensor, image: torch.Tensor, conf: dict, want_score_map: bool = False):
-        """image [B,1,H,W] float32 on the GPU.  Returns dict of fixed-stride tensors + counts."""
+    def forward(self, packed: torch.Tensor, image: torch.Tensor, conf: dict, want_score_map: bool = False, kcap: int | None = None):
+        """image [B,1,H,W] float32 on the GPU.  Returns dict of fixed-stride tensors + counts.
+
+        Never synchronises: `status` [1] int32 is the selection status word on the device (0 = fine; bit 1 =
+        `kcap` was too small, which only max_keypoints = -1 with exactly tied scores can cause) -- callers that
+        read `num_keypoints` on the host anyway (the ragged plugin path) read it in the same copy."""
         hd = get_handle(image.device)
         if packed.device != image.device:
             raise ImcuiHipError("packed weights and image live on different devices")
@@ -109,33 +136,27 @@ class SuperPointHIP:
             raise ImcuiHipError(f"SuperPoint expects a 1-channel image, got {Cc}")
         nms = int(conf["nms_radius"])
         maxk = int(conf["max_keypoints"])
-        bound = lib.imcui_hip_superpoint_max_keypoints_bound(H, W, nms)
-        kcap = bound if maxk < 0 else max(1, min(maxk, H * W))
+        if maxk > SP_TOPK_MAX and H * W > SP_TOPK_MAX:
+            raise ImcuiHipError(f"max_keypoints={maxk} exceeds the on-chip top-k sorter ({SP_TOPK_MAX}); use -1 to keep every key-point")
+        if kcap is None:
+            kcap = lib.imcui_hip_superpoint_max_keypoints_bound(H, W, nms) if maxk < 0 else max(1, min(maxk, H * W))
         dev = image.device
+        kpts = torch.empty((B, kcap, 2), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, kcap), dtype=torch.float32, device=dev)
+        desc = torch.empty((B, kcap, 256), dtype=torch.float32, device=dev)
+        nk = torch.empty((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((1,), dtype=torch.int32, device=dev)
+        smap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score_map else None
         with self._lock:
-            for attempt in range(2):
-                kpts = torch.empty((B, kcap, 2), dtype=torch.float32, device=dev)
-                scores = torch.empty((B, kcap), dtype=torch.float32, device=dev)
-                desc = torch.empty((B, kcap, 256), dtype=torch.float32, device=dev)
-                nk = torch.empty((B,), dtype=torch.int32, device=dev)
-                smap = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score_map else None
-                nbytes = lib.imcui_hip_superpoint_workspace_bytes(B, H, W, nms)
-                ws = self._ws.get(nbytes, dev)
-                with torch.cuda.device(dev):
-                    rc = lib.imcui_hip_superpoint_forward(
-                        hd.h, _ptr(packed), _ptr(image), B, H, W, nms, float(conf["keypoint_threshold"]),
-                        int(conf["remove_borders"]), maxk, int(bool(conf.get("fix_sampling", False))), kcap,
-                        _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(nk), _ptr(smap), _ptr(ws), ws.numel(), _stream_ptr(),
-                    )  # fmt: skip
-                    hd.check(rc, "imcui_hip_superpoint_forward")
-                    if maxk >= 0 or attempt == 1:
-                        break
-                    # max_keypoints = -1: the NMS bound can be exceeded only by exactly tied scores
-                    rc = lib.imcui_hip_superpoint_status(hd.h, B, H, W, nms, _ptr(ws), ws.numel(), _stream_ptr())
-                    if rc == 0:
-                        break
-                    kcap = H * W
-        out = {"keypoints": kpts, "scores": scores, "descriptors": desc, "num_keypoints": nk}
+            ws = self._ws.get(lib.imcui_hip_superpoint_workspace_bytes(B, H, W, nms), dev)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_superpoint_forward(
+                    hd.h, _ptr(packed), _ptr(image), B, H, W, nms, float(conf["keypoint_threshold"]),
+                    int(conf["remove_borders"]), maxk, int(bool(conf.get("fix_sampling", False))), kcap,
+                    _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(nk), _ptr(status), _ptr(smap), _ptr(ws), ws.numel(), _stream_ptr(),
+                )  # fmt: skip
+                hd.check(rc, "imcui_hip_superpoint_forward")
+        out = {"keypoints": kpts, "scores": scores, "descriptors": desc, "num_keypoints": nk, "status": status}
         if want_score_map:
             out["score_map"] = smap
         return out
@@ -185,8 +206,10 @@ class LightGlueHIP:
         self._lock = threading.Lock()
 
     def forward(self, packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, depth_confidence, width_confidence,
-                filter_threshold):  # fmt: skip
-        """kptsX [B,ncap,2], descX [B,ncap,256] (row per point), nX [B] int32 on the GPU; sizeX = (W, H)."""
+                filter_threshold, pruning_threshold: int = -1, layer_dump: bool = False):  # fmt: skip
+        """kptsX [B,ncap,2], descX [B,ncap,256] (row per point), nX [B] int32 on the GPU; sizeX = (W, H).
+        pruning_threshold: upstream pruning_keypoint_thresholds[device] (-1 = the CPU path: always prune).
+        layer_dump (parity tests): also return `_layers` [9, 2B, R, 256], the token states after every layer."""
         dev = kpts0.device
         hd = get_handle(dev)
         lib = hd.lib
@@ -213,20 +236,32 @@ class LightGlueHIP:
         stop = torch.empty((B,), dtype=torch.int32, device=dev)
         p0 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
         p1 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
+        dump = None
         with self._lock:
             ws = self._ws.get(lib.imcui_hip_lightglue_workspace_bytes(B, ncap), dev)
             with torch.cuda.device(dev):
-                rc = lib.imcui_hip_lightglue_forward(
-                    hd.h, _ptr(packed), B, ncap, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(n0), _ptr(n1),
-                    float(size0[0]), float(size0[1]), float(size1[0]), float(size1[1]),
-                    float(depth_confidence), float(width_confidence), float(filter_threshold),
-                    _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(stop), _ptr(p0), _ptr(p1), _ptr(ws), ws.numel(), _stream_ptr(),
-                )  # fmt: skip
+                if layer_dump:
+                    R = (ncap + 127) // 128 * 128
+                    dump = torch.zeros((9, 2 * B, R, 256), dtype=torch.float32, device=dev)
+                    hd.check(lib.imcui_hip_lightglue_set_layer_dump(hd.h, _ptr(dump), dump.numel()), "set_layer_dump")
+                try:
+                    rc = lib.imcui_hip_lightglue_forward(
+                        hd.h, _ptr(packed), B, ncap, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(n0), _ptr(n1),
+                        float(size0[0]), float(size0[1]), float(size1[0]), float(size1[1]),
+                        float(depth_confidence), float(width_confidence), int(pruning_threshold), float(filter_threshold),
+                        _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(stop), _ptr(p0), _ptr(p1), _ptr(ws), ws.numel(), _stream_ptr(),
+                    )  # fmt: skip
+                finally:
+                    if layer_dump:
+                        lib.imcui_hip_lightglue_set_layer_dump(hd.h, None, 0)
                 hd.check(rc, "imcui_hip_lightglue_forward")
-        return {
+        out = {
             "matches0": m0[:, :ncap0], "matches1": m1[:, :ncap1], "matching_scores0": s0[:, :ncap0],
             "matching_scores1": s1[:, :ncap1], "stop": stop, "prune0": p0[:, :ncap0], "prune1": p1[:, :ncap1],
         }  # fmt: skip
+        if dump is not None:
+            out["_layers"] = dump
+        return out
 
 
 # ------------------------------------------------------------------ SuperGlue
@@ -397,7 +432,11 @@ class LoFTRHIP:
         hd = get_handle(dev)
         lib = hd.lib
         if image0.shape != image1.shape:
-            raise ImcuiHipError("the HIP LoFTR path needs image0 and image1 of the same size (the reference config force-resizes both)")
+            raise ImcuiHipError(
+                f"the HIP LoFTR path needs image0 and image1 of the same size, got {tuple(image0.shape[-2:])} and {tuple(image1.shape[-2:])}: "
+                "the zoo's `loftr` conf force-resizes both images to 640x480 (configs/matchers.py:249-267), but confs with force_resize "
+                "False (`minima_loftr`, :283) keep each image's aspect ratio -- resize or pad the pair to a common size first"
+            )
         image0, image1 = image0.contiguous().float(), image1.contiguous().float()
         B, Cc, H, W = image0.shape
         if Cc != 1:

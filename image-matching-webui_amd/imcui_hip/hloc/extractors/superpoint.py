@@ -35,16 +35,29 @@ class SuperPoint(BaseModel):
         self._impl = backend.SuperPointHIP()
 
     def forward_batched(self, image: torch.Tensor, want_score_map: bool = False) -> dict:
-        """Fixed-stride outputs, no host synchronisation: keypoints [B,K,2], scores [B,K],
-        descriptors [B,K,256] (row per key-point), num_keypoints [B] int32."""
+        """Fixed-stride outputs, no host synchronisation (graph-capturable for every conf): keypoints [B,K,2],
+        scores [B,K], descriptors [B,K,256] (row per key-point), num_keypoints [B] int32, status [1] int32."""
+        return self._impl.forward(self.packed, self._gray(image), self.conf, want_score_map)
+
+    @staticmethod
+    def _gray(image: torch.Tensor) -> torch.Tensor:
         if image.shape[1] == 3:  # RGB -> gray (upstream weights), the hloc path always feeds gray
             scale = image.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)
             image = (image * scale).sum(1, keepdim=True)
-        return self._impl.forward(self.packed, image, self.conf, want_score_map)
+        return image
 
     def _forward(self, data):
         out = self.forward_batched(data["image"])
-        counts = out["num_keypoints"].tolist()  # ragged lists are the reference contract (one D2H)
+        # ragged lists are the reference contract: ONE device->host copy brings the counts and the status word
+        *counts, status = torch.cat([out["num_keypoints"], out["status"]]).tolist()
+        if status & 2:
+            # max_keypoints = -1 sizes the outputs by the NMS bound, which only exactly tied scores (flat images)
+            # can exceed: redo the call with room for every pixel
+            image = data["image"]
+            out = self._impl.forward(self.packed, self._gray(image), self.conf, kcap=image.shape[-2] * image.shape[-1])
+            *counts, status = torch.cat([out["num_keypoints"], out["status"]]).tolist()
+        if status:
+            raise backend.ImcuiHipError(f"SuperPoint key-point selection failed (status {status})")
         kpts = [out["keypoints"][b, :n] for b, n in enumerate(counts)]
         scores = [out["scores"][b, :n] for b, n in enumerate(counts)]
         # reference layout is [256, N]: a transposed view of the row-per-keypoint buffer

@@ -25,7 +25,14 @@ class LightGlue(BaseModel):
         "flash": True,  # accepted for compatibility; the HIP kernels are always the fused path
         "mp": False,
         "add_scale_ori": False,
+        # Upstream prunes a side only while it holds more than pruning_keypoint_thresholds[device] points:
+        # {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}.  The parity bar of this backend is the reference's
+        # PyTorch-CPU path, so the default is "cpu" (-1: prune whenever width_confidence > 0); "cuda" / "flash"
+        # (or an integer) reproduce what the reference does when it runs on a GPU.  matches0 / scores are the
+        # same up to the few points pruning removes; prune0/1 and the work done differ.
+        "pruning_device": "cpu",
     }
+    PRUNING_KEYPOINT_THRESHOLDS = {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}
     required_inputs = [
         "image0",
         "keypoints0",
@@ -47,14 +54,16 @@ class LightGlue(BaseModel):
         self.register_buffer("packed", backend.pack_lightglue(sd), persistent=False)
         self._impl = backend.LightGlueHIP()
 
-    def forward_batched(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1) -> dict:
+    def forward_batched(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, layer_dump: bool = False) -> dict:
         """Row-per-point descriptors [B,N,256]; n0/n1 [B] int32 valid counts; sizes (W, H).
         Fixed-stride int32 outputs, no host synchronisation."""
         c = self.conf
+        pd = c.get("pruning_device", "cpu")
+        pth = self.PRUNING_KEYPOINT_THRESHOLDS[pd] if isinstance(pd, str) else int(pd)
         # the UI mutates match_threshold at run time (imcui/ui/utils.py:921-922)
         return self._impl.forward(
             self.packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1,
-            c["depth_confidence"], c["width_confidence"], c["match_threshold"],
+            c["depth_confidence"], c["width_confidence"], c["match_threshold"], pruning_threshold=pth, layer_dump=layer_dump,
         )  # fmt: skip
 
     def _forward(self, data):

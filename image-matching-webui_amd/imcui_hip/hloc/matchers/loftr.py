@@ -7,6 +7,10 @@ before the net ("we refine kpts in image0", :42-51), the top-k matches by confid
 (:67-70).  The model itself (kornia.feature.LoFTR.forward, :54) runs in libimcui_hip
 (imcui_hip_loftr_forward).  Weights: kornia's `outdoor` checkpoint state dict (or the MINIMA variant,
 which sets temp_bug_fix, :27-36), given as conf["state_dict"] / conf["weights_path"].
+
+Limitation: image0 and image1 must have the same size (the C ABI takes one H, W).  That is what the zoo's `loftr`
+conf produces (force_resize to 640x480, imcui/hloc/configs/matchers.py:249-267); `minima_loftr` (:283, force_resize
+False) keeps each image's aspect ratio, so pairs of different shapes raise ImcuiHipError here instead of matching.
 """
 from __future__ import annotations
 

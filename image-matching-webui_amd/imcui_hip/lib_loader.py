@@ -43,7 +43,7 @@ SIGNATURES = {
     "imcui_hip_superpoint_forward": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
-        + [C.c_void_p] * 5
+        + [C.c_void_p] * 6
         + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_superpoint_status": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -58,10 +58,11 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         + [C.c_void_p] * 6
         + [C.c_float] * 4
-        + [C.c_double] * 3
+        + [C.c_double, C.c_double, C.c_int, C.c_double]
         + [C.c_void_p] * 7
         + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "imcui_hip_lightglue_set_layer_dump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "imcui_hip_superglue_packed_floats": (C.c_size_t, []),
     "imcui_hip_superglue_num_tensors": (C.c_int, []),
     "imcui_hip_superglue_tensor_name": (C.c_char_p, [C.c_int]),

@@ -5,7 +5,7 @@ imcui/hloc/extractors/superpoint.py:48-53, imcui/hloc/matchers/lightglue.py:39-5
 the parity tests load the SAME seeded tensors into the HIP backend and -- in the tests -- into the oracle.  Key names /
 shapes follow SURVEY.md Appendix A.1 / A.2, so a real `superpoint_v1.pth` / `superpoint_lightglue.pth` /
 `superglue_outdoor.pth` state dict drops in unchanged.  This module is data generation only (like synth.py): it holds
-no model arithmetic; `oracle/weights.py` re-exports it for the checker side.
+no model arithmetic and imports nothing from `oracle/`.
 """
 from __future__ import annotations
 
@@ -71,7 +71,8 @@ def _mean_descriptor_logits(sd: dict, g: torch.Generator) -> torch.Tensor:
     return y.mean(dim=(0, 2, 3))
 
 
-def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads: int = 4, structured: bool = True) -> dict:
+def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads: int = 4, structured: bool = True,
+                         damp: float | None = None, ln_noise: float | None = None, final_gain: float | None = None) -> dict:
     """Random LightGlue weights in the upstream (new-style) key layout.
 
     transformers.{i}.self_attn.{Wqkv,out_proj,ffn.0,ffn.1,ffn.3}
@@ -85,6 +86,13 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
     SuperPoint descriptors then win the dual soft-max), matchability logits spread
     around +1 (a few points fall below the 1 - width_confidence prune threshold) and
     the token-confidence bias rises with depth (pairs early-stop at varying layers).
+
+    `damp` / `ln_noise` override the residual damping (default 0.03 structured, 1.0 otherwise) and the spread of
+    the LayerNorm gamma / beta (default 0 structured, 0.1 otherwise): `structured=True, damp=1.0, ln_noise=0.1`
+    keeps the shaped heads but makes every layer a full-strength update, so an error in the attention / FFN
+    arithmetic reaches the outputs undiminished (the "undamped" parity tests); `final_gain` rescales the identity part
+    of `final_proj` (the residual stream grows with strong updates, and similarities far above ~100 turn fp32 round-off
+    into score differences no two fp32 implementations can agree on to 1e-4).
     """
     g = torch.Generator().manual_seed(seed)
 
@@ -99,14 +107,15 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
     head_dim = dim // heads
     # gamma = 1 -> std 1 upstream (nn.init.normal_(std=gamma**-2))
     sd["posenc.Wr.weight"] = torch.randn(head_dim // 2, 2, generator=g)
-    damp = 0.03 if structured else 1.0
+    damp = (0.03 if structured else 1.0) if damp is None else damp
+    ln_noise = (0.0 if structured else 0.1) if ln_noise is None else ln_noise
     for i in range(n_layers):
         p = f"transformers.{i}."
         sd.update(lin(3 * dim, dim, scale=10.0 if structured else 1.0, prefix=p + "self_attn.Wqkv"))
         sd.update(lin(dim, dim, prefix=p + "self_attn.out_proj"))
         sd.update(lin(2 * dim, 2 * dim, prefix=p + "self_attn.ffn.0"))
-        sd[p + "self_attn.ffn.1.weight"] = 1.0 + (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd[p + "self_attn.ffn.1.bias"] = (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
+        sd[p + "self_attn.ffn.1.weight"] = 1.0 + ln_noise * torch.randn(2 * dim, generator=g)
+        sd[p + "self_attn.ffn.1.bias"] = ln_noise * torch.randn(2 * dim, generator=g)
         sd.update(lin(dim, 2 * dim, scale=damp, prefix=p + "self_attn.ffn.3"))
         if structured:  # zero-mean rows: no common-mode drift of the residual stream
             w = sd[p + "self_attn.ffn.3.weight"]
@@ -116,8 +125,8 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
         sd.update(lin(dim, dim, prefix=p + "cross_attn.to_v"))
         sd.update(lin(dim, dim, prefix=p + "cross_attn.to_out"))
         sd.update(lin(2 * dim, 2 * dim, prefix=p + "cross_attn.ffn.0"))
-        sd[p + "cross_attn.ffn.1.weight"] = 1.0 + (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
-        sd[p + "cross_attn.ffn.1.bias"] = (0.0 if structured else 0.1) * torch.randn(2 * dim, generator=g)
+        sd[p + "cross_attn.ffn.1.weight"] = 1.0 + ln_noise * torch.randn(2 * dim, generator=g)
+        sd[p + "cross_attn.ffn.1.bias"] = ln_noise * torch.randn(2 * dim, generator=g)
         sd.update(lin(dim, 2 * dim, scale=damp, prefix=p + "cross_attn.ffn.3"))
         if structured:
             w = sd[p + "cross_attn.ffn.3.weight"]
@@ -128,7 +137,7 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
             sd.update(lin(1, dim, scale=48.0, prefix=q + "matchability"))  # logit std ~2.5 per unit |x|
             sd[q + "matchability.bias"] = sd[q + "matchability.bias"] + 2.0
             sd.update(lin(dim, dim, scale=2.0, prefix=q + "final_proj"))
-            sd[q + "final_proj.weight"] = sd[q + "final_proj.weight"] + 4.0 * math.sqrt(60.0) * torch.eye(dim)
+            sd[q + "final_proj.weight"] = sd[q + "final_proj.weight"] + (4.0 * math.sqrt(60.0) if final_gain is None else final_gain) * torch.eye(dim)
         else:
             sd.update(lin(1, dim, prefix=q + "matchability"))
             sd.update(lin(dim, dim, scale=4.0, prefix=q + "final_proj"))
@@ -186,11 +195,7 @@ def loftr_state_dict(seed: int = 0, structured: bool = True) -> dict:
         # x3 is post-ReLU and dominated by one common direction: project the mean feature of a small
         # calibration image out of every row, then apply a gain, so that the coarse dual soft-max is
         # driven by image content and produces confident mutual matches with random weights
-        from oracle.loftr import LoFTROracle
-
-        with torch.no_grad():
-            _, _, x3 = LoFTROracle(sd).encoder_stages(torch.rand(1, 1, 96, 128, generator=g))
-        m = x3.mean(dim=(0, 2, 3))
+        m = _loftr_mean_stage3_feature(sd, torch.rand(1, 1, 96, 128, generator=g))
         m = m / m.norm()
         wc = sd[b + "layer3_outconv.weight"][:, :, 0, 0]
         wc = wc - (wc @ m)[:, None] * m[None, :]
@@ -225,6 +230,29 @@ def loftr_state_dict(seed: int = 0, structured: bool = True) -> dict:
     lin("fine_preprocess.merge_feat", 128, 256, bias=True)
     encoder("loftr_fine", 2, 128)
     return sd
+
+
+def _loftr_mean_stage3_feature(sd: dict, x: torch.Tensor) -> torch.Tensor:
+    """Mean 1/8-resolution ResNet feature of a small calibration image (plain torch; weight shaping only, like
+    `_mean_descriptor_logits` for SuperPoint).  Stages = conv7x7/2 + BN + ReLU, then three pairs of BasicBlocks."""
+    import torch.nn.functional as F
+
+    def bn(t, p):
+        return F.batch_norm(t, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+    def block(t, p, stride):
+        y = F.relu(bn(F.conv2d(t, sd[p + ".conv1.weight"], None, stride, 1), p + ".bn1"))
+        y = bn(F.conv2d(y, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
+        if p + ".downsample.0.weight" in sd:
+            t = bn(F.conv2d(t, sd[p + ".downsample.0.weight"], None, stride, 0), p + ".downsample.1")
+        return F.relu(t + y)
+
+    b = "backbone."
+    with torch.no_grad():
+        t = F.relu(bn(F.conv2d(x, sd[b + "conv1.weight"], None, 2, 3), b + "bn1"))
+        for li, stride in ((1, 1), (2, 2), (3, 2)):
+            t = block(block(t, f"{b}layer{li}.0", stride), f"{b}layer{li}.1", 1)
+    return t.mean(dim=(0, 2, 3))
 
 
 def superglue_state_dict(seed: int = 0, structured: bool = True) -> dict:

@@ -84,12 +84,17 @@ int imcui_hip_superpoint_max_keypoints_bound(int H, int W, int nms_radius);
  *   scores      [dev, B,kcap]
  *   descriptors [dev, B,kcap,256] row per key-point (the reference's [256,N] is its transpose view)
  *   num_keypoints [dev, B] int32
+ *   status      [dev, 1] int32 optional (may be NULL): selection status word of this call, 0 = fine, bit 1 = `kcap`
+ *               too small (only possible with max_keypoints = -1 and exactly tied scores; the first kcap are
+ *               returned), bit 0 = candidate overflow.  Reading it is the caller's business (no sync here).
  *   score_map   [dev, B,H,W] optional (may be NULL): dense pre-NMS detector scores
+ * max_keypoints above 16384 (the on-chip sorter; the UI slider ends at 10000) is rejected with
+ * IMCUI_HIP_ERR_UNSUPPORTED before anything is launched; -1 (all) has no such limit.
  * Order: score-descending (ties: lower flat index first) when top-k applies, row-major otherwise. */
 int imcui_hip_superpoint_forward(imcui_hip_t* h, const float* packed, const float* image, int B, int H, int W,
                                  int nms_radius, float keypoint_threshold, int remove_borders, int max_keypoints,
                                  int fix_sampling, int kcap, float* keypoints, float* scores, float* descriptors,
-                                 int* num_keypoints, float* score_map, void* ws, size_t ws_bytes, void* stream);
+                                 int* num_keypoints, int* status, float* score_map, void* ws, size_t ws_bytes, void* stream);
 /* Synchronises `stream` and reports selection overflow of the last forward on `ws`
  * (IMCUI_HIP_ERR_UNSUPPORTED + message) -- e.g. kcap too small for a max_keypoints = -1 call. */
 int imcui_hip_superpoint_status(imcui_hip_t* h, int B, int H, int W, int nms_radius, void* ws, size_t ws_bytes,
@@ -115,6 +120,9 @@ size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap);
  * n0/n1 [dev, B] int32 valid counts (<= ncap).  size0/size1: (W,H) of the images the key-points
  * live in (only used to normalise key-points, lightglue.py passes `image.shape`).
  * depth_confidence / width_confidence <= 0 disable early stopping / point pruning;
+ * pruning_threshold: a side is pruned only while it holds MORE than this many points -- upstream's
+ * pruning_keypoint_thresholds[device] (cpu / mps -1 = always, cuda 1024, flash 1536); -1 reproduces the
+ * reference's PyTorch-CPU path, which is what the parity tests pin;
  * filter_threshold is conf["match_threshold"] (imcui/hloc/matchers/lightglue.py:50).  The three
  * thresholds are doubles because the reference compares fp32 tensors against Python floats
  * (e.g. `1 - width_confidence` is formed in double before the fp32 cast).
@@ -123,9 +131,15 @@ size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap);
 int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
                                 const float* keypoints1, const float* descriptors0, const float* descriptors1,
                                 const int* n0, const int* n1, float w0, float h0, float w1, float h1,
-                                double depth_confidence, double width_confidence, double filter_threshold, int* matches0,
-                                int* matches1, float* matching_scores0, float* matching_scores1, int* stop, int* prune0,
-                                int* prune1, void* ws, size_t ws_bytes, void* stream);
+                                double depth_confidence, double width_confidence, int pruning_threshold,
+                                double filter_threshold, int* matches0, int* matches1, float* matching_scores0,
+                                float* matching_scores1, int* stop, int* prune0, int* prune1, void* ws, size_t ws_bytes,
+                                void* stream);
+/* Parity-test hook (the oracle exposes the same intermediates): while `dump` [dev] is non-NULL every
+ * imcui_hip_lightglue_forward on this handle copies the token states x [2B, R, 256] (R = roundup(ncap, 128),
+ * row (2*pair + image)*R + i, rows in their current -- pruned -- order) after each of the 9 layers to
+ * dump + layer * 2B*R*256; `floats` = capacity of `dump`.  NULL switches it off. */
+int imcui_hip_lightglue_set_layer_dump(imcui_hip_t* h, float* dump, size_t floats);
 
 /* ---- SuperGlue (imcui/hloc/matchers/superglue.py:42-43 `self.net(data)`) ---------- */
 /* Host-side packing of the upstream state dict (Vincentqyw/SuperGluePretrainedNetwork models/superglue.py:

@@ -24,6 +24,8 @@ DEFAULT_CONF = {  # imcui/hloc/matchers/lightglue.py:15-25 merged over upstream 
     "filter_threshold": 0.2,
     "width_confidence": 0.99,
     "depth_confidence": 0.95,
+    # upstream pruning_keypoint_thresholds[device]: {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}
+    "pruning_threshold": -1,
 }
 
 
@@ -194,7 +196,7 @@ class LightGlueOracle:
 
         do_early_stop = conf["depth_confidence"] > 0
         do_point_pruning = conf["width_confidence"] > 0
-        pruning_th = -1  # upstream pruning_keypoint_thresholds["cpu"]
+        pruning_th = conf["pruning_threshold"]  # upstream pruning_keypoint_thresholds[device]; "cpu" = -1
         if do_point_pruning:
             ind0 = torch.arange(0, m)[None]
             ind1 = torch.arange(0, n)[None]

@@ -4,6 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+from oracle.audit import assert_matches_equal_or_tied, audit_keypoint_differences  # noqa: F401  (re-exported)
 from oracle.superpoint import remove_borders, simple_nms
 
 

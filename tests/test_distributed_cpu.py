@@ -79,3 +79,25 @@ def test_match_table_layout_with_and_without_stop():
     assert torch.equal(t[:, 6:].contiguous().view(torch.float32), out["matching_scores0"])
     out["stop"] = torch.tensor([9, 4], dtype=torch.int32)
     assert match_table(out)[:, 2].tolist() == [9, 4]
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (it re-executes itself under
+    torch.distributed.run) and report n_gpus = 2; a launcher that started a different rank count is refused.  Runs the
+    launch / timing / all-gather scaffold of bench.py on gloo (`--workload launchcheck`: no HIP work)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "launchcheck", "--gpus", "2", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)  # fmt: skip
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "launchcheck", "--gpus", "4", "--steps", "1"],
+                         capture_output=True, text=True, timeout=120, env={**env, "WORLD_SIZE": "2", "RANK": "0"}, cwd=root)  # fmt: skip
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

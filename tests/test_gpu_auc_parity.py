@@ -9,7 +9,7 @@ import torch
 from geometry_utils import corner_error, error_auc, ransac_homography
 from oracle.lightglue import LightGlueOracle
 from oracle.superpoint import SuperPointOracle
-from oracle.weights import lightglue_state_dict, superpoint_state_dict
+from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -72,7 +72,7 @@ def test_homography_auc_matches_the_oracle_superglue():
     from imcui_hip.pipeline import SuperPointSuperGluePipeline
     from imcui_hip.synth import make_pair_batch
     from oracle.superglue import SuperGlueOracle
-    from oracle.weights import superglue_state_dict
+    from imcui_hip.synth_weights import superglue_state_dict
 
     torch.set_num_threads(8)
     ssd, gsd = superpoint_state_dict(0), superglue_state_dict(0)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from imcui_hip.synth import make_pair
 from oracle.loftr import LoFTROracle
-from oracle.weights import loftr_state_dict
+from imcui_hip.synth_weights import loftr_state_dict
 
 pytestmark = pytest.mark.gpu
 SD = loftr_state_dict(0)
@@ -43,22 +43,20 @@ def test_conv_gemm_vs_torch(cin, cout, ks, stride, act, use_res, precision):
     assert (out - ref).abs().max().item() / ref.abs().max().item() < 4e-6
 
 
-@pytest.mark.parametrize("h,w,B", [(240, 320, 1), (96, 160, 2)])
-def test_loftr_vs_oracle(h, w, B, precision):
+def _loftr_case(h, w, B, sd, thr, min_matches):
     from imcui_hip.hloc.matchers.loftr import LoFTR
 
-    torch.set_num_threads(8)
+    torch.set_num_threads(16)
     pairs = [crops(3 + b, h, w) for b in range(B)]
     img0 = torch.cat([p[0] for p in pairs], 0)
     img1 = torch.cat([p[1] for p in pairs], 0)
-    thr = 0.01
-    model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": SD}).eval().to("cuda:0")
+    model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to("cuda:0")
     out = model.forward_batched(img0.cuda(), img1.cuda())
     torch.cuda.synchronize()
     n = int(out["num_matches"][0])
     hc, wc = h // 8, w // 8
     L = hc * wc
-    ora = LoFTROracle(SD, {"match_threshold": thr, "max_keypoints": None})
+    ora = LoFTROracle(sd, {"match_threshold": thr, "max_keypoints": None})
     ref = ora.net(img0, img1, return_intermediates=True)
     # intermediates: coarse features after the transformer, fine features, similarity
     fc = model._impl.debug_buffer(0, B, h, w, (2 * B, L, 256)).cpu()
@@ -68,13 +66,35 @@ def test_loftr_vs_oracle(h, w, B, precision):
     assert (fc - fc_ref).abs().max().item() < 2e-4 * fc_ref.abs().max().item(), "coarse features after the transformer"
     # coarse matches: same (b, i, j) triplets in the same order
     mi = (out["keypoints0"][:n, 1] / 8 * wc + out["keypoints0"][:n, 0] / 8).round().long().cpu()
-    assert n == len(ref["confidence"]) and n > 20, (n, len(ref["confidence"]))
+    assert n == len(ref["confidence"]) and n >= min_matches, (n, len(ref["confidence"]))
     assert torch.equal(out["batch_indexes"][:n].cpu().long(), ref["batch_indexes"])
     assert torch.equal(mi, ref["_i_ids"])
     assert torch.equal(out["keypoints0"][:n].cpu(), ref["keypoints0"].float())
     assert (out["confidence"][:n].cpu() - ref["confidence"]).abs().max().item() < 1e-4
     # fine refinement: sub-pixel key-points of image1
-    assert (out["keypoints1"][:n].cpu() - ref["keypoints1"]).abs().max().item() < 2e-3
+    if n:
+        assert (out["keypoints1"][:n].cpu() - ref["keypoints1"]).abs().max().item() < 2e-3
+    return n
+
+
+@pytest.mark.parametrize("h,w,B", [(240, 320, 1), (96, 160, 2), (480, 640, 1)])
+def test_loftr_vs_oracle(h, w, B, precision):
+    """Includes the zoo's LoFTR size: configs/matchers.py:249-267 force-resizes every pair to 640 x 480."""
+    _loftr_case(h, w, B, SD, 0.01, 21)
+
+
+def test_loftr_1024_vs_oracle():
+    """BASELINE configs[3], the size bench.py --workload loftr runs: 1024 x 1024 -> L = S = 16384 coarse cells (the
+    chunked K'V / column reductions take their large-L paths; the similarity matrix is 1.07 GB).  Default arithmetic mode."""
+    n = _loftr_case(1024, 1024, 1, SD, 0.2, 21)
+    print(f"[parity] LoFTR 1024x1024: {n} matches identical to the oracle's")
+
+
+def test_loftr_unshaped_weights_vs_oracle(precision):
+    """Plain random weights (no calibrated out-conv, LayerNorm gains ~1: nothing damped): backbone + both transformers
+    within 2e-4 of the oracle; the dual soft-max of random features is diffuse, so few or no matches pass -- those
+    that do must be identical."""
+    _loftr_case(240, 320, 1, loftr_state_dict(0, structured=False), 0.001, 0)
 
 
 def test_loftr_plugin_contract():

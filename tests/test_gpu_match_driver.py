@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from imcui_hip.hloc import match_features as mf
-from oracle.weights import lightglue_state_dict, superglue_state_dict
+from imcui_hip.synth_weights import lightglue_state_dict, superglue_state_dict
 from parity_utils import synthetic_matching_problem
 
 pytestmark = pytest.mark.gpu

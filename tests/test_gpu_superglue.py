@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle.superglue import SuperGlueOracle
-from oracle.weights import superglue_state_dict
+from imcui_hip.synth_weights import superglue_state_dict
 from parity_utils import synthetic_matching_problem
 
 pytestmark = pytest.mark.gpu

@@ -14,7 +14,7 @@ transformers = pytest.importorskip("transformers")
 @pytest.mark.parametrize("dc,wc", [(-1.0, -1.0), (0.95, 0.99)])
 def test_lightglue_hip_vs_hf_port(dc, wc):
     from imcui_hip.hloc.matchers.lightglue import LightGlue
-    from oracle.weights import lightglue_state_dict
+    from imcui_hip.synth_weights import lightglue_state_dict
 
     torch.set_num_threads(8)
     lsd = lightglue_state_dict(0)
@@ -44,7 +44,7 @@ def test_lightglue_hip_vs_hf_port(dc, wc):
 @pytest.mark.parametrize("iters", [5, 50])
 def test_superglue_hip_vs_hf_port(iters):
     from imcui_hip.hloc.matchers.superglue import SuperGlue
-    from oracle.weights import superglue_state_dict
+    from imcui_hip.synth_weights import superglue_state_dict
 
     torch.set_num_threads(8)
     sd = superglue_state_dict(0)

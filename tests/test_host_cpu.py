@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.weights import lightglue_state_dict, superpoint_state_dict
+from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -161,7 +161,7 @@ def test_plugins_follow_the_reference_seam(lib):
     out = nn_model({"descriptors0": torch.zeros(1, 128, 5), "descriptors1": torch.zeros(1, 128, 0)})
     assert (out["matches0"] == -1).all()
     # SuperGlue wrapper (imcui/hloc/matchers/superglue.py:14-29)
-    from oracle.weights import superglue_state_dict
+    from imcui_hip.synth_weights import superglue_state_dict
 
     SG = dynamic_load(matchers, "superglue")
     assert issubclass(SG, BaseModel)
@@ -214,7 +214,7 @@ def test_superglue_packing_folds_bn_merge_and_heads(lib):
     torch reproduce the oracle: checks the host packer without a GPU."""
     from imcui_hip import backend
     from oracle.superglue import SuperGlueOracle, log_optimal_transport, normalize_keypoints
-    from oracle.weights import superglue_state_dict
+    from imcui_hip.synth_weights import superglue_state_dict
 
     torch.set_num_threads(4)
     sd = superglue_state_dict(3)

@@ -12,7 +12,7 @@ import torch
 from imcui_hip.synth import make_pair
 from oracle.lightglue import LightGlueOracle
 from oracle.superpoint import SuperPointOracle
-from oracle.weights import lightglue_state_dict, superpoint_state_dict
+from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
 
 transformers = pytest.importorskip("transformers")
 
@@ -206,7 +206,7 @@ def test_superglue_oracle_vs_hf(iters):
     """Same seeded weights through the restatement and through the independent HF port (equal key-point
     counts: the HF port stacks the two images)."""
     from oracle.superglue import SuperGlueOracle
-    from oracle.weights import superglue_state_dict
+    from imcui_hip.synth_weights import superglue_state_dict
 
     torch.set_num_threads(4)
     sd = superglue_state_dict(0)

@@ -7,7 +7,7 @@ import torch
 
 from imcui_hip.synth import make_pair
 from oracle.loftr import LoFTROracle
-from oracle.weights import loftr_state_dict
+from imcui_hip.synth_weights import loftr_state_dict
 
 
 def test_loftr_oracle_recovers_known_translation():

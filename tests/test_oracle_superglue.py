@@ -3,7 +3,7 @@ implementation: the log-domain Sinkhorn with dust-bins must produce the marginal
 import torch
 
 from oracle.superglue import SuperGlueOracle, log_optimal_transport, normalize_keypoints
-from oracle.weights import superglue_state_dict
+from imcui_hip.synth_weights import superglue_state_dict
 
 
 def test_transport_marginals():

@@ -1,0 +1,54 @@
+"""The audited comparisons of tests/parity_utils.py must accept round-off ties and reject anything else (CPU)."""
+import pytest
+import torch
+
+from parity_utils import assert_matches_equal_or_tied, audit_keypoint_differences, oracle_select_on
+
+CONF = dict(nms_radius=3, keypoint_threshold=0.005, remove_borders=4, max_keypoints=40)
+
+
+def _maps():
+    g = torch.Generator().manual_seed(0)
+    dense = torch.rand(64, 96, generator=g) * 0.05
+    (sel, _, _), _ = oracle_select_on(dense, CONF)
+    y, x = divmod(int(sel[5]), 96)
+    ref, hip = dense.clone(), dense.clone()
+    ref[y, x + 1] = ref[y, x] - 2e-8  # neighbour just below the maximum on the oracle's map ...
+    hip[y, x + 1] = ref[y, x] + 2e-8  # ... just above it on the other: the NMS winner moves by one pixel
+    return ref, hip
+
+
+def test_keypoint_audit_accepts_a_roundoff_tie():
+    ref, hip = _maps()
+    (sr, _, _), _ = oracle_select_on(ref, CONF)
+    (sh, _, _), _ = oracle_select_on(hip, CONF)
+    assert set(sr.tolist()) != set(sh.tolist())
+    assert audit_keypoint_differences(sh, sr, hip, ref, CONF) == 2
+
+
+def test_keypoint_audit_rejects_a_real_difference():
+    ref, _ = _maps()
+    (sr, _, _), _ = oracle_select_on(ref, CONF)
+    other = ref.clone()
+    other[10, 10] = 1.0
+    (so, _, _), _ = oracle_select_on(other, CONF)
+    with pytest.raises(AssertionError, match="without a round-off tie"):
+        audit_keypoint_differences(so, sr, ref, ref, CONF)
+
+
+def test_match_audit_accepts_ties_only():
+    g = torch.Generator().manual_seed(1)
+    S = torch.randn(9, 7, generator=g) - 3.0
+    S[2, 3], S[2, 5] = -0.5, -0.5 - 3e-5  # near tie in row 2
+    S[:, 3] -= 10
+    S[2, 3] += 10
+    S[:, 5] -= 10
+    S[2, 5] += 10
+    m_ref = torch.full((8,), -1)
+    m_ref[2] = 3
+    m_hip = m_ref.clone()
+    m_hip[2] = 5
+    assert assert_matches_equal_or_tied(m_hip, S, m_ref, 0.1) == 1
+    S[2, 5] = -2.0  # no longer a tie
+    with pytest.raises(AssertionError, match="is not a tie"):
+        assert_matches_equal_or_tied(m_hip, S, m_ref, 0.1)
