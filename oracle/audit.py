@@ -12,21 +12,26 @@ import torch
 from .superpoint import simple_nms
 
 
-def assert_matches_equal_or_tied(m_hip, log_assignment, m_ref, filter_threshold, tol=1e-4, max_frac=0.002, tag=""):
-    """matches0 of the HIP path vs the oracle for ONE un-pruned pair.
+def assert_matches_equal_or_tied(m_hip, log_assignment, m_ref, filter_threshold, tol=1e-4, max_frac=0.002, tag="", ind0=None, ind1=None):
+    """matches0 of the HIP path vs the oracle for ONE pair.
 
     Equal rows pass.  A differing row must be a numerically fragile decision in the ORACLE's own log-assignment
     matrix `log_assignment` [m+1, n+1] -- its row arg-max, the column arg-max of the winning column, or the
     `exp(score) > filter_threshold` test decided by a margin below `tol` (the same 1e-4 the scores are held to) --
-    and there may be at most max(1, max_frac * m) of them.  Anything else fails.  Returns the number of audited ties."""
+    and there may be at most max(1, max_frac * m) of them.  Anything else fails.  With point pruning the matrix lives
+    in the pruned index space: `ind0` / `ind1` (the oracle's `_ind0` / `_ind1`, original index of every surviving
+    row / column) map it back; a row the oracle pruned can only be unmatched.  Returns the number of audited ties."""
     m_hip, m_ref = m_hip.long(), m_ref.long()
     bad = torch.nonzero(m_hip != m_ref).flatten().tolist()
     if not bad:
         return 0
     S = log_assignment[:-1, :-1]
+    row_of = {int(o): r for r, o in enumerate(ind0.flatten().tolist())} if ind0 is not None else None
     assert len(bad) <= max(1, int(max_frac * len(m_ref))), f"{tag}: {len(bad)} differing rows"
     for i in bad:
-        row = S[i]
+        if row_of is not None:
+            assert i in row_of, f"{tag}: row {i} was pruned by the oracle but the HIP path matched it to {int(m_hip[i])}"
+        row = S[row_of[i] if row_of is not None else i]
         top = torch.topk(row, min(2, row.numel()))
         j = int(top.indices[0])
         g_row = float(top.values[0] - top.values[1]) if row.numel() > 1 else float("inf")

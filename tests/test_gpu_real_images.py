@@ -1,0 +1,116 @@
+"""Real images through the HIP path (AUC leg): the reference's 15 EVD pairs with ground-truth
+homographies plus its own tests/data pair, decoded by tests/golden/make_evd_fixtures.py into tests/golden/evd_pairs.npz
+(gray, 640 x 480 -- the `superpoint_max` force-resize).  HIP SuperPoint + LightGlue vs the oracle on identical bytes:
+dense score maps to round-off, every key-point difference an audited tie, matches identical, and the same seeded host
+DLT-RANSAC on both match sets gives identical corner errors and AUC@{3,5,10 px}.
+
+The weights are seeded random tensors (no checkpoint offline), so on the EVD pairs themselves (extreme view changes)
+few matches survive and both AUCs are ~0 -- the pairs exercise real image statistics (flat / saturated regions,
+exact score ties, 8-bit quantisation) rather than matching quality.  The second test therefore warps real EVD images
+with mild known homographies: real texture AND a recoverable ground truth.
+"""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from geometry_utils import corner_error, error_auc, ransac_homography
+from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
+from oracle.lightglue import LightGlueOracle
+from oracle.superpoint import SuperPointOracle
+from parity_utils import assert_matches_equal_or_tied, audit_keypoint_differences
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+H, W = 480, 640
+SPC = dict(nms_radius=3, max_keypoints=2048, keypoint_threshold=0.005, remove_borders=4)  # configs/extractors.py:29-45
+
+
+def load_pairs():
+    from PIL import Image
+
+    z = np.load(os.path.join(HERE, "golden", "evd_pairs.npz"))
+    names = [str(n) for n in z["names"]]
+    dec = lambda k: torch.from_numpy(np.asarray(Image.open(io.BytesIO(z[k].tobytes()))).astype(np.float32) / 255.0)  # noqa: E731
+    img0 = torch.stack([dec(f"img0_{i}") for i in range(len(names))])[:, None]
+    img1 = torch.stack([dec(f"img1_{i}") for i in range(len(names))])[:, None]
+    return names, img0, img1, z["homographies"]
+
+
+def _run_and_check(img0, img1, hgt, lgc, names, need_matches):
+    """HIP pipeline on the batch vs the oracle pair by pair; returns (errors_hip, errors_ref, matches per pair)."""
+    from imcui_hip.pipeline import SuperPointLightGluePipeline
+
+    torch.set_num_threads(16)
+    ssd, lsd = superpoint_state_dict(0), lightglue_state_dict(0)
+    pipe = SuperPointLightGluePipeline({**SPC, "state_dict": ssd}, {**lgc, "state_dict": lsd}).eval().to("cuda:0")
+    B = img0.shape[0]
+    dense = pipe.extractor.forward_batched(torch.cat([img0, img1]).cuda(), want_score_map=True)["score_map"].cpu()
+    out = {k: v.cpu() for k, v in pipe(img0.cuda(), img1.cuda()).items()}
+    sp = SuperPointOracle(ssd)
+    lg = LightGlueOracle(lsd, dict(depth_confidence=lgc["depth_confidence"], width_confidence=lgc["width_confidence"], filter_threshold=lgc["match_threshold"]))
+    e_hip, e_ref, nm, n_ties = [], [], [], 0
+    for b in range(B):
+        n0, n1 = int(out["num_keypoints0"][b]), int(out["num_keypoints1"][b])
+        for side, (img, kp, n) in enumerate(((img0, out["keypoints0"], n0), (img1, out["keypoints1"], n1))):
+            ref = sp({"image": img[b : b + 1]}, SPC, return_intermediates=True)
+            d_hip, d_ref = dense[side * B + b], ref["_dense_scores"][0]
+            assert (d_hip - d_ref).abs().max().item() < 2e-5, f"{names[b]} image {side}: dense scores"
+            k_h, k_r = kp[b, :n], ref["keypoints"][0]
+            flat_h, flat_r = (k_h[:, 1] * W + k_h[:, 0]).long(), (k_r[:, 1] * W + k_r[:, 0]).long()
+            n_ties += audit_keypoint_differences(flat_h, flat_r, d_hip, d_ref, SPC, tag=f"{names[b]} image {side}")
+            assert len(set(flat_h.tolist()) & set(flat_r.tolist())) >= 0.98 * len(flat_r), names[b]
+        k0, k1 = out["keypoints0"][b, :n0], out["keypoints1"][b, :n1]
+        ref = lg({"image0": img0[b : b + 1], "image1": img1[b : b + 1], "keypoints0": k0[None], "keypoints1": k1[None],
+                  "descriptors0": out["descriptors0"][b, :n0].t()[None], "descriptors1": out["descriptors1"][b, :n1].t()[None]},
+                 return_intermediates=True)  # fmt: skip
+        assert int(out["stop"][b]) == ref["stop"], names[b]
+        m_h, m_r = out["matches0"][b, :n0].long(), ref["matches0"][0]
+        if "_log_assignment" in ref:
+            assert_matches_equal_or_tied(m_h, ref["_log_assignment"][0], m_r, lgc["match_threshold"], tag=names[b], ind0=ref.get("_ind0"), ind1=ref.get("_ind1"))
+        else:  # a side lost all its points: nothing was matched
+            assert torch.equal(m_h, m_r), names[b]
+        same = m_h == m_r
+        assert (out["matching_scores0"][b, :n0] - ref["matching_scores0"][0]).abs()[same].max().item() < 1e-4, names[b]
+        nm.append(int((m_r >= 0).sum()))
+        if np.isnan(hgt[b]).any():
+            continue
+        for m, errs in ((m_h, e_hip), (m_r, e_ref)):
+            v = m >= 0
+            if int(v.sum()) < 4:
+                errs.append(float("inf"))
+                continue
+            hm, _ = ransac_homography(k0[v].numpy().astype(np.float64), k1[m[v]].numpy().astype(np.float64), thresh=3.0, iters=300, seed=b)
+            errs.append(float(corner_error(hm, np.asarray(hgt[b]), W, H)))
+    auc_hip, auc_ref = error_auc(e_hip), error_auc(e_ref)
+    print(f"[real images] {B} pairs, matches/pair {nm}, {n_ties} audited key-point ties, AUC@3/5/10 hip {auc_hip} oracle {auc_ref}")
+    assert e_hip == e_ref and auc_hip == auc_ref
+    assert sum(nm) >= need_matches, nm
+    return auc_ref
+
+
+@pytest.mark.parametrize("lgc", [dict(depth_confidence=0.95, width_confidence=0.99, match_threshold=0.2),
+                                 dict(depth_confidence=-1.0, width_confidence=-1.0, match_threshold=0.1)], ids=["zoo-conf", "fixed-depth"])  # fmt: skip
+def test_evd_pairs_parity_and_auc(lgc):
+    """configs/matchers.py:34-50 (`superpoint-lightglue`: match_threshold 0.2, depth 0.95, width 0.99) and the bench's
+    fixed-work mode on the 16 real pairs."""
+    names, img0, img1, hgt = load_pairs()
+    _run_and_check(img0, img1, hgt, lgc, names, need_matches=20)
+
+
+def test_real_texture_known_homography_auc(precision):
+    """Real EVD images warped by seeded mild homographies: the AUC is non-trivial and must equal the oracle's."""
+    from imcui_hip.synth import random_homography, warp_image
+
+    names, img0, _, _ = load_pairs()
+    pick = [names.index(n) for n in ("graf", "cafe", "there", "girl", "shop", "grand")]
+    g = torch.Generator().manual_seed(7)
+    a = img0[pick]
+    hm = torch.stack([random_homography(g, H, W) for _ in pick])
+    b = torch.cat([warp_image(a[i : i + 1], hm[i]) for i in range(len(pick))]).clamp_(0, 1)
+    b = (b * 255).round() / 255  # 8-bit images, like a decoded file
+    auc = _run_and_check(a, b, hm.numpy().astype(np.float64), dict(depth_confidence=-1.0, width_confidence=-1.0, match_threshold=0.1),
+                         [names[i] for i in pick], need_matches=200)  # fmt: skip
+    assert auc[2] > 0.3, f"AUC@10 {auc}: the warped real-image pairs should be matchable"
