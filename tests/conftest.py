@@ -30,3 +30,12 @@ def precision(request):
     backend.set_precision(dev, request.param)
     yield request.param
     backend.set_precision(dev, 1)
+
+
+@pytest.fixture(scope="session")
+def lib():
+    """The built C-ABI library (hipcc cross-compiles without a GPU)."""
+    from imcui_hip import build, load_library
+
+    build.build()
+    return load_library()

@@ -13,14 +13,6 @@ from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib():
-    from imcui_hip import build, load_library
-
-    build.build()
-    return load_library()
-
-
 def test_every_header_symbol_is_exported_and_bound(lib):
     from imcui_hip.lib_loader import SIGNATURES
 
