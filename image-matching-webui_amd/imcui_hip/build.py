@@ -12,9 +12,14 @@ CSRC = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "..", "include"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip"]
+SOURCES = ["api.hip", "gemm.hip", "conv.hip", "attention.hip", "attention_pipe.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
+# Per-source code-generation switches.  attention_pipe.hip is a hand-interleaved instruction stream (one wave per SIMD,
+# every MFMA followed by its share of vector work, order pinned with sched_barrier): its accumulators must be VGPRs
+# (the soft-max reads them with vector instructions; in AGPRs every value costs a v_accvgpr_read), and machine sinking
+# must not move the exponentials of a tile behind the barrier into the next iteration, out from under the MFMAs.
+EXTRA_FLAGS = {"attention_pipe.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-disable-machine-sink"]}
 
 
 def _newest_source_mtime() -> float:
@@ -29,7 +34,7 @@ def needs_build() -> bool:
 # MFMA kernels whose register budget is part of the design: a build that spills them to scratch is rejected (two
 # experimental builds of the split GEMM that spilled -- 128-VGPR and 168-VGPR-with-20-B-scratch variants -- were
 # slower AND failed the parity / determinism tests on the GPU; hipcc is not to be trusted with spills around them).
-NO_SPILL_KERNELS = ("gemm_split_kernel", "gemm_kernel", "attn_split_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_kernel")
+NO_SPILL_KERNELS = ("gemm_split_kernel", "gemm_kernel", "attn_split_kernel", "attn_split_pipe_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_kernel")
 
 
 def _check_no_spills(src: str, remarks: str) -> None:
@@ -53,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

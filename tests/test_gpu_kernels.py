@@ -144,3 +144,31 @@ def test_rgb_to_gray_bit_exact(B, H, W):
     out = backend.rgb_to_gray(torch.from_numpy(img).cuda()).cpu().numpy()
     ref = preprocess_gray(img)
     assert out.shape == ref.shape and np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_long_ragged_sequences(cross, precision):
+    """The bench shape (2048 rows per sequence, 32 key tiles: the steady-state, hand-interleaved iterations of
+    attn_split_pipe_kernel run 14 times) with ragged counts -- full, one key short of a tile, one key into a tile, a
+    single tile, odd and even tile counts -- poisoned padding and a spiked key that moves the running maximum late."""
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(9)
+    S, Hh, R = 6, 4, 2048
+    cnt = torch.tensor([2048, 1999, 1025, 64, 1984, 1857], dtype=torch.int32)
+    q = torch.randn(S, Hh, R, 64, generator=g) * 0.6
+    k = torch.randn(S, Hh, R, 64, generator=g)
+    v = torch.randn(S, Hh, R, 64, generator=g)
+    k[:, :, 1000] *= 3.0  # late spike: the O / l rescale branch fires in the middle of the sequence
+    for s in range(S):
+        k[s, :, cnt[s]:] = float("nan")
+        v[s, :, cnt[s]:] = float("inf")
+    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), cross).cpu().view(S, R, Hh, 64)
+    for s in range(S):
+        ks = s ^ 1 if cross else s
+        nq, nk = int(cnt[s]), int(cnt[ks])
+        att = torch.softmax(q[s, :, :nq].double() @ k[ks, :, :nk].double().transpose(-1, -2), -1)
+        ref = (att @ v[ks, :, :nk].double()).float().permute(1, 0, 2)
+        got = out[s, :nq]
+        assert torch.isfinite(got).all(), f"sequence {s}"
+        assert (got - ref).abs().max().item() < 3e-5, f"sequence {s}: {(got - ref).abs().max().item():.2e}"
