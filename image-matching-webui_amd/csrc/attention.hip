@@ -9,8 +9,6 @@
 // touch only that lane (plus one cross-half exchange), and the S^T accumulator registers are
 // already the B operand of the second product (its k index = key = the register's row).
 // K/V tiles of 64 keys are prefetched through registers while the previous tile is multiplied.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "attention.h"
@@ -424,20 +422,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     }
 }
 
-// attention_pipe.hip: the software-pipelined split kernel (one wave per SIMD)
-void attention_pipe_launch(const AttnP& p, hipStream_t stream);
-
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (p.rows_per_seq % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.nseq <= 0) return IMCUI_OK;
     if ((p.heads * p.nseq) % 8 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: heads*nseq=%d must be a multiple of 8", p.heads * p.nseq);
     dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
-    // IMCUI_ATTN_PIPE=0 selects the older two-workgroups-per-CU split kernel (kept for A/B measurements)
-    static const bool use_pipe = !(getenv("IMCUI_ATTN_PIPE") && atoi(getenv("IMCUI_ATTN_PIPE")) == 0);
-    if (h->precision == 1 && use_pipe)
-        attention_pipe_launch(p, stream);
-    else if (h->precision == 1)
+    if (h->precision == 1)
         hipLaunchKernelGGL(attn_split_kernel, grid, dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);

@@ -590,6 +590,46 @@ def rgb_to_gray(rgb_u8: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_area_tables: dict = {}
+
+
+def _area_table(ssize: int, dsize: int, device: torch.device):
+    """OpenCV INTER_AREA decimation table ssize -> dsize as device tensors (start [dsize+1], index, weight); cached."""
+    key = (ssize, dsize, str(device))
+    if key not in _area_tables:
+        lib = load_library()
+        start = np.zeros(dsize + 1, dtype=np.int32)
+        n = lib.imcui_hip_area_table(ssize, dsize, start.ctypes.data, None, None)
+        if n <= 0:
+            raise ImcuiHipError(f"area table {ssize} -> {dsize}: only shrinking resizes are supported")
+        idx, wgt = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.float32)
+        lib.imcui_hip_area_table(ssize, dsize, start.ctypes.data, idx.ctypes.data, wgt.ctypes.data)
+        _area_tables[key] = tuple(torch.from_numpy(a).to(device) for a in (start, idx, wgt))
+    return _area_tables[key]
+
+
+def preprocess_area(img_u8: torch.Tensor, size) -> torch.Tensor:
+    """Device-side `extract.preprocess` with a resize (extract_features.py:120-148): uint8 [B,H,W] / [B,H,W,1] gray or
+    [B,H,W,3] RGB on the device -> gray (cv2 fixed point) -> float32 -> cv2.INTER_AREA to `size` = (w, h) -> / 255 ->
+    float32 [B,1,h,w].  Shrinking resizes only."""
+    if img_u8.dtype != torch.uint8 or img_u8.dim() not in (3, 4):
+        raise ImcuiHipError("preprocess_area expects uint8 [B,H,W] or [B,H,W,C]")
+    if img_u8.dim() == 3:
+        img_u8 = img_u8[..., None]
+    hd = get_handle(img_u8.device)
+    img_u8 = img_u8.contiguous()
+    B, H, W, Cc = img_u8.shape
+    ow, oh = int(size[0]), int(size[1])
+    out = torch.empty((B, 1, oh, ow), dtype=torch.float32, device=img_u8.device)
+    tabs = [None] * 6
+    if not (W % ow == 0 and H % oh == 0) and ow <= W and oh <= H:
+        tabs = [*_area_table(W, ow, img_u8.device), *_area_table(H, oh, img_u8.device)]
+    with torch.cuda.device(img_u8.device):
+        hd.check(hd.lib.imcui_hip_preprocess_area_f32(hd.h, _ptr(img_u8), B, H, W, Cc, *[_ptr(t) for t in tabs], _ptr(out), oh, ow, _stream_ptr()),
+                 "preprocess_area")
+    return out
+
+
 def pack_linear_split(w: torch.Tensor):
     """Host: nn.Linear weight [N, K] -> (hi, lo) uint16 fragment-major planes and the inverse scale 2^-e."""
     from .lib_loader import load_library

@@ -8,9 +8,10 @@ grouped by image size (the C ABI normalises key-points with one (W, H) per call)
 batches, and every pair's `matches0` (int16) / `matching_scores0` (float16) goes to a sink in the reference's
 on-disk layout (`writer_fn` :73-83: group `name0/name1`).
 
-The HDF5 store / sink need `h5py` (the reference's own dependency, requirements.txt); they raise ImportError when
-it is missing -- there is no silent alternative format.  `DictFeatureStore` / `DictMatchSink` are the in-memory
-equivalents used by pipelines that keep features resident and by the tests.
+The HDF5 store / sink open files through `utils.h5lite.open_h5`: `h5py` (the reference's own dependency) when it is
+installed, the HDF5 C library through ctypes otherwise -- real HDF5 files either way, ImportError when neither exists
+(there is no silent alternative format).  `DictFeatureStore` / `DictMatchSink` are the in-memory equivalents used by
+pipelines that keep features resident and by the tests.
 """
 from __future__ import annotations
 
@@ -20,6 +21,8 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from .utils.h5lite import open_h5
 
 
 # ------------------------------------------------------------------ pair lists (imcui/hloc/utils/parsers.py:43-63)
@@ -82,22 +85,17 @@ class H5FeatureStore:
     """The reference's feature file: one group per image with `keypoints`, `scores`, `descriptors`, `image_size`."""
 
     def __init__(self, path):
-        import h5py  # noqa: F401  (ImportError here is the loud failure: no alternative format)
-
         self.path = Path(path)
         if not self.path.exists():
             raise FileNotFoundError(f"Feature file {self.path}.")
+        open_h5(self.path, "r").close()  # ImportError here is the loud failure: no alternative format
 
     def __contains__(self, name):
-        import h5py
-
-        with h5py.File(str(self.path), "r", libver="latest") as fd:
+        with open_h5(self.path, "r") as fd:
             return name in fd
 
     def get(self, name: str) -> dict:
-        import h5py
-
-        with h5py.File(str(self.path), "r", libver="latest") as fd:
+        with open_h5(self.path, "r") as fd:
             return {k: v.__array__() for k, v in fd[name].items()}
 
 
@@ -121,23 +119,18 @@ class H5MatchSink:
     """The reference's match file (imcui/hloc/match_features.py:73-83)."""
 
     def __init__(self, path):
-        import h5py  # noqa: F401
-
         self.path = Path(path)
         self.path.parent.mkdir(exist_ok=True, parents=True)
+        open_h5(self.path, "a").close()
 
     def __contains__(self, pair):
-        import h5py
-
         if not self.path.exists():
             return False
-        with h5py.File(str(self.path), "r", libver="latest") as fd:
+        with open_h5(self.path, "r") as fd:
             return pair in fd
 
     def put(self, pair: str, matches0: np.ndarray, scores0: Optional[np.ndarray]):
-        import h5py
-
-        with h5py.File(str(self.path), "a", libver="latest") as fd:
+        with open_h5(self.path, "a") as fd:
             if pair in fd:
                 del fd[pair]
             grp = fd.create_group(pair)

@@ -31,6 +31,8 @@ SIGNATURES = {
     "imcui_hip_get_precision": (C.c_int, [C.c_void_p]),
     "imcui_hip_conv3x3_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_rgb_to_gray_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "imcui_hip_area_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "imcui_hip_preprocess_area_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_linear_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_linear_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
     "imcui_hip_conv3x3_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]),

@@ -228,6 +228,18 @@ float imcui_hip_conv3x3_pack_split(const float* w_oihw, int Cout, int Cin, unsig
  * rgb: uint8 [B,H,W,3] (interleaved, as decoded), out: float32 [B,1,H,W].  H*W % 4 == 0. */
 int imcui_hip_rgb_to_gray_f32(imcui_hip_t* h, const unsigned char* rgb_hwc, float* out, int B, int H, int W, void* stream);
 
+/* The same step WITH a resize (imcui/hloc/extract_features.py:26-40 `resize_image(.., "cv2_area")`, :80-99, :120-148):
+ *   uint8 [B,H,W,C] (C = 1 gray, C = 3 RGB interleaved) -> [cv2 RGB2GRAY fixed point] -> float32 -> cv2.resize(INTER_AREA)
+ *   to oh x ow -> / 255.0 -> out float32 [B,1,oh,ow].  Shrinking only (the reference switches to INTER_LINEAR when a side
+ * grows: IMCUI_HIP_ERR_UNSUPPORTED).  Non-integer factors use OpenCV's decimation tables, built on the HOST by
+ * imcui_hip_area_table(ssize, dsize, start[dsize+1], index, weight) (returns the entry count; call it with
+ * index = weight = NULL first to size the arrays) and uploaded by the caller: x tables for W -> ow, y tables for H -> oh
+ * (NULL for integer factors).  float32 arithmetic in OpenCV's order; equals oracle/preprocess.py bit for bit. */
+int imcui_hip_area_table(int ssize, int dsize, int* start, int* index, float* weight);
+int imcui_hip_preprocess_area_f32(imcui_hip_t* h, const unsigned char* src, int B, int H, int W, int C, const int* xstart,
+                                  const int* xindex, const float* xweight, const int* ystart, const int* yindex,
+                                  const float* yweight, float* out, int oh, int ow, void* stream);
+
 /* nn.Linear weight [N][K] (K % 16 == 0) -> f16 hi / lo planes of w * 2^e in the FRAGMENT-MAJOR order the split GEMM
  * streams ([ceil(N/32)][K/16][2][32][8] halves per plane, rows >= N zero: each 1 KiB block is one MFMA operand
  * fragment of a wave); returns 2^-e (0 on bad arguments).  Planes hold roundup(N,32) * K halves each. */
