@@ -1,0 +1,183 @@
+"""Batched feature-extraction driver on the HIP plugins (SURVEY.md section 8f rank 2 + 3).
+
+What `imcui/hloc/extract_features.py:174-248` (`main`) does one image per `model(data)` call, done here with B images
+per `forward_batched` call and the preprocessing on the device:
+
+  * image list / skipping of already exported names: `ImageDataset.__init__` (:53-77) and `list_h5_names`
+    (utils/io.py:24-37) semantics;
+  * preprocessing (`ImageDataset.__getitem__` :79-103): decode (host, PIL or cv2), gray conversion, optional
+    `resize_max` / `force_resize` with "cv2_area" interpolation, `/ 255` -- the arithmetic runs on the GPU
+    (`backend.preprocess_area`: cv2's 8-bit RGB2GRAY fixed point + INTER_AREA decimation + float32 division);
+  * images of equal preprocessed size are batched; key-points are mapped back to the original resolution with
+    `(k + 0.5) * scales - 0.5` (:212-215), `uncertainty = detection_noise * scales.mean()` (:219), float32 -> float16
+    when `as_half` (:221-225);
+  * one HDF5 group per image with a dataset per tensor + `image_size`, `keypoints.attrs["uncertainty"]` (:227-235),
+    through `utils.h5lite.open_h5` (h5py when installed, the HDF5 C library otherwise).
+
+Differences from the reference, all on the host side of the boundary: colour images are decoded as RGB and reduced to
+gray with cv2's `cvtColor` fixed-point formula (the reference lets `cv2.imread(IMREAD_GRAYSCALE)` do it inside the
+decoder); a resize that GROWS a side (the reference switches to INTER_LINEAR there, :30-31) is not offered on the device
+and raises.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import backend
+from .utils.h5lite import open_h5
+
+GLOBS = ["*.jpg", "*.png", "*.jpeg", "*.JPG", "*.PNG"]  # ImageDataset.default_conf["globs"]
+DEFAULT_PREPROCESSING = {"globs": GLOBS, "grayscale": False, "resize_max": None, "force_resize": False, "interpolation": "cv2_area"}
+
+
+def list_h5_names(path) -> List[str]:
+    """Names of the groups that hold datasets (imcui/hloc/utils/io.py:24-37)."""
+    names = []
+    with open_h5(path, "r") as fd:
+
+        def visit(name, obj):
+            if hasattr(obj, "shape") and hasattr(obj, "dtype"):  # a dataset
+                names.append(name.rsplit("/", 1)[0].strip("/"))
+
+        fd.visititems(visit)
+    return list(dict.fromkeys(names))
+
+
+def read_image_u8(path) -> np.ndarray:
+    """Decoded image as uint8 [H,W] (gray files) or [H,W,3] RGB."""
+    try:
+        import cv2
+
+        img = cv2.imread(str(path), cv2.IMREAD_UNCHANGED)
+        if img is None:
+            raise ValueError(f"Cannot read image {path}.")
+        if img.ndim == 3:
+            img = img[:, :, :3][:, :, ::-1]  # BGR(A) -> RGB
+        return np.ascontiguousarray(img.astype(np.uint8))
+    except ImportError:
+        from PIL import Image
+
+        with Image.open(str(path)) as im:
+            if im.mode not in ("L", "RGB"):
+                im = im.convert("RGB")
+            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+
+
+def image_names(root: Path, conf: SimpleNamespace, paths=None) -> List[str]:
+    """`ImageDataset.__init__` (:53-77): glob the root or take an explicit list; every name must exist."""
+    root = Path(root)
+    if paths is None:
+        found = []
+        for g in conf.globs:
+            found += list(root.glob("**/" + g))
+        if len(found) == 0:
+            raise ValueError(f"Could not find any image in root: {root}.")
+        return [p.relative_to(root).as_posix() for p in sorted(set(found))]
+    if isinstance(paths, (Path, str)):
+        with open(paths, "r") as fh:
+            names = [ln.strip() for ln in fh if ln.strip() and not ln.startswith("#")]
+    else:
+        names = [p.as_posix() if isinstance(p, Path) else p for p in paths]
+    for n in names:
+        if not (root / n).exists():
+            raise ValueError(f"Image {n} does not exists in root: {root}.")
+    return names
+
+
+def target_size(size, conf: SimpleNamespace):
+    """(w, h) after `ImageDataset.__getitem__`'s resize rule (:85-91), or None when the image is kept."""
+    if conf.resize_max and (conf.force_resize or max(size) > conf.resize_max):
+        scale = conf.resize_max / max(size)
+        return tuple(int(round(x * scale)) for x in size)
+    return None
+
+
+def preprocess_on_device(img_u8: np.ndarray, conf: SimpleNamespace, device) -> torch.Tensor:
+    """uint8 [H,W] / [H,W,3] (host) -> float32 [1,1,h,w] in [0,1] on the device, following :79-99."""
+    if not conf.grayscale:
+        raise NotImplementedError("the HIP extractors take gray images (SuperPoint conf `grayscale: True`)")
+    if conf.interpolation != "cv2_area":
+        raise NotImplementedError(f"interpolation {conf.interpolation!r}: only cv2_area runs on the device")
+    t = torch.from_numpy(img_u8).to(device)[None]
+    h, w = img_u8.shape[:2]
+    new = target_size((w, h), conf)
+    if new is None:
+        new = (w, h)
+    if new[0] > w or new[1] > h:
+        raise NotImplementedError(f"resize {w}x{h} -> {new[0]}x{new[1]} grows a side: the reference uses INTER_LINEAR there, not offered on the device")
+    if new == (w, h) and img_u8.ndim == 3:
+        return backend.rgb_to_gray(t) if (h * w) % 4 == 0 else backend.preprocess_area(t, new)
+    return backend.preprocess_area(t, new)
+
+
+@torch.no_grad()
+def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half: bool = True,
+         image_list: Optional[Union[Path, Sequence[str]]] = None, feature_path: Optional[Path] = None, overwrite: bool = False,
+         model=None, batch_size: int = 32, device="cuda") -> Path:  # fmt: skip
+    """Reference signature (:174-182) + `model` (a loaded HIP extractor plugin; built from conf["model"] when None) and
+    `batch_size` (images per C-ABI call).  Returns the feature file path."""
+    pconf = SimpleNamespace(**{**DEFAULT_PREPROCESSING, **conf.get("preprocessing", {})})
+    image_dir = Path(image_dir)
+    names = image_names(image_dir, pconf, image_list)
+    if feature_path is None:
+        feature_path = Path(export_dir, conf["output"] + ".h5")
+    feature_path = Path(feature_path)
+    feature_path.parent.mkdir(exist_ok=True, parents=True)
+    skip = set(list_h5_names(feature_path) if feature_path.exists() and not overwrite else ())
+    names = [n for n in names if n not in skip]
+    if len(names) == 0:
+        return feature_path
+    if model is None:
+        from . import extractors
+        from .utils.base_model import dynamic_load
+
+        model = dynamic_load(extractors, conf["model"]["name"])(conf["model"]).eval().to(device)
+    device = next(model.buffers()).device
+    noise = getattr(model, "detection_noise", 1)
+
+    pending: Dict[tuple, list] = {}  # preprocessed (h, w) -> [(name, image tensor, original size)]
+
+    def flush(key):
+        items = pending.pop(key, [])
+        if not items:
+            return
+        out = model.forward_batched(torch.cat([it[1] for it in items], 0))
+        counts = out["num_keypoints"].tolist()
+        kp, sc, de = out["keypoints"].cpu().numpy(), out["scores"].cpu().numpy(), out["descriptors"].cpu().numpy()
+        with open_h5(feature_path, "a") as fd:
+            for b, (name, img, original_size) in enumerate(items):
+                n = counts[b]
+                size = np.array(img.shape[-2:][::-1])
+                scales = (original_size / size).astype(np.float32)
+                pred = {
+                    "keypoints": (kp[b, :n] + 0.5) * scales[None] - 0.5,
+                    "scores": sc[b, :n],
+                    "descriptors": np.ascontiguousarray(de[b, :n].T),  # [256, N] like the reference plugin
+                    "image_size": original_size,
+                }
+                uncertainty = noise * scales.mean()
+                if as_half:
+                    pred = {k: (v.astype(np.float16) if v.dtype == np.float32 else v) for k, v in pred.items()}
+                if name in fd:
+                    del fd[name]
+                grp = fd.create_group(name)
+                for k, v in pred.items():
+                    grp.create_dataset(k, data=v)
+                grp["keypoints"].attrs["uncertainty"] = uncertainty
+
+    for name in names:
+        img_u8 = read_image_u8(image_dir / name)
+        original_size = np.array(img_u8.shape[:2][::-1])
+        img = preprocess_on_device(img_u8, pconf, device)
+        key = tuple(img.shape[-2:])
+        pending.setdefault(key, []).append((name, img, original_size))
+        if len(pending[key]) >= batch_size:
+            flush(key)
+    for key in list(pending):
+        flush(key)
+    return feature_path

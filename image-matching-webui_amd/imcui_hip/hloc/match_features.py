@@ -121,7 +121,7 @@ class H5MatchSink:
     def __init__(self, path):
         self.path = Path(path)
         self.path.parent.mkdir(exist_ok=True, parents=True)
-        open_h5(self.path, "a").close()
+        open_h5(self.path, "r" if self.path.exists() else "a").close()  # no HDF5 library -> ImportError here, not at the first put()
 
     def __contains__(self, pair):
         if not self.path.exists():

@@ -76,6 +76,7 @@ def _load():
             "H5Pcreate": (hid_t, [hid_t]),
             "H5Pclose": (herr_t, [hid_t]),
             "H5Pset_create_intermediate_group": (herr_t, [hid_t, C.c_uint]),
+            "H5Pset_fclose_degree": (herr_t, [hid_t, C.c_int]),
             "H5Screate_simple": (hid_t, [C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
             "H5Screate": (hid_t, [C.c_int]),
             "H5Sclose": (herr_t, [hid_t]),
@@ -366,14 +367,20 @@ class File(Group):
         lib = _load()
         p = os.fspath(path).encode()
         with _lock:
+            # H5F_CLOSE_STRONG: closing the file closes every group / dataset handle still open on it, so the file (and
+            # its lock) is released at `close()` / the end of a `with` block, like h5py does
+            fapl = lib.H5Pcreate(_global("H5P_CLS_FILE_ACCESS_ID_g"))
+            lib.H5Pset_fclose_degree(fapl, 3)
             if mode == "r":
-                fid = lib.H5Fopen(p, H5F_ACC_RDONLY, H5P_DEFAULT)
+                fid = lib.H5Fopen(p, H5F_ACC_RDONLY, fapl)
             elif mode == "w":
-                fid = lib.H5Fcreate(p, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+                fid = lib.H5Fcreate(p, H5F_ACC_TRUNC, H5P_DEFAULT, fapl)
             elif mode == "a":
-                fid = lib.H5Fopen(p, H5F_ACC_RDWR, H5P_DEFAULT) if os.path.exists(path) else lib.H5Fcreate(p, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT)
+                fid = lib.H5Fopen(p, H5F_ACC_RDWR, fapl) if os.path.exists(path) else lib.H5Fcreate(p, H5F_ACC_EXCL, H5P_DEFAULT, fapl)
             else:
+                lib.H5Pclose(fapl)
                 raise ValueError(f"h5lite: unsupported mode {mode!r}")
+            lib.H5Pclose(fapl)
         if fid < 0:
             raise OSError(f"h5lite: cannot open {path} (mode {mode})")
         super().__init__(fid, "/")

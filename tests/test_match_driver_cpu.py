@@ -98,18 +98,3 @@ def test_batched_driver_equals_per_pair_calls(with_scores):
         assert np.array_equal(got["matches0"], exp["matches0"]) and np.array_equal(got["matching_scores0"], exp["matching_scores0"])
     assert (sink.matches["img2/img3"]["matches0"] == -1).all()  # empty second image
     assert (sink.matches["img0/img1"]["matches0"] > -1).sum() > 5
-
-
-def test_h5_backends_fail_loudly_without_h5py(tmp_path):
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            mf.H5MatchSink(tmp_path / "m.h5")
-        with pytest.raises(ImportError):
-            mf.H5FeatureStore(tmp_path / "f.h5")
-        return
-    # with h5py: the reference's file layout round-trips
-    sink = mf.H5MatchSink(tmp_path / "m.h5")
-    sink.put("a/b", np.array([1, -1], dtype=np.int16), np.array([0.5, 0.0], dtype=np.float16))
-    assert "a/b" in sink and "b/a" not in sink
