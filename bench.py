@@ -169,7 +169,7 @@ def bench_loftr(args, dev, rank, world):
     from imcui_hip.synth_weights import loftr_state_dict  # seeded weights only
 
     Hh, Ww = args.size if args.size else (1024, 1024)
-    B = args.batch if args.batch != 32 else 1
+    B = args.batch
     model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
     base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
@@ -406,7 +406,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 32; loftr: 4)")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
@@ -418,6 +418,8 @@ def main():
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4 if args.workload == "loftr" else 32
 
     if args.workload == "launchcheck":
         return launchcheck(args)

@@ -8,6 +8,9 @@
 #include <math.h>
 
 #include "common.h"
+
+// Built with -ffp-contract=off (imcui_hip/build.py): the table passes must round like the host code they restate --
+// multiply, THEN add -- and hipcc's default would fuse them into FMAs.
 #include "imcui_hip.h"
 
 // OpenCV computeResizeAreaTab (modules/imgproc/src/resize.cpp): entries (source index, weight) per destination index

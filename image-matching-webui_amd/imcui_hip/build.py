@@ -15,8 +15,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
 SOURCES = ["api.hip", "preprocess.hip", "gemm.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
-# Per-source code-generation switches (none needed today; tools/attn_pipe_lab shows what they looked like).
-EXTRA_FLAGS: dict = {}
+# Per-source code-generation switches.  preprocess.hip restates host float32 arithmetic that rounds after every
+# multiply and every add: hipcc's default FMA contraction would change the last bit.
+EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"]}
 
 
 def _newest_source_mtime() -> float:

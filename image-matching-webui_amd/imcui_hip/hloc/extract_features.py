@@ -65,7 +65,7 @@ def read_image_u8(path) -> np.ndarray:
         with Image.open(str(path)) as im:
             if im.mode not in ("L", "RGB"):
                 im = im.convert("RGB")
-            return np.ascontiguousarray(np.asarray(im, dtype=np.uint8))
+            return np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy)
 
 
 def image_names(root: Path, conf: SimpleNamespace, paths=None) -> List[str]:
