@@ -35,6 +35,7 @@ struct LgLayout {
     LgLayerOff L[LG_LAYERS];
     size_t wfinal, bfinal, wmatch, bmatch, wtoken, btoken;
     LgSplit sfinal;  // [9] planes, scale array [9]
+    size_t wr4, winp, binp;  // variants: posenc.Wr with scale / orientation columns [32][4], input_proj [256][<=256] + bias
     size_t total;
 };
 
@@ -93,6 +94,9 @@ static LgLayout lg_layout() {
         o.s2c = take_split(256 * 512);
     }
     l.sfinal = take_split((size_t)LG_LAYERS * 256 * 256);
+    l.wr4 = take(128);
+    l.winp = take(256 * 256);
+    l.binp = take(256);
     l.total = off;
     return l;
 }
@@ -278,6 +282,24 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     return w;
 }
 
+// Variant inputs (upstream LightGlue `features` table: disk / aliked 128-d descriptors -> `input_proj` Linear(input_dim, 256);
+// sift / doghardnet additionally `add_scale_ori`: posenc.Wr takes (x, y, scale, orientation)).  Call after
+// imcui_hip_lightglue_pack_weights on the same host buffer.
+extern "C" int imcui_hip_lightglue_pack_input(const float* wr, int wr_cols, const float* w_input_proj, const float* b_input_proj,
+                                              int input_dim, float* packed) {
+    if (!wr || !packed || (wr_cols != 2 && wr_cols != 4) || input_dim <= 0 || input_dim > 256 || input_dim % 32 != 0) return IMCUI_ERR_ARG;
+    if (input_dim != 256 && (!w_input_proj || !b_input_proj)) return IMCUI_ERR_ARG;
+    const LgLayout l = lg_layout();
+    for (int i = 0; i < 32; ++i)
+        for (int c = 0; c < 4; ++c) packed[l.wr4 + i * 4 + c] = c < wr_cols ? wr[i * wr_cols + c] : 0.0f;
+    if (wr_cols == 2) memcpy(packed + l.wr, wr, 64 * sizeof(float));
+    if (input_dim != 256) {
+        memcpy(packed + l.winp, w_input_proj, (size_t)256 * input_dim * sizeof(float));
+        memcpy(packed + l.binp, b_input_proj, 256 * sizeof(float));
+    }
+    return IMCUI_OK;
+}
+
 extern "C" int imcui_hip_lightglue_set_layer_dump(imcui_hip_t* h, float* dump, size_t floats) {
     if (!h) return IMCUI_ERR_ARG;
     h->lg_dump = dump;
@@ -296,7 +318,10 @@ __global__ __launch_bounds__(256) void lg_init_kernel(const float* __restrict__ 
                                                       const float* __restrict__ d0, const float* __restrict__ d1,
                                                       const int* __restrict__ n0, const int* __restrict__ n1, int ncap,
                                                       int R, float w0, float h0, float w1, float h1,
-                                                      const float* __restrict__ wr, float* __restrict__ x,
+                                                      const float* __restrict__ wr, const float* __restrict__ wr4,
+                                                      const float* __restrict__ sc0, const float* __restrict__ or0,
+                                                      const float* __restrict__ sc1, const float* __restrict__ or1,
+                                                      int copy_desc, float* __restrict__ x,
                                                       float* __restrict__ cs, float* __restrict__ sn,
                                                       int* __restrict__ ind, int* __restrict__ prune, int prune_init,
                                                       int* __restrict__ matches0, int* __restrict__ matches1,
@@ -318,15 +343,23 @@ __global__ __launch_bounds__(256) void lg_init_kernel(const float* __restrict__ 
         }
     }
     if (i >= n) return;
-    const float* d = (img ? d1 : d0) + ((size_t)b * ncap + i) * 256;
-    *reinterpret_cast<float4*>(x + row * 256 + lane * 4) = *reinterpret_cast<const float4*>(d + lane * 4);
+    if (copy_desc) {  // 256-d descriptors: input_proj is the identity
+        const float* d = (img ? d1 : d0) + ((size_t)b * ncap + i) * 256;
+        *reinterpret_cast<float4*>(x + row * 256 + lane * 4) = *reinterpret_cast<const float4*>(d + lane * 4);
+    }
     if (lane < 32) {
         const float* kp = (img ? kp1 : kp0) + ((size_t)b * ncap + i) * 2;
         const float W = img ? w1 : w0, H = img ? h1 : h0;
         // normalize_keypoints: (k - size/2) / (max(size)/2)
         const float scale = fmaxf(W, H) / 2.0f;
         const float kx = (kp[0] - W / 2.0f) / scale, ky = (kp[1] - H / 2.0f) / scale;
-        const float pr = kx * wr[lane * 2 + 0] + ky * wr[lane * 2 + 1];
+        float pr;
+        if (sc0 != nullptr) {  // add_scale_ori: Wr(cat[kpts_normalised, scale, orientation])
+            const float s = (img ? sc1 : sc0)[(size_t)b * ncap + i], o = (img ? or1 : or0)[(size_t)b * ncap + i];
+            pr = kx * wr4[lane * 4 + 0] + ky * wr4[lane * 4 + 1] + s * wr4[lane * 4 + 2] + o * wr4[lane * 4 + 3];
+        } else {
+            pr = kx * wr[lane * 2 + 0] + ky * wr[lane * 2 + 1];
+        }
         cs[row * 32 + lane] = cosf(pr);
         sn[row * 32 + lane] = sinf(pr);
     }
@@ -791,9 +824,11 @@ __global__ __launch_bounds__(256) void lg_filter_kernel(const int* __restrict__ 
 }
 
 // ------------------------------------------------------------------ forward
-extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
-                                           const float* keypoints1, const float* descriptors0,
-                                           const float* descriptors1, const int* n0, const int* n1, float w0, float h0,
+extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, int input_dim,
+                                           const float* keypoints0, const float* keypoints1, const float* descriptors0,
+                                           const float* descriptors1, const float* scales0, const float* oris0,
+                                           const float* scales1, const float* oris1, const int* n0, const int* n1, float w0,
+                                           float h0,
                                            float w1, float h1, double depth_confidence, double width_confidence,
                                            int pruning_threshold, double filter_threshold, int* matches0, int* matches1,
                                            float* mscores0,
@@ -803,6 +838,10 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     if (!h) return IMCUI_ERR_ARG;
     if (B <= 0) return IMCUI_OK;
     if (ncap <= 0) return imcui_set_err(h, IMCUI_ERR_ARG, "lightglue: ncap=%d must be positive", ncap);
+    if (input_dim <= 0 || input_dim > 256 || input_dim % 32 != 0)
+        return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "lightglue: input_dim=%d must be a multiple of 32, at most 256", input_dim);
+    if ((scales0 != nullptr) != (oris0 != nullptr) || (scales0 != nullptr) != (scales1 != nullptr) || (scales0 != nullptr) != (oris1 != nullptr))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "lightglue: scales / oris must be given for both images or not at all");
     if (!packed || !keypoints0 || !keypoints1 || !descriptors0 || !descriptors1 || !n0 || !n1 || !matches0 || !matches1 ||
         !mscores0 || !mscores1 || !stop || !prune0 || !prune1)
         return imcui_set_err(h, IMCUI_ERR_ARG, "lightglue: null argument");
@@ -830,9 +869,33 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     hipLaunchKernelGGL(lg_init_pairs_kernel, dim3(cdiv(B, 64)), dim3(64), 0, stream, n0, n1, B, cnt_cur, w.norig, w.active,
                        stop);
     hipLaunchKernelGGL(lg_init_kernel, rowgrid, blk, 0, stream, keypoints0, keypoints1, descriptors0, descriptors1, n0, n1,
-                       ncap, R, w0, h0, w1, h1, P + l.wr, w.x, w.cs, w.sn, w.ind, w.prune, do_prune ? 1 : LG_LAYERS, matches0,
-                       matches1, mscores0, mscores1, prune0, prune1);
+                       ncap, R, w0, h0, w1, h1, P + l.wr, P + l.wr4, scales0, oris0, scales1, oris1, input_dim == 256 ? 1 : 0, w.x, w.cs,
+                       w.sn, w.ind, w.prune, do_prune ? 1 : LG_LAYERS, matches0, matches1, mscores0, mscores1, prune0, prune1);
     IMCUI_CHECK_LAUNCH(h);
+    if (input_dim != 256) {
+        // upstream `input_proj` = Linear(input_dim, 256): image `img` of pair z -> rows of sequence 2 z + img
+        for (int img = 0; img < 2; ++img) {
+            GemmP g;
+            g.epi = EPI_BIAS;
+            g.batch = B;
+            g.A = img ? descriptors1 : descriptors0;
+            g.lda = input_dim;
+            g.a_bs = (long)ncap * input_dim;
+            g.W = P + l.winp;
+            g.ldw = input_dim;
+            g.bias = P + l.binp;
+            g.C = w.x + (size_t)img * R * 256;
+            g.ldc = 256;
+            g.c_bs = (long)2 * R * 256;
+            g.M = ncap;
+            g.N = 256;
+            g.K = input_dim;
+            g.mcnt = img ? n1 : n0;
+            g.cnt_stride = 1;
+            rc = gemm_launch(h, g, stream);
+            if (rc != IMCUI_OK) return rc;
+        }
+    }
 
     const bool split = h->precision == 1;
     auto base = [&](GemmP& g) {

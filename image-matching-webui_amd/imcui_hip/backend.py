@@ -181,6 +181,15 @@ def _rename_old_lightglue_keys(sd: dict) -> dict:
     return out
 
 
+def lightglue_variant(state_dict: dict) -> tuple[int, bool]:
+    """(input_dim, add_scale_ori) of a LightGlue state dict: upstream's `features` table in the weights themselves --
+    `input_proj` exists when the descriptors are not 256-d (disk / aliked / sift: 128), `posenc.Wr` has 4 input columns
+    when key-point scale and orientation are encoded (sift, doghardnet)."""
+    sd = _rename_old_lightglue_keys(state_dict)
+    input_dim = int(sd["input_proj.weight"].shape[1]) if "input_proj.weight" in sd else 256
+    return input_dim, int(sd["posenc.Wr.weight"].shape[1]) == 4
+
+
 def pack_lightglue(state_dict: dict) -> torch.Tensor:
     lib = load_library()
     sd = _rename_old_lightglue_keys(state_dict)
@@ -190,13 +199,22 @@ def pack_lightglue(state_dict: dict) -> torch.Tensor:
         if n not in sd:
             raise ImcuiHipError(f"LightGlue state dict lacks '{n}'")
         arrs.append(_as_f32_host(sd[n]))
-    if arrs[0].shape != (32, 2) or arrs[1].shape != (768, 256):
-        raise ImcuiHipError("only the 256-d / 4-head / 9-layer LightGlue (superpoint) is supported")
+    input_dim, scale_ori = lightglue_variant(sd)
+    if arrs[0].shape not in ((32, 2), (32, 4)) or arrs[1].shape != (768, 256) or input_dim % 32 or input_dim > 256:
+        raise ImcuiHipError("only the 256-d / 4-head / 9-layer LightGlue (descriptor input 32..256, optional scale / orientation) is supported")
     packed = np.zeros(lib.imcui_hip_lightglue_packed_floats(), dtype=np.float32)
+    wr = arrs[0]
+    arrs[0] = np.ascontiguousarray(wr[:, :2])  # the base packer takes the (x, y) columns; pack_input stores all of them
     tp = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
     rc = lib.imcui_hip_lightglue_pack_weights(tp, packed.ctypes.data)
     if rc != 0:
         raise ImcuiHipError(f"imcui_hip_lightglue_pack_weights failed ({rc})")
+    wi = _as_f32_host(sd["input_proj.weight"]) if input_dim != 256 else None
+    bi = _as_f32_host(sd["input_proj.bias"]) if input_dim != 256 else None
+    rc = lib.imcui_hip_lightglue_pack_input(wr.ctypes.data, wr.shape[1], None if wi is None else wi.ctypes.data,
+                                            None if bi is None else bi.ctypes.data, input_dim, packed.ctypes.data)  # fmt: skip
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_lightglue_pack_input failed ({rc})")
     return torch.from_numpy(packed)
 
 
@@ -206,8 +224,9 @@ class LightGlueHIP:
         self._lock = threading.Lock()
 
     def forward(self, packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, depth_confidence, width_confidence,
-                filter_threshold, pruning_threshold: int = -1, layer_dump: bool = False):  # fmt: skip
-        """kptsX [B,ncap,2], descX [B,ncap,256] (row per point), nX [B] int32 on the GPU; sizeX = (W, H).
+                filter_threshold, pruning_threshold: int = -1, layer_dump: bool = False, scales_oris=None):  # fmt: skip
+        """kptsX [B,ncap,2], descX [B,ncap,D] (row per point; D = the weights' input_dim), nX [B] int32 on the GPU;
+        sizeX = (W, H); scales_oris = (scales0, oris0, scales1, oris1) [B,ncap] for add_scale_ori weights.
         pruning_threshold: upstream pruning_keypoint_thresholds[device] (-1 = the CPU path: always prune).
         layer_dump (parity tests): also return `_layers` [9, 2B, R, 256], the token states after every layer."""
         dev = kpts0.device
@@ -227,6 +246,8 @@ class LightGlueHIP:
             return o
 
         kpts0, kpts1, desc0, desc1 = pad(kpts0, ncap), pad(kpts1, ncap), pad(desc0, ncap), pad(desc1, ncap)
+        input_dim = desc0.shape[2]
+        so = [None] * 4 if scales_oris is None else [pad(t, ncap) for t in scales_oris]
         n0 = n0.to(device=dev, dtype=torch.int32).contiguous()
         n1 = n1.to(device=dev, dtype=torch.int32).contiguous()
         m0 = torch.empty((B, ncap), dtype=torch.int32, device=dev)
@@ -246,7 +267,8 @@ class LightGlueHIP:
                     hd.check(lib.imcui_hip_lightglue_set_layer_dump(hd.h, _ptr(dump), dump.numel()), "set_layer_dump")
                 try:
                     rc = lib.imcui_hip_lightglue_forward(
-                        hd.h, _ptr(packed), B, ncap, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1), _ptr(n0), _ptr(n1),
+                        hd.h, _ptr(packed), B, ncap, input_dim, _ptr(kpts0), _ptr(kpts1), _ptr(desc0), _ptr(desc1),
+                        _ptr(so[0]), _ptr(so[1]), _ptr(so[2]), _ptr(so[3]), _ptr(n0), _ptr(n1),
                         float(size0[0]), float(size0[1]), float(size1[0]), float(size1[1]),
                         float(depth_confidence), float(width_confidence), int(pruning_threshold), float(filter_threshold),
                         _ptr(m0), _ptr(m1), _ptr(s0), _ptr(s1), _ptr(stop), _ptr(p0), _ptr(p1), _ptr(ws), ws.numel(), _stream_ptr(),

@@ -1,5 +1,9 @@
 """LightGlue matcher plugin on the MI355X HIP backend.
 
+Covers the zoo's LightGlue entries (imcui/hloc/configs/matchers.py:34-83,140-170): superpoint- / minima_ (256-d),
+disk- / aliked- / raco- (128-d descriptors through `input_proj`) and sift-lightglue (128-d + key-point scale and
+orientation in the positional encoding).
+
 Drop-in for imcui/hloc/matchers/lightglue.py: module name `lightglue`, same `default_conf`
 (:15-25), `required_inputs` (:26-35), `filter_threshold = match_threshold` (:50) and flat input
 keys (:54-70: descriptors arrive [B,D,N] and are permuted to [B,N,D]).  The arithmetic (:75 ->
@@ -45,25 +49,31 @@ class LightGlue(BaseModel):
     ]
 
     def _init(self, conf):
-        if conf["features"] != "superpoint" or conf["add_scale_ori"]:
-            raise NotImplementedError("the HIP LightGlue backend covers the 256-d superpoint variant")
         sd = resolve_state_dict(conf, "lightglue")
+        # upstream's `features` table lives in the weights: input_dim (superpoint 256; disk / aliked / raco-aliked / sift 128)
+        # and add_scale_ori (sift, doghardnet) are read from the state dict, conf["features"] only names the checkpoint
+        self.input_dim, self.add_scale_ori = backend.lightglue_variant(sd)
         conf.pop("state_dict", None)
         self.conf.pop("state_dict", None)
         self.conf["filter_threshold"] = conf["match_threshold"]
         self.register_buffer("packed", backend.pack_lightglue(sd), persistent=False)
         self._impl = backend.LightGlueHIP()
 
-    def forward_batched(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, layer_dump: bool = False) -> dict:
-        """Row-per-point descriptors [B,N,256]; n0/n1 [B] int32 valid counts; sizes (W, H).
-        Fixed-stride int32 outputs, no host synchronisation."""
+    def forward_batched(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, layer_dump: bool = False, scales_oris=None) -> dict:
+        """Row-per-point descriptors [B,N,input_dim]; n0/n1 [B] int32 valid counts; sizes (W, H); scales_oris =
+        (scales0, oris0, scales1, oris1) [B,N] when the weights encode them.  Fixed-stride int32 outputs, no host sync."""
         c = self.conf
+        if desc0.shape[-1] != self.input_dim or desc1.shape[-1] != self.input_dim:
+            raise backend.ImcuiHipError(f"these LightGlue weights take {self.input_dim}-d descriptors, got {desc0.shape[-1]} / {desc1.shape[-1]}")
+        if self.add_scale_ori != (scales_oris is not None):
+            raise backend.ImcuiHipError("key-point scales / orientations must be given exactly when the weights were trained with add_scale_ori")
         pd = c.get("pruning_device", "cpu")
         pth = self.PRUNING_KEYPOINT_THRESHOLDS[pd] if isinstance(pd, str) else int(pd)
         # the UI mutates match_threshold at run time (imcui/ui/utils.py:921-922)
         return self._impl.forward(
             self.packed, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1,
             c["depth_confidence"], c["width_confidence"], c["match_threshold"], pruning_threshold=pth, layer_dump=layer_dump,
+            scales_oris=scales_oris,
         )  # fmt: skip
 
     def _forward(self, data):
@@ -77,7 +87,10 @@ class LightGlue(BaseModel):
         size1 = tuple(data["image1"].shape[-2:][::-1])
         n0 = torch.full((B,), m, dtype=torch.int32, device=dev)
         n1 = torch.full((B,), n, dtype=torch.int32, device=dev)
-        out = self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1)
+        so = None
+        if self.add_scale_ori:  # imcui/hloc/matchers/lightglue.py:62-73 forwards them when the extractor provides them
+            so = tuple(data[k] for k in ("scales0", "oris0", "scales1", "oris1"))
+        out = self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, scales_oris=so)
         m0, m1 = out["matches0"].long(), out["matches1"].long()
         ms0, ms1 = out["matching_scores0"], out["matching_scores1"]
         matches, mscores = [], []

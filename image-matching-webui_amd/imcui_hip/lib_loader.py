@@ -55,10 +55,11 @@ SIGNATURES = {
     "imcui_hip_lightglue_tensor_name": (C.c_char_p, [C.c_int]),
     "imcui_hip_lightglue_pack_weights": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
     "imcui_hip_lightglue_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "imcui_hip_lightglue_pack_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "imcui_hip_lightglue_forward": (
         C.c_int,
-        [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-        + [C.c_void_p] * 6
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        + [C.c_void_p] * 10
         + [C.c_float] * 4
         + [C.c_double, C.c_double, C.c_int, C.c_double]
         + [C.c_void_p] * 7

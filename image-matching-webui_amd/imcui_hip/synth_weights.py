@@ -72,7 +72,8 @@ def _mean_descriptor_logits(sd: dict, g: torch.Generator) -> torch.Tensor:
 
 
 def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads: int = 4, structured: bool = True,
-                         damp: float | None = None, ln_noise: float | None = None, final_gain: float | None = None) -> dict:
+                         damp: float | None = None, ln_noise: float | None = None, final_gain: float | None = None,
+                         input_dim: int = 256, add_scale_ori: bool = False) -> dict:
     """Random LightGlue weights in the upstream (new-style) key layout.
 
     transformers.{i}.self_attn.{Wqkv,out_proj,ffn.0,ffn.1,ffn.3}
@@ -148,6 +149,14 @@ def lightglue_state_dict(seed: int = 0, n_layers: int = 9, dim: int = 256, heads
                 sd[t + ".bias"] = sd[t + ".bias"] + 1.2 + 0.4 * i
             else:
                 sd.update(lin(1, dim, scale=2.0, prefix=t))
+    # variants of upstream's `features` table, drawn last so that the 256-d superpoint tensors above do not change
+    if add_scale_ori:
+        sd["posenc.Wr.weight"] = torch.cat([sd["posenc.Wr.weight"], 0.3 * torch.randn(head_dim // 2, 2, generator=g)], 1)
+    if input_dim != dim:
+        # disk / aliked / sift: Linear(input_dim, 256); a scaled partial isometry + noise keeps distinctive descriptors distinctive
+        q, _ = torch.linalg.qr(torch.randn(dim, input_dim, generator=g))
+        sd["input_proj.weight"] = q + 0.02 * torch.randn(dim, input_dim, generator=g)
+        sd["input_proj.bias"] = 0.01 * torch.randn(dim, generator=g)
     return sd
 
 

@@ -113,10 +113,18 @@ size_t imcui_hip_lightglue_packed_floats(void);
 int imcui_hip_lightglue_num_tensors(void);
 const char* imcui_hip_lightglue_tensor_name(int i); /* upstream state-dict key of tensor i */
 int imcui_hip_lightglue_pack_weights(const float* const* tensors, float* packed);
+/* Variants of upstream's `features` table (imcui/hloc/configs/matchers.py:51-83,140-150: disk- / aliked- / raco- /
+ * sift-lightglue).  Call after imcui_hip_lightglue_pack_weights on the same host buffer:
+ *   wr [32][wr_cols]: posenc.Wr.weight, wr_cols = 2, or 4 with add_scale_ori (sift, doghardnet: (x, y, scale, orientation));
+ *   w_input_proj [256][input_dim], b_input_proj [256]: `input_proj` when input_dim != 256 (128 for disk / aliked / sift);
+ *   input_dim: descriptor size, a multiple of 32 and at most 256. */
+int imcui_hip_lightglue_pack_input(const float* wr, int wr_cols, const float* w_input_proj, const float* b_input_proj, int input_dim,
+                                   float* packed);
 
 size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap);
 
-/* B pairs.  keypoints0/1 [dev, B,ncap,2] pixel (x,y); descriptors0/1 [dev, B,ncap,256];
+/* B pairs.  keypoints0/1 [dev, B,ncap,2] pixel (x,y); descriptors0/1 [dev, B,ncap,input_dim] (256 for SuperPoint);
+ * scales0/1, oris0/1 [dev, B,ncap] or all NULL: only for weights with add_scale_ori (lightglue.py:62-73 passes them on);
  * n0/n1 [dev, B] int32 valid counts (<= ncap).  size0/size1: (W,H) of the images the key-points
  * live in (only used to normalise key-points, lightglue.py passes `image.shape`).
  * depth_confidence / width_confidence <= 0 disable early stopping / point pruning;
@@ -128,8 +136,9 @@ size_t imcui_hip_lightglue_workspace_bytes(int B, int ncap);
  * (e.g. `1 - width_confidence` is formed in double before the fp32 cast).
  * Outputs [dev]: matches0/1 [B,ncap] int32 (-1 = unmatched), matching_scores0/1 [B,ncap],
  * stop [B] int32 (layers run), prune0/1 [B,ncap] int32.  Entries >= n are -1 / 0. */
-int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, const float* keypoints0,
+int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, int B, int ncap, int input_dim, const float* keypoints0,
                                 const float* keypoints1, const float* descriptors0, const float* descriptors1,
+                                const float* scales0, const float* oris0, const float* scales1, const float* oris1,
                                 const int* n0, const int* n1, float w0, float h0, float w1, float h1,
                                 double depth_confidence, double width_confidence, int pruning_threshold,
                                 double filter_threshold, int* matches0, int* matches1, float* matching_scores0,

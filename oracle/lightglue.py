@@ -190,7 +190,12 @@ class LightGlueOracle:
         size1 = data["image1"].shape[-2:][::-1]
         kpts0 = normalize_keypoints(kpts0, size0).clone()
         kpts1 = normalize_keypoints(kpts1, size1).clone()
-        # input_proj is Identity for 256-d SuperPoint descriptors
+        if self.sd["posenc.Wr.weight"].shape[1] == 4:  # add_scale_ori (upstream: sift, doghardnet)
+            kpts0 = torch.cat([kpts0, data["scales0"].float().cpu().unsqueeze(-1), data["oris0"].float().cpu().unsqueeze(-1)], -1)
+            kpts1 = torch.cat([kpts1, data["scales1"].float().cpu().unsqueeze(-1), data["oris1"].float().cpu().unsqueeze(-1)], -1)
+        # input_proj is Identity for 256-d SuperPoint descriptors, Linear(input_dim, 256) otherwise (disk, aliked, sift: 128)
+        if "input_proj.weight" in self.sd:
+            desc0, desc1 = self._lin(desc0, "input_proj"), self._lin(desc1, "input_proj")
         encoding0 = self.posenc(kpts0)
         encoding1 = self.posenc(kpts1)
 

@@ -157,6 +157,61 @@ def test_lightglue_gpu_pruning_thresholds_vs_oracle():
         assert pruned_any or dev_name == "flash"
 
 
+@pytest.mark.parametrize("add_scale_ori", [False, True], ids=["disk-aliked-128d", "sift-128d-scale-ori"])
+def test_lightglue_variants_vs_oracle(add_scale_ori, precision):
+    """The zoo's other LightGlue entries (configs/matchers.py:51-83,140-150): 128-d descriptors through `input_proj`
+    (disk- / aliked- / raco-lightglue) and, for sift-lightglue, key-point scale + orientation in the positional encoding."""
+    import torch.nn.functional as F
+
+    torch.set_num_threads(8)
+    sd = lightglue_state_dict(0, input_dim=128, add_scale_ori=add_scale_ori)
+    g = torch.Generator().manual_seed(11)
+    problems, extras = [], []
+    for n, m, n_out in [(700, 650, 150), (130, 257, 30), (1024, 900, 300)]:
+        a, c, e, f = synthetic_matching_problem(60 + n, n, m, n_out)
+        proj = torch.randn(256, 128, generator=g) / 16.0  # 128-d descriptors with the same correspondences
+        problems.append((a, c, F.normalize(e @ proj, dim=1), F.normalize(f @ proj, dim=1)))
+        extras.append((torch.rand(n, generator=g) * 4 + 1, torch.rand(n, generator=g) * 6.28, torch.rand(m, generator=g) * 4 + 1, torch.rand(m, generator=g) * 6.28))
+    B = len(problems)
+    ncap = max(max(p[0].shape[0], p[1].shape[0]) for p in problems)
+    k0, k1 = torch.zeros(B, ncap, 2), torch.zeros(B, ncap, 2)
+    d0, d1 = torch.zeros(B, ncap, 128), torch.zeros(B, ncap, 128)
+    so = [torch.zeros(B, ncap) for _ in range(4)]
+    n0, n1 = torch.zeros(B, dtype=torch.int32), torch.zeros(B, dtype=torch.int32)
+    for b, ((a, c, e, f), ex) in enumerate(zip(problems, extras)):
+        k0[b, : len(a)], k1[b, : len(c)], d0[b, : len(a)], d1[b, : len(c)] = a, c, e, f
+        n0[b], n1[b] = len(a), len(c)
+        for t, v in zip(so, ex):
+            t[b, : len(v)] = v
+    model = _model(0.95, 0.99, sd=sd)
+    assert model.input_dim == 128 and model.add_scale_ori == add_scale_ori
+    out = model.forward_batched(k0.cuda(), k1.cuda(), d0.cuda(), d1.cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480),
+                                scales_oris=tuple(t.cuda() for t in so) if add_scale_ori else None)  # fmt: skip
+    torch.cuda.synchronize()
+    out = {k: v.cpu() for k, v in out.items()}
+    ora = LightGlueOracle(sd, dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1))
+    total = 0
+    for b, ((a, c, e, f), ex) in enumerate(zip(problems, extras)):
+        data = {"image0": IMG, "image1": IMG, "keypoints0": a[None], "keypoints1": c[None], "descriptors0": e.t()[None], "descriptors1": f.t()[None]}
+        if add_scale_ori:
+            data.update(scales0=ex[0][None], oris0=ex[1][None], scales1=ex[2][None], oris1=ex[3][None])
+        ref = ora(data, return_intermediates=True)
+        na, nc = len(a), len(c)
+        tag = f"variant pair {b}"
+        assert int(out["stop"][b]) == ref["stop"], tag
+        assert torch.equal(out["prune0"][b, :na].long(), ref["prune0"][0].long()), tag
+        assert_matches_equal_or_tied(out["matches0"][b, :na], ref["_log_assignment"][0], ref["matches0"][0], 0.1, tag=tag, ind0=ref.get("_ind0"), ind1=ref.get("_ind1"))
+        same = out["matches0"][b, :na].long() == ref["matches0"][0]
+        assert (out["matching_scores0"][b, :na] - ref["matching_scores0"][0]).abs()[same].max().item() < 1e-4, tag
+        total += int((ref["matches0"] > -1).sum())
+    assert total > 100
+    # wrong descriptor size / missing scales fail loudly
+    from imcui_hip import ImcuiHipError
+
+    with pytest.raises(ImcuiHipError):
+        model.forward_batched(k0.cuda(), k1.cuda(), torch.zeros(B, ncap, 256).cuda(), torch.zeros(B, ncap, 256).cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480))
+
+
 def test_lightglue_plugin_contract_and_empty():
     """Flat hloc dict in (descriptors [B,256,N]) -> reference keys out; empty side -> all -1."""
     a, c, e, f = synthetic_matching_problem(3, 300, 280, 60)

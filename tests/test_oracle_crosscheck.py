@@ -84,12 +84,15 @@ def test_superpoint_oracle_vs_hf(nms_radius, max_kpts):
 def _hf_lightglue(lsd, dc, wc, th):
     from transformers import LightGlueConfig, LightGlueForKeypointMatching, SuperPointConfig
 
+    input_dim = lsd["input_proj.weight"].shape[1] if "input_proj.weight" in lsd else 256
     cfg = LightGlueConfig(
-        keypoint_detector_config=SuperPointConfig(), depth_confidence=dc, width_confidence=wc, filter_threshold=th
+        keypoint_detector_config=SuperPointConfig(descriptor_decoder_dim=input_dim), depth_confidence=dc, width_confidence=wc, filter_threshold=th
     )
     hf = LightGlueForKeypointMatching(cfg).eval()
     m = {k: v for k, v in hf.state_dict().items() if k.startswith("keypoint_detector")}
     m["positional_encoder.projector.weight"] = lsd["posenc.Wr.weight"]
+    if input_dim != 256:  # the port projects 128-d descriptors (disk / aliked variants) like upstream's `input_proj`
+        m["input_projection.weight"], m["input_projection.bias"] = lsd["input_proj.weight"], lsd["input_proj.bias"]
     for i in range(9):
         p, q = f"transformers.{i}.", f"transformer_layers.{i}."
         W = lsd[p + "self_attn.Wqkv.weight"].view(4, 64, 3, 256)
@@ -120,7 +123,7 @@ def _hf_lightglue(lsd, dc, wc, th):
     return hf
 
 
-def synthetic_matching_problem(seed, n, m, n_out, noise=0.05):
+def synthetic_matching_problem(seed, n, m, n_out, noise=0.05, dim=256):
     """Keypoints/descriptors with known correspondences (distinctive random descriptors)."""
     import torch.nn.functional as F
 
@@ -128,9 +131,9 @@ def synthetic_matching_problem(seed, n, m, n_out, noise=0.05):
     k0 = torch.rand(n, 2, generator=g) * torch.tensor([632.0, 472.0]) + 4
     perm = torch.randperm(n, generator=g)[:m]
     k1 = k0[perm] + torch.randn(m, 2, generator=g)
-    d0 = F.normalize(torch.randn(n, 256, generator=g), dim=1)
-    d1 = F.normalize(d0[perm] + noise * torch.randn(m, 256, generator=g), dim=1)
-    d1[:n_out] = F.normalize(torch.randn(n_out, 256, generator=g), dim=1)
+    d0 = F.normalize(torch.randn(n, dim, generator=g), dim=1)
+    d1 = F.normalize(d0[perm] + noise * torch.randn(m, dim, generator=g), dim=1)
+    d1[:n_out] = F.normalize(torch.randn(n_out, dim, generator=g), dim=1)
     img = torch.zeros(1, 1, 480, 640)
     return {
         "image0": img,
@@ -143,17 +146,18 @@ def synthetic_matching_problem(seed, n, m, n_out, noise=0.05):
 
 
 # Only these two modes run in the HF port: it crashes when exactly one of early-stop / pruning is on.
+@pytest.mark.parametrize("input_dim", [256, 128])
 @pytest.mark.parametrize("dc,wc", [(-1.0, -1.0), (0.95, 0.99)])
-def test_lightglue_oracle_vs_hf(dc, wc):
+def test_lightglue_oracle_vs_hf(dc, wc, input_dim):
     torch.set_num_threads(4)
-    lsd = lightglue_state_dict(0)
-    data = synthetic_matching_problem(7, 400, 350, 100)
+    lsd = lightglue_state_dict(0, input_dim=input_dim)
+    data = synthetic_matching_problem(7, 400, 350, 100, dim=input_dim)
     out = LightGlueOracle(lsd, dict(depth_confidence=dc, width_confidence=wc, filter_threshold=0.1))(data)
     hf = _hf_lightglue(lsd, dc, wc, 0.1)
     n0, n1 = data["keypoints0"].shape[1], data["keypoints1"].shape[1]
     N = max(n0, n1)
     kp = torch.zeros(1, 2, N, 2)
-    de = torch.zeros(1, 2, N, 256)
+    de = torch.zeros(1, 2, N, input_dim)
     mask = torch.zeros(1, 2, N, dtype=torch.int)
     kp[0, 0, :n0], kp[0, 1, :n1] = data["keypoints0"][0], data["keypoints1"][0]
     de[0, 0, :n0], de[0, 1, :n1] = data["descriptors0"][0].T, data["descriptors1"][0].T
