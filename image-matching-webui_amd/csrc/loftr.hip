@@ -129,13 +129,15 @@ struct LfWs {
     size_t total;
     bool ok;
 };
-static LfWs lf_carve(void* ws, size_t bytes, int B, int H, int W) {
+static LfWs lf_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int W1) {
     WsAlloc a(ws, bytes);
     LfWs w;
-    const size_t n2 = 2 * (size_t)B;
-    const size_t p2 = n2 * (H / 2) * (W / 2), p4 = n2 * (H / 4) * (W / 4), p8 = n2 * (H / 8) * (W / 8);
-    const size_t L = (size_t)(H / 8) * (W / 8);
-    const size_t cap = (size_t)B * L;
+    // per-image buffers hold the B images of side 0 followed by the B images of side 1 (sizes may differ per side)
+    const size_t p2 = (size_t)B * ((size_t)(H0 / 2) * (W0 / 2) + (size_t)(H1 / 2) * (W1 / 2));
+    const size_t p4 = (size_t)B * ((size_t)(H0 / 4) * (W0 / 4) + (size_t)(H1 / 4) * (W1 / 4));
+    const size_t L0 = (size_t)(H0 / 8) * (W0 / 8), L1 = (size_t)(H1 / 8) * (W1 / 8);
+    const size_t p8 = (size_t)B * (L0 + L1);
+    const size_t cap = (size_t)B * L0, cap1 = (size_t)B * L1;
     w.x0 = a.get<float>(p2 * 128);
     w.t1 = a.get<float>(p2 * 128);
     w.x1a = a.get<float>(p2 * 128);
@@ -164,18 +166,18 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H, int W) {
     w.m = a.get<float>(p8 * 256);
     w.hb = a.get<float>(p8 * 512);
     w.ob = a.get<float>(p8 * 256);
-    const size_t nchunk = (L + LA_CHUNK - 1) / LA_CHUNK;
-    w.kvpart = a.get<float>(n2 * 8 * nchunk * (32 * 32 + 32));
-    w.kv = a.get<float>(n2 * 8 * (32 * 32 + 32));
-    w.sim = a.get<float>((size_t)B * L * L);
+    const size_t nchunk = ((L0 > L1 ? L0 : L1) + LA_CHUNK - 1) / LA_CHUNK;
+    w.kvpart = a.get<float>((size_t)2 * B * 8 * nchunk * (32 * 32 + 32));
+    w.kv = a.get<float>((size_t)2 * B * 8 * (32 * 32 + 32));
+    w.sim = a.get<float>((size_t)B * L0 * L1);
     w.rmax = a.get<float>(cap);
     w.rsum = a.get<float>(cap);
-    w.cmax = a.get<float>(cap);
-    w.csum = a.get<float>(cap);
+    w.cmax = a.get<float>(cap1);
+    w.csum = a.get<float>(cap1);
     w.best = a.get<float>(cap);
-    w.cbest = a.get<float>(cap);
-    w.pc0 = a.get<float>(cap * LF_RCH);
-    w.pc1 = a.get<float>(cap * LF_RCH);
+    w.cbest = a.get<float>(cap1);
+    w.pc0 = a.get<float>(cap1 * LF_RCH);
+    w.pc1 = a.get<float>(cap1 * LF_RCH);
     w.X = a.get<float>(2 * cap * 25 * 256);
     w.CG = a.get<float>(2 * cap * 256);
     w.CW = a.get<float>(2 * cap * 128);
@@ -199,12 +201,12 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H, int W) {
     w.ok = a.ok;
     return w;
 }
-extern "C" size_t imcui_hip_loftr_workspace_bytes(int B, int H, int W) { return lf_carve(nullptr, 0, B, H, W).total; }
+extern "C" size_t imcui_hip_loftr_workspace_bytes(int B, int H0, int W0, int H1, int W1) { return lf_carve(nullptr, 0, B, H0, W0, H1, W1).total; }
 
-// byte offsets of a few workspace buffers, for the parity tests: 0 = coarse features after the
-// transformer [2B, L, 256], 1 = fine features [2B, H/2, W/2, 128], 2 = sim [B, L, L], 3 = fine windows F
-extern "C" size_t imcui_hip_loftr_debug_offset(int which, int B, int H, int W) {
-    LfWs w = lf_carve((void*)256, (size_t)-1 >> 1, B, H, W);
+// byte offsets of a few workspace buffers, for the parity tests: 0 = coarse features after the transformer
+// [B*L0 + B*L1, 256], 1 = fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 = sim [B, L0, L1], 3 = fine windows F
+extern "C" size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1) {
+    LfWs w = lf_carve((void*)256, (size_t)-1 >> 1, B, H0, W0, H1, W1);
     const char* base = (const char*)256;
     switch (which) {
         case 0: return (const char*)w.fc - base;
@@ -226,24 +228,30 @@ __global__ void lf_copy_int_kernel(const int* src, int* dst, int n) {
 
 // ------------------------------------------------------------------ forward
 extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B,
-                                       int H, int W, double match_threshold, int temp_bug_fix, float* keypoints0,
-                                       float* keypoints1, float* confidence, int* batch_indexes, int* num_matches,
-                                       void* ws, size_t ws_bytes, void* stream_) {
+                                       int H0, int W0, int H1, int W1, double match_threshold, int temp_bug_fix,
+                                       float* keypoints0, float* keypoints1, float* confidence, int* batch_indexes,
+                                       int* num_matches, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!h) return IMCUI_ERR_ARG;
     if (B <= 0) return IMCUI_OK;
-    if (H % 8 || W % 8 || H < 32 || W < 32) return imcui_set_err(h, IMCUI_ERR_ARG, "loftr: H=%d W=%d must be multiples of 8 (>= 32)", H, W);
+    if (H0 % 8 || W0 % 8 || H0 < 32 || W0 < 32 || H1 % 8 || W1 % 8 || H1 < 32 || W1 < 32)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "loftr: image sizes %dx%d / %dx%d must be multiples of 8 (>= 32)", W0, H0, W1, H1);
     if (!packed || !image0 || !image1 || !keypoints0 || !keypoints1 || !confidence || !batch_indexes || !num_matches)
         return imcui_set_err(h, IMCUI_ERR_ARG, "loftr: null argument");
-    const int hc = H / 8, wc = W / 8;
-    if (hc > 256 || wc > 256) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "loftr: coarse map %dx%d exceeds the 256x256 positional encoding", hc, wc);
-    LfWs w = lf_carve(ws, ws_bytes, B, H, W);
+    // per side s: image size, 1/2 - 1/4 - 1/8 maps.  kornia runs the backbone on the concatenated batch when both
+    // images have one size and on each image otherwise (LoFTR.forward); convolutions do not mix images either way.
+    const int Hs[2] = {H0, H1}, Ws[2] = {W0, W1};
+    const int hcs[2] = {H0 / 8, H1 / 8}, wcs[2] = {W0 / 8, W1 / 8};
+    if (hcs[0] > 256 || wcs[0] > 256 || hcs[1] > 256 || wcs[1] > 256)
+        return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "loftr: coarse maps %dx%d / %dx%d exceed the 256x256 positional encoding", wcs[0], hcs[0], wcs[1], hcs[1]);
+    LfWs w = lf_carve(ws, ws_bytes, B, H0, W0, H1, W1);
     if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "loftr: workspace too small (%zu < %zu)", ws_bytes, w.total);
     const LfLayout l = lf_layout();
     const float* P = packed;
     const bool split = h->precision == 1;
-    const int n2 = 2 * B;
-    const int L = hc * wc;
+    const bool same = (H0 == H1 && W0 == W1);
+    const int Ls[2] = {hcs[0] * wcs[0], hcs[1] * wcs[1]};
+    const int L = Ls[0], S = Ls[1];
     const int cap = B * L;
     int rc;
 #define LFRUN(x)                       \
@@ -266,76 +274,88 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
             g.wscale = P + l.ws[li];
         }
     };
-    // conv as GEMM over NHWC: in [n2, hin, win, cin] -> out [n2, hout, wout, N]
-    auto conv = [&](int li, const float* in, float* out, int hin, int win, int cin, int ks, int stride, const float* resid,
-                    int act) -> int {
-        GemmP g;
-        wts(g, li);
-        g.epi = EPI_CONV;
-        const int pad = ks / 2;
-        const int hout = (hin + 2 * pad - ks) / stride + 1, wout = (win + 2 * pad - ks) / stride + 1;
-        g.A = in;
-        g.conv_k = ks;
-        g.conv_stride = stride;
-        g.conv_pad = pad;
-        g.conv_hin = hin;
-        g.conv_win = win;
-        g.conv_hout = hout;
-        g.conv_wout = wout;
-        g.conv_cin = cin;
-        g.M = n2 * hout * wout;
-        g.C = out;
-        g.ldc = g.N;
-        g.resid = resid;
-        g.ldr = g.N;
-        g.act = act;
-        return gemm_launch(h, g, stream);
+    // pixels per image of side s at resolution 1/div
+    auto npx = [&](int s, int div) { return (size_t)(Hs[s] / div) * (Ws[s] / div); };
+    // conv as GEMM over NHWC at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one launch over
+    // the 2B images when both sides have one size, one launch per side otherwise
+    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
+        for (int s = 0; s < (same ? 1 : 2); ++s) {
+            GemmP g;
+            wts(g, li);
+            g.epi = EPI_CONV;
+            const int pad = ks / 2;
+            const int hin = Hs[s] / div, win = Ws[s] / div;
+            const int hout = (hin + 2 * pad - ks) / stride + 1, wout = (win + 2 * pad - ks) / stride + 1;
+            const size_t ioff = s ? (size_t)B * npx(0, div) * cin : 0;
+            const size_t ooff = s ? (size_t)B * npx(0, div * stride) * g.N : 0;
+            g.A = in + ioff;
+            g.conv_k = ks;
+            g.conv_stride = stride;
+            g.conv_pad = pad;
+            g.conv_hin = hin;
+            g.conv_win = win;
+            g.conv_hout = hout;
+            g.conv_wout = wout;
+            g.conv_cin = cin;
+            g.M = (same ? 2 * B : B) * hout * wout;
+            g.C = out + ooff;
+            g.ldc = g.N;
+            g.resid = resid ? resid + ooff : nullptr;
+            g.ldr = g.N;
+            g.act = act;
+            const int r = gemm_launch(h, g, stream);
+            if (r != IMCUI_OK) return r;
+        }
+        return IMCUI_OK;
     };
-    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
     // ---- a13: ResNetFPN_8_2
-    {
-        const long npix = (long)B * H2 * W2;
+    for (int s = 0; s < 2; ++s) {
+        const int H2s = Hs[s] / 2, W2s = Ws[s] / 2;
+        const long npix = (long)B * H2s * W2s;
         long blocks = min((npix + 15) / 16, (long)256 * 32);
-        hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, image0, P + l.conv1_w, P + l.conv1_b,
-                           w.x0, H, W, H2, W2, npix);
-        hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, image1, P + l.conv1_w, P + l.conv1_b,
-                           w.x0 + (size_t)npix * 128, H, W, H2, W2, npix);
-        IMCUI_CHECK_LAUNCH(h);
+        hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, s ? image1 : image0, P + l.conv1_w,
+                           P + l.conv1_b, w.x0 + (s ? (size_t)B * npx(0, 2) * 128 : 0), Hs[s], Ws[s], H2s, W2s, npix);
     }
-    LFRUN(conv(LF_L1_0_C1, w.x0, w.t1, H2, W2, 128, 3, 1, nullptr, 1));
-    LFRUN(conv(LF_L1_0_C2, w.t1, w.x1a, H2, W2, 128, 3, 1, w.x0, 1));
-    LFRUN(conv(LF_L1_1_C1, w.x1a, w.t1, H2, W2, 128, 3, 1, nullptr, 1));
-    LFRUN(conv(LF_L1_1_C2, w.t1, w.x1, H2, W2, 128, 3, 1, w.x1a, 1));
-    LFRUN(conv(LF_L2_0_C1, w.x1, w.t2, H2, W2, 128, 3, 2, nullptr, 1));
-    LFRUN(conv(LF_L2_0_DS, w.x1, w.ds2, H2, W2, 128, 1, 2, nullptr, 0));
-    LFRUN(conv(LF_L2_0_C2, w.t2, w.x2a, H4, W4, CP, 3, 1, w.ds2, 1));
-    LFRUN(conv(LF_L2_1_C1, w.x2a, w.t2, H4, W4, CP, 3, 1, nullptr, 1));
-    LFRUN(conv(LF_L2_1_C2, w.t2, w.x2, H4, W4, CP, 3, 1, w.x2a, 1));
-    LFRUN(conv(LF_L3_0_C1, w.x2, w.t3, H4, W4, CP, 3, 2, nullptr, 1));
-    LFRUN(conv(LF_L3_0_DS, w.x2, w.ds3, H4, W4, CP, 1, 2, nullptr, 0));
-    LFRUN(conv(LF_L3_0_C2, w.t3, w.x3a, hc, wc, 256, 3, 1, w.ds3, 1));
-    LFRUN(conv(LF_L3_1_C1, w.x3a, w.t3, hc, wc, 256, 3, 1, nullptr, 1));
-    LFRUN(conv(LF_L3_1_C2, w.t3, w.x3, hc, wc, 256, 3, 1, w.x3a, 1));
-    LFRUN(conv(LF_OUT3, w.x3, w.fc, hc, wc, 256, 1, 1, nullptr, 0));
-    auto upsample = [&](const float* in, float* out, int hh, int ww, int C) {
-        const long n4 = (long)n2 * (2 * hh) * (2 * ww) * (C / 4);
-        hipLaunchKernelGGL(lf_upsample2_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), dim3(256), 0, stream, in,
-                           out, hh, ww, C, n4);
+    IMCUI_CHECK_LAUNCH(h);
+    LFRUN(conv(LF_L1_0_C1, w.x0, w.t1, 2, 128, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L1_0_C2, w.t1, w.x1a, 2, 128, 3, 1, w.x0, 1));
+    LFRUN(conv(LF_L1_1_C1, w.x1a, w.t1, 2, 128, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L1_1_C2, w.t1, w.x1, 2, 128, 3, 1, w.x1a, 1));
+    LFRUN(conv(LF_L2_0_C1, w.x1, w.t2, 2, 128, 3, 2, nullptr, 1));
+    LFRUN(conv(LF_L2_0_DS, w.x1, w.ds2, 2, 128, 1, 2, nullptr, 0));
+    LFRUN(conv(LF_L2_0_C2, w.t2, w.x2a, 4, CP, 3, 1, w.ds2, 1));
+    LFRUN(conv(LF_L2_1_C1, w.x2a, w.t2, 4, CP, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L2_1_C2, w.t2, w.x2, 4, CP, 3, 1, w.x2a, 1));
+    LFRUN(conv(LF_L3_0_C1, w.x2, w.t3, 4, CP, 3, 2, nullptr, 1));
+    LFRUN(conv(LF_L3_0_DS, w.x2, w.ds3, 4, CP, 1, 2, nullptr, 0));
+    LFRUN(conv(LF_L3_0_C2, w.t3, w.x3a, 8, 256, 3, 1, w.ds3, 1));
+    LFRUN(conv(LF_L3_1_C1, w.x3a, w.t3, 8, 256, 3, 1, nullptr, 1));
+    LFRUN(conv(LF_L3_1_C2, w.t3, w.x3, 8, 256, 3, 1, w.x3a, 1));
+    LFRUN(conv(LF_OUT3, w.x3, w.fc, 8, 256, 1, 1, nullptr, 0));
+    // bilinear x2 (align_corners=True) of the maps at resolution 1/div with C channels, per side
+    auto upsample = [&](const float* in, float* out, int div, int C) {
+        for (int s = 0; s < (same ? 1 : 2); ++s) {
+            const int hh = Hs[s] / div, ww = Ws[s] / div;
+            const long n4 = (long)(same ? 2 * B : B) * (2 * hh) * (2 * ww) * (C / 4);
+            hipLaunchKernelGGL(lf_upsample2_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), dim3(256), 0, stream,
+                               in + (s ? (size_t)B * npx(0, div) * C : 0), out + (s ? (size_t)B * npx(0, div / 2) * C : 0), hh, ww, C, n4);
+        }
     };
-    upsample(w.fc, w.up3, hc, wc, 256);
-    LFRUN(conv(LF_OUT2, w.x2, w.x2o, H4, W4, CP, 1, 1, w.up3, 0));
-    LFRUN(conv(LF_OUT2B_0, w.x2o, w.y2, H4, W4, 256, 3, 1, nullptr, 2));
-    LFRUN(conv(LF_OUT2B_3, w.y2, w.x2out, H4, W4, 256, 3, 1, nullptr, 0));
-    upsample(w.x2out, w.up2, H4, W4, CP);
-    LFRUN(conv(LF_OUT1, w.x1, w.x1o, H2, W2, 128, 1, 1, w.up2, 0));
-    LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, H2, W2, CP, 3, 1, nullptr, 2));
-    LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, H2, W2, CP, 3, 1, nullptr, 0));
+    upsample(w.fc, w.up3, 8, 256);
+    LFRUN(conv(LF_OUT2, w.x2, w.x2o, 4, CP, 1, 1, w.up3, 0));
+    LFRUN(conv(LF_OUT2B_0, w.x2o, w.y2, 4, 256, 3, 1, nullptr, 2));
+    LFRUN(conv(LF_OUT2B_3, w.y2, w.x2out, 4, 256, 3, 1, nullptr, 0));
+    upsample(w.x2out, w.up2, 4, CP);
+    LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.up2, 0));
+    LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, 2, CP, 3, 1, nullptr, 2));
+    LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, 2, CP, 3, 1, nullptr, 0));
 
     // ---- a14: positional encoding + coarse LocalFeatureTransformer (linear attention)
-    {
-        const long n = (long)n2 * L * 256;
-        hipLaunchKernelGGL(lf_posenc_kernel, dim3((unsigned)min((n + 255) / 256, (long)65536)), dim3(256), 0, stream, w.fc, hc,
-                           wc, 256, n, temp_bug_fix);
+    const size_t tok1 = (size_t)B * L;  // first token row of side 1
+    for (int s = 0; s < (same ? 1 : 2); ++s) {
+        const long n = (long)(same ? 2 * B : B) * Ls[s] * 256;
+        hipLaunchKernelGGL(lf_posenc_kernel, dim3((unsigned)min((n + 255) / 256, (long)65536)), dim3(256), 0, stream,
+                           w.fc + (s ? tok1 * 256 : 0), hcs[s], wcs[s], 256, n, temp_bug_fix);
     }
     auto lin = [&](int li, const float* A, long lda, const float* A2, float* C, long rows, int relu, const int* mcnt) -> int {
         GemmP g;
@@ -356,41 +376,48 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.cnt_stride = 0;
         return gemm_launch(h, g, stream);
     };
-    const int nchunk = cdiv(L, LA_CHUNK);
-    // encoder layer on query sequences [qs0, qs0+ns) with source sequences [ss0, ss0+ns)
-    auto coarse_layer = [&](int layer, int qs0, int ss0, int ns) -> int {
+    const int nchunk_max = cdiv(L > S ? L : S, LA_CHUNK);
+    // encoder layer: `ns` query sequences of Lq tokens starting at token row qt attend to `ns` source sequences of Lsrc
+    // tokens starting at token row st; kvslot = first K'V slot (sequence index) used for the sources
+    auto coarse_layer = [&](int layer, size_t qt, size_t st, int ns, int Lq, int Lsrc, int kvslot) -> int {
         const int base = LF_COARSE0 + layer * 6;
-        const size_t qo = (size_t)qs0 * L * 256, so = (size_t)ss0 * L * 256;
-        const long rows = (long)ns * L;
+        const size_t qo = qt * 256, so = st * 256;
+        const long qrows = (long)ns * Lq, srows = (long)ns * Lsrc;
+        const int nchunk = cdiv(Lsrc, LA_CHUNK);
         int r;
-        if ((r = lin(base + 0, w.fc + qo, 256, nullptr, w.q + qo, rows, 0, nullptr))) return r;
-        if ((r = lin(base + 1, w.fc + so, 256, nullptr, w.k + so, rows, 0, nullptr))) return r;
-        if ((r = lin(base + 2, w.fc + so, 256, nullptr, w.v + so, rows, 0, nullptr))) return r;
-        hipLaunchKernelGGL(lf_la_kv_partial_kernel<32>, dim3(nchunk, 8, ns), dim3(256), 0, stream, w.k + so, w.v + so, L, 8,
-                           w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk);
-        hipLaunchKernelGGL(lf_la_kv_reduce_kernel<32>, dim3(ns * 8, cdiv(1056, 256)), dim3(256), 0, stream,
-                           w.kvpart + (size_t)ss0 * 8 * nchunk * 1056, nchunk, w.kv + (size_t)ss0 * 8 * 1056);
+        if ((r = lin(base + 0, w.fc + qo, 256, nullptr, w.q + qo, qrows, 0, nullptr))) return r;
+        if ((r = lin(base + 1, w.fc + so, 256, nullptr, w.k + so, srows, 0, nullptr))) return r;
+        if ((r = lin(base + 2, w.fc + so, 256, nullptr, w.v + so, srows, 0, nullptr))) return r;
+        float* part = w.kvpart + (size_t)kvslot * 8 * nchunk_max * 1056;
+        float* kv = w.kv + (size_t)kvslot * 8 * 1056;
+        hipLaunchKernelGGL(lf_la_kv_partial_kernel<32>, dim3(nchunk, 8, ns), dim3(256), 0, stream, w.k + so, w.v + so, Lsrc, 8, part, nchunk);
+        hipLaunchKernelGGL(lf_la_kv_reduce_kernel<32>, dim3(ns * 8, cdiv(1056, 256)), dim3(256), 0, stream, part, nchunk, kv);
         const size_t smem = (8 * 1056 + 4 * 256) * sizeof(float);
-        hipLaunchKernelGGL(lf_la_apply_kernel<32>, dim3(cdiv(L, 64), ns), dim3(256), smem, stream, w.q, w.kv, qs0, ss0, L, L, 8,
-                           w.att);
-        if ((r = lin(base + 3, w.att + qo, 256, nullptr, w.m + qo, rows, 0, nullptr))) return r;
+        hipLaunchKernelGGL(lf_la_apply_kernel<32>, dim3(cdiv(Lq, 64), ns), dim3(256), smem, stream, w.q + qo, kv, 0, 0, Lq, Lsrc, 8,
+                           w.att + qo);
+        if ((r = lin(base + 3, w.att + qo, 256, nullptr, w.m + qo, qrows, 0, nullptr))) return r;
         const float* n1w = P + l.norm[layer * 4 + 0];
-        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.m + qo, n1w,
-                           P + l.norm[layer * 4 + 1], (const float*)nullptr, w.m + qo, rows, 0);
-        if ((r = lin(base + 4, w.fc + qo, 256, w.m + qo, w.hb + (size_t)qs0 * L * 512, rows, 1, nullptr))) return r;
-        if ((r = lin(base + 5, w.hb + (size_t)qs0 * L * 512, 512, nullptr, w.ob + qo, rows, 0, nullptr))) return r;
-        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.ob + qo,
-                           P + l.norm[layer * 4 + 2], P + l.norm[layer * 4 + 3], w.fc + qo, w.fc + qo, rows, 1);
+        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, w.m + qo, n1w,
+                           P + l.norm[layer * 4 + 1], (const float*)nullptr, w.m + qo, qrows, 0);
+        if ((r = lin(base + 4, w.fc + qo, 256, w.m + qo, w.hb + qt * 512, qrows, 1, nullptr))) return r;
+        if ((r = lin(base + 5, w.hb + qt * 512, 512, nullptr, w.ob + qo, qrows, 0, nullptr))) return r;
+        hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, w.ob + qo,
+                           P + l.norm[layer * 4 + 2], P + l.norm[layer * 4 + 3], w.fc + qo, w.fc + qo, qrows, 1);
         return IMCUI_OK;
     };
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lf_la_apply_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (8 * 1056 + 4 * 256) * (int)sizeof(float));
     for (int layer = 0; layer < 8; ++layer) {
-        if ((layer & 1) == 0) {
-            LFRUN(coarse_layer(layer, 0, 0, n2));  // self: both images, sources = themselves
+        if ((layer & 1) == 0) {  // self: every image attends to itself
+            if (same) {
+                LFRUN(coarse_layer(layer, 0, 0, 2 * B, L, L, 0));
+            } else {
+                LFRUN(coarse_layer(layer, 0, 0, B, L, L, 0));
+                LFRUN(coarse_layer(layer, tok1, tok1, B, S, S, B));
+            }
         } else {
-            LFRUN(coarse_layer(layer, 0, B, B));  // feat0 <- layer(feat0, feat1)
-            LFRUN(coarse_layer(layer, B, 0, B));  // feat1 <- layer(feat1, updated feat0)
+            LFRUN(coarse_layer(layer, 0, tok1, B, L, S, B));  // feat0 <- layer(feat0, feat1)
+            LFRUN(coarse_layer(layer, tok1, 0, B, S, L, 0));  // feat1 <- layer(feat1, updated feat0)
         }
     }
     IMCUI_CHECK_LAUNCH(h);
@@ -403,37 +430,37 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.A = w.fc;
         g.lda = 256;
         g.a_bs = (long)L * 256;
-        g.W = w.fc + (size_t)B * L * 256;
+        g.W = w.fc + tok1 * 256;
         g.ldw = 256;
-        g.w_bs = (long)L * 256;
+        g.w_bs = (long)S * 256;
         g.C = w.sim;
-        g.ldc = L;
-        g.c_bs = (long)L * L;
+        g.ldc = S;
+        g.c_bs = (long)L * S;
         g.M = L;
-        g.N = L;
+        g.N = S;
         g.K = 256;
         g.alpha = 0.00390625f / 0.1f;
         LFRUN(gemm_launch(h, g, stream));
     }
     const dim3 rg(cdiv(L, 4), B), blk(256);
-    hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum);
-    const dim3 cgz(cdiv(L, 64), B, LF_RCH), cg1(cdiv(L, 256), B);
-    hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, L, w.pc0, w.pc1);
-    hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, L, w.cmax, w.csum);
+    hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum);
+    const dim3 cgz(cdiv(S, 64), B, LF_RCH), cg1(cdiv(S, 256), B);
+    hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, S, w.pc0, w.pc1);
+    hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, S, w.cmax, w.csum);
     // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
-    hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
-    hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
-    hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, L, w.cbest);
-    hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, L, wc, hc, wc, hc, 2,
-                       (float)match_threshold, w.flag, (long)cap);
+    hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
+    hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
+    hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, S, w.cbest);
+    hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, S, wcs[0], hcs[0], wcs[1], hcs[1],
+                       2, (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi,
                        w.mj, w.mconf, w.nmatch);
     hipLaunchKernelGGL(lf_counts_kernel, dim3(1), dim3(1), 0, stream, w.nmatch, w.cnt2);
     IMCUI_CHECK_LAUNCH(h);
 
     // ---- a16: fine level on the 5x5 windows of the matches
-    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap, H2, W2,
-                       hc, wc, 4, w.X, w.CG);
+    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap, H0 / 2, W0 / 2,
+                       hcs[0], wcs[0], H1 / 2, W1 / 2, hcs[1], wcs[1], 4, w.X, w.CG);
     auto lin_b = [&](int li, const float* A, long lda, const float* A2, float* C, long side_rows_cap, int relu, int per_token,
                      int side0, int nsides, bool with_bias) -> int {
         // rows of side s start at s * side_rows_cap; valid rows = nmatch (* 25)
@@ -490,8 +517,9 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     LFRUN(fine_layer(0, 0, 2, 0));  // self on both windows
     LFRUN(fine_layer(1, 0, 1, 1));  // cross: window0 <- (window0, window1)
     LFRUN(fine_layer(1, 1, 1, 1));  //        window1 <- (window1, updated window0)
-    hipLaunchKernelGGL(lf_fine_match_kernel, dim3(cdiv(cap, 4)), blk, 0, stream, w.F, w.mi, w.mj, w.nmatch, cap, wc, wc,
-                       (float)H / (float)hc, (float)H / (float)H2, keypoints0, keypoints1);
+    // kornia: scale = hw0_i[0] / hw0_c[0] (= 8) for BOTH images' coarse key-points, fine offsets scaled by hw0_i[0] / hw0_f[0] (= 2)
+    hipLaunchKernelGGL(lf_fine_match_kernel, dim3(cdiv(cap, 4)), blk, 0, stream, w.F, w.mi, w.mj, w.nmatch, cap, wcs[0], wcs[1],
+                       (float)H0 / (float)hcs[0], (float)H0 / (float)(H0 / 2), keypoints0, keypoints1);
     hipMemcpyAsync(confidence, w.mconf, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, stream);
     hipLaunchKernelGGL(lf_copy_int_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.mb, batch_indexes, cap);
     hipLaunchKernelGGL(lf_copy_int_kernel, dim3(1), dim3(64), 0, stream, w.nmatch, num_matches, 1);

@@ -495,25 +495,28 @@ __global__ __launch_bounds__(1024) void lf_compact_kernel(const int* __restrict_
 __global__ __launch_bounds__(256) void lf_fine_gather_kernel(const float* __restrict__ feat_f, const float* __restrict__ feat_c,
                                                              const int* __restrict__ mb, const int* __restrict__ mi,
                                                              const int* __restrict__ mj, const int* __restrict__ nmatch,
-                                                             int B, int cap, int hf, int wf, int hc, int wc, int stride,
-                                                             float* __restrict__ X, float* __restrict__ CG) {
+                                                             int B, int cap, int hf0, int wf0, int hc0, int wc0, int hf1, int wf1,
+                                                             int hc1, int wc1, int stride, float* __restrict__ X,
+                                                             float* __restrict__ CG) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x, side = blockIdx.y;
     if (m >= *nmatch) return;
     const int b = mb[m];
     const int cell = side ? mj[m] : mi[m];
-    const int img = side * B + b;  // image index in the concatenated batch
+    // the B images of side 1 follow the B images of side 0 in both feature buffers (sizes may differ per side)
+    const int hf = side ? hf1 : hf0, wf = side ? wf1 : wf0, hc = side ? hc1 : hc0, wc = side ? wc1 : wc0;
+    const float* ff = feat_f + (side ? (size_t)B * hf0 * wf0 * 128 : 0) + (size_t)b * hf * wf * 128;
+    const float* fc = feat_c + (side ? (size_t)B * hc0 * wc0 * 256 : 0) + (size_t)b * hc * wc * 256;
     const int cy = cell / wc, cx = cell - cy * wc;
     const size_t wrow0 = ((size_t)side * cap + m) * 25;
     for (int ww = threadIdx.x >> 6; ww < 25; ww += 4) {
         const int fy = cy * stride + ww / 5 - 2, fx = cx * stride + ww % 5 - 2;
         float2 v = make_float2(0.f, 0.f);
-        if (fy >= 0 && fy < hf && fx >= 0 && fx < wf)
-            v = *reinterpret_cast<const float2*>(feat_f + (((size_t)img * hf + fy) * wf + fx) * 128 + lane * 2);
+        if (fy >= 0 && fy < hf && fx >= 0 && fx < wf) v = *reinterpret_cast<const float2*>(ff + ((size_t)fy * wf + fx) * 128 + lane * 2);
         *reinterpret_cast<float2*>(X + (wrow0 + ww) * 256 + lane * 2) = v;
     }
     if (threadIdx.x < 64) {
-        const float4 c = *reinterpret_cast<const float4*>(feat_c + ((size_t)img * hc * wc + cell) * 256 + lane * 4);
+        const float4 c = *reinterpret_cast<const float4*>(fc + (size_t)cell * 256 + lane * 4);
         *reinterpret_cast<float4*>(CG + ((size_t)side * cap + m) * 256 + lane * 4) = c;
     }
 }

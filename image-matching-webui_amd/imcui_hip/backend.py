@@ -449,40 +449,38 @@ class LoFTRHIP:
         self.last_ws = None
 
     def forward(self, packed, image0, image1, match_threshold, temp_bug_fix=False):
-        """kornia LoFTR.forward on [B,1,H,W] pairs; fixed-capacity outputs + device match count."""
+        """kornia LoFTR.forward on image0 [B,1,H0,W0] / image1 [B,1,H1,W1] (sizes may differ between the two sides);
+        fixed-capacity outputs + device match count."""
         dev = image0.device
         hd = get_handle(dev)
         lib = hd.lib
-        if image0.shape != image1.shape:
-            raise ImcuiHipError(
-                f"the HIP LoFTR path needs image0 and image1 of the same size, got {tuple(image0.shape[-2:])} and {tuple(image1.shape[-2:])}: "
-                "the zoo's `loftr` conf force-resizes both images to 640x480 (configs/matchers.py:249-267), but confs with force_resize "
-                "False (`minima_loftr`, :283) keep each image's aspect ratio -- resize or pad the pair to a common size first"
-            )
         image0, image1 = image0.contiguous().float(), image1.contiguous().float()
-        B, Cc, H, W = image0.shape
-        if Cc != 1:
-            raise ImcuiHipError("LoFTR expects 1-channel images")
-        cap = B * (H // 8) * (W // 8)
+        B, Cc, H0, W0 = image0.shape
+        B1, C1, H1, W1 = image1.shape
+        if Cc != 1 or C1 != 1 or B1 != B:
+            raise ImcuiHipError("LoFTR expects two batches of 1-channel images of equal batch size")
+        cap = B * (H0 // 8) * (W0 // 8)
         kp0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
         kp1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
         conf = torch.empty((cap,), dtype=torch.float32, device=dev)
         bidx = torch.empty((cap,), dtype=torch.int32, device=dev)
         nm = torch.zeros((1,), dtype=torch.int32, device=dev)
         with self._lock:
-            ws = self._ws.get(lib.imcui_hip_loftr_workspace_bytes(B, H, W), dev)
+            ws = self._ws.get(lib.imcui_hip_loftr_workspace_bytes(B, H0, W0, H1, W1), dev)
             self.last_ws = ws
+            self.last_dims = (B, H0, W0, H1, W1)
             with torch.cuda.device(dev):
                 rc = lib.imcui_hip_loftr_forward(
-                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H, W, float(match_threshold), int(bool(temp_bug_fix)),
+                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H0, W0, H1, W1, float(match_threshold), int(bool(temp_bug_fix)),
                     _ptr(kp0), _ptr(kp1), _ptr(conf), _ptr(bidx), _ptr(nm), _ptr(ws), ws.numel(), _stream_ptr(),
                 )  # fmt: skip
                 hd.check(rc, "imcui_hip_loftr_forward")
         return {"keypoints0": kp0, "keypoints1": kp1, "confidence": conf, "batch_indexes": bidx, "num_matches": nm}
 
-    def debug_buffer(self, which: int, B: int, H: int, W: int, shape) -> torch.Tensor:
+    def debug_buffer(self, which: int, shape) -> torch.Tensor:
+        """Workspace buffer `which` of the last forward (imcui_hip_loftr_debug_offset) viewed as float32 `shape`."""
         lib = load_library()
-        off = lib.imcui_hip_loftr_debug_offset(which, B, H, W)
+        off = lib.imcui_hip_loftr_debug_offset(which, *self.last_dims)
         n = int(np.prod(shape))
         return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
 

@@ -8,9 +8,7 @@ before the net ("we refine kpts in image0", :42-51), the top-k matches by confid
 (imcui_hip_loftr_forward).  Weights: kornia's `outdoor` checkpoint state dict (or the MINIMA variant,
 which sets temp_bug_fix, :27-36), given as conf["state_dict"] / conf["weights_path"].
 
-Limitation: image0 and image1 must have the same size (the C ABI takes one H, W).  That is what the zoo's `loftr`
-conf produces (force_resize to 640x480, imcui/hloc/configs/matchers.py:249-267); `minima_loftr` (:283, force_resize
-False) keeps each image's aspect ratio, so pairs of different shapes raise ImcuiHipError here instead of matching.
+image0 and image1 may have different sizes (`minima_loftr`, configs/matchers.py:283, keeps each image's aspect ratio).
 """
 from __future__ import annotations
 

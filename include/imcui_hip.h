@@ -187,19 +187,22 @@ int imcui_hip_loftr_num_norms(void);
 int imcui_hip_loftr_norm_dim(int i);
 int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* conv1_b, const float* const* w, const float* const* b,
                                  const float* const* norms, float* packed);
-size_t imcui_hip_loftr_workspace_bytes(int B, int H, int W);
-/* kornia LoFTR.forward on B pairs: image0 / image1 [dev, B,1,H,W] (same size, multiples of 8).
- * Outputs with capacity B*(H/8)*(W/8) rows, first num_matches[0] valid, ordered like torch.where
+size_t imcui_hip_loftr_workspace_bytes(int B, int H0, int W0, int H1, int W1);
+/* kornia LoFTR.forward on B pairs: image0 [dev, B,1,H0,W0], image1 [dev, B,1,H1,W1] (multiples of 8, >= 32; the two
+ * sizes may differ -- `minima_loftr` keeps each image's aspect ratio, configs/matchers.py:283 -- kornia then runs the
+ * backbone per image instead of on the concatenated batch, which gives the same values).
+ * Outputs with capacity B*(H0/8)*(W0/8) rows, first num_matches[0] valid, ordered like torch.where
  * (batch-major, coarse cell of image0 ascending): keypoints0/1 [dev, cap,2] pixel (x,y),
  * confidence [dev, cap], batch_indexes [dev, cap] int32, num_matches [dev, 1] int32.
  * match_threshold = conf["match_threshold"] (loftr.py:23); temp_bug_fix = 1 only for MINIMA weights (:28). */
-int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H,
-                            int W, double match_threshold, int temp_bug_fix, float* keypoints0, float* keypoints1,
-                            float* confidence, int* batch_indexes, int* num_matches, void* ws, size_t ws_bytes, void* stream);
+int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0,
+                            int W0, int H1, int W1, double match_threshold, int temp_bug_fix, float* keypoints0,
+                            float* keypoints1, float* confidence, int* batch_indexes, int* num_matches, void* ws,
+                            size_t ws_bytes, void* stream);
 
-/* byte offset inside the LoFTR workspace of: 0 coarse features after the transformer [2B,L,256],
- * 1 fine features [2B,H/2,W/2,128], 2 sim [B,L,L], 3 fine windows [2,B*L,25,128]  (parity tests) */
-size_t imcui_hip_loftr_debug_offset(int which, int B, int H, int W);
+/* byte offset inside the LoFTR workspace of: 0 coarse features after the transformer [B*L0 + B*L1, 256] (side 0 first),
+ * 1 fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 sim [B,L0,L1], 3 fine windows [2,B*L0,25,128]  (parity tests) */
+size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);
 
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);

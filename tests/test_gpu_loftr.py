@@ -43,26 +43,28 @@ def test_conv_gemm_vs_torch(cin, cout, ks, stride, act, use_res, precision):
     assert (out - ref).abs().max().item() / ref.abs().max().item() < 4e-6
 
 
-def _loftr_case(h, w, B, sd, thr, min_matches):
+def _loftr_case(h, w, B, sd, thr, min_matches, hw1=None):
+    """`hw1`: size of the second image when it differs from (h, w)."""
     from imcui_hip.hloc.matchers.loftr import LoFTR
 
     torch.set_num_threads(16)
-    pairs = [crops(3 + b, h, w) for b in range(B)]
-    img0 = torch.cat([p[0] for p in pairs], 0)
-    img1 = torch.cat([p[1] for p in pairs], 0)
+    h1, w1 = hw1 if hw1 is not None else (h, w)
+    pairs = [crops(3 + b, max(h, h1), max(w, w1)) for b in range(B)]
+    img0 = torch.cat([p[0][..., :h, :w] for p in pairs], 0).contiguous()
+    img1 = torch.cat([p[1][..., :h1, :w1] for p in pairs], 0).contiguous()
     model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to("cuda:0")
     out = model.forward_batched(img0.cuda(), img1.cuda())
     torch.cuda.synchronize()
     n = int(out["num_matches"][0])
     hc, wc = h // 8, w // 8
-    L = hc * wc
+    L, S = hc * wc, (h1 // 8) * (w1 // 8)
     ora = LoFTROracle(sd, {"match_threshold": thr, "max_keypoints": None})
     ref = ora.net(img0, img1, return_intermediates=True)
-    # intermediates: coarse features after the transformer, fine features, similarity
-    fc = model._impl.debug_buffer(0, B, h, w, (2 * B, L, 256)).cpu()
-    ff = model._impl.debug_buffer(1, B, h, w, (2 * B, h // 2, w // 2, 128)).cpu()
-    fc_ref = torch.cat([ref["_feat_c0"], ref["_feat_c1"]], 0)
-    assert (ff[:B] - ref["_feat_f0"].permute(0, 2, 3, 1)).abs().max().item() < 2e-4 * ref["_feat_f0"].abs().max().item(), "fine backbone features"
+    # intermediates: coarse features after the transformer (side 0 then side 1), fine features of side 0
+    fc = model._impl.debug_buffer(0, (B * L + B * S, 256)).cpu()
+    ff = model._impl.debug_buffer(1, (B, h // 2, w // 2, 128)).cpu()
+    fc_ref = torch.cat([ref["_feat_c0"].reshape(-1, 256), ref["_feat_c1"].reshape(-1, 256)], 0)
+    assert (ff - ref["_feat_f0"].permute(0, 2, 3, 1)).abs().max().item() < 2e-4 * ref["_feat_f0"].abs().max().item(), "fine backbone features"
     assert (fc - fc_ref).abs().max().item() < 2e-4 * fc_ref.abs().max().item(), "coarse features after the transformer"
     # coarse matches: same (b, i, j) triplets in the same order
     mi = (out["keypoints0"][:n, 1] / 8 * wc + out["keypoints0"][:n, 0] / 8).round().long().cpu()
@@ -81,6 +83,13 @@ def _loftr_case(h, w, B, sd, thr, min_matches):
 def test_loftr_vs_oracle(h, w, B, precision):
     """Includes the zoo's LoFTR size: configs/matchers.py:249-267 force-resizes every pair to 640 x 480."""
     _loftr_case(h, w, B, SD, 0.01, 21)
+
+
+@pytest.mark.parametrize("hw0,hw1,B", [((240, 320), (320, 256), 1), ((160, 224), (96, 160), 2), ((480, 640), (424, 640), 1)])
+def test_loftr_images_of_different_sizes(hw0, hw1, B, precision):
+    """`minima_loftr` (configs/matchers.py:283: force_resize False) hands the matcher pairs whose two images differ in
+    size; kornia then runs the backbone per image.  Same parity bar as the equal-size path."""
+    _loftr_case(hw0[0], hw0[1], B, SD, 0.01, 5, hw1=hw1)
 
 
 def test_loftr_1024_vs_oracle():
