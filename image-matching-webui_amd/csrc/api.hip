@@ -223,7 +223,7 @@ extern "C" int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in, const fl
 }
 
 extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O,
-                                       const int* cnt, int S, int heads, int rows, int cross, void* stream) {
+                                       const int* cnt, int S, int heads, int rows, int cross, int log2_domain, void* stream) {
     if (!h || !Q || !K || !V || !O || !cnt) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: null argument");
     AttnP a;
     a.Q = Q;
@@ -235,5 +235,6 @@ extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const flo
     a.heads = heads;
     a.rows_per_seq = rows;
     a.cross = cross;
+    a.log2_domain = log2_domain;
     return attention_launch(h, a, (hipStream_t)stream);
 }

@@ -126,13 +126,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
         const float m_new = fmaxf(m_run, m_t);  // finite: every tile holds >= 1 valid key
-        const float alpha = expf(m_run - m_new);
+        const bool l2d = p.log2_domain != 0;         // Q pre-multiplied by log2(e): the exponentials are base 2
+        const float alpha = l2d ? exp2f(m_run - m_new) : expf(m_run - m_new);
         float l_t = 0.0f;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = expf(s[f][r] - m_new);
+                const float pv = l2d ? exp2f(s[f][r] - m_new) : expf(s[f][r] - m_new);
                 s[f][r] = pv;
                 l_t += pv;
             }
@@ -201,6 +202,30 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Operands arrive PRE-SPLIT from the projection epilogue (gemm.hip, split_out): each of Q, K,
 // V^T is two f16 planes (hi then lo) in the buffer that holds the f32 tensor in exact mode, so a
 // K/V element is split once instead of once per query block and staging is a pure copy.
+//
+// On this part the matrix pipe and every other instruction a SIMD's waves issue take turns rather than overlap
+// (tools/overlap_lab.hip, tools/attn_pipe_lab): a key tile costs the 48 MFMAs plus whatever else is issued, so the
+// loop is trimmed to the instructions the arithmetic needs:
+//   * K / V^T tiles are fetched with buffer loads (wave-uniform descriptor + per-thread offset + scalar tile offset):
+//     no per-load 64-bit address arithmetic;
+//   * `log2_domain` callers (LightGlue / SuperGlue) deliver Q pre-multiplied by log2(e), and the S accumulators start
+//     from c = 14 - m_ref instead of 0, so the MFMAs themselves produce s log2e - m_ref log2e + 14 and a probability is
+//     ONE v_exp_f32 -- no multiply-add per element.  m_ref is the running maximum as of the last tile that moved it by
+//     more than 1.5 (in log2 units): a smaller growth only makes the tile's numbers up to 2^1.5 larger, well inside the
+//     f16 range of the split (hi < 2^16), and O / l is invariant to the reference.  A larger growth takes the rescale
+//     path (subtract the excess before the exponential, scale O and l), the first tile always does.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define DEFER_THR 1.5f
+
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    // the pointer only depends on blockIdx: tell the compiler (buffer descriptors must live in SGPRs)
+    const size_t v = (size_t)p;
+    return (const void*)((size_t)__builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu)) |
+                         ((size_t)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32));
+}
+
+template <bool L2D>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
@@ -228,6 +253,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     const unsigned short* Qh = reinterpret_cast<const unsigned short*>(p.Q) + ((size_t)seq * p.heads + head) * R * 64;
     const unsigned short* Kg = reinterpret_cast<const unsigned short*>(p.K) + ((size_t)kseq * p.heads + head) * R * 64;
     const unsigned short* Vg = reinterpret_cast<const unsigned short*>(p.V) + ((size_t)kseq * p.heads + head) * 64 * R;
+    // one (sequence, head) slab of R x 64 halves per plane and operand; reads past it return zeros
+    const unsigned slab = (unsigned)R * 64u * 2u;
+    const __amdgpu_buffer_rsrc_t rKh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(Kg)), 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rKl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(Kg + plane)), 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rVh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(Vg)), 0, slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rVl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(Vg + plane)), 0, slab, 0x00020000);
 
     // Q fragment of this lane: query q0 + wid*32 + lo, dims 16s + 8hi .. +7
     uint4 qh[4], ql[4];
@@ -246,7 +277,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
-    float m_run = -INFINITY, l_run = 0.0f;
+    // m_ref: reference maximum (log2 units when log2_domain) the numbers of O and l are scaled by; l_run: running sum
+    float m_ref = 0.0f, l_run = 0.0f;
+    constexpr bool l2d = L2D;  // Q pre-multiplied by log2(e) by the producer (the layers) or natural-log operands (C-ABI block)
+    f32x16 cinit;  // start value of the S accumulators: 0, or 14 - m_ref once a log2-domain reference exists
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.0f;
 
     // staging registers (named, see gemm.hip): K 64 keys x 8 octets x 2 planes = 4 x 16 B per thread,
     // V^T 64 d x 16 key-quads x 2 planes = 8 x 8 B per thread
@@ -254,21 +290,32 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     uint2 rv0, rv1, rv2, rv3, rv4, rv5, rv6, rv7;
     const int k_key = tid >> 3, k_oc = tid & 7;  // + 32 keys for the second item
     const int v_d = tid >> 4, v_kq = tid & 15;   // + 16 d per item
+    // per-thread byte offsets inside a slab; the tile adds a scalar (k0 keys = 128 k0 bytes of K, 2 k0 bytes of a V^T row)
+    const unsigned ko0 = (unsigned)(k_key * 64 + k_oc * 8) * 2u, ko1 = ko0 + 32u * 64u * 2u;
+    const unsigned vo0 = ((unsigned)v_d * (unsigned)R + (unsigned)v_kq * 4u) * 2u;
+    const unsigned vo1 = vo0 + 16u * (unsigned)R * 2u, vo2 = vo0 + 32u * (unsigned)R * 2u, vo3 = vo0 + 48u * (unsigned)R * 2u;
+    auto ld4 = [](const __amdgpu_buffer_rsrc_t& r, unsigned vo, unsigned so) __attribute__((always_inline)) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    auto ld2 = [](const __amdgpu_buffer_rsrc_t& r, unsigned vo, unsigned so) __attribute__((always_inline)) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0);
+        return make_uint2(v.x, v.y);
+    };
     auto load_tile = [&](int k0) __attribute__((always_inline)) {
-        const unsigned short* ks = Kg + (size_t)(k0 + k_key) * 64 + k_oc * 8;
-        rk0 = *reinterpret_cast<const uint4*>(ks);
-        rk1 = *reinterpret_cast<const uint4*>(ks + plane);
-        rk2 = *reinterpret_cast<const uint4*>(ks + 32 * 64);
-        rk3 = *reinterpret_cast<const uint4*>(ks + 32 * 64 + plane);
-        const unsigned short* vs = Vg + (size_t)v_d * R + k0 + v_kq * 4;
-        rv0 = *reinterpret_cast<const uint2*>(vs);
-        rv1 = *reinterpret_cast<const uint2*>(vs + plane);
-        rv2 = *reinterpret_cast<const uint2*>(vs + (size_t)16 * R);
-        rv3 = *reinterpret_cast<const uint2*>(vs + (size_t)16 * R + plane);
-        rv4 = *reinterpret_cast<const uint2*>(vs + (size_t)32 * R);
-        rv5 = *reinterpret_cast<const uint2*>(vs + (size_t)32 * R + plane);
-        rv6 = *reinterpret_cast<const uint2*>(vs + (size_t)48 * R);
-        rv7 = *reinterpret_cast<const uint2*>(vs + (size_t)48 * R + plane);
+        const unsigned sk = (unsigned)k0 * 128u, sv = (unsigned)k0 * 2u;
+        rk0 = ld4(rKh, ko0, sk);
+        rk1 = ld4(rKl, ko0, sk);
+        rk2 = ld4(rKh, ko1, sk);
+        rk3 = ld4(rKl, ko1, sk);
+        rv0 = ld2(rVh, vo0, sv);
+        rv1 = ld2(rVl, vo0, sv);
+        rv2 = ld2(rVh, vo1, sv);
+        rv3 = ld2(rVl, vo1, sv);
+        rv4 = ld2(rVh, vo2, sv);
+        rv5 = ld2(rVl, vo2, sv);
+        rv6 = ld2(rVh, vo3, sv);
+        rv7 = ld2(rVl, vo3, sv);
     };
     // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
     const int v_u = ((v_kq >> 2) * 2 + (v_kq & 1)) * 2 + ((v_kq >> 1) & 1);
@@ -301,22 +348,26 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     };
 
     // one 64-key tile: S^T = K.Q^T, online soft-max, O^T += V^T.P^T
-    auto compute_tile = [&](int k0, auto tail) __attribute__((always_inline)) {
+    //   FIRST: no reference maximum yet (accumulators start from 0, the tile's own maximum becomes the reference)
+    //   TAIL : the tile may hold keys past the sequence end
+    auto compute_tile = [&](int k0, auto first, auto tail) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value, TAIL = decltype(tail)::value;
+        // with a reference the accumulation starts from cinit = 14 - m_ref (the C operand of the first MFMA of both
+        // fragments; kept in registers across tiles, rewritten only when the reference moves): the MFMAs deliver the
+        // exponent directly
         f32x16 s[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[f][r] = 0.0f;
-#pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const uint4 ah = Kh[(2 * st + hi) * KSTR + 32 * f + lo];
                 const uint4 al = Kl[(2 * st + hi) * KSTR + 32 * f + lo];
-                s[f] = mfma16(al, qh[st], s[f]);
+                s[f] = mfma16(al, qh[st], st == 0 ? cinit : s[f]);
                 s[f] = mfma16(ah, ql[st], s[f]);
                 s[f] = mfma16(ah, qh[st], s[f]);
             }
         }
-        if (decltype(tail)::value) {  // only the last tile can hold keys past the sequence end
+        if (TAIL) {  // only the last tile can hold keys past the sequence end
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -329,35 +380,82 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
-        const float m_new = fmaxf(m_run, m_t);
-        // p * 2^14 = exp2(s*log2e - m*log2e + 14): one fma + one v_exp_f32 per element; the 2^14
-        // (which keeps the f16 low parts of small probabilities normal) cancels in O / l.
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        const float bias = P_SHIFT - m_new * LOG2E;
-        // two elements per instruction where the ISA has packed f32 forms (v_pk_fma_f32, v_pk_add_f32): on a
-        // SIMD the VALU and matrix instructions of co-resident waves serialise, so every VALU slot saved is
-        // matrix time gained
-        f32x2 l2 = {0.0f, 0.0f};
-        const f32x2 k2 = {LOG2E, LOG2E}, b2 = {bias, bias};
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 x = {s[f][r], s[f][r + 1]};
-                const f32x2 a = __builtin_elementwise_fma(x, k2, b2);
-                const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-                l2 += e;
-                s[f][r] = e[0];
-                s[f][r + 1] = e[1];
-            }
-        const float l_t = l2[0] + l2[1];
-        l_run = l_run * alpha + l_t;
-        m_run = m_new;
-        if (__ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
+        f32x2 la = {0.0f, 0.0f}, lb = {0.0f, 0.0f};
+        if constexpr (!l2d) {
+            // natural-log operands (building-block entry point): p * 2^14 = exp2(s*log2e - m*log2e + 14), one fma + one v_exp_f32
+            const float m_new = FIRST ? m_t : fmaxf(m_ref, m_t);
+            const float alpha = FIRST ? 0.0f : __builtin_amdgcn_exp2f((m_ref - m_new) * LOG2E);
+            const float bias = P_SHIFT - m_new * LOG2E;
+            const f32x2 k2 = {LOG2E, LOG2E}, b2 = {bias, bias};
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+                for (int r = 0; r < 16; r += 4) {
+                    const f32x2 x = {s[f][r], s[f][r + 1]}, y = {s[f][r + 2], s[f][r + 3]};
+                    const f32x2 a = __builtin_elementwise_fma(x, k2, b2), b = __builtin_elementwise_fma(y, k2, b2);
+                    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    const f32x2 g = {__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+                    la += e;
+                    lb += g;
+                    s[f][r] = e[0];
+                    s[f][r + 1] = e[1];
+                    s[f][r + 2] = g[0];
+                    s[f][r + 3] = g[1];
+                }
+            l_run = l_run * alpha + ((la[0] + la[1]) + (lb[0] + lb[1]));
+            m_ref = m_new;
+            if (!FIRST && __ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+            }
+        } else {
+            // log2 domain.  FIRST: s holds the raw exponents, the tile maximum becomes the reference.  Later tiles: s already
+            // holds s - m_ref + 14; only a growth of the maximum beyond DEFER_THR needs work before the exponential.
+            const float excess = FIRST ? m_t - P_SHIFT : fmaxf(m_t - P_SHIFT, 0.0f);  // what to take off the exponents
+            const bool shift = FIRST || (__ballot(m_t > P_SHIFT + DEFER_THR) != 0ull);
+            if (shift) {
+                const f32x2 d2 = {excess, excess};
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 x = {s[f][r], s[f][r + 1]};
+                        const f32x2 y = x - d2;
+                        s[f][r] = y[0];
+                        s[f][r + 1] = y[1];
+                    }
+                if (FIRST) {
+                    m_ref = m_t;  // the tile maximum (accumulators started from 0) is the first reference
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cinit[r] = P_SHIFT - m_ref;
+                } else {
+                    const float alpha = __builtin_amdgcn_exp2f(-excess);
+                    m_ref += excess;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cinit[r] = P_SHIFT - m_ref;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const f32x2 e = {__builtin_amdgcn_exp2f(s[f][r]), __builtin_amdgcn_exp2f(s[f][r + 1])};
+                    const f32x2 g = {__builtin_amdgcn_exp2f(s[f][r + 2]), __builtin_amdgcn_exp2f(s[f][r + 3])};
+                    la += e;
+                    lb += g;
+                    s[f][r] = e[0];
+                    s[f][r + 1] = e[1];
+                    s[f][r + 2] = g[0];
+                    s[f][r + 3] = g[1];
+                }
+            l_run += (la[0] + la[1]) + (lb[0] + lb[1]);
         }
         // step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
 #pragma unroll
@@ -383,18 +481,28 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 
     const int ntile = (nk + KT - 1) / KT;
     if (ntile > 0) load_tile(0);
-    for (int tile = 0; tile + 1 < ntile; ++tile) {
+    if (ntile > 1) {  // first tile sets the reference maximum
+        __syncthreads();
+        store_tile(0, std::false_type{});
+        __syncthreads();
+        load_tile(KT);
+        compute_tile(0, std::true_type{}, std::false_type{});
+    }
+    for (int tile = 1; tile + 1 < ntile; ++tile) {
         __syncthreads();  // previous tile fully consumed
         store_tile(tile * KT, std::false_type{});
         __syncthreads();
         load_tile((tile + 1) * KT);
-        compute_tile(tile * KT, std::false_type{});
+        compute_tile(tile * KT, std::false_type{}, std::false_type{});
     }
     if (ntile > 0) {
         __syncthreads();
         store_tile((ntile - 1) * KT, std::true_type{});
         __syncthreads();
-        compute_tile((ntile - 1) * KT, std::true_type{});
+        if (ntile == 1)
+            compute_tile(0, std::true_type{}, std::true_type{});
+        else
+            compute_tile((ntile - 1) * KT, std::false_type{}, std::true_type{});
     }
 
     // ---- normalise and write (transpose through LDS so each query row is stored contiguously)
@@ -428,8 +536,10 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if ((p.heads * p.nseq) % 8 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: heads*nseq=%d must be a multiple of 8", p.heads * p.nseq);
     dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
-    if (h->precision == 1)
-        hipLaunchKernelGGL(attn_split_kernel, grid, dim3(256), 0, stream, p);
+    if (h->precision == 1 && p.log2_domain)
+        hipLaunchKernelGGL(attn_split_kernel<true>, grid, dim3(256), 0, stream, p);
+    else if (h->precision == 1)
+        hipLaunchKernelGGL(attn_split_kernel<false>, grid, dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
     imcui_prof_end(h, PROF_ATTN, stream);

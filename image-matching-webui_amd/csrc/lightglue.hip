@@ -969,7 +969,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.V = w.v;
             g.rope_cos = w.cs;
             g.rope_sin = w.sn;
-            g.alpha = 0.125f;  // 1/sqrt(64), folded into q (exact power of two)
+            g.alpha = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) and log2(e) folded into q: the attention kernels work in base 2
             g.heads = LG_HEADS;
             LGRUN(gemm_launch(h, g, stream));
             AttnP a;
@@ -983,6 +983,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.heads = LG_HEADS;
             a.rows_per_seq = R;
             a.cross = 0;
+            a.log2_domain = 1;
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.b2s));
         }
@@ -1003,7 +1004,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.plane_halves = (size_t)S * R * 256;
             g.Q = w.q;
             g.V = w.v;
-            g.alpha = (float)0.35355339059327373;  // (64 ** -0.5) ** 0.5 applied to both sides
+            g.alpha = (float)(0.35355339059327373 * 1.2011224087864498);  // (64 ** -0.5) ** 0.5 and sqrt(log2 e), applied to both sides
             g.heads = LG_HEADS;
             LGRUN(gemm_launch(h, g, stream));
             AttnP a;
@@ -1017,6 +1018,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.heads = LG_HEADS;
             a.rows_per_seq = R;
             a.cross = 1;
+            a.log2_domain = 1;
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
         }

@@ -865,7 +865,7 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
         g.V = w.v;
         g.rope_cos = w.one;  // no rotary encoding in SuperGlue: q * 1 + rotate_half(q) * 0
         g.rope_sin = w.zero;
-        g.alpha = 0.125f;  // scores / 64 ** .5, folded into q (exact power of two)
+        g.alpha = 0.125f * 1.44269504088896340736f;  // scores / 64 ** .5 and log2(e) folded into q: the attention kernels work in base 2
         g.heads = SG_HEADS;
         SGRUN(gemm_launch(h, g, stream));
         AttnP a;
@@ -879,6 +879,7 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
         a.heads = SG_HEADS;
         a.rows_per_seq = R;
         a.cross = layer & 1;
+        a.log2_domain = 1;
         SGRUN(attention_launch(h, a, stream));
         GemmP f1;  // relu(bn(mlp.0(cat[x, merge(ctx)]))) with merge and bn folded into the weights
         base(f1);

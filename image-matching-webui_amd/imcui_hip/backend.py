@@ -727,11 +727,14 @@ def _split_planes(t: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo], 0).contiguous()
 
 
-def attention_f32(q, k, v, cnt, cross=False):
-    """q,k,v [S,heads,rows,64] head-major (q pre-scaled); cnt [S] int32 -> [S*rows, heads*64]."""
+def attention_f32(q, k, v, cnt, cross=False, log2_domain=False):
+    """q,k,v [S,heads,rows,64] head-major (q pre-scaled); cnt [S] int32 -> [S*rows, heads*64].
+    log2_domain: q is multiplied by log2(e) here and the kernel's base-2 soft-max path (the one the layers use) runs."""
     hd = get_handle(q.device)
     S, Hh, R, d = q.shape
     assert d == 64
+    if log2_domain:
+        q = q.float() * 1.4426950408889634
     if hd.lib.imcui_hip_get_precision(hd.h) == 1:
         # the split kernel consumes pre-split f16 planes of Q, K and V^T [S,heads,64,rows]
         q, k, v = _split_planes(q.float()), _split_planes(k.float()), _split_planes(v.float().transpose(2, 3).contiguous())
@@ -741,7 +744,7 @@ def attention_f32(q, k, v, cnt, cross=False):
     cnt = cnt.to(torch.int32).contiguous()
     with torch.cuda.device(q.device):
         hd.check(
-            hd.lib.imcui_hip_attention_f32(hd.h, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(cnt), S, Hh, R, int(cross), _stream_ptr()),
+            hd.lib.imcui_hip_attention_f32(hd.h, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(cnt), S, Hh, R, int(cross), int(bool(log2_domain)), _stream_ptr()),
             "attention",
         )
     return o

@@ -106,7 +106,7 @@ SIGNATURES = {
     "imcui_hip_linear_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "imcui_hip_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_conv3x3_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
-    "imcui_hip_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p]),
+    "imcui_hip_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
 }
 
 

@@ -271,9 +271,11 @@ int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in_nhwc, const float* w
                             float* out_nhwc, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int act,
                             void* stream);
 /* softmax(Q K^T) V, head_dim 64, operands head-major [S][heads][rows][64] (Q pre-scaled),
- * output token-major [S*rows][heads*64]; cnt [dev, S] valid rows; cross: keys of sequence s^1. */
+ * output token-major [S*rows][heads*64]; cnt [dev, S] valid rows; cross: keys of sequence s^1.
+ * log2_domain = 1: Q additionally carries a factor log2(e) and the soft-max is evaluated in base 2 (what the LightGlue /
+ * SuperGlue layers do: one v_exp_f32 per probability, no multiply); 0: natural-log operands. */
 int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,
-                            int heads, int rows, int cross, void* stream);
+                            int heads, int rows, int cross, int log2_domain, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,8 +96,10 @@ def test_attention_f32(cross, precision):
         assert (got - ref).abs().max().item() < 2e-5
 
 
-def test_attention_sharp_softmax(precision):
-    """Large logits: one key dominates; exercises the running-max rescale across tiles."""
+@pytest.mark.parametrize("log2_domain", [False, True], ids=["natural-log", "base-2"])
+def test_attention_sharp_softmax(log2_domain, precision):
+    """Large logits: one key dominates; exercises the running-max rescale across tiles (base 2: the deferred-maximum path --
+    a spike far above the reference must take the rescale branch, growth below 1.5 must not change the result)."""
     from imcui_hip import backend
 
     g = torch.Generator().manual_seed(6)
@@ -107,7 +109,7 @@ def test_attention_sharp_softmax(precision):
     k = torch.randn(S, Hh, R, 64, generator=g) * 3.0
     k[:, :, 290] *= 4.0  # spike in the last tile
     v = torch.randn(S, Hh, R, 64, generator=g)
-    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), False).cpu().view(S, R, Hh, 64)
+    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), False, log2_domain).cpu().view(S, R, Hh, 64)
     for s in range(S):
         n = int(cnt[s])
         att = torch.softmax(q[s, :, :n].double() @ k[s, :, :n].double().transpose(-1, -2), -1)
@@ -146,8 +148,9 @@ def test_rgb_to_gray_bit_exact(B, H, W):
     assert out.shape == ref.shape and np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("log2_domain", [False, True], ids=["natural-log", "base-2"])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_long_ragged_sequences(cross, precision):
+def test_attention_long_ragged_sequences(cross, log2_domain, precision):
     """The bench shape (2048 rows per sequence, 32 key tiles: the steady-state, hand-interleaved iterations of
     attn_split_pipe_kernel run 14 times) with ragged counts -- full, one key short of a tile, one key into a tile, a
     single tile, odd and even tile counts -- poisoned padding and a spiked key that moves the running maximum late."""
@@ -163,7 +166,7 @@ def test_attention_long_ragged_sequences(cross, precision):
     for s in range(S):
         k[s, :, cnt[s]:] = float("nan")
         v[s, :, cnt[s]:] = float("inf")
-    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), cross).cpu().view(S, R, Hh, 64)
+    out = backend.attention_f32(q.to(_dev()), k.to(_dev()), v.to(_dev()), cnt.to(_dev()), cross, log2_domain).cpu().view(S, R, Hh, 64)
     for s in range(S):
         ks = s ^ 1 if cross else s
         nq, nk = int(cnt[s]), int(cnt[ks])
