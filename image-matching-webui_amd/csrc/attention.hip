@@ -221,8 +221,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     // the pointer only depends on blockIdx: tell the compiler (buffer descriptors must live in SGPRs)
     const size_t v = (size_t)p;
-    return (const void*)((size_t)__builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu)) |
-                         ((size_t)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32));
+    // (the builtin returns int: go through unsigned before widening, or a low word with its top bit set sign-extends
+    // into the high word)
+    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
+    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void*)((size_t)lo32 | ((size_t)hi32 << 32));
 }
 
 template <bool L2D>
