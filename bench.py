@@ -206,6 +206,15 @@ def bench_loftr(args, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
+        import glob
+
+        # HBM bytes of the GEMM-class kernels per launch from the committed PMC passes of the same workload (1024^2 only)
+        traffic = None
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_loftr.json")))
+        if cands and (Hh, Ww) == (1024, 1024) and gemm_n:
+            with open(cands[-1]) as fh:
+                tj = json.load(fh)
+            traffic = tj["traffic_bytes_per_step_gemm_kernels"] * B / tj["pairs_per_step"] / (gemm_n / args.steps)
         # algorithmic work: 2.55 TF / pair at 1024^2, scaled by area (coarse sim by area^2)
         area = Hh * Ww / (1024.0 * 1024.0)
         tf_pair = (2.03 + 0.35 + 0.03) * area + 0.14 * area * area
@@ -216,10 +225,10 @@ def bench_loftr(args, dev, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
             "config": {"workload": f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM",
                        "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), "weights": "seeded random (imcui_hip/synth_weights.py), kornia LoFTR architecture"},
-            "roofline": {"kernel": "gemm_split_kernel (convolutions as implicit-im2col GEMM)" if split else "gemm_kernel", "bound": "mfma",
+            "roofline": {"kernel": "gemm_split_kernel (GEMM class: convolutions as implicit-im2col GEMM + transformer projections)" if split else "gemm_kernel", "bound": "mfma",
                          "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": (tf_pair * B * args.steps / (gemm_ms * 1e-3) / (PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF)) if gemm_ms else 0.0,
-                         "traffic": None, "gemm_ms_per_step": gemm_ms / args.steps, "launches_per_step": gemm_n / args.steps,
+                         "traffic": traffic, "gemm_ms_per_step": gemm_ms / args.steps, "launches_per_step": gemm_n / args.steps,
                          "note": "achieved = algorithmic TFLOP of a pair / summed GEMM-class kernel time (HIP events)"},
             "algorithmic_tflops_end_to_end": tf_pair * B / (dt / args.steps),
         }  # fmt: skip
@@ -512,8 +521,11 @@ def main():
         # HBM-side bytes per attention launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs, FETCH doubled per MI355X_MICROARCH.md); scales with the batch
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
-        if split and os.path.exists(tpath):
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_attention_traffic.json")))  # newest round's PMC passes
+        tpath = cands[-1] if cands else ""
+        if split and tpath:
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic = tj["traffic_bytes_per_launch"] * B / tj["batch_pairs"]

@@ -175,3 +175,55 @@ def test_attention_long_ragged_sequences(cross, log2_domain, precision):
         got = out[s, :nq]
         assert torch.isfinite(got).all(), f"sequence {s}"
         assert (got - ref).abs().max().item() < 3e-5, f"sequence {s}: {(got - ref).abs().max().item():.2e}"
+
+
+def _wide_range(shape, g, lo_exp=-7.0, hi_exp=4.7):
+    """Random signs, magnitudes log-uniform over many decades (1e-7 .. 5e4): what real checkpoints feed the kernels --
+    post-ReLU feature maps with a few very large channels next to near-zero ones."""
+    mag = 10.0 ** (torch.rand(shape, generator=g) * (hi_exp - lo_exp) + lo_exp)
+    return mag * (torch.randint(0, 2, shape, generator=g).float() * 2 - 1)
+
+
+def test_split_mode_dynamic_range():
+    """The 3 x f16 split keeps a value as hi = f16(x) + lo = f16(x - hi): exact to 2^-22 relative while lo is a normal
+    f16, and to an ABSOLUTE 3e-8 (half the smallest f16 subnormal) once |x| < ~1e-3 makes lo subnormal; |x| up to
+    2 x 65504 is representable (hi saturates, lo takes the rest).  Activations are not rescaled (weights are), so this
+    checks the matrix kernels on inputs spanning 1e-7 .. 5e4 -- far beyond the seeded synthetic data -- against fp64:
+    the error stays at fp32 round-off level relative to the magnitude of the outputs."""
+    from imcui_hip import backend
+
+    dev = _dev()
+    backend.set_precision(dev, 1)
+    g = torch.Generator().manual_seed(77)
+    # GEMM, pre-split weights (every network projection)
+    a = _wide_range((384, 256), g)
+    w = torch.randn(512, 256, generator=g) / 16.0
+    ref = a.double() @ w.double().t()
+    out = backend.linear_split_f32(a.to(dev), w, None).cpu()
+    assert (out - ref.float()).abs().max().item() / ref.abs().max().item() < 4e-6
+    # small-magnitude rows must not be flushed: compare them on their own scale
+    tiny = a.abs().max(dim=1).values.argmin()
+    a2 = a.clone()
+    a2[tiny] = _wide_range((256,), g, -7.0, -4.0)  # a row entirely below 1e-4: its lo parts are all subnormal
+    ref2 = a2[tiny].double() @ w.double().t()
+    out2 = backend.linear_split_f32(a2.to(dev), w, None).cpu()[tiny]
+    assert (out2 - ref2.float()).abs().max().item() < 64 * 3e-8 * 256 ** 0.5  # absolute bound from the subnormal lo parts
+    # both operands activations (similarity products): f32 weights split on the fly
+    b = _wide_range((320, 256), g, -5.0, 2.5)
+    ref = a.double() @ b.double().t()
+    out = backend.linear_f32(a.to(dev), b.to(dev), None).cpu()
+    assert (out - ref.float()).abs().max().item() / ref.abs().max().item() < 4e-6
+    # 3x3 convolution
+    x = _wide_range((1, 64, 24, 40), g, -6.0, 3.5).abs()  # post-ReLU like
+    wc = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    bc = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wc.double(), bc.double(), padding=1)).float().permute(0, 2, 3, 1)
+    out = backend.conv3x3_f32(x.permute(0, 2, 3, 1).contiguous().to(dev), wc, bc, relu=True, pool=False).cpu()
+    assert (out - ref).abs().max().item() / ref.abs().max().item() < 4e-6
+    # values between one and two times the f16 maximum still split exactly
+    big = torch.full((128, 256), 0.0)
+    big[:, 0] = 1.2e5
+    big[:, 1] = -9.0e4
+    ref = big.double() @ w.double().t()
+    out = backend.linear_split_f32(big.to(dev), w, None).cpu()
+    assert torch.isfinite(out).all() and (out - ref.float()).abs().max().item() / ref.abs().max().item() < 4e-6

@@ -337,3 +337,56 @@ def test_graph_replay_equals_eager_launches():
     assert (eager_a["matches0"] > -1).sum() > 20
     with pytest.raises(ValueError):
         g(a0[:1], a1[:1])
+
+
+def test_two_streams_do_not_share_scratch():
+    """Scratch workspaces are per (device, stream): the same plugin objects driven from two HIP streams at once (two
+    Gradio worker threads) must give the results of serial calls -- with a shared workspace the second launch would
+    overwrite the first one's intermediates while its kernels are still in flight."""
+    from imcui_hip.pipeline import SuperPointLightGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from imcui_hip.synth_weights import superpoint_state_dict
+
+    pipe = SuperPointLightGluePipeline(
+        {"nms_radius": 3, "max_keypoints": 1024, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)},
+        {"depth_confidence": -1.0, "width_confidence": -1.0, "match_threshold": 0.1, "state_dict": LSD},
+    ).eval().to("cuda:0")
+    a0, a1, _ = make_pair_batch(31, 4, 480, 640)
+    b0, b1, _ = make_pair_batch(32, 4, 480, 640)
+    a0, a1, b0, b1 = a0.cuda(), a1.cuda(), b0.cuda(), b1.cuda()
+    keys = ("num_keypoints0", "keypoints0", "matches0", "matching_scores0", "matches1")
+    ref_a = {k: v.clone() for k, v in pipe(a0, a1).items() if k in keys}
+    ref_b = {k: v.clone() for k, v in pipe(b0, b1).items() if k in keys}
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):  # several rounds: the overlap is a race, give it chances
+        with torch.cuda.stream(s1):
+            out_a = pipe(a0, a1)
+        with torch.cuda.stream(s2):
+            out_b = pipe(b0, b1)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(out_a[k], ref_a[k]), f"stream 1: {k}"
+            assert torch.equal(out_b[k], ref_b[k]), f"stream 2: {k}"
+
+
+def test_all_keypoints_conf_is_graph_capturable():
+    """max_keypoints = -1 (the plugin default) used to synchronise to read the selection status, which made HIP-graph
+    capture fail; the status is a device tensor now."""
+    from imcui_hip.pipeline import GraphedPipeline, SuperPointLightGluePipeline
+    from imcui_hip.synth import make_pair_batch
+    from imcui_hip.synth_weights import superpoint_state_dict
+
+    pipe = SuperPointLightGluePipeline(
+        {"nms_radius": 4, "max_keypoints": -1, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)},
+        {"depth_confidence": 0.95, "width_confidence": 0.99, "match_threshold": 0.1, "state_dict": LSD},
+    ).eval().to("cuda:0")
+    a0, a1, _ = make_pair_batch(7, 1, 240, 320, n_blobs=500)
+    a0, a1 = a0.cuda(), a1.cuda()
+    eager = {k: v.clone() for k, v in pipe(a0, a1).items()}
+    g = GraphedPipeline(pipe, a0, a1)
+    out = g(a0, a1)
+    torch.cuda.synchronize()
+    for k in ("num_keypoints0", "keypoints1", "matches0", "matching_scores0", "stop"):
+        assert torch.equal(out[k], eager[k]), k
+    assert int(eager["num_keypoints0"][0]) > 100

@@ -20,12 +20,23 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spl
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   echo pmc $c rc $?
+  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_loftr_$c -o loftr -- python $R/bench.py --workload loftr --steps 2 --warmup 1 > $O/pmc_loftr_$c.log 2>&1
 done
+# matrix-pipe occupancy and stall breakdown (one pass: 7 of the 8 SQ slots)
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_SQ -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_SQ.log 2>&1
+echo pmc SQ rc $?
 [ $K = 1 ] || timeout 60 $R/tools/clock_lab > $O/lab_clock.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/overlap_lab > $O/lab_overlap.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/launch_lab > $O/lab_launch.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/gridsync_lab > $O/lab_gridsync.txt 2>&1
 ( cd $R && timeout 100 python bench.py --adaptive --no-cpu-baseline > $O/bench_splg_adaptive.json.log 2>&1; tail -1 $O/bench_splg_adaptive.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python bench.py --batch 1 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_splg_b1.json.log 2>&1; tail -1 $O/bench_splg_b1.json.log | cut -c1-160 )
+( cd $R && timeout 100 python bench.py --batch 64 --steps 6 --no-cpu-baseline > $O/bench_splg_b64.json.log 2>&1; tail -1 $O/bench_splg_b64.json.log | cut -c1-160 )
+# HIP-graph replay vs eager launches at the latency-bound operating points (reference-default adaptive LightGlue)
+for b in 1 4; do
+  ( cd $R && timeout 100 python bench.py --batch $b --adaptive --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_splg_adaptive_b${b}_eager.json.log 2>&1 )
+  ( cd $R && timeout 100 python bench.py --batch $b --adaptive --graph --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_splg_adaptive_b${b}_graph.json.log 2>&1 )
+done
+[ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 ls $O

@@ -15,10 +15,14 @@ P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
 
-def agg(counter):
-    rows = list(csv.DictReader(open(os.path.join(F, f"pmc_{counter}", "splg_counter_collection.csv"))))
+def agg(counter, sub=None, stem="splg", name=None):
+    """Per-kernel mean of one counter over the launches of a PMC pass (directory pmc_<sub>, counter column `name`)."""
+    path = os.path.join(F, f"pmc_{sub or counter}", f"{stem}_counter_collection.csv")
+    rows = list(csv.DictReader(open(path)))
     by = collections.defaultdict(list)
     for r in rows:
+        if name is not None and r.get("Counter_Name") != name:
+            continue
         by[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in by.items()}
 
@@ -33,15 +37,46 @@ for k in fe:
 json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1, B={B} pairs; per-launch "
                    "averages in bytes; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md", "batch_pairs": B, "kernels": out},
           open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-a = out["attn_split_kernel"]
-json.dump({"kernel": "attn_split_kernel", "source": f"profiles/{tag}_pmc_traffic.json", "batch_pairs": B,
+akey = next(k for k in out if k.startswith("attn_split_kernel"))
+a = out[akey]
+json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_pairs": B,
            "fetch_bytes_per_launch": a["fetch_bytes_per_launch"], "write_bytes_per_launch": a["write_bytes_per_launch"],
            "traffic_bytes_per_launch": a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"],
            "algorithmic_bytes_per_launch": 16777216 * B,
            "note": "Q, K, V^T planes read once + O written once per launch; the XCD-aware grid keeps the K/V of a (sequence, head) in one L2 "
                    "(traffic == compulsory bytes; it was 4.5x that before the remap)"},
-          open(os.path.join(P, "r01_attention_traffic.json"), "w"), indent=1)
-for opt in ("adaptive", "b1"):  # operating points beside the headline line (collected when present)
+          open(os.path.join(P, f"{tag}_attention_traffic.json"), "w"), indent=1)
+# LoFTR: HBM traffic of the GEMM-class kernels per step (same two passes on the loftr workload)
+if os.path.exists(os.path.join(F, "pmc_loftr_FETCH_SIZE", "loftr_counter_collection.csv")):
+    lfe, lwr = agg("FETCH_SIZE", "loftr_FETCH_SIZE", "loftr"), agg("WRITE_SIZE", "loftr_WRITE_SIZE", "loftr")
+    lb = json.loads(open(os.path.join(F, "bench_loftr_1024.json.log")).read().strip().split("\n")[-1])
+    lout = {k: {"launches": v[1], "fetch_bytes_per_launch": v[0] * 1024 * 2, "write_bytes_per_launch": lwr.get(k, (0, 0))[0] * 1024}
+            for k, v in lfe.items() if v[1] >= 2}
+    steps = 3  # bench.py --steps 2 --warmup 1
+    tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in lout.values()) / steps
+    gem = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for k, v in lout.items() if k.startswith("gemm_")) / steps
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload loftr --steps 2 --warmup 1; FETCH doubled",
+               "pairs_per_step": lb["config"]["pairs_per_step_per_gpu"], "traffic_bytes_per_step_all_kernels": tot,
+               "traffic_bytes_per_step_gemm_kernels": gem, "kernels": lout}, open(os.path.join(P, f"{tag}_pmc_traffic_loftr.json"), "w"), indent=1)
+# matrix-pipe occupancy / stall breakdown from the SQ pass
+sqp = os.path.join(F, "pmc_SQ", "splg_counter_collection.csv")
+if os.path.exists(sqp):
+    names = ["SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT"]
+    cnt = {n: agg(None, "SQ", "splg", n) for n in names}
+    sq = {}
+    for k, (busy, n) in cnt["SQ_BUSY_CYCLES"].items():
+        g = lambda c: cnt[c].get(k, (0.0, 0))[0]  # noqa: E731
+        kc = busy / 32.0  # SQ_BUSY_CYCLES is summed over the 32 shader engines
+        wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+        sq[k] = {"launches": n, "kernel_cycles": kc, "mfma_busy_cycles_per_simd": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0,
+                 "mfma_busy_frac": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / max(kc, 1.0), "valu_active_frac_of_wave_cycles": g("SQ_ACTIVE_INST_VALU") / wc,
+                 "wait_any_frac": g("SQ_WAIT_ANY") / wc, "wait_inst_frac": g("SQ_WAIT_INST_ANY") / wc, "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT")}
+    json.dump({"note": f"rocprofv3 --pmc SQ_* (one pass), bench.py --steps 2 --warmup 1, B={B}; kernel_cycles = SQ_BUSY_CYCLES / 32 shader engines, "
+                       "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; per-launch averages", "kernels": sq},
+              open(os.path.join(P, f"{tag}_pmc_sq.json"), "w"), indent=1)
+    for k, v in sorted(sq.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])[:6]:
+        print(f"{k[:50]:50s} mfma_busy {v['mfma_busy_frac']:.3f} wait_any {v['wait_any_frac']:.2f} wait_inst {v['wait_inst_frac']:.2f}")
+for opt in ("adaptive", "b1", "adaptive_b1_eager", "adaptive_b1_graph", "adaptive_b4_eager", "adaptive_b4_graph"):  # operating points beside the headline line
     if os.path.exists(os.path.join(F, f"bench_splg_{opt}.json.log")):
         shutil.copy(os.path.join(F, f"bench_splg_{opt}.json.log"), os.path.join(P, f"{tag}_bench_splg_{opt}.json.log"))
 for src, dst in [("bench_superglue.json.log", f"{tag}_bench_superglue.json.log"),
@@ -53,8 +88,7 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_superpoint.json.log", f"{tag}_bench_superpoint.json.log"),
                  ("stats_splg/splg_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg.csv"),
                  ("stats_loftr/loftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_loftr_1024.csv"),
-                 ("lab_clock.txt", "r01_lab_mfma_clock.txt"), ("lab_overlap.txt", "r01_lab_mfma_valu_overlap.txt"),
-                 ("lab_launch.txt", "r01_lab_workgroup_launch.txt"), ("lab_gridsync.txt", "r01_lab_gridsync_barrier.txt")]:
+                 ("bench_loftr_640x480.json.log", f"{tag}_bench_loftr_640x480.json.log"), ("bench_splg_b64.json.log", f"{tag}_bench_splg_b64.json.log")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
     shutil.copy(os.path.join(F, src), os.path.join(P, dst))
