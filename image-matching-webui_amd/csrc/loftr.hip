@@ -501,17 +501,18 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
                            w.fatt);
         if ((r = lin_b(base + 3, w.fatt, 128, nullptr, w.fm, wcap, 0, 1, side0, nsides, false))) return r;
         const int nl = 32 + layer * 4;
-        // LayerNorm over every (capacity) row of the processed sides: rows past nmatch*25 hold stale data and are never read
+        // LayerNorm of the live window tokens of the processed sides (nmatch * 25 of the wcap rows per side)
         const long rows = (long)nsides * wcap;
         float* fm0 = w.fm + (size_t)side0 * wcap * 128;
-        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, fm0, P + l.norm[nl + 0],
-                           P + l.norm[nl + 1], (const float*)nullptr, fm0, rows, 0);
+        const unsigned lngrid = (unsigned)min((rows + 3) / 4, (long)4096);
+        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3(lngrid), blk, 0, stream, fm0, P + l.norm[nl + 0],
+                           P + l.norm[nl + 1], (const float*)nullptr, fm0, rows, 0, w.cnt2 + 1, wcap);
         if ((r = lin_b(base + 4, w.F, 128, w.fm, w.fh, wcap, 1, 1, side0, nsides, false))) return r;
         if ((r = lin_b(base + 5, w.fh, 256, nullptr, w.fo, wcap, 0, 1, side0, nsides, false))) return r;
         float* fo0 = w.fo + (size_t)side0 * wcap * 128;
         float* f0 = w.F + (size_t)side0 * wcap * 128;
-        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, fo0, P + l.norm[nl + 2],
-                           P + l.norm[nl + 3], f0, f0, rows, 1);
+        hipLaunchKernelGGL(lf_layernorm_kernel<2>, dim3(lngrid), blk, 0, stream, fo0, P + l.norm[nl + 2],
+                           P + l.norm[nl + 3], f0, f0, rows, 1, w.cnt2 + 1, wcap);
         return IMCUI_OK;
     };
     LFRUN(fine_layer(0, 0, 2, 0));  // self on both windows

@@ -102,35 +102,43 @@ __global__ __launch_bounds__(256) void lf_posenc_kernel(float* __restrict__ feat
 
 // ------------------------------------------------------------------ LayerNorm over D = 64 * VEC features, one wave per row
 // mode 0: y = LN(x)   mode 1: y = res + LN(x)   (y may alias res)
+// valid / group (optional): the rows come in groups of `group` rows of which only the first *valid are in use (the
+// fine level: capacity B*L*25 window tokens per side, nmatch*25 of them live) -- the rest is skipped
 template <int VEC>
 __global__ __launch_bounds__(256) void lf_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* res,
-                                                           float* y, long rows, int mode) {
+                                                           float* y, long rows, int mode, const int* __restrict__ valid = nullptr,
+                                                           long group = 0) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     constexpr int D = 64 * VEC;
-    float v[VEC];
-    const float* xr = x + row * D + lane * VEC;
-    float s = 0.0f;
+    // live rows: all of them, or the first *valid of every group (then the launch is a fixed-size grid-stride loop: the
+    // count lives on the device and capacity-sized grids of empty workgroups cost more than the work)
+    const long nval = valid ? (long)*valid : 0;
+    const long nlive = valid ? (rows / group) * nval : rows;
+    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < nlive; t += (long)gridDim.x * 4) {
+        const long row = valid ? (t / nval) * group + (t % nval) : t;
+        float v[VEC];
+        const float* xr = x + row * D + lane * VEC;
+        float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        v[j] = xr[j];
-        s += v[j];
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.0f;
+        for (int j = 0; j < VEC; ++j) {
+            v[j] = xr[j];
+            s += v[j];
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.0f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        v[j] -= mean;
-        q += v[j] * v[j];
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+        for (int j = 0; j < VEC; ++j) {
+            v[j] -= mean;
+            q += v[j] * v[j];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        float o = v[j] * rstd * gamma[lane * VEC + j] + beta[lane * VEC + j];
-        if (mode == 1) o += res[row * D + lane * VEC + j];
-        y[row * D + lane * VEC + j] = o;
+        for (int j = 0; j < VEC; ++j) {
+            float o = v[j] * rstd * gamma[lane * VEC + j] + beta[lane * VEC + j];
+            if (mode == 1) o += res[row * D + lane * VEC + j];
+            y[row * D + lane * VEC + j] = o;
+        }
     }
 }
 
