@@ -416,8 +416,11 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         } else {
             // log2 domain.  FIRST: s holds the raw exponents, the tile maximum becomes the reference.  Later tiles: s already
             // holds s - m_ref + 14; only a growth of the maximum beyond DEFER_THR needs work before the exponential.
-            const float excess = FIRST ? m_t - P_SHIFT : fmaxf(m_t - P_SHIFT, 0.0f);  // what to take off the exponents
-            const bool shift = FIRST || (__ballot(m_t > P_SHIFT + DEFER_THR) != 0ull);
+            // what to take off this query's exponents: its own decision only (a lane whose maximum grew by less than the
+            // threshold subtracts 0 and scales by 1 even when another query of the wave takes the branch, so a result
+            // never depends on which other rows -- padding included -- share the wave)
+            const float excess = FIRST ? m_t - P_SHIFT : (m_t > P_SHIFT + DEFER_THR ? m_t - P_SHIFT : 0.0f);
+            const bool shift = FIRST || (__ballot(excess != 0.0f) != 0ull);
             if (shift) {
                 const f32x2 d2 = {excess, excess};
 #pragma unroll

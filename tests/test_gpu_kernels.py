@@ -177,6 +177,33 @@ def test_attention_long_ragged_sequences(cross, log2_domain, precision):
         assert (got - ref).abs().max().item() < 3e-5, f"sequence {s}: {(got - ref).abs().max().item():.2e}"
 
 
+@pytest.mark.parametrize("log2_domain", [False, True], ids=["natural-log", "base-2"])
+def test_attention_valid_rows_do_not_depend_on_padding(log2_domain, precision):
+    """The rows past a sequence's count are unwritten capacity.  What they hold (zeros, huge values, another batch's
+    tokens) must not change a single bit of the valid rows: a pair matched alone and the same pair inside a batch go
+    through different capacities.  The deferred-maximum branch of the base-2 kernel is wave-wide, so this is the case
+    that catches a decision leaking from a padded query lane into its neighbours."""
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(21)
+    S, Hh, R = 2, 4, 512
+    cnt = torch.tensor([300, 211], dtype=torch.int32)  # both end inside a 32-query wave
+    q = torch.randn(S, Hh, R, 64, generator=g) * 0.7
+    k = torch.randn(S, Hh, R, 64, generator=g)
+    v = torch.randn(S, Hh, R, 64, generator=g)
+    k[:, :, 150] *= 2.5  # a late spike close to the deferral threshold for many queries
+    outs = []
+    for fill in (0.0, 40.0, -40.0):
+        qq, kk, vv = q.clone(), k.clone(), v.clone()
+        for s in range(S):
+            qq[s, :, cnt[s]:] = fill * torch.randn(R - int(cnt[s]), 64, generator=g) if fill else 0.0
+            kk[s, :, cnt[s]:] = fill
+            vv[s, :, cnt[s]:] = fill
+        o = backend.attention_f32(qq.to(_dev()), kk.to(_dev()), vv.to(_dev()), cnt.to(_dev()), False, log2_domain).cpu().view(S, R, Hh, 64)
+        outs.append(torch.cat([o[s, : int(cnt[s])].reshape(-1) for s in range(S)]))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def _wide_range(shape, g, lo_exp=-7.0, hi_exp=4.7):
     """Random signs, magnitudes log-uniform over many decades (1e-7 .. 5e4): what real checkpoints feed the kernels --
     post-ReLU feature maps with a few very large channels next to near-zero ones."""
@@ -186,8 +213,8 @@ def _wide_range(shape, g, lo_exp=-7.0, hi_exp=4.7):
 
 def test_split_mode_dynamic_range():
     """The 3 x f16 split keeps a value as hi = f16(x) + lo = f16(x - hi): exact to 2^-22 relative while lo is a normal
-    f16, and to an ABSOLUTE 3e-8 (half the smallest f16 subnormal) once |x| < ~1e-3 makes lo subnormal; |x| up to
-    2 x 65504 is representable (hi saturates, lo takes the rest).  Activations are not rescaled (weights are), so this
+    f16, and to an ABSOLUTE 3e-8 (half the smallest f16 subnormal) once |x| < ~1e-3 makes lo subnormal; above 65504 hi
+    saturates and the value keeps f16-class precision up to 2 x 65504.  Activations are not rescaled (weights are), so this
     checks the matrix kernels on inputs spanning 1e-7 .. 5e4 -- far beyond the seeded synthetic data -- against fp64:
     the error stays at fp32 round-off level relative to the magnitude of the outputs."""
     from imcui_hip import backend
@@ -220,10 +247,12 @@ def test_split_mode_dynamic_range():
     ref = F.relu(F.conv2d(x.double(), wc.double(), bc.double(), padding=1)).float().permute(0, 2, 3, 1)
     out = backend.conv3x3_f32(x.permute(0, 2, 3, 1).contiguous().to(dev), wc, bc, relu=True, pool=False).cpu()
     assert (out - ref).abs().max().item() / ref.abs().max().item() < 4e-6
-    # values between one and two times the f16 maximum still split exactly
+    # beyond the f16 maximum the split degrades gracefully, it does not overflow: hi saturates at 65504 and lo takes the
+    # rest with f16 precision, so values up to 2 x 65504 stay finite and accurate to ~2^-11 (no network on this path
+    # produces such activations; the soft-max numbers are bounded by 2^15.5 by construction)
     big = torch.full((128, 256), 0.0)
     big[:, 0] = 1.2e5
     big[:, 1] = -9.0e4
     ref = big.double() @ w.double().t()
     out = backend.linear_split_f32(big.to(dev), w, None).cpu()
-    assert torch.isfinite(out).all() and (out - ref.float()).abs().max().item() / ref.abs().max().item() < 4e-6
+    assert torch.isfinite(out).all() and (out - ref.float()).abs().max().item() / ref.abs().max().item() < 1e-3
