@@ -5,6 +5,7 @@
 
 #include "attention.h"
 #include "conv.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
 
@@ -165,6 +166,40 @@ extern "C" int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const 
     g.N = N;
     g.K = K;
     return gemm_launch(h, g, (hipStream_t)stream);
+}
+
+extern "C" float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsigned short* lo) {
+    if (!w2 || !hi || !lo) return 0.0f;
+    float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));
+    if (!perm) return 0.0f;
+    ffn_permute_k(w2, 256, 512, perm);
+    const float sc = split_weights_frag_host(perm, 256, 512, hi, lo);
+    free(perm);
+    return sc;
+}
+
+extern "C" int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const float* ctx, const unsigned short* w1h,
+                                       const unsigned short* w1l, const float* s1, const float* b1, const float* gamma,
+                                       const float* beta, const unsigned short* w2h, const unsigned short* w2l, const float* s2,
+                                       const float* b2, float* out, int M, void* stream) {
+    if (!h) return IMCUI_ERR_ARG;
+    if (M % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: M=%d must be a multiple of 128", M);
+    FfnP p;
+    p.x = x;
+    p.ctx = ctx;
+    p.out = out;
+    p.w1h = w1h;
+    p.w1l = w1l;
+    p.w2h = w2h;
+    p.w2l = w2l;
+    p.s1 = s1;
+    p.s2 = s2;
+    p.b1 = b1;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.b2 = b2;
+    p.M = M;
+    return ffn_launch(h, p, (hipStream_t)stream);
 }
 
 extern "C" int imcui_hip_conv3x3_pack(const float* w_oihw, int Cout, int Cin, float* packed) {

@@ -1,0 +1,373 @@
+// Fused FFN of a LightGlue block on gfx950, 3 x f16 split arithmetic (see ffn.h for the operator).
+//
+// Why one kernel: as three launches the block moves the 512-wide hidden activations through HBM three times
+// (GEMM 1 writes 268 MB, LayerNorm/GELU reads and writes them, GEMM 2 reads them: 1.07 GB of the 1.6 GB the
+// three kernels touch at 64 x 2048 tokens) and re-splits them into f16 planes inside GEMM 2's K loop.  Here a
+// workgroup owns 128 tokens from the two K slabs to the residual store:
+//
+//   GEMM 1   8 waves, wave w owns hidden features [64w, 64w + 64) of all 128 tokens: 2 x 4 accumulator
+//            fragments (128 VGPRs).  The activations ([x | ctx], f32) are split and staged through LDS in the
+//            swizzled fragment order of gemm.hip, two 16 KB stages, one barrier per 32-wide K tile.  No two waves
+//            share a weight fragment, so the pre-split fragment-major planes go global -> registers directly
+//            (16-byte loads, one k-step ahead): the weights never touch LDS.
+//   LN/GELU  on the accumulators: two LDS exchanges of per-token partial sums (mean, then centred sum of squares,
+//            the two-pass form of the reference), then normalise, GELU, split -- all in registers.
+//   GEMM 2   the MFMA B operand wants, per lane, 8 consecutive k of one token; a lane's accumulator registers
+//            8ks .. 8ks+7 ARE 8 hidden features of its token, so the wave writes them as one 16-byte fragment row
+//            and W2's K axis is permuted once at pack time to match (ffn_permute_k).  The 128 x 512 hidden tile
+//            is 256 KB as two f16 planes, so it passes through LDS in two halves of 128 KB (fragment n = 0, then
+//            n = 1, of every wave); wave w accumulates output features [32w, 32w + 32) of all tokens (64 VGPRs),
+//            W2 fragments again straight from global memory.
+//   store    through LDS so that every global store / residual load is a full 1 KB row.
+//
+// Occupancy: one workgroup of 512 threads per CU (2 waves per SIMD, 256 VGPRs each), 136 KB of LDS.
+#include "ffn.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define FFN_G_BYTES 131072               // two f16 planes of one half of the hidden tile (also: 2 A stages, the output tile)
+#define FFN_LDS_BYTES (FFN_G_BYTES + 8192)  // + 2 x [8 waves][128 tokens] partial sums
+#define FFN_YLD 260                      // row stride (floats) of the output tile in LDS
+
+// GELU(y) = 0.5 y (1 + erf(y / sqrt 2)), erf(t) = 1 - 2^(-t Q(t)) for t = min(|.|, 4): coefficients and the measured
+// float32 error (1.3e-7 absolute on erf) from tools/fit/fit_gelu_erf.py.  Branch-free: 7 FMAs and one v_exp_f32.
+__device__ __forceinline__ float ffn_gelu(float y) {
+    const float a = y * 0.70710678118654752440f;
+    const float t = fminf(fabsf(a), 4.0f);
+    float q = 4.535851622e-05f;
+    q = fmaf(q, t, -4.455066228e-04f);
+    q = fmaf(q, t, 1.489437302e-03f);
+    q = fmaf(q, t, 7.746380288e-04f);
+    q = fmaf(q, t, -2.825368941e-02f);
+    q = fmaf(q, t, 1.484816223e-01f);
+    q = fmaf(q, t, 9.184163809e-01f);
+    q = fmaf(q, t, 1.627908587e+00f);
+    const float e = __builtin_amdgcn_exp2f(-(t * q));
+    const float r = copysignf(1.0f - e, a);
+    const float hy = 0.5f * y;
+    return fmaf(hy, r, hy);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
+    extern __shared__ uint4 ffn_smem[];
+    char* sm = reinterpret_cast<char*>(ffn_smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+    if (row0 >= p.M) return;
+    if (p.rows_per_seq > 0) {
+        const int seq = row0 / p.rows_per_seq;
+        if (p.cnt && row0 - seq * p.rows_per_seq >= p.cnt[seq]) return;
+        if (p.active && p.active[seq >> 1] == 0) return;
+    }
+
+    // ================================================================== GEMM 1: H^T[512][128] = W1 * [x | ctx]^T
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
+
+    // staging: thread -> k-octet g (8 consecutive k of the 32-wide tile) of token srow
+    const int srow = tid >> 2, g = tid & 3;
+    const int grow = min(row0 + srow, p.M - 1);
+    const float* px = p.x + (size_t)grow * 256 + g * 8;
+    const float* pc = p.ctx + (size_t)grow * 256 + g * 8;
+    // granule of fragment (ks = g >> 1, token block srow >> 5): half g & 1, position (srow & 31) ^ 2g (gemm.hip's swizzle)
+    const int wo = (((g >> 1) * 4 + (srow >> 5)) * 64 + (g & 1) * 32 + ((srow & 31) ^ (2 * g))) * 16;
+    const uint4* w1h = reinterpret_cast<const uint4*>(p.w1h) + ((size_t)(2 * wid) * 32) * 64 + lane;  // fragment (nf, ks) at (nf * 32 + ks) * 64
+    const uint4* w1l = reinterpret_cast<const uint4*>(p.w1l) + ((size_t)(2 * wid) * 32) * 64 + lane;
+    f32x4 a0, a1;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        const float* q = kt < 8 ? px + kt * 32 : pc + (kt - 8) * 32;
+        a0 = *reinterpret_cast<const f32x4*>(q);
+        a1 = *reinterpret_cast<const f32x4*>(q + 4);
+    };
+    auto store = [&](int stg) __attribute__((always_inline)) {
+        uint4 h, l;
+        split8(__builtin_bit_cast(float4, a0), __builtin_bit_cast(float4, a1), h, l);
+        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo) = h;
+        *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo) = l;
+    };
+    uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step
+    auto loadw = [&](int s, uint4(&w)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            w[n][0] = w1h[(size_t)(n * 32 + s) * 64];
+            w[n][1] = w1l[(size_t)(n * 32 + s) * 64];
+        }
+    };
+    auto kstep = [&](int stg, int ks, uint4(&w)[2][2]) __attribute__((always_inline)) {
+        const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
+        uint4 ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int fo = stg * 16384 + (ks * 4 + m) * 1024 + apos;
+            ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
+            al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[n][m] = mfma16(w[n][0], al[m], acc[n][m]);
+                acc[n][m] = mfma16(w[n][1], ah[m], acc[n][m]);
+                acc[n][m] = mfma16(w[n][0], ah[m], acc[n][m]);
+            }
+    };
+    if constexpr (VAR == 0) {
+        // rolled loop, weights one k-step ahead
+        issue(0);
+        loadw(0, wc);
+        store(0);
+        issue(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int kt = 0; kt < 16; ++kt) {
+            const int stg = kt & 1;
+            loadw(2 * kt + 1, wn);
+            kstep(stg, 0, wc);
+            if (kt + 1 < 16) {
+                store(stg ^ 1);  // its readers finished before the barrier that ended iteration kt - 1
+                if (kt + 2 < 16) issue(kt + 2);
+                loadw(2 * kt + 2, wc);
+            }
+            kstep(stg, 1, wn);
+            __syncthreads();
+        }
+    } else {
+        // Fully unrolled, weights TWO k-steps ahead in three rotating register sets.  vmcnt retires in order, so a
+        // wait for a weight fragment also waits for every activation load issued before it: an activation tile gets
+        // exactly as much time as the weights requested right after it.  Order per K tile (k-steps s = 2 kt, s + 1):
+        //   W(s+2) | MFMAs of s | store tile kt+1 (waits X(kt+1), requested one tile ago) | X(kt+2) | W(s+3) | MFMAs of s+1
+        // -> X(kt+2) must land before the MFMAs of s + 3, one whole tile later, which is also when its store needs it.
+        uint4 wr[3][2][2];
+        issue(0);
+        loadw(0, wr[0]);
+        loadw(1, wr[1]);
+        store(0);
+        issue(1);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+            const int stg = kt & 1, s = 2 * kt;
+            if (s + 2 < 32) loadw(s + 2, wr[(s + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(stg, 0, wr[s % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < 16) {
+                store(stg ^ 1);
+                if (kt + 2 < 16) issue(kt + 2);
+            }
+            if (s + 3 < 32) loadw(s + 3, wr[(s + 3) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(stg, 1, wr[(s + 1) % 3]);
+            __syncthreads();
+        }
+    }
+
+    // ================================================================== bias, LayerNorm (two passes), GELU -- in registers
+    // accumulator (n, m, r) of lane (lo, hi): feature 64 wid + 32 n + 8 (r >> 2) + 4 hi + (r & 3), token 32 m + lo
+    float* stat = reinterpret_cast<float*>(sm + FFN_G_BYTES);  // [8][128] partial sums
+    float* stat2 = stat + 1024;
+    const float s1 = *p.s1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + 64 * wid + 32 * n + 8 * q + 4 * hi);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[n][m][4 * q + 0] = acc[n][m][4 * q + 0] * s1 + b4.x;
+                acc[n][m][4 * q + 1] = acc[n][m][4 * q + 1] * s1 + b4.y;
+                acc[n][m][4 * q + 2] = acc[n][m][4 * q + 2] * s1 + b4.z;
+                acc[n][m][4 * q + 3] = acc[n][m][4 * q + 3] * s1 + b4.w;
+            }
+        }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float s = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[n][m][r];
+        s += __shfl_xor(s, 32, 64);
+        if (hi == 0) stat[wid * 128 + 32 * m + lo] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += stat[w * 128 + 32 * m + lo];
+        mean[m] = s * (1.0f / 512.0f);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float s = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[n][m][r] - mean[m];
+                acc[n][m][r] = d;
+                s += d * d;
+            }
+        s += __shfl_xor(s, 32, 64);
+        if (hi == 0) stat2[wid * 128 + 32 * m + lo] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += stat2[w * 128 + 32 * m + lo];
+        rstd[m] = 1.0f / sqrtf(s * (1.0f / 512.0f) + 1e-5f);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 64 * wid + 32 * n + 8 * q + 4 * hi;
+            const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + f0);
+            const float4 e4 = *reinterpret_cast<const float4*>(p.beta + f0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[n][m][4 * q + 0] = ffn_gelu(acc[n][m][4 * q + 0] * rstd[m] * g4.x + e4.x);
+                acc[n][m][4 * q + 1] = ffn_gelu(acc[n][m][4 * q + 1] * rstd[m] * g4.y + e4.y);
+                acc[n][m][4 * q + 2] = ffn_gelu(acc[n][m][4 * q + 2] * rstd[m] * g4.z + e4.z);
+                acc[n][m][4 * q + 3] = ffn_gelu(acc[n][m][4 * q + 3] * rstd[m] * g4.w + e4.w);
+            }
+        }
+
+    // ================================================================== GEMM 2: Y^T[256][128] = W2 * G^T, two K halves
+    f32x16 acc2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[m][r] = 0.0f;
+    // W2 planes in the permuted K order: k-step kk = 4 w + 2 n + ks holds the features wave w hands over from
+    // registers 8 ks .. 8 ks + 7 of its fragment n
+    const uint4* w2h = reinterpret_cast<const uint4*>(p.w2h) + ((size_t)wid * 32) * 64 + lane;
+    const uint4* w2l = reinterpret_cast<const uint4*>(p.w2l) + ((size_t)wid * 32) * 64 + lane;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) __syncthreads();  // every wave has read the first half
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v0 = make_float4(acc[ph][m][8 * ks + 0], acc[ph][m][8 * ks + 1], acc[ph][m][8 * ks + 2], acc[ph][m][8 * ks + 3]);
+                const float4 v1 = make_float4(acc[ph][m][8 * ks + 4], acc[ph][m][8 * ks + 5], acc[ph][m][8 * ks + 6], acc[ph][m][8 * ks + 7]);
+                uint4 h, l;
+                split8(v0, v1, h, l);
+                const int off = (((wid * 2 + ks) * 4 + m) * 64 + lane) * 16;
+                *reinterpret_cast<uint4*>(sm + off) = h;
+                *reinterpret_cast<uint4*>(sm + 65536 + off) = l;
+            }
+        __syncthreads();
+        uint4 wq[2][2];  // [k-step parity][plane], two k-steps ahead
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int gk = (u >> 1) * 4 + ph * 2 + (u & 1);
+            wq[u][0] = w2h[(size_t)gk * 64];
+            wq[u][1] = w2l[(size_t)gk * 64];
+        }
+#pragma unroll 1
+        for (int kk = 0; kk < 16; kk += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 wh = wq[u][0], wl = wq[u][1];
+                if (kk + 2 < 16) {
+                    const int gk = ((kk + 2) >> 1) * 4 + ph * 2 + u;
+                    wq[u][0] = w2h[(size_t)gk * 64];
+                    wq[u][1] = w2l[(size_t)gk * 64];
+                }
+                uint4 gh[4], gl[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int off = (((kk + u) * 4 + m) * 64 + lane) * 16;
+                    gh[m] = *reinterpret_cast<const uint4*>(sm + off);
+                    gl[m] = *reinterpret_cast<const uint4*>(sm + 65536 + off);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc2[m] = mfma16(wh, gl[m], acc2[m]);
+                    acc2[m] = mfma16(wl, gh[m], acc2[m]);
+                    acc2[m] = mfma16(wh, gh[m], acc2[m]);
+                }
+            }
+        }
+    }
+
+    // ================================================================== bias, residual, row-major store through LDS
+    __syncthreads();  // the second half has been read
+    float* Y = reinterpret_cast<float*>(sm);
+    const float s2 = *p.s2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wid + 8 * q + 4 * hi;
+        const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + f0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float4 v;
+            v.x = acc2[m][4 * q + 0] * s2 + b4.x;
+            v.y = acc2[m][4 * q + 1] * s2 + b4.y;
+            v.z = acc2[m][4 * q + 2] * s2 + b4.z;
+            v.w = acc2[m][4 * q + 3] * s2 + b4.w;
+            *reinterpret_cast<float4*>(Y + (32 * m + lo) * FFN_YLD + f0) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int row = pass * 8 + wid;
+        const int gr = row0 + row;
+        if (gr < p.M) {
+            const float4 v = *reinterpret_cast<const float4*>(Y + row * FFN_YLD + lane * 4);
+            const float4 r4 = *reinterpret_cast<const float4*>(p.x + (size_t)gr * 256 + lane * 4);
+            *reinterpret_cast<float4*>(p.out + (size_t)gr * 256 + lane * 4) = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+        }
+    }
+}
+
+int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "ffn: the fused kernel is the 3 x f16 split path (precision 1)");
+    if (!p.x || !p.ctx || !p.out || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.s1 || !p.s2 || !p.b1 || !p.gamma || !p.beta || !p.b2)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: null argument");
+    if (p.rows_per_seq > 0 && p.rows_per_seq % 128 != 0)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
+    if (p.M <= 0) return IMCUI_OK;
+    static const int variant = getenv("IMCUI_FFN_VARIANT") ? atoi(getenv("IMCUI_FFN_VARIANT")) : 1;
+    static bool attr_set[2] = {false, false};  // > 64 KB of dynamic LDS needs the opt-in
+    const void* fn = variant == 0 ? reinterpret_cast<const void*>(lg_ffn_kernel<0>) : reinterpret_cast<const void*>(lg_ffn_kernel<1>);
+    if (!attr_set[variant != 0]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
+            return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
+        attr_set[variant != 0] = true;
+    }
+    imcui_prof_begin(h, PROF_GEMM, stream);
+    if (variant == 0)
+        hipLaunchKernelGGL(lg_ffn_kernel<0>, dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL(lg_ffn_kernel<1>, dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
+    imcui_prof_end(h, PROF_GEMM, stream);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// new K position 16 kk + 8 h + j  <-  original feature 16 kk + 8 (j >> 2) + 4 h + (j & 3): within every 16 features, the
+// two halves of a wave hold {0-3, 8-11} and {4-7, 12-15} (accumulator rows (r & 3) + 8 (r >> 2) + 4 hi)
+void ffn_permute_k(const float* src, int N, int K, float* dst) {
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < K; ++c) {
+            const int kk = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+            dst[(size_t)n * K + c] = src[(size_t)n * K + 16 * kk + 8 * (j >> 2) + 4 * hh + (j & 3)];
+        }
+}

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
 
@@ -29,6 +30,7 @@ struct LgLayerOff {
     size_t wqkv, bqkv, wo, bo, w1s, b1s, gs, bs, w2s, b2s;
     size_t wx, bx, wto, bto, w1c, b1c, gc, bc, w2c, b2c;
     LgSplit sqkv, s1s, s2s, sx, s1c, s2c;  // out_proj / to_out are folded into ffn.0: no planes of their own
+    LgSplit s2sp, s2cp;                    // ffn.3 planes with the K axis in the fused FFN kernel's order (ffn_permute_k)
 };
 struct LgLayout {
     size_t wr;
@@ -92,6 +94,8 @@ static LgLayout lg_layout() {
         o.sx = take_split(512 * 256);
         o.s1c = take_split(512 * 512);
         o.s2c = take_split(256 * 512);
+        o.s2sp = take_split(256 * 512);
+        o.s2cp = take_split(256 * 512);
     }
     l.sfinal = take_split((size_t)LG_LAYERS * 256 * 256);
     l.wr4 = take(128);
@@ -217,6 +221,8 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
         packed[d.s + slot] = split_weights_frag_host(packed + src, N, K, reinterpret_cast<unsigned short*>(packed + d.h) + (size_t)slot * n,
                                                      reinterpret_cast<unsigned short*>(packed + d.l) + (size_t)slot * n);
     };
+    float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));
+    if (!perm) return IMCUI_ERR_ARG;
     for (int i = 0; i < LG_LAYERS; ++i) {
         const LgLayerOff& o = l.L[i];
         sp(o.sqkv, o.wqkv, 768, 256, 0);
@@ -225,8 +231,13 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
         sp(o.sx, o.wx, 512, 256, 0);
         sp(o.s1c, o.w1c, 512, 512, 0);
         sp(o.s2c, o.w2c, 256, 512, 0);
+        ffn_permute_k(packed + o.w2s, 256, 512, perm);
+        packed[o.s2sp.s] = split_weights_frag_host(perm, 256, 512, reinterpret_cast<unsigned short*>(packed + o.s2sp.h), reinterpret_cast<unsigned short*>(packed + o.s2sp.l));
+        ffn_permute_k(packed + o.w2c, 256, 512, perm);
+        packed[o.s2cp.s] = split_weights_frag_host(perm, 256, 512, reinterpret_cast<unsigned short*>(packed + o.s2cp.h), reinterpret_cast<unsigned short*>(packed + o.s2cp.l));
         sp(l.sfinal, l.wfinal + (size_t)i * 65536, 256, 256, i);
     }
+    free(perm);
     return IMCUI_OK;
 }
 
@@ -912,8 +923,31 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             g.wscale = P + sp.s;
         }
     };
+    // split mode: the whole FFN is one kernel (ffn.hip); IMCUI_LG_FFN_UNFUSED=1 keeps the three-launch path for A/B runs
+    static const bool ffn_unfused = getenv("IMCUI_LG_FFN_UNFUSED") != nullptr;
     auto ffn = [&](const float* ctx, size_t w1, const LgSplit& s1, size_t b1, size_t gm, size_t bt, size_t w2,
-                   const LgSplit& s2, size_t b2) -> int {
+                   const LgSplit& s2, const LgSplit& s2p, size_t b2) -> int {
+        if (split && !ffn_unfused) {
+            FfnP f;
+            f.x = w.x;
+            f.ctx = ctx;
+            f.out = w.x;
+            f.w1h = reinterpret_cast<const unsigned short*>(P + s1.h);
+            f.w1l = reinterpret_cast<const unsigned short*>(P + s1.l);
+            f.s1 = P + s1.s;
+            f.b1 = P + b1;
+            f.gamma = P + gm;
+            f.beta = P + bt;
+            f.w2h = reinterpret_cast<const unsigned short*>(P + s2p.h);
+            f.w2l = reinterpret_cast<const unsigned short*>(P + s2p.l);
+            f.s2 = P + s2p.s;
+            f.b2 = P + b2;
+            f.M = S * R;
+            f.cnt = cnt_cur;
+            f.active = w.active;
+            f.rows_per_seq = R;
+            return ffn_launch(h, f, stream);
+        }
         GemmP g;
         base(g);
         g.epi = EPI_BIAS;
@@ -985,7 +1019,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.cross = 0;
             a.log2_domain = 1;
             LGRUN(attention_launch(h, a, stream));
-            LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.b2s));
+            LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.s2sp, o.b2s));
         }
         // ---- CrossBlock
         {
@@ -1020,7 +1054,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.cross = 1;
             a.log2_domain = 1;
             LGRUN(attention_launch(h, a, stream));
-            LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.b2c));
+            LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.s2cp, o.b2c));
         }
         if (h->lg_dump) {  // parity-test hook: token states after this layer (rows in their current, pruned order)
             const size_t nf = (size_t)S * R * 256;

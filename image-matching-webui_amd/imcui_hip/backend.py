@@ -684,6 +684,49 @@ def linear_split_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
     return c
 
 
+def pack_ffn_w2(w2: torch.Tensor):
+    """Host: ffn.3 weight [256, 512] -> planes in the K order of the fused FFN kernel, and the inverse scale."""
+    from .lib_loader import load_library
+
+    lib = load_library()
+    wh = _as_f32_host(w2)
+    assert wh.shape == (256, 512)
+    hi = np.zeros(256 * 512, dtype=np.uint16)
+    lo = np.zeros(256 * 512, dtype=np.uint16)
+    sc = lib.imcui_hip_ffn_pack_w2(wh.ctypes.data, hi.ctypes.data, lo.ctypes.data)
+    if sc <= 0:
+        raise ImcuiHipError("ffn_pack_w2 failed")
+    return hi, lo, float(sc)
+
+
+class FusedFFN:
+    """Building block: x + W2 GELU(LN(W1 [x | ctx] + b1)) + b2 in ONE kernel (csrc/ffn.hip), weights packed once."""
+
+    def __init__(self, w1, b1, gamma, beta, w2, b2, device):
+        def up(a):
+            return torch.from_numpy(a.view(np.int16)).to(device)
+
+        h1, l1, s1 = pack_linear_split(w1)
+        h2, l2, s2 = pack_ffn_w2(w2)
+        self.w1h, self.w1l, self.w2h, self.w2l = up(h1), up(l1), up(h2), up(l2)
+        self.s1 = torch.tensor([s1], dtype=torch.float32, device=device)
+        self.s2 = torch.tensor([s2], dtype=torch.float32, device=device)
+        self.b1, self.gamma, self.beta, self.b2 = (t.detach().float().contiguous().to(device) for t in (b1, gamma, beta, b2))
+
+    def __call__(self, x: torch.Tensor, ctx: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        hd = get_handle(x.device)
+        x, ctx = x.contiguous().float(), ctx.contiguous().float()
+        M = x.shape[0]
+        out = torch.empty_like(x) if out is None else out
+        with torch.cuda.device(x.device):
+            hd.check(
+                hd.lib.imcui_hip_ffn_split_f32(hd.h, _ptr(x), _ptr(ctx), _ptr(self.w1h), _ptr(self.w1l), _ptr(self.s1), _ptr(self.b1), _ptr(self.gamma),
+                                               _ptr(self.beta), _ptr(self.w2h), _ptr(self.w2l), _ptr(self.s2), _ptr(self.b2), _ptr(out), M, _stream_ptr()),
+                "ffn_split",
+            )
+        return out
+
+
 def conv3x3_f32(x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, relu=True, pool=False) -> torch.Tensor:
     hd = get_handle(x_nhwc.device)
     lib = hd.lib

@@ -262,6 +262,18 @@ float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* 
 int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned short* wh, const unsigned short* wl,
                                const float* wscale, const float* bias, float* C, int M, int N, int K, int relu, void* stream);
 
+/* Fused transformer FFN of a LightGlue block (upstream TransformerLayer.ffn on cat([x, message]) with the attention
+ * out-projection folded into W1; reached from imcui/hloc/matchers/lightglue.py:75):
+ *   out = x + W2 * GELU(LayerNorm_512(W1 * [x | ctx] + b1)) + b2,   x, ctx, out [M][256] (out may alias x), M % 128 == 0.
+ * W1 [512][512] as planes from imcui_hip_linear_pack_split; W2 [256][512] as planes from imcui_hip_ffn_pack_w2 (the
+ * same fragment-major planes with the K axis in the order the kernel's first GEMM hands its accumulators over);
+ * s1 / s2 = device floats holding the returned 2^-e.  precision 1 only.  One kernel: the 512-wide hidden row stays
+ * on the CU (registers -> LDS), no LayerNorm / GELU pass over HBM. */
+float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsigned short* lo);
+int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const float* ctx, const unsigned short* w1h, const unsigned short* w1l,
+                            const float* s1, const float* b1, const float* gamma, const float* beta, const unsigned short* w2h,
+                            const unsigned short* w2l, const float* s2, const float* b2, float* out, int M, void* stream);
+
 int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
                                 const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,
                                 int Cout, int relu, int pool, void* stream);

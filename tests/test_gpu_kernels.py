@@ -256,3 +256,38 @@ def test_split_mode_dynamic_range():
     ref = big.double() @ w.double().t()
     out = backend.linear_split_f32(big.to(dev), w, None).cpu()
     assert torch.isfinite(out).all() and (out - ref.float()).abs().max().item() / ref.abs().max().item() < 1e-3
+
+
+def _ffn_reference(x, ctx, w1, b1, gamma, beta, w2, b2):
+    h = torch.cat([x, ctx], -1).double() @ w1.double().t() + b1.double()
+    h = torch.nn.functional.layer_norm(h, (512,), gamma.double(), beta.double(), 1e-5)
+    h = torch.nn.functional.gelu(h)
+    return x.double() + h @ w2.double().t() + b2.double()
+
+
+@pytest.mark.parametrize("M,scale", [(128, 1.0), (1024, 1.0), (4096, 6.0)])
+def test_fused_ffn_vs_fp64(M, scale):
+    """The LightGlue FFN as one kernel (GEMM 512x512 -> LayerNorm -> GELU -> GEMM 256x512 -> residual) against float64
+    torch: upstream lightglue.py TransformerLayer.ffn on cat([x, message]).  `scale` widens the hidden activations so
+    that the GELU polynomial is exercised over its whole range (|y| up to ~10)."""
+    from imcui_hip import backend
+
+    backend.set_precision(_dev(), 1)
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 256, generator=g)
+    ctx = torch.randn(M, 256, generator=g) * 0.7
+    w1 = torch.randn(512, 512, generator=g) / 512 ** 0.5
+    b1 = torch.randn(512, generator=g) * 0.1
+    gamma = (1.0 + 0.3 * torch.randn(512, generator=g)) * scale
+    beta = torch.randn(512, generator=g) * 0.2 * scale
+    w2 = torch.randn(256, 512, generator=g) / 512 ** 0.5
+    b2 = torch.randn(256, generator=g) * 0.1
+    ffn = backend.FusedFFN(w1, b1, gamma, beta, w2, b2, _dev())
+    out = ffn(x.to(_dev()), ctx.to(_dev())).cpu()
+    ref = _ffn_reference(x, ctx, w1, b1, gamma, beta, w2, b2)
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert torch.isfinite(out).all() and err < 3e-6, err
+    # in place (out aliases x), the way the LightGlue layers call it
+    xd = x.to(_dev())
+    ffn(xd, ctx.to(_dev()), out=xd)
+    assert torch.equal(xd.cpu(), out)
