@@ -178,10 +178,16 @@ extern "C" float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsi
     return sc;
 }
 
+extern "C" int imcui_hip_ffn_set_debug(imcui_hip_t* h, long long* stamps) {
+    if (!h) return IMCUI_ERR_ARG;
+    h->ffn_dbg = stamps;
+    return IMCUI_OK;
+}
+
 extern "C" int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const float* ctx, const unsigned short* w1h,
                                        const unsigned short* w1l, const float* s1, const float* b1, const float* gamma,
                                        const float* beta, const unsigned short* w2h, const unsigned short* w2l, const float* s2,
-                                       const float* b2, float* out, int M, void* stream) {
+                                       const float* b2, float* out, int M, int act, void* stream) {
     if (!h) return IMCUI_ERR_ARG;
     if (M % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: M=%d must be a multiple of 128", M);
     FfnP p;
@@ -199,6 +205,8 @@ extern "C" int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const flo
     p.beta = beta;
     p.b2 = b2;
     p.M = M;
+    p.act = act;
+    p.dbg = h->ffn_dbg;
     return ffn_launch(h, p, (hipStream_t)stream);
 }
 

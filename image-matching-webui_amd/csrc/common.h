@@ -117,6 +117,7 @@ struct imcui_hip_s {
     hipEvent_t* prof_ev[PROF_NCLS];  // pairs (start, stop)
     float* lg_dump;  // parity-test hook (imcui_hip_lightglue_set_layer_dump): per-layer token states
     size_t lg_dump_floats;
+    long long* ffn_dbg;  // lab hook (imcui_hip_ffn_set_debug): per-workgroup phase stamps of the fused FFN kernel
 };
 void imcui_prof_begin(imcui_hip_s* h, int cls, hipStream_t s);
 void imcui_prof_end(imcui_hip_s* h, int cls, hipStream_t s);

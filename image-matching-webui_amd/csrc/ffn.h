@@ -1,5 +1,6 @@
-// Fused transformer FFN of the LightGlue blocks (3 x f16 split mode):
+// Fused transformer FFN of the LightGlue / SuperGlue blocks (3 x f16 split mode):
 //   x <- x + W2 * GELU(LayerNorm(W1 * [x | ctx] + b1)) + b2          (512 hidden features, 256-wide residual stream)
+//   x <- x + W2 * ReLU(W1 * [x | ctx] + b1) + b2                     (act = 1: SuperGlue's MLP, BatchNorm folded)
 // one kernel per block instead of GEMM -> LayerNorm/GELU -> GEMM: the 512-wide hidden row never leaves the CU.
 #pragma once
 #include "common.h"
@@ -14,11 +15,13 @@ struct FfnP {
     const float *s1 = nullptr, *s2 = nullptr;  // 2^-e scales of the planes (device)
     const float *b1 = nullptr, *gamma = nullptr, *beta = nullptr;  // [512]
     const float* b2 = nullptr;                                     // [256]
+    int act = 0;  // 0: LayerNorm + GELU between the GEMMs (LightGlue); 1: ReLU only (SuperGlue, BatchNorm folded into W1)
     int M = 0;
     // ragged sequences, as in GemmP: a 128-row tile whose first row is >= cnt[seq] or whose pair is inactive is skipped
     const int* cnt = nullptr;
     const int* active = nullptr;
     int rows_per_seq = 0;
+    long long* dbg = nullptr;  // lab only: 8 wall-clock stamps per workgroup (phase boundaries, wave 0)
 };
 
 int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream);

@@ -49,7 +49,7 @@ __device__ __forceinline__ float ffn_gelu(float y) {
     return fmaf(hy, r, hy);
 }
 
-template <int VAR>
+template <int VAR, int ACT>
 __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     extern __shared__ uint4 ffn_smem[];
     char* sm = reinterpret_cast<char*>(ffn_smem);
@@ -64,6 +64,9 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
         if (p.active && p.active[seq >> 1] == 0) return;
     }
 
+#define FFN_STAMP(i)                                                                        \
+    if (p.dbg != nullptr && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)wall_clock64();
+    FFN_STAMP(0)
     // ================================================================== GEMM 1: H^T[512][128] = W1 * [x | ctx]^T
     f32x16 acc[2][4];
 #pragma unroll
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
         }
     }
 
+    FFN_STAMP(1)
     // ================================================================== bias, LayerNorm (two passes), GELU -- in registers
     // accumulator (n, m, r) of lane (lo, hi): feature 64 wid + 32 n + 8 (r >> 2) + 4 hi + (r & 3), token 32 m + lo
     float* stat = reinterpret_cast<float*>(sm + FFN_G_BYTES);  // [8][128] partial sums
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
                 acc[n][m][4 * q + 3] = acc[n][m][4 * q + 3] * s1 + b4.w;
             }
         }
+    if constexpr (ACT == 0) {
     float mean[4], rstd[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -244,21 +249,43 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
                 acc[n][m][4 * q + 2] = ffn_gelu(acc[n][m][4 * q + 2] * rstd[m] * g4.z + e4.z);
                 acc[n][m][4 * q + 3] = ffn_gelu(acc[n][m][4 * q + 3] * rstd[m] * g4.w + e4.w);
             }
+            __builtin_amdgcn_sched_barrier(0);  // 16 GELU chains in flight are enough; more only costs registers
         }
+    } else {
+        // SuperGlue's MLP: BatchNorm is folded into W1 / b1 at pack time, the activation is ReLU
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][m][r] = fmaxf(acc[n][m][r], 0.0f);
+    }
 
+    FFN_STAMP(2)
     // ================================================================== GEMM 2: Y^T[256][128] = W2 * G^T, two K halves
+    // W2 planes in the permuted K order: k-step kk = 4 w + 2 n + ks holds the features wave w hands over from
+    // registers 8 ks .. 8 ks + 7 of its fragment n.
+    // Wave tile 32 output features x 128 tokens.  (A 64 x 64 wave tile halves the LDS fragment reads but doubles the
+    // weight fragments every wave pulls through the vector L1: measured 12.6 -> 14.6 us per half.)
+    int lane2 = lane, wid2 = wid;
+    // opaque copies of the thread coordinates: the address arithmetic of this section must not be hoisted into the
+    // register-tight LayerNorm / GELU section above
+    asm volatile("" : "+v"(lane2), "+v"(wid2));
+    const int lo2 = lane2 & 31, hi2 = lane2 >> 5;
     f32x16 acc2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[m][r] = 0.0f;
-    // W2 planes in the permuted K order: k-step kk = 4 w + 2 n + ks holds the features wave w hands over from
-    // registers 8 ks .. 8 ks + 7 of its fragment n
-    const uint4* w2h = reinterpret_cast<const uint4*>(p.w2h) + ((size_t)wid * 32) * 64 + lane;
-    const uint4* w2l = reinterpret_cast<const uint4*>(p.w2l) + ((size_t)wid * 32) * 64 + lane;
+    const uint4* w2h = reinterpret_cast<const uint4*>(p.w2h) + ((size_t)wid2 * 32) * 64 + lane2;
+    const uint4* w2l = reinterpret_cast<const uint4*>(p.w2l) + ((size_t)wid2 * 32) * 64 + lane2;
+    float4 res[16];  // residual rows in the order of the final row-major store, requested before the last MFMA loop
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-        if (ph == 1) __syncthreads();  // every wave has read the first half
+        if (ph == 1) {
+            FFN_STAMP(3)
+            __syncthreads();  // every wave has read the first half
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -267,15 +294,23 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
                 const float4 v1 = make_float4(acc[ph][m][8 * ks + 4], acc[ph][m][8 * ks + 5], acc[ph][m][8 * ks + 6], acc[ph][m][8 * ks + 7]);
                 uint4 h, l;
                 split8(v0, v1, h, l);
-                const int off = (((wid * 2 + ks) * 4 + m) * 64 + lane) * 16;
+                // wave w's 8 fragments, hi and lo planes interleaved: 16 KB reachable from one base register
+                const int off = wid2 * 16384 + lane2 * 16 + ((ks * 4 + m) * 2) * 1024;
                 *reinterpret_cast<uint4*>(sm + off) = h;
-                *reinterpret_cast<uint4*>(sm + 65536 + off) = l;
+                *reinterpret_cast<uint4*>(sm + off + 1024) = l;
             }
         __syncthreads();
+        if (ph == 1) {
+            // the hidden accumulators are dead: 64 registers take the residual rows (whole 1 KB rows per wave) while
+            // the MFMAs run, so the store phase has no load latency in it
+#pragma unroll
+            for (int pass = 0; pass < 16; ++pass)
+                res[pass] = *reinterpret_cast<const float4*>(p.x + (size_t)min(row0 + pass * 8 + wid2, p.M - 1) * 256 + lane2 * 4);
+        }
         uint4 wq[2][2];  // [k-step parity][plane], two k-steps ahead
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int gk = (u >> 1) * 4 + ph * 2 + (u & 1);
+            const int gk = ph * 2 + u;
             wq[u][0] = w2h[(size_t)gk * 64];
             wq[u][1] = w2l[(size_t)gk * 64];
         }
@@ -292,9 +327,9 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
                 uint4 gh[4], gl[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const int off = (((kk + u) * 4 + m) * 64 + lane) * 16;
+                    const int off = (kk >> 1) * 16384 + lane2 * 16 + ((u * 4 + m) * 2) * 1024;
                     gh[m] = *reinterpret_cast<const uint4*>(sm + off);
-                    gl[m] = *reinterpret_cast<const uint4*>(sm + 65536 + off);
+                    gl[m] = *reinterpret_cast<const uint4*>(sm + off + 1024);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -306,13 +341,14 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
         }
     }
 
+    FFN_STAMP(4)
     // ================================================================== bias, residual, row-major store through LDS
     __syncthreads();  // the second half has been read
     float* Y = reinterpret_cast<float*>(sm);
     const float s2 = *p.s2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int f0 = 32 * wid + 8 * q + 4 * hi;
+        const int f0 = 32 * wid2 + 8 * q + 4 * hi2;
         const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + f0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -321,42 +357,43 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             v.y = acc2[m][4 * q + 1] * s2 + b4.y;
             v.z = acc2[m][4 * q + 2] * s2 + b4.z;
             v.w = acc2[m][4 * q + 3] * s2 + b4.w;
-            *reinterpret_cast<float4*>(Y + (32 * m + lo) * FFN_YLD + f0) = v;
+            *reinterpret_cast<float4*>(Y + (32 * m + lo2) * FFN_YLD + f0) = v;
         }
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
-        const int row = pass * 8 + wid;
+        const int row = pass * 8 + wid2;
         const int gr = row0 + row;
         if (gr < p.M) {
-            const float4 v = *reinterpret_cast<const float4*>(Y + row * FFN_YLD + lane * 4);
-            const float4 r4 = *reinterpret_cast<const float4*>(p.x + (size_t)gr * 256 + lane * 4);
-            *reinterpret_cast<float4*>(p.out + (size_t)gr * 256 + lane * 4) = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+            const float4 v = *reinterpret_cast<const float4*>(Y + row * FFN_YLD + lane2 * 4);
+            *reinterpret_cast<float4*>(p.out + (size_t)gr * 256 + lane2 * 4) = make_float4(v.x + res[pass].x, v.y + res[pass].y, v.z + res[pass].z, v.w + res[pass].w);
         }
     }
+    FFN_STAMP(5)
+#undef FFN_STAMP
 }
 
 int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "ffn: the fused kernel is the 3 x f16 split path (precision 1)");
-    if (!p.x || !p.ctx || !p.out || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.s1 || !p.s2 || !p.b1 || !p.gamma || !p.beta || !p.b2)
+    if (!p.x || !p.ctx || !p.out || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.s1 || !p.s2 || !p.b1 || !p.b2 ||
+        (p.act == 0 && (!p.gamma || !p.beta)))
         return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: null argument");
     if (p.rows_per_seq > 0 && p.rows_per_seq % 128 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.M <= 0) return IMCUI_OK;
     static const int variant = getenv("IMCUI_FFN_VARIANT") ? atoi(getenv("IMCUI_FFN_VARIANT")) : 1;
-    static bool attr_set[2] = {false, false};  // > 64 KB of dynamic LDS needs the opt-in
-    const void* fn = variant == 0 ? reinterpret_cast<const void*>(lg_ffn_kernel<0>) : reinterpret_cast<const void*>(lg_ffn_kernel<1>);
-    if (!attr_set[variant != 0]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
+    typedef void (*kern_t)(FfnP);
+    static const kern_t kerns[2][2] = {{lg_ffn_kernel<0, 0>, lg_ffn_kernel<0, 1>}, {lg_ffn_kernel<1, 0>, lg_ffn_kernel<1, 1>}};
+    static bool attr_set[2][2] = {{false, false}, {false, false}};  // > 64 KB of dynamic LDS needs the opt-in
+    const int v = variant != 0, a = p.act != 0;
+    if (!attr_set[v][a]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v][a]), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
             return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
-        attr_set[variant != 0] = true;
+        attr_set[v][a] = true;
     }
     imcui_prof_begin(h, PROF_GEMM, stream);
-    if (variant == 0)
-        hipLaunchKernelGGL(lg_ffn_kernel<0>, dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
-    else
-        hipLaunchKernelGGL(lg_ffn_kernel<1>, dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kerns[v][a], dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
     imcui_prof_end(h, PROF_GEMM, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "attention.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
 
@@ -34,7 +35,7 @@ struct SgSplit {
 };
 struct SgLayerOff {
     size_t wqkv, bqkv, w1, b1, w2, b2;
-    SgSplit sqkv, s1, s2;
+    SgSplit sqkv, s1, s2, s2p;  // s2p: mlp.3 planes in the fused FFN kernel's K order
 };
 struct SgLayout {
     size_t k0;                  // [32][4]: wx, wy, wscore, bias of the first key-point encoder layer (BN folded)
@@ -85,6 +86,7 @@ static SgLayout sg_layout() {
         o.sqkv = take_split(768 * 256);
         o.s1 = take_split(512 * 512);
         o.s2 = take_split(256 * 512);
+        o.s2p = take_split(256 * 512);
     }
     l.sfinal = take_split(256 * 256);
     l.total = off;
@@ -206,6 +208,10 @@ extern "C" int imcui_hip_superglue_pack_weights(const float* const* t, float* pa
         sp(o.sqkv, o.wqkv, 768, 256);
         sp(o.s1, o.w1, 512, 512);
         sp(o.s2, o.w2, 256, 512);
+        std::vector<float> perm((size_t)256 * 512);
+        ffn_permute_k(packed + o.w2, 256, 512, perm.data());
+        packed[o.s2p.s] = split_weights_frag_host(perm.data(), 256, 512, reinterpret_cast<unsigned short*>(packed + o.s2p.h),
+                                                  reinterpret_cast<unsigned short*>(packed + o.s2p.l));
     }
     sp(l.sfinal, l.wfinal, 256, 256);
     return IMCUI_OK;
@@ -814,6 +820,7 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
         g.active = w.active;
         g.rows_per_seq = R;
     };
+    static const bool ffn_unfused = getenv("IMCUI_LG_FFN_UNFUSED") != nullptr;  // A/B switch, as in lightglue.hip
     auto wts = [&](GemmP& g, size_t wf32, const SgSplit& sp) {
         g.W = P + wf32;
         if (split) {
@@ -881,6 +888,28 @@ extern "C" int imcui_hip_superglue_forward(imcui_hip_t* h, const float* packed, 
         a.cross = layer & 1;
         a.log2_domain = 1;
         SGRUN(attention_launch(h, a, stream));
+        if (split && !ffn_unfused) {
+            // x += mlp.3(relu(bn(mlp.0(cat[x, merge(ctx)])))) as one kernel (ffn.hip; merge and bn folded into mlp.0)
+            FfnP f;
+            f.act = 1;
+            f.x = w.x;
+            f.ctx = w.ctx;
+            f.out = w.x;
+            f.w1h = reinterpret_cast<const unsigned short*>(P + o.s1.h);
+            f.w1l = reinterpret_cast<const unsigned short*>(P + o.s1.l);
+            f.s1 = P + o.s1.s;
+            f.b1 = P + o.b1;
+            f.w2h = reinterpret_cast<const unsigned short*>(P + o.s2p.h);
+            f.w2l = reinterpret_cast<const unsigned short*>(P + o.s2p.l);
+            f.s2 = P + o.s2p.s;
+            f.b2 = P + o.b2;
+            f.M = S * R;
+            f.cnt = w.cnt;
+            f.active = w.active;
+            f.rows_per_seq = R;
+            SGRUN(ffn_launch(h, f, stream));
+            continue;
+        }
         GemmP f1;  // relu(bn(mlp.0(cat[x, merge(ctx)]))) with merge and bn folded into the weights
         base(f1);
         f1.epi = EPI_RELU;

@@ -700,9 +700,13 @@ def pack_ffn_w2(w2: torch.Tensor):
 
 
 class FusedFFN:
-    """Building block: x + W2 GELU(LN(W1 [x | ctx] + b1)) + b2 in ONE kernel (csrc/ffn.hip), weights packed once."""
+    """Building block: x + W2 GELU(LN(W1 [x | ctx] + b1)) + b2 in ONE kernel (csrc/ffn.hip), weights packed once.
+    gamma = beta = None: ReLU instead of LayerNorm + GELU (SuperGlue's MLP with the BatchNorm folded into W1, b1)."""
 
     def __init__(self, w1, b1, gamma, beta, w2, b2, device):
+        self.act = 1 if gamma is None else 0
+        if gamma is None:
+            gamma = beta = torch.zeros(512)
         def up(a):
             return torch.from_numpy(a.view(np.int16)).to(device)
 
@@ -721,7 +725,7 @@ class FusedFFN:
         with torch.cuda.device(x.device):
             hd.check(
                 hd.lib.imcui_hip_ffn_split_f32(hd.h, _ptr(x), _ptr(ctx), _ptr(self.w1h), _ptr(self.w1l), _ptr(self.s1), _ptr(self.b1), _ptr(self.gamma),
-                                               _ptr(self.beta), _ptr(self.w2h), _ptr(self.w2l), _ptr(self.s2), _ptr(self.b2), _ptr(out), M, _stream_ptr()),
+                                               _ptr(self.beta), _ptr(self.w2h), _ptr(self.w2l), _ptr(self.s2), _ptr(self.b2), _ptr(out), M, self.act, _stream_ptr()),
                 "ffn_split",
             )
         return out

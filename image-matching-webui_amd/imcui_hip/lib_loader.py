@@ -36,7 +36,8 @@ SIGNATURES = {
     "imcui_hip_linear_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_linear_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
     "imcui_hip_ffn_pack_w2": (C.c_float, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "imcui_hip_ffn_split_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_void_p]),
+    "imcui_hip_ffn_set_debug": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "imcui_hip_ffn_split_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_conv3x3_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]),
     "imcui_hip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "imcui_hip_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -268,11 +268,16 @@ int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned sh
  * W1 [512][512] as planes from imcui_hip_linear_pack_split; W2 [256][512] as planes from imcui_hip_ffn_pack_w2 (the
  * same fragment-major planes with the K axis in the order the kernel's first GEMM hands its accumulators over);
  * s1 / s2 = device floats holding the returned 2^-e.  precision 1 only.  One kernel: the 512-wide hidden row stays
- * on the CU (registers -> LDS), no LayerNorm / GELU pass over HBM. */
+ * on the CU (registers -> LDS), no LayerNorm / GELU pass over HBM.  act = 1 replaces LayerNorm + GELU by ReLU (gamma, beta
+ * may be NULL): SuperGlue's MLP([512, 512, 256]) with its BatchNorm folded into W1 / b1 (imcui/hloc/matchers/superglue.py:26). */
 float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsigned short* lo);
 int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const float* ctx, const unsigned short* w1h, const unsigned short* w1l,
                             const float* s1, const float* b1, const float* gamma, const float* beta, const unsigned short* w2h,
-                            const unsigned short* w2l, const float* s2, const float* b2, float* out, int M, void* stream);
+                            const unsigned short* w2l, const float* s2, const float* b2, float* out, int M, int act, void* stream);
+
+/* Lab hook (tools/ffn_bench.py): when `stamps` is non-NULL every workgroup of the next imcui_hip_ffn_split_f32 calls
+ * writes 8 wall-clock (100 MHz) values at its phase boundaries to stamps[8 * workgroup ..]; NULL switches it off. */
+int imcui_hip_ffn_set_debug(imcui_hip_t* h, long long* stamps);
 
 int imcui_hip_conv3x3_split_f32(imcui_hip_t* h, const float* in_nhwc, const unsigned short* wh, const unsigned short* wl,
                                 const float* wscale, const float* bias, float* out_nhwc, int B, int H, int W, int Cin,

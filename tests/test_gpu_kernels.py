@@ -260,8 +260,10 @@ def test_split_mode_dynamic_range():
 
 def _ffn_reference(x, ctx, w1, b1, gamma, beta, w2, b2):
     h = torch.cat([x, ctx], -1).double() @ w1.double().t() + b1.double()
-    h = torch.nn.functional.layer_norm(h, (512,), gamma.double(), beta.double(), 1e-5)
-    h = torch.nn.functional.gelu(h)
+    if gamma is None:
+        h = torch.relu(h)
+    else:
+        h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(h, (512,), gamma.double(), beta.double(), 1e-5))
     return x.double() + h @ w2.double().t() + b2.double()
 
 
@@ -291,3 +293,21 @@ def test_fused_ffn_vs_fp64(M, scale):
     xd = x.to(_dev())
     ffn(xd, ctx.to(_dev()), out=xd)
     assert torch.equal(xd.cpu(), out)
+
+
+def test_fused_ffn_relu_mode_vs_fp64():
+    """act = 1: SuperGlue's MLP([512, 512, 256]) on cat([x, message]) with the BatchNorm folded (ReLU between the GEMMs)."""
+    from imcui_hip import backend
+
+    backend.set_precision(_dev(), 1)
+    g = torch.Generator().manual_seed(77)
+    M = 2048
+    x = torch.randn(M, 256, generator=g)
+    ctx = torch.randn(M, 256, generator=g)
+    w1 = torch.randn(512, 512, generator=g) / 512 ** 0.5
+    b1 = torch.randn(512, generator=g) * 0.3
+    w2 = torch.randn(256, 512, generator=g) / 512 ** 0.5
+    b2 = torch.randn(256, generator=g) * 0.1
+    out = backend.FusedFFN(w1, b1, None, None, w2, b2, _dev())(x.to(_dev()), ctx.to(_dev())).cpu()
+    ref = _ffn_reference(x, ctx, w1, b1, None, None, w2, b2)
+    assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
