@@ -1,8 +1,10 @@
 // Device kernels of the LoFTR path that are not GEMM-shaped:
 // first 7x7 conv, bilinear up-sampling, positional encoding, linear attention, LayerNorm,
-// dual-softmax coarse matching, fine window gather and fine matching.  Included by loftr.hip only.
+// dual-softmax coarse matching, fine window gather and fine matching.  Included by loftr.hip (all of it) and eloftr.hip (LayerNorm, dual-softmax matching).
 #pragma once
 #include "common.h"
+
+namespace {  // internal linkage: loftr.hip and eloftr.hip both include these kernels
 
 // ------------------------------------------------------------------ conv1: 7x7 stride 2 pad 3, 1 -> 128 (+folded BN, ReLU)
 // 16 lanes x 8 channels cover the 128 output channels of one pixel; a wave stores 4 pixels
@@ -620,3 +622,5 @@ __global__ __launch_bounds__(256) void lf_fine_match_kernel(const float* __restr
         kp1[2 * m + 1] = (float)(j / w1c) * scale_c + ey * 2.0f * scale_f;
     }
 }
+
+}  // namespace

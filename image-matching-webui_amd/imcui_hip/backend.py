@@ -485,6 +485,132 @@ class LoFTRHIP:
         return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
 
 
+# ------------------------------------------------------------------ EfficientLoFTR
+def _repvgg_reparam(sd: dict, p: str, eps: float = 1e-5):
+    """One RepVGG block (3x3 + BN, 1x1 + BN, optional identity BN) -> a single 3x3 convolution (w, b): the
+    `reparameter()` step of the reference wrapper (eloftr.py:61), done in float64."""
+    def branch(wk, bn):
+        w = sd[wk].double()
+        g = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + eps)
+        return w * g.view(-1, 1, 1, 1), sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * g
+
+    w3, b3 = branch(p + ".conv1.conv.weight", p + ".conv1.norm")
+    w1, b1 = branch(p + ".conv2.conv.weight", p + ".conv2.norm")
+    w = w3.clone()
+    w[:, :, 1:2, 1:2] += w1
+    b = b3 + b1
+    if p + ".identity.weight" in sd:
+        c = w.shape[0]
+        g = sd[p + ".identity.weight"].double() / torch.sqrt(sd[p + ".identity.running_var"].double() + eps)
+        w[torch.arange(c), torch.arange(c), 1, 1] += g
+        b = b + sd[p + ".identity.bias"].double() - sd[p + ".identity.running_mean"].double() * g
+    return w.float(), b.float()
+
+
+def pack_eloftr(state_dict: dict) -> torch.Tensor:
+    """EfficientLoFTR state dict (names of `transformers.EfficientLoFTRForKeypointMatching`) -> packed float32 buffer
+    (host): RepVGG re-parameterisation, BatchNorm folding, GEMM layouts."""
+    lib = load_library()
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
+    bb = "efficientloftr.backbone.stages."
+    w0, b0 = _repvgg_reparam(sd, bb + "0.blocks.0")
+    conv0_w = np.ascontiguousarray(w0[:, 0].reshape(64, 9).t().numpy(), dtype=np.float32)  # [tap][cout]
+    conv0_b = np.ascontiguousarray(b0.numpy(), dtype=np.float32)
+    ws, bs = [], []
+    for s, nb in ((1, 2), (2, 4), (3, 14)):
+        for b in range(nb):
+            w, bias = _repvgg_reparam(sd, f"{bb}{s}.blocks.{b}")
+            wg, bg = _conv_gemm_layout(w, bias, w.shape[0], w.shape[1])
+            ws.append(wg)
+            bs.append(bg)
+    tr = "efficientloftr.local_feature_transformer.layers."
+    dws, norms = [], []
+    for layer in range(4):
+        for kind in ("self_attention", "cross_attention"):
+            p = f"{tr}{layer}.{kind}."
+            for n in ("attention.q_proj", "attention.k_proj", "attention.v_proj", "attention.o_proj", "mlp.fc1", "mlp.fc2"):
+                ws.append(sd[p + n + ".weight"].contiguous())
+                bs.append(None)
+            dws.append(sd[p + "aggregation.q_aggregation.weight"].reshape(256, 16).contiguous())
+            norms += [sd[p + "aggregation.norm.weight"], sd[p + "aggregation.norm.bias"], sd[p + "mlp.layer_norm.weight"], sd[p + "mlp.layer_norm.bias"]]
+    rf = "refinement_layer."
+    w = sd[rf + "out_conv.weight"] / 16.0  # coarse features enter the fusion divided by sqrt(256)
+    wg, bg = _conv_gemm_layout(w, torch.zeros(w.shape[0]), w.shape[0], w.shape[1])
+    ws.append(wg)
+    bs.append(bg)
+    for i in range(2):
+        p = f"{rf}out_conv_layers.{i}."
+        for wk, bn in ((p + "out_conv1", None), (p + "out_conv2", p + "batch_norm"), (p + "out_conv3", None)):
+            w, bias = _fold_bn(sd[wk + ".weight"], sd, bn)
+            wg, bg = _conv_gemm_layout(w, bias, w.shape[0], w.shape[1])
+            ws.append(wg)
+            bs.append(bg)
+    nl = lib.imcui_hip_eloftr_num_layers()
+    assert len(ws) == nl, (len(ws), nl)
+    N, K = C.c_int(), C.c_int()
+    w_np, b_np = [], []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        lib.imcui_hip_eloftr_layer_shape(i, C.byref(N), C.byref(K))
+        if tuple(w.shape) != (N.value, K.value):
+            raise ImcuiHipError(f"EfficientLoFTR layer {i}: expected {(N.value, K.value)}, got {tuple(w.shape)}")
+        w_np.append(_as_f32_host(w))
+        b_np.append(None if b is None else _as_f32_host(b))
+    d_np = [_as_f32_host(d) for d in dws]
+    n_np = [_as_f32_host(n) for n in norms]
+    inv_freq = _as_f32_host(1.0 / (10000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128)))  # the port's rope init, float32
+    packed = np.zeros(lib.imcui_hip_eloftr_packed_floats(), dtype=np.float32)
+    wp = (C.c_void_p * nl)(*[a.ctypes.data for a in w_np])
+    bp = (C.c_void_p * nl)(*[(0 if a is None else a.ctypes.data) for a in b_np])
+    dp = (C.c_void_p * 8)(*[a.ctypes.data for a in d_np])
+    npp = (C.c_void_p * len(n_np))(*[a.ctypes.data for a in n_np])
+    rc = lib.imcui_hip_eloftr_pack_weights(conv0_w.ctypes.data, conv0_b.ctypes.data, wp, bp, dp, npp, inv_freq.ctypes.data, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_eloftr_pack_weights failed ({rc})")
+    return torch.from_numpy(packed)
+
+
+class ELoFTRHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+        self.last_ws = None
+
+    def forward(self, packed, image0, image1, match_threshold, debug_windows=False):
+        """Upstream EfficientLoFTR forward on image0 / image1 [B,1,H,W] (one size, multiples of 32); fixed-capacity
+        outputs + device match count."""
+        dev = image0.device
+        hd = get_handle(dev)
+        lib = hd.lib
+        image0, image1 = image0.contiguous().float(), image1.contiguous().float()
+        B, Cc, H, W = image0.shape
+        if Cc != 1 or tuple(image1.shape) != (B, 1, H, W):
+            raise ImcuiHipError("EfficientLoFTR expects two batches of 1-channel images of one size")
+        cap = B * (H // 8) * (W // 8)
+        kp0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        kp1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+        conf = torch.empty((cap,), dtype=torch.float32, device=dev)
+        bidx = torch.empty((cap,), dtype=torch.int32, device=dev)
+        nm = torch.zeros((1,), dtype=torch.int32, device=dev)
+        with self._lock:
+            ws = self._ws.get(lib.imcui_hip_eloftr_workspace_bytes(B, H, W, int(bool(debug_windows))), dev)
+            self.last_ws = ws
+            self.last_dims = (B, H, W)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_eloftr_forward(
+                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H, W, float(match_threshold), _ptr(kp0), _ptr(kp1), _ptr(conf),
+                    _ptr(bidx), _ptr(nm), int(bool(debug_windows)), _ptr(ws), ws.numel(), _stream_ptr(),
+                )  # fmt: skip
+                hd.check(rc, "imcui_hip_eloftr_forward")
+        return {"keypoints0": kp0, "keypoints1": kp1, "confidence": conf, "batch_indexes": bidx, "num_matches": nm}
+
+    def debug_buffer(self, which: int, shape) -> torch.Tensor:
+        """Workspace buffer `which` of the last forward (imcui_hip_eloftr_debug_offset) viewed as float32 `shape`."""
+        lib = load_library()
+        off = lib.imcui_hip_eloftr_debug_offset(which, *self.last_dims)
+        n = int(np.prod(shape))
+        return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
+
+
 def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):
     """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 32 == 0)."""
     hd = get_handle(x_nhwc.device)

@@ -85,3 +85,18 @@ def make_pair_batch(seed: int, batch: int, h: int = 480, w: int = 640, n_blobs: 
     img1 = torch.cat([pairs[i][1] for i in idx], 0)
     hm = torch.stack([pairs[i][2] for i in idx], 0)
     return img0, img1, hm
+
+
+def make_shifted_pair(seed: int, h: int = 480, w: int = 640, shift=(16, 8), n_blobs: int = 2000, noise: float = 0.0):
+    """Two crops of one synthetic scene: img1(x, y) = img0(x + dx, y + dy).  Returns (img0, img1 [1,1,H,W], (dx, dy)).
+    A match (p0, p1) of the pair satisfies p0 - p1 = (dx, dy).  Translations by multiples of 8 px keep the 1/8 grids of
+    the dense matchers aligned, which is what lets random-weight networks produce many confident matches."""
+    g = torch.Generator().manual_seed(seed)
+    dx, dy = shift
+    m = 8 * ((max(abs(dx), abs(dy)) + 7) // 8)
+    base = _add_blobs(g, _band_limited_noise(g, h + 2 * m, w + 2 * m), n_blobs * (h + 2 * m) * (w + 2 * m) // (h * w))
+    img0 = base[:, :, m : m + h, m : m + w]
+    img1 = base[:, :, m + dy : m + dy + h, m + dx : m + dx + w]
+    if noise > 0:
+        img1 = (img1 + noise * torch.randn(img1.shape, generator=g)).clamp(0, 1)
+    return img0.contiguous(), img1.contiguous(), (dx, dy)

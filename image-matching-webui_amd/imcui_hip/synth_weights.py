@@ -318,3 +318,115 @@ def superglue_state_dict(seed: int = 0, structured: bool = True) -> dict:
         sd["final_proj.weight"] = sd["final_proj.weight"] + 4.0 * math.sqrt(60.0) * torch.eye(256)[:, :, None]
     sd["bin_score"] = torch.tensor(35.0 if structured else 1.0)  # above the best random-column score of an outlier
     return sd
+
+
+def eloftr_state_dict(seed: int = 0, gain: float = 1.0, shaped: bool = True) -> dict:
+    """Random EfficientLoFTR weights in the layout of `transformers.EfficientLoFTRForKeypointMatching.state_dict()`
+    (the maintained port of the upstream network the reference wrapper imports, imcui/hloc/matchers/eloftr.py:13-18):
+
+    efficientloftr.backbone.stages.{s}.blocks.{b}.{conv1,conv2}.{conv.weight,norm.*}[, identity.*]   RepVGG 1-64-64-128-256
+    efficientloftr.local_feature_transformer.layers.{0..3}.{self,cross}_attention.
+        {aggregation.{q_aggregation.weight,norm.*}, attention.{q,k,v,o}_proj.weight, mlp.{fc1,fc2}.weight, mlp.layer_norm.*}
+    refinement_layer.{out_conv.weight, out_conv_layers.{0,1}.{out_conv1,out_conv2,out_conv3}.weight, batch_norm.*}
+
+    `gain` scales the transformer's residual updates (the LayerNorm that closes each block); `shaped` re-weights the last
+    block so that with random weights the coarse features are content codes and the dual soft-max at temperature 0.1
+    produces confident mutual matches on overlapping images.
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k, s=1.0, groups=1):
+        sd[name] = torch.randn(cout, cin // groups, k, k, generator=g) * math.sqrt(2.0 / (cin // groups * k * k)) * s
+
+    def bn(name, c, wmean=1.0):
+        sd[name + ".weight"] = wmean * (1.0 + 0.1 * torch.randn(c, generator=g))
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 1.0 + 0.2 * torch.rand(c, generator=g)
+        sd[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    def lin(name, out_f, in_f, s=1.0):
+        sd[name] = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * math.sqrt(3.0 / in_f) * s
+
+    def ln(name, c, wmean=1.0):
+        sd[name + ".weight"] = wmean * (1.0 + 0.05 * torch.randn(c, generator=g))
+        sd[name + ".bias"] = 0.02 * torch.randn(c, generator=g)
+
+    blocks, strides, dims = [1, 2, 4, 14], [2, 1, 2, 2], [64, 64, 128, 256]
+    cin = 1
+    for s in range(4):
+        for b in range(blocks[s]):
+            p = f"efficientloftr.backbone.stages.{s}.blocks.{b}"
+            cout = dims[s]
+            stride = strides[s] if b == 0 else 1
+            has_id = cin == cout and stride == 1
+            # three branches are summed before the ReLU: keep the sum at unit variance
+            local = shaped and s == 3 and b > 0  # keep the receptive field of the 14-block stage small
+            conv(p + ".conv1.conv.weight", cout, cin, 3, 0.3 if local else 0.8)
+            bn(p + ".conv1.norm", cout)
+            conv(p + ".conv2.conv.weight", cout, cin, 1, 0.7 if local else 0.5)
+            bn(p + ".conv2.norm", cout)
+            if has_id:
+                bn(p + ".identity", cin, 0.6 if local else 0.5)
+            cin = cout
+    for i in range(4):
+        for kind in ("self_attention", "cross_attention"):
+            p = f"efficientloftr.local_feature_transformer.layers.{i}.{kind}"
+            sd[p + ".aggregation.q_aggregation.weight"] = torch.randn(256, 1, 4, 4, generator=g) * 0.25 + 1.0 / 16
+            ln(p + ".aggregation.norm", 256)
+            for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                lin(f"{p}.attention.{nm}.weight", 256, 256, 2.0 if nm in ("q_proj", "k_proj") else 1.0)
+            lin(p + ".mlp.fc1.weight", 512, 512)
+            lin(p + ".mlp.fc2.weight", 256, 512)
+            ln(p + ".mlp.layer_norm", 256, 0.05 if shaped else gain * 0.25)  # shaped: the last block carries the code (below)
+    if shaped:
+        # The 1/8 features are post-ReLU, share one large common direction and vary smoothly, which makes a few cells
+        # the nearest neighbour of everything.  Let the block every token passes through last (layer 3, cross
+        # attention) add a large content code: its first linear layer reads the WHITENED deviation of the token from
+        # the mean feature (principal components of a calibration image, each scaled to unit variance, then a random
+        # mix) and mostly ignores the attention half; the LayerNorm that closes the block applies a big gamma.
+        from .synth import _add_blobs, _band_limited_noise
+
+        p = "efficientloftr.local_feature_transformer.layers.3.cross_attention"
+        cal = _eloftr_stage3_cells(sd, _add_blobs(g, _band_limited_noise(g, 160, 192), 600))  # [480, 256]
+        mean = cal.mean(0)
+        _, sv, vt = torch.linalg.svd(cal - mean, full_matrices=False)
+        k = 64
+        white = vt[:k] / (sv[:k, None] / math.sqrt(cal.shape[0] - 1))  # [k, 256]: z = white @ (x - mean), unit variance
+        mix = torch.randn(512, k, generator=g) / math.sqrt(k)
+        wx = mix @ white
+        w1 = sd[p + ".mlp.fc1.weight"]
+        sd[p + ".mlp.fc1.weight"] = torch.cat([wx, w1[:, 256:] * 0.1], 1).contiguous()
+        # fc1 has no bias: the mean feature is removed by making every row orthogonal to it
+        wx = sd[p + ".mlp.fc1.weight"][:, :256]
+        mh = mean / mean.norm()
+        sd[p + ".mlp.fc1.weight"][:, :256] = wx - (wx @ mh)[:, None] * mh[None, :]
+        sd[p + ".mlp.layer_norm.weight"] = sd[p + ".mlp.layer_norm.weight"] / 0.05 * 3.0
+    conv("refinement_layer.out_conv.weight", 256, 256, 1)
+    for i, (hid, mid) in enumerate([(128, 256), (64, 128)]):
+        p = f"refinement_layer.out_conv_layers.{i}"
+        conv(p + ".out_conv1.weight", mid, hid, 1)
+        conv(p + ".out_conv2.weight", mid, mid, 3)
+        bn(p + ".batch_norm", mid)
+        conv(p + ".out_conv3.weight", hid, mid, 3)
+    return sd
+
+
+def _eloftr_stage3_cells(sd: dict, x: torch.Tensor) -> torch.Tensor:
+    """1/8-resolution RepVGG features of a small calibration image as [cells, 256] (plain torch; weight shaping only)."""
+    import torch.nn.functional as F
+
+    def bn(t, p):
+        return F.batch_norm(t, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+
+    for s, (nb, stride) in enumerate(zip([1, 2, 4, 14], [2, 1, 2, 2])):
+        for b in range(nb):
+            p = f"efficientloftr.backbone.stages.{s}.blocks.{b}"
+            st = stride if b == 0 else 1
+            y = bn(F.conv2d(x, sd[p + ".conv1.conv.weight"], None, st, 1), p + ".conv1.norm")
+            y = y + bn(F.conv2d(x, sd[p + ".conv2.conv.weight"], None, st, 0), p + ".conv2.norm")
+            if p + ".identity.weight" in sd:
+                y = y + bn(x, p + ".identity")
+            x = F.relu(y)
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1])

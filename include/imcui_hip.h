@@ -204,6 +204,36 @@ int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* im
  * 1 fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 sim [B,L0,L1], 3 fine windows [2,B*L0,25,128]  (parity tests) */
 size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);
 
+/* ---- EfficientLoFTR (upstream zju3dv/EfficientLoFTR `LoFTR` behind
+ * imcui/hloc/matchers/eloftr.py:79, 'full' model, fp32) ------------------------------------------------------ */
+/* Host-side packing, as for LoFTR: imcui_hip_eloftr_num_layers() layers W[N][K] (+ bias, may be NULL) of
+ * imcui_hip_eloftr_layer_shape(i) in GEMM layout -- 20 re-parameterised RepVGG blocks ([Cout][tap][Cin]; 3x3 + 1x1 +
+ * identity branches and their BatchNorms folded, what the reference's `reparameter()` does, eloftr.py:61), 8 attention
+ * blocks x {q, k, v, o, fc1, fc2}, 7 fine-fusion convolutions (BatchNorm folded, the 1/16 coarse-feature scale folded
+ * into the first) -- built from the state dict by imcui_hip/backend.py:pack_eloftr.  conv0_w [9][64] / conv0_b [64]: the
+ * first block (1 -> 64, stride 2).  dw: 8 depth-wise 4x4 query-aggregation kernels [256][16] (block = layer * 2 +
+ * {self, cross}).  norms: 32 vectors of 256 (per block: aggregation norm w, b; mlp LayerNorm w, b).  inv_freq [64]:
+ * rotary frequencies 1 / 10000^(2t/128). */
+size_t imcui_hip_eloftr_packed_floats(void);
+int imcui_hip_eloftr_num_layers(void);
+int imcui_hip_eloftr_layer_shape(int i, int* N, int* K);
+int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* conv0_b, const float* const* w, const float* const* b,
+                                  const float* const* dw, const float* const* norms, const float* inv_freq, float* packed);
+size_t imcui_hip_eloftr_workspace_bytes(int B, int H, int W, int debug_windows);
+/* Upstream LoFTR.forward on B pairs of images [dev, B,1,H,W] of ONE size (H, W multiples of 32, >= 64; the wrapper's
+ * preprocessing resizes both images to width x height, configs/matchers.py:296-303).  Outputs with capacity
+ * B*(H/8)*(W/8) rows, first num_matches[0] valid, ordered batch-major by the coarse cell of image0: keypoints0/1
+ * [dev, cap,2] pixel (x,y) after the two-stage fine refinement, confidence [dev, cap], batch_indexes [dev, cap] int32,
+ * num_matches [dev, 1] int32.  match_threshold = conf["match_threshold"] (eloftr.py:54).  debug_windows != 0 also
+ * writes the unfolded fine windows to the workspace (parity tests; size it with the same flag). */
+int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H, int W,
+                             double match_threshold, float* keypoints0, float* keypoints1, float* confidence,
+                             int* batch_indexes, int* num_matches, int debug_windows, void* ws, size_t ws_bytes, void* stream);
+/* byte offset inside the workspace of: 0 backbone 1/2 features [2B,H/2,W/2,64] (images 0 first), 1 1/4 features
+ * [2B,H/4,W/4,128], 2 coarse features after the transformer [2B,L,256], 3 sim [B,L,L], 4 fused 1/2-resolution fine map
+ * [2B,H/2,W/2,64], 5 fine windows [B*L][64 + 100][64] (debug_windows)  (parity tests) */
+size_t imcui_hip_eloftr_debug_offset(int which, int B, int H, int W);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /

@@ -1,0 +1,119 @@
+"""EfficientLoFTR HIP path vs the CPU oracle on identical seeded inputs (GPU box only).
+
+Bar: every intermediate map within 2e-4 of its magnitude; the coarse match list (b, i, j) identical, or different only
+where the oracle's confidence is within 1e-4 of the threshold / of its mutual-maximum rival (audited, not waved
+through); confidences within 1e-4; refined key-points within 2e-3 px wherever both sides picked the same fine window
+positions, and where the first-stage argmax differs the oracle's two candidates must be tied to 1e-5.
+Pairs are two crops of one synthetic scene offset by a multiple of 8 px (`make_shifted_pair`), so that the shaped
+random weights give hundreds of confident mutual matches and the whole fine path is exercised.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from imcui_hip.synth import make_shifted_pair
+from imcui_hip.synth_weights import eloftr_state_dict
+from oracle.eloftr import ELoFTROracle
+
+pytestmark = pytest.mark.gpu
+SD = eloftr_state_dict(0)
+SD_RAW = eloftr_state_dict(5, gain=1.0, shaped=False)  # every attention block at full strength, no hand shaping
+
+
+def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24, -16))):
+    from imcui_hip.hloc.matchers.eloftr import ELoFTR
+
+    torch.set_num_threads(16)
+    pairs = [make_shifted_pair(11 + b, h, w, shifts[b % len(shifts)], n_blobs=max(300, h * w // 130)) for b in range(B)]
+    img0 = torch.cat([p[0] for p in pairs], 0).contiguous()
+    img1 = torch.cat([p[1] for p in pairs], 0).contiguous()
+    model = ELoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to("cuda:0")
+    out = model.forward_batched(img0.cuda(), img1.cuda(), debug_windows=True)
+    torch.cuda.synchronize()
+    n = int(out["num_matches"][0])
+    hc, wc = h // 8, w // 8
+    L = hc * wc
+    ref = ELoFTROracle(sd, {"match_threshold": thr, "max_keypoints": None}).net(img0, img1, return_intermediates=True)
+    dbg = model._impl.debug_buffer
+
+    def close(name, got, want, tol=2e-4):
+        err = (got - want).abs().max().item()
+        assert err < tol * want.abs().max().item(), f"{name}: {err:.3e} vs magnitude {want.abs().max().item():.3e}"
+
+    # intermediates (NHWC on the device; images 0 of the batch first, then images 1)
+    close("1/2 backbone features", dbg(0, (2 * B, h // 2, w // 2, 64)).cpu(), ref["_x1"].permute(0, 2, 3, 1))
+    close("1/4 backbone features", dbg(1, (2 * B, h // 4, w // 4, 128)).cpu(), ref["_x2"].permute(0, 2, 3, 1))
+    fc_ref = torch.cat([ref["_feat_c0"], ref["_feat_c1"]], 0).permute(0, 2, 3, 1).reshape(2 * B, L, 256)
+    close("coarse features after the transformer", dbg(2, (2 * B, L, 256)).cpu(), fc_ref)
+    close("fused 1/2-resolution fine map", dbg(4, (2 * B, h // 2, w // 2, 64)).cpu(), ref["_fine_half"].permute(0, 2, 3, 1))
+    # coarse match list
+    conf = ref["_conf"]
+    got = list(zip(out["batch_indexes"][:n].cpu().tolist(),
+                   ((out["keypoints0"][:n, 1].cpu() / 8).round() * wc + (out["keypoints0"][:n, 0].cpu() / 8).round()).long().tolist()))  # fine offsets are < 4 px
+    want = list(zip(ref["batch_indexes"].tolist(), ref["_i_ids"].tolist()))
+    assert len(want) >= min_matches, len(want)
+    if got != want:
+        # audit: every row present on one side only must be a threshold / mutual-maximum near-tie in the oracle
+        for b, i in set(got) ^ set(want):
+            row = conf[b, i]
+            j = int(row.argmax())
+            margin = min(abs(row[j].item() - thr), (conf[b, :, j].max() - row[j]).abs().item() + abs(row[j].item() - thr))
+            assert margin < 1e-4, f"match ({b},{i}) differs and is not a near-tie (conf {row[j].item():.6f}, thr {thr})"
+    common = sorted(set(got) & set(want))
+    gi = {k: t for t, k in enumerate(got)}
+    wi = {k: t for t, k in enumerate(want)}
+    g_idx = torch.tensor([gi[k] for k in common])
+    w_idx = torch.tensor([wi[k] for k in common])
+    assert len(common) >= 0.99 * len(want)
+    assert (out["confidence"][:n].cpu()[g_idx] - ref["confidence"][w_idx]).abs().max().item() < 1e-4
+    # fine windows of the common matches (debug buffer is indexed by the device's match order)
+    win = dbg(5, (B * L, 164, 64))[:n].cpu()[g_idx]
+    close("fine windows of image 0", win[:, :64], ref["_win0"][w_idx])
+    close("fine windows of image 1", win[:, 64:], ref["_win1"][w_idx])
+    # refined key-points
+    k0, k1 = out["keypoints0"][:n].cpu()[g_idx], out["keypoints1"][:n].cpu()[g_idx]
+    r0, r1 = ref["keypoints0"][w_idx], ref["keypoints1"][w_idx]
+    same = ((k0 - r0).abs().max(1).values < 1e-3) & ((k1 - r1).abs().max(1).values < 2e-3)
+    if not bool(same.all()):
+        # a different first-stage argmax: legitimate only if the oracle's best two fine confidences are tied
+        u0, u1 = ref["_win0"][w_idx][~same], ref["_win1"][w_idx][~same]
+        a0, a1 = u0[..., :56] / 56**0.5, u1[..., :56] / 56**0.5
+        s = a0 @ a1.transpose(-1, -2)
+        cf = (F.softmax(s, 1) * F.softmax(s, 2)).reshape(-1, 64, 10, 10)[..., 1:-1, 1:-1].reshape(len(u0), -1)
+        top = cf.topk(2, -1).values
+        assert ((top[:, 0] - top[:, 1]) < 1e-5 * top[:, 0]).all(), f"{int((~same).sum())} fine positions differ without a tie"
+    assert same.float().mean().item() > 0.98
+    return len(want)
+
+
+@pytest.mark.parametrize("h,w,B", [(160, 224, 2), (480, 640, 1)])
+def test_eloftr_vs_oracle(h, w, B, precision):
+    n = _case(h, w, B, SD, 0.2, 100 if h < 200 else 1000)
+    print(f"ELoFTR {w}x{h} B={B}: {n} matches")
+
+
+def test_eloftr_unshaped_weights():
+    """Weights without the hand shaping: all eight attention blocks contribute at full strength (few or no matches above
+    the threshold -- the intermediate maps carry the comparison)."""
+    _case(224, 320, 2, SD_RAW, 0.01, 0)
+
+
+def test_eloftr_plugin_contract():
+    """The wrapper's outputs: images swapped before the net and swapped back, top-k by confidence, key names
+    (imcui/hloc/matchers/eloftr.py:68-104)."""
+    from imcui_hip.hloc.matchers.eloftr import ELoFTR
+
+    torch.set_num_threads(16)
+    i0, i1, (dx, dy) = make_shifted_pair(2, 256, 320, (16, 24), 600)
+    conf = {"match_threshold": 0.2, "max_keypoints": 200, "state_dict": SD}
+    model = ELoFTR(conf).eval().to("cuda:0")
+    pred = model({"image0": i0.cuda(), "image1": i1.cuda()})
+    ref = ELoFTROracle(SD, {"match_threshold": 0.2, "max_keypoints": 200})({"image0": i0, "image1": i1})
+    assert set(pred) >= {"keypoints0", "keypoints1", "scores"} and len(pred["scores"]) == 200 == len(ref["scores"])
+    assert (pred["scores"].cpu() - ref["scores"]).abs().max().item() < 1e-4
+    # the kept set is the same up to confidence ties at the cut
+    d = pred["keypoints0"].cpu() - pred["keypoints1"].cpu()
+    assert ((d - torch.tensor([float(dx), float(dy)])).norm(dim=1) < 2).float().mean().item() > 0.9
+    a = {tuple(r) for r in torch.cat([pred["keypoints0"].cpu(), pred["keypoints1"].cpu()], 1).round().int().tolist()}
+    b = {tuple(r) for r in torch.cat([ref["keypoints0"], ref["keypoints1"]], 1).round().int().tolist()}
+    assert len(a & b) >= 198

@@ -229,3 +229,73 @@ def test_superglue_oracle_vs_hf(iters):
     assert torch.equal(matches[0, 1].long(), out["matches1"][0].long())
     assert (mscores[0, 0] - out["matching_scores0"][0]).abs().max().item() < 2e-5
     assert (mscores[0, 1] - out["matching_scores1"][0]).abs().max().item() < 2e-5
+
+
+def test_eloftr_oracle_vs_hf_port():
+    """oracle/eloftr.py against `transformers.EfficientLoFTRForKeypointMatching` with the same seeded weights: backbone
+    features, transformed coarse features, coarse matches (the port's per-row form) and the unfolded fine windows.  The
+    port's fine MATCHING is not compared: it applies the two soft-maxes over the (key-point, window-0) axes of its 4-D
+    tensors, which equals the upstream per-match soft-max only for a single match, and it pairs windows by list position."""
+    import torch.nn.functional as F
+    from transformers import EfficientLoFTRConfig, EfficientLoFTRForKeypointMatching
+
+    from imcui_hip.synth import make_shifted_pair
+    from imcui_hip.synth_weights import eloftr_state_dict
+    from oracle.eloftr import ELoFTROracle
+
+    torch.set_num_threads(4)
+    sd = eloftr_state_dict(3)
+    hf = EfficientLoFTRForKeypointMatching(EfficientLoFTRConfig()).eval()
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    i0, i1, _ = make_shifted_pair(4, 160, 224, (16, 8), 400)
+    out = ELoFTROracle(sd).net(i0, i1, True)
+    assert len(out["confidence"]) > 100  # the shaped weights produce a dense match list on an aligned shift
+    x = torch.stack([i0, i1], 1).expand(-1, -1, 3, -1, -1).contiguous()
+    with torch.no_grad():
+        bo = hf.efficientloftr(x)
+        fc = bo.feature_maps[0]
+        assert torch.equal(bo.feature_maps[1], out["_x1"]) and torch.equal(bo.feature_maps[2], out["_x2"])
+        scale = fc.abs().max().item()
+        assert (fc[:, 0] - out["_feat_c0"]).abs().max().item() < 2e-5 * scale
+        assert (fc[:, 1] - out["_feat_c1"]).abs().max().item() < 2e-5 * scale
+        _, sc, mi = hf._coarse_matching(fc, 8.0)
+        rows = (sc[0, 1] > 0).nonzero()[:, 0]
+        assert torch.equal(rows, out["_i_ids"]) and torch.equal(mi[0, 1][rows], out["_j_ids"])
+        assert (sc[0, 1][rows] - out["confidence"]).abs().max().item() < 1e-4
+        f0, f1 = hf.refinement_layer(fc / 16.0, bo.feature_maps[1:])
+    ff = out["_fine"]
+    u0 = F.unfold(ff[:1], 8, stride=8).view(1, 64, 64, -1).permute(0, 3, 2, 1)
+    u1 = F.unfold(ff[1:], 10, stride=8, padding=1).view(1, 64, 100, -1).permute(0, 3, 2, 1)
+    fs = f0.abs().max().item()
+    assert (u0 - f0).abs().max().item() < 2e-5 * fs and (u1 - f1).abs().max().item() < 2e-5 * fs
+    # geometry: the matches agree with the known translation (fine stage included)
+    e = (out["keypoints0"] - out["keypoints1"] - torch.tensor([16.0, 8.0])).norm(dim=1)
+    assert (e < 2).float().mean().item() > 0.9
+
+
+def test_eloftr_reparameterisation_and_packing():
+    """Host logic of the HIP path: the folded RepVGG blocks (one 3x3 convolution each) reproduce the three-branch
+    backbone of the oracle, and the packer accepts the state dict (layer table shapes checked inside)."""
+    import torch.nn.functional as F
+
+    from imcui_hip import backend
+    from imcui_hip.synth_weights import eloftr_state_dict
+    from oracle.eloftr import ELoFTROracle
+
+    sd = eloftr_state_dict(1)
+    packed = backend.pack_eloftr(sd)
+    assert packed.dtype == torch.float32 and packed.numel() == backend.load_library().imcui_hip_eloftr_packed_floats()
+    orc = ELoFTROracle(sd)
+    x = torch.rand(2, 1, 64, 96, generator=torch.Generator().manual_seed(0))
+    _, _, x3 = orc.backbone(x)
+    y = x
+    for s, nb, st in ((0, 1, 2), (1, 2, 1), (2, 4, 2), (3, 14, 2)):
+        for b in range(nb):
+            w, bias = backend._repvgg_reparam(orc.sd, f"efficientloftr.backbone.stages.{s}.blocks.{b}")
+            y = F.relu(F.conv2d(y, w, bias, st if b == 0 else 1, 1))
+    assert (y - x3).abs().max().item() < 2e-5 * x3.abs().max().item()
+    from imcui_hip.hloc.matchers.eloftr import check_port_names
+
+    with pytest.raises(KeyError):
+        check_port_names({"matcher.backbone.layer0.rbr_dense.conv.weight": torch.zeros(1)})
