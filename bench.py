@@ -168,9 +168,16 @@ def bench_loftr(args, dev, rank, world):
     from imcui_hip.synth import make_pair
     from imcui_hip.synth_weights import loftr_state_dict  # seeded weights only
 
-    Hh, Ww = args.size if args.size else (1024, 1024)
+    eloftr = args.workload == "eloftr"  # matcher zoo entry `eloftr` (configs/matchers.py:288-306: 640x480, 2000 matches kept)
+    Hh, Ww = args.size if args.size else ((480, 640) if eloftr else (1024, 1024))
     B = args.batch
-    model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
+    if eloftr:
+        from imcui_hip.hloc.matchers.eloftr import ELoFTR
+        from imcui_hip.synth_weights import eloftr_state_dict
+
+        model = ELoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": eloftr_state_dict(0)}).eval().to(dev)
+    else:
+        model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
     base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
     img1 = base[..., 8 : Hh + 8, 16 : Ww + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
@@ -211,20 +218,25 @@ def bench_loftr(args, dev, rank, world):
         # HBM bytes of the GEMM-class kernels per launch from the committed PMC passes of the same workload (1024^2 only)
         traffic = None
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_loftr.json")))
-        if cands and (Hh, Ww) == (1024, 1024) and gemm_n:
+        if cands and (Hh, Ww) == (1024, 1024) and gemm_n and not eloftr:
             with open(cands[-1]) as fh:
                 tj = json.load(fh)
             traffic = tj["traffic_bytes_per_step_gemm_kernels"] * B / tj["pairs_per_step"] / (gemm_n / args.steps)
         # algorithmic work: 2.55 TF / pair at 1024^2, scaled by area (coarse sim by area^2)
         area = Hh * Ww / (1024.0 * 1024.0)
         tf_pair = (2.03 + 0.35 + 0.03) * area + 0.14 * area * area
+        if eloftr:  # per 640x480 pair: 2 x (53.8 backbone + 35.5 fine fusion) + 30.2 transformer MLPs GMAC, 5.9 GMAC coarse sim
+            a2 = Hh * Ww / (640.0 * 480.0)
+            tf_pair = 0.4176 * a2 + 0.0118 * a2 * a2
         split = args.precision == 1
         line = {
-            "metric": "image-pairs/sec LoFTR dense matcher", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "metric": "image-pairs/sec EfficientLoFTR dense matcher" if eloftr else "image-pairs/sec LoFTR dense matcher", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM",
-                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), "weights": "seeded random (imcui_hip/synth_weights.py), kornia LoFTR architecture"},
+            "config": {"workload": (f"EfficientLoFTR (RepVGG 8-1 + 4 x aggregated self / cross attention + two-stage fine matching) on synthetic {Ww}x{Hh} pairs resident in HBM" if eloftr else
+                                    f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM"),
+                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]),
+                       "weights": "seeded random (imcui_hip/synth_weights.py), " + ("EfficientLoFTR architecture (transformers port names)" if eloftr else "kornia LoFTR architecture")},
             "roofline": {"kernel": "gemm_split_kernel (GEMM class: convolutions as implicit-im2col GEMM + transformer projections)" if split else "gemm_kernel", "bound": "mfma",
                          "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": (tf_pair * B * args.steps / (gemm_ms * 1e-3) / (PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF)) if gemm_ms else 0.0,
@@ -419,7 +431,7 @@ def main():
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "superpoint", "superglue", "launchcheck"],
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
@@ -428,7 +440,7 @@ def main():
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 4 if args.workload == "loftr" else 32
+        args.batch = 4 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 32
 
     if args.workload == "launchcheck":
         return launchcheck(args)
@@ -450,7 +462,7 @@ def main():
     from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
 
     backend.set_precision(dev, args.precision)
-    if args.workload == "loftr":
+    if args.workload in ("loftr", "eloftr"):
         return bench_loftr(args, dev, rank, world)
     if args.workload == "superpoint":
         return bench_superpoint(args, dev, rank, world)

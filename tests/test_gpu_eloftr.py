@@ -65,7 +65,10 @@ def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24,
     g_idx = torch.tensor([gi[k] for k in common])
     w_idx = torch.tensor([wi[k] for k in common])
     assert len(common) >= 0.99 * len(want)
-    assert (out["confidence"][:n].cpu()[g_idx] - ref["confidence"][w_idx]).abs().max().item() < 1e-4
+    # conf = exp(sim - lse_row) * exp(sim - lse_col): an f32 rounding of the features moves sim by |sim| * 2^-23 or so and the
+    # confidence by about twice that, relatively -- the shaped weights push |sim| to ~130 (real checkpoints: tens)
+    sim_max = (fc_ref[:B] * fc_ref[B:]).sum(-1).abs().max().item() / 25.6
+    assert (out["confidence"][:n].cpu()[g_idx] - ref["confidence"][w_idx]).abs().max().item() < 1e-4 * max(1.0, sim_max / 40.0), sim_max
     # fine windows of the common matches (debug buffer is indexed by the device's match order)
     win = dbg(5, (B * L, 164, 64))[:n].cpu()[g_idx]
     close("fine windows of image 0", win[:, :64], ref["_win0"][w_idx])
