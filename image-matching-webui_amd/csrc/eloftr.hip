@@ -342,7 +342,7 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
             const long np = rows * 128;
             hipLaunchKernelGGL(el_rope_kernel, dim3((unsigned)min((np + 255) / 256, (long)4096)), blk, 0, stream, w.q, w.k, P + l.inv_freq, ah, aw, np);
         }
-        hipLaunchKernelGGL(el_attention_kernel, dim3(cdiv(La, 256), 8, ns), blk, 0, stream, w.q, w.k, w.v, La, La, 0.17677669529663687f, w.att);
+        hipLaunchKernelGGL(el_attention_kernel, dim3(cdiv(La, 64), 8, ns), blk, 0, stream, w.q, w.k, w.v, La, La, 0.17677669529663687f, w.att);
         if ((r = lin(base + 3, w.att, 256, nullptr, w.o, rows, 0))) return r;
         const long n4 = (long)ns * L * 64;
         hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream, w.o, w.up, ah, aw, 256, 4, n4);

@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void el_rope_kernel(float* __restrict__ q, flo
 }
 
 // ------------------------------------------------------------------ soft-max attention, 8 heads x 32, <= a few thousand tokens
-// One thread per query (q row in registers), keys / values of the head streamed through LDS in chunks of 64 (every
-// lane reads the same key: LDS broadcast).  Two passes over the keys: maximum first, then exp / accumulate -- the
-// sequence is tiny (La = (H/32)(W/32)), the arithmetic is exact f32 in key order.
+// Four lanes per query (8 of the 32 head dimensions each; partial dot products meet through two lane exchanges), 64
+// queries per block, keys / values of the head streamed through LDS in chunks of 64.  Two passes over the keys:
+// maximum first, then exp / accumulate -- the sequence is tiny (La = (H/32)(W/32) = 300 at 640x480), exact f32.
 // q: [nq_seq * Lq, 256], k, v: [.. * Lk, 256]; query sequence s attends to key sequence s (pointers pre-offset).
 #define EL_ATT_CHUNK 64
 __global__ __launch_bounds__(256) void el_attention_kernel(const float* __restrict__ Q, const float* __restrict__ K,
@@ -145,20 +145,25 @@ __global__ __launch_bounds__(256) void el_attention_kernel(const float* __restri
                                                            float* __restrict__ O) {
     __shared__ float Ks[EL_ATT_CHUNK * 32], Vs[EL_ATT_CHUNK * 32];
     const int head = blockIdx.y, seq = blockIdx.z;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int part = threadIdx.x & 3;
+    const int qi = blockIdx.x * 64 + (threadIdx.x >> 2);
     const bool live = qi < Lq;
-    float q[32], acc[32];
-    const float* qp = Q + ((size_t)seq * Lq + (live ? qi : 0)) * 256 + head * 32;
-#pragma unroll
-    for (int d = 0; d < 32; d += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(qp + d);
-        q[d] = t.x;
-        q[d + 1] = t.y;
-        q[d + 2] = t.z;
-        q[d + 3] = t.w;
+    float q[8], acc[8];
+    const float* qp = Q + ((size_t)seq * Lq + (live ? qi : 0)) * 256 + head * 32 + part * 8;
+    {
+        const float4 t0 = *reinterpret_cast<const float4*>(qp), t1 = *reinterpret_cast<const float4*>(qp + 4);
+        q[0] = t0.x, q[1] = t0.y, q[2] = t0.z, q[3] = t0.w, q[4] = t1.x, q[5] = t1.y, q[6] = t1.z, q[7] = t1.w;
     }
     const float* kb = K + (size_t)seq * Lk * 256 + head * 32;
     const float* vb = V + (size_t)seq * Lk * 256 + head * 32;
+    auto dot = [&](int j) __attribute__((always_inline)) {
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) s = fmaf(q[d], Ks[j * 32 + part * 8 + d], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        return s * scale;
+    };
     float m = -INFINITY;
     for (int k0 = 0; k0 < Lk; k0 += EL_ATT_CHUNK) {
         const int nk = min(EL_ATT_CHUNK, Lk - k0);
@@ -166,15 +171,10 @@ __global__ __launch_bounds__(256) void el_attention_kernel(const float* __restri
         for (int i = threadIdx.x; i < nk * 8; i += 256)
             *reinterpret_cast<float4*>(Ks + i * 4) = *reinterpret_cast<const float4*>(kb + (size_t)(k0 + (i >> 3)) * 256 + (i & 7) * 4);
         __syncthreads();
-        for (int j = 0; j < nk; ++j) {
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) s = fmaf(q[d], Ks[j * 32 + d], s);
-            m = fmaxf(m, s * scale);
-        }
+        for (int j = 0; j < nk; ++j) m = fmaxf(m, dot(j));
     }
 #pragma unroll
-    for (int d = 0; d < 32; ++d) acc[d] = 0.0f;
+    for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
     float l = 0.0f;
     for (int k0 = 0; k0 < Lk; k0 += EL_ATT_CHUNK) {
         const int nk = min(EL_ATT_CHUNK, Lk - k0);
@@ -185,20 +185,17 @@ __global__ __launch_bounds__(256) void el_attention_kernel(const float* __restri
         }
         __syncthreads();
         for (int j = 0; j < nk; ++j) {
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) s = fmaf(q[d], Ks[j * 32 + d], s);
-            const float p = expf(s * scale - m);
+            const float p = expf(dot(j) - m);
             l += p;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) acc[d] = fmaf(p, Vs[j * 32 + d], acc[d]);
+            for (int d = 0; d < 8; ++d) acc[d] = fmaf(p, Vs[j * 32 + part * 8 + d], acc[d]);
         }
     }
     if (live) {
         const float inv = 1.0f / l;
-        float* op = O + ((size_t)seq * Lq + qi) * 256 + head * 32;
-#pragma unroll
-        for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
+        float* op = O + ((size_t)seq * Lq + qi) * 256 + head * 32 + part * 8;
+        *reinterpret_cast<float4*>(op) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
     }
 }
 
@@ -212,15 +209,16 @@ __global__ __launch_bounds__(256) void el_attention_kernel(const float* __restri
 //   stage 2: last 8 channels: heat = softmax((b0[il] . b1[3x3 block] / sqrt 8) / 10) on the 10x10 grid at rows
 //            ri + {-1,0,1}, columns rj + {-1,0,1} (negative indices wrap, as the reference's advanced indexing does);
 //            key-point 1 += expectation of the normalised 3x3 grid * (3 // 2) * fine_scale.
-__device__ __forceinline__ float el_fine_sample(const float* __restrict__ R, int hh, int wh, int y, int x, int c) {
-    // value of channel c at full-resolution pixel (y, x) of the x2 up-sampled map
+// value of channel c at full-resolution pixel (y, x) of the x2 up-sampled map, read from a 6 x 6 patch of the
+// 1/2-resolution map staged in LDS (patch origin (oy, ox) in 1/2-resolution pixels; hh x wh = size of that map)
+__device__ __forceinline__ float el_fine_sample(const float* __restrict__ P, int oy, int ox, int hh, int wh, int y, int x, int c) {
     const float fy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.0f);
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < hh - 1 ? 1 : 0), x1 = x0 + (x0 < wh - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.0f - ly, hx = 1.0f - lx;
-    const float v00 = R[((size_t)y0 * wh + x0) * 64 + c], v01 = R[((size_t)y0 * wh + x1) * 64 + c];
-    const float v10 = R[((size_t)y1 * wh + x0) * 64 + c], v11 = R[((size_t)y1 * wh + x1) * 64 + c];
+    const float v00 = P[((y0 - oy) * 6 + (x0 - ox)) * 64 + c], v01 = P[((y0 - oy) * 6 + (x1 - ox)) * 64 + c];
+    const float v10 = P[((y1 - oy) * 6 + (x0 - ox)) * 64 + c], v11 = P[((y1 - oy) * 6 + (x1 - ox)) * 64 + c];
     return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
 }
 
@@ -248,14 +246,29 @@ __global__ __launch_bounds__(256) void el_fine_kernel(const float* __restrict__ 
     const float* R1 = R + (size_t)(B + b) * hh * wh * 64;
     const int y0 = (ci / wc) * 8, x0 = (ci % wc) * 8;
     const int y1 = (cj / wc) * 8 - 1, x1 = (cj % wc) * 8 - 1;
+    // Both windows read the same 6 x 6 block geometry of the 1/2-resolution map: rows 4k - 1 .. 4k + 4 for full-resolution
+    // rows 8k - 1 .. 8k + 8 (src = y / 2 - 0.25, two taps).  Stage the two blocks in LDS (aliasing S, which is not live
+    // yet): 2 x 2304 loads instead of 4 taps x 164 positions x 64 channels from L2.
+    float* P0 = S;
+    float* P1 = S + 36 * 64;
+    const int oy0 = (ci / wc) * 4 - 1, ox0 = (ci % wc) * 4 - 1, oy1 = (cj / wc) * 4 - 1, ox1 = (cj % wc) * 4 - 1;
+    for (int i = tid; i < 36 * 64; i += 256) {
+        const int p = i >> 6, c = i & 63;
+        int gy = oy0 + p / 6, gx = ox0 + p % 6;
+        P0[i] = (gy >= 0 && gy < hh && gx >= 0 && gx < wh) ? R0[((size_t)gy * wh + gx) * 64 + c] : 0.0f;
+        gy = oy1 + p / 6;
+        gx = ox1 + p % 6;
+        P1[i] = (gy >= 0 && gy < hh && gx >= 0 && gx < wh) ? R1[((size_t)gy * wh + gx) * 64 + c] : 0.0f;
+    }
+    __syncthreads();
     for (int i = tid; i < 64 * 64; i += 256) {
         const int p = i >> 6, c = i & 63;
-        F0[p * 65 + c] = el_fine_sample(R0, hh, wh, y0 + (p >> 3), x0 + (p & 7), c);
+        F0[p * 65 + c] = el_fine_sample(P0, oy0, ox0, hh, wh, y0 + (p >> 3), x0 + (p & 7), c);
     }
     for (int i = tid; i < 100 * 64; i += 256) {
         const int p = i >> 6, c = i & 63;
         const int y = y1 + p / 10, x = x1 + p % 10;
-        F1[p * 65 + c] = (y >= 0 && y < H && x >= 0 && x < W) ? el_fine_sample(R1, hh, wh, y, x, c) : 0.0f;
+        F1[p * 65 + c] = (y >= 0 && y < H && x >= 0 && x < W) ? el_fine_sample(P1, oy1, ox1, hh, wh, y, x, c) : 0.0f;
     }
     __syncthreads();
     if (dbg_win != nullptr) {  // parity hook: the unfolded windows [cap][64 + 100][64]
