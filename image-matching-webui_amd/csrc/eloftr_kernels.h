@@ -276,14 +276,39 @@ __global__ __launch_bounds__(256) void el_fine_kernel(const float* __restrict__ 
             const int p = i >> 6, c = i & 63;
             dbg_win[((size_t)m * 164 + p) * 64 + c] = p < 64 ? F0[p * 65 + c] : F1[(p - 64) * 65 + c];
         }
+        __syncthreads();  // the windows are scaled in place below
     }
-    // stage 1 similarities: (a0 / sqrt 56) . (a1 / sqrt 56)
+    // stage 1 similarities: (a0 / sqrt 56) . (a1 / sqrt 56).  The first 56 channels are scaled in place (the second stage
+    // reads channels 56..63 only), then every thread owns a 4 x 5 block of the 64 x 100 matrix: 9 LDS reads per 20 FMAs.
     const float isq = 1.0f / sqrtf(56.0f);
-    for (int i = tid; i < 6400; i += 256) {
-        const int l = i / 100, r = i - l * 100;
-        float s = 0.0f;
-        for (int c = 0; c < 56; ++c) s = fmaf(F0[l * 65 + c] * isq, F1[r * 65 + c] * isq, s);
-        S[i] = s;
+    for (int i = tid; i < 164 * 56; i += 256) {
+        const int p = i / 56, c = i - p * 56;
+        float* f = p < 64 ? F0 + p * 65 + c : F1 + (p - 64) * 65 + c;
+        *f = *f * isq;
+    }
+    __syncthreads();
+    for (int t = tid; t < 320; t += 256) {
+        const int l0 = (t / 20) * 4, r0 = (t % 20) * 5;
+        float acc[4][5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[i][j] = 0.0f;
+        for (int c = 0; c < 56; ++c) {
+            float a[4], b[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = F0[(l0 + i) * 65 + c];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) b[j] = F1[(r0 + j) * 65 + c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) S[(l0 + i) * 100 + r0 + j] = acc[i][j];
     }
     __syncthreads();
     if (tid < 100) {
