@@ -38,5 +38,10 @@ for b in 1 4; do
   ( cd $R && timeout 100 python bench.py --batch $b --adaptive --graph --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_splg_adaptive_b${b}_graph.json.log 2>&1 )
 done
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 > $O/rocprof_eloftr.log 2>&1
+# the fused FFN kernel: A/B against the three-launch path, and its phase breakdown
+( cd $R && IMCUI_LG_FFN_UNFUSED=1 timeout 100 python bench.py --no-cpu-baseline > $O/bench_splg_unfused_ffn.json.log 2>&1; tail -1 $O/bench_splg_unfused_ffn.json.log | cut -c1-160 )
+( cd $R && timeout 100 python tools/ffn_bench.py > $O/lab_ffn_phases.txt 2>&1 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 ls $O
