@@ -60,6 +60,25 @@ class ELoFTR(BaseModel):
         """Upstream forward(image0, image1) on a batch: fixed-capacity outputs, no host sync."""
         return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], debug_windows)
 
+    def forward_pairs(self, image0: torch.Tensor, image1: torch.Tensor) -> list:
+        """`_forward` on B pairs at once (the batched dense driver): the per-pair dictionaries the wrapper would return for
+        `{"image0": image0[b:b+1], "image1": image1[b:b+1]}` -- images exchanged before the net, per-pair top-k by confidence,
+        key names exchanged back.  One device-to-host read (the match count)."""
+        out = self.forward_batched(image1, image0)
+        n = int(out["num_matches"][0])
+        bidx = out["batch_indexes"][:n]
+        kp0, kp1, conf = out["keypoints0"][:n], out["keypoints1"][:n], out["confidence"][:n]
+        top_k = self.conf["max_keypoints"]
+        res = []
+        for b in range(image0.shape[0]):
+            sel = (bidx == b).nonzero()[:, 0]
+            k0, k1, sc = kp0[sel], kp1[sel], conf[sel]
+            if top_k is not None and len(sc) > top_k:
+                keep = torch.argsort(sc, descending=True)[:top_k]
+                k0, k1, sc = k0[keep], k1[keep], sc[keep]
+            res.append({"keypoints0": k1, "keypoints1": k0, "scores": sc})
+        return res
+
     def _forward(self, data):
         out = self.forward_batched(data["image1"], data["image0"])  # the reference refines key-points in image0
         n = int(out["num_matches"][0])

@@ -106,3 +106,65 @@ def test_extract_then_match_from_files_equals_the_per_call_plugins(tmp_path):
             assert np.array_equal(grp["matching_scores0"].__array__(), pred["matching_scores0"][0].cpu().numpy().astype(np.float16))
             total += int((m >= 0).sum())
     assert total > 10
+
+
+@pytest.mark.parametrize("matcher", ["loftr", "eloftr"])
+def test_dense_driver_equals_one_pair_per_call(tmp_path, matcher):
+    """`match_dense` on image files (imcui/hloc/match_dense.py:196-253), B pairs per C-ABI call, against the reference flow:
+    one `model({"image0", "image1"})` call per pair on the same preprocessed tensors, key-points rescaled to the original
+    resolution, groups `name0/name1` with keypoints0 / keypoints1 / scores.  Includes a pair that is flipped because its
+    first image is an existing reference, an image that needs the area resize, and one whose size needs the dfactor resize."""
+    from types import SimpleNamespace
+
+    from PIL import Image
+
+    from imcui_hip.hloc import match_dense as md
+    from imcui_hip.hloc.match_features import names_to_pair
+    from imcui_hip.hloc.utils.h5lite import open_h5
+    from imcui_hip.synth import make_shifted_pair
+    from imcui_hip.synth_weights import eloftr_state_dict, loftr_state_dict
+
+    root = tmp_path / "images"
+    root.mkdir()
+    names = []
+    for i, (hw, shift) in enumerate([((256, 320), (16, 8)), ((256, 320), (8, 24)), ((256, 320), (-16, 0)), ((512, 640), (32, 16)), ((262, 325), (16, 8))]):
+        i0, i1, _ = make_shifted_pair(40 + i, hw[0], hw[1], shift, 900)
+        for side, img in (("a", i0), ("b", i1)):
+            Image.fromarray((img[0, 0] * 255).round().to(torch.uint8).numpy()).save(root / f"{side}{i}.png")
+        names.append((f"a{i}.png", f"b{i}.png"))
+    df = 32 if matcher == "eloftr" else 8
+    conf = {"model": {"name": matcher, "match_threshold": 0.2, "max_keypoints": 500}, "preprocessing": {"grayscale": True, "resize_max": 320, "dfactor": df}}
+    if matcher == "eloftr":
+        from imcui_hip.hloc.matchers.eloftr import ELoFTR as Model
+
+        sd = eloftr_state_dict(0)
+    else:
+        from imcui_hip.hloc.matchers.loftr import LoFTR as Model
+
+        sd = loftr_state_dict(0)
+    model = Model({**conf["model"], "state_dict": sd}).eval().to("cuda:0")
+    existing = {"a1.png"}
+    path = md.match_dense(conf, names, root, tmp_path / "dense.h5", existing_refs=existing, model=model, batch_size=3)
+    pconf = SimpleNamespace(**{**md.DEFAULT_PREPROCESSING, **conf["preprocessing"]})
+    total = 0
+    with open_h5(path, "r") as fd:
+        for n0, n1 in names:
+            im0, s0 = md.preprocess_pair_image(md.read_image_u8(root / n0), pconf, torch.device("cuda:0"))
+            im1, s1 = md.preprocess_pair_image(md.read_image_u8(root / n1), pconf, torch.device("cuda:0"))
+            assert im0.shape[-1] % df == 0 and im0.shape[-2] % df == 0 and max(im0.shape[-2:]) <= 320
+            with torch.no_grad():
+                if n0 in existing:
+                    pred = model({"image0": im1, "image1": im0})
+                    pred = {**pred, "keypoints0": pred["keypoints1"], "keypoints1": pred["keypoints0"]}
+                else:
+                    pred = model({"image0": im0, "image1": im1})
+            grp = fd[names_to_pair(n0, n1)]
+            k0 = ((pred["keypoints0"] + 0.5) * pred["keypoints0"].new_tensor(s0) - 0.5).cpu().numpy()
+            k1 = ((pred["keypoints1"] + 0.5) * pred["keypoints1"].new_tensor(s1) - 0.5).cpu().numpy()
+            # the same set of matches; the order inside a pair may differ where confidences tie at the top-k sort
+            got = np.concatenate([grp["keypoints0"].__array__(), grp["keypoints1"].__array__(), grp["scores"].__array__()[:, None]], 1)
+            want = np.concatenate([k0, k1, pred["scores"].cpu().numpy()[:, None]], 1)
+            assert got.shape == want.shape and got.dtype == np.float32
+            assert np.allclose(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])], atol=1e-4)
+            total += len(got)
+    assert total > 300
