@@ -131,9 +131,9 @@ extern "C" int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* 
 struct ElWs {
     float *s0, *s1a, *s1b, *x1, *s2a, *s2b, *x2, *s3a, *s3b, *fc;
     float *qa, *ka, *q, *k, *v, *att, *o, *up, *hb, *ob;
-    float *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *mconf;
+    float *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *rp0, *rp1, *mconf;
     float *f8, *u4, *a4, *b4, *r4, *u2, *a2, *b2, *r2, *win;
-    int *bestj, *flag, *mb, *mi, *mj, *nmatch;
+    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *rpj;
     size_t total;
     bool ok;
 };
@@ -171,8 +171,11 @@ static ElWs el_carve(void* ws, size_t bytes, int B, int H, int W, int dbg_window
     w.csum = a.get<float>(cap);
     w.best = a.get<float>(cap);
     w.cbest = a.get<float>(cap);
-    w.pc0 = a.get<float>(cap * LF_RCH);
-    w.pc1 = a.get<float>(cap * LF_RCH);
+    w.pc0 = a.get<float>(cap * lf2_nbd((int)L));
+    w.pc1 = a.get<float>(cap * lf2_nbd((int)L));
+    w.rp0 = a.get<float>(cap * lf2_nch((int)L));
+    w.rp1 = a.get<float>(cap * lf2_nch((int)L));
+    w.rpj = a.get<int>(cap * lf2_nch((int)L));
     w.mconf = a.get<float>(cap);
     w.f8 = a.get<float>(p8 * 256);
     w.u4 = a.get<float>(p4 * 256);
@@ -380,14 +383,7 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         g.alpha = 0.00390625f / 0.1f;
         ELRUN(gemm_launch(h, g, stream));
     }
-    const dim3 rg(cdiv(L, 4), B);
-    hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum);
-    const dim3 cgz(cdiv(L, 64), B, LF_RCH), cg1(cdiv(L, 256), B);
-    hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, L, w.pc0, w.pc1);
-    hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, L, w.cmax, w.csum);
-    hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
-    hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, L, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
-    hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, L, w.cbest);
+    lf_dual_softmax2_launch(w.sim, B, L, L, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
     hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, L, wc, hc, wc, hc, 2,
                        (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi, w.mj,

@@ -9,6 +9,7 @@
 // coarse matching and the fine 5x5-window stage are the small kernels of loftr_kernels.h.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gemm.h"
@@ -123,9 +124,9 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
 // ------------------------------------------------------------------ workspace
 struct LfWs {
     float *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *fc, *up3, *x2o, *y2, *x2out, *up2, *x1o, *y1, *ff;
-    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1;
+    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *rp0, *rp1;
     float *X, *CG, *CW, *F, *fq, *fk, *fv, *fatt, *fm, *fh, *fo, *mconf;
-    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2;
+    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2, *rpj;
     size_t total;
     bool ok;
 };
@@ -176,8 +177,12 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int 
     w.csum = a.get<float>(cap1);
     w.best = a.get<float>(cap);
     w.cbest = a.get<float>(cap1);
-    w.pc0 = a.get<float>(cap1 * LF_RCH);
-    w.pc1 = a.get<float>(cap1 * LF_RCH);
+    const size_t ncp = (size_t)(lf2_nbd((int)L0) > LF_RCH ? lf2_nbd((int)L0) : LF_RCH);  // column partials: row bands (two-pass) or row chunks (four-pass)
+    w.pc0 = a.get<float>(cap1 * ncp);
+    w.pc1 = a.get<float>(cap1 * ncp);
+    w.rp0 = a.get<float>(cap * lf2_nch((int)L1));
+    w.rp1 = a.get<float>(cap * lf2_nch((int)L1));
+    w.rpj = a.get<int>(cap * lf2_nch((int)L1));
     w.X = a.get<float>(2 * cap * 25 * 256);
     w.CG = a.get<float>(2 * cap * 256);
     w.CW = a.get<float>(2 * cap * 128);
@@ -442,15 +447,21 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.alpha = 0.00390625f / 0.1f;
         LFRUN(gemm_launch(h, g, stream));
     }
-    const dim3 rg(cdiv(L, 4), B), blk(256);
-    hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum);
-    const dim3 cgz(cdiv(S, 64), B, LF_RCH), cg1(cdiv(S, 256), B);
-    hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, S, w.pc0, w.pc1);
-    hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, S, w.cmax, w.csum);
-    // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
-    hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
-    hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
-    hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, S, w.cbest);
+    const dim3 blk(256);
+    static const bool four_pass = getenv("IMCUI_LF_MATCH_4PASS") != nullptr;  // A/B switch: the round-1 form that reads sim four times
+    if (!four_pass) {
+        lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
+    } else {
+        const dim3 rg(cdiv(L, 4), B);
+        hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum);
+        const dim3 cgz(cdiv(S, 64), B, LF_RCH), cg1(cdiv(S, 256), B);
+        hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, S, w.pc0, w.pc1);
+        hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, S, w.cmax, w.csum);
+        // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
+        hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
+        hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
+        hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, S, w.cbest);
+    }
     hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, S, wcs[0], hcs[0], wcs[1], hcs[1],
                        2, (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi,
