@@ -129,7 +129,7 @@ extern "C" int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* 
 
 // ------------------------------------------------------------------ workspace
 struct ElWs {
-    float *s0, *s1a, *s1b, *x1, *s2a, *s2b, *x2, *s3a, *s3b, *fc;
+    float *s0, *s1a, *x1, *s2a, *s2b, *x2, *s3a, *s3b, *fc;
     float *qa, *ka, *q, *k, *v, *att, *o, *up, *hb, *ob;
     float *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *rp0, *rp1, *mconf;
     float *f8, *u4, *a4, *b4, *r4, *u2, *a2, *b2, *r2, *win;
@@ -153,7 +153,6 @@ static ElWs el_carve(void* ws, size_t bytes, int B, int H, int W, int dbg_window
     w.s3a = a.get<float>(p8 * 256);
     w.s3b = a.get<float>(p8 * 256);
     w.fc = a.get<float>(p8 * 256);
-    w.s1b = nullptr;
     w.qa = a.get<float>(n * La * 256);
     w.ka = a.get<float>(n * La * 256);
     w.q = a.get<float>(n * La * 256);

@@ -31,7 +31,7 @@ echo pmc SQ rc $?
 [ $K = 1 ] || timeout 60 $R/tools/gridsync_lab > $O/lab_gridsync.txt 2>&1
 ( cd $R && timeout 100 python bench.py --adaptive --no-cpu-baseline > $O/bench_splg_adaptive.json.log 2>&1; tail -1 $O/bench_splg_adaptive.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python bench.py --batch 1 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_splg_b1.json.log 2>&1; tail -1 $O/bench_splg_b1.json.log | cut -c1-160 )
-( cd $R && timeout 100 python bench.py --batch 64 --steps 6 --no-cpu-baseline > $O/bench_splg_b64.json.log 2>&1; tail -1 $O/bench_splg_b64.json.log | cut -c1-160 )
+( cd $R && timeout 100 python bench.py --batch 32 --no-cpu-baseline > $O/bench_splg_b32.json.log 2>&1; tail -1 $O/bench_splg_b32.json.log | cut -c1-160 )
 # HIP-graph replay vs eager launches at the latency-bound operating points (reference-default adaptive LightGlue)
 for b in 1 4; do
   ( cd $R && timeout 100 python bench.py --batch $b --adaptive --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_splg_adaptive_b${b}_eager.json.log 2>&1 )
@@ -42,6 +42,7 @@ done
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 > $O/rocprof_eloftr.log 2>&1
 # the fused FFN kernel: A/B against the three-launch path, and its phase breakdown
 ( cd $R && IMCUI_LG_FFN_UNFUSED=1 timeout 100 python bench.py --no-cpu-baseline > $O/bench_splg_unfused_ffn.json.log 2>&1; tail -1 $O/bench_splg_unfused_ffn.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && IMCUI_LF_MATCH_4PASS=1 timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024_4pass.json.log 2>&1; tail -1 $O/bench_loftr_1024_4pass.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python tools/ffn_bench.py > $O/lab_ffn_phases.txt 2>&1 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 ls $O

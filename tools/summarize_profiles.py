@@ -88,7 +88,8 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_superpoint.json.log", f"{tag}_bench_superpoint.json.log"),
                  ("stats_splg/splg_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg.csv"),
                  ("stats_loftr/loftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_loftr_1024.csv"),
-                 ("bench_loftr_640x480.json.log", f"{tag}_bench_loftr_640x480.json.log"), ("bench_splg_b64.json.log", f"{tag}_bench_splg_b64.json.log"),
+                 ("bench_loftr_640x480.json.log", f"{tag}_bench_loftr_640x480.json.log"), ("bench_splg_b64.json.log", f"{tag}_bench_splg_b64.json.log"), ("bench_splg_b32.json.log", f"{tag}_bench_splg_b32.json.log"),
+                 ("bench_loftr_1024_4pass.json.log", f"{tag}_bench_loftr_1024_4pass.json.log"),
                  ("bench_eloftr_640x480.json.log", f"{tag}_bench_eloftr_640x480.json.log"),
                  ("stats_eloftr/eloftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_eloftr_640x480.csv"),
                  ("bench_splg_unfused_ffn.json.log", f"{tag}_bench_splg_unfused_ffn.json.log"),
