@@ -104,6 +104,31 @@ def cpu_baseline(max_seconds: float = 28.0, min_pairs: int = 10, max_pairs: int 
                       f"CPUs (fastest of 8/16/32/64/128 threads); batched_extractor_value = same with SuperPoint on a batch of 8 images"}  # fmt: skip
 
 
+def cpu_baseline_dense(eloftr: bool, Hh: int, Ww: int, sd: dict, img0, img1, max_seconds: float = 30.0):
+    """The dense matcher's oracle (= restated reference CPU path, one pair per call as `match_dense` runs it) timed on this host's
+    cores on the bench pair: one warm-up, then the median of up to 3 pairs within `max_seconds`."""
+    from oracle.eloftr import ELoFTROracle
+    from oracle.loftr import LoFTROracle
+
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(ncpu, 32))  # the thread count the sparse baseline settles on for these convolution sizes
+    ora = (ELoFTROracle if eloftr else LoFTROracle)(sd, {"match_threshold": 0.2, "max_keypoints": 2000})
+    data = {"image0": img0[:1].cpu(), "image1": img1[:1].cpu()}
+    t0 = time.perf_counter()
+    ora(data)
+    warm = time.perf_counter() - t0
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_start + warm < max_seconds):
+        t0 = time.perf_counter()
+        ora(data)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return {"value": 1.0 / times[len(times) // 2], "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
+            "sample": f"median of {len(times)} synthetic {Ww}x{Hh} pair(s) after 1 warm-up, one pair per call, fp32, "
+                      f"{'EfficientLoFTR' if eloftr else 'LoFTR'} oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} of {ncpu} host CPUs)"}  # fmt: skip
+
+
 def bench_superpoint(args, dev, rank, world):
     """configs[1]: SuperPoint extractor (max 2048 key-points) on 640x480 batches; images/s, weak scaling."""
     from imcui_hip import backend
@@ -175,9 +200,11 @@ def bench_loftr(args, dev, rank, world):
         from imcui_hip.hloc.matchers.eloftr import ELoFTR
         from imcui_hip.synth_weights import eloftr_state_dict
 
-        model = ELoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": eloftr_state_dict(0)}).eval().to(dev)
+        sd = eloftr_state_dict(0)
+        model = ELoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": sd}).eval().to(dev)
     else:
-        model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": loftr_state_dict(0)}).eval().to(dev)
+        sd = loftr_state_dict(0)
+        model = LoFTR({"match_threshold": 0.2, "max_keypoints": 2000, "state_dict": sd}).eval().to(dev)
     base, _, _ = make_pair(77 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
     img1 = base[..., 8 : Hh + 8, 16 : Ww + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
@@ -244,6 +271,8 @@ def bench_loftr(args, dev, rank, world):
                          "note": "achieved = algorithmic TFLOP of a pair / summed GEMM-class kernel time (HIP events)"},
             "algorithmic_tflops_end_to_end": tf_pair * B / (dt / args.steps),
         }  # fmt: skip
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_dense(eloftr, Hh, Ww, sd, img0, img1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,7 +1,7 @@
 // EfficientLoFTR forward on MI355X (upstream zju3dv/EfficientLoFTR `LoFTR.forward`, called by
 // imcui/hloc/matchers/eloftr.py:79 with the 'full' model type in fp32).
 //
-// Data path (NHWC activations, images of one size, H and W multiples of 32):
+// Data path (NHWC activations, H and W multiples of 32; the two images of a pair may differ in size):
 //   backbone   RepVGG 1-64-64-128-256 at 1/2, 1/2, 1/4, 1/8: every block is ONE 3x3 convolution + ReLU after the
 //              host-side re-parameterisation (3x3 + 1x1 + identity branches and their BatchNorms folded, which is
 //              what the reference's `reparameter()` does at load time, eloftr.py:61) -> the implicit-im2col GEMM of
@@ -137,13 +137,16 @@ struct ElWs {
     size_t total;
     bool ok;
 };
-static ElWs el_carve(void* ws, size_t bytes, int B, int H, int W, int dbg_windows) {
+static ElWs el_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int W1, int dbg_windows) {
     WsAlloc a(ws, bytes);
     ElWs w;
-    const size_t n = 2 * (size_t)B;
-    const size_t p2 = n * (H / 2) * (W / 2), p4 = n * (H / 4) * (W / 4), p8 = n * (H / 8) * (W / 8);
-    const size_t L = (size_t)(H / 8) * (W / 8), La = (size_t)(H / 32) * (W / 32);
-    const size_t cap = (size_t)B * L;
+    // per-image buffers hold the B images of side 0 followed by the B images of side 1 (sizes may differ per side)
+    const size_t p2 = (size_t)B * ((size_t)(H0 / 2) * (W0 / 2) + (size_t)(H1 / 2) * (W1 / 2));
+    const size_t p4 = (size_t)B * ((size_t)(H0 / 4) * (W0 / 4) + (size_t)(H1 / 4) * (W1 / 4));
+    const size_t L0 = (size_t)(H0 / 8) * (W0 / 8), L1 = (size_t)(H1 / 8) * (W1 / 8);
+    const size_t p8 = (size_t)B * (L0 + L1);
+    const size_t pa = (size_t)B * ((size_t)(H0 / 32) * (W0 / 32) + (size_t)(H1 / 32) * (W1 / 32));
+    const size_t cap = (size_t)B * L0, cap1 = (size_t)B * L1;
     w.s0 = a.get<float>(p2 * 64);
     w.s1a = a.get<float>(p2 * 64);
     w.x1 = a.get<float>(p2 * 64);
@@ -153,28 +156,28 @@ static ElWs el_carve(void* ws, size_t bytes, int B, int H, int W, int dbg_window
     w.s3a = a.get<float>(p8 * 256);
     w.s3b = a.get<float>(p8 * 256);
     w.fc = a.get<float>(p8 * 256);
-    w.qa = a.get<float>(n * La * 256);
-    w.ka = a.get<float>(n * La * 256);
-    w.q = a.get<float>(n * La * 256);
-    w.k = a.get<float>(n * La * 256);
-    w.v = a.get<float>(n * La * 256);
-    w.att = a.get<float>(n * La * 256);
-    w.o = a.get<float>(n * La * 256);
+    w.qa = a.get<float>(pa * 256);
+    w.ka = a.get<float>(pa * 256);
+    w.q = a.get<float>(pa * 256);
+    w.k = a.get<float>(pa * 256);
+    w.v = a.get<float>(pa * 256);
+    w.att = a.get<float>(pa * 256);
+    w.o = a.get<float>(pa * 256);
     w.up = a.get<float>(p8 * 256);
     w.hb = a.get<float>(p8 * 512);
     w.ob = a.get<float>(p8 * 256);
-    w.sim = a.get<float>((size_t)B * L * L);
+    w.sim = a.get<float>((size_t)B * L0 * L1);
     w.rmax = a.get<float>(cap);
     w.rsum = a.get<float>(cap);
-    w.cmax = a.get<float>(cap);
-    w.csum = a.get<float>(cap);
+    w.cmax = a.get<float>(cap1);
+    w.csum = a.get<float>(cap1);
     w.best = a.get<float>(cap);
-    w.cbest = a.get<float>(cap);
-    w.pc0 = a.get<float>(cap * lf2_nbd((int)L));
-    w.pc1 = a.get<float>(cap * lf2_nbd((int)L));
-    w.rp0 = a.get<float>(cap * lf2_nch((int)L));
-    w.rp1 = a.get<float>(cap * lf2_nch((int)L));
-    w.rpj = a.get<int>(cap * lf2_nch((int)L));
+    w.cbest = a.get<float>(cap1);
+    w.pc0 = a.get<float>(cap1 * lf2_nbd((int)L0));
+    w.pc1 = a.get<float>(cap1 * lf2_nbd((int)L0));
+    w.rp0 = a.get<float>(cap * lf2_nch((int)L1));
+    w.rp1 = a.get<float>(cap * lf2_nch((int)L1));
+    w.rpj = a.get<int>(cap * lf2_nch((int)L1));
     w.mconf = a.get<float>(cap);
     w.f8 = a.get<float>(p8 * 256);
     w.u4 = a.get<float>(p4 * 256);
@@ -196,14 +199,16 @@ static ElWs el_carve(void* ws, size_t bytes, int B, int H, int W, int dbg_window
     w.ok = a.ok;
     return w;
 }
-// debug_windows != 0 reserves (and the forward fills) the unfolded fine windows [B*L][64 + 100][64] for the parity tests
-extern "C" size_t imcui_hip_eloftr_workspace_bytes(int B, int H, int W, int debug_windows) { return el_carve(nullptr, 0, B, H, W, debug_windows).total; }
+// debug_windows != 0 reserves (and the forward fills) the unfolded fine windows [B*L0][64 + 100][64] for the parity tests
+extern "C" size_t imcui_hip_eloftr_workspace_bytes(int B, int H0, int W0, int H1, int W1, int debug_windows) {
+    return el_carve(nullptr, 0, B, H0, W0, H1, W1, debug_windows).total;
+}
 
-// byte offsets of workspace buffers, for the parity tests: 0 = backbone 1/2 features [2B,H/2,W/2,64], 1 = 1/4 features
-// [.,128], 2 = coarse features after the transformer [2B, L, 256], 3 = sim [B, L, L], 4 = fused 1/2 map R [2B,H/2,W/2,64],
-// 5 = fine windows (debug_windows only)
-extern "C" size_t imcui_hip_eloftr_debug_offset(int which, int B, int H, int W) {
-    ElWs w = el_carve((void*)256, (size_t)-1 >> 1, B, H, W, 1);
+// byte offsets of workspace buffers, for the parity tests (every per-image buffer: the B images of side 0, then side 1):
+// 0 = backbone 1/2 features [.,H/2,W/2,64], 1 = 1/4 features [.,128], 2 = coarse features after the transformer [., L, 256],
+// 3 = sim [B, L0, L1], 4 = fused 1/2 map R [.,H/2,W/2,64], 5 = fine windows (debug_windows only)
+extern "C" size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1) {
+    ElWs w = el_carve((void*)256, (size_t)-1 >> 1, B, H0, W0, H1, W1, 1);
     const char* base = (const char*)256;
     switch (which) {
         case 0: return (const char*)w.x1 - base;
@@ -217,25 +222,31 @@ extern "C" size_t imcui_hip_eloftr_debug_offset(int which, int B, int H, int W) 
 }
 
 // ------------------------------------------------------------------ forward
-extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H,
-                                        int W, double match_threshold, float* keypoints0, float* keypoints1, float* confidence,
-                                        int* batch_indexes, int* num_matches, int debug_windows, void* ws, size_t ws_bytes,
-                                        void* stream_) {
+extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0,
+                                        int W0, int H1, int W1, double match_threshold, float* keypoints0, float* keypoints1,
+                                        float* confidence, int* batch_indexes, int* num_matches, int debug_windows, void* ws,
+                                        size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!h) return IMCUI_ERR_ARG;
     if (B <= 0) return IMCUI_OK;
-    if (H % 32 || W % 32 || H < 64 || W < 64)
-        return imcui_set_err(h, IMCUI_ERR_ARG, "eloftr: image size %dx%d must be a multiple of 32 (>= 64): the 1/8 grid is aggregated 4x4", W, H);
+    if (H0 % 32 || W0 % 32 || H0 < 64 || W0 < 64 || H1 % 32 || W1 % 32 || H1 < 64 || W1 < 64)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "eloftr: image sizes %dx%d / %dx%d must be multiples of 32 (>= 64): the 1/8 grid is aggregated 4x4", W0, H0, W1, H1);
     if (!packed || !image0 || !image1 || !keypoints0 || !keypoints1 || !confidence || !batch_indexes || !num_matches)
         return imcui_set_err(h, IMCUI_ERR_ARG, "eloftr: null argument");
-    ElWs w = el_carve(ws, ws_bytes, B, H, W, debug_windows);
+    ElWs w = el_carve(ws, ws_bytes, B, H0, W0, H1, W1, debug_windows);
     if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "eloftr: workspace too small (%zu < %zu)", ws_bytes, w.total);
     const ElLayout l = el_layout();
     const float* P = packed;
     const bool split = h->precision == 1;
-    const int n = 2 * B;
-    const int hc = H / 8, wc = W / 8, L = hc * wc;
-    const int ah = hc / 4, aw = wc / 4, La = ah * aw;
+    // per side s: image size and its 1/8 grid.  Upstream runs the backbone on the concatenated batch when both images have
+    // one size and image by image otherwise; convolutions do not mix images either way.
+    const int Hs[2] = {H0, H1}, Ws[2] = {W0, W1};
+    const int hcs[2] = {H0 / 8, H1 / 8}, wcs[2] = {W0 / 8, W1 / 8};
+    const int Ls[2] = {hcs[0] * wcs[0], hcs[1] * wcs[1]};
+    const int ahs[2] = {hcs[0] / 4, hcs[1] / 4}, aws[2] = {wcs[0] / 4, wcs[1] / 4};
+    const int Las[2] = {ahs[0] * aws[0], ahs[1] * aws[1]};
+    const bool same = (H0 == H1 && W0 == W1);
+    const int L = Ls[0], S = Ls[1];
     const int cap = B * L;
     const dim3 blk(256);
     int rc;
@@ -259,53 +270,60 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
             g.wscale = P + l.ws[li];
         }
     };
-    // convolution as a GEMM over the NHWC maps of `nimg` images at resolution 1/div
-    auto conv = [&](int li, const float* in, float* out, int nimg, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
-        GemmP g;
-        wts(g, li);
-        g.epi = EPI_CONV;
-        const int pad = ks / 2;
-        const int hin = H / div, win = W / div;
-        const int hout = (hin + 2 * pad - ks) / stride + 1, wout = (win + 2 * pad - ks) / stride + 1;
-        g.A = in;
-        g.conv_k = ks;
-        g.conv_stride = stride;
-        g.conv_pad = pad;
-        g.conv_hin = hin;
-        g.conv_win = win;
-        g.conv_hout = hout;
-        g.conv_wout = wout;
-        g.conv_cin = cin;
-        g.M = nimg * hout * wout;
-        g.C = out;
-        g.ldc = g.N;
-        g.resid = resid;
-        g.ldr = g.N;
-        g.act = act;
-        return gemm_launch(h, g, stream);
+    auto npx = [&](int s, int div) { return (size_t)(Hs[s] / div) * (Ws[s] / div); };
+    // convolution as a GEMM over the NHWC maps at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one
+    // launch over the 2B images when both sides have one size, one launch per side otherwise
+    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
+        for (int s = 0; s < (same ? 1 : 2); ++s) {
+            GemmP g;
+            wts(g, li);
+            g.epi = EPI_CONV;
+            const int pad = ks / 2;
+            const int hin = Hs[s] / div, win = Ws[s] / div;
+            const int hout = (hin + 2 * pad - ks) / stride + 1, wout = (win + 2 * pad - ks) / stride + 1;
+            const size_t ioff = s ? (size_t)B * npx(0, div) * cin : 0;
+            const size_t ooff = s ? (size_t)B * npx(0, div * stride) * g.N : 0;
+            g.A = in + ioff;
+            g.conv_k = ks;
+            g.conv_stride = stride;
+            g.conv_pad = pad;
+            g.conv_hin = hin;
+            g.conv_win = win;
+            g.conv_hout = hout;
+            g.conv_wout = wout;
+            g.conv_cin = cin;
+            g.M = (same ? 2 * B : B) * hout * wout;
+            g.C = out + ooff;
+            g.ldc = g.N;
+            g.resid = resid ? resid + ooff : nullptr;
+            g.ldr = g.N;
+            g.act = act;
+            const int r = gemm_launch(h, g, stream);
+            if (r != IMCUI_OK) return r;
+        }
+        return IMCUI_OK;
     };
     // ---- backbone
     {
-        // images 0 of the batch, then images 1: one buffer of 2B maps
         for (int s = 0; s < 2; ++s) {
-            const long npix = (long)B * (H / 2) * (W / 2);
+            const long npix = (long)B * (Hs[s] / 2) * (Ws[s] / 2);
             const long blocks = min((npix + 15) / 16, (long)256 * 32);
             hipLaunchKernelGGL(el_conv0_kernel, dim3((unsigned)blocks), blk, 0, stream, s ? image1 : image0, P + l.conv0_w, P + l.conv0_b,
-                               w.s0 + (s ? (size_t)npix * 64 : 0), H, W, H / 2, W / 2, npix);
+                               w.s0 + (s ? (size_t)B * npx(0, 2) * 64 : 0), Hs[s], Ws[s], Hs[s] / 2, Ws[s] / 2, npix);
         }
         IMCUI_CHECK_LAUNCH(h);
         // stage 1 (1/2, 64): 2 blocks; stage 2 (1/4, 128): 4; stage 3 (1/8, 256): 14
-        ELRUN(conv(EL_BB0 + 0, w.s0, w.s1a, n, 2, 64, 3, 1, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 1, w.s1a, w.x1, n, 2, 64, 3, 1, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 2, w.x1, w.s2a, n, 2, 64, 3, 2, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 3, w.s2a, w.s2b, n, 4, 128, 3, 1, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 4, w.s2b, w.s2a, n, 4, 128, 3, 1, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 5, w.s2a, w.x2, n, 4, 128, 3, 1, nullptr, 1));
-        ELRUN(conv(EL_BB0 + 6, w.x2, w.s3a, n, 4, 128, 3, 2, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 0, w.s0, w.s1a, 2, 64, 3, 1, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 1, w.s1a, w.x1, 2, 64, 3, 1, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 2, w.x1, w.s2a, 2, 64, 3, 2, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 3, w.s2a, w.s2b, 4, 128, 3, 1, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 4, w.s2b, w.s2a, 4, 128, 3, 1, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 5, w.s2a, w.x2, 4, 128, 3, 1, nullptr, 1));
+        ELRUN(conv(EL_BB0 + 6, w.x2, w.s3a, 4, 128, 3, 2, nullptr, 1));
         const float* src = w.s3a;
         for (int i = 7; i < 20; ++i) {
             float* dst = (i == 19) ? w.fc : (src == w.s3a ? w.s3b : w.s3a);
-            ELRUN(conv(EL_BB0 + i, src, dst, n, 8, 256, 3, 1, nullptr, 1));
+            ELRUN(conv(EL_BB0 + i, src, dst, 8, 256, 3, 1, nullptr, 1));
             src = dst;
         }
     }
@@ -327,28 +345,31 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         g.M = (int)rows;
         return gemm_launch(h, g, stream);
     };
-    // block t: `ns` images starting at image q0 attend to the `ns` images starting at image s0
-    auto block = [&](int t, int q0, int s0, int ns, bool rope) -> int {
+    const size_t tok1 = (size_t)B * L;  // first token row of side 1
+    // block t: `ns` maps of side qs (first token row qt, grid hq x wq) attend to `ns` maps of side ss (first token row st)
+    auto block = [&](int t, size_t qt, int qs, size_t st, int ss, int ns, bool rope) -> int {
         const int base = EL_TR0 + t * 6;
-        float* x = w.fc + (size_t)q0 * L * 256;
-        const float* src = w.fc + (size_t)s0 * L * 256;
+        float* x = w.fc + qt * 256;
+        const float* src = w.fc + st * 256;
+        const int Lq = Ls[qs], Laq = Las[qs], Lak = Las[ss];
         const float *gw = P + l.norm[4 * t + 0], *gb = P + l.norm[4 * t + 1];
-        hipLaunchKernelGGL(el_aggregate_kernel, dim3(ns * La), blk, 0, stream, x, P + l.dw[t], gw, gb, hc, wc, 0, w.qa);
-        hipLaunchKernelGGL(el_aggregate_kernel, dim3(ns * La), blk, 0, stream, src, P + l.dw[t], gw, gb, hc, wc, 1, w.ka);
-        const long rows = (long)ns * La;
+        hipLaunchKernelGGL(el_aggregate_kernel, dim3(ns * Laq), blk, 0, stream, x, P + l.dw[t], gw, gb, hcs[qs], wcs[qs], 0, w.qa);
+        hipLaunchKernelGGL(el_aggregate_kernel, dim3(ns * Lak), blk, 0, stream, src, P + l.dw[t], gw, gb, hcs[ss], wcs[ss], 1, w.ka);
+        const long qrows = (long)ns * Laq, krows = (long)ns * Lak;
         int r;
-        if ((r = lin(base + 0, w.qa, 256, nullptr, w.q, rows, 0))) return r;
-        if ((r = lin(base + 1, w.ka, 256, nullptr, w.k, rows, 0))) return r;
-        if ((r = lin(base + 2, w.ka, 256, nullptr, w.v, rows, 0))) return r;
-        if (rope) {
-            const long np = rows * 128;
-            hipLaunchKernelGGL(el_rope_kernel, dim3((unsigned)min((np + 255) / 256, (long)4096)), blk, 0, stream, w.q, w.k, P + l.inv_freq, ah, aw, np);
+        if ((r = lin(base + 0, w.qa, 256, nullptr, w.q, qrows, 0))) return r;
+        if ((r = lin(base + 1, w.ka, 256, nullptr, w.k, krows, 0))) return r;
+        if ((r = lin(base + 2, w.ka, 256, nullptr, w.v, krows, 0))) return r;
+        if (rope) {  // self attention: queries and keys live on the same aggregated grid
+            const long np = qrows * 128;
+            hipLaunchKernelGGL(el_rope_kernel, dim3((unsigned)min((np + 255) / 256, (long)4096)), blk, 0, stream, w.q, w.k, P + l.inv_freq, ahs[qs],
+                               aws[qs], np);
         }
-        hipLaunchKernelGGL(el_attention_kernel, dim3(cdiv(La, 64), 8, ns), blk, 0, stream, w.q, w.k, w.v, La, La, 0.17677669529663687f, w.att);
-        if ((r = lin(base + 3, w.att, 256, nullptr, w.o, rows, 0))) return r;
-        const long n4 = (long)ns * L * 64;
-        hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream, w.o, w.up, ah, aw, 256, 4, n4);
-        const long trows = (long)ns * L;
+        hipLaunchKernelGGL(el_attention_kernel, dim3(cdiv(Laq, 64), 8, ns), blk, 0, stream, w.q, w.k, w.v, Laq, Lak, 0.17677669529663687f, w.att);
+        if ((r = lin(base + 3, w.att, 256, nullptr, w.o, qrows, 0))) return r;
+        const long n4 = (long)ns * Lq * 64;
+        hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream, w.o, w.up, ahs[qs], aws[qs], 256, 4, n4);
+        const long trows = (long)ns * Lq;
         if ((r = lin(base + 4, x, 256, w.up, w.hb, trows, 2))) return r;  // LeakyReLU(0.01)
         if ((r = lin(base + 5, w.hb, 512, nullptr, w.ob, trows, 0))) return r;
         hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)min((trows + 3) / 4, (long)65536)), blk, 0, stream, w.ob, P + l.norm[4 * t + 2],
@@ -356,13 +377,18 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         return IMCUI_OK;
     };
     for (int layer = 0; layer < 4; ++layer) {
-        ELRUN(block(layer * 2 + 0, 0, 0, n, true));   // self attention on all 2B maps
-        ELRUN(block(layer * 2 + 1, 0, B, B, false));  // images 0 <- images 1
-        ELRUN(block(layer * 2 + 1, B, 0, B, false));  // images 1 <- UPDATED images 0
+        if (same) {
+            ELRUN(block(layer * 2 + 0, 0, 0, 0, 0, 2 * B, true));  // self attention on all 2B maps
+        } else {
+            ELRUN(block(layer * 2 + 0, 0, 0, 0, 0, B, true));
+            ELRUN(block(layer * 2 + 0, tok1, 1, tok1, 1, B, true));
+        }
+        ELRUN(block(layer * 2 + 1, 0, 0, tok1, 1, B, false));  // images 0 <- images 1
+        ELRUN(block(layer * 2 + 1, tok1, 1, 0, 0, B, false));  // images 1 <- UPDATED images 0
     }
     IMCUI_CHECK_LAUNCH(h);
 
-    // ---- dual soft-max coarse matching (LoFTR kernels; equal grids on both sides)
+    // ---- dual soft-max coarse matching (LoFTR kernels)
     {
         GemmP g;  // sim = (f0 / 16) . (f1 / 16)^T / 0.1
         g.epi = EPI_BIAS;
@@ -370,20 +396,20 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         g.A = w.fc;
         g.lda = 256;
         g.a_bs = (long)L * 256;
-        g.W = w.fc + (size_t)B * L * 256;
+        g.W = w.fc + tok1 * 256;
         g.ldw = 256;
-        g.w_bs = (long)L * 256;
+        g.w_bs = (long)S * 256;
         g.C = w.sim;
-        g.ldc = L;
-        g.c_bs = (long)L * L;
+        g.ldc = S;
+        g.c_bs = (long)L * S;
         g.M = L;
-        g.N = L;
+        g.N = S;
         g.K = 256;
         g.alpha = 0.00390625f / 0.1f;
         ELRUN(gemm_launch(h, g, stream));
     }
-    lf_dual_softmax2_launch(w.sim, B, L, L, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
-    hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, L, wc, hc, wc, hc, 2,
+    lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
+    hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, S, wcs[0], hcs[0], wcs[1], hcs[1], 2,
                        (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi, w.mj,
                        w.mconf, w.nmatch);
@@ -391,23 +417,27 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
 
     // ---- fine feature fusion
     auto upsample2 = [&](const float* in, float* out, int div, int C) {
-        const long n4 = (long)n * (2 * (H / div)) * (2 * (W / div)) * (C / 4);
-        hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream, in, out, H / div, W / div, C, 2, n4);
+        for (int s = 0; s < (same ? 1 : 2); ++s) {
+            const int hh = Hs[s] / div, ww = Ws[s] / div;
+            const long n4 = (long)(same ? 2 * B : B) * (2 * hh) * (2 * ww) * (C / 4);
+            hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream,
+                               in + (s ? (size_t)B * npx(0, div) * C : 0), out + (s ? (size_t)B * npx(0, div / 2) * C : 0), hh, ww, C, 2, n4);
+        }
     };
-    ELRUN(conv(EL_OUT, w.fc, w.f8, n, 8, 256, 1, 1, nullptr, 0));
+    ELRUN(conv(EL_OUT, w.fc, w.f8, 8, 256, 1, 1, nullptr, 0));
     upsample2(w.f8, w.u4, 8, 256);
-    ELRUN(conv(EL_F0_C1, w.x2, w.a4, n, 4, 128, 1, 1, w.u4, 0));
-    ELRUN(conv(EL_F0_C2, w.a4, w.b4, n, 4, 256, 3, 1, nullptr, 2));
-    ELRUN(conv(EL_F0_C3, w.b4, w.r4, n, 4, 256, 3, 1, nullptr, 0));
+    ELRUN(conv(EL_F0_C1, w.x2, w.a4, 4, 128, 1, 1, w.u4, 0));
+    ELRUN(conv(EL_F0_C2, w.a4, w.b4, 4, 256, 3, 1, nullptr, 2));
+    ELRUN(conv(EL_F0_C3, w.b4, w.r4, 4, 256, 3, 1, nullptr, 0));
     upsample2(w.r4, w.u2, 4, 128);
-    ELRUN(conv(EL_F1_C1, w.x1, w.a2, n, 2, 64, 1, 1, w.u2, 0));
-    ELRUN(conv(EL_F1_C2, w.a2, w.b2, n, 2, 128, 3, 1, nullptr, 2));
-    ELRUN(conv(EL_F1_C3, w.b2, w.r2, n, 2, 128, 3, 1, nullptr, 0));
+    ELRUN(conv(EL_F1_C1, w.x1, w.a2, 2, 64, 1, 1, w.u2, 0));
+    ELRUN(conv(EL_F1_C2, w.a2, w.b2, 2, 128, 3, 1, nullptr, 2));
+    ELRUN(conv(EL_F1_C3, w.b2, w.r2, 2, 128, 3, 1, nullptr, 0));
 
     // ---- two-stage fine matching on the windows of the matches
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(el_fine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)EL_FINE_SMEM);
-    hipLaunchKernelGGL(el_fine_kernel, dim3(cap), blk, EL_FINE_SMEM, stream, w.r2, w.mb, w.mi, w.mj, w.nmatch, B, H, W, wc, (float)H / (float)hc,
-                       1.0f, keypoints0, keypoints1, w.win);
+    hipLaunchKernelGGL(el_fine_kernel, dim3(cap), blk, EL_FINE_SMEM, stream, w.r2, w.mb, w.mi, w.mj, w.nmatch, B, H0, W0, H1, W1, wcs[0], wcs[1],
+                       (float)H0 / (float)hcs[0], 1.0f, keypoints0, keypoints1, w.win);
     hipMemcpyAsync(confidence, w.mconf, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, stream);
     hipMemcpyAsync(batch_indexes, w.mb, (size_t)cap * sizeof(int), hipMemcpyDeviceToDevice, stream);
     hipMemcpyAsync(num_matches, w.nmatch, sizeof(int), hipMemcpyDeviceToDevice, stream);

@@ -224,8 +224,8 @@ __device__ __forceinline__ float el_fine_sample(const float* __restrict__ P, int
 
 __global__ __launch_bounds__(256) void el_fine_kernel(const float* __restrict__ R, const int* __restrict__ mb,
                                                       const int* __restrict__ mi, const int* __restrict__ mj,
-                                                      const int* __restrict__ nmatch, int B, int H, int W, int wc,
-                                                      float scale_c, float scale_f, float* __restrict__ kp0,
+                                                      const int* __restrict__ nmatch, int B, int H0, int W0, int H1, int W1,
+                                                      int wc0, int wc1, float scale_c, float scale_f, float* __restrict__ kp0,
                                                       float* __restrict__ kp1, float* __restrict__ dbg_win) {
     extern __shared__ float el_sm[];
     float* F0 = el_sm;            // [64][65]  (row stride 65: conflict-free column walks)
@@ -241,34 +241,35 @@ __global__ __launch_bounds__(256) void el_fine_kernel(const float* __restrict__ 
     if (m >= *nmatch) return;
     const int tid = threadIdx.x;
     const int b = mb[m], ci = mi[m], cj = mj[m];
-    const int hh = H / 2, wh = W / 2;
-    const float* R0 = R + (size_t)b * hh * wh * 64;
-    const float* R1 = R + (size_t)(B + b) * hh * wh * 64;
-    const int y0 = (ci / wc) * 8, x0 = (ci % wc) * 8;
-    const int y1 = (cj / wc) * 8 - 1, x1 = (cj % wc) * 8 - 1;
+    // the B maps of image 1 follow the B maps of image 0 (sizes may differ per side)
+    const int hh0 = H0 / 2, wh0 = W0 / 2, hh1 = H1 / 2, wh1 = W1 / 2;
+    const float* R0 = R + (size_t)b * hh0 * wh0 * 64;
+    const float* R1 = R + ((size_t)B * hh0 * wh0 + (size_t)b * hh1 * wh1) * 64;
+    const int y0 = (ci / wc0) * 8, x0 = (ci % wc0) * 8;
+    const int y1 = (cj / wc1) * 8 - 1, x1 = (cj % wc1) * 8 - 1;
     // Both windows read the same 6 x 6 block geometry of the 1/2-resolution map: rows 4k - 1 .. 4k + 4 for full-resolution
     // rows 8k - 1 .. 8k + 8 (src = y / 2 - 0.25, two taps).  Stage the two blocks in LDS (aliasing S, which is not live
     // yet): 2 x 2304 loads instead of 4 taps x 164 positions x 64 channels from L2.
     float* P0 = S;
     float* P1 = S + 36 * 64;
-    const int oy0 = (ci / wc) * 4 - 1, ox0 = (ci % wc) * 4 - 1, oy1 = (cj / wc) * 4 - 1, ox1 = (cj % wc) * 4 - 1;
+    const int oy0 = (ci / wc0) * 4 - 1, ox0 = (ci % wc0) * 4 - 1, oy1 = (cj / wc1) * 4 - 1, ox1 = (cj % wc1) * 4 - 1;
     for (int i = tid; i < 36 * 64; i += 256) {
         const int p = i >> 6, c = i & 63;
         int gy = oy0 + p / 6, gx = ox0 + p % 6;
-        P0[i] = (gy >= 0 && gy < hh && gx >= 0 && gx < wh) ? R0[((size_t)gy * wh + gx) * 64 + c] : 0.0f;
+        P0[i] = (gy >= 0 && gy < hh0 && gx >= 0 && gx < wh0) ? R0[((size_t)gy * wh0 + gx) * 64 + c] : 0.0f;
         gy = oy1 + p / 6;
         gx = ox1 + p % 6;
-        P1[i] = (gy >= 0 && gy < hh && gx >= 0 && gx < wh) ? R1[((size_t)gy * wh + gx) * 64 + c] : 0.0f;
+        P1[i] = (gy >= 0 && gy < hh1 && gx >= 0 && gx < wh1) ? R1[((size_t)gy * wh1 + gx) * 64 + c] : 0.0f;
     }
     __syncthreads();
     for (int i = tid; i < 64 * 64; i += 256) {
         const int p = i >> 6, c = i & 63;
-        F0[p * 65 + c] = el_fine_sample(P0, oy0, ox0, hh, wh, y0 + (p >> 3), x0 + (p & 7), c);
+        F0[p * 65 + c] = el_fine_sample(P0, oy0, ox0, hh0, wh0, y0 + (p >> 3), x0 + (p & 7), c);
     }
     for (int i = tid; i < 100 * 64; i += 256) {
         const int p = i >> 6, c = i & 63;
         const int y = y1 + p / 10, x = x1 + p % 10;
-        F1[p * 65 + c] = (y >= 0 && y < H && x >= 0 && x < W) ? el_fine_sample(P1, oy1, ox1, hh, wh, y, x, c) : 0.0f;
+        F1[p * 65 + c] = (y >= 0 && y < H1 && x >= 0 && x < W1) ? el_fine_sample(P1, oy1, ox1, hh1, wh1, y, x, c) : 0.0f;
     }
     __syncthreads();
     if (dbg_win != nullptr) {  // parity hook: the unfolded windows [cap][64 + 100][64]
@@ -384,10 +385,10 @@ __global__ __launch_bounds__(256) void el_fine_kernel(const float* __restrict__ 
             ex += (float)(t % 3 - 1) * hv;
             ey += (float)(t / 3 - 1) * hv;
         }
-        kp0[2 * m + 0] = (float)(ci % wc) * scale_c + g0x * scale_f;
-        kp0[2 * m + 1] = (float)(ci / wc) * scale_c + g0y * scale_f;
-        kp1[2 * m + 0] = (float)(cj % wc) * scale_c + g1x * scale_f + ex * 1.0f * scale_f;
-        kp1[2 * m + 1] = (float)(cj / wc) * scale_c + g1y * scale_f + ey * 1.0f * scale_f;
+        kp0[2 * m + 0] = (float)(ci % wc0) * scale_c + g0x * scale_f;
+        kp0[2 * m + 1] = (float)(ci / wc0) * scale_c + g0y * scale_f;
+        kp1[2 * m + 0] = (float)(cj % wc1) * scale_c + g1x * scale_f + ex * 1.0f * scale_f;
+        kp1[2 * m + 1] = (float)(cj / wc1) * scale_c + g1y * scale_f + ey * 1.0f * scale_f;
     }
 }
 #define EL_FINE_SMEM ((64 * 65 + 100 * 65 + 6400 + 200 + 128) * sizeof(float))

@@ -576,29 +576,30 @@ class ELoFTRHIP:
         self.last_ws = None
 
     def forward(self, packed, image0, image1, match_threshold, debug_windows=False):
-        """Upstream EfficientLoFTR forward on image0 / image1 [B,1,H,W] (one size, multiples of 32); fixed-capacity
-        outputs + device match count."""
+        """Upstream EfficientLoFTR forward on image0 [B,1,H0,W0] / image1 [B,1,H1,W1] (multiples of 32; the two sizes may
+        differ); fixed-capacity outputs + device match count."""
         dev = image0.device
         hd = get_handle(dev)
         lib = hd.lib
         image0, image1 = image0.contiguous().float(), image1.contiguous().float()
-        B, Cc, H, W = image0.shape
-        if Cc != 1 or tuple(image1.shape) != (B, 1, H, W):
-            raise ImcuiHipError("EfficientLoFTR expects two batches of 1-channel images of one size")
-        cap = B * (H // 8) * (W // 8)
+        B, Cc, H0, W0 = image0.shape
+        B1, C1, H1, W1 = image1.shape
+        if Cc != 1 or C1 != 1 or B1 != B:
+            raise ImcuiHipError("EfficientLoFTR expects two batches of 1-channel images of equal batch size")
+        cap = B * (H0 // 8) * (W0 // 8)
         kp0 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
         kp1 = torch.empty((cap, 2), dtype=torch.float32, device=dev)
         conf = torch.empty((cap,), dtype=torch.float32, device=dev)
         bidx = torch.empty((cap,), dtype=torch.int32, device=dev)
         nm = torch.zeros((1,), dtype=torch.int32, device=dev)
         with self._lock:
-            ws = self._ws.get(lib.imcui_hip_eloftr_workspace_bytes(B, H, W, int(bool(debug_windows))), dev)
+            ws = self._ws.get(lib.imcui_hip_eloftr_workspace_bytes(B, H0, W0, H1, W1, int(bool(debug_windows))), dev)
             self.last_ws = ws
-            self.last_dims = (B, H, W)
+            self.last_dims = (B, H0, W0, H1, W1)
             with torch.cuda.device(dev):
                 rc = lib.imcui_hip_eloftr_forward(
-                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H, W, float(match_threshold), _ptr(kp0), _ptr(kp1), _ptr(conf),
-                    _ptr(bidx), _ptr(nm), int(bool(debug_windows)), _ptr(ws), ws.numel(), _stream_ptr(),
+                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H0, W0, H1, W1, float(match_threshold), _ptr(kp0), _ptr(kp1),
+                    _ptr(conf), _ptr(bidx), _ptr(nm), int(bool(debug_windows)), _ptr(ws), ws.numel(), _stream_ptr(),
                 )  # fmt: skip
                 hd.check(rc, "imcui_hip_eloftr_forward")
         return {"keypoints0": kp0, "keypoints1": kp1, "confidence": conf, "batch_indexes": bidx, "num_matches": nm}

@@ -12,6 +12,8 @@ The upstream `eloftr_outdoor.ckpt` the reference downloads stores the same tenso
 sources are an un-vendored submodule, absent from the reference tree, so the name mapping cannot be verified here): such
 a checkpoint is refused with a clear message rather than mapped by guesswork -- convert it once with the port.
 
+Image pairs whose two images differ in size are accepted (the batch path of `match_dense.py` produces them).
+
 `model_type: "opt"` and `precision: "mp" / "fp16"` (eloftr.py:39-47) are speed variants of the same network for CUDA
 hosts; the HIP path always computes the 'full' network with fp32-grade arithmetic and rejects other settings loudly.
 """

@@ -219,20 +219,21 @@ int imcui_hip_eloftr_num_layers(void);
 int imcui_hip_eloftr_layer_shape(int i, int* N, int* K);
 int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* conv0_b, const float* const* w, const float* const* b,
                                   const float* const* dw, const float* const* norms, const float* inv_freq, float* packed);
-size_t imcui_hip_eloftr_workspace_bytes(int B, int H, int W, int debug_windows);
-/* Upstream LoFTR.forward on B pairs of images [dev, B,1,H,W] of ONE size (H, W multiples of 32, >= 64; the wrapper's
- * preprocessing resizes both images to width x height, configs/matchers.py:296-303).  Outputs with capacity
- * B*(H/8)*(W/8) rows, first num_matches[0] valid, ordered batch-major by the coarse cell of image0: keypoints0/1
+size_t imcui_hip_eloftr_workspace_bytes(int B, int H0, int W0, int H1, int W1, int debug_windows);
+/* Upstream LoFTR.forward on B pairs: image0 [dev, B,1,H0,W0], image1 [dev, B,1,H1,W1] (multiples of 32, >= 64; the UI path
+ * resizes both images to width x height, configs/matchers.py:296-303, the batch path of match_dense.py does not, so the two
+ * sizes may differ: the backbone then runs side by side and the attention is between token sets of different length).
+ * Outputs with capacity B*(H0/8)*(W0/8) rows, first num_matches[0] valid, ordered batch-major by the coarse cell of image0: keypoints0/1
  * [dev, cap,2] pixel (x,y) after the two-stage fine refinement, confidence [dev, cap], batch_indexes [dev, cap] int32,
  * num_matches [dev, 1] int32.  match_threshold = conf["match_threshold"] (eloftr.py:54).  debug_windows != 0 also
  * writes the unfolded fine windows to the workspace (parity tests; size it with the same flag). */
-int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H, int W,
-                             double match_threshold, float* keypoints0, float* keypoints1, float* confidence,
+int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0, int W0,
+                             int H1, int W1, double match_threshold, float* keypoints0, float* keypoints1, float* confidence,
                              int* batch_indexes, int* num_matches, int debug_windows, void* ws, size_t ws_bytes, void* stream);
-/* byte offset inside the workspace of: 0 backbone 1/2 features [2B,H/2,W/2,64] (images 0 first), 1 1/4 features
- * [2B,H/4,W/4,128], 2 coarse features after the transformer [2B,L,256], 3 sim [B,L,L], 4 fused 1/2-resolution fine map
- * [2B,H/2,W/2,64], 5 fine windows [B*L][64 + 100][64] (debug_windows)  (parity tests) */
-size_t imcui_hip_eloftr_debug_offset(int which, int B, int H, int W);
+/* byte offset inside the workspace of (per-image buffers: the B maps of image 0, then the B maps of image 1): 0 backbone 1/2
+ * features [.,H/2,W/2,64], 1 1/4 features [.,H/4,W/4,128], 2 coarse features after the transformer [.,L,256], 3 sim [B,L0,L1],
+ * 4 fused 1/2-resolution fine map [.,H/2,W/2,64], 5 fine windows [B*L0][64 + 100][64] (debug_windows)  (parity tests) */
+size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);
 
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);

@@ -120,14 +120,14 @@ class ELoFTROracle:
         return x + t.permute(0, 3, 1, 2)
 
     def transformer(self, f0, f1):
-        """f0, f1 [B,256,h,w] -> transformed.  Self attention with the rotary embedding; cross attention without;
-        image 1 attends to the UPDATED image 0 (upstream behaviour the port keeps, see its layer forward)."""
-        h, w = f0.shape[2:]
-        rope = self.rope((h - AGG) // AGG + 1, (w - AGG) // AGG + 1)
+        """f0 [B,256,h0,w0], f1 [B,256,h1,w1] -> transformed.  Self attention with the rotary embedding of the map's own
+        aggregated grid; cross attention without; image 1 attends to the UPDATED image 0 (upstream behaviour the port
+        keeps, see its layer forward).  The two maps may differ in size (the attention is between token sets)."""
+        ropes = [self.rope((f.shape[2] - AGG) // AGG + 1, (f.shape[3] - AGG) // AGG + 1) for f in (f0, f1)]
         for i in range(4):
             p = f"{P}local_feature_transformer.layers.{i}"
-            f0 = self._agg_attention(p + ".self_attention", f0, f0, rope)
-            f1 = self._agg_attention(p + ".self_attention", f1, f1, rope)
+            f0 = self._agg_attention(p + ".self_attention", f0, f0, ropes[0])
+            f1 = self._agg_attention(p + ".self_attention", f1, f1, ropes[1])
             f0 = self._agg_attention(p + ".cross_attention", f0, f1, None)
             f1 = self._agg_attention(p + ".cross_attention", f1, f0, None)
         return f0, f1
@@ -135,11 +135,12 @@ class ELoFTROracle:
     # -- coarse matching (dual soft-max, upstream match-list order) ---------------------------------------------------
     def coarse_matching(self, fc0, fc1, hw_i, thr):
         n, c, h, w = fc0.shape
+        h1, w1 = fc1.shape[2:]
         f0 = fc0.permute(0, 2, 3, 1).reshape(n, h * w, c) / c**0.5
-        f1 = fc1.permute(0, 2, 3, 1).reshape(n, h * w, c) / c**0.5
+        f1 = fc1.permute(0, 2, 3, 1).reshape(n, h1 * w1, c) / c**0.5
         sim = f0 @ f1.transpose(-1, -2) / self.temperature
         conf = F.softmax(sim, 1) * F.softmax(sim, 2)
-        mask = (conf > thr).view(n, h, w, h, w).clone()
+        mask = (conf > thr).view(n, h, w, h1, w1).clone()
         b = self.border_rm
         mask[:, :b] = False
         mask[:, :, :b] = False
@@ -149,14 +150,14 @@ class ELoFTROracle:
         mask[:, :, -b:] = False
         mask[:, :, :, -b:] = False
         mask[:, :, :, :, -b:] = False
-        mask = mask.view(n, h * w, h * w)
+        mask = mask.view(n, h * w, h1 * w1)
         mask = mask * (conf == conf.max(dim=2, keepdim=True)[0]) * (conf == conf.max(dim=1, keepdim=True)[0])
         mask_v, all_j = mask.max(dim=2)
         b_ids, i_ids = torch.where(mask_v)
         j_ids = all_j[b_ids, i_ids]
-        scale = hw_i[0] / h
+        scale = hw_i[0] / h  # as in LoFTR: the scale of image 0 for both key-point sets (8 either way)
         mk0 = torch.stack([i_ids % w, torch.div(i_ids, w, rounding_mode="trunc")], 1) * scale
-        mk1 = torch.stack([j_ids % w, torch.div(j_ids, w, rounding_mode="trunc")], 1) * scale
+        mk1 = torch.stack([j_ids % w1, torch.div(j_ids, w1, rounding_mode="trunc")], 1) * scale
         return dict(b_ids=b_ids, i_ids=i_ids, j_ids=j_ids, mconf=conf[b_ids, i_ids, j_ids], mkpts0_c=mk0, mkpts1_c=mk1, conf_matrix=conf)
 
     # -- fine feature fusion: 1/8 -> 1/4 -> 1/2 -> 1/1, 64 channels ------------------------------------------------------
@@ -184,7 +185,7 @@ class ELoFTROracle:
         u1 = F.unfold(ff1, FINE_W + 2, stride=stride, padding=1)
         n, _, l = u0.shape
         u0 = u0.view(n, c, FINE_W**2, l).permute(0, 3, 2, 1)[b, i]           # [M, 64, C]
-        u1 = u1.view(n, c, (FINE_W + 2) ** 2, l).permute(0, 3, 2, 1)[b, j]   # [M, 100, C]
+        u1 = u1.view(n, c, (FINE_W + 2) ** 2, u1.shape[2]).permute(0, 3, 2, 1)[b, j]   # [M, 100, C]
         return u0, u1
 
     @staticmethod
@@ -227,17 +228,24 @@ class ELoFTROracle:
     def net(self, image0, image1, return_intermediates=False):
         bs = image0.shape[0]
         hw_i = image0.shape[2:]
-        assert image1.shape == image0.shape, "the aggregated transformer and RoPE grid are built for equal sizes"
-        x1, x2, x3 = self.backbone(torch.cat([image0, image1], 0))
-        f0, f1 = self.transformer(x3[:bs], x3[bs:])
+        if image1.shape == image0.shape:
+            x1, x2, x3 = self.backbone(torch.cat([image0, image1], 0))
+            x1, x2, x3 = (x1[:bs], x1[bs:]), (x2[:bs], x2[bs:]), (x3[:bs], x3[bs:])
+        else:  # images of different sizes go through the backbone one after the other (upstream LoFTR.forward does the same)
+            a, b = self.backbone(image0), self.backbone(image1)
+            x1, x2, x3 = (a[0], b[0]), (a[1], b[1]), (a[2], b[2])
+        f0, f1 = self.transformer(x3[0], x3[1])
         cm = self.coarse_matching(f0, f1, hw_i, self.conf["match_threshold"])
-        ff = self.fine_features(torch.cat([f0, f1], 0) / 256**0.5, x2, x1)
-        u0, u1 = self.fine_windows(ff[:bs], ff[bs:], cm, ff.shape[2] // f0.shape[2])
-        mk0, mk1 = self.fine_matching(u0, u1, cm, hw_i[0] / ff.shape[2])
+        ff0 = self.fine_features(f0 / 256**0.5, x2[0], x1[0])
+        half0 = self._last_pre_upsample
+        ff1 = self.fine_features(f1 / 256**0.5, x2[1], x1[1])
+        half1 = self._last_pre_upsample
+        u0, u1 = self.fine_windows(ff0, ff1, cm, ff0.shape[2] // f0.shape[2])
+        mk0, mk1 = self.fine_matching(u0, u1, cm, hw_i[0] / ff0.shape[2])
         out = {"keypoints0": mk0, "keypoints1": mk1, "confidence": cm["mconf"], "batch_indexes": cm["b_ids"]}
         if return_intermediates:
             out.update(_x1=x1, _x2=x2, _x3=x3, _feat_c0=f0, _feat_c1=f1, _conf=cm["conf_matrix"], _i_ids=cm["i_ids"], _j_ids=cm["j_ids"],
-                       _fine=ff, _fine_half=self._last_pre_upsample, _win0=u0, _win1=u1, _mkpts0_c=cm["mkpts0_c"], _mkpts1_c=cm["mkpts1_c"])  # fmt: skip
+                       _fine=(ff0, ff1), _fine_half=(half0, half1), _win0=u0, _win1=u1, _mkpts0_c=cm["mkpts0_c"], _mkpts1_c=cm["mkpts1_c"])  # fmt: skip
         return out
 
     # -- the reference wrapper (imcui/hloc/matchers/eloftr.py:68-104) --------------------------------------------------

@@ -20,19 +20,21 @@ SD = eloftr_state_dict(0)
 SD_RAW = eloftr_state_dict(5, gain=1.0, shaped=False)  # every attention block at full strength, no hand shaping
 
 
-def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24, -16))):
+def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24, -16)), hw1=None):
+    """`hw1`: size of the second image when it differs from (h, w) (a crop of the shifted view)."""
     from imcui_hip.hloc.matchers.eloftr import ELoFTR
 
     torch.set_num_threads(16)
-    pairs = [make_shifted_pair(11 + b, h, w, shifts[b % len(shifts)], n_blobs=max(300, h * w // 130)) for b in range(B)]
-    img0 = torch.cat([p[0] for p in pairs], 0).contiguous()
-    img1 = torch.cat([p[1] for p in pairs], 0).contiguous()
+    h1, w1 = hw1 if hw1 is not None else (h, w)
+    pairs = [make_shifted_pair(11 + b, max(h, h1), max(w, w1), shifts[b % len(shifts)], n_blobs=max(300, h * w // 130)) for b in range(B)]
+    img0 = torch.cat([p[0][..., :h, :w] for p in pairs], 0).contiguous()
+    img1 = torch.cat([p[1][..., :h1, :w1] for p in pairs], 0).contiguous()
     model = ELoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to("cuda:0")
     out = model.forward_batched(img0.cuda(), img1.cuda(), debug_windows=True)
     torch.cuda.synchronize()
     n = int(out["num_matches"][0])
     hc, wc = h // 8, w // 8
-    L = hc * wc
+    L, S = hc * wc, (h1 // 8) * (w1 // 8)
     ref = ELoFTROracle(sd, {"match_threshold": thr, "max_keypoints": None}).net(img0, img1, return_intermediates=True)
     dbg = model._impl.debug_buffer
 
@@ -40,12 +42,15 @@ def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24,
         err = (got - want).abs().max().item()
         assert err < tol * want.abs().max().item(), f"{name}: {err:.3e} vs magnitude {want.abs().max().item():.3e}"
 
-    # intermediates (NHWC on the device; images 0 of the batch first, then images 1)
-    close("1/2 backbone features", dbg(0, (2 * B, h // 2, w // 2, 64)).cpu(), ref["_x1"].permute(0, 2, 3, 1))
-    close("1/4 backbone features", dbg(1, (2 * B, h // 4, w // 4, 128)).cpu(), ref["_x2"].permute(0, 2, 3, 1))
-    fc_ref = torch.cat([ref["_feat_c0"], ref["_feat_c1"]], 0).permute(0, 2, 3, 1).reshape(2 * B, L, 256)
-    close("coarse features after the transformer", dbg(2, (2 * B, L, 256)).cpu(), fc_ref)
-    close("fused 1/2-resolution fine map", dbg(4, (2 * B, h // 2, w // 2, 64)).cpu(), ref["_fine_half"].permute(0, 2, 3, 1))
+    def sides(t):  # oracle (side 0, side 1) maps [B,C,h,w] -> one flat NHWC buffer, side 0 first (the device layout)
+        return torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in t], 0)
+
+    # intermediates (NHWC on the device; the B maps of image 0 first, then the B maps of image 1)
+    close("1/2 backbone features", dbg(0, (B * (h * w + h1 * w1) // 4 * 64,)).cpu(), sides(ref["_x1"]))
+    close("1/4 backbone features", dbg(1, (B * (h * w + h1 * w1) // 16 * 128,)).cpu(), sides(ref["_x2"]))
+    fc_ref = sides((ref["_feat_c0"], ref["_feat_c1"])).view(B * (L + S), 256)
+    close("coarse features after the transformer", dbg(2, (B * (L + S), 256)).cpu(), fc_ref)
+    close("fused 1/2-resolution fine map", dbg(4, (B * (h * w + h1 * w1) // 4 * 64,)).cpu(), sides(ref["_fine_half"]))
     # coarse match list
     conf = ref["_conf"]
     got = list(zip(out["batch_indexes"][:n].cpu().tolist(),
@@ -67,7 +72,7 @@ def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24,
     assert len(common) >= 0.99 * len(want)
     # conf = exp(sim - lse_row) * exp(sim - lse_col): an f32 rounding of the features moves sim by |sim| * 2^-23 or so and the
     # confidence by about twice that, relatively -- the shaped weights push |sim| to ~130 (real checkpoints: tens)
-    sim_max = (fc_ref[:B] * fc_ref[B:]).sum(-1).abs().max().item() / 25.6
+    sim_max = (ref["_feat_c0"].flatten(2).transpose(1, 2) @ ref["_feat_c1"].flatten(2)).abs().max().item() / 25.6
     assert (out["confidence"][:n].cpu()[g_idx] - ref["confidence"][w_idx]).abs().max().item() < 1e-4 * max(1.0, sim_max / 40.0), sim_max
     # fine windows of the common matches (debug buffer is indexed by the device's match order)
     win = dbg(5, (B * L, 164, 64))[:n].cpu()[g_idx]
@@ -93,6 +98,14 @@ def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24,
 def test_eloftr_vs_oracle(h, w, B, precision):
     n = _case(h, w, B, SD, 0.2, 100 if h < 200 else 1000)
     print(f"ELoFTR {w}x{h} B={B}: {n} matches")
+
+
+def test_eloftr_images_of_different_sizes():
+    """The batch path of match_dense.py preprocesses every image on its own (resize_max + dfactor), so the two images of a
+    pair need not have one size: the backbone then runs side by side and attention is between token sets of different length."""
+    n = _case(192, 256, 2, SD, 0.2, 60, hw1=(160, 224))
+    m = _case(160, 224, 1, SD, 0.2, 60, hw1=(224, 288))
+    print(f"ELoFTR unequal sizes: {n} / {m} matches")
 
 
 def test_eloftr_unshaped_weights():

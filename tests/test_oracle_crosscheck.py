@@ -255,7 +255,7 @@ def test_eloftr_oracle_vs_hf_port():
     with torch.no_grad():
         bo = hf.efficientloftr(x)
         fc = bo.feature_maps[0]
-        assert torch.equal(bo.feature_maps[1], out["_x1"]) and torch.equal(bo.feature_maps[2], out["_x2"])
+        assert torch.equal(bo.feature_maps[1], torch.cat(out["_x1"], 0)) and torch.equal(bo.feature_maps[2], torch.cat(out["_x2"], 0))
         scale = fc.abs().max().item()
         assert (fc[:, 0] - out["_feat_c0"]).abs().max().item() < 2e-5 * scale
         assert (fc[:, 1] - out["_feat_c1"]).abs().max().item() < 2e-5 * scale
@@ -264,14 +264,18 @@ def test_eloftr_oracle_vs_hf_port():
         assert torch.equal(rows, out["_i_ids"]) and torch.equal(mi[0, 1][rows], out["_j_ids"])
         assert (sc[0, 1][rows] - out["confidence"]).abs().max().item() < 1e-4
         f0, f1 = hf.refinement_layer(fc / 16.0, bo.feature_maps[1:])
-    ff = out["_fine"]
-    u0 = F.unfold(ff[:1], 8, stride=8).view(1, 64, 64, -1).permute(0, 3, 2, 1)
-    u1 = F.unfold(ff[1:], 10, stride=8, padding=1).view(1, 64, 100, -1).permute(0, 3, 2, 1)
+    ff0, ff1 = out["_fine"]
+    u0 = F.unfold(ff0, 8, stride=8).view(1, 64, 64, -1).permute(0, 3, 2, 1)
+    u1 = F.unfold(ff1, 10, stride=8, padding=1).view(1, 64, 100, -1).permute(0, 3, 2, 1)
     fs = f0.abs().max().item()
     assert (u0 - f0).abs().max().item() < 2e-5 * fs and (u1 - f1).abs().max().item() < 2e-5 * fs
     # geometry: the matches agree with the known translation (fine stage included)
     e = (out["keypoints0"] - out["keypoints1"] - torch.tensor([16.0, 8.0])).norm(dim=1)
     assert (e < 2).float().mean().item() > 0.9
+    # images of different sizes: a narrower second image (a crop of the same scene) still matches cell to cell
+    out2 = ELoFTROracle(sd).net(i0, i1[..., :128, :192].contiguous(), True)
+    e2 = (out2["keypoints0"] - out2["keypoints1"] - torch.tensor([16.0, 8.0])).norm(dim=1)
+    assert len(e2) > 50 and (e2 < 2).float().mean().item() > 0.8
 
 
 def test_eloftr_reparameterisation_and_packing():
