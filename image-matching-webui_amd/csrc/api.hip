@@ -189,7 +189,6 @@ extern "C" int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const flo
                                        const float* beta, const unsigned short* w2h, const unsigned short* w2l, const float* s2,
                                        const float* b2, float* out, int M, int act, void* stream) {
     if (!h) return IMCUI_ERR_ARG;
-    if (M % 128 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: M=%d must be a multiple of 128", M);
     FfnP p;
     p.x = x;
     p.ctx = ctx;

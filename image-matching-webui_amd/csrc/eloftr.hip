@@ -17,9 +17,11 @@
 //              on the 8x8 / 10x10 windows of the matches, inside the two-stage fine matching kernel.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "eloftr_kernels.h"
+#include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
 #include "loftr_kernels.h"
@@ -60,6 +62,7 @@ struct ElLayout {
     size_t conv0_w, conv0_b;  // [9][64], [64]
     size_t w[EL_NLAYERS], b[EL_NLAYERS], wh[EL_NLAYERS], wl[EL_NLAYERS], ws[EL_NLAYERS];
     size_t dw[8];             // depth-wise query aggregation [256][16]
+    size_t wph[8], wpl[8], wps[8];  // mlp.fc2 planes with the K axis in the fused FFN kernel's order (ffn_permute_k)
     size_t norm[EL_NNORMS];
     size_t inv_freq;          // [64] rotary frequencies
     size_t total;
@@ -85,6 +88,11 @@ static ElLayout el_layout() {
         l.ws[i] = take(64);
     }
     for (int i = 0; i < 8; ++i) l.dw[i] = take(256 * 16);
+    for (int i = 0; i < 8; ++i) {
+        l.wph[i] = take(256 * 512 / 2);
+        l.wpl[i] = take(256 * 512 / 2);
+        l.wps[i] = take(64);
+    }
     for (int i = 0; i < EL_NNORMS; ++i) l.norm[i] = take(256);
     l.inv_freq = take(64);
     l.total = off;
@@ -115,10 +123,19 @@ extern "C" int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* 
         packed[l.ws[i]] = split_weights_frag_host(w[i], N, K, reinterpret_cast<unsigned short*>(packed + l.wh[i]),
                                                   reinterpret_cast<unsigned short*>(packed + l.wl[i]));
     }
+    float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));
+    if (!perm) return IMCUI_ERR_ARG;
     for (int i = 0; i < 8; ++i) {
-        if (!dw[i]) return IMCUI_ERR_ARG;
+        if (!dw[i]) {
+            free(perm);
+            return IMCUI_ERR_ARG;
+        }
         memcpy(packed + l.dw[i], dw[i], 256 * 16 * sizeof(float));
+        ffn_permute_k(w[EL_TR0 + i * 6 + 5], 256, 512, perm);
+        packed[l.wps[i]] = split_weights_frag_host(perm, 256, 512, reinterpret_cast<unsigned short*>(packed + l.wph[i]),
+                                                   reinterpret_cast<unsigned short*>(packed + l.wpl[i]));
     }
+    free(perm);
     for (int i = 0; i < EL_NNORMS; ++i) {
         if (!norms[i]) return IMCUI_ERR_ARG;
         memcpy(packed + l.norm[i], norms[i], 256 * sizeof(float));
@@ -346,6 +363,7 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         return gemm_launch(h, g, stream);
     };
     const size_t tok1 = (size_t)B * L;  // first token row of side 1
+    static const bool mlp_unfused = getenv("IMCUI_LG_FFN_UNFUSED") != nullptr;  // A/B switch shared with lightglue.hip
     // block t: `ns` maps of side qs (first token row qt, grid hq x wq) attend to `ns` maps of side ss (first token row st)
     auto block = [&](int t, size_t qt, int qs, size_t st, int ss, int ns, bool rope) -> int {
         const int base = EL_TR0 + t * 6;
@@ -370,6 +388,23 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         const long n4 = (long)ns * Lq * 64;
         hipLaunchKernelGGL(el_upsample_kernel, dim3((unsigned)min((n4 + 255) / 256, (long)65536)), blk, 0, stream, w.o, w.up, ahs[qs], aws[qs], 256, 4, n4);
         const long trows = (long)ns * Lq;
+        if (split && !mlp_unfused) {  // x += LayerNorm(fc2(leaky_relu(fc1([x | up])))) in one kernel (ffn.hip)
+            FfnP f;
+            f.act = 2;
+            f.x = x;
+            f.ctx = w.up;
+            f.out = x;
+            f.w1h = reinterpret_cast<const unsigned short*>(P + l.wh[base + 4]);
+            f.w1l = reinterpret_cast<const unsigned short*>(P + l.wl[base + 4]);
+            f.s1 = P + l.ws[base + 4];
+            f.w2h = reinterpret_cast<const unsigned short*>(P + l.wph[t]);
+            f.w2l = reinterpret_cast<const unsigned short*>(P + l.wpl[t]);
+            f.s2 = P + l.wps[t];
+            f.gamma = P + l.norm[4 * t + 2];
+            f.beta = P + l.norm[4 * t + 3];
+            f.M = (int)trows;
+            return ffn_launch(h, f, stream);
+        }
         if ((r = lin(base + 4, x, 256, w.up, w.hb, trows, 2))) return r;  // LeakyReLU(0.01)
         if ((r = lin(base + 5, w.hb, 512, nullptr, w.ob, trows, 0))) return r;
         hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)min((trows + 3) / 4, (long)65536)), blk, 0, stream, w.ob, P + l.norm[4 * t + 2],

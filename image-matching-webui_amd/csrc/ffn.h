@@ -1,6 +1,7 @@
 // Fused transformer FFN of the LightGlue / SuperGlue blocks (3 x f16 split mode):
 //   x <- x + W2 * GELU(LayerNorm(W1 * [x | ctx] + b1)) + b2          (512 hidden features, 256-wide residual stream)
 //   x <- x + W2 * ReLU(W1 * [x | ctx] + b1) + b2                     (act = 1: SuperGlue's MLP, BatchNorm folded)
+//   x <- x + LayerNorm(W2 * act(W1 * [x | ctx]))                    (act = 2 / 3: the dense matchers' MLPs)
 // one kernel per block instead of GEMM -> LayerNorm/GELU -> GEMM: the 512-wide hidden row never leaves the CU.
 #pragma once
 #include "common.h"
@@ -15,7 +16,10 @@ struct FfnP {
     const float *s1 = nullptr, *s2 = nullptr;  // 2^-e scales of the planes (device)
     const float *b1 = nullptr, *gamma = nullptr, *beta = nullptr;  // [512]
     const float* b2 = nullptr;                                     // [256]
-    int act = 0;  // 0: LayerNorm + GELU between the GEMMs (LightGlue); 1: ReLU only (SuperGlue, BatchNorm folded into W1)
+    // 0: LayerNorm(512) + GELU between the GEMMs (LightGlue); 1: ReLU (SuperGlue, BatchNorm folded into W1);
+    // 2 / 3: LeakyReLU(0.01) / ReLU between the GEMMs and LayerNorm(256) (gamma, beta [256]) after the second, before the
+    // residual (EfficientLoFTR / LoFTR coarse MLPs: x + LN(fc2(act(fc1([x | message])))), no biases: b1 = b2 = nullptr)
+    int act = 0;
     int M = 0;
     // ragged sequences, as in GemmP: a 128-row tile whose first row is >= cnt[seq] or whose pair is inactive is skipped
     const int* cnt = nullptr;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + 64 * wid + 32 * n + 8 * q + 4 * hi);
+            const float4 b4 = p.b1 ? *reinterpret_cast<const float4*>(p.b1 + 64 * wid + 32 * n + 8 * q + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 acc[n][m][4 * q + 0] = acc[n][m][4 * q + 0] * s1 + b4.x;
@@ -252,13 +252,17 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             __builtin_amdgcn_sched_barrier(0);  // 16 GELU chains in flight are enough; more only costs registers
         }
     } else {
-        // SuperGlue's MLP: BatchNorm is folded into W1 / b1 at pack time, the activation is ReLU
+        // ACT 1: SuperGlue's MLP (BatchNorm folded into W1 / b1 at pack time), ReLU.  ACT 2 / 3: the dense matchers' MLPs,
+        // LeakyReLU(0.01) (EfficientLoFTR) / ReLU (LoFTR) here and a LayerNorm AFTER the second GEMM (store phase below)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][m][r] = fmaxf(acc[n][m][r], 0.0f);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[n][m][r];
+                    acc[n][m][r] = (ACT == 2) ? (v > 0.0f ? v : 0.01f * v) : fmaxf(v, 0.0f);
+                }
     }
 
     FFN_STAMP(2)
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * wid2 + 8 * q + 4 * hi2;
-        const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + f0);
+        const float4 b4 = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float4 v;
@@ -365,8 +369,17 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     for (int pass = 0; pass < 16; ++pass) {
         const int row = pass * 8 + wid2;
         const int gr = row0 + row;
-        if (gr < p.M) {
-            const float4 v = *reinterpret_cast<const float4*>(Y + row * FFN_YLD + lane2 * 4);
+        if (gr < p.M) {  // wave-uniform: a wave owns the whole row
+            float4 v = *reinterpret_cast<const float4*>(Y + row * FFN_YLD + lane2 * 4);
+            if constexpr (ACT >= 2) {
+                // LayerNorm(256) of the MLP output before the residual, a row per wave, 4 values per lane: the arithmetic of
+                // lf_layernorm_kernel<4> (mean, centred sum of squares, 1 / sqrt(var + 1e-5))
+                const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+                v.x -= mean, v.y -= mean, v.z -= mean, v.w -= mean;
+                const float rstd = 1.0f / sqrtf(wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.0f / 256.0f) + 1e-5f);
+                const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + lane2 * 4), e4 = *reinterpret_cast<const float4*>(p.beta + lane2 * 4);
+                v = make_float4(v.x * rstd * g4.x + e4.x, v.y * rstd * g4.y + e4.y, v.z * rstd * g4.z + e4.z, v.w * rstd * g4.w + e4.w);
+            }
             *reinterpret_cast<float4*>(p.out + (size_t)gr * 256 + lane2 * 4) = make_float4(v.x + res[pass].x, v.y + res[pass].y, v.z + res[pass].z, v.w + res[pass].w);
         }
     }
@@ -376,17 +389,18 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
 
 int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "ffn: the fused kernel is the 3 x f16 split path (precision 1)");
-    if (!p.x || !p.ctx || !p.out || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.s1 || !p.s2 || !p.b1 || !p.b2 ||
-        (p.act == 0 && (!p.gamma || !p.beta)))
+    if (!p.x || !p.ctx || !p.out || !p.w1h || !p.w1l || !p.w2h || !p.w2l || !p.s1 || !p.s2 || (p.act != 1 && (!p.gamma || !p.beta)))
         return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: null argument");
+    if (p.act < 0 || p.act > 3) return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: act=%d (0 LN+GELU, 1 ReLU, 2 LeakyReLU + post-LN, 3 ReLU + post-LN)", p.act);
     if (p.rows_per_seq > 0 && p.rows_per_seq % 128 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "ffn: rows_per_seq=%d must be a multiple of 128", p.rows_per_seq);
     if (p.M <= 0) return IMCUI_OK;
     static const int variant = getenv("IMCUI_FFN_VARIANT") ? atoi(getenv("IMCUI_FFN_VARIANT")) : 1;
     typedef void (*kern_t)(FfnP);
-    static const kern_t kerns[2][2] = {{lg_ffn_kernel<0, 0>, lg_ffn_kernel<0, 1>}, {lg_ffn_kernel<1, 0>, lg_ffn_kernel<1, 1>}};
-    static bool attr_set[2][2] = {{false, false}, {false, false}};  // > 64 KB of dynamic LDS needs the opt-in
-    const int v = variant != 0, a = p.act != 0;
+    static const kern_t kerns[2][4] = {{lg_ffn_kernel<0, 0>, lg_ffn_kernel<0, 1>, lg_ffn_kernel<0, 2>, lg_ffn_kernel<0, 3>},
+                                       {lg_ffn_kernel<1, 0>, lg_ffn_kernel<1, 1>, lg_ffn_kernel<1, 2>, lg_ffn_kernel<1, 3>}};
+    static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};  // > 64 KB of dynamic LDS needs the opt-in
+    const int v = variant != 0, a = p.act;
     if (!attr_set[v][a]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v][a]), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
             return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);

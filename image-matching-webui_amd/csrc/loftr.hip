@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
 #include "loftr_kernels.h"
@@ -60,6 +61,7 @@ struct LfLayout {
     size_t conv1_w, conv1_b;  // [49][128], [128]
     size_t w[LF_NLAYERS], b[LF_NLAYERS], wh[LF_NLAYERS], wl[LF_NLAYERS], ws[LF_NLAYERS];
     size_t norm[LF_NNORMS];
+    size_t wph[8], wpl[8], wps[8];  // coarse mlp.2 planes with the K axis in the fused FFN kernel's order (ffn_permute_k)
     size_t total;
 };
 static LfLayout lf_layout() {
@@ -82,6 +84,11 @@ static LfLayout lf_layout() {
         l.ws[i] = take(64);
     }
     for (int i = 0; i < LF_NNORMS; ++i) l.norm[i] = take(lf_norm_dim(i));
+    for (int i = 0; i < 8; ++i) {
+        l.wph[i] = take(256 * 512 / 2);
+        l.wpl[i] = take(256 * 512 / 2);
+        l.wps[i] = take(64);
+    }
     l.total = off;
     return l;
 }
@@ -118,6 +125,14 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
         if (!norms[i]) return IMCUI_ERR_ARG;
         memcpy(packed + l.norm[i], norms[i], lf_norm_dim(i) * sizeof(float));
     }
+    float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));
+    if (!perm) return IMCUI_ERR_ARG;
+    for (int i = 0; i < 8; ++i) {
+        ffn_permute_k(w[LF_COARSE0 + i * 6 + 5], 256, 512, perm);
+        packed[l.wps[i]] = split_weights_frag_host(perm, 256, 512, reinterpret_cast<unsigned short*>(packed + l.wph[i]),
+                                                   reinterpret_cast<unsigned short*>(packed + l.wpl[i]));
+    }
+    free(perm);
     return IMCUI_OK;
 }
 
@@ -382,6 +397,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         return gemm_launch(h, g, stream);
     };
     const int nchunk_max = cdiv(L > S ? L : S, LA_CHUNK);
+    static const bool mlp_unfused = getenv("IMCUI_LG_FFN_UNFUSED") != nullptr;  // A/B switch shared with lightglue.hip
     // encoder layer: `ns` query sequences of Lq tokens starting at token row qt attend to `ns` source sequences of Lsrc
     // tokens starting at token row st; kvslot = first K'V slot (sequence index) used for the sources
     auto coarse_layer = [&](int layer, size_t qt, size_t st, int ns, int Lq, int Lsrc, int kvslot) -> int {
@@ -404,6 +420,23 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         const float* n1w = P + l.norm[layer * 4 + 0];
         hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, w.m + qo, n1w,
                            P + l.norm[layer * 4 + 1], (const float*)nullptr, w.m + qo, qrows, 0);
+        if (split && !mlp_unfused) {  // x += norm2(mlp.2(relu(mlp.0([x | message])))) in one kernel (ffn.hip)
+            FfnP f;
+            f.act = 3;
+            f.x = w.fc + qo;
+            f.ctx = w.m + qo;
+            f.out = w.fc + qo;
+            f.w1h = reinterpret_cast<const unsigned short*>(P + l.wh[base + 4]);
+            f.w1l = reinterpret_cast<const unsigned short*>(P + l.wl[base + 4]);
+            f.s1 = P + l.ws[base + 4];
+            f.w2h = reinterpret_cast<const unsigned short*>(P + l.wph[layer]);
+            f.w2l = reinterpret_cast<const unsigned short*>(P + l.wpl[layer]);
+            f.s2 = P + l.wps[layer];
+            f.gamma = P + l.norm[layer * 4 + 2];
+            f.beta = P + l.norm[layer * 4 + 3];
+            f.M = (int)qrows;
+            return ffn_launch(h, f, stream);
+        }
         if ((r = lin(base + 4, w.fc + qo, 256, w.m + qo, w.hb + qt * 512, qrows, 1, nullptr))) return r;
         if ((r = lin(base + 5, w.hb + qt * 512, 512, nullptr, w.ob + qo, qrows, 0, nullptr))) return r;
         hipLaunchKernelGGL(lf_layernorm_kernel<4>, dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, stream, w.ob + qo,

@@ -828,10 +828,11 @@ def pack_ffn_w2(w2: torch.Tensor):
 
 class FusedFFN:
     """Building block: x + W2 GELU(LN(W1 [x | ctx] + b1)) + b2 in ONE kernel (csrc/ffn.hip), weights packed once.
-    gamma = beta = None: ReLU instead of LayerNorm + GELU (SuperGlue's MLP with the BatchNorm folded into W1, b1)."""
+    gamma = beta = None: ReLU instead of LayerNorm + GELU (SuperGlue's MLP with the BatchNorm folded into W1, b1).
+    act = 2 / 3: x + LN_256(W2 act(W1 [x | ctx] + b1) + b2) with LeakyReLU(0.01) / ReLU (gamma, beta [256]): the dense matchers."""
 
-    def __init__(self, w1, b1, gamma, beta, w2, b2, device):
-        self.act = 1 if gamma is None else 0
+    def __init__(self, w1, b1, gamma, beta, w2, b2, device, act=None):
+        self.act = act if act is not None else (1 if gamma is None else 0)
         if gamma is None:
             gamma = beta = torch.zeros(512)
         def up(a):

@@ -295,12 +295,14 @@ int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned sh
 
 /* Fused transformer FFN of a LightGlue block (upstream TransformerLayer.ffn on cat([x, message]) with the attention
  * out-projection folded into W1; reached from imcui/hloc/matchers/lightglue.py:75):
- *   out = x + W2 * GELU(LayerNorm_512(W1 * [x | ctx] + b1)) + b2,   x, ctx, out [M][256] (out may alias x), M % 128 == 0.
+ *   out = x + W2 * GELU(LayerNorm_512(W1 * [x | ctx] + b1)) + b2,   x, ctx, out [M][256] (out may alias x).
  * W1 [512][512] as planes from imcui_hip_linear_pack_split; W2 [256][512] as planes from imcui_hip_ffn_pack_w2 (the
  * same fragment-major planes with the K axis in the order the kernel's first GEMM hands its accumulators over);
  * s1 / s2 = device floats holding the returned 2^-e.  precision 1 only.  One kernel: the 512-wide hidden row stays
  * on the CU (registers -> LDS), no LayerNorm / GELU pass over HBM.  act = 1 replaces LayerNorm + GELU by ReLU (gamma, beta
- * may be NULL): SuperGlue's MLP([512, 512, 256]) with its BatchNorm folded into W1 / b1 (imcui/hloc/matchers/superglue.py:26). */
+ * may be NULL): SuperGlue's MLP([512, 512, 256]) with its BatchNorm folded into W1 / b1 (imcui/hloc/matchers/superglue.py:26).
+ * act = 2 / 3: out = x + LayerNorm_256(W2 * act(W1 * [x | ctx] + b1) + b2) with LeakyReLU(0.01) / ReLU and gamma, beta [256]
+ * (b1, b2 may be NULL): the coarse MLPs of EfficientLoFTR (eloftr.py:79) / LoFTR (loftr.py:54). */
 float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsigned short* lo);
 int imcui_hip_ffn_split_f32(imcui_hip_t* h, const float* x, const float* ctx, const unsigned short* w1h, const unsigned short* w1l,
                             const float* s1, const float* b1, const float* gamma, const float* beta, const unsigned short* w2h,

@@ -258,8 +258,12 @@ def test_split_mode_dynamic_range():
     assert torch.isfinite(out).all() and (out - ref.float()).abs().max().item() / ref.abs().max().item() < 1e-3
 
 
-def _ffn_reference(x, ctx, w1, b1, gamma, beta, w2, b2):
+def _ffn_reference(x, ctx, w1, b1, gamma, beta, w2, b2, act=None):
     h = torch.cat([x, ctx], -1).double() @ w1.double().t() + b1.double()
+    if act in (2, 3):  # the dense matchers: activation, second Linear, LayerNorm(256), residual
+        h = F.leaky_relu(h, 0.01) if act == 2 else torch.relu(h)
+        y = h @ w2.double().t() + b2.double()
+        return x.double() + F.layer_norm(y, (256,), gamma.double(), beta.double(), 1e-5)
     if gamma is None:
         h = torch.relu(h)
     else:
@@ -311,3 +315,23 @@ def test_fused_ffn_relu_mode_vs_fp64():
     out = backend.FusedFFN(w1, b1, None, None, w2, b2, _dev())(x.to(_dev()), ctx.to(_dev())).cpu()
     ref = _ffn_reference(x, ctx, w1, b1, None, None, w2, b2)
     assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
+@pytest.mark.parametrize("act,M", [(2, 4800), (3, 2400), (3, 16384)])
+def test_fused_ffn_post_layernorm_modes_vs_fp64(act, M):
+    """act 2 / 3: x + LayerNorm(fc2(act(fc1([x | message])))) -- the coarse MLPs of EfficientLoFTR (LeakyReLU) and LoFTR
+    (ReLU).  M = 4800 / 2400 are not multiples of the 128-token tile: the last tile is partly masked."""
+    from imcui_hip import backend
+
+    backend.set_precision(_dev(), 1)
+    g = torch.Generator().manual_seed(act * 100 + M)
+    x = torch.randn(M, 256, generator=g)
+    ctx = torch.randn(M, 256, generator=g) * 0.8
+    w1 = torch.randn(512, 512, generator=g) / 512 ** 0.5
+    w2 = torch.randn(256, 512, generator=g) / 512 ** 0.5
+    gamma = 1.0 + 0.3 * torch.randn(256, generator=g)
+    beta = 0.2 * torch.randn(256, generator=g)
+    zero1, zero2 = torch.zeros(512), torch.zeros(256)
+    out = backend.FusedFFN(w1, zero1, gamma, beta, w2, zero2, _dev(), act=act)(x.to(_dev()), ctx.to(_dev())).cpu()
+    ref = _ffn_reference(x, ctx, w1, zero1, gamma, beta, w2, zero2, act=act)
+    assert torch.isfinite(out).all() and (out.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
