@@ -108,6 +108,25 @@ def test_eloftr_images_of_different_sizes():
     print(f"ELoFTR unequal sizes: {n} / {m} matches")
 
 
+def test_eloftr_1024(precision):
+    """1024 x 1024 (the LoFTR bench size): 16384 coarse cells per image, a 1 GB similarity matrix, 1024 aggregated tokens."""
+    if precision == 0:
+        pytest.skip("the exact-f32 mode is covered at the smaller sizes; this case is about sizes")
+    n = _case(1024, 1024, 1, SD, 0.2, 5000)
+    print(f"ELoFTR 1024x1024: {n} matches")
+
+
+def test_eloftr_no_matches():
+    """A threshold nothing passes: empty outputs, no fine stage work, no error."""
+    from imcui_hip.hloc.matchers.eloftr import ELoFTR
+
+    i0, i1, _ = make_shifted_pair(3, 160, 224, (16, 8), 300)
+    model = ELoFTR({"match_threshold": 0.9999, "max_keypoints": 100, "state_dict": SD}).eval().to("cuda:0")
+    pred = model({"image0": i0.cuda(), "image1": torch.rand_like(i1).cuda()})
+    assert pred["keypoints0"].shape == (0, 2) and pred["keypoints1"].shape == (0, 2) and pred["scores"].shape == (0,)
+    assert [len(d["scores"]) for d in model.forward_pairs(i0.cuda(), torch.rand_like(i1).cuda())] == [0]
+
+
 def test_eloftr_unshaped_weights():
     """Weights without the hand shaping: all eight attention blocks contribute at full strength (few or no matches above
     the threshold -- the intermediate maps carry the comparison)."""
