@@ -244,8 +244,8 @@ def bench_loftr(args, dev, rank, world):
 
         # HBM bytes of the GEMM-class kernels per launch from the committed PMC passes of the same workload (1024^2 only)
         traffic = None
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_loftr.json")))
-        if cands and (Hh, Ww) == (1024, 1024) and gemm_n and not eloftr:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_eloftr.json" if eloftr else "r*_pmc_traffic_loftr.json")))
+        if cands and (Hh, Ww) == ((480, 640) if eloftr else (1024, 1024)) and gemm_n:
             with open(cands[-1]) as fh:
                 tj = json.load(fh)
             traffic = tj["traffic_bytes_per_step_gemm_kernels"] * B / tj["pairs_per_step"] / (gemm_n / args.steps)

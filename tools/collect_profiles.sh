@@ -20,7 +20,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_spl
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
   echo pmc $c rc $?
-  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_loftr_$c -o loftr -- python $R/bench.py --workload loftr --steps 2 --warmup 1 > $O/pmc_loftr_$c.log 2>&1
+  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_loftr_$c -o loftr -- python $R/bench.py --workload loftr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_loftr_$c.log 2>&1
+  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_eloftr_$c -o eloftr -- python $R/bench.py --workload eloftr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_eloftr_$c.log 2>&1
 done
 # matrix-pipe occupancy and stall breakdown (one pass: 7 of the 8 SQ slots)
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_SQ -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_SQ.log 2>&1

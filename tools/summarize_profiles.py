@@ -46,18 +46,22 @@ json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_
            "note": "Q, K, V^T planes read once + O written once per launch; the XCD-aware grid keeps the K/V of a (sequence, head) in one L2 "
                    "(traffic == compulsory bytes; it was 4.5x that before the remap)"},
           open(os.path.join(P, f"{tag}_attention_traffic.json"), "w"), indent=1)
-# LoFTR: HBM traffic of the GEMM-class kernels per step (same two passes on the loftr workload)
-if os.path.exists(os.path.join(F, "pmc_loftr_FETCH_SIZE", "loftr_counter_collection.csv")):
-    lfe, lwr = agg("FETCH_SIZE", "loftr_FETCH_SIZE", "loftr"), agg("WRITE_SIZE", "loftr_WRITE_SIZE", "loftr")
-    lb = json.loads(open(os.path.join(F, "bench_loftr_1024.json.log")).read().strip().split("\n")[-1])
+# LoFTR / EfficientLoFTR: HBM traffic of the GEMM-class kernels per step (same two passes on the dense workloads)
+for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench_eloftr_640x480.json.log")):
+    if not os.path.exists(os.path.join(F, f"pmc_{stem}_FETCH_SIZE", f"{stem}_counter_collection.csv")):
+        continue
+    lfe, lwr = agg("FETCH_SIZE", f"{stem}_FETCH_SIZE", stem), agg("WRITE_SIZE", f"{stem}_WRITE_SIZE", stem)
+    lb = json.loads(open(os.path.join(F, benchlog)).read().strip().split("\n")[-1])
     lout = {k: {"launches": v[1], "fetch_bytes_per_launch": v[0] * 1024 * 2, "write_bytes_per_launch": lwr.get(k, (0, 0))[0] * 1024}
             for k, v in lfe.items() if v[1] >= 2}
     steps = 3  # bench.py --steps 2 --warmup 1
     tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in lout.values()) / steps
-    gem = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for k, v in lout.items() if k.startswith("gemm_")) / steps
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload loftr --steps 2 --warmup 1; FETCH doubled",
+    gem = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for k, v in lout.items()
+              if k.startswith("gemm_") or k.startswith("lg_ffn")) / steps
+    json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {stem} --steps 2 --warmup 1; FETCH doubled; "
+                       "GEMM class = gemm_* and the fused MLP kernel (what the bench's HIP-event class times)",
                "pairs_per_step": lb["config"]["pairs_per_step_per_gpu"], "traffic_bytes_per_step_all_kernels": tot,
-               "traffic_bytes_per_step_gemm_kernels": gem, "kernels": lout}, open(os.path.join(P, f"{tag}_pmc_traffic_loftr.json"), "w"), indent=1)
+               "traffic_bytes_per_step_gemm_kernels": gem, "kernels": lout}, open(os.path.join(P, f"{tag}_pmc_traffic_{stem}.json"), "w"), indent=1)
 # matrix-pipe occupancy / stall breakdown from the SQ pass
 sqp = os.path.join(F, "pmc_SQ", "splg_counter_collection.csv")
 if os.path.exists(sqp):
