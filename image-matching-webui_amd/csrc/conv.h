@@ -11,9 +11,11 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 
 // split-precision variant (imcui_hip_s::precision == 1): weights pre-split into f16 hi / lo planes
 //   wh/wl : [Cin/32][9 taps][4 octets][Cout][8 halves] of w * 2^e ; wscale -> 2^-e (device scalar)
+//   relu  : activation code 0 none / 1 ReLU / 2 LeakyReLU(0.01);  resid (optional, no pooling): a map of the output's shape
+//           added before the activation (residual blocks of the dense matchers' backbones)
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream);
+                         int relu, int pool, hipStream_t stream, const float* resid = nullptr);
 // SuperPoint conv1a (1->64, VALU, evaluated on the fly for the patch) fused into conv1b (64->64, split MFMA):
 // image [B,H,W] -> relu(conv1b(relu(conv1a(image)))) (+2x2 max-pool), NHWC out
 int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* w1a, const float* b1a,
@@ -21,6 +23,8 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
                                float* out, int B, int H, int W, int pool, hipStream_t stream);
 // host: OIHW -> the split layout above; returns 2^-e
 float pack_conv3x3_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+// host: the same from the implicit-GEMM layout [Cout][9 taps][Cin] (pack_conv_gemm); planes of 9 * Cin * Cout halves each
+float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
 
 // first layer: 1 -> 64 channels, 3x3, pad 1, +bias, +ReLU.  in [B,H,W] ; w [9][64] ; out [B,H,W,64]
 int conv1a_launch(imcui_hip_s* h, const float* in, const float* w, const float* bias, float* out, int B, int H, int W,

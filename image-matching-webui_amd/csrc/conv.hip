@@ -159,6 +159,8 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 // as conv1a_kernel, so the fused and unfused paths agree bit for bit.
 #define ITW (STW + 4)  // image tile: patch + 1-pixel halo of the first conv
 #define ITH (STH + 4)
+__device__ __forceinline__ float conv_act(float v, int code) { return code == 2 ? (v > 0.0f ? v : 0.01f * v) : (code == 1 ? fmaxf(v, 0.0f) : v); }
+
 template <bool FUSE1A>
 __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restrict__ in,
                                                             const unsigned short* __restrict__ wh,
@@ -349,6 +351,10 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
     // Written straight from the fragments a store touches 32 pixels x 32 B; the finished values are parked in LDS
     // ([pixel][64 channels], 68-float rows: conflict-free both ways) and leave as whole 256-byte channel runs.
     const float wsc = wscale[0];
+    // `relu`: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Plain layers pass a residual map (same shape as the output) in the
+    // unused first-layer pointer: it is added before the activation, in the coalesced store loop.
+    const float* resid = FUSE1A ? nullptr : w1a;
+    const bool late = resid != nullptr;
     __syncthreads();  // every wave is done with the patch / weight buffers
     float* st = reinterpret_cast<float*>(smem);
     constexpr int SROW = 68;
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                 v[3] += b4.w;
                 if (relu) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], relu);
                 }
                 if ((lo & 1) == 0) *reinterpret_cast<float4*>(st + (wid * 16 + (lo >> 1)) * SROW + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -400,11 +406,11 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                         for (int m = 0; m < 2; ++m) {
                             float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y,
                                                    acc[m][n][4 * q + 2] * wsc + b4.z, acc[m][n][4 * q + 3] * wsc + b4.w);
-                            if (relu) {
-                                v.x = fmaxf(v.x, 0.0f);
-                                v.y = fmaxf(v.y, 0.0f);
-                                v.z = fmaxf(v.z, 0.0f);
-                                v.w = fmaxf(v.w, 0.0f);
+                            if (relu && !late) {
+                                v.x = conv_act(v.x, relu);
+                                v.y = conv_act(v.y, relu);
+                                v.z = conv_act(v.z, relu);
+                                v.w = conv_act(v.w, relu);
                             }
                             *reinterpret_cast<float4*>(st + (((wid & 1) * 2 + m) * 32 + lo) * SROW + cl) = v;
                         }
@@ -415,9 +421,15 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
             for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
                 const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
                 const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
-                if (oy < H && ox < W)
-                    *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4) =
-                        *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+                if (oy < H && ox < W) {
+                    float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+                    const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4;
+                    if (late) {  // residual connection: added before the activation (BasicBlock: relu(conv + identity))
+                        const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
+                        v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
+                    }
+                    *reinterpret_cast<float4*>(out + o) = v;
+                }
             }
             if (h2 == 0) __syncthreads();
         }
@@ -426,7 +438,8 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream) {
+                         int relu, int pool, hipStream_t stream, const float* resid) {
+    if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (Cin % 32 != 0 || Cout % 64 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
@@ -435,7 +448,7 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
     hipLaunchKernelGGL(conv3x3_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H,
-                       W, Cin, Cout, tiles_x, tiles_y, relu, pool, (const float*)nullptr, (const float*)nullptr);
+                       W, Cin, Cout, tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -542,4 +555,15 @@ float pack_conv3x3_split(const float* w, int Cout, int Cin, unsigned short* hi, 
 void pack_conv1a(const float* w, float* dst) {
     for (int tap = 0; tap < 9; ++tap)
         for (int co = 0; co < 64; ++co) dst[tap * 64 + co] = w[co * 9 + tap];
+}
+
+float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo) {
+    float* oihw = (float*)malloc((size_t)Cout * Cin * 9 * sizeof(float));
+    if (!oihw) return 0.0f;
+    for (int co = 0; co < Cout; ++co)
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < Cin; ++ci) oihw[((size_t)co * Cin + ci) * 9 + t] = w_gemm[((size_t)co * 9 + t) * Cin + ci];
+    const float sc = pack_conv3x3_split(oihw, Cout, Cin, hi, lo);
+    free(oihw);
+    return sc;
 }

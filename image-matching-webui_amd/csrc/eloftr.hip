@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "conv.h"
 #include "eloftr_kernels.h"
 #include "ffn.h"
 #include "gemm.h"
@@ -61,6 +62,7 @@ static void el_shape(int i, int* N, int* K) {
 struct ElLayout {
     size_t conv0_w, conv0_b;  // [9][64], [64]
     size_t w[EL_NLAYERS], b[EL_NLAYERS], wh[EL_NLAYERS], wl[EL_NLAYERS], ws[EL_NLAYERS];
+    size_t c3h[EL_NLAYERS], c3l[EL_NLAYERS], c3s[EL_NLAYERS];  // 3x3 layers: planes in the layout of conv3x3_split_kernel (0 = none)
     size_t dw[8];             // depth-wise query aggregation [256][16]
     size_t wph[8], wpl[8], wps[8];  // mlp.fc2 planes with the K axis in the fused FFN kernel's order (ffn_permute_k)
     size_t norm[EL_NNORMS];
@@ -86,6 +88,12 @@ static ElLayout el_layout() {
         l.wh[i] = take(npad / 2);
         l.wl[i] = take(npad / 2);
         l.ws[i] = take(64);
+        l.c3h[i] = l.c3l[i] = l.c3s[i] = 0;
+        if (K % 288 == 0 && N % 64 == 0) {  // a 3x3 convolution (K = 9 Cin, Cin a multiple of 32): also packed for the patch-staging kernel
+            l.c3h[i] = take((size_t)N * K / 2);
+            l.c3l[i] = take((size_t)N * K / 2);
+            l.c3s[i] = take(64);
+        }
     }
     for (int i = 0; i < 8; ++i) l.dw[i] = take(256 * 16);
     for (int i = 0; i < 8; ++i) {
@@ -122,6 +130,9 @@ extern "C" int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* 
         if (b[i]) memcpy(packed + l.b[i], b[i], (size_t)N * sizeof(float));
         packed[l.ws[i]] = split_weights_frag_host(w[i], N, K, reinterpret_cast<unsigned short*>(packed + l.wh[i]),
                                                   reinterpret_cast<unsigned short*>(packed + l.wl[i]));
+        if (l.c3s[i])
+            packed[l.c3s[i]] = pack_conv3x3_split_from_gemm(w[i], N, K / 9, reinterpret_cast<unsigned short*>(packed + l.c3h[i]),
+                                                            reinterpret_cast<unsigned short*>(packed + l.c3l[i]));
     }
     float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));
     if (!perm) return IMCUI_ERR_ARG;
@@ -290,8 +301,21 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
     auto npx = [&](int s, int div) { return (size_t)(Hs[s] / div) * (Ws[s] / div); };
     // convolution as a GEMM over the NHWC maps at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one
     // launch over the 2B images when both sides have one size, one launch per side otherwise
+    static const bool conv_gemm_only = getenv("IMCUI_CONV_GEMM_ONLY") != nullptr;  // A/B switch: every convolution on the implicit GEMM
     auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
         for (int s = 0; s < (same ? 1 : 2); ++s) {
+            if (split && !conv_gemm_only && ks == 3 && stride == 1 && l.c3s[li] != 0) {
+                // 3x3 stride 1: the patch-staging kernel (conv.hip) reads every input pixel once per 64 output channels; the
+                // implicit GEMM re-reads it once per tap and misses L2 at these map sizes (PMC: 5-10 x the input bytes fetched)
+                int N, K;
+                el_shape(li, &N, &K);
+                const size_t off = s ? (size_t)B * npx(0, div) : 0;
+                const int r = conv3x3_split_launch(h, in + off * cin, reinterpret_cast<const unsigned short*>(P + l.c3h[li]),
+                                                   reinterpret_cast<const unsigned short*>(P + l.c3l[li]), P + l.c3s[li], P + l.b[li], out + off * N,
+                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, cin, N, act, 0, stream, resid ? resid + off * N : nullptr);
+                if (r != IMCUI_OK) return r;
+                continue;
+            }
             GemmP g;
             wts(g, li);
             g.epi = EPI_CONV;

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "conv.h"
 #include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
@@ -61,6 +62,7 @@ struct LfLayout {
     size_t conv1_w, conv1_b;  // [49][128], [128]
     size_t w[LF_NLAYERS], b[LF_NLAYERS], wh[LF_NLAYERS], wl[LF_NLAYERS], ws[LF_NLAYERS];
     size_t norm[LF_NNORMS];
+    size_t c3h[LF_NLAYERS], c3l[LF_NLAYERS], c3s[LF_NLAYERS];  // 3x3 convolutions: planes in the layout of conv3x3_split_kernel (0 = none)
     size_t wph[8], wpl[8], wps[8];  // coarse mlp.2 planes with the K axis in the fused FFN kernel's order (ffn_permute_k)
     size_t total;
 };
@@ -88,6 +90,16 @@ static LfLayout lf_layout() {
         l.wph[i] = take(256 * 512 / 2);
         l.wpl[i] = take(256 * 512 / 2);
         l.wps[i] = take(64);
+    }
+    for (int i = 0; i < LF_NLAYERS; ++i) {
+        int N, K;
+        lf_shape(i, &N, &K);
+        l.c3h[i] = l.c3l[i] = l.c3s[i] = 0;
+        if (i < LF_COARSE0 && K % 288 == 0 && N % 64 == 0) {  // 3x3 convolution (K = 9 Cin)
+            l.c3h[i] = take((size_t)N * K / 2);
+            l.c3l[i] = take((size_t)N * K / 2);
+            l.c3s[i] = take(64);
+        }
     }
     l.total = off;
     return l;
@@ -133,6 +145,13 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
                                                    reinterpret_cast<unsigned short*>(packed + l.wpl[i]));
     }
     free(perm);
+    for (int i = 0; i < LF_NLAYERS; ++i)
+        if (l.c3s[i]) {
+            int N, K;
+            lf_shape(i, &N, &K);
+            packed[l.c3s[i]] = pack_conv3x3_split_from_gemm(w[i], N, K / 9, reinterpret_cast<unsigned short*>(packed + l.c3h[i]),
+                                                            reinterpret_cast<unsigned short*>(packed + l.c3l[i]));
+        }
     return IMCUI_OK;
 }
 
@@ -298,8 +317,21 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     auto npx = [&](int s, int div) { return (size_t)(Hs[s] / div) * (Ws[s] / div); };
     // conv as GEMM over NHWC at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one launch over
     // the 2B images when both sides have one size, one launch per side otherwise
+    static const bool conv_gemm_only = getenv("IMCUI_CONV_GEMM_ONLY") != nullptr;  // A/B switch: every convolution on the implicit GEMM
     auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
         for (int s = 0; s < (same ? 1 : 2); ++s) {
+            if (split && !conv_gemm_only && ks == 3 && stride == 1 && l.c3s[li] != 0) {
+                // 3x3 stride 1: the patch-staging kernel (conv.hip) reads every input pixel once per 64 output channels; the
+                // implicit GEMM re-reads it once per tap and misses L2 at these map sizes (PMC: 6-10 x the input bytes fetched)
+                int N, K;
+                lf_shape(li, &N, &K);
+                const size_t off = s ? (size_t)B * npx(0, div) : 0;
+                const int r = conv3x3_split_launch(h, in + off * cin, reinterpret_cast<const unsigned short*>(P + l.c3h[li]),
+                                                   reinterpret_cast<const unsigned short*>(P + l.c3l[li]), P + l.c3s[li], P + l.b[li], out + off * N,
+                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, cin, N, act, 0, stream, resid ? resid + off * N : nullptr);
+                if (r != IMCUI_OK) return r;
+                continue;
+            }
             GemmP g;
             wts(g, li);
             g.epi = EPI_CONV;
