@@ -234,6 +234,8 @@ def bench_loftr(args, dev, rank, world):
         dist.barrier()
     dt = time.perf_counter() - t0
     gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
+    conv_ms, conv_n = backend.profile_read(dev, "conv3x3")  # the 3x3 stride-1 convolutions run on the patch-staging kernel
+    gemm_ms, gemm_n = gemm_ms + conv_ms, gemm_n + conv_n
     backend.profile_enable(dev, False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -264,11 +266,11 @@ def bench_loftr(args, dev, rank, world):
                                     f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM"),
                        "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]),
                        "weights": "seeded random (imcui_hip/synth_weights.py), " + ("EfficientLoFTR architecture (transformers port names)" if eloftr else "kornia LoFTR architecture")},
-            "roofline": {"kernel": "gemm_split_kernel (GEMM class: convolutions as implicit-im2col GEMM + transformer projections)" if split else "gemm_kernel", "bound": "mfma",
+            "roofline": {"kernel": "conv3x3_split_kernel + gemm_split_kernel + lg_ffn_kernel (matrix class: 3x3 convolutions, strided / 1x1 convolutions as implicit GEMM, projections, fused MLPs)" if split else "gemm_kernel", "bound": "mfma",
                          "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": (tf_pair * B * args.steps / (gemm_ms * 1e-3) / (PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF)) if gemm_ms else 0.0,
                          "traffic": traffic, "gemm_ms_per_step": gemm_ms / args.steps, "launches_per_step": gemm_n / args.steps,
-                         "note": "achieved = algorithmic TFLOP of a pair / summed GEMM-class kernel time (HIP events)"},
+                         "note": "achieved = algorithmic TFLOP of a pair / summed matrix-class kernel time (HIP events; conv3x3 + GEMM classes)"},
             "algorithmic_tflops_end_to_end": tf_pair * B / (dt / args.steps),
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:

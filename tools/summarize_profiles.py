@@ -57,9 +57,9 @@ for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench
     steps = 3  # bench.py --steps 2 --warmup 1
     tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in lout.values()) / steps
     gem = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for k, v in lout.items()
-              if k.startswith("gemm_") or k.startswith("lg_ffn")) / steps
+              if k.startswith("gemm_") or k.startswith("lg_ffn") or k.startswith("conv3x3_")) / steps
     json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {stem} --steps 2 --warmup 1; FETCH doubled; "
-                       "GEMM class = gemm_* and the fused MLP kernel (what the bench's HIP-event class times)",
+                       "matrix class = conv3x3_*, gemm_* and the fused MLP kernel (what the bench's HIP-event classes time)",
                "pairs_per_step": lb["config"]["pairs_per_step_per_gpu"], "traffic_bytes_per_step_all_kernels": tot,
                "traffic_bytes_per_step_gemm_kernels": gem, "kernels": lout}, open(os.path.join(P, f"{tag}_pmc_traffic_{stem}.json"), "w"), indent=1)
 # matrix-pipe occupancy / stall breakdown from the SQ pass
