@@ -465,6 +465,7 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         g.N = S;
         g.K = 256;
         g.alpha = 0.00390625f / 0.1f;
+        g.group_rows = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;
         ELRUN(gemm_launch(h, g, stream));
     }
     lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);

@@ -35,6 +35,7 @@ struct GemmP {
     long ldc = 0;
     int M = 0, N = 0, K = 0;
     float alpha = 1.0f;
+    int group_rows = 0;  // > 1: tile order in groups of this many 128-row panels (L2 re-use when both operands are large)
     // ragged sequences: row tile r0 belongs to sequence r0 / rows_per_seq; tiles whose first
     // row is >= cnt[seq] (or whose pair active[seq >> 1] == 0) are skipped.
     const int* cnt = nullptr;

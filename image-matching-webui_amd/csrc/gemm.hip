@@ -30,8 +30,21 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int 
     c.N = p.ncnt ? p.ncnt[c.z * p.cnt_stride] : p.N;
     const int ncol = (p.N + bn - 1) / bn;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    c.row0 = (tile / ncol) * BM;
-    c.col0 = (tile % ncol) * bn;
+    if (p.group_rows > 1) {
+        // both operands are large (similarity matrices): walk the tiles group by group of `group_rows` row panels, column
+        // panel by column panel inside a group, so a weight-side panel is re-used by the whole group while it is in L2 and
+        // the group's row panels stay resident across the columns (row-major order streams the whole second operand once
+        // per row panel: 2.1 GB per 16384 x 16384 x 256 product instead of 0.27 GB)
+        const int nrow = (p.M + BM - 1) / BM;
+        const int per = p.group_rows * ncol;
+        const int g = tile / per, t = tile - g * per;
+        const int rows = min(p.group_rows, nrow - g * p.group_rows);
+        c.row0 = (g * p.group_rows + t % rows) * BM;
+        c.col0 = (t / rows) * bn;
+    } else {
+        c.row0 = (tile / ncol) * BM;
+        c.col0 = (tile % ncol) * bn;
+    }
     if (c.row0 >= c.M || c.col0 >= c.N) return false;
     c.bias = p.bias;
     c.seq = 0;
