@@ -23,7 +23,7 @@ def agg(counter, sub=None, stem="splg", name=None):
     for r in rows:
         if name is not None and r.get("Counter_Name") != name:
             continue
-        by[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+        by[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in by.items()}
 
 
