@@ -161,8 +161,10 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 #define ITH (STH + 4)
 __device__ __forceinline__ float conv_act(float v, int code) { return code == 2 ? (v > 0.0f ? v : 0.01f * v) : (code == 1 ? fmaxf(v, 0.0f) : v); }
 
-template <bool FUSE1A>
-__global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restrict__ in,
+// NC = 32-channel output fragments per wave: 2 -> 64 output channels per workgroup, 4 -> 128 (per tap 24 LDS fragment reads for
+// 48 MFMAs instead of 16 for 24, half as many barriers per MFMA; used when Cout % 128 == 0)
+template <bool FUSE1A, int NC>
+__global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(const float* __restrict__ in,
                                                             const unsigned short* __restrict__ wh,
                                                             const unsigned short* __restrict__ wl,
                                                             const float* __restrict__ wscale,
@@ -170,16 +172,18 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                                                             int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
                                                             int relu, int pool, const float* __restrict__ w1a,
                                                             const float* __restrict__ b1a) {
-    __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSTR + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
+    constexpr int WSN = NC * 32 + 1;  // padded cout stride of the weight slab (16-byte units)
+    static_assert(NC == 2 || (NC == 4 && !FUSE1A), "the fused first layer has 64 output channels");
+    __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSN + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
     uint4* Ph = smem;
     uint4* Pl = smem + 4 * SPSTR;
-    uint4* Wb = smem + 2 * 4 * SPSTR;  // [buf][plane][4 * WSTR]
-    float* img = reinterpret_cast<float*>(smem + 2 * 4 * SPSTR + 2 * 2 * 4 * WSTR);  // [ITH][ITW] (FUSE1A)
+    uint4* Wb = smem + 2 * 4 * SPSTR;  // [buf][plane][4 * WSN]
+    float* img = reinterpret_cast<float*>(smem + 2 * 4 * SPSTR + 2 * 2 * 4 * WSN);  // [ITH][ITW] (FUSE1A)
     float* w1 = img + ITH * ITW;                                                       // [9][64] + bias [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
-    const int ncout = Cout >> 6;
+    const int ncout = Cout / (32 * NC);
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = t % ncout;
     int sp = t / ncout;
@@ -187,13 +191,13 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
     sp /= tiles_x;
     const int ty = sp % tiles_y;
     const int b = sp / tiles_y;
-    const int y0 = ty * STH, x0 = tx * STW, cout0 = ct * 64;
+    const int y0 = ty * STH, x0 = tx * STW, cout0 = ct * 32 * NC;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NC];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NC; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
@@ -245,13 +249,17 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
             }
         }
     };
-    if (!FUSE1A) patch_fetch(0);
+    // NC = 4 has no registers left to hold the next chunk's patch across the nine taps (128 accumulators): it fetches the patch
+    // at the chunk boundary and relies on the co-resident workgroup to cover the latency
+    constexpr bool PREFETCH = (NC == 2);
+    if (!FUSE1A && PREFETCH) patch_fetch(0);
 
     for (int ch = 0; ch < nchunk; ++ch) {
+        if (!FUSE1A && !PREFETCH) patch_fetch(ch);
         __syncthreads();  // everybody is done with the previous patch (and the image tile is visible)
         if (!FUSE1A) {
             patch_store();
-            if (ch + 1 < nchunk) patch_fetch(ch + 1);
+            if (PREFETCH && ch + 1 < nchunk) patch_fetch(ch + 1);
         }
         // fused first layer: a thread always works on the same channel octet (256 % 4 == 0), so the 9 x 8 weights
         // and the bias of that octet are fetched from LDS once per chunk, not once per granule
@@ -303,26 +311,35 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
             Ph[oc * SPSTR + pp] = hq;
             Pl[oc * SPSTR + pp] = lq;
         }
-        // weight slab of a tap: 4 octets x 64 cout per plane = 256 x 16 B -> one per thread per plane
-        uint4 rwh, rwl;
+        // weight slab of a tap: 4 octets x 32 NC cout per plane = NC / 2 x 256 x 16 B -> NC / 2 per thread per plane (named
+        // registers: an array captured by the lambda ends up in scratch memory)
+        uint4 rwh, rwl, rwh1, rwl1;
         auto wload = [&](int tap) __attribute__((always_inline)) {
             const size_t o = ((size_t)(ch * 9 + tap) * 4 + (tid >> 6)) * Cout + cout0 + (tid & 63);
             rwh = wh4[o];
             rwl = wl4[o];
+            if constexpr (NC == 4) {
+                rwh1 = wh4[o + 64];
+                rwl1 = wl4[o + 64];
+            }
         };
         wload(0);
         for (int tap = 0; tap < 9; ++tap) {
-            uint4* wbh = Wb + (tap & 1) * (2 * 4 * WSTR);
-            uint4* wbl = wbh + 4 * WSTR;
-            wbh[(tid >> 6) * WSTR + (tid & 63)] = rwh;
-            wbl[(tid >> 6) * WSTR + (tid & 63)] = rwl;
+            uint4* wbh = Wb + (tap & 1) * (2 * 4 * WSN);
+            uint4* wbl = wbh + 4 * WSN;
+            wbh[(tid >> 6) * WSN + (tid & 63)] = rwh;
+            wbl[(tid >> 6) * WSN + (tid & 63)] = rwl;
+            if constexpr (NC == 4) {
+                wbh[(tid >> 6) * WSN + (tid & 63) + 64] = rwh1;
+                wbl[(tid >> 6) * WSN + (tid & 63) + 64] = rwl1;
+            }
             __syncthreads();
             if (tap + 1 < 9) wload(tap + 1);
             const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int oc = 2 * st + hi;
-                uint4 ah[2], al[2], bh[2], bl[2];
+                uint4 ah[2], al[2], bh[NC], bl[NC];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int pp = (2 * wid + m + dy) * SPW + lo + dx;
@@ -330,14 +347,14 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
                     al[m] = Pl[oc * SPSTR + pp];
                 }
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    bh[n] = wbh[oc * WSTR + n * 32 + lo];
-                    bl[n] = wbl[oc * WSTR + n * 32 + lo];
+                for (int n = 0; n < NC; ++n) {
+                    bh[n] = wbh[oc * WSN + n * 32 + lo];
+                    bl[n] = wbl[oc * WSN + n * 32 + lo];
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < NC; ++n) {
                         // weights = MFMA A operand (rows = output channels), pixels = B (columns)
                         acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
                         acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
@@ -358,80 +375,86 @@ __global__ __launch_bounds__(256) void conv3x3_split_kernel(const float* __restr
     __syncthreads();  // every wave is done with the patch / weight buffers
     float* st = reinterpret_cast<float*>(smem);
     constexpr int SROW = 68;
-    if (pool) {
-        const int Ho = H >> 1, Wo = W >> 1;
+    // the staging tile holds 64 channels: NC / 2 passes (half = fragments 2 half, 2 half + 1)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+    for (int half = 0; half < NC / 2; ++half) {
+        const int coutH = cout0 + 64 * half;
+        if (half > 0) __syncthreads();  // the previous half has been stored
+        if (pool) {
+            const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = n * 32 + 8 * q + 4 * hi;
-                const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
-                float v[4];
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float tv = fmaxf(acc[0][n][4 * q + j], acc[1][n][4 * q + j]);  // rows 2w, 2w+1
-                    tv = fmaxf(tv, __shfl_xor(tv, 1, 64));                          // columns x, x^1
-                    v[j] = tv * wsc;
-                }
-                v[0] += b4.x;
-                v[1] += b4.y;
-                v[2] += b4.z;
-                v[3] += b4.w;
-                if (relu) {
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = n * 32 + 8 * q + 4 * hi;
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + coutH + cl);
+                    float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], relu);
-                }
-                if ((lo & 1) == 0) *reinterpret_cast<float4*>(st + (wid * 16 + (lo >> 1)) * SROW + cl) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {  // 64 pooled pixels x 16 channel quads
-            const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
-            const int oy = (y0 >> 1) + (px >> 4), pxo = (x0 >> 1) + (px & 15);
-            if (oy < Ho && pxo < Wo)
-                *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + cout0 + 4 * c4) =
-                    *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
-        }
-    } else {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {  // image rows 4 h2 .. 4 h2 + 3 of the tile (waves 2 h2, 2 h2 + 1)
-            if ((wid >> 1) == h2) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int cl = n * 32 + 8 * q + 4 * hi;
-                        const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y,
-                                                   acc[m][n][4 * q + 2] * wsc + b4.z, acc[m][n][4 * q + 3] * wsc + b4.w);
-                            if (relu && !late) {
-                                v.x = conv_act(v.x, relu);
-                                v.y = conv_act(v.y, relu);
-                                v.z = conv_act(v.z, relu);
-                                v.w = conv_act(v.w, relu);
-                            }
-                            *reinterpret_cast<float4*>(st + (((wid & 1) * 2 + m) * 32 + lo) * SROW + cl) = v;
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        float tv = fmaxf(acc[0][2 * half + n][4 * q + j], acc[1][2 * half + n][4 * q + j]);  // rows 2w, 2w+1
+                        tv = fmaxf(tv, __shfl_xor(tv, 1, 64));                                            // columns x, x^1
+                        v[j] = tv * wsc;
                     }
-            }
+                    v[0] += b4.x;
+                    v[1] += b4.y;
+                    v[2] += b4.z;
+                    v[3] += b4.w;
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], relu);
+                    }
+                    if ((lo & 1) == 0) *reinterpret_cast<float4*>(st + (wid * 16 + (lo >> 1)) * SROW + cl) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
+            for (int it = 0; it < 4; ++it) {  // 64 pooled pixels x 16 channel quads
                 const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
-                const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
-                if (oy < H && ox < W) {
-                    float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
-                    const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4;
-                    if (late) {  // residual connection: added before the activation (BasicBlock: relu(conv + identity))
-                        const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
-                        v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
-                    }
-                    *reinterpret_cast<float4*>(out + o) = v;
-                }
+                const int oy = (y0 >> 1) + (px >> 4), pxo = (x0 >> 1) + (px & 15);
+                if (oy < Ho && pxo < Wo)
+                    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + coutH + 4 * c4) =
+                        *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
             }
-            if (h2 == 0) __syncthreads();
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {  // image rows 4 h2 .. 4 h2 + 3 of the tile (waves 2 h2, 2 h2 + 1)
+                if ((wid >> 1) == h2) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int cl = n * 32 + 8 * q + 4 * hi;
+                            const float4 b4 = *reinterpret_cast<const float4*>(bias + coutH + cl);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                float4 v = make_float4(acc[m][2 * half + n][4 * q + 0] * wsc + b4.x, acc[m][2 * half + n][4 * q + 1] * wsc + b4.y,
+                                                       acc[m][2 * half + n][4 * q + 2] * wsc + b4.z, acc[m][2 * half + n][4 * q + 3] * wsc + b4.w);
+                                if (relu && !late) {
+                                    v.x = conv_act(v.x, relu);
+                                    v.y = conv_act(v.y, relu);
+                                    v.z = conv_act(v.z, relu);
+                                    v.w = conv_act(v.w, relu);
+                                }
+                                *reinterpret_cast<float4*>(st + (((wid & 1) * 2 + m) * 32 + lo) * SROW + cl) = v;
+                            }
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
+                    const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
+                    const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
+                    if (oy < H && ox < W) {
+                        float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+                        const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + coutH + 4 * c4;
+                        if (late) {  // residual connection: added before the activation (BasicBlock: relu(conv + identity))
+                            const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
+                            v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
+                        }
+                        *reinterpret_cast<float4*>(out + o) = v;
+                    }
+                }
+                if (h2 == 0) __syncthreads();
+            }
         }
     }
 }
@@ -444,11 +467,18 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
     const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, STH);
-    const long nwg = (long)tiles_x * tiles_y * (Cout / 64) * B;
+    // 128 output channels per workgroup when the layer has them (fewer LDS fragment reads and barriers per MFMA)
+    static const bool narrow_only = getenv("IMCUI_CONV_NARROW") != nullptr;  // A/B switch
+    const bool wide = (Cout % 128 == 0) && !narrow_only;
+    const long nwg = (long)tiles_x * tiles_y * (Cout / (wide ? 128 : 64)) * B;
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
-    hipLaunchKernelGGL(conv3x3_split_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H,
-                       W, Cin, Cout, tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
+    if (wide)
+        hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((conv3x3_split_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -462,7 +492,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
     const long nwg = (long)tiles_x * tiles_y * B;
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
-    hipLaunchKernelGGL(conv3x3_split_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
+    hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
                        W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
