@@ -364,7 +364,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     for (int s = 0; s < 2; ++s) {
         const int H2s = Hs[s] / 2, W2s = Ws[s] / 2;
         const long npix = (long)B * H2s * W2s;
-        long blocks = min((npix + 15) / 16, (long)256 * 32);
+        long blocks = min((npix / 4 + 15) / 16, (long)256 * 32);  // a thread group of 16 lanes does 4 pixels
         hipLaunchKernelGGL(lf_conv7_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, s ? image1 : image0, P + l.conv1_w,
                            P + l.conv1_b, w.x0 + (s ? (size_t)B * npx(0, 2) * 128 : 0), Hs[s], Ws[s], H2s, W2s, npix);
     }
