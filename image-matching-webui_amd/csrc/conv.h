@@ -15,7 +15,8 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 //           added before the activation (residual blocks of the dense matchers' backbones)
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid = nullptr);
+                         int relu, int pool, hipStream_t stream, const float* resid = nullptr, int cin_stride = 0);
+// cin_stride: floats between two pixels of `in` when the map stores more channels than the Cin that are used (0 = Cin)
 // SuperPoint conv1a (1->64, VALU, evaluated on the fly for the patch) fused into conv1b (64->64, split MFMA):
 // image [B,H,W] -> relu(conv1b(relu(conv1a(image)))) (+2x2 max-pool), NHWC out
 int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* w1a, const float* b1a,
@@ -24,7 +25,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
 // host: OIHW -> the split layout above; returns 2^-e
 float pack_conv3x3_split(const float* w_oihw, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
 // host: the same from the implicit-GEMM layout [Cout][9 taps][Cin] (pack_conv_gemm); planes of 9 * Cin * Cout halves each
-float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo);
+float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo, int cin_used = 0);
 
 // first layer: 1 -> 64 channels, 3x3, pad 1, +bias, +ReLU.  in [B,H,W] ; w [9][64] ; out [B,H,W,64]
 int conv1a_launch(imcui_hip_s* h, const float* in, const float* w, const float* bias, float* out, int B, int H, int W,

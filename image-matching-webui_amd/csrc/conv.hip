@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
                                                             int relu, int pool, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a) {
+                                                            const float* __restrict__ b1a, int cin_stride) {
     constexpr int WSN = NC * 32 + 1;  // padded cout stride of the weight slab (16-byte units)
     static_assert(NC == 2 || (NC == 4 && !FUSE1A), "the fused first layer has 64 output channels");
     __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSN + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
             const int py = pp / SPW, px = pp - py * SPW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             if (idx < SNPIX * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
+                const float* src = in + (((size_t)b * H + gy) * W + gx) * cin_stride + ch * 32 + oc * 8;
                 pa[k] = *reinterpret_cast<const float4*>(src);
                 pc[k] = *reinterpret_cast<const float4*>(src + 4);
                 pvalid |= 1u << k;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                     a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
                     c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
                 } else {
-                    const float* src = in + (((size_t)b * H + gy) * W + gx) * Cin + ch * 32 + oc * 8;
+                    const float* src = in + (((size_t)b * H + gy) * W + gx) * cin_stride + ch * 32 + oc * 8;
                     a = *reinterpret_cast<const float4*>(src);
                     c = *reinterpret_cast<const float4*>(src + 4);
                 }
@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid) {
+                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride) {
+    if (cin_stride <= 0) cin_stride = Cin;
+    if (cin_stride < Cin || cin_stride % 4 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pixel stride %d for %d input channels", cin_stride, Cin);
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (Cin % 32 != 0 || Cout % 64 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
@@ -475,10 +477,10 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     imcui_prof_begin(h, PROF_CONV, stream);
     if (wide)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride);
     else
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr);
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -493,7 +495,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
     hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
-                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a);
+                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -587,13 +589,15 @@ void pack_conv1a(const float* w, float* dst) {
         for (int co = 0; co < 64; ++co) dst[tap * 64 + co] = w[co * 9 + tap];
 }
 
-float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo) {
-    float* oihw = (float*)malloc((size_t)Cout * Cin * 9 * sizeof(float));
+float pack_conv3x3_split_from_gemm(const float* w_gemm, int Cout, int Cin, unsigned short* hi, unsigned short* lo, int cin_used) {
+    // cin_used <= Cin: only the first cin_used input channels are packed (the rest are zero padding of the stored maps)
+    if (cin_used <= 0) cin_used = Cin;
+    float* oihw = (float*)malloc((size_t)Cout * cin_used * 9 * sizeof(float));
     if (!oihw) return 0.0f;
     for (int co = 0; co < Cout; ++co)
         for (int t = 0; t < 9; ++t)
-            for (int ci = 0; ci < Cin; ++ci) oihw[((size_t)co * Cin + ci) * 9 + t] = w_gemm[((size_t)co * 9 + t) * Cin + ci];
-    const float sc = pack_conv3x3_split(oihw, Cout, Cin, hi, lo);
+            for (int ci = 0; ci < cin_used; ++ci) oihw[((size_t)co * cin_used + ci) * 9 + t] = w_gemm[((size_t)co * 9 + t) * Cin + ci];
+    const float sc = pack_conv3x3_split(oihw, Cout, cin_used, hi, lo);
     free(oihw);
     return sc;
 }

@@ -54,6 +54,16 @@ static void lf_shape(int i, int* N, int* K) {
     *N = (j == 4) ? 2 * d : d;
     *K = (j >= 4) ? 2 * d : d;
 }
+// 3x3 layers whose INPUT is the 196-channel stage (stored padded to CP = 256 channels): the patch-staging conv kernel reads
+// only the first 224 channels (a multiple of its 32-channel chunk): 12.5 % less work in those layers
+static int lf_cin_used(int li) {
+    static const bool off = getenv("IMCUI_LF_NO_UNPAD") != nullptr;  // A/B switch (read at pack time and at launch time alike)
+    if (off) return 0;
+    switch (li) {
+        case LF_L2_0_C2: case LF_L2_1_C1: case LF_L2_1_C2: case LF_OUT1B_0: case LF_OUT1B_3: return 224;
+        default: return 0;
+    }
+}
 // norm vectors: coarse layer l: 4l + {norm1.w, norm1.b, norm2.w, norm2.b} (256), then fine (128)
 #define LF_NNORMS (8 * 4 + 2 * 4)
 static int lf_norm_dim(int i) { return i < 32 ? 256 : 128; }
@@ -150,7 +160,7 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
             int N, K;
             lf_shape(i, &N, &K);
             packed[l.c3s[i]] = pack_conv3x3_split_from_gemm(w[i], N, K / 9, reinterpret_cast<unsigned short*>(packed + l.c3h[i]),
-                                                            reinterpret_cast<unsigned short*>(packed + l.c3l[i]));
+                                                            reinterpret_cast<unsigned short*>(packed + l.c3l[i]), lf_cin_used(i));
         }
     return IMCUI_OK;
 }
@@ -326,9 +336,10 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
                 int N, K;
                 lf_shape(li, &N, &K);
                 const size_t off = s ? (size_t)B * npx(0, div) : 0;
+                const int used = lf_cin_used(li) ? lf_cin_used(li) : cin;
                 const int r = conv3x3_split_launch(h, in + off * cin, reinterpret_cast<const unsigned short*>(P + l.c3h[li]),
                                                    reinterpret_cast<const unsigned short*>(P + l.c3l[li]), P + l.c3s[li], P + l.b[li], out + off * N,
-                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, cin, N, act, 0, stream, resid ? resid + off * N : nullptr);
+                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, used, N, act, 0, stream, resid ? resid + off * N : nullptr, cin);
                 if (r != IMCUI_OK) return r;
                 continue;
             }
