@@ -1,12 +1,12 @@
 // LoFTR forward on MI355X (kornia.feature.LoFTR semantics, called by
 // imcui/hloc/matchers/loftr.py:54).
 //
-// Every convolution of the ResNet-FPN backbone and every Linear of the two transformers is one
-// "linear layer" W[N][K] (+bias) run by the MFMA GEMM kernel of gemm.hip: 3x3 / 1x1 / strided
-// convolutions through its implicit-im2col addressing on NHWC activations (BatchNorm folded into
-// W and bias on the host, residual add + ReLU / LeakyReLU fused in the epilogue), the 196-channel
-// stage padded to 256 channels with zero weights.  Linear attention, LayerNorm, the dual-softmax
-// coarse matching and the fine 5x5-window stage are the small kernels of loftr_kernels.h.
+// The 3x3 stride-1 convolutions of the ResNet-FPN backbone run on the patch-staging conv kernel of conv.hip (BatchNorm folded
+// into weights and bias on the host, residual add + ReLU / LeakyReLU in its store loop); the strided and 1x1 convolutions and
+// every Linear of the two transformers are "linear layers" W[N][K] (+bias) on the MFMA GEMM of gemm.hip (implicit-im2col
+// addressing on NHWC activations); the 196-channel stage is stored padded to 256 channels.  The coarse MLPs (mlp.0, ReLU, mlp.2,
+// norm2, residual) are one launch of the fused FFN kernel (ffn.hip).  Linear attention, LayerNorm, the dual-softmax coarse
+// matching and the fine 5x5-window stage are the small kernels of loftr_kernels.h.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
