@@ -85,10 +85,12 @@ def test_loftr_vs_oracle(h, w, B, precision):
     _loftr_case(h, w, B, SD, 0.01, 21)
 
 
-@pytest.mark.parametrize("hw0,hw1,B", [((240, 320), (320, 256), 1), ((160, 224), (96, 160), 2), ((480, 640), (424, 640), 1)])
+@pytest.mark.parametrize("hw0,hw1,B", [((240, 320), (320, 256), 1), ((160, 224), (96, 160), 2), ((480, 640), (424, 640), 1), ((72, 104), (88, 120), 2)])
 def test_loftr_images_of_different_sizes(hw0, hw1, B, precision):
     """`minima_loftr` (configs/matchers.py:283: force_resize False) hands the matcher pairs whose two images differ in
-    size; kornia then runs the backbone per image.  Same parity bar as the equal-size path."""
+    size; kornia then runs the backbone per image.  Same parity bar as the equal-size path.  The last case has odd coarse
+    grids (9 x 13 and 11 x 15 cells: row lengths that are not multiples of 4, one partly filled 1024-column chunk, maps
+    smaller than a conv tile in one direction)."""
     _loftr_case(hw0[0], hw0[1], B, SD, 0.01, 5, hw1=hw1)
 
 
