@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
                                                             int relu, int pool, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a, int cin_stride) {
+                                                            const float* __restrict__ b1a, int cin_stride, int cout_live) {
     constexpr int WSN = NC * 32 + 1;  // padded cout stride of the weight slab (16-byte units)
     static_assert(NC == 2 || (NC == 4 && !FUSE1A), "the fused first layer has 64 output channels");
     __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSN + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
     const int ty = sp % tiles_y;
     const int b = sp / tiles_y;
     const int y0 = ty * STH, x0 = tx * STW, cout0 = ct * 32 * NC;
+    // 32-channel fragments of this workgroup that hold live output channels (the rest is zero padding of the layer: its
+    // products are skipped, the accumulators stay 0 and the padded channels are stored as act(0 + 0) = 0)
+    const int nlive = min(NC, (cout_live - cout0 + 31) >> 5);
 
     f32x16 acc[2][NC];
 #pragma unroll
@@ -352,14 +355,16 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                     bl[n] = wbl[oc * WSN + n * 32 + lo];
                 }
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int n = 0; n < NC; ++n) {
+                    if (NC == 4 && n == NC - 1 && nlive < NC) break;  // wave-uniform: the last fragment is padding
 #pragma unroll
-                    for (int n = 0; n < NC; ++n) {
+                    for (int m = 0; m < 2; ++m) {
                         // weights = MFMA A operand (rows = output channels), pixels = B (columns)
                         acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
                         acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
                         acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
                     }
+                }
             }
         }
     }
@@ -461,8 +466,9 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride) {
+                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live) {
     if (cin_stride <= 0) cin_stride = Cin;
+    if (cout_live <= 0 || cout_live > Cout) cout_live = Cout;
     if (cin_stride < Cin || cin_stride % 4 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pixel stride %d for %d input channels", cin_stride, Cin);
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (Cin % 32 != 0 || Cout % 64 != 0)
@@ -477,10 +483,10 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     imcui_prof_begin(h, PROF_CONV, stream);
     if (wide)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride);
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
     else
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride);
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -495,7 +501,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
     hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
-                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64);
+                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64, 64);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

@@ -302,7 +302,9 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
     // convolution as a GEMM over the NHWC maps at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one
     // launch over the 2B images when both sides have one size, one launch per side otherwise
     static const bool conv_gemm_only = getenv("IMCUI_CONV_GEMM_ONLY") != nullptr;  // A/B switch: every convolution on the implicit GEMM
-    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
+    // rup: `resid` is the map at HALF the output resolution whose bilinear x2 up-sampling is the residual (evaluated in the GEMM
+    // epilogue; 1x1 stride-1 layers of the split mode)
+    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act, bool rup = false) -> int {
         for (int s = 0; s < (same ? 1 : 2); ++s) {
             if (split && !conv_gemm_only && ks == 3 && stride == 1 && l.c3s[li] != 0) {
                 // 3x3 stride 1: the patch-staging kernel (conv.hip) reads every input pixel once per 64 output channels; the
@@ -338,6 +340,12 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
             g.ldc = g.N;
             g.resid = resid ? resid + ooff : nullptr;
             g.ldr = g.N;
+            if (rup) {
+                g.resid = resid + (s ? (size_t)B * npx(0, 2 * div) * g.N : 0);
+                g.rup_h = Hs[s] / (2 * div);
+                g.rup_w = Ws[s] / (2 * div);
+                g.rup_align = 0;
+            }
             g.act = act;
             const int r = gemm_launch(h, g, stream);
             if (r != IMCUI_OK) return r;
@@ -485,12 +493,22 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
         }
     };
     ELRUN(conv(EL_OUT, w.fc, w.f8, 8, 256, 1, 1, nullptr, 0));
-    upsample2(w.f8, w.u4, 8, 256);
-    ELRUN(conv(EL_F0_C1, w.x2, w.a4, 4, 128, 1, 1, w.u4, 0));
+    static const bool up_unfused = getenv("IMCUI_UPSAMPLE_UNFUSED") != nullptr;  // A/B switch: materialise the up-sampled maps
+    const bool upf = split && !up_unfused;
+    if (upf) {
+        ELRUN(conv(EL_F0_C1, w.x2, w.a4, 4, 128, 1, 1, w.f8, 0, true));  // + bilinear x2 of out_conv's map, in the epilogue
+    } else {
+        upsample2(w.f8, w.u4, 8, 256);
+        ELRUN(conv(EL_F0_C1, w.x2, w.a4, 4, 128, 1, 1, w.u4, 0));
+    }
     ELRUN(conv(EL_F0_C2, w.a4, w.b4, 4, 256, 3, 1, nullptr, 2));
     ELRUN(conv(EL_F0_C3, w.b4, w.r4, 4, 256, 3, 1, nullptr, 0));
-    upsample2(w.r4, w.u2, 4, 128);
-    ELRUN(conv(EL_F1_C1, w.x1, w.a2, 2, 64, 1, 1, w.u2, 0));
+    if (upf) {
+        ELRUN(conv(EL_F1_C1, w.x1, w.a2, 2, 64, 1, 1, w.r4, 0, true));
+    } else {
+        upsample2(w.r4, w.u2, 4, 128);
+        ELRUN(conv(EL_F1_C1, w.x1, w.a2, 2, 64, 1, 1, w.u2, 0));
+    }
     ELRUN(conv(EL_F1_C2, w.a2, w.b2, 2, 128, 3, 1, nullptr, 2));
     ELRUN(conv(EL_F1_C3, w.b2, w.r2, 2, 128, 3, 1, nullptr, 0));
 

@@ -64,6 +64,10 @@ struct GemmP {
     int conv_k = 0, conv_stride = 1, conv_pad = 0, conv_hin = 0, conv_win = 0, conv_hout = 0, conv_wout = 0, conv_cin = 0;
     const float* resid = nullptr;  // EPI_CONV: [M, N] added before the activation (may alias C)
     long ldr = 0;
+    // EPI_CONV, split kernels: the residual is the bilinear x2 up-sampling of the NHWC map `resid` [images, rup_h, rup_w, ldr]
+    // (rows of the GEMM = pixels of the 2 rup_h x 2 rup_w maps), evaluated in the epilogue instead of being materialised;
+    // rup_align = align_corners of the interpolation (LoFTR: 1, EfficientLoFTR: 0).  0 = plain [M, N] residual.
+    int rup_h = 0, rup_w = 0, rup_align = 1;
     int act = 0;
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;

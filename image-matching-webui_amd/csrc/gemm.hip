@@ -533,7 +533,39 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                 float v[4] = {t4.x + b[0], t4.y + b[1], t4.z + b[2], t4.w + b[3]};
                 float* dst = C + (size_t)row * p.ldc + f0;
                 if (EPI == EPI_CONV) {
-                    if (p.resid != nullptr) {
+                    if (p.resid != nullptr && p.rup_h > 0) {
+                        // residual = bilinear x2 of a half-resolution map, ATen's formula and evaluation order (what the
+                        // stand-alone up-sampling kernels compute), N % 4 == 0 checked at launch
+                        const int hh = p.rup_h, ww = p.rup_w, Wo = 2 * ww, Ho = 2 * hh;
+                        const int ox = row % Wo, t2 = row / Wo, oy = t2 % Ho, bi = t2 / Ho;
+                        float fy, fx;
+                        int y1, x1;
+                        if (p.rup_align) {
+                            fy = ((float)(hh - 1) / (float)(Ho - 1)) * (float)oy;
+                            fx = ((float)(ww - 1) / (float)(Wo - 1)) * (float)ox;
+                        } else {
+                            fy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.0f);
+                            fx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.0f);
+                        }
+                        const int y0 = (int)fy, x0 = (int)fx;
+                        if (p.rup_align) {
+                            y1 = min(y0 + 1, hh - 1);
+                            x1 = min(x0 + 1, ww - 1);
+                        } else {
+                            y1 = y0 + (y0 < hh - 1 ? 1 : 0);
+                            x1 = x0 + (x0 < ww - 1 ? 1 : 0);
+                        }
+                        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+                        const float* base = p.resid + (size_t)bi * hh * ww * p.ldr + f0;
+                        const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * ww + x0) * p.ldr);
+                        const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * ww + x1) * p.ldr);
+                        const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * ww + x0) * p.ldr);
+                        const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * ww + x1) * p.ldr);
+                        v[0] += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+                        v[1] += hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+                        v[2] += hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+                        v[3] += hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+                    } else if (p.resid != nullptr) {
                         const float* rs = p.resid + (size_t)row * p.ldr + f0;
                         if (full && res_vec) {
                             const float4 r4 = *reinterpret_cast<const float4*>(rs);
@@ -979,6 +1011,8 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm(conv): cin=%d must be a multiple of %d, K=%d == k*k*cin, epilogue EPI_CONV", p.conv_cin,
                              BK32, p.K);
     const bool split = h->precision == 1;
+    if (p.rup_h > 0 && (!split || p.epi != EPI_CONV || p.N % 4 != 0 || p.ldr % 4 != 0 || p.M % (4 * p.rup_h * p.rup_w) != 0))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: the up-sampled residual needs the split mode, EPI_CONV, N %% 4 == 0 and M = images x 4 rup_h rup_w");
     if (p.split_out && (!split || p.rows_per_seq <= 0 || p.N % BN != 0 || p.M % BM != 0 || p.batch != 1))
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: split_out needs the split mode and whole 128x128 tiles (M=%d N=%d)", p.M, p.N);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");

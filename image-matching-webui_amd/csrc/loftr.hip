@@ -64,6 +64,16 @@ static int lf_cin_used(int li) {
         default: return 0;
     }
 }
+// 3x3 layers whose OUTPUT is the 196-channel stage (N = CP = 256): the fragment of channels 224..255 is all padding and is
+// not multiplied (conv3x3_split_launch's cout_live)
+static int lf_cout_live(int li) {
+    static const bool off = getenv("IMCUI_LF_NO_UNPAD") != nullptr;
+    if (off) return 0;
+    switch (li) {
+        case LF_L2_0_C2: case LF_L2_1_C1: case LF_L2_1_C2: case LF_OUT2B_3: case LF_OUT1B_0: return 224;
+        default: return 0;
+    }
+}
 // norm vectors: coarse layer l: 4l + {norm1.w, norm1.b, norm2.w, norm2.b} (256), then fine (128)
 #define LF_NNORMS (8 * 4 + 2 * 4)
 static int lf_norm_dim(int i) { return i < 32 ? 256 : 128; }
@@ -328,7 +338,9 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     // conv as GEMM over NHWC at input resolution 1/div: `in` / `out` / `resid` hold side 0 then side 1; one launch over
     // the 2B images when both sides have one size, one launch per side otherwise
     static const bool conv_gemm_only = getenv("IMCUI_CONV_GEMM_ONLY") != nullptr;  // A/B switch: every convolution on the implicit GEMM
-    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act) -> int {
+    // rup: `resid` is the map at HALF the output resolution whose bilinear x2 up-sampling is the residual (evaluated in the GEMM
+    // epilogue; 1x1 stride-1 layers of the split mode)
+    auto conv = [&](int li, const float* in, float* out, int div, int cin, int ks, int stride, const float* resid, int act, bool rup = false) -> int {
         for (int s = 0; s < (same ? 1 : 2); ++s) {
             if (split && !conv_gemm_only && ks == 3 && stride == 1 && l.c3s[li] != 0) {
                 // 3x3 stride 1: the patch-staging kernel (conv.hip) reads every input pixel once per 64 output channels; the
@@ -339,7 +351,8 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
                 const int used = lf_cin_used(li) ? lf_cin_used(li) : cin;
                 const int r = conv3x3_split_launch(h, in + off * cin, reinterpret_cast<const unsigned short*>(P + l.c3h[li]),
                                                    reinterpret_cast<const unsigned short*>(P + l.c3l[li]), P + l.c3s[li], P + l.b[li], out + off * N,
-                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, used, N, act, 0, stream, resid ? resid + off * N : nullptr, cin);
+                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, used, N, act, 0, stream, resid ? resid + off * N : nullptr, cin,
+                                                   lf_cout_live(li));
                 if (r != IMCUI_OK) return r;
                 continue;
             }
@@ -365,6 +378,12 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
             g.ldc = g.N;
             g.resid = resid ? resid + ooff : nullptr;
             g.ldr = g.N;
+            if (rup) {
+                g.resid = resid + (s ? (size_t)B * npx(0, 2 * div) * g.N : 0);
+                g.rup_h = Hs[s] / (2 * div);
+                g.rup_w = Ws[s] / (2 * div);
+                g.rup_align = 1;
+            }
             g.act = act;
             const int r = gemm_launch(h, g, stream);
             if (r != IMCUI_OK) return r;
@@ -404,12 +423,22 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
                                in + (s ? (size_t)B * npx(0, div) * C : 0), out + (s ? (size_t)B * npx(0, div / 2) * C : 0), hh, ww, C, n4);
         }
     };
-    upsample(w.fc, w.up3, 8, 256);
-    LFRUN(conv(LF_OUT2, w.x2, w.x2o, 4, CP, 1, 1, w.up3, 0));
+    static const bool up_unfused = getenv("IMCUI_UPSAMPLE_UNFUSED") != nullptr;  // A/B switch: materialise the up-sampled maps
+    const bool upf = split && !up_unfused;
+    if (upf) {
+        LFRUN(conv(LF_OUT2, w.x2, w.x2o, 4, CP, 1, 1, w.fc, 0, true));  // + bilinear x2 of layer3_outconv's map, in the epilogue
+    } else {
+        upsample(w.fc, w.up3, 8, 256);
+        LFRUN(conv(LF_OUT2, w.x2, w.x2o, 4, CP, 1, 1, w.up3, 0));
+    }
     LFRUN(conv(LF_OUT2B_0, w.x2o, w.y2, 4, 256, 3, 1, nullptr, 2));
     LFRUN(conv(LF_OUT2B_3, w.y2, w.x2out, 4, 256, 3, 1, nullptr, 0));
-    upsample(w.x2out, w.up2, 4, CP);
-    LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.up2, 0));
+    if (upf) {
+        LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.x2out, 0, true));
+    } else {
+        upsample(w.x2out, w.up2, 4, CP);
+        LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.up2, 0));
+    }
     LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, 2, CP, 3, 1, nullptr, 2));
     LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, 2, CP, 3, 1, nullptr, 0));
 

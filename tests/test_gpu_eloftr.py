@@ -3,7 +3,7 @@
 Bar: every intermediate map within 2e-4 of its magnitude; the coarse match list (b, i, j) identical, or different only
 where the oracle's confidence is within 1e-4 of the threshold / of its mutual-maximum rival (audited, not waved
 through); confidences within 1e-4; refined key-points within 2e-3 px wherever both sides picked the same fine window
-positions, and where the first-stage argmax differs the oracle's two candidates must be tied to 1e-5.
+positions, and where the first-stage argmax differs the oracle's two candidates must be tied to 5e-5 (relative).
 Pairs are two crops of one synthetic scene offset by a multiple of 8 px (`make_shifted_pair`), so that the shaped
 random weights give hundreds of confident mutual matches and the whole fine path is exercised.
 """
@@ -89,7 +89,10 @@ def _case(h, w, B, sd, thr, min_matches, shifts=((16, 8), (-8, 24), (0, 0), (24,
         s = a0 @ a1.transpose(-1, -2)
         cf = (F.softmax(s, 1) * F.softmax(s, 2)).reshape(-1, 64, 10, 10)[..., 1:-1, 1:-1].reshape(len(u0), -1)
         top = cf.topk(2, -1).values
-        assert ((top[:, 0] - top[:, 1]) < 1e-5 * top[:, 0]).all(), f"{int((~same).sum())} fine positions differ without a tie"
+        # a tie: an error d of a window similarity moves its confidence by 2 d, relatively; the f32 similarities (56-term dot
+        # products of magnitude |s| ~ 20 here) carry d ~ 1e-5, so candidates closer than 5e-5 cannot be told apart in f32
+        rel = (top[:, 0] - top[:, 1]) / top[:, 0]
+        assert (rel < 5e-5).all(), f"{int((~same).sum())} fine positions differ without a tie (relative gaps {rel.tolist()})"
     assert same.float().mean().item() > 0.98
     return len(want)
 
