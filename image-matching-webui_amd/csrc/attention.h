@@ -14,7 +14,7 @@ struct AttnP {
     const int* cnt = nullptr;   // valid rows per sequence
     const int* active = nullptr;  // per pair (seq >> 1), may be null
     int nseq = 0, heads = 4, rows_per_seq = 0;
-    int cross = 0;  // 0: keys/values of the same sequence; 1: of the partner image (seq ^ 1)
+    int cross = 0;  // 0: keys/values of the same sequence; 1: of the partner image (seq ^ 1); 2: of sequence (seq + nseq / 2) % nseq
     // 1: Q (hence Q.K) was pre-multiplied by log2(e) by the producer, soft-max = exp2(s - max): the split kernel then needs no
     // multiply per probability (the layers set it; the C-ABI building block passes natural-log operands, 0)
     int log2_domain = 0;

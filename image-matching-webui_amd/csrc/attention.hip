@@ -16,6 +16,14 @@
 #define KT 64        // keys per tile
 #define KSTR 65      // padded key stride of the K image (float4 units)
 
+// sequence whose keys / values sequence `seq` attends to
+__device__ __forceinline__ int attn_key_seq(const AttnP& p, int seq) {
+    if (p.cross == 0) return seq;
+    if (p.cross == 1) return seq ^ 1;
+    const int half = p.nseq >> 1;  // cross == 2: the sequences are [views 1 of all pairs | views 2 of all pairs]
+    return seq < half ? seq + half : seq - half;
+}
+
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // one LDS object: K image [d-quad][key] (float4), then V [key][d]; the front of it is
     // reused as the per-wave output transpose buffer after the last tile
@@ -35,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     const int nq = p.cnt[seq];
     if (q0 >= nq) return;
     if (p.active && p.active[seq >> 1] == 0) return;
-    const int kseq = p.cross ? (seq ^ 1) : seq;
+    const int kseq = attn_key_seq(p, seq);
     const int nk = p.cnt[kseq];
     const int R = p.rows_per_seq;
 
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     const int nq = p.cnt[seq];
     if (q0 >= nq) return;
     if (p.active && p.active[seq >> 1] == 0) return;
-    const int kseq = p.cross ? (seq ^ 1) : seq;
+    const int kseq = attn_key_seq(p, seq);
     const int nk = p.cnt[kseq];
     const int R = p.rows_per_seq;
     const size_t plane = (size_t)p.nseq * p.heads * R * 64;  // halves per plane

@@ -1,0 +1,607 @@
+// DUSt3R pair network on MI355X: what `dust3r.inference.inference(pairs, self.net, ...)` computes for
+// imcui/hloc/matchers/duster.py:58-74 (`AsymmetricCroCo3DStereo`, ViT-L encoder / ViT-B decoder / DPT head, the
+// un-vendored `third_party/dust3r` submodule; BASELINE config 5).  3 x f16 split mode only.
+//
+//   encoder   every IMAGE is encoded once (the reference encodes both images again for the swapped pair): 16x16 patches as a
+//             GEMM, then per block LayerNorm -> qkv GEMM -> RoPE2D + f16 planes -> the flash attention kernel of attention.hip
+//             (head_dim 64, the LightGlue kernel) -> projection GEMM with the residual in its epilogue -> LayerNorm -> fc1 GEMM with
+//             GELU in its epilogue -> fc2 GEMM with the residual.
+//   decoder   token streams [view 1 of every directed pair | view 2 of every directed pair]; the first half runs through
+//             `dec_blocks`, the second through `dec_blocks2`.  Per block: keys / values of the cross attention from the OTHER
+//             half's tokens as they are before the block, self attention, cross attention (attention kernel with key
+//             sequence (seq + P) % 2P), MLP.
+//   head      DPT over four hooked token maps (NHWC = token-major rows, so the reassembly is GEMMs plus a pixel shuffle for
+//             the kernel = stride transposed convolutions), 3x3 convolutions on the patch-staging kernel of conv.hip, bilinear x2
+//             (align_corners=True), then 1x1 128 -> 4 fused with the point-map post-processing.
+// Token rows are padded to R = roundup(T, 128) per sequence; GEMMs skip the tiles past T, LayerNorm / element-wise kernels run
+// over them harmlessly (row-wise arithmetic), the plane-split kernels write zeros there.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "attention.h"
+#include "conv.h"
+#include "dust3r_kernels.h"
+#include "gemm.h"
+#include "imcui_hip.h"
+
+// ------------------------------------------------------------------ layer table
+struct DuCfg {
+    int E, enc_depth, D, dec_depth;
+};
+static const int DU_LD[4] = {96, 192, 384, 768};
+enum { DU_HEAD_LAYERS = 33, DU_ENC_J = 4, DU_DEC_J = 7 };
+// encoder block: qkv, proj, fc1, fc2.  decoder block: qkv, proj, cross q, cross [k | v], cross proj, fc1, fc2.
+// head: 0 act1 1x1 | 1 act1 transposed 4x4/4 | 2 act2 1x1 | 3 act2 transposed 2x2/2 | 4 act3 1x1 | 5 act4 1x1 | 6 act4 3x3/2 |
+//       7-10 layer_rn | 11 + 5 q + {rcu1.conv1, rcu1.conv2, rcu2.conv1, rcu2.conv2, out_conv} for refinenet 4 - q | 31 head.0 | 32 head.2
+static int du_l_enc(const DuCfg&, int i, int j) { return 1 + DU_ENC_J * i + j; }
+static int du_l_demb(const DuCfg& c) { return 1 + DU_ENC_J * c.enc_depth; }
+static int du_l_dec(const DuCfg& c, int s, int i, int j) { return du_l_demb(c) + 1 + (s * c.dec_depth + i) * DU_DEC_J + j; }
+static int du_l_head(const DuCfg& c, int hd) { return du_l_demb(c) + 1 + 2 * c.dec_depth * DU_DEC_J + hd * DU_HEAD_LAYERS; }
+static int du_nlayers(const DuCfg& c) { return du_l_head(c, 2); }
+
+// kind 0: GEMM weight [N][K] -> fragment-major planes; 1: 3x3 stride-1 convolution [N][9][Cin] -> planes of conv3x3_split_kernel
+static void du_shape(const DuCfg& c, int li, int* N, int* K, int* kind) {
+    *kind = 0;
+    const int E = c.E, D = c.D;
+    if (li == 0) {
+        *N = E;
+        *K = 768;
+        return;
+    }
+    if (li < du_l_demb(c)) {
+        const int j = (li - 1) % DU_ENC_J;
+        *N = j == 0 ? 3 * E : j == 2 ? 4 * E : E;
+        *K = j == 3 ? 4 * E : E;
+        return;
+    }
+    if (li == du_l_demb(c)) {
+        *N = D;
+        *K = E;
+        return;
+    }
+    if (li < du_l_head(c, 0)) {
+        const int j = (li - du_l_demb(c) - 1) % DU_DEC_J;
+        *N = j == 0 ? 3 * D : j == 3 ? 2 * D : j == 5 ? 4 * D : D;
+        *K = j == 6 ? 4 * D : D;
+        return;
+    }
+    const int j = (li - du_l_head(c, 0)) % DU_HEAD_LAYERS;
+    static const int tabN[7] = {96, 96 * 16, 192, 192 * 4, 384, 768, 768};
+    if (j < 7) {
+        const int tabK[7] = {E, 96, D, 192, D, D, 9 * 768};
+        *N = tabN[j];
+        *K = tabK[j];
+        return;
+    }
+    if (j < 11) {
+        *N = 256;
+        *K = 9 * DU_LD[j - 7];
+        *kind = 1;
+        return;
+    }
+    if (j < 31) {
+        const int u = (j - 11) % 5;
+        *N = 256;
+        *K = u == 4 ? 256 : 9 * 256;
+        *kind = u == 4 ? 0 : 1;
+        return;
+    }
+    *N = 128;
+    *K = j == 31 ? 9 * 256 : 9 * 128;
+    *kind = 1;
+}
+
+// f32 vectors: encoder block i: 4 i + {norm1.w, norm1.b, norm2.w, norm2.b}; enc_norm; decoder (side s, block i): 8 (s dec_depth + i)
+// + {norm1, norm2, norm_y, norm3} x {w, b}; dec_norm; head hd: head.4 weight [4][128], bias [4]; rotary inv_freq [16]
+static int du_v_enc(const DuCfg&, int i, int j) { return 4 * i + j; }
+static int du_v_encn(const DuCfg& c) { return 4 * c.enc_depth; }
+static int du_v_dec(const DuCfg& c, int s, int i, int j) { return du_v_encn(c) + 2 + 8 * (s * c.dec_depth + i) + j; }
+static int du_v_decn(const DuCfg& c) { return du_v_encn(c) + 2 + 16 * c.dec_depth; }
+static int du_v_head(const DuCfg& c, int hd) { return du_v_decn(c) + 2 + 2 * hd; }
+static int du_v_invf(const DuCfg& c) { return du_v_decn(c) + 6; }
+static int du_nvec(const DuCfg& c) { return du_v_invf(c) + 1; }
+static int du_vec_len(const DuCfg& c, int vi) {
+    if (vi < du_v_encn(c) + 2) return c.E;
+    if (vi < du_v_decn(c) + 2) return c.D;
+    if (vi == du_v_invf(c)) return 16;
+    return ((vi - du_v_decn(c) - 2) & 1) ? 4 : 512;
+}
+
+static bool du_cfg_ok(const DuCfg& c) {
+    return c.E >= 64 && c.E <= 1024 && c.E % 64 == 0 && c.D >= 64 && c.D <= 1024 && c.D % 64 == 0 && c.enc_depth >= 1 && c.dec_depth >= 4 &&
+           c.dec_depth % 4 == 0;
+}
+
+struct DuLayout {
+    std::vector<size_t> b, wh, wl, ws, vec;
+    size_t total;
+};
+static DuLayout du_layout(const DuCfg& c) {
+    DuLayout l;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t r = off;
+        off += align_up(n, 64);
+        return r;
+    };
+    const int nl = du_nlayers(c);
+    l.b.resize(nl);
+    l.wh.resize(nl);
+    l.wl.resize(nl);
+    l.ws.resize(nl);
+    for (int i = 0; i < nl; ++i) {
+        int N, K, kind;
+        du_shape(c, i, &N, &K, &kind);
+        const size_t rows = kind == 1 ? (size_t)N : (size_t)((N + 31) / 32 * 32);
+        l.b[i] = take((size_t)(N + 3) / 4 * 4 + 64);  // conv3x3_split_kernel reads whole 64-channel bias groups
+        l.wh[i] = take(rows * K / 2);
+        l.wl[i] = take(rows * K / 2);
+        l.ws[i] = take(64);
+    }
+    const int nv = du_nvec(c);
+    l.vec.resize(nv);
+    for (int i = 0; i < nv; ++i) l.vec[i] = take(du_vec_len(c, i));
+    l.total = off;
+    return l;
+}
+
+static DuCfg du_cfg(int enc_dim, int enc_depth, int dec_dim, int dec_depth) { return DuCfg{enc_dim, enc_depth, dec_dim, dec_depth}; }
+
+extern "C" size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    return du_cfg_ok(c) ? du_layout(c).total : 0;
+}
+extern "C" int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    return du_cfg_ok(c) ? du_nlayers(c) : 0;
+}
+extern "C" int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    return du_cfg_ok(c) ? du_nvec(c) : 0;
+}
+extern "C" int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i, int* N, int* K) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c) || i < 0 || i >= du_nlayers(c) || !N || !K) return IMCUI_ERR_ARG;
+    int kind;
+    du_shape(c, i, N, K, &kind);
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c) || i < 0 || i >= du_nvec(c)) return 0;
+    return du_vec_len(c, i);
+}
+
+// w[i]: [N][K] f32 (convolutions in the implicit-GEMM order [Cout][tap][Cin], transposed convolutions as [(dy, dx, cout)][cin]),
+// b[i]: [N] or null (zero), vec[i]: the f32 vectors in the order above.  The layers are split on a few host threads.
+extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* const* w,
+                                             const float* const* b, const float* const* vec, float* packed) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c) || !w || !b || !vec || !packed) return IMCUI_ERR_ARG;
+    const DuLayout l = du_layout(c);
+    const int nl = du_nlayers(c), nv = du_nvec(c);
+    for (int i = 0; i < nl; ++i)
+        if (!w[i]) return IMCUI_ERR_ARG;
+    for (int i = 0; i < nv; ++i)
+        if (!vec[i]) return IMCUI_ERR_ARG;
+    memset(packed, 0, l.total * sizeof(float));
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (nthr == 0) nthr = 1;
+    if (nthr > 16) nthr = 16;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthr; ++t)
+        pool.emplace_back([&, t]() {
+            for (int i = (int)t; i < nl; i += (int)nthr) {
+                int N, K, kind;
+                du_shape(c, i, &N, &K, &kind);
+                if (b[i]) memcpy(packed + l.b[i], b[i], (size_t)N * sizeof(float));
+                unsigned short* hi = reinterpret_cast<unsigned short*>(packed + l.wh[i]);
+                unsigned short* lo = reinterpret_cast<unsigned short*>(packed + l.wl[i]);
+                packed[l.ws[i]] = kind == 1 ? pack_conv3x3_split_from_gemm(w[i], N, K / 9, hi, lo) : split_weights_frag_host(w[i], N, K, hi, lo);
+            }
+        });
+    for (auto& th : pool) th.join();
+    for (int i = 0; i < nv; ++i) memcpy(packed + l.vec[i], vec[i], (size_t)du_vec_len(c, i) * sizeof(float));
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+struct DuWs {
+    float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
+    float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2;
+    int *cnt, *smap;
+    size_t total;
+    bool ok;
+};
+static int du_R(int H, int W) { return ((H / 16) * (W / 16) + 127) / 128 * 128; }
+static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int H, int W) {
+    WsAlloc a(ws, bytes);
+    DuWs w;
+    const size_t E = c.E, D = c.D;
+    const size_t T = (size_t)(H / 16) * (W / 16), R = du_R(H, W);
+    const size_t me = (size_t)NI * R, md = (size_t)2 * P * R;
+    const size_t mx = me * E > md * D ? me * E : md * D;  // largest token buffer of either stage
+    w.A0 = a.get<float>(me * 768);
+    w.x = a.get<float>(me * E);
+    w.xn = a.get<float>(mx);
+    w.qkv = a.get<float>(3 * mx);
+    w.qp = a.get<float>(mx);  // two f16 planes each
+    w.kp = a.get<float>(mx);
+    w.vp = a.get<float>(mx);
+    w.kc = a.get<float>(md * D);
+    w.vc = a.get<float>(md * D);
+    w.att = a.get<float>(mx);
+    w.hid = a.get<float>(4 * mx);
+    w.fenc = a.get<float>(me * E);
+    w.g = a.get<float>(me * D);
+    w.y = a.get<float>(md * D);
+    w.qc = a.get<float>(md * D);
+    const size_t bt = (size_t)2 * P * T;  // dense token rows of both views
+    w.tok0 = a.get<float>(bt * E);
+    for (int k = 0; k < 3; ++k) w.hook[k] = a.get<float>(bt * D);
+    const size_t pt = (size_t)P * T;  // one view: P maps of T cells
+    w.ta = a.get<float>(pt * 768);
+    w.tb = a.get<float>(pt * 1536);
+    w.tm = a.get<float>(pt * 16 * 96 > pt * 768 ? pt * 16 * 96 : pt * 768);
+    w.rn[0] = a.get<float>(pt * 16 * 256);
+    w.rn[1] = a.get<float>(pt * 4 * 256);
+    w.rn[2] = a.get<float>(pt * 256);
+    w.rn[3] = a.get<float>(pt * 256);  // (h / 2)(w / 2) <= T / 4 rounded up: T is plenty
+    w.s0 = a.get<float>(pt * 16 * 256);
+    w.s1 = a.get<float>(pt * 16 * 256);
+    w.s2 = a.get<float>(pt * 16 * 256);
+    w.s3 = a.get<float>(pt * 64 * 256);
+    w.pa = a.get<float>(pt * 64 * 256);
+    w.pb = a.get<float>(pt * 64 * 256);
+    w.hd0 = a.get<float>(pt * 64 * 128);
+    w.hd1 = a.get<float>(pt * 256 * 128);
+    w.hd2 = a.get<float>(pt * 256 * 128);
+    w.cnt = a.get<int>((size_t)(NI > 2 * P ? NI : 2 * P) + 64);
+    w.smap = a.get<int>((size_t)2 * P + 64);
+    w.total = a.off;
+    w.ok = a.ok;
+    return w;
+}
+static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0; }
+
+extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
+    return du_carve(nullptr, 0, c, NI, P, H, W).total;
+}
+
+// floats the optional dump of the forward holds: (enc_depth + 2) x [NI R E] (patch embedding, every block, enc_norm), (dec_depth + 2) x
+// [2P R D] (embedded streams, every block, dec_norm), then per view: layer_rn 0..3, path 4..1, the 128-channel full-resolution
+// feature map, the raw [P H W 4] regression
+extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
+    const size_t R = du_R(H, W), h = H / 16, w = W / 16, p = P;
+    size_t n = (size_t)(c.enc_depth + 2) * NI * R * c.E + (size_t)(c.dec_depth + 2) * 2 * P * R * c.D;
+    const size_t per_view = p * 256 * (16 * h * w + 4 * h * w + h * w + (h / 2) * (w / 2))   // layer_rn
+                            + p * 256 * (h * w + 4 * h * w + 16 * h * w + 64 * h * w)          // paths 4, 3, 2, 1
+                            + p * (size_t)H * W * 128 + p * (size_t)H * W * 4;
+    return n + 2 * per_view;
+}
+
+// ------------------------------------------------------------------ forward
+// images [NI,3,H,W] in [0,1]; pairs (device) [P][2]: directed pair p = (view 1 image, view 2 image), indices clamped to [0, NI).
+// Outputs, view-major:
+// pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W].
+extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* packed,
+                                        const float* images, int NI, int H, int W, const int* pairs, int P, float* pts3d, float* conf,
+                                        float* dump, size_t dump_floats, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    if (!du_cfg_ok(c)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: unsupported configuration (dims multiples of 64 up to 1024, dec_depth a multiple of 4)");
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
+    if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 32", NI, W, H, P);
+    if (!packed || !images || !pairs || !pts3d || !conf) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
+    if (((size_t)(c.E / 64) * NI) % 8 != 0 || ((size_t)(c.D / 64) * 2 * P) % 8 != 0)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: heads x sequences must be a multiple of 8 (encoder %d x %d, decoder %d x %d)", c.E / 64, NI, c.D / 64, 2 * P);
+    DuWs w = du_carve(ws, ws_bytes, c, NI, P, H, W);
+    if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "dust3r: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const DuLayout l = du_layout(c);
+    const float* Pk = packed;
+    const int E = c.E, D = c.D, hg = H / 16, wg = W / 16, T = hg * wg, R = du_R(H, W);
+    const dim3 blk(256);
+    int rc;
+#define DURUN(x)                       \
+    do {                               \
+        rc = (x);                      \
+        if (rc != IMCUI_OK) return rc; \
+    } while (0)
+    auto blocks = [](long n) { return dim3((unsigned)(n < 256 ? 1 : (n + 255) / 256 > 65536 * 16 ? 65536 * 16 : (n + 255) / 256)); };
+    size_t dump_off = 0;
+    bool dump_ok = true;
+    auto dump_take = [&](size_t n) -> float* {
+        if (!dump) return nullptr;
+        if (dump_off + n > dump_floats) {
+            dump_ok = false;
+            return nullptr;
+        }
+        float* r = dump + dump_off;
+        dump_off += n;
+        return r;
+    };
+    auto dump_copy = [&](const float* src, size_t n) {
+        float* d = dump_take(n);
+        if (d) hipMemcpyAsync(d, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    };
+    const float* vecs = Pk;
+    auto V = [&](int vi) { return vecs + l.vec[vi]; };
+
+    // linear layer li on `nseq` sequences of R rows (T live): C = act(A W^T + b + resid)
+    auto lin = [&](int li, const float* A, float* C, int nseq, const float* resid, int act) -> int {
+        int N, K, kind;
+        du_shape(c, li, &N, &K, &kind);
+        GemmP g;
+        g.epi = EPI_CONV;
+        g.N = N;
+        g.K = K;
+        g.ldw = K;
+        g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[li]);
+        g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[li]);
+        g.wscale = Pk + l.ws[li];
+        g.bias = Pk + l.b[li];
+        g.A = A;
+        g.lda = K;
+        g.C = C;
+        g.ldc = N;
+        g.resid = resid;
+        g.ldr = N;
+        g.act = act;
+        g.M = nseq * R;
+        g.cnt = w.cnt;
+        g.rows_per_seq = R;
+        return gemm_launch(h, g, stream);
+    };
+    // the same on dense rows (DPT head)
+    auto lin_dense = [&](int li, const float* A, float* C, long rows) -> int {
+        int N, K, kind;
+        du_shape(c, li, &N, &K, &kind);
+        GemmP g;
+        g.epi = EPI_CONV;
+        g.N = N;
+        g.K = K;
+        g.ldw = K;
+        g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[li]);
+        g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[li]);
+        g.wscale = Pk + l.ws[li];
+        g.bias = Pk + l.b[li];
+        g.A = A;
+        g.lda = K;
+        g.C = C;
+        g.ldc = N;
+        g.M = (int)rows;
+        return gemm_launch(h, g, stream);
+    };
+    auto layernorm = [&](const float* x, int vi, float* out, long rows, int C) {
+        hipLaunchKernelGGL(du_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, x, V(vi), V(vi + 1), out, rows, C, 1e-6f);
+    };
+    const float q_alpha = 0.125f * 1.44269504088896340736f;  // 1 / sqrt(64) and log2(e): the attention kernel works in base 2
+    // q / k planes of `nseq` sequences read from src[:, col0 : col0 + C]
+    auto rope_split = [&](const float* src, long ld, int col0, int C, int nseq, float* planes, int nseq_planes, int seq_out0, float alpha) {
+        const long n = (long)nseq * R * (C / 64) * 4;
+        hipLaunchKernelGGL(du_rope_split_kernel, blocks(n), blk, 0, stream, src, ld, col0, C / 64, T, R, wg, V(du_v_invf(c)), alpha, 1,
+                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0, n);
+    };
+    auto vt_split = [&](const float* src, long ld, int col0, int C, int nseq, float* planes, int nseq_planes, int seq_out0) {
+        hipLaunchKernelGGL(du_vt_split_kernel, dim3((unsigned)(nseq * (C / 64) * (R / 64))), blk, 0, stream, src, ld, col0, C / 64, T, R,
+                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0);
+    };
+    auto attend = [&](const float* q, const float* k, const float* v, float* out, int nseq, int C, int cross) -> int {
+        AttnP a;
+        a.Q = q;
+        a.K = k;
+        a.V = v;
+        a.O = out;
+        a.cnt = w.cnt;
+        a.nseq = nseq;
+        a.heads = C / 64;
+        a.rows_per_seq = R;
+        a.cross = cross;
+        a.log2_domain = 1;
+        return attention_launch(h, a, stream);
+    };
+
+    {
+        const int ncnt = NI > 2 * P ? NI : 2 * P;
+        hipLaunchKernelGGL(du_fill_int_kernel, dim3((unsigned)cdiv(ncnt, 256)), blk, 0, stream, w.cnt, T, ncnt);
+        // stream s < P: view 1 of pair s, stream P + s: view 2
+        hipLaunchKernelGGL(du_smap_kernel, dim3((unsigned)cdiv(2 * P, 256)), blk, 0, stream, pairs, w.smap, P, NI);
+    }
+
+    // ---- encoder: every image once
+    const long me = (long)NI * R;
+    {
+        const long n4 = me * 192;
+        hipLaunchKernelGGL(du_patchify_kernel, blocks(n4), blk, 0, stream, images, w.A0, H, W, T, R, n4);
+        IMCUI_CHECK_LAUNCH(h);
+        DURUN(lin(0, w.A0, w.x, NI, nullptr, 0));
+        dump_copy(w.x, (size_t)me * E);
+    }
+    for (int i = 0; i < c.enc_depth; ++i) {
+        layernorm(w.x, du_v_enc(c, i, 0), w.xn, me, E);
+        DURUN(lin(du_l_enc(c, i, 0), w.xn, w.qkv, NI, nullptr, 0));
+        rope_split(w.qkv, 3 * E, 0, E, NI, w.qp, NI, 0, q_alpha);
+        rope_split(w.qkv, 3 * E, E, E, NI, w.kp, NI, 0, 1.0f);
+        vt_split(w.qkv, 3 * E, 2 * E, E, NI, w.vp, NI, 0);
+        IMCUI_CHECK_LAUNCH(h);
+        DURUN(attend(w.qp, w.kp, w.vp, w.att, NI, E, 0));
+        DURUN(lin(du_l_enc(c, i, 1), w.att, w.x, NI, w.x, 0));
+        layernorm(w.x, du_v_enc(c, i, 2), w.xn, me, E);
+        DURUN(lin(du_l_enc(c, i, 2), w.xn, w.hid, NI, nullptr, 3));
+        DURUN(lin(du_l_enc(c, i, 3), w.hid, w.x, NI, w.x, 0));
+        dump_copy(w.x, (size_t)me * E);
+    }
+    layernorm(w.x, du_v_encn(c), w.fenc, me, E);
+    dump_copy(w.fenc, (size_t)me * E);
+
+    // ---- decoder
+    const long md = (long)2 * P * R, ms = (long)P * R;  // rows of all streams / of one side
+    DURUN(lin(du_l_demb(c), w.fenc, w.g, NI, nullptr, 0));
+    {
+        const long n4 = md * (D / 4);
+        hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, w.g, w.smap, w.y, R, R, D / 4, n4);
+        IMCUI_CHECK_LAUNCH(h);
+        dump_copy(w.y, (size_t)md * D);
+    }
+    const int hooks[3] = {c.dec_depth * 2 / 4, c.dec_depth * 3 / 4, c.dec_depth};
+    auto save_hook = [&](const float* src, int k) {
+        const long n4 = (long)2 * P * T * (D / 4);
+        hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, src, (const int*)nullptr, w.hook[k], R, T, D / 4, n4);
+    };
+    for (int i = 0; i < c.dec_depth; ++i) {
+        // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block
+        for (int s = 0; s < 2; ++s) {
+            const int o = 1 - s;
+            layernorm(w.y + (size_t)o * ms * D, du_v_dec(c, s, i, 4), w.xn, ms, D);
+            DURUN(lin(du_l_dec(c, s, i, 3), w.xn, w.qkv, P, nullptr, 0));
+            rope_split(w.qkv, 2 * D, 0, D, P, w.kc, 2 * P, o * P, 1.0f);
+            vt_split(w.qkv, 2 * D, D, D, P, w.vc, 2 * P, o * P);
+        }
+        // self attention
+        for (int s = 0; s < 2; ++s) {
+            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, ms, D);
+            DURUN(lin(du_l_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, w.qkv + (size_t)s * ms * 3 * D, P, nullptr, 0));
+        }
+        rope_split(w.qkv, 3 * D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
+        rope_split(w.qkv, 3 * D, D, D, 2 * P, w.kp, 2 * P, 0, 1.0f);
+        vt_split(w.qkv, 3 * D, 2 * D, D, 2 * P, w.vp, 2 * P, 0);
+        IMCUI_CHECK_LAUNCH(h);
+        DURUN(attend(w.qp, w.kp, w.vp, w.att, 2 * P, D, 0));
+        for (int s = 0; s < 2; ++s) DURUN(lin(du_l_dec(c, s, i, 1), w.att + (size_t)s * ms * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
+        // cross attention
+        for (int s = 0; s < 2; ++s) {
+            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, ms, D);
+            DURUN(lin(du_l_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, w.qc + (size_t)s * ms * D, P, nullptr, 0));
+        }
+        rope_split(w.qc, D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
+        IMCUI_CHECK_LAUNCH(h);
+        DURUN(attend(w.qp, w.kc, w.vc, w.att, 2 * P, D, 2));
+        for (int s = 0; s < 2; ++s) DURUN(lin(du_l_dec(c, s, i, 4), w.att + (size_t)s * ms * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
+        // MLP
+        for (int s = 0; s < 2; ++s) {
+            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 6), w.xn + (size_t)s * ms * D, ms, D);
+            DURUN(lin(du_l_dec(c, s, i, 5), w.xn + (size_t)s * ms * D, w.hid + (size_t)s * ms * 4 * D, P, nullptr, 3));
+            DURUN(lin(du_l_dec(c, s, i, 6), w.hid + (size_t)s * ms * 4 * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
+        }
+        dump_copy(w.y, (size_t)md * D);
+        for (int k = 0; k < 2; ++k)
+            if (i + 1 == hooks[k]) save_hook(w.y, k);
+    }
+    layernorm(w.y, du_v_decn(c), w.xn, md, D);
+    dump_copy(w.xn, (size_t)md * D);
+    save_hook(w.xn, 2);
+    {
+        const long n4 = (long)2 * P * T * (E / 4);
+        hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, w.fenc, w.smap, w.tok0, R, T, E / 4, n4);
+    }
+    IMCUI_CHECK_LAUNCH(h);
+
+    // ---- DPT heads (view v: downstream_head{v + 1} on the tokens of the streams [v P, (v + 1) P))
+    const long pt = (long)P * T;
+    for (int v = 0; v < 2; ++v) {
+        const int L0 = du_l_head(c, v);
+        auto conv3 = [&](int li, const float* in, float* out, int hh, int ww, int act, const float* resid) -> int {
+            int N, K, kind;
+            du_shape(c, li, &N, &K, &kind);
+            return conv3x3_split_launch(h, in, reinterpret_cast<const unsigned short*>(Pk + l.wh[li]), reinterpret_cast<const unsigned short*>(Pk + l.wl[li]),
+                                        Pk + l.ws[li], Pk + l.b[li], out, P, hh, ww, K / 9, N, act, 0, stream, resid);
+        };
+        auto shuffle = [&](const float* src, float* dst, int s, int C) {
+            const long n4 = pt * s * s * (C / 4);
+            hipLaunchKernelGGL(du_pixel_shuffle_kernel, blocks(n4), blk, 0, stream, src, dst, hg, wg, s, C / 4, n4);
+        };
+        const float* tok0 = w.tok0 + (size_t)v * pt * E;
+        const float* hk[3] = {w.hook[0] + (size_t)v * pt * D, w.hook[1] + (size_t)v * pt * D, w.hook[2] + (size_t)v * pt * D};
+        // reassemble: 1/4, 1/8, 1/16, 1/32
+        DURUN(lin_dense(L0 + 0, tok0, w.ta, pt));
+        DURUN(lin_dense(L0 + 1, w.ta, w.tb, pt));
+        shuffle(w.tb, w.tm, 4, 96);
+        DURUN(conv3(L0 + 7, w.tm, w.rn[0], 4 * hg, 4 * wg, 0, nullptr));
+        DURUN(lin_dense(L0 + 2, hk[0], w.ta, pt));
+        DURUN(lin_dense(L0 + 3, w.ta, w.tb, pt));
+        shuffle(w.tb, w.tm, 2, 192);
+        DURUN(conv3(L0 + 8, w.tm, w.rn[1], 2 * hg, 2 * wg, 0, nullptr));
+        DURUN(lin_dense(L0 + 4, hk[1], w.ta, pt));
+        DURUN(conv3(L0 + 9, w.ta, w.rn[2], hg, wg, 0, nullptr));
+        DURUN(lin_dense(L0 + 5, hk[2], w.ta, pt));
+        {
+            int N, K, kind;
+            du_shape(c, L0 + 6, &N, &K, &kind);
+            GemmP g;  // 3x3 stride 2, padding 1: the implicit-im2col GEMM
+            g.epi = EPI_CONV;
+            g.N = N;
+            g.K = K;
+            g.ldw = K;
+            g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[L0 + 6]);
+            g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[L0 + 6]);
+            g.wscale = Pk + l.ws[L0 + 6];
+            g.bias = Pk + l.b[L0 + 6];
+            g.A = w.ta;
+            g.conv_k = 3;
+            g.conv_stride = 2;
+            g.conv_pad = 1;
+            g.conv_hin = hg;
+            g.conv_win = wg;
+            g.conv_hout = hg / 2;
+            g.conv_wout = wg / 2;
+            g.conv_cin = 768;
+            g.M = P * (hg / 2) * (wg / 2);
+            g.C = w.tm;
+            g.ldc = N;
+            DURUN(gemm_launch(h, g, stream));
+        }
+        DURUN(conv3(L0 + 10, w.tm, w.rn[3], hg / 2, wg / 2, 0, nullptr));
+        const int rh[4] = {4 * hg, 2 * hg, hg, hg / 2}, rw[4] = {4 * wg, 2 * wg, wg, wg / 2};
+        for (int k = 0; k < 4; ++k) dump_copy(w.rn[k], (size_t)P * rh[k] * rw[k] * 256);
+        // fusion: refinenet 4, 3, 2, 1
+        const float* path = nullptr;
+        for (int q = 0; q < 4; ++q) {
+            const int lv = 3 - q, hh = rh[lv], ww = rw[lv];
+            const long n4 = (long)P * hh * ww * 64;
+            const int Lq = L0 + 11 + 5 * q;
+            const float* xres;
+            if (q == 0) {
+                hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[3], w.s1, n4);
+                xres = w.rn[3];
+            } else {
+                hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[lv], w.s0, n4);
+                DURUN(conv3(Lq + 0, w.s0, w.s1, hh, ww, 1, nullptr));
+                DURUN(conv3(Lq + 1, w.s1, w.s0, hh, ww, 0, w.rn[lv]));
+                hipLaunchKernelGGL(du_add_relu_kernel, blocks(n4), blk, 0, stream, path, w.s0, w.s2, w.s1, n4);
+                xres = w.s2;
+            }
+            DURUN(conv3(Lq + 2, w.s1, w.s0, hh, ww, 1, nullptr));
+            DURUN(conv3(Lq + 3, w.s0, w.s1, hh, ww, 0, xres));
+            hipLaunchKernelGGL(du_upsample2_kernel, blocks(4 * n4), blk, 0, stream, w.s1, w.s3, hh, ww, 64, 4 * n4);
+            float* out = (q & 1) ? w.pb : w.pa;
+            DURUN(lin_dense(Lq + 4, w.s3, out, (long)P * 4 * hh * ww));
+            path = out;
+            dump_copy(out, (size_t)P * 4 * hh * ww * 256);
+        }
+        // head: 3x3 256 -> 128 at 1/2, x2, 3x3 128 -> 128 + ReLU, 1x1 128 -> 4 + post-processing
+        DURUN(conv3(L0 + 31, path, w.hd0, H / 2, W / 2, 0, nullptr));
+        {
+            const long n4 = (long)P * H * W * 32;
+            hipLaunchKernelGGL(du_upsample2_kernel, blocks(n4), blk, 0, stream, w.hd0, w.hd1, H / 2, W / 2, 32, n4);
+        }
+        DURUN(conv3(L0 + 32, w.hd1, w.hd2, H, W, 1, nullptr));
+        const long npix = (long)P * H * W;
+        dump_copy(w.hd2, (size_t)npix * 128);
+        float* raw = dump_take((size_t)npix * 4);
+        hipLaunchKernelGGL(du_regress_kernel, blocks(npix * 32), blk, 0, stream, w.hd2, V(du_v_head(c, v)), V(du_v_head(c, v) + 1),
+                           pts3d + (size_t)v * npix * 3, conf + (size_t)v * npix, raw, npix);
+        IMCUI_CHECK_LAUNCH(h);
+    }
+    if (!dump_ok) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: dump buffer too small (%zu floats)", dump_floats);
+    return IMCUI_OK;
+}

@@ -12,7 +12,7 @@ enum GemmEpi {
     EPI_RESID = 2,  // C += acc + bias                  (in-place residual)
     EPI_QKV = 3,    // LightGlue SelfBlock: bias, RoPE on q/k, q *= alpha, head-major split
     EPI_CROSS = 4,  // LightGlue CrossBlock: [qk | v] = bias, qk *= alpha, head-major split
-    EPI_CONV = 5,   // C = act(acc + bias + resid): act 0 none / 1 ReLU / 2 LeakyReLU(0.01)
+    EPI_CONV = 5,   // C = act(acc + bias + resid): act 0 none / 1 ReLU / 2 LeakyReLU(0.01) / 3 GELU (erf)
 };
 
 struct GemmP {

@@ -612,6 +612,160 @@ class ELoFTRHIP:
         return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
 
 
+DUST3R_CFG = {"enc_dim": 1024, "enc_depth": 24, "dec_dim": 768, "dec_depth": 12}  # DUSt3R_ViTLarge_BaseDecoder_512_dpt
+
+
+def dust3r_cfg_of(state_dict: dict) -> dict:
+    """Architecture of an `AsymmetricCroCo3DStereo` state dict (dims from the tensors, depths from the block indices)."""
+    def depth(prefix):
+        return 1 + max(int(k[len(prefix) :].split(".")[0]) for k in state_dict if k.startswith(prefix))
+
+    return {
+        "enc_dim": state_dict["patch_embed.proj.weight"].shape[0],
+        "enc_depth": depth("enc_blocks."),
+        "dec_dim": state_dict["decoder_embed.weight"].shape[0],
+        "dec_depth": depth("dec_blocks."),
+    }
+
+
+def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
+    """`AsymmetricCroCo3DStereo` state dict (head_type 'dpt', upstream names; imcui/hloc/matchers/duster.py:37) -> (packed
+    float32 host buffer, cfg).  Layer order and layouts: include/imcui_hip.h, the DUSt3R section."""
+    lib = load_library()
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
+    cfg = dust3r_cfg_of(sd)
+    c4 = (cfg["enc_dim"], cfg["enc_depth"], cfg["dec_dim"], cfg["dec_depth"])
+    nl = lib.imcui_hip_dust3r_num_layers(*c4)
+    if nl == 0:
+        raise ImcuiHipError(f"DUSt3R configuration {cfg} is not supported (dims multiples of 64 up to 1024, dec_depth a multiple of 4)")
+    ws, bs, vecs = [], [], []
+
+    def lin(name):
+        ws.append(sd[name + ".weight"].reshape(sd[name + ".weight"].shape[0], -1).contiguous())
+        bs.append(sd.get(name + ".bias"))
+
+    def conv(name):  # OIHW -> [Cout][tap][Cin]
+        w = sd[name + ".weight"]
+        ws.append(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous())
+        bs.append(sd.get(name + ".bias"))
+
+    def deconv(name):  # [Cin][Cout][s][s] -> [(dy, dx, cout)][cin], bias tiled over (dy, dx)
+        w = sd[name + ".weight"]
+        s = w.shape[2]
+        ws.append(w.permute(2, 3, 1, 0).reshape(s * s * w.shape[1], w.shape[0]).contiguous())
+        bs.append(sd[name + ".bias"].repeat(s * s).contiguous())
+
+    def norm(name):
+        vecs.extend([sd[name + ".weight"], sd[name + ".bias"]])
+
+    lin("patch_embed.proj")
+    for i in range(cfg["enc_depth"]):
+        p = f"enc_blocks.{i}."
+        for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            lin(p + n)
+        norm(p + "norm1")
+        norm(p + "norm2")
+    norm("enc_norm")
+    lin("decoder_embed")
+    for blocks in ("dec_blocks", "dec_blocks2"):
+        for i in range(cfg["dec_depth"]):
+            p = f"{blocks}.{i}."
+            lin(p + "attn.qkv")
+            lin(p + "attn.proj")
+            lin(p + "cross_attn.projq")
+            ws.append(torch.cat((sd[p + "cross_attn.projk.weight"], sd[p + "cross_attn.projv.weight"]), 0).contiguous())
+            bs.append(torch.cat((sd[p + "cross_attn.projk.bias"], sd[p + "cross_attn.projv.bias"]), 0).contiguous())
+            lin(p + "cross_attn.proj")
+            lin(p + "mlp.fc1")
+            lin(p + "mlp.fc2")
+            for n in ("norm1", "norm2", "norm_y", "norm3"):
+                norm(p + n)
+    norm("dec_norm")
+    for hd in (1, 2):
+        p = f"downstream_head{hd}.dpt."
+        lin(p + "act_postprocess.0.0")
+        deconv(p + "act_postprocess.0.1")
+        lin(p + "act_postprocess.1.0")
+        deconv(p + "act_postprocess.1.1")
+        lin(p + "act_postprocess.2.0")
+        lin(p + "act_postprocess.3.0")
+        conv(p + "act_postprocess.3.1")
+        for k in range(4):
+            conv(f"{p}scratch.layer_rn.{k}")
+        for r in (4, 3, 2, 1):
+            for u in (1, 2):
+                conv(f"{p}scratch.refinenet{r}.resConfUnit{u}.conv1")
+                conv(f"{p}scratch.refinenet{r}.resConfUnit{u}.conv2")
+            lin(f"{p}scratch.refinenet{r}.out_conv")
+        conv(p + "head.0")
+        conv(p + "head.2")
+    for hd in (1, 2):
+        p = f"downstream_head{hd}.dpt.head.4"
+        vecs.extend([sd[p + ".weight"].reshape(4, 128).contiguous(), sd[p + ".bias"]])
+    vecs.append(1.0 / (100.0 ** (torch.arange(0, 32, 2, dtype=torch.float32) / 32)))  # RoPE2D(freq=100), D = 32 per axis
+    nv = lib.imcui_hip_dust3r_num_vectors(*c4)
+    assert len(ws) == nl and len(vecs) == nv, (len(ws), nl, len(vecs), nv)
+    N, K = C.c_int(), C.c_int()
+    w_np, b_np, v_np = [], [], []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        lib.imcui_hip_dust3r_layer_shape(*c4, i, C.byref(N), C.byref(K))
+        if tuple(w.shape) != (N.value, K.value):
+            raise ImcuiHipError(f"DUSt3R layer {i}: expected {(N.value, K.value)}, got {tuple(w.shape)}")
+        w_np.append(_as_f32_host(w))
+        b_np.append(None if b is None else _as_f32_host(b))
+    for i, v in enumerate(vecs):
+        if v.numel() != lib.imcui_hip_dust3r_vector_len(*c4, i):
+            raise ImcuiHipError(f"DUSt3R vector {i}: expected {lib.imcui_hip_dust3r_vector_len(*c4, i)} values, got {v.numel()}")
+        v_np.append(_as_f32_host(v))
+    packed = np.zeros(lib.imcui_hip_dust3r_packed_floats(*c4), dtype=np.float32)
+    wp = (C.c_void_p * nl)(*[a.ctypes.data for a in w_np])
+    bp = (C.c_void_p * nl)(*[(0 if a is None else a.ctypes.data) for a in b_np])
+    vp = (C.c_void_p * nv)(*[a.ctypes.data for a in v_np])
+    rc = lib.imcui_hip_dust3r_pack_weights(*c4, wp, bp, vp, packed.ctypes.data)
+    if rc != 0:
+        raise ImcuiHipError(f"imcui_hip_dust3r_pack_weights failed ({rc})")
+    return torch.from_numpy(packed), cfg
+
+
+class DUSt3RHIP:
+    def __init__(self):
+        self._ws = _Workspace()
+        self._lock = threading.Lock()
+        self.last_dump = None
+
+    def forward(self, packed, cfg, images, pairs, dump=False):
+        """images [NI,3,H,W] in [0,1] (H, W multiples of 32), pairs [P,2] int (view-1 image, view-2 image) ->
+        {"pts3d": [2,P,H,W,3], "conf": [2,P,H,W]} (view 1 in its own frame, view 2 in view 1's frame)."""
+        dev = images.device
+        hd = get_handle(dev)
+        lib = hd.lib
+        images = images.contiguous().float()
+        NI, Cc, H, W = images.shape
+        if Cc != 3:
+            raise ImcuiHipError("DUSt3R expects 3-channel images")
+        pairs = torch.as_tensor(pairs, dtype=torch.int32).reshape(-1, 2)
+        if int(pairs.min()) < 0 or int(pairs.max()) >= NI:
+            raise ImcuiHipError(f"DUSt3R pair table refers to images outside [0, {NI})")
+        pairs = pairs.to(dev).contiguous()
+        P = pairs.shape[0]
+        c4 = (cfg["enc_dim"], cfg["enc_depth"], cfg["dec_dim"], cfg["dec_depth"])
+        pts = torch.empty((2, P, H, W, 3), dtype=torch.float32, device=dev)
+        conf = torch.empty((2, P, H, W), dtype=torch.float32, device=dev)
+        nd = lib.imcui_hip_dust3r_dump_floats(*c4, NI, P, H, W) if dump else 0
+        dbuf = torch.zeros((nd,), dtype=torch.float32, device=dev) if dump else None
+        with self._lock:
+            nbytes = lib.imcui_hip_dust3r_workspace_bytes(*c4, NI, P, H, W)
+            if nbytes == 0:
+                raise ImcuiHipError(f"DUSt3R: unsupported sizes ({NI} images of {W}x{H}, {P} pairs; multiples of 32)")
+            ws = self._ws.get(nbytes, dev)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), _ptr(images), NI, H, W, _ptr(pairs), P, _ptr(pts), _ptr(conf),
+                                                  _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
+                hd.check(rc, "imcui_hip_dust3r_forward")
+        self.last_dump = dbuf
+        return {"pts3d": pts, "conf": conf}
+
+
 def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):
     """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 32 == 0)."""
     hd = get_handle(x_nhwc.device)

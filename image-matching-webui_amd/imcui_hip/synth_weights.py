@@ -430,3 +430,86 @@ def _eloftr_stage3_cells(sd: dict, x: torch.Tensor) -> torch.Tensor:
                 y = y + bn(x, p + ".identity")
             x = F.relu(y)
     return x[0].permute(1, 2, 0).reshape(-1, x.shape[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------- DUSt3R
+DUST3R_CFG = {"enc_dim": 1024, "enc_depth": 24, "dec_dim": 768, "dec_depth": 12}  # DUSt3R_ViTLarge_BaseDecoder_512_dpt
+DUST3R_LAYER_DIMS = (96, 192, 384, 768)
+
+
+def dust3r_state_dict(seed: int = 0, cfg: dict | None = None, gain: float = 1.0) -> dict:
+    """Random weights in the state-dict layout of `AsymmetricCroCo3DStereo` (head_type 'dpt', output_mode 'pts3d';
+    imcui/hloc/matchers/duster.py:37 loads `duster_vit_large.pth` into it).  Linear layers are drawn at
+    gain / sqrt(fan_in), so every sub-layer moves the residual stream by O(1) (attention logits have unit spread, the
+    MLPs are not negligible next to the stream): the parity tests then see each block's arithmetic, which the usual
+    std = 0.02 initialisation would hide.  The last 1x1 convolution is small enough that expm1(|xyz|) stays O(1).
+    `cfg` overrides enc_dim / enc_depth / dec_dim / dec_depth (dims multiples of 64, dec_depth a multiple of 4)."""
+    c = {**DUST3R_CFG, **(cfg or {})}
+    E, D = c["enc_dim"], c["dec_dim"]
+    g = torch.Generator().manual_seed(seed)
+    sd: dict = {}
+
+    def lin(name, n, k, s=1.0, bias=True):
+        sd[name + ".weight"] = torch.randn(n, k, generator=g) * (gain * s / math.sqrt(k))
+        if bias:
+            sd[name + ".bias"] = torch.randn(n, generator=g) * 0.1
+
+    def norm(name, n):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(n, generator=g)
+        sd[name + ".bias"] = 0.05 * torch.randn(n, generator=g)
+
+    def conv(name, co, ci, k, s=1.0, bias=True, transposed=False):
+        shape = (ci, co, k, k) if transposed else (co, ci, k, k)
+        fan = ci if transposed else ci * k * k  # a transposed convolution with kernel = stride sums over Cin only
+        sd[name + ".weight"] = torch.randn(*shape, generator=g) * (gain * s / math.sqrt(fan))
+        if bias:
+            sd[name + ".bias"] = torch.randn(co, generator=g) * 0.1
+
+    conv("patch_embed.proj", E, 3, 16, s=2.0)
+    for i in range(c["enc_depth"]):
+        p = f"enc_blocks.{i}."
+        norm(p + "norm1", E)
+        lin(p + "attn.qkv", 3 * E, E)
+        lin(p + "attn.proj", E, E, 0.5)
+        norm(p + "norm2", E)
+        lin(p + "mlp.fc1", 4 * E, E)
+        lin(p + "mlp.fc2", E, 4 * E, 0.7)
+    norm("enc_norm", E)
+    lin("decoder_embed", D, E)
+    for blocks in ("dec_blocks", "dec_blocks2"):
+        for i in range(c["dec_depth"]):
+            p = f"{blocks}.{i}."
+            norm(p + "norm1", D)
+            lin(p + "attn.qkv", 3 * D, D)
+            lin(p + "attn.proj", D, D, 0.5)
+            norm(p + "norm2", D)
+            norm(p + "norm_y", D)
+            for n in ("projq", "projk", "projv"):
+                lin(p + "cross_attn." + n, D, D)
+            lin(p + "cross_attn.proj", D, D, 0.5)
+            norm(p + "norm3", D)
+            lin(p + "mlp.fc1", 4 * D, D)
+            lin(p + "mlp.fc2", D, 4 * D, 0.7)
+    norm("dec_norm", D)
+    for hd in (1, 2):
+        p = f"downstream_head{hd}.dpt."
+        dims_in = (E, D, D, D)
+        for k, ld in enumerate(DUST3R_LAYER_DIMS):
+            conv(f"{p}act_postprocess.{k}.0", ld, dims_in[k], 1)
+            if k == 0:
+                conv(f"{p}act_postprocess.0.1", ld, ld, 4, transposed=True)
+            elif k == 1:
+                conv(f"{p}act_postprocess.1.1", ld, ld, 2, transposed=True)
+            elif k == 3:
+                conv(f"{p}act_postprocess.3.1", ld, ld, 3)
+            conv(f"{p}scratch.layer_rn.{k}", 256, ld, 3, bias=False)
+            sd[f"{p}scratch.layer{k + 1}_rn.weight"] = sd[f"{p}scratch.layer_rn.{k}.weight"]  # upstream registers the module twice
+        for r in (1, 2, 3, 4):
+            for u in (1, 2):
+                conv(f"{p}scratch.refinenet{r}.resConfUnit{u}.conv1", 256, 256, 3, 1.2)
+                conv(f"{p}scratch.refinenet{r}.resConfUnit{u}.conv2", 256, 256, 3, 0.6)
+            conv(f"{p}scratch.refinenet{r}.out_conv", 256, 256, 1, 0.8)
+        conv(p + "head.0", 128, 256, 3)
+        conv(p + "head.2", 128, 128, 3, 1.4)
+        conv(p + "head.4", 4, 128, 1, 0.5)
+    return sd

@@ -235,6 +235,38 @@ int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* i
  * 4 fused 1/2-resolution fine map [.,H/2,W/2,64], 5 fine windows [B*L0][64 + 100][64] (debug_windows)  (parity tests) */
 size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);
 
+/* ---- DUSt3R pair network (BASELINE config 5; what `dust3r.inference.inference(pairs, self.net, ...)`
+ * computes at imcui/hloc/matchers/duster.py:73 with self.net = AsymmetricCroCo3DStereo (duster.py:37): ViT encoder with 2-D rotary
+ * embedding, two-stream cross-attention decoder, DPT point-map head; the un-vendored `third_party/dust3r` submodule) -------- */
+/* The architecture is given by (enc_dim, enc_depth, dec_dim, dec_depth): 1024, 24, 768, 12 for `duster_vit_large.pth`; dims are
+ * multiples of 64 (head_dim 64) up to 1024, dec_depth a multiple of 4 (DPT hooks at 0, dec_depth/2, 3 dec_depth/4, dec_depth).
+ * Host-side packing: imcui_hip_dust3r_num_layers() matrices W[N][K] of imcui_hip_dust3r_layer_shape(i) (+ bias [N] or NULL):
+ * patch_embed.proj as [E][3*16*16]; per encoder block qkv, proj, fc1, fc2; decoder_embed; per decoder block of dec_blocks then
+ * dec_blocks2: qkv, proj, cross projq, [projk ; projv], cross proj, fc1, fc2; per head (downstream_head1, 2): act_postprocess
+ * 1x1 convolutions, the kernel = stride transposed convolutions as [(dy, dx, cout)][cin] with the bias tiled, the 3x3
+ * convolutions in implicit-GEMM order [cout][tap][cin] (act_postprocess.3.1, layer_rn, refinenet 4..1 residual units + out_conv,
+ * head.0, head.2).  imcui_hip_dust3r_num_vectors() f32 vectors of imcui_hip_dust3r_vector_len(i): the LayerNorm weights / biases in
+ * module order, head.4 weight [4][128] and bias [4] per head, the 16 rotary frequencies 100^(-i/16).  Built from the upstream
+ * state dict by imcui_hip/backend.py:pack_dust3r. */
+size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
+int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
+int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
+int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i, int* N, int* K);
+int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i);
+int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* const* w, const float* const* b,
+                                  const float* const* vec, float* packed);
+size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W);
+size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W);
+/* `AsymmetricCroCo3DStereo.forward(view1, view2)` for P directed pairs over NI images: images [dev, NI,3,H,W] in [0,1] (the
+ * wrapper's mean = std = 0.5 normalisation, duster.py:60-64, is applied inside), H and W multiples of 32; pairs [dev, P,2] int32 =
+ * (view-1 image, view-2 image) -- duster.py:70-72 asks for (0,1) and (1,0).  Every image is encoded once.  Outputs, view-major:
+ * pts3d [dev, 2,P,H,W,3] (view 1: `pts3d`; view 2: `pts3d_in_other_view`, i.e. in view 1's frame), conf [dev, 2,P,H,W].
+ * dump (may be NULL; parity tests): imcui_hip_dust3r_dump_floats() floats of intermediate token states and head maps.
+ * Split arithmetic only (IMCUI_ERR_UNSUPPORTED in precision 0). */
+int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* packed,
+                             const float* images, int NI, int H, int W, const int* pairs, int P, float* pts3d, float* conf, float* dump,
+                             size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /

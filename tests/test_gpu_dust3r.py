@@ -1,0 +1,151 @@
+"""DUSt3R pair network (HIP) vs the CPU oracle on identical seeded inputs (GPU box only).
+
+Bar: every token state (patch embedding, each encoder block, each decoder block of both streams) and every map of the DPT
+heads within 2e-4 of its magnitude; point maps within 1e-4 of the scene scale and confidences within 1e-4 relative.  A test
+walks ALL stages and reports every violation at once (one GPU run shows the whole picture).  The weights are drawn at
+1 / sqrt(fan_in) (imcui_hip.synth_weights.dust3r_state_dict), so every block moves the residual stream by O(1).
+The reference pins nothing for this path (oracle/dust3r.py: parity unpinned).
+"""
+import pytest
+import torch
+
+from imcui_hip.synth import make_shifted_pair
+from imcui_hip.synth_weights import dust3r_state_dict
+from oracle.dust3r import DUSt3ROracle
+
+pytestmark = pytest.mark.gpu
+SMALL = {"enc_dim": 512, "enc_depth": 2, "dec_dim": 256, "dec_depth": 4}
+_CACHE = {}
+
+
+def _model(cfg, seed=0):
+    from imcui_hip.hloc.matchers.duster import Duster
+
+    key = (tuple(sorted(cfg.items())), seed)
+    if key not in _CACHE:
+        sd = dust3r_state_dict(seed, cfg)
+        _CACHE[key] = (sd, Duster({"state_dict": sd}).eval().to("cuda:0"))
+    return _CACHE[key]
+
+
+def _images(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    a, b, _ = make_shifted_pair(seed, h, w, (16, 8), n_blobs=max(100, h * w // 400))
+    # three channels with different content (the synthetic scenes are gray)
+    i0 = torch.cat((a, a.flip(-1) * 0.7 + 0.1, torch.rand(1, 1, h, w, generator=g)), 1).clamp(0, 1)
+    i1 = torch.cat((b, b.flip(-2) * 0.6 + 0.2, torch.rand(1, 1, h, w, generator=g)), 1).clamp(0, 1)
+    return i0.contiguous(), i1.contiguous()
+
+
+def _compare(cfg, h, w, seed=0, tol=2e-4):
+    torch.set_num_threads(16)
+    sd, model = _model(cfg)
+    i0, i1 = _images(h, w, seed)
+    imgs = torch.cat((i0, i1), 0).cuda()
+    pairs = [[0, 1], [1, 0]]
+    out = model.forward_pairs(imgs, pairs, dump=True)
+    torch.cuda.synchronize()
+    dump = model._impl.last_dump.cpu()
+    ref = DUSt3ROracle(sd, cfg).inference_symmetrized(i0, i1, return_intermediates=True)
+    passes = ref["_passes"]  # [(res1, res2) of (0 -> 1), of (1 -> 0)]
+    E, D, ne, nd = cfg["enc_dim"], cfg["dec_dim"], cfg["enc_depth"], cfg["dec_depth"]
+    NI, P = 2, 2
+    hg, wg = h // 16, w // 16
+    T = hg * wg
+    R = (T + 127) // 128 * 128
+    bad, report = [], []
+    off = 0
+
+    def take(shape):
+        nonlocal off
+        n = 1
+        for s in shape:
+            n *= s
+        t = dump[off : off + n].view(*shape)
+        off += n
+        return t
+
+    def check(name, got, want, t=tol):
+        err = (got - want).abs().max().item()
+        mag = want.abs().max().item()
+        report.append(f"{name}: err {err:.3e} / magnitude {mag:.3e}")
+        if not (err < t * max(mag, 1e-6)) or not torch.isfinite(got).all():
+            bad.append(report[-1])
+
+    # encoder: image 0 = view 1 of pass 0, image 1 = view 2 of pass 0
+    enc_ref = [torch.cat((a, b), 0) for a, b in zip(passes[0][0]["_enc_layers"], passes[0][1]["_enc_layers"])]
+    for i in range(ne + 1):
+        check(f"encoder state {i}", take((NI, R, E))[:, :T], enc_ref[i])
+    check("encoder output (enc_norm)", take((NI, R, E))[:, :T], torch.cat((passes[0][0]["_dec"][0], passes[0][1]["_dec"][0]), 0))
+    # decoder streams: [view 1 of pass 0, view 1 of pass 1 | view 2 of pass 0, view 2 of pass 1]
+    take((2 * P, R, D))  # embedded tokens (checked through block 1)
+    for i in range(1, nd + 1):
+        got = take((2 * P, R, D))[:, :T]
+        if i < nd:
+            want = torch.cat([passes[p][v]["_dec"][i] for v in (0, 1) for p in (0, 1)], 0)
+            check(f"decoder state {i}", got, want)
+    got = take((2 * P, R, D))[:, :T]
+    check("decoder output (dec_norm)", got, torch.cat([passes[p][v]["_dec"][nd] for v in (0, 1) for p in (0, 1)], 0))
+    # heads
+    rh = (4 * hg, 2 * hg, hg, hg // 2)
+    rw = (4 * wg, 2 * wg, wg, wg // 2)
+    for v in (0, 1):
+        for k in range(4):
+            want = torch.cat([passes[p][v]["_layers"][k] for p in (0, 1)], 0).permute(0, 2, 3, 1)
+            check(f"view {v + 1} layer_rn {k}", take((P, rh[k], rw[k], 256)), want)
+        for q, name in enumerate(("_path4", "_path3", "_path2", "_path1")):
+            want = torch.cat([passes[p][v][name] for p in (0, 1)], 0).permute(0, 2, 3, 1)
+            check(f"view {v + 1} {name[1:]}", take((P, 2 * rh[3 - q], 2 * rw[3 - q], 256)), want)
+        want = torch.cat([passes[p][v]["_feat"] for p in (0, 1)], 0).permute(0, 2, 3, 1)
+        check(f"view {v + 1} head features", take((P, h, w, 128)), want)
+        want = torch.cat([passes[p][v]["_raw"] for p in (0, 1)], 0)
+        check(f"view {v + 1} raw regression", take((P, h, w, 4)), want)
+    assert off == dump.numel(), (off, dump.numel())
+    # outputs
+    pts, conf = out["pts3d"].cpu(), out["conf"].cpu()
+    scale = ref["pred1"]["pts3d"].norm(dim=-1).mean().item()
+    for v, (pk, pred) in enumerate((("pts3d", ref["pred1"]), ("pts3d_in_other_view", ref["pred2"]))):
+        err = (pts[v] - pred[pk]).abs().max().item()
+        report.append(f"view {v + 1} pts3d: err {err:.3e} / scene scale {scale:.3e}")
+        if not err < 1e-4 * max(scale, pred[pk].abs().max().item()):
+            bad.append(report[-1])
+        rel = ((conf[v] - pred["conf"]).abs() / pred["conf"]).max().item()
+        report.append(f"view {v + 1} conf: relative err {rel:.3e}")
+        if not rel < 1e-4:
+            bad.append(report[-1])
+    print("\n".join(report))
+    assert not bad, "\n" + "\n".join(bad)
+
+
+def test_dust3r_small_config_vs_oracle():
+    """2 + 4 blocks, 512 / 256 wide, 224 x 160 images: 140 tokens per image (padding rows in every sequence)."""
+    _compare(SMALL, 160, 224)
+
+
+def test_dust3r_small_config_full_tiles():
+    """256 x 256: 256 tokens, no padding rows."""
+    _compare(SMALL, 256, 256, seed=3)
+
+
+def test_dust3r_plugin_output_structure():
+    """`inference_output` has the layout of upstream's `inference` result for the symmetrised pair; the swapped pair is the same
+    network with the roles of the images exchanged (batch entry 1 of pred1 = view 1 of (image1, image0))."""
+    sd, model = _model(SMALL)
+    i0, i1 = _images(160, 224, 1)
+    out = model.inference_output({"image0": i0.cuda(), "image1": i1.cuda()})
+    assert set(out) >= {"view1", "view2", "pred1", "pred2"}
+    assert out["pred1"]["pts3d"].shape == (2, 160, 224, 3) and out["pred1"]["conf"].shape == (2, 160, 224)
+    assert out["pred2"]["pts3d_in_other_view"].shape == (2, 160, 224, 3)
+    assert (out["pred1"]["conf"] > 1).all() and (out["pred2"]["conf"] > 1).all()
+    swapped = model.inference_output({"image0": i1.cuda(), "image1": i0.cuda()})
+    assert torch.equal(swapped["pred1"]["pts3d"][0], out["pred1"]["pts3d"][1])
+    assert torch.equal(swapped["pred2"]["conf"][1], out["pred2"]["conf"][0])
+    with pytest.raises(ImportError):
+        model({"image0": i0.cuda(), "image1": i1.cuda()})  # the host-side aligner of upstream is not installed here
+
+
+def test_dust3r_full_model_512():
+    """The benchmarked configuration: ViT-L / ViT-B / DPT at 512 x 512 (BASELINE config 5)."""
+    from imcui_hip.synth_weights import DUST3R_CFG
+
+    _compare(dict(DUST3R_CFG), 512, 512, seed=5, tol=5e-4)

@@ -1,0 +1,133 @@
+"""CPU checks of the DUSt3R oracle's building blocks against independent formulations available in the container
+(oracle/dust3r.py: the network itself is "parity unpinned" -- upstream's sources are an un-vendored submodule)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from imcui_hip.synth_weights import dust3r_state_dict
+from oracle.dust3r import DUSt3ROracle, rope2d
+
+CFG = {"enc_dim": 128, "enc_depth": 2, "dec_dim": 128, "dec_depth": 4}
+
+
+def test_rope2d_is_a_rotation_by_position_times_frequency():
+    """Complex-number formulation: inside each 32-wide half, feature i < 16 and feature i + 16 form one complex number that is
+    multiplied by exp(j * pos * 100^(-i/16)); the y half uses the row, the x half the column."""
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(2, 3, 35, 64, generator=g)
+    pos = torch.stack((torch.randint(0, 32, (2, 35), generator=g), torch.randint(0, 32, (2, 35), generator=g)), -1)
+    got = rope2d(t, pos, 100.0)
+    want = torch.empty_like(t)
+    for half in (0, 1):
+        z = torch.complex(t[..., 32 * half : 32 * half + 16].double(), t[..., 32 * half + 16 : 32 * half + 32].double())
+        f = 100.0 ** (-torch.arange(16, dtype=torch.float64) / 16)
+        ang = pos[..., half][:, None, :, None].double() * f
+        z = z * torch.polar(torch.ones_like(ang), ang)
+        want[..., 32 * half : 32 * half + 16] = z.real.float()
+        want[..., 32 * half + 16 : 32 * half + 32] = z.imag.float()
+    assert (got - want).abs().max().item() < 1e-5
+    # relative-position property: <rope(q, p), rope(k, p')> depends on p - p' only
+    q, k = torch.randn(1, 1, 1, 64, generator=g), torch.randn(1, 1, 1, 64, generator=g)
+    def dot(pq, pk):
+        return (rope2d(q, torch.tensor([[pq]]), 100.0) * rope2d(k, torch.tensor([[pk]]), 100.0)).sum().item()
+    assert abs(dot([3, 7], [1, 2]) - dot([13, 17], [11, 12])) < 1e-4
+
+
+def test_attention_block_against_sdpa():
+    sd = dust3r_state_dict(1, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 24, 128, generator=g)
+    pos = o.positions(2, 4, 6)
+    got = o._self_attn(x, pos, "enc_blocks.0.attn")
+    qkv = F.linear(x, sd["enc_blocks.0.attn.qkv.weight"], sd["enc_blocks.0.attn.qkv.bias"]).view(2, 24, 3, 2, 64)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    att = F.scaled_dot_product_attention(rope2d(q, pos, 100.0), rope2d(k, pos, 100.0), v)
+    want = F.linear(att.transpose(1, 2).reshape(2, 24, 128), sd["enc_blocks.0.attn.proj.weight"], sd["enc_blocks.0.attn.proj.bias"])
+    assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_fusion_blocks_against_the_transformers_dpt_modules():
+    """`FeatureFusionBlock_custom` (pre-activation residual units, x2 bilinear align_corners=True, 1x1 out_conv) restated by
+    transformers' DPTFeatureFusionLayer: same tensors loaded, same outputs."""
+    dpt = pytest.importorskip("transformers.models.dpt.modeling_dpt")
+    from transformers import DPTConfig
+
+    sd = dust3r_state_dict(3, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    conf = DPTConfig(fusion_hidden_size=256, use_batch_norm_in_fusion_residual=False)
+    layer = dpt.DPTFeatureFusionLayer(conf, align_corners=True).eval()
+    p = "downstream_head1.dpt.scratch.refinenet2."
+    m = {"projection": "out_conv", "residual_layer1.convolution1": "resConfUnit1.conv1", "residual_layer1.convolution2": "resConfUnit1.conv2",
+         "residual_layer2.convolution1": "resConfUnit2.conv1", "residual_layer2.convolution2": "resConfUnit2.conv2"}
+    layer.load_state_dict({f"{a}.{t}": sd[f"{p}{b}.{t}"] for a, b in m.items() for t in ("weight", "bias")})
+    g = torch.Generator().manual_seed(4)
+    x, skip = torch.randn(1, 256, 6, 9, generator=g), torch.randn(1, 256, 6, 9, generator=g)
+    with torch.no_grad():
+        want2 = layer(x, skip)
+        want1 = layer(x)
+    assert (o._fusion(p[:-1], x, skip) - want2).abs().max().item() < 1e-4 * want2.abs().max().item()
+    assert (o._fusion(p[:-1], x) - want1).abs().max().item() < 1e-4 * want1.abs().max().item()
+
+
+def test_reassemble_against_the_transformers_dpt_stage():
+    """Token maps -> (x4 transposed conv, x2 transposed conv, identity, 3x3 stride 2) after a 1x1 projection: transformers'
+    DPTReassembleLayer with factors 4, 2, 1, 0.5 loaded with the same tensors."""
+    dpt = pytest.importorskip("transformers.models.dpt.modeling_dpt")
+    from transformers import DPTConfig
+
+    sd = dust3r_state_dict(5, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    g = torch.Generator().manual_seed(6)
+    h, w = 4, 6
+    toks = [torch.randn(1, h * w, 128, generator=g) for _ in range(5)]
+    p = "downstream_head1.dpt."
+    maps = []
+    for k, hook in enumerate(o.hooks):
+        conf = DPTConfig(hidden_size=128)
+        lay = dpt.DPTReassembleLayer(conf, channels=(96, 192, 384, 768)[k], factor=(4, 2, 1, 0.5)[k]).eval()
+        tens = {"projection.weight": sd[f"{p}act_postprocess.{k}.0.weight"], "projection.bias": sd[f"{p}act_postprocess.{k}.0.bias"]}
+        if k != 2:
+            tens["resize.weight"] = sd[f"{p}act_postprocess.{k}.1.weight"]
+            tens["resize.bias"] = sd[f"{p}act_postprocess.{k}.1.bias"]
+        lay.load_state_dict(tens)
+        with torch.no_grad():
+            m = lay(toks[hook].transpose(1, 2).reshape(1, 128, h, w))
+        maps.append(F.conv2d(m, sd[f"{p}scratch.layer_rn.{k}.weight"], None, 1, 1))
+    got = o.reassemble(toks, 1, h, w)
+    for a, b in zip(got, maps):
+        assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * b.abs().max().item()
+
+
+def test_symmetrised_driver_and_postprocessing():
+    sd = dust3r_state_dict(7, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    g = torch.Generator().manual_seed(8)
+    a, b = torch.rand(1, 3, 64, 96, generator=g), torch.rand(1, 3, 64, 96, generator=g)
+    r = o.inference_symmetrized(a, b, return_intermediates=True)
+    assert r["pred1"]["pts3d"].shape == (2, 64, 96, 3) and r["pred2"]["pts3d_in_other_view"].shape == (2, 64, 96, 3)
+    assert (r["pred1"]["conf"] > 1).all()
+    raw = r["_passes"][0][0]["_raw"]
+    d = raw[..., :3].norm(dim=-1)
+    assert torch.allclose(r["pred1"]["pts3d"][:1].norm(dim=-1), torch.expm1(d), rtol=1e-5, atol=1e-6)  # |pts| = expm1(|xyz|)
+    # the swapped call is the swapped pair
+    s = o.inference_symmetrized(b, a)
+    assert torch.equal(s["pred1"]["pts3d"][0], r["pred1"]["pts3d"][1]) and torch.equal(s["pred2"]["conf"][1], r["pred2"]["conf"][0])
+
+
+def test_pack_dust3r_layout_matches_the_library():
+    """The host packer walks the state dict in the order of the C layer table and every shape agrees (no GPU needed)."""
+    from imcui_hip.backend import dust3r_cfg_of, pack_dust3r
+    from imcui_hip.lib_loader import load_library
+
+    cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4}
+    sd = dust3r_state_dict(9, cfg)
+    assert dust3r_cfg_of(sd) == cfg
+    packed, c = pack_dust3r(sd)
+    lib = load_library()
+    assert c == cfg and packed.numel() == lib.imcui_hip_dust3r_packed_floats(128, 1, 64, 4)
+    assert lib.imcui_hip_dust3r_num_layers(100, 1, 64, 4) == 0  # widths must be multiples of 64
+    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 2, 2, 100, 128) == 0  # sizes must be multiples of 32
+    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 2, 2, 96, 128) > 0
