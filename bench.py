@@ -280,6 +280,103 @@ def bench_loftr(args, dev, rank, world):
         dist.destroy_process_group()
 
 
+def dust3r_tflop_per_pair(cfg: dict, H: int, W: int) -> dict:
+    """Algorithmic TFLOP of one symmetrised image pair (2 images encoded once, 2 directed pairs decoded, 4 DPT heads)."""
+    E, D, ne, nd = cfg["enc_dim"], cfg["dec_dim"], cfg["enc_depth"], cfg["dec_depth"]
+    T = (H // 16) * (W // 16)
+    enc = 2 * (T * 2 * 768 * E + ne * (T * 2 * 12 * E * E + 4 * T * T * E))
+    dec = 2 * (T * 2 * E * D) + 2 * 2 * nd * (T * 2 * 16 * D * D + 2 * 4 * T * T * D)
+    px = lambda lvl: T * 4.0 ** lvl  # cells of the 1/16 grid scaled by 4^lvl: -1 = 1/32, 0 = 1/16, 1 = 1/8, 2 = 1/4, 3 = 1/2, 4 = full resolution
+    head = (T * 2 * (E * 96 + 96 * 1536 + D * 192 + 192 * 768 + D * 384 + D * 768) + px(-1) * 18 * 768 * 768  # reassemble
+            + 18 * 256 * (px(2) * 96 + px(1) * 192 + px(0) * 384 + px(-1) * 768)                                 # layer_rn
+            + 18 * 256 * 256 * (2 * px(-1) + 4 * px(0) + 4 * px(1) + 4 * px(2))                                  # residual units
+            + 2 * 256 * 256 * (px(0) + px(1) + px(2) + px(3))                                                    # out_conv
+            + 18 * 256 * 128 * px(3) + 18 * 128 * 128 * px(4) + 2 * 128 * 4 * px(4))                             # head
+    return {"encoder": enc / 1e12, "decoder": dec / 1e12, "heads": 4 * head / 1e12, "total": (enc + dec + 4 * head) / 1e12}
+
+
+def bench_dust3r(args, dev, rank, world):
+    """configs[4]: DUSt3R ViT-L pair encoder + DPT regression head on 512x512 pairs; symmetrised image pairs/s (what one call of
+    imcui/hloc/matchers/duster.py processes: the directed pairs (0, 1) and (1, 0)), weak scaling, pairs sharded over the ranks,
+    no collective (the outputs are dense point maps consumed by the host-side aligner of the rank that owns the pair)."""
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.duster import Duster
+    from imcui_hip.synth import make_pair
+    from imcui_hip.synth_weights import DUST3R_CFG, dust3r_state_dict  # seeded weights only
+
+    Hh, Ww = args.size if args.size else (512, 512)
+    B = args.batch
+    cfg = dict(DUST3R_CFG)
+    sd = dust3r_state_dict(0, cfg)
+    model = Duster({"state_dict": sd}).eval().to(dev)
+    base, _, _ = make_pair(91 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
+    g = torch.Generator().manual_seed(5 + rank)
+    i0 = torch.cat((base[..., 0:Hh, 0:Ww], base[..., 4 : Hh + 4, 2 : Ww + 2] * 0.8 + 0.1, torch.rand(1, 1, Hh, Ww, generator=g)), 1)
+    i1 = torch.cat((base[..., 8 : Hh + 8, 16 : Ww + 16], base[..., 12 : Hh + 12, 6 : Ww + 6] * 0.8 + 0.1, torch.rand(1, 1, Hh, Ww, generator=g)), 1)
+    images = torch.cat((i0, i1), 0).repeat(B, 1, 1, 1).contiguous().to(dev)  # [2B,3,H,W]: images 2b, 2b+1 form pair b
+    pairs = torch.tensor([[2 * b + a, 2 * b + 1 - a] for b in range(B) for a in (0, 1)], dtype=torch.int32, device=dev)
+
+    def step():
+        return model.forward_pairs(images, pairs)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    backend.profile_enable(dev, True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    cls_ms = {k: backend.profile_read(dev, k) for k in ("gemm", "conv3x3", "attention")}
+    backend.profile_enable(dev, False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        tf = dust3r_tflop_per_pair(cfg, Hh, Ww)
+        mat_ms = sum(v[0] for v in cls_ms.values())
+        mat_n = sum(v[1] for v in cls_ms.values())
+        ach = tf["total"] * B * args.steps / (mat_ms * 1e-3) if mat_ms else 0.0
+        line = {
+            "metric": "image-pairs/sec DUSt3R pair network @512x512", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate (the reference config names bf16; this path keeps fp32-grade results)",
+            "data": "synthetic",
+            "config": {"workload": f"configs[4]: DUSt3R ViT-L/16 encoder (24 x 1024) + 2 x 12 x 768 cross-attention decoder + DPT point-map heads on synthetic {Ww}x{Hh} "
+                                   "pairs resident in HBM; one pair = the symmetrised call of duster.py (directed pairs (0,1) and (1,0), each image encoded once)",
+                       "pairs_per_step_per_gpu": B, "weights": "seeded random (imcui_hip/synth_weights.py), AsymmetricCroCo3DStereo architecture, 578 M parameters",
+                       "mean_confidence": float(out["conf"].mean())},
+            "roofline": {"kernel": "gemm_split_kernel + conv3x3_split_kernel + attn_split_kernel (matrix class)", "bound": "mfma", "achieved": ach,
+                         "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": None,
+                         "class_ms_per_step": {k: v[0] / args.steps for k, v in cls_ms.items()}, "launches_per_step": mat_n / args.steps,
+                         "algorithmic_tflop_per_pair": tf,
+                         "note": "achieved = algorithmic TFLOP of a pair / summed matrix-class kernel time (HIP events); the split mode executes 3 f16 MFMAs per product"},
+            "algorithmic_tflops_end_to_end": tf["total"] * B / (dt / args.steps),
+        }  # fmt: skip
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.dust3r import DUSt3ROracle
+
+            ncpu = os.cpu_count() or 1
+            torch.set_num_threads(min(ncpu, 32))
+            ora = DUSt3ROracle(sd, cfg)
+            t0 = time.perf_counter()
+            ora.inference_symmetrized(i0, i1)
+            el = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": 1.0 / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
+                                    "sample": f"ONE synthetic {Ww}x{Hh} pair, no warm-up, fp32, the oracle's restatement of duster.py:66-73 (two forward passes, "
+                                              f"both images encoded in each, as upstream's inference does), torch {torch.__version__} CPU, "
+                                              f"{torch.get_num_threads()} of {ncpu} host CPUs"}  # fmt: skip
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def bench_superglue(args, dev, rank, world):
     """SuperPoint + SuperGlue (matcher zoo entry `superglue`, imcui/hloc/configs/matchers.py:10-24: 50 Sinkhorn rounds) on
     640x480 pairs; pairs/s, weak scaling (pairs are independent; one all-gather of the match tables per step)."""
@@ -458,11 +555,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 64; loftr: 4, eloftr: 8)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 64; loftr: 4, eloftr: 8, dust3r: 8)")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "superpoint", "superglue", "launchcheck"],
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "dust3r", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
@@ -471,7 +568,7 @@ def main():
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 4 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels)
+        args.batch = 4 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 8 if args.workload == "dust3r" else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels)
 
     if args.workload == "launchcheck":
         return launchcheck(args)
@@ -495,6 +592,8 @@ def main():
     backend.set_precision(dev, args.precision)
     if args.workload in ("loftr", "eloftr"):
         return bench_loftr(args, dev, rank, world)
+    if args.workload == "dust3r":
+        return bench_dust3r(args, dev, rank, world)
     if args.workload == "superpoint":
         return bench_superpoint(args, dev, rank, world)
     if args.workload == "superglue":
