@@ -206,6 +206,9 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
             }
         });
     for (auto& th : pool) th.join();
+    // one launch can serve both decoder sides (GemmP.wsel): the scale of the dec_blocks2 layer sits right behind its dec_blocks twin
+    for (int i = 0; i < c.dec_depth; ++i)
+        for (int j = 0; j < DU_DEC_J; ++j) packed[l.ws[du_l_dec(c, 0, i, j)] + 1] = packed[l.ws[du_l_dec(c, 1, i, j)]];
     for (int i = 0; i < nv; ++i) memcpy(packed + l.vec[i], vec[i], (size_t)du_vec_len(c, i) * sizeof(float));
     return IMCUI_OK;
 }
@@ -214,7 +217,7 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
 struct DuWs {
     float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
     float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2;
-    int *cnt, *smap;
+    int *cnt, *smap, *wsel, *wsel_rev;
     size_t total;
     bool ok;
 };
@@ -263,6 +266,8 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     w.hd2 = a.get<float>(pt * 256 * 128);
     w.cnt = a.get<int>((size_t)(NI > 2 * P ? NI : 2 * P) + 64);
     w.smap = a.get<int>((size_t)2 * P + 64);
+    w.wsel = a.get<int>((size_t)P + 64);
+    w.wsel_rev = a.get<int>((size_t)P + 64);
     w.total = a.off;
     w.ok = a.ok;
     return w;
@@ -362,6 +367,48 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.rows_per_seq = R;
         return gemm_launch(h, g, stream);
     };
+    // decoder layer j of block i on ALL 2P streams in one launch: sequences [0, P) use the weights of `dec_blocks`, [P, 2P) those of
+    // `dec_blocks2` (`swap`: the other way round -- keys / values are projected by the block of the side that will READ them).
+    // The weight set is chosen per sequence PAIR (GemmP.wsel), so this needs an even P; otherwise one launch per side.
+    static const bool dec_two_launches = getenv("IMCUI_DUST3R_DEC_SPLIT") != nullptr;  // A/B switch
+    const bool merged = (P % 2 == 0) && !dec_two_launches;
+    auto lin2 = [&](int i, int j, const float* A, long lda_rows, float* C, long ldc_rows, const float* resid, int act, bool swap) -> int {
+        const int L0 = du_l_dec(c, 0, i, j), L1 = du_l_dec(c, 1, i, j);
+        if (!merged) {
+            for (int s = 0; s < 2; ++s) {
+                const int li = swap ? (s ? L0 : L1) : (s ? L1 : L0);
+                const int r = lin(li, A + (size_t)s * P * R * lda_rows, C + (size_t)s * P * R * ldc_rows, P,
+                                  resid ? resid + (size_t)s * P * R * ldc_rows : nullptr, act);
+                if (r != IMCUI_OK) return r;
+            }
+            return IMCUI_OK;
+        }
+        int N, K, kind;
+        du_shape(c, L0, &N, &K, &kind);
+        GemmP g;
+        g.epi = EPI_CONV;
+        g.N = N;
+        g.K = K;
+        g.ldw = K;
+        g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[L0]);
+        g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[L0]);
+        g.wscale = Pk + l.ws[L0];
+        g.bias = Pk + l.b[L0];
+        g.wsel = swap ? w.wsel_rev : w.wsel;
+        g.w_stride = (long)(l.wh[L1] - l.wh[L0]) * 2;  // halves between the planes of the two sides (same for hi and lo)
+        g.b_stride = (long)(l.b[L1] - l.b[L0]);
+        g.A = A;
+        g.lda = K;
+        g.C = C;
+        g.ldc = N;
+        g.resid = resid;
+        g.ldr = N;
+        g.act = act;
+        g.M = 2 * P * R;
+        g.cnt = w.cnt;
+        g.rows_per_seq = R;
+        return gemm_launch(h, g, stream);
+    };
     // the same on dense rows (DPT head)
     auto lin_dense = [&](int li, const float* A, float* C, long rows) -> int {
         int N, K, kind;
@@ -416,6 +463,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         hipLaunchKernelGGL(du_fill_int_kernel, dim3((unsigned)cdiv(ncnt, 256)), blk, 0, stream, w.cnt, T, ncnt);
         // stream s < P: view 1 of pair s, stream P + s: view 2
         hipLaunchKernelGGL(du_smap_kernel, dim3((unsigned)cdiv(2 * P, 256)), blk, 0, stream, pairs, w.smap, P, NI);
+        hipLaunchKernelGGL(du_wsel_kernel, dim3((unsigned)cdiv(P, 256)), blk, 0, stream, w.wsel, w.wsel_rev, P);
     }
 
     // ---- encoder: every image once
@@ -459,40 +507,32 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, src, (const int*)nullptr, w.hook[k], R, T, D / 4, n4);
     };
     for (int i = 0; i < c.dec_depth; ++i) {
-        // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block
-        for (int s = 0; s < 2; ++s) {
-            const int o = 1 - s;
-            layernorm(w.y + (size_t)o * ms * D, du_v_dec(c, s, i, 4), w.xn, ms, D);
-            DURUN(lin(du_l_dec(c, s, i, 3), w.xn, w.qkv, P, nullptr, 0));
-            rope_split(w.qkv, 2 * D, 0, D, P, w.kc, 2 * P, o * P, 1.0f);
-            vt_split(w.qkv, 2 * D, D, D, P, w.vc, 2 * P, o * P);
-        }
+        // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block, normalised by
+        // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o
+        for (int o = 0; o < 2; ++o) layernorm(w.y + (size_t)o * ms * D, du_v_dec(c, 1 - o, i, 4), w.xn + (size_t)o * ms * D, ms, D);
+        DURUN(lin2(i, 3, w.xn, D, w.qkv, 2 * D, nullptr, 0, true));
+        rope_split(w.qkv, 2 * D, 0, D, 2 * P, w.kc, 2 * P, 0, 1.0f);
+        vt_split(w.qkv, 2 * D, D, D, 2 * P, w.vc, 2 * P, 0);
         // self attention
-        for (int s = 0; s < 2; ++s) {
-            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, ms, D);
-            DURUN(lin(du_l_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, w.qkv + (size_t)s * ms * 3 * D, P, nullptr, 0));
-        }
+        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, ms, D);
+        DURUN(lin2(i, 0, w.xn, D, w.qkv, 3 * D, nullptr, 0, false));
         rope_split(w.qkv, 3 * D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
         rope_split(w.qkv, 3 * D, D, D, 2 * P, w.kp, 2 * P, 0, 1.0f);
         vt_split(w.qkv, 3 * D, 2 * D, D, 2 * P, w.vp, 2 * P, 0);
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, 2 * P, D, 0));
-        for (int s = 0; s < 2; ++s) DURUN(lin(du_l_dec(c, s, i, 1), w.att + (size_t)s * ms * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
+        DURUN(lin2(i, 1, w.att, D, w.y, D, w.y, 0, false));
         // cross attention
-        for (int s = 0; s < 2; ++s) {
-            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, ms, D);
-            DURUN(lin(du_l_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, w.qc + (size_t)s * ms * D, P, nullptr, 0));
-        }
+        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, ms, D);
+        DURUN(lin2(i, 2, w.xn, D, w.qc, D, nullptr, 0, false));
         rope_split(w.qc, D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kc, w.vc, w.att, 2 * P, D, 2));
-        for (int s = 0; s < 2; ++s) DURUN(lin(du_l_dec(c, s, i, 4), w.att + (size_t)s * ms * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
+        DURUN(lin2(i, 4, w.att, D, w.y, D, w.y, 0, false));
         // MLP
-        for (int s = 0; s < 2; ++s) {
-            layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 6), w.xn + (size_t)s * ms * D, ms, D);
-            DURUN(lin(du_l_dec(c, s, i, 5), w.xn + (size_t)s * ms * D, w.hid + (size_t)s * ms * 4 * D, P, nullptr, 3));
-            DURUN(lin(du_l_dec(c, s, i, 6), w.hid + (size_t)s * ms * 4 * D, w.y + (size_t)s * ms * D, P, w.y + (size_t)s * ms * D, 0));
-        }
+        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 6), w.xn + (size_t)s * ms * D, ms, D);
+        DURUN(lin2(i, 5, w.xn, D, w.hid, 4 * D, nullptr, 3, false));
+        DURUN(lin2(i, 6, w.hid, 4 * D, w.y, D, w.y, 0, false));
         dump_copy(w.y, (size_t)md * D);
         for (int k = 0; k < 2; ++k)
             if (i + 1 == hooks[k]) save_hook(w.y, k);

@@ -281,6 +281,17 @@ __global__ void du_smap_kernel(const int* __restrict__ pairs, int* __restrict__ 
     }
 }
 
+// weight-set table of the merged decoder launches (GemmP.wsel is indexed by sequence pair): pairs of the first P streams -> set 0
+// (`dec_blocks`), of the last P -> set 1 (`dec_blocks2`); `rev` the other way round
+__global__ void du_wsel_kernel(int* __restrict__ fwd, int* __restrict__ rev, int P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P) {
+        const int side = (2 * i >= P) ? 1 : 0;
+        fwd[i] = side;
+        rev[i] = 1 - side;
+    }
+}
+
 __global__ void du_fill_int_kernel(int* p, int v, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;

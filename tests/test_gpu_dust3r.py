@@ -127,6 +127,24 @@ def test_dust3r_small_config_full_tiles():
     _compare(SMALL, 256, 256, seed=3)
 
 
+@pytest.mark.parametrize("pairs", [[[0, 1]], [[0, 1], [1, 2], [2, 0]], [[0, 1], [1, 0], [0, 2], [2, 1]]])
+def test_dust3r_pair_lists(pairs):
+    """Any list of directed pairs over a set of images in one call (1 and 3 pairs: one GEMM launch per decoder side; 4: the
+    merged launches): every pair equals the oracle's forward on that pair."""
+    torch.set_num_threads(16)
+    sd, model = _model(SMALL)
+    imgs = torch.cat([_images(128, 160, 20 + k)[k % 2] for k in range(3)], 0)
+    out = model.forward_pairs(imgs.cuda(), pairs)
+    ora = DUSt3ROracle(sd, SMALL)
+    norm = (imgs - 0.5) / 0.5
+    for p, (a, b) in enumerate(pairs):
+        r1, r2 = ora.forward(norm[a : a + 1], norm[b : b + 1])
+        for v, (want, wconf) in enumerate(((r1["pts3d"], r1["conf"]), (r2["pts3d_in_other_view"], r2["conf"]))):
+            err = (out["pts3d"][v, p].cpu() - want[0]).abs().max().item()
+            assert err < 1e-4 * want.abs().max().item(), (p, v, err)
+            assert ((out["conf"][v, p].cpu() - wconf[0]).abs() / wconf[0]).max().item() < 1e-4
+
+
 def test_dust3r_plugin_output_structure():
     """`inference_output` has the layout of upstream's `inference` result for the symmetrised pair; the swapped pair is the same
     network with the roles of the images exchanged (batch entry 1 of pred1 = view 1 of (image1, image0))."""
