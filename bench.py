@@ -307,8 +307,23 @@ def bench_dust3r(args, dev, rank, world):
     Hh, Ww = args.size if args.size else (512, 512)
     B = args.batch
     cfg = dict(DUST3R_CFG)
-    sd = dust3r_state_dict(0, cfg)
-    model = Duster({"state_dict": sd}).eval().to(dev)
+    # generating and packing the 578 M seeded parameters takes ~30 s of host time: the packed buffer (a pure function of the seed) is
+    # kept in the temp directory so that profiler passes of the same command line do not repeat it
+    import tempfile
+
+    cache = os.path.join(tempfile.gettempdir(), f"imcui_hip_dust3r_seed0_rank{rank}.pt")
+    sd = None
+    if os.path.exists(cache):
+        packed = torch.load(cache)
+    else:
+        sd = dust3r_state_dict(0, cfg)
+        packed, _ = backend.pack_dust3r(sd)
+        try:
+            torch.save(packed, cache)
+        except OSError:
+            pass
+    model = Duster({"packed": (packed, cfg)}).eval().to(dev)
+    del packed
     base, _, _ = make_pair(91 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     g = torch.Generator().manual_seed(5 + rank)
     i0 = torch.cat((base[..., 0:Hh, 0:Ww], base[..., 4 : Hh + 4, 2 : Ww + 2] * 0.8 + 0.1, torch.rand(1, 1, Hh, Ww, generator=g)), 1)
@@ -343,6 +358,15 @@ def bench_dust3r(args, dev, rank, world):
         mat_ms = sum(v[0] for v in cls_ms.values())
         mat_n = sum(v[1] for v in cls_ms.values())
         ach = tf["total"] * B * args.steps / (mat_ms * 1e-3) if mat_ms else 0.0
+        # HBM bytes of the matrix-class kernels per launch from the committed PMC passes of the same workload (512x512 only)
+        import glob
+
+        traffic = None
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_dust3r.json")))
+        if cands and (Hh, Ww) == (512, 512) and mat_n:
+            with open(cands[-1]) as fh:
+                tj = json.load(fh)
+            traffic = tj["traffic_bytes_per_step_gemm_kernels"] * B / tj["pairs_per_step"] / (mat_n / args.steps)
         line = {
             "metric": "image-pairs/sec DUSt3R pair network @512x512", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -353,7 +377,7 @@ def bench_dust3r(args, dev, rank, world):
                        "pairs_per_step_per_gpu": B, "weights": "seeded random (imcui_hip/synth_weights.py), AsymmetricCroCo3DStereo architecture, 578 M parameters",
                        "mean_confidence": float(out["conf"].mean())},
             "roofline": {"kernel": "gemm_split_kernel + conv3x3_split_kernel + attn_split_kernel (matrix class)", "bound": "mfma", "achieved": ach,
-                         "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": None,
+                         "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": traffic,
                          "class_ms_per_step": {k: v[0] / args.steps for k, v in cls_ms.items()}, "launches_per_step": mat_n / args.steps,
                          "algorithmic_tflop_per_pair": tf,
                          "note": "achieved = algorithmic TFLOP of a pair / summed matrix-class kernel time (HIP events); the split mode executes 3 f16 MFMAs per product"},
@@ -364,7 +388,7 @@ def bench_dust3r(args, dev, rank, world):
 
             ncpu = os.cpu_count() or 1
             torch.set_num_threads(min(ncpu, 32))
-            ora = DUSt3ROracle(sd, cfg)
+            ora = DUSt3ROracle(sd if sd is not None else dust3r_state_dict(0, cfg), cfg)
             t0 = time.perf_counter()
             ora.inference_symmetrized(i0, i1)
             el = time.perf_counter() - t0

@@ -85,6 +85,25 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // log(sigmoid(x)) = min(x,0) - log1p(exp(-|x|))  (same form ATen uses)
 __device__ __forceinline__ float logsigmoidf_(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 
+// GELU(y) = 0.5 y (1 + erf(y / sqrt 2)), erf(t) = 1 - 2^(-t Q(t)) for t = min(|.|, 4): coefficients and the measured
+// float32 error (1.3e-7 absolute on erf) from tools/fit/fit_gelu_erf.py.  Branch-free: 7 FMAs and one v_exp_f32.
+__device__ __forceinline__ float gelu_poly(float y) {
+    const float a = y * 0.70710678118654752440f;
+    const float t = fminf(fabsf(a), 4.0f);
+    float q = 4.535851622e-05f;
+    q = fmaf(q, t, -4.455066228e-04f);
+    q = fmaf(q, t, 1.489437302e-03f);
+    q = fmaf(q, t, 7.746380288e-04f);
+    q = fmaf(q, t, -2.825368941e-02f);
+    q = fmaf(q, t, 1.484816223e-01f);
+    q = fmaf(q, t, 9.184163809e-01f);
+    q = fmaf(q, t, 1.627908587e+00f);
+    const float e = __builtin_amdgcn_exp2f(-(t * q));
+    const float r = copysignf(1.0f - e, a);
+    const float hy = 0.5f * y;
+    return fmaf(hy, r, hy);
+}
+
 // Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a
 // private 4 MiB L2).  Give every XCD a contiguous run of tile ids so that neighbouring tiles
 // (which share an operand panel) hit the same L2.  Bijective for any nwg.  Speed only.

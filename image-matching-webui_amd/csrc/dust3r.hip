@@ -192,7 +192,7 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
     memset(packed, 0, l.total * sizeof(float));
     unsigned nthr = std::thread::hardware_concurrency();
     if (nthr == 0) nthr = 1;
-    if (nthr > 16) nthr = 16;
+    if (nthr > 64) nthr = 64;
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nthr; ++t)
         pool.emplace_back([&, t]() {

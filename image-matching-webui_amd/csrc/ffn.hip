@@ -30,24 +30,7 @@
 #define FFN_LDS_BYTES (FFN_G_BYTES + 8192)  // + 2 x [8 waves][128 tokens] partial sums
 #define FFN_YLD 260                      // row stride (floats) of the output tile in LDS
 
-// GELU(y) = 0.5 y (1 + erf(y / sqrt 2)), erf(t) = 1 - 2^(-t Q(t)) for t = min(|.|, 4): coefficients and the measured
-// float32 error (1.3e-7 absolute on erf) from tools/fit/fit_gelu_erf.py.  Branch-free: 7 FMAs and one v_exp_f32.
-__device__ __forceinline__ float ffn_gelu(float y) {
-    const float a = y * 0.70710678118654752440f;
-    const float t = fminf(fabsf(a), 4.0f);
-    float q = 4.535851622e-05f;
-    q = fmaf(q, t, -4.455066228e-04f);
-    q = fmaf(q, t, 1.489437302e-03f);
-    q = fmaf(q, t, 7.746380288e-04f);
-    q = fmaf(q, t, -2.825368941e-02f);
-    q = fmaf(q, t, 1.484816223e-01f);
-    q = fmaf(q, t, 9.184163809e-01f);
-    q = fmaf(q, t, 1.627908587e+00f);
-    const float e = __builtin_amdgcn_exp2f(-(t * q));
-    const float r = copysignf(1.0f - e, a);
-    const float hy = 0.5f * y;
-    return fmaf(hy, r, hy);
-}
+__device__ __forceinline__ float ffn_gelu(float y) { return gelu_poly(y); }  // common.h
 
 template <int VAR, int ACT>
 __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {

@@ -14,7 +14,8 @@ That is RANSAC geometry on the host in the reference and stays there (north_star
 upstream's own `dust3r` package when it is importable (the `third_party/dust3r` submodule of the reference checkout) and
 raises a clear ImportError otherwise -- neither the package nor cv2 exist offline, so they are not restated here.
 
-Weights: conf["state_dict"] / conf["weights_path"] with upstream's parameter names (`duster_vit_large.pth` holds them under
+Weights: conf["state_dict"] / conf["weights_path"] (or conf["packed"], the result of an earlier `backend.pack_dust3r`: packing
+the 578 M parameters takes ~20 s) with upstream's parameter names (`duster_vit_large.pth` holds them under
 the key "model", which `resolve_state_dict` unwraps).  The architecture (widths, depths) is read from the tensors.
 """
 from __future__ import annotations
@@ -37,6 +38,12 @@ class Duster(BaseModel):
     required_inputs = ["image0", "image1"]
 
     def _init(self, conf):
+        if conf.get("packed") is not None:  # (packed buffer, architecture) of an earlier backend.pack_dust3r call
+            packed, self.net_cfg = conf["packed"]
+            self.conf.pop("packed", None)
+            self.register_buffer("packed", packed, persistent=False)
+            self._impl = backend.DUSt3RHIP()
+            return
         sd = resolve_state_dict(conf, "duster")
         if "patch_embed.proj.weight" not in sd or not any(k.startswith("downstream_head1.dpt.") for k in sd):
             raise KeyError("DUSt3R weights must be an AsymmetricCroCo3DStereo state dict with the DPT head (keys patch_embed.proj.*, downstream_head1.dpt.*)")

@@ -9,6 +9,26 @@ mkdir -p $O
 L=${LG_ONLY:-0}
 K=${SKIP_LABS:-$L}
 cd /tmp && export TMPDIR=/tmp
+# QUICK=1: the four bench lines (headline, LoFTR 1024^2 / 640x480, EfficientLoFTR, DUSt3R), their kernel tables and the DUSt3R
+# counter passes only (after a change that leaves the other operating points, A/B legs and counters as they were)
+if [ "${QUICK:-0}" = 1 ]; then
+  ( cd $R && timeout 300 python bench.py > $O/bench_splg.json.log 2>&1; tail -1 $O/bench_splg.json.log | cut -c1-160 )
+  ( cd $R && timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024.json.log 2>&1; tail -1 $O/bench_loftr_1024.json.log | cut -c1-160 )
+  ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 --no-cpu-baseline > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
+  ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
+  ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_loftr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_eloftr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_dust3r.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_$c.log 2>&1
+    echo pmc dust3r $c rc $?
+  done
+  ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
+  ls $O
+  exit 0
+fi
 ( cd $R && timeout 300 python bench.py > $O/bench_splg.json.log 2>&1; tail -1 $O/bench_splg.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024.json.log 2>&1; tail -1 $O/bench_loftr_1024.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload superpoint > $O/bench_superpoint.json.log 2>&1; tail -1 $O/bench_superpoint.json.log | cut -c1-160 )
@@ -41,6 +61,11 @@ done
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 > $O/rocprof_eloftr.log 2>&1
+[ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_dust3r.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_$c.log 2>&1
+done
 # the fused FFN kernel: A/B against the three-launch path, and its phase breakdown
 ( cd $R && IMCUI_LG_FFN_UNFUSED=1 timeout 100 python bench.py --no-cpu-baseline > $O/bench_splg_unfused_ffn.json.log 2>&1; tail -1 $O/bench_splg_unfused_ffn.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_LF_MATCH_4PASS=1 timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024_4pass.json.log 2>&1; tail -1 $O/bench_loftr_1024_4pass.json.log | cut -c1-160 )

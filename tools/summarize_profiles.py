@@ -47,7 +47,7 @@ json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_
                    "(traffic == compulsory bytes; it was 4.5x that before the remap)"},
           open(os.path.join(P, f"{tag}_attention_traffic.json"), "w"), indent=1)
 # LoFTR / EfficientLoFTR: HBM traffic of the GEMM-class kernels per step (same two passes on the dense workloads)
-for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench_eloftr_640x480.json.log")):
+for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench_eloftr_640x480.json.log"), ("dust3r", "bench_dust3r_512.json.log")):
     if not os.path.exists(os.path.join(F, f"pmc_{stem}_FETCH_SIZE", f"{stem}_counter_collection.csv")):
         continue
     lfe, lwr = agg("FETCH_SIZE", f"{stem}_FETCH_SIZE", stem), agg("WRITE_SIZE", f"{stem}_WRITE_SIZE", stem)
@@ -57,9 +57,9 @@ for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench
     steps = 3  # bench.py --steps 2 --warmup 1
     tot = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in lout.values()) / steps
     gem = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for k, v in lout.items()
-              if k.startswith("gemm_") or k.startswith("lg_ffn") or k.startswith("conv3x3_")) / steps
+              if k.startswith("gemm_") or k.startswith("lg_ffn") or k.startswith("conv3x3_") or (stem == "dust3r" and k.startswith("attn_"))) / steps
     json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {stem} --steps 2 --warmup 1; FETCH doubled; "
-                       "matrix class = conv3x3_*, gemm_* and the fused MLP kernel (what the bench's HIP-event classes time)",
+                       "matrix class = conv3x3_*, gemm_* and the fused MLP kernel, for dust3r also attn_* (what the bench's HIP-event classes time)",
                "pairs_per_step": lb["config"]["pairs_per_step_per_gpu"], "traffic_bytes_per_step_all_kernels": tot,
                "traffic_bytes_per_step_gemm_kernels": gem, "kernels": lout}, open(os.path.join(P, f"{tag}_pmc_traffic_{stem}.json"), "w"), indent=1)
 # matrix-pipe occupancy / stall breakdown from the SQ pass
@@ -96,6 +96,8 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_loftr_1024_4pass.json.log", f"{tag}_bench_loftr_1024_4pass.json.log"),
                  ("bench_eloftr_640x480.json.log", f"{tag}_bench_eloftr_640x480.json.log"),
                  ("stats_eloftr/eloftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_eloftr_640x480.csv"),
+                 ("bench_dust3r_512.json.log", f"{tag}_bench_dust3r_512.json.log"),
+                 ("stats_dust3r/dust3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_dust3r_512.csv"),
                  ("bench_splg_unfused_ffn.json.log", f"{tag}_bench_splg_unfused_ffn.json.log"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
     if not os.path.exists(os.path.join(F, src)):
