@@ -331,6 +331,8 @@ def bench_dust3r(args, dev, rank, world):
     images = torch.cat((i0, i1), 0).repeat(B, 1, 1, 1).contiguous().to(dev)  # [2B,3,H,W]: images 2b, 2b+1 form pair b
     pairs = torch.tensor([[2 * b + a, 2 * b + 1 - a] for b in range(B) for a in (0, 1)], dtype=torch.int32, device=dev)
 
+    model.conf["arithmetic"] = args.arith
+
     def step():
         return model.forward_pairs(images, pairs)
 
@@ -370,7 +372,9 @@ def bench_dust3r(args, dev, rank, world):
         line = {
             "metric": "image-pairs/sec DUSt3R pair network @512x512", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate (the reference config names bf16; this path keeps fp32-grade results)",
+            "vs_baseline": None,
+            "dtype": ("f32 via 3xf16 split MFMA, f32 accumulate (the reference config names bf16; this path keeps fp32-grade results)" if args.arith == "fp32" else
+                      "f16 operands (one MFMA product, 11-bit mantissa), f32 accumulate in the GEMMs and convolutions; attention in 3xf16 split (the reference config names bf16)"),
             "data": "synthetic",
             "config": {"workload": f"configs[4]: DUSt3R ViT-L/16 encoder (24 x 1024) + 2 x 12 x 768 cross-attention decoder + DPT point-map heads on synthetic {Ww}x{Hh} "
                                    "pairs resident in HBM; one pair = the symmetrised call of duster.py (directed pairs (0,1) and (1,0), each image encoded once)",
@@ -381,6 +385,7 @@ def bench_dust3r(args, dev, rank, world):
                          "class_ms_per_step": {k: v[0] / args.steps for k, v in cls_ms.items()}, "launches_per_step": mat_n / args.steps,
                          "algorithmic_tflop_per_pair": tf,
                          "note": "achieved = algorithmic TFLOP of a pair / summed matrix-class kernel time (HIP events); the split mode executes 3 f16 MFMAs per product"},
+            "arithmetic": args.arith,
             "algorithmic_tflops_end_to_end": tf["total"] * B / (dt / args.steps),
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
@@ -588,6 +593,8 @@ def main():
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
+    ap.add_argument("--arith", default="fp32", choices=["fp32", "fp16"],
+                    help="dust3r: fp32 = 3 x f16 split products (default, the parity mode), fp16 = one f16 product per element pair (bf16-class)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()

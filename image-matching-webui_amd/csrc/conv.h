@@ -15,10 +15,12 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 //           added before the activation (residual blocks of the dense matchers' backbones)
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid = nullptr, int cin_stride = 0, int cout_live = 0);
+                         int relu, int pool, hipStream_t stream, const float* resid = nullptr, int cin_stride = 0, int cout_live = 0,
+                         int single = 0);
 // cin_stride: floats between two pixels of `in` when the map stores more channels than the Cin that are used (0 = Cin)
 // cout_live: output channels >= cout_live are zero padding of the layer (zero weights and bias): their 32-channel fragments
 // are not multiplied, the channels are stored as zeros (0 = Cout)
+// single: one f16 product per element pair (hi planes only) instead of three, see GemmP.single
 // SuperPoint conv1a (1->64, VALU, evaluated on the fly for the patch) fused into conv1b (64->64, split MFMA):
 // image [B,H,W] -> relu(conv1b(relu(conv1a(image)))) (+2x2 max-pool), NHWC out
 int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* w1a, const float* b1a,

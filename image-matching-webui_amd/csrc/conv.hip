@@ -163,7 +163,8 @@ __device__ __forceinline__ float conv_act(float v, int code) { return code == 2 
 
 // NC = 32-channel output fragments per wave: 2 -> 64 output channels per workgroup, 4 -> 128 (per tap 24 LDS fragment reads for
 // 48 MFMAs instead of 16 for 24, half as many barriers per MFMA; used when Cout % 128 == 0)
-template <bool FUSE1A, int NC>
+// SINGLE: one f16 product per element pair (hi planes only) instead of three: see GemmP.single
+template <bool FUSE1A, int NC, bool SINGLE = false>
 __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(const float* __restrict__ in,
                                                             const unsigned short* __restrict__ wh,
                                                             const unsigned short* __restrict__ wl,
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                 uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
                 if ((pvalid >> k) & 1u) split8(pa[k], pc[k], hq, lq);
                 Ph[(idx & 3) * SPSTR + (idx >> 2)] = hq;
-                Pl[(idx & 3) * SPSTR + (idx >> 2)] = lq;
+                if constexpr (!SINGLE) Pl[(idx & 3) * SPSTR + (idx >> 2)] = lq;
             }
         }
     };
@@ -320,10 +321,10 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
         auto wload = [&](int tap) __attribute__((always_inline)) {
             const size_t o = ((size_t)(ch * 9 + tap) * 4 + (tid >> 6)) * Cout + cout0 + (tid & 63);
             rwh = wh4[o];
-            rwl = wl4[o];
+            if constexpr (!SINGLE) rwl = wl4[o];
             if constexpr (NC == 4) {
                 rwh1 = wh4[o + 64];
-                rwl1 = wl4[o + 64];
+                if constexpr (!SINGLE) rwl1 = wl4[o + 64];
             }
         };
         wload(0);
@@ -331,10 +332,10 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
             uint4* wbh = Wb + (tap & 1) * (2 * 4 * WSN);
             uint4* wbl = wbh + 4 * WSN;
             wbh[(tid >> 6) * WSN + (tid & 63)] = rwh;
-            wbl[(tid >> 6) * WSN + (tid & 63)] = rwl;
+            if constexpr (!SINGLE) wbl[(tid >> 6) * WSN + (tid & 63)] = rwl;
             if constexpr (NC == 4) {
                 wbh[(tid >> 6) * WSN + (tid & 63) + 64] = rwh1;
-                wbl[(tid >> 6) * WSN + (tid & 63) + 64] = rwl1;
+                if constexpr (!SINGLE) wbl[(tid >> 6) * WSN + (tid & 63) + 64] = rwl1;
             }
             __syncthreads();
             if (tap + 1 < 9) wload(tap + 1);
@@ -347,12 +348,12 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                 for (int m = 0; m < 2; ++m) {
                     const int pp = (2 * wid + m + dy) * SPW + lo + dx;
                     ah[m] = Ph[oc * SPSTR + pp];
-                    al[m] = Pl[oc * SPSTR + pp];
+                    if constexpr (!SINGLE) al[m] = Pl[oc * SPSTR + pp];
                 }
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
                     bh[n] = wbh[oc * WSN + n * 32 + lo];
-                    bl[n] = wbl[oc * WSN + n * 32 + lo];
+                    if constexpr (!SINGLE) bl[n] = wbl[oc * WSN + n * 32 + lo];
                 }
 #pragma unroll
                 for (int n = 0; n < NC; ++n) {
@@ -360,8 +361,10 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         // weights = MFMA A operand (rows = output channels), pixels = B (columns)
-                        acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
-                        acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                        if constexpr (!SINGLE) {
+                            acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                            acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                        }
                         acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
                     }
                 }
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live) {
+                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single) {
     if (cin_stride <= 0) cin_stride = Cin;
     if (cout_live <= 0 || cout_live > Cout) cout_live = Cout;
     if (cin_stride < Cin || cin_stride % 4 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pixel stride %d for %d input channels", cin_stride, Cin);
@@ -481,7 +484,13 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     const long nwg = (long)tiles_x * tiles_y * (Cout / (wide ? 128 : 64)) * B;
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
-    if (wide)
+    if (wide && single)
+        hipLaunchKernelGGL((conv3x3_split_kernel<false, 4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+    else if (single)
+        hipLaunchKernelGGL((conv3x3_split_kernel<false, 2, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+    else if (wide)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
                            tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
     else

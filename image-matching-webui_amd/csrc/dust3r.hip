@@ -32,16 +32,19 @@
 // ------------------------------------------------------------------ layer table
 struct DuCfg {
     int E, enc_depth, D, dec_depth;
+    int desc;  // MASt3R: width of the local descriptors (head_local_features); 0 = DUSt3R
 };
 static const int DU_LD[4] = {96, 192, 384, 768};
-enum { DU_HEAD_LAYERS = 33, DU_ENC_J = 4, DU_DEC_J = 7 };
+enum { DU_HEAD_BASE = 33, DU_ENC_J = 4, DU_DEC_J = 7 };
+static int du_head_layers(const DuCfg& c) { return DU_HEAD_BASE + (c.desc > 0 ? 2 : 0); }
 // encoder block: qkv, proj, fc1, fc2.  decoder block: qkv, proj, cross q, cross [k | v], cross proj, fc1, fc2.
 // head: 0 act1 1x1 | 1 act1 transposed 4x4/4 | 2 act2 1x1 | 3 act2 transposed 2x2/2 | 4 act3 1x1 | 5 act4 1x1 | 6 act4 3x3/2 |
 //       7-10 layer_rn | 11 + 5 q + {rcu1.conv1, rcu1.conv2, rcu2.conv1, rcu2.conv2, out_conv} for refinenet 4 - q | 31 head.0 | 32 head.2
+//       MASt3R: 33 head_local_features.fc1 (E + D -> 4 (E + D)) | 34 .fc2 (-> (desc + 1) x 256)
 static int du_l_enc(const DuCfg&, int i, int j) { return 1 + DU_ENC_J * i + j; }
 static int du_l_demb(const DuCfg& c) { return 1 + DU_ENC_J * c.enc_depth; }
 static int du_l_dec(const DuCfg& c, int s, int i, int j) { return du_l_demb(c) + 1 + (s * c.dec_depth + i) * DU_DEC_J + j; }
-static int du_l_head(const DuCfg& c, int hd) { return du_l_demb(c) + 1 + 2 * c.dec_depth * DU_DEC_J + hd * DU_HEAD_LAYERS; }
+static int du_l_head(const DuCfg& c, int hd) { return du_l_demb(c) + 1 + 2 * c.dec_depth * DU_DEC_J + hd * du_head_layers(c); }
 static int du_nlayers(const DuCfg& c) { return du_l_head(c, 2); }
 
 // kind 0: GEMM weight [N][K] -> fragment-major planes; 1: 3x3 stride-1 convolution [N][9][Cin] -> planes of conv3x3_split_kernel
@@ -70,7 +73,7 @@ static void du_shape(const DuCfg& c, int li, int* N, int* K, int* kind) {
         *K = j == 6 ? 4 * D : D;
         return;
     }
-    const int j = (li - du_l_head(c, 0)) % DU_HEAD_LAYERS;
+    const int j = (li - du_l_head(c, 0)) % du_head_layers(c);
     static const int tabN[7] = {96, 96 * 16, 192, 192 * 4, 384, 768, 768};
     if (j < 7) {
         const int tabK[7] = {E, 96, D, 192, D, D, 9 * 768};
@@ -91,9 +94,14 @@ static void du_shape(const DuCfg& c, int li, int* N, int* K, int* kind) {
         *kind = u == 4 ? 0 : 1;
         return;
     }
-    *N = 128;
-    *K = j == 31 ? 9 * 256 : 9 * 128;
-    *kind = 1;
+    if (j < 33) {
+        *N = 128;
+        *K = j == 31 ? 9 * 256 : 9 * 128;
+        *kind = 1;
+        return;
+    }
+    *N = j == 33 ? 4 * (E + D) : (c.desc + 1) * 256;
+    *K = j == 33 ? E + D : 4 * (E + D);
 }
 
 // f32 vectors: encoder block i: 4 i + {norm1.w, norm1.b, norm2.w, norm2.b}; enc_norm; decoder (side s, block i): 8 (s dec_depth + i)
@@ -114,7 +122,7 @@ static int du_vec_len(const DuCfg& c, int vi) {
 
 static bool du_cfg_ok(const DuCfg& c) {
     return c.E >= 64 && c.E <= 1024 && c.E % 64 == 0 && c.D >= 64 && c.D <= 1024 && c.D % 64 == 0 && c.enc_depth >= 1 && c.dec_depth >= 4 &&
-           c.dec_depth % 4 == 0;
+           c.dec_depth % 4 == 0 && c.desc >= 0 && c.desc <= 63 && (c.desc == 0 || (c.E + c.D) % 32 == 0);
 }
 
 struct DuLayout {
@@ -150,38 +158,40 @@ static DuLayout du_layout(const DuCfg& c) {
     return l;
 }
 
-static DuCfg du_cfg(int enc_dim, int enc_depth, int dec_dim, int dec_depth) { return DuCfg{enc_dim, enc_depth, dec_dim, dec_depth}; }
+static DuCfg du_cfg(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim) {
+    return DuCfg{enc_dim, enc_depth, dec_dim, dec_depth, desc_dim};
+}
 
-extern "C" size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     return du_cfg_ok(c) ? du_layout(c).total : 0;
 }
-extern "C" int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     return du_cfg_ok(c) ? du_nlayers(c) : 0;
 }
-extern "C" int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     return du_cfg_ok(c) ? du_nvec(c) : 0;
 }
-extern "C" int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i, int* N, int* K) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i, int* N, int* K) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || i < 0 || i >= du_nlayers(c) || !N || !K) return IMCUI_ERR_ARG;
     int kind;
     du_shape(c, i, N, K, &kind);
     return IMCUI_OK;
 }
-extern "C" int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || i < 0 || i >= du_nvec(c)) return 0;
     return du_vec_len(c, i);
 }
 
 // w[i]: [N][K] f32 (convolutions in the implicit-GEMM order [Cout][tap][Cin], transposed convolutions as [(dy, dx, cout)][cin]),
 // b[i]: [N] or null (zero), vec[i]: the f32 vectors in the order above.  The layers are split on a few host threads.
-extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* const* w,
+extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* const* w,
                                              const float* const* b, const float* const* vec, float* packed) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || !w || !b || !vec || !packed) return IMCUI_ERR_ARG;
     const DuLayout l = du_layout(c);
     const int nl = du_nlayers(c), nv = du_nvec(c);
@@ -216,7 +226,7 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
 // ------------------------------------------------------------------ workspace
 struct DuWs {
     float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
-    float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2;
+    float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2, *lfh, *lfo;
     int *cnt, *smap, *wsel, *wsel_rev;
     size_t total;
     bool ok;
@@ -264,6 +274,8 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     w.hd0 = a.get<float>(pt * 64 * 128);
     w.hd1 = a.get<float>(pt * 256 * 128);
     w.hd2 = a.get<float>(pt * 256 * 128);
+    w.lfh = c.desc > 0 ? a.get<float>(pt * 4 * (E + D)) : nullptr;  // MASt3R: hidden layer and output of head_local_features
+    w.lfo = c.desc > 0 ? a.get<float>(pt * (size_t)(c.desc + 1) * 256) : nullptr;
     w.cnt = a.get<int>((size_t)(NI > 2 * P ? NI : 2 * P) + 64);
     w.smap = a.get<int>((size_t)2 * P + 64);
     w.wsel = a.get<int>((size_t)P + 64);
@@ -274,8 +286,8 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
 }
 static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0; }
 
-extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
     return du_carve(nullptr, 0, c, NI, P, H, W).total;
 }
@@ -283,8 +295,8 @@ extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, i
 // floats the optional dump of the forward holds: (enc_depth + 2) x [NI R E] (patch embedding, every block, enc_norm), (dec_depth + 2) x
 // [2P R D] (embedded streams, every block, dec_norm), then per view: layer_rn 0..3, path 4..1, the 128-channel full-resolution
 // feature map, the raw [P H W 4] regression
-extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W) {
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
     const size_t R = du_R(H, W), h = H / 16, w = W / 16, p = P;
     size_t n = (size_t)(c.enc_depth + 2) * NI * R * c.E + (size_t)(c.dec_depth + 2) * 2 * P * R * c.D;
@@ -296,18 +308,24 @@ extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int d
 
 // ------------------------------------------------------------------ forward
 // images [NI,3,H,W] in [0,1]; pairs (device) [P][2]: directed pair p = (view 1 image, view 2 image), indices clamped to [0, NI).
-// Outputs, view-major:
-// pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W].
-extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* packed,
-                                        const float* images, int NI, int H, int W, const int* pairs, int P, float* pts3d, float* conf,
-                                        float* dump, size_t dump_floats, void* ws, size_t ws_bytes, void* stream_) {
+// arith: 0 = the 3 x f16 split products of the library's default mode (fp32-grade results), 1 = ONE f16 product per element pair in the
+// GEMMs and convolutions (f32 accumulate; 11-bit operands: the class of the bf16 run BASELINE's configs[4] names).  Outputs, view-major:
+// pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W];
+// MASt3R (desc_dim > 0): desc [2][P][H][W][desc_dim] (unit norm), desc_conf [2][P][H][W].
+extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
+                                        const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d,
+                                        float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes,
+                                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!h) return IMCUI_ERR_ARG;
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth);
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: unsupported configuration (dims multiples of 64 up to 1024, dec_depth a multiple of 4)");
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
+    if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: arith = %d (0: 3 x f16 split products, 1: one f16 product)", arith);
+    const int single = arith;  // GEMMs and 3x3 convolutions with ONE f16 product per element pair; attention stays in the split arithmetic
     if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 32", NI, W, H, P);
-    if (!packed || !images || !pairs || !pts3d || !conf) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
+    if (!packed || !images || !pairs || !pts3d || !conf || (c.desc > 0 && (!desc || !desc_conf)))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
     if (((size_t)(c.E / 64) * NI) % 8 != 0 || ((size_t)(c.D / 64) * 2 * P) % 8 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: heads x sequences must be a multiple of 8 (encoder %d x %d, decoder %d x %d)", c.E / 64, NI, c.D / 64, 2 * P);
     DuWs w = du_carve(ws, ws_bytes, c, NI, P, H, W);
@@ -362,6 +380,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.resid = resid;
         g.ldr = N;
         g.act = act;
+        g.single = single;
         g.M = nseq * R;
         g.cnt = w.cnt;
         g.rows_per_seq = R;
@@ -404,6 +423,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.resid = resid;
         g.ldr = N;
         g.act = act;
+        g.single = single;
         g.M = 2 * P * R;
         g.cnt = w.cnt;
         g.rows_per_seq = R;
@@ -426,6 +446,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.lda = K;
         g.C = C;
         g.ldc = N;
+        g.single = single;
         g.M = (int)rows;
         return gemm_launch(h, g, stream);
     };
@@ -554,7 +575,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             int N, K, kind;
             du_shape(c, li, &N, &K, &kind);
             return conv3x3_split_launch(h, in, reinterpret_cast<const unsigned short*>(Pk + l.wh[li]), reinterpret_cast<const unsigned short*>(Pk + l.wl[li]),
-                                        Pk + l.ws[li], Pk + l.b[li], out, P, hh, ww, K / 9, N, act, 0, stream, resid);
+                                        Pk + l.ws[li], Pk + l.b[li], out, P, hh, ww, K / 9, N, act, 0, stream, resid, 0, 0, single);
         };
         auto shuffle = [&](const float* src, float* dst, int s, int C) {
             const long n4 = pt * s * s * (C / 4);
@@ -598,6 +619,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             g.M = P * (hg / 2) * (wg / 2);
             g.C = w.tm;
             g.ldc = N;
+            g.single = single;
             DURUN(gemm_launch(h, g, stream));
         }
         DURUN(conv3(L0 + 10, w.tm, w.rn[3], hg / 2, wg / 2, 0, nullptr));
@@ -641,6 +663,36 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         hipLaunchKernelGGL(du_regress_kernel, blocks(npix * 32), blk, 0, stream, w.hd2, V(du_v_head(c, v)), V(du_v_head(c, v) + 1),
                            pts3d + (size_t)v * npix * 3, conf + (size_t)v * npix, raw, npix);
         IMCUI_CHECK_LAUNCH(h);
+        if (c.desc > 0) {
+            // MASt3R (mast3r.py:41-66): local features = MLP([encoder tokens | last decoder tokens]) per token, (desc + 1) x 16 x 16 values
+            // = the descriptors and their confidence logit of the token's 16x16 pixels (pixel shuffle), descriptors L2-normalised
+            int N, K, kind;
+            du_shape(c, L0 + 33, &N, &K, &kind);
+            GemmP g;
+            g.epi = EPI_CONV;
+            g.N = N;
+            g.K = K;
+            g.ldw = K;
+            g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[L0 + 33]);
+            g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[L0 + 33]);
+            g.wscale = Pk + l.ws[L0 + 33];
+            g.bias = Pk + l.b[L0 + 33];
+            g.A = tok0;
+            g.lda = E;
+            g.A2 = hk[2];
+            g.lda2 = D;
+            g.K1 = E;
+            g.C = w.lfh;
+            g.ldc = N;
+            g.act = 3;
+            g.single = single;
+            g.M = (int)pt;
+            DURUN(gemm_launch(h, g, stream));
+            DURUN(lin_dense(L0 + 34, w.lfh, w.lfo, pt));
+            hipLaunchKernelGGL(du_desc_kernel, blocks(npix), blk, 0, stream, w.lfo, desc + (size_t)v * npix * c.desc, desc_conf + (size_t)v * npix, H, W,
+                               c.desc, npix);
+            IMCUI_CHECK_LAUNCH(h);
+        }
     }
     if (!dump_ok) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: dump buffer too small (%zu floats)", dump_floats);
     return IMCUI_OK;

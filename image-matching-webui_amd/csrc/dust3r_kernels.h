@@ -272,6 +272,34 @@ __global__ __launch_bounds__(256) void du_regress_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ MASt3R local features: pixel shuffle + L2 normalisation
+// lf [P*T][(dd + 1) * 256]: column c * 256 + (y % 16) * 16 + (x % 16) of token (y / 16, x / 16) is channel c of pixel (y, x)
+// (F.pixel_shuffle(., 16) of the [B, (dd + 1) * 256, H/16, W/16] view).  desc [npix][dd] = channels 0 .. dd-1 / their norm
+// (desc_mode 'norm'), desc_conf [npix] = exp(channel dd) (desc_conf_mode ('exp', 0, inf)).  One thread per pixel, consecutive
+// threads = consecutive positions inside a token (coalesced 64-byte runs per channel).
+__global__ __launch_bounds__(256) void du_desc_kernel(const float* __restrict__ lf, float* __restrict__ desc, float* __restrict__ desc_conf, int H,
+                                                      int W, int dd, long npix) {
+    const int wg = W >> 4, T = (H >> 4) * wg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        // i enumerates (image, token, position inside the token)
+        const int sub = (int)(i & 255);
+        const long bt = i >> 8;
+        const int t = (int)(bt % T);
+        const long b = bt / T;
+        const int y = (t / wg) * 16 + (sub >> 4), x = (t % wg) * 16 + (sub & 15);
+        const float* src = lf + bt * (long)(dd + 1) * 256 + sub;
+        float ss = 0.0f;
+        for (int c = 0; c < dd; ++c) {
+            const float u = src[(long)c * 256];
+            ss += u * u;
+        }
+        const float nrm = sqrtf(ss);
+        const long p = (b * H + y) * (long)W + x;
+        for (int c = 0; c < dd; ++c) desc[p * dd + c] = src[(long)c * 256] / nrm;  // second read of the 64-byte runs: L2 hits
+        desc_conf[p] = expf(src[(long)dd * 256]);
+    }
+}
+
 // stream table of the decoder: smap[s] = view-1 image of pair s, smap[P + s] = its view-2 image
 __global__ void du_smap_kernel(const int* __restrict__ pairs, int* __restrict__ smap, int P, int NI) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -69,6 +69,9 @@ struct GemmP {
     // rup_align = align_corners of the interpolation (LoFTR: 1, EfficientLoFTR: 0).  0 = plain [M, N] residual.
     int rup_h = 0, rup_w = 0, rup_align = 1;
     int act = 0;
+    // 1: ONE f16 product per element pair (hi planes only, f32 accumulate) instead of the three of the split arithmetic: 11-bit
+    // operands, the class of a bf16 / fp16 autocast run.  EPI_CONV with pre-split weight planes only.
+    int single = 0;
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;

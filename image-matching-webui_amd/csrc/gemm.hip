@@ -644,13 +644,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
 // NW:   32-column fragments per wave: 2 -> tile 128 x 128 (three workgroups per CU), 4 -> tile 128 x 256 (two per
 //       CU, 80 KB LDS): per MFMA half the LDS fragment reads and half the activation staging -- on a SIMD the
 //       matrix pipe and everything else serialise, so the wave tile is the efficiency lever
-template <int EPI, int ASRC, bool WDMA, int NW>
+// SINGLE: one f16 product per element pair instead of three (hi planes only, f32 accumulate): the arithmetic class of a
+//       bf16 / fp16 autocast run (11-bit operands) for callers that ask for it (GemmP.single; pre-split weights only)
+template <int EPI, int ASRC, bool WDMA, int NW, bool SINGLE = false>
 __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_kernel(GemmP p) {
     // 128-column tiles: the four weight fragments of a wave in four registers, single LDS buffer (written between
     // the two barriers like the activations).  256-column tiles: eight fragments, four registers, two halves,
     // double-buffered in LDS (parked while the current tile is multiplied).
     constexpr bool WREGP = WDMA && NW == 2;
     static_assert(NW == 2 || (NW == 4 && WDMA), "256-column tiles need pre-split weight planes");
+    static_assert(!SINGLE || WDMA, "the single-product variant reads pre-split weight planes");
     constexpr int BPL = 4 * NW * 1024;  // bytes per B plane per stage: [ks 2][nf 2 NW] fragments of 1 KiB
     // A_hi 8K | A_lo 8K | B stage 0 (hi, lo) | B stage 1 (256-column tiles) ; reused by the epilogue (<= 36864 B)
     __shared__ uint4 smem[((WDMA && NW == 2) ? 36864 : 16384 + 4 * BPL) / 16];
@@ -741,13 +744,13 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
         if (ASRC == 1 && !v0) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
         split8(fa, fb, h, l);
         *reinterpret_cast<uint4*>(sm + wo0) = h;
-        *reinterpret_cast<uint4*>(sm + 8192 + wo0) = l;
+        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + 8192 + wo0) = l;
         fa = __builtin_bit_cast(float4, a1);
         fb = __builtin_bit_cast(float4, b1);
         if (ASRC == 1 && !v1) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
         split8(fa, fb, h, l);
         *reinterpret_cast<uint4*>(sm + wo1) = h;
-        *reinterpret_cast<uint4*>(sm + 8192 + wo1) = l;
+        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + 8192 + wo1) = l;
     };
 
     // ---- B operand
@@ -769,30 +772,38 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
     auto load_bp2 = [&](int kt, uint4& q0, uint4& q1, uint4& q2, uint4& q3) __attribute__((always_inline)) {
         q0 = wh[0][(size_t)(kt * 2 + 0) * 64];
         q1 = wh[0][(size_t)(kt * 2 + 1) * 64];
-        q2 = wl[0][(size_t)(kt * 2 + 0) * 64];
-        q3 = wl[0][(size_t)(kt * 2 + 1) * 64];
+        if constexpr (!SINGLE) {
+            q2 = wl[0][(size_t)(kt * 2 + 0) * 64];
+            q3 = wl[0][(size_t)(kt * 2 + 1) * 64];
+        }
     };
     auto store_bp2 = [&](int stg, uint4& q0, uint4& q1, uint4& q2, uint4& q3) __attribute__((always_inline)) {
         char* d = sm + 16384 + wid * 1024 + lane * 16;  // single buffer: written between the two barriers, like A
         (void)stg;
         *reinterpret_cast<uint4*>(d) = q0;
         *reinterpret_cast<uint4*>(d + BPL / 2) = q1;
-        *reinterpret_cast<uint4*>(d + BPL) = q2;
-        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = q3;
+        if constexpr (!SINGLE) {
+            *reinterpret_cast<uint4*>(d + BPL) = q2;
+            *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = q3;
+        }
     };
     // 256-column tiles: the wave's two column blocks (u = 0, 1) go through the same four registers one after the other
     auto load_bu = [&](int kt, int u) __attribute__((always_inline)) {
         bq0 = wh[u][(size_t)(kt * 2 + 0) * 64];
         bq1 = wh[u][(size_t)(kt * 2 + 1) * 64];
-        bq2 = wl[u][(size_t)(kt * 2 + 0) * 64];
-        bq3 = wl[u][(size_t)(kt * 2 + 1) * 64];
+        if constexpr (!SINGLE) {
+            bq2 = wl[u][(size_t)(kt * 2 + 0) * 64];
+            bq3 = wl[u][(size_t)(kt * 2 + 1) * 64];
+        }
     };
     auto store_bu = [&](int stg, int u) __attribute__((always_inline)) {
         char* d = sm + 16384 + stg * 2 * BPL + (wid + 4 * u) * 1024 + lane * 16;
         *reinterpret_cast<uint4*>(d) = bq0;
         *reinterpret_cast<uint4*>(d + BPL / 2) = bq1;
-        *reinterpret_cast<uint4*>(d + BPL) = bq2;
-        *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = bq3;
+        if constexpr (!SINGLE) {
+            *reinterpret_cast<uint4*>(d + BPL) = bq2;
+            *reinterpret_cast<uint4*>(d + BPL + BPL / 2) = bq3;
+        }
     };
     auto load_bp = [&](int kt) __attribute__((always_inline)) { load_bp2(kt, bq0, bq1, bq2, bq3); };
     auto store_bp = [&](int stg) __attribute__((always_inline)) { store_bp2(stg, bq0, bq1, bq2, bq3); };
@@ -830,21 +841,23 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
             for (int m = 0; m < 2; ++m) {
                 const int fo = (ks * 4 + wm * 2 + m) * 1024 + apos;
                 ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
-                al[m] = *reinterpret_cast<const uint4*>(sm + 8192 + fo);
+                if constexpr (!SINGLE) al[m] = *reinterpret_cast<const uint4*>(sm + 8192 + fo);
             }
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 const int fo = (ks * 2 * NW + wn * NW + n) * 1024 + (WDMA ? lane * 16 : apos);
                 bh[n] = *reinterpret_cast<const uint4*>(sbt + fo);
-                bl[n] = *reinterpret_cast<const uint4*>(sbt + BPL + fo);
+                if constexpr (!SINGLE) bl[n] = *reinterpret_cast<const uint4*>(sbt + BPL + fo);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < NW; ++n) {
                     // weight fragment = MFMA A operand (rows = features), activations = B (cols = tokens)
-                    acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
-                    acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                    if constexpr (!SINGLE) {
+                        acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                        acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                    }
                     acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
                 }
         }
@@ -986,11 +999,24 @@ static void launch_one(const GemmP& p, bool split, hipStream_t stream) {
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI>, grid, dim3(256), 0, stream, p);
     else if (wide) {
+        if constexpr (EPI == EPI_CONV) {
+            if (p.single) {
+                hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 4, true>), grid, dim3(256), 0, stream, p);
+                return;
+            }
+        }
         if constexpr (EPI != EPI_QKV && EPI != EPI_CROSS)
             hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 4>), grid, dim3(256), 0, stream, p);
     }
-    else if (p.Wh != nullptr)
+    else if (p.Wh != nullptr) {
+        if constexpr (EPI == EPI_CONV) {
+            if (p.single) {
+                hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 2, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, true, 2>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
+    }
     else
         hipLaunchKernelGGL((gemm_split_kernel<EPI, 0, false, 2>), grid, dim3(256), 0, stream, p);
 }
@@ -999,8 +1025,12 @@ static void launch_conv(const GemmP& p, bool split, hipStream_t stream) {
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, wide ? 256 : BN), 1, p.batch);
     if (!split)
         hipLaunchKernelGGL(gemm_kernel<EPI_CONV>, grid, dim3(256), 0, stream, p);
+    else if (wide && p.single)
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 4, true>), grid, dim3(256), 0, stream, p);
     else if (wide)
         hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 4>), grid, dim3(256), 0, stream, p);
+    else if (p.Wh != nullptr && p.single)
+        hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 2, true>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else if (p.Wh != nullptr)
         hipLaunchKernelGGL((gemm_split_kernel<EPI_CONV, 1, true, 2>), grid, dim3(256), occupancy_pad((long)grid.x * grid.z), stream, p);
     else
@@ -1022,6 +1052,8 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     if (p.split_out && (!split || p.rows_per_seq <= 0 || p.N % BN != 0 || p.M % BM != 0 || p.batch != 1))
         return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: split_out needs the split mode and whole 128x128 tiles (M=%d N=%d)", p.M, p.N);
     if (!split && p.W == nullptr) return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: f32 weights missing");
+    if (p.single && (!split || p.Wh == nullptr || p.epi != EPI_CONV))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: the single-product variant needs the split mode, pre-split weight planes and EPI_CONV");
     static const bool dbg = getenv("IMCUI_HIP_GEMM_DEBUG") != nullptr;
     if (dbg) {
         hipStreamSynchronize(stream);

@@ -612,7 +612,11 @@ class ELoFTRHIP:
         return self.last_ws[off : off + 4 * n].view(torch.float32).view(*shape)
 
 
-DUST3R_CFG = {"enc_dim": 1024, "enc_depth": 24, "dec_dim": 768, "dec_depth": 12}  # DUSt3R_ViTLarge_BaseDecoder_512_dpt
+DUST3R_CFG = {"enc_dim": 1024, "enc_depth": 24, "dec_dim": 768, "dec_depth": 12, "desc_dim": 0}  # DUSt3R_ViTLarge_BaseDecoder_512_dpt
+
+
+def _dust3r_c5(cfg: dict) -> tuple:
+    return (cfg["enc_dim"], cfg["enc_depth"], cfg["dec_dim"], cfg["dec_depth"], cfg.get("desc_dim", 0))
 
 
 def dust3r_cfg_of(state_dict: dict) -> dict:
@@ -625,6 +629,8 @@ def dust3r_cfg_of(state_dict: dict) -> dict:
         "enc_depth": depth("enc_blocks."),
         "dec_dim": state_dict["decoder_embed.weight"].shape[0],
         "dec_depth": depth("dec_blocks."),
+        # MASt3R: head_local_features.fc2 emits (desc_dim + 1) x 16 x 16 values per token
+        "desc_dim": (state_dict["downstream_head1.head_local_features.fc2.weight"].shape[0] // 256 - 1) if "downstream_head1.head_local_features.fc2.weight" in state_dict else 0,
     }
 
 
@@ -634,7 +640,7 @@ def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
     lib = load_library()
     sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
     cfg = dust3r_cfg_of(sd)
-    c4 = (cfg["enc_dim"], cfg["enc_depth"], cfg["dec_dim"], cfg["dec_depth"])
+    c4 = _dust3r_c5(cfg)
     nl = lib.imcui_hip_dust3r_num_layers(*c4)
     if nl == 0:
         raise ImcuiHipError(f"DUSt3R configuration {cfg} is not supported (dims multiples of 64 up to 1024, dec_depth a multiple of 4)")
@@ -699,6 +705,9 @@ def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
             lin(f"{p}scratch.refinenet{r}.out_conv")
         conv(p + "head.0")
         conv(p + "head.2")
+        if cfg["desc_dim"] > 0:
+            lin(f"downstream_head{hd}.head_local_features.fc1")
+            lin(f"downstream_head{hd}.head_local_features.fc2")
     for hd in (1, 2):
         p = f"downstream_head{hd}.dpt.head.4"
         vecs.extend([sd[p + ".weight"].reshape(4, 128).contiguous(), sd[p + ".bias"]])
@@ -733,9 +742,11 @@ class DUSt3RHIP:
         self._lock = threading.Lock()
         self.last_dump = None
 
-    def forward(self, packed, cfg, images, pairs, dump=False):
+    def forward(self, packed, cfg, images, pairs, dump=False, arith=0):
         """images [NI,3,H,W] in [0,1] (H, W multiples of 32), pairs [P,2] int (view-1 image, view-2 image) ->
-        {"pts3d": [2,P,H,W,3], "conf": [2,P,H,W]} (view 1 in its own frame, view 2 in view 1's frame)."""
+        {"pts3d": [2,P,H,W,3], "conf": [2,P,H,W]} (view 1 in its own frame, view 2 in view 1's frame); a MASt3R network
+        (cfg["desc_dim"] > 0) also returns "desc" [2,P,H,W,desc_dim] and "desc_conf" [2,P,H,W].
+        arith: 0 = 3 x f16 split products (fp32-grade), 1 = one f16 product per element pair (bf16-class)."""
         dev = images.device
         hd = get_handle(dev)
         lib = hd.lib
@@ -748,9 +759,12 @@ class DUSt3RHIP:
             raise ImcuiHipError(f"DUSt3R pair table refers to images outside [0, {NI})")
         pairs = pairs.to(dev).contiguous()
         P = pairs.shape[0]
-        c4 = (cfg["enc_dim"], cfg["enc_depth"], cfg["dec_dim"], cfg["dec_depth"])
+        c4 = _dust3r_c5(cfg)
+        dd = c4[4]
         pts = torch.empty((2, P, H, W, 3), dtype=torch.float32, device=dev)
         conf = torch.empty((2, P, H, W), dtype=torch.float32, device=dev)
+        desc = torch.empty((2, P, H, W, dd), dtype=torch.float32, device=dev) if dd else None
+        dconf = torch.empty((2, P, H, W), dtype=torch.float32, device=dev) if dd else None
         nd = lib.imcui_hip_dust3r_dump_floats(*c4, NI, P, H, W) if dump else 0
         dbuf = torch.zeros((nd,), dtype=torch.float32, device=dev) if dump else None
         with self._lock:
@@ -759,11 +773,14 @@ class DUSt3RHIP:
                 raise ImcuiHipError(f"DUSt3R: unsupported sizes ({NI} images of {W}x{H}, {P} pairs; multiples of 32)")
             ws = self._ws.get(nbytes, dev)
             with torch.cuda.device(dev):
-                rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), _ptr(images), NI, H, W, _ptr(pairs), P, _ptr(pts), _ptr(conf),
-                                                  _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
+                rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), _ptr(images), NI, H, W, _ptr(pairs), P, int(arith), _ptr(pts), _ptr(conf),
+                                                  _ptr(desc), _ptr(dconf), _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
                 hd.check(rc, "imcui_hip_dust3r_forward")
         self.last_dump = dbuf
-        return {"pts3d": pts, "conf": conf}
+        out = {"pts3d": pts, "conf": conf}
+        if dd:
+            out.update(desc=desc, desc_conf=dconf)
+        return out
 
 
 def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):

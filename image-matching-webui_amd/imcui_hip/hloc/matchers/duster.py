@@ -34,8 +34,10 @@ class Duster(BaseModel):
         "model_name": "duster_vit_large.pth",
         "max_keypoints": 3000,
         "vit_patch_size": 16,
+        "arithmetic": "fp32",  # HIP backend only: "fp32" = 3 x f16 split products (fp32-grade results), "fp16" = one f16 product (bf16-class, faster)
     }
     required_inputs = ["image0", "image1"]
+    weights_subdir = "duster"  # sub-directory of the checkpoint repository (base_model._download_model: stem of the module file)
 
     def _init(self, conf):
         if conf.get("packed") is not None:  # (packed buffer, architecture) of an earlier backend.pack_dust3r call
@@ -44,7 +46,7 @@ class Duster(BaseModel):
             self.register_buffer("packed", packed, persistent=False)
             self._impl = backend.DUSt3RHIP()
             return
-        sd = resolve_state_dict(conf, "duster")
+        sd = resolve_state_dict(conf, self.weights_subdir)
         if "patch_embed.proj.weight" not in sd or not any(k.startswith("downstream_head1.dpt.") for k in sd):
             raise KeyError("DUSt3R weights must be an AsymmetricCroCo3DStereo state dict with the DPT head (keys patch_embed.proj.*, downstream_head1.dpt.*)")
         self.conf.pop("state_dict", None)
@@ -54,7 +56,8 @@ class Duster(BaseModel):
 
     def forward_pairs(self, images: torch.Tensor, pairs, dump: bool = False) -> dict:
         """The network on any set of directed pairs over `images` [NI,3,H,W] in [0,1]: {"pts3d": [2,P,H,W,3], "conf": [2,P,H,W]}."""
-        return self._impl.forward(self.packed, self.net_cfg, images, pairs, dump)
+        arith = {"fp32": 0, "fp16": 1}[self.conf.get("arithmetic", "fp32")]  # read per call: conf is mutable at run time
+        return self._impl.forward(self.packed, self.net_cfg, images, pairs, dump, arith)
 
     def inference_output(self, data: dict) -> dict:
         """What `inference(pairs, self.net, device, batch_size=1)` returns for the symmetrised pair (duster.py:66-73)."""
@@ -65,6 +68,7 @@ class Duster(BaseModel):
         if H % 32 or W % 32:
             raise ValueError(f"the HIP DUSt3R path needs image sizes that are multiples of 32, got {W}x{H}")
         out = self.forward_pairs(torch.cat((img0, img1), 0), [[0, 1], [1, 0]])
+        self._last_forward = out
         norm = [(img0 - 0.5) / 0.5, (img1 - 0.5) / 0.5]
         shape = torch.tensor([[H, W], [H, W]])
 

@@ -106,17 +106,17 @@ SIGNATURES = {
         [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_double] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_eloftr_debug_offset": (C.c_size_t, [C.c_int] * 6),
-    "imcui_hip_dust3r_packed_floats": (C.c_size_t, [C.c_int] * 4),
-    "imcui_hip_dust3r_num_layers": (C.c_int, [C.c_int] * 4),
-    "imcui_hip_dust3r_num_vectors": (C.c_int, [C.c_int] * 4),
-    "imcui_hip_dust3r_layer_shape": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "imcui_hip_dust3r_vector_len": (C.c_int, [C.c_int] * 5),
-    "imcui_hip_dust3r_pack_weights": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
-    "imcui_hip_dust3r_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
-    "imcui_hip_dust3r_dump_floats": (C.c_size_t, [C.c_int] * 8),
+    "imcui_hip_dust3r_packed_floats": (C.c_size_t, [C.c_int] * 5),
+    "imcui_hip_dust3r_num_layers": (C.c_int, [C.c_int] * 5),
+    "imcui_hip_dust3r_num_vectors": (C.c_int, [C.c_int] * 5),
+    "imcui_hip_dust3r_layer_shape": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imcui_hip_dust3r_vector_len": (C.c_int, [C.c_int] * 6),
+    "imcui_hip_dust3r_pack_weights": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "imcui_hip_dust3r_workspace_bytes": (C.c_size_t, [C.c_int] * 9),
+    "imcui_hip_dust3r_dump_floats": (C.c_size_t, [C.c_int] * 9),
     "imcui_hip_dust3r_forward": (
         C.c_int,
-        [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_conv_gemm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]),

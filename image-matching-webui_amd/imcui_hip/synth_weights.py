@@ -443,7 +443,8 @@ def dust3r_state_dict(seed: int = 0, cfg: dict | None = None, gain: float = 1.0)
     gain / sqrt(fan_in), so every sub-layer moves the residual stream by O(1) (attention logits have unit spread, the
     MLPs are not negligible next to the stream): the parity tests then see each block's arithmetic, which the usual
     std = 0.02 initialisation would hide.  The last 1x1 convolution is small enough that expm1(|xyz|) stays O(1).
-    `cfg` overrides enc_dim / enc_depth / dec_dim / dec_depth (dims multiples of 64, dec_depth a multiple of 4)."""
+    `cfg` overrides enc_dim / enc_depth / dec_dim / dec_depth (dims multiples of 64, dec_depth a multiple of 4); cfg["desc_dim"] > 0
+    adds MASt3R's `head_local_features` (`AsymmetricMASt3R`, imcui/hloc/matchers/mast3r.py:41: 24 for the shipped checkpoint)."""
     c = {**DUST3R_CFG, **(cfg or {})}
     E, D = c["enc_dim"], c["dec_dim"]
     g = torch.Generator().manual_seed(seed)
@@ -512,4 +513,9 @@ def dust3r_state_dict(seed: int = 0, cfg: dict | None = None, gain: float = 1.0)
         conv(p + "head.0", 128, 256, 3)
         conv(p + "head.2", 128, 128, 3, 1.4)
         conv(p + "head.4", 4, 128, 1, 0.5)
+        dd = c.get("desc_dim", 0)
+        if dd:
+            q = f"downstream_head{hd}.head_local_features."
+            lin(q + "fc1", 4 * (E + D), E + D)
+            lin(q + "fc2", (dd + 1) * 256, 4 * (E + D), 1.5)
     return sd

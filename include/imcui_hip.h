@@ -248,24 +248,31 @@ size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, i
  * head.0, head.2).  imcui_hip_dust3r_num_vectors() f32 vectors of imcui_hip_dust3r_vector_len(i): the LayerNorm weights / biases in
  * module order, head.4 weight [4][128] and bias [4] per head, the 16 rotary frequencies 100^(-i/16).  Built from the upstream
  * state dict by imcui_hip/backend.py:pack_dust3r. */
-size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
-int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
-int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth);
-int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i, int* N, int* K);
-int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int i);
-int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* const* w, const float* const* b,
-                                  const float* const* vec, float* packed);
-size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W);
-size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int NI, int P, int H, int W);
+/* desc_dim: 0 = DUSt3R; > 0 = MASt3R (`AsymmetricMASt3R`, imcui/hloc/matchers/mast3r.py:41 with the 'catmlp+dpt' head of
+ * `MASt3R_ViTLarge_BaseDecoder_512_catmlpdpt_metric.pth`, desc_dim = 24): two more matrices per head, head_local_features.fc1
+ * [4 (E + D)][E + D] and .fc2 [(desc_dim + 1) * 256][4 (E + D)], after head.2. */
+size_t imcui_hip_dust3r_packed_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim);
+int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim);
+int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim);
+int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i, int* N, int* K);
+int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i);
+int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* const* w,
+                                  const float* const* b, const float* const* vec, float* packed);
+size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);
+size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);
 /* `AsymmetricCroCo3DStereo.forward(view1, view2)` for P directed pairs over NI images: images [dev, NI,3,H,W] in [0,1] (the
  * wrapper's mean = std = 0.5 normalisation, duster.py:60-64, is applied inside), H and W multiples of 32; pairs [dev, P,2] int32 =
  * (view-1 image, view-2 image) -- duster.py:70-72 asks for (0,1) and (1,0).  Every image is encoded once.  Outputs, view-major:
- * pts3d [dev, 2,P,H,W,3] (view 1: `pts3d`; view 2: `pts3d_in_other_view`, i.e. in view 1's frame), conf [dev, 2,P,H,W].
+ * pts3d [dev, 2,P,H,W,3] (view 1: `pts3d`; view 2: `pts3d_in_other_view`, i.e. in view 1's frame), conf [dev, 2,P,H,W]; with
+ * desc_dim > 0 also desc [dev, 2,P,H,W,desc_dim] (unit-norm local descriptors: MLP on [encoder | decoder] tokens, pixel shuffle
+ * 16, `desc / |desc|`) and desc_conf [dev, 2,P,H,W] = exp(.) (mast3r.py:61-64 reads `pred1["desc"]`, `pred2["desc"]`); NULL otherwise.
  * dump (may be NULL; parity tests): imcui_hip_dust3r_dump_floats() floats of intermediate token states and head maps.
- * Split arithmetic only (IMCUI_ERR_UNSUPPORTED in precision 0). */
-int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, const float* packed,
-                             const float* images, int NI, int H, int W, const int* pairs, int P, float* pts3d, float* conf, float* dump,
-                             size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
+ * arith: 0 = 3 x f16 split products (fp32-grade results, the parity mode), 1 = one f16 product per element pair in the GEMMs and
+ * convolutions with f32 accumulation (the class of the bf16 run the reference's configuration names; attention stays split).
+ * The handle must be in the split mode (IMCUI_ERR_UNSUPPORTED in precision 0). */
+int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
+                             const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d, float* conf,
+                             float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);

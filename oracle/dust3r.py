@@ -247,6 +247,43 @@ class DUSt3ROracle:
         return res
 
 
+class MASt3ROracle(DUSt3ROracle):
+    """`AsymmetricMASt3R` (imcui/hloc/matchers/mast3r.py:41; `third_party/mast3r`, un-vendored): the DUSt3R network with the
+    'catmlp+dpt' head (Leroy et al., "Grounding Image Matching in 3D with MASt3R", ECCV 2024): next to the DPT point-map head an
+    MLP (`head_local_features`, hidden width 4 (E + D), GELU) reads the concatenation [encoder tokens | last decoder tokens] and
+    emits (desc_dim + 1) x 16 x 16 values per token; `F.pixel_shuffle(., 16)` spreads them over the token's pixels; the first
+    desc_dim channels, L2-normalised (`desc_mode='norm'`), are the local descriptors, the last is the logit of their confidence
+    (`desc_conf_mode=('exp', 0, inf)`: exp(x)).  The wrapper matches `pred1["desc"][1]` with `pred2["desc"][1]` (mast3r.py:61-75).
+    PARITY UNPINNED like the base class."""
+
+    def __init__(self, state_dict: dict, cfg: dict | None = None):
+        super().__init__(state_dict, cfg)
+        self.desc_dim = self.sd["downstream_head1.head_local_features.fc2.weight"].shape[0] // 256 - 1
+
+    def head(self, tokens, head, H, W, return_intermediates=False):
+        res = super().head(tokens, head, H, W, return_intermediates)
+        p = f"downstream_head{head}.head_local_features"
+        cat = torch.cat((tokens[0], tokens[-1]), -1)
+        lf = self._lin(F.gelu(self._lin(cat, p + ".fc1")), p + ".fc2")  # [B, T, (dd + 1) * 256]
+        B = lf.shape[0]
+        lf = lf.transpose(-1, -2).reshape(B, -1, H // self.cfg["patch"], W // self.cfg["patch"])
+        fmap = F.pixel_shuffle(lf, self.cfg["patch"]).permute(0, 2, 3, 1)  # [B, H, W, dd + 1]
+        d = fmap[..., : self.desc_dim]
+        res["desc"] = d / d.norm(dim=-1, keepdim=True)
+        res["desc_conf"] = fmap[..., self.desc_dim].exp()
+        return res
+
+    def inference_symmetrized(self, image0, image1, return_intermediates=False):
+        res = super().inference_symmetrized(image0, image1, return_intermediates=True)
+        out = res["_passes"]
+        for k, pred in ((0, "pred1"), (1, "pred2")):
+            res[pred]["desc"] = torch.cat([o[k]["desc"] for o in out], 0)
+            res[pred]["desc_conf"] = torch.cat([o[k]["desc_conf"] for o in out], 0)
+        if not return_intermediates:
+            res.pop("_passes")
+        return res
+
+
 def num_params(cfg: dict | None = None) -> int:
     c = {**DEFAULT_CFG, **(cfg or {})}
     E, D = c["enc_dim"], c["dec_dim"]

@@ -122,12 +122,38 @@ def test_pack_dust3r_layout_matches_the_library():
     from imcui_hip.backend import dust3r_cfg_of, pack_dust3r
     from imcui_hip.lib_loader import load_library
 
-    cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4}
-    sd = dust3r_state_dict(9, cfg)
-    assert dust3r_cfg_of(sd) == cfg
-    packed, c = pack_dust3r(sd)
     lib = load_library()
-    assert c == cfg and packed.numel() == lib.imcui_hip_dust3r_packed_floats(128, 1, 64, 4)
-    assert lib.imcui_hip_dust3r_num_layers(100, 1, 64, 4) == 0  # widths must be multiples of 64
-    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 2, 2, 100, 128) == 0  # sizes must be multiples of 32
-    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 2, 2, 96, 128) > 0
+    for dd in (0, 24):  # DUSt3R, MASt3R (two more matrices per head)
+        cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4, "desc_dim": dd}
+        sd = dust3r_state_dict(9, cfg)
+        assert dust3r_cfg_of(sd) == cfg
+        packed, c = pack_dust3r(sd)
+        assert c == cfg and packed.numel() == lib.imcui_hip_dust3r_packed_floats(128, 1, 64, 4, dd)
+        assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, dd, 2, 2, 96, 128) > 0
+    assert lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 24) == lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 0) + 4
+    assert lib.imcui_hip_dust3r_num_layers(100, 1, 64, 4, 0) == 0  # widths must be multiples of 64
+    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 0, 2, 2, 100, 128) == 0  # sizes must be multiples of 32
+
+
+def test_mast3r_local_features_are_a_pixel_shuffle_of_the_token_mlp():
+    """MASt3R head: descriptor channel c of pixel (y, x) is output (c * 256 + (y % 16) * 16 + x % 16) of the MLP on token
+    (y // 16, x // 16); descriptors have unit norm, their confidence is exp(last channel)."""
+    from oracle.dust3r import MASt3ROracle
+
+    cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4, "desc_dim": 5}
+    sd = dust3r_state_dict(11, cfg)
+    o = MASt3ROracle(sd, cfg)
+    g = torch.Generator().manual_seed(12)
+    a, b = torch.rand(1, 3, 32, 48, generator=g), torch.rand(1, 3, 32, 48, generator=g)
+    res1, _ = o.forward((a - 0.5) / 0.5, (b - 0.5) / 0.5, return_intermediates=True)
+    assert res1["desc"].shape == (1, 32, 48, 5) and res1["desc_conf"].shape == (1, 32, 48)
+    assert torch.allclose(res1["desc"].norm(dim=-1), torch.ones(1, 32, 48), atol=1e-5)
+    toks = res1["_dec"]
+    cat = torch.cat((toks[0], toks[-1]), -1)
+    p = "downstream_head1.head_local_features"
+    lf = F.linear(F.gelu(F.linear(cat, sd[p + ".fc1.weight"], sd[p + ".fc1.bias"])), sd[p + ".fc2.weight"], sd[p + ".fc2.bias"])[0]  # [T, 6 * 256]
+    for y, x in ((0, 0), (17, 5), (31, 47), (16, 32)):
+        t = (y // 16) * 3 + x // 16
+        v = torch.stack([lf[t, c * 256 + (y % 16) * 16 + x % 16] for c in range(6)])
+        assert torch.allclose(res1["desc"][0, y, x], v[:5] / v[:5].norm(), atol=1e-6)
+        assert torch.allclose(res1["desc_conf"][0, y, x], v[5].exp(), rtol=1e-5)
