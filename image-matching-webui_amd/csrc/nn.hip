@@ -141,3 +141,155 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }
+
+// ------------------------------------------------------------------ nearest neighbour by dot product, fused (no similarity matrix)
+// idx[q] = first arg-max over n of <queries[q], db[n]>  (what `cdistMatcher(dist='dot').query` / `bruteforce_reciprocal_nns` of
+// upstream's mast3r/fast_nn.py returns for the queries -- the primitive `fast_reciprocal_NNs` iterates, imcui/hloc/matchers/
+// mast3r.py:68-75; 65 536 queries against the 262 144 descriptors of a 512x512 map would be a 69 GB similarity matrix).
+// Exact-f32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain over the D components), db rows as the A operand and queries as B: a lane
+// then owns ONE query column and 16 db rows per 32x32 tile, so the running (max, arg-max) is lane-local; rows are visited in
+// increasing order with a strict compare = first maximum.  Workgroup = 256 queries (4 waves x 2 column tiles) x one range of db rows
+// (64-row tiles through LDS, double-buffered); `nsplit` ranges per query block keep the chip full when few queries are left, a second
+// kernel folds the per-range results in range order.
+template <int D>
+__global__ __launch_bounds__(256) void nn_argmax_kernel(const float* __restrict__ q, const float* __restrict__ db, int Q, int N, int chunk,
+                                                        float* __restrict__ pbest, int* __restrict__ pidx) {
+    constexpr int DH = D / 2, RS = D + 1;  // row stride in LDS (odd: conflict-free column reads)
+    __shared__ float tile[2][64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wid * 64;
+    const int split = blockIdx.y;
+    const int n0 = split * chunk, n1 = min(N, n0 + chunk);
+    // B operand: query column lo of column tile c, components 2 s + hi
+    float bq[2][DH];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float* qr = q + (size_t)min(q0 + c * 32 + lo, Q - 1) * D + hi;
+#pragma unroll
+        for (int s = 0; s < DH; ++s) bq[c][s] = qr[2 * s];
+    }
+    float best[2] = {-INFINITY, -INFINITY};
+    int bidx[2] = {n0, n0};
+    // staging: 64 rows x D floats per tile, D / 4 float4 per row
+    constexpr int F4 = D / 4, NF4 = 64 * F4;
+    auto stage = [&](int buf, int base) {
+        for (int i = tid; i < NF4; i += 256) {
+            const int r = i / F4, f = i - r * F4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base + r < n1) v = *reinterpret_cast<const float4*>(db + (size_t)(base + r) * D + 4 * f);
+            float* d = &tile[buf][r * RS + 4 * f];
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+    };
+    if (n0 < n1) stage(0, n0);
+    __syncthreads();
+    int buf = 0;
+    for (int base = n0; base < n1; base += 64, buf ^= 1) {
+        if (base + 64 < n1) stage(buf ^ 1, base + 64);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DH; ++s) {
+            const float a0 = tile[buf][lo * RS + 2 * s + hi], a1 = tile[buf][(32 + lo) * RS + 2 * s + hi];
+            acc[0][0] = mfma32(a0, bq[0][s], acc[0][0]);
+            acc[0][1] = mfma32(a0, bq[1][s], acc[0][1]);
+            acc[1][0] = mfma32(a1, bq[0][s], acc[1][0]);
+            acc[1][1] = mfma32(a1, bq[1][s], acc[1][1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = base + rt * 32 + frag_row(r, hi);  // increasing in (rt, r) for a lane
+                if (row < n1) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float v = acc[rt][c][r];
+                        if (v > best[c]) {
+                            best[c] = v;
+                            bidx[c] = row;
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        // the two lanes of a query column (hi = 0 / 1) hold disjoint row sets: larger value wins, equal values -> smaller row
+        const float ov = __shfl_xor(best[c], 32, 64);
+        const int oi = __shfl_xor(bidx[c], 32, 64);
+        if (ov > best[c] || (ov == best[c] && oi < bidx[c])) {
+            best[c] = ov;
+            bidx[c] = oi;
+        }
+        const int qi = q0 + c * 32 + lo;
+        if (hi == 0 && qi < Q) {
+            pbest[(size_t)split * Q + qi] = best[c];
+            pidx[(size_t)split * Q + qi] = bidx[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_argmax_fold_kernel(const float* __restrict__ pbest, const int* __restrict__ pidx, int Q, int nsplit,
+                                                             int* __restrict__ idx, float* __restrict__ best) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Q) return;
+    float b = pbest[i];
+    int j = pidx[i];
+    for (int s = 1; s < nsplit; ++s) {  // ranges in increasing row order, strict compare: the first maximum survives
+        const float v = pbest[(size_t)s * Q + i];
+        if (v > b) {
+            b = v;
+            j = pidx[(size_t)s * Q + i];
+        }
+    }
+    idx[i] = j;
+    if (best) best[i] = b;
+}
+
+static int nn_argmax_nsplit(int Q, int N) {
+    const int qb = (Q + 255) / 256;
+    int ns = (1024 + qb - 1) / qb;  // about four workgroups per CU
+    const int maxs = (N + 1023) / 1024;  // at least 16 tiles per range
+    if (ns > maxs) ns = maxs;
+    if (ns > 256) ns = 256;
+    return ns < 1 ? 1 : ns;
+}
+extern "C" size_t imcui_hip_nn_argmax_workspace_bytes(int Q, int N) {
+    if (Q <= 0 || N <= 0) return 256;
+    return (size_t)nn_argmax_nsplit(Q, N) * Q * 8 + 512;
+}
+extern "C" int imcui_hip_nn_argmax_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best, void* ws,
+                                       size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (Q <= 0) return IMCUI_OK;
+    if (N <= 0 || !queries || !db || !idx) return imcui_set_err(h, IMCUI_ERR_ARG, "nn_argmax: empty data base or null argument");
+    if (D != 16 && D != 24 && D != 32) return imcui_set_err(h, IMCUI_ERR_ARG, "nn_argmax: D=%d (supported: 16, 24, 32)", D);
+    const int ns = nn_argmax_nsplit(Q, N);
+    const size_t need = (size_t)ns * Q * 8 + 512;
+    if (!ws || ws_bytes < need) return imcui_set_err(h, IMCUI_ERR_WS, "nn_argmax: workspace too small (%zu < %zu)", ws_bytes, need);
+    float* pbest = (float*)ws;
+    int* pidx = (int*)((char*)ws + align_up((size_t)ns * Q * 4, 256));
+    const int chunk = (((N + ns - 1) / ns) + 63) / 64 * 64;
+    const dim3 grid((Q + 255) / 256, ns);
+    if (D == 16)
+        hipLaunchKernelGGL(nn_argmax_kernel<16>, grid, dim3(256), 0, stream, queries, db, Q, N, chunk, pbest, pidx);
+    else if (D == 24)
+        hipLaunchKernelGGL(nn_argmax_kernel<24>, grid, dim3(256), 0, stream, queries, db, Q, N, chunk, pbest, pidx);
+    else
+        hipLaunchKernelGGL(nn_argmax_kernel<32>, grid, dim3(256), 0, stream, queries, db, Q, N, chunk, pbest, pidx);
+    hipLaunchKernelGGL(nn_argmax_fold_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, pbest, pidx, Q, ns, idx, best);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}

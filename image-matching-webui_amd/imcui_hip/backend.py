@@ -834,6 +834,27 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
+def nn_argmax(queries: torch.Tensor, db: torch.Tensor, return_best: bool = False):
+    """queries [Q,D], db [N,D] (D in 16 / 24 / 32) -> int64 [Q]: the FIRST arg-max over n of <queries[q], db[n]> (what
+    `cdistMatcher(dist="dot").query` of upstream's mast3r/fast_nn.py returns; imcui/hloc/matchers/mast3r.py:68-75)."""
+    dev = queries.device
+    hd = get_handle(dev)
+    lib = hd.lib
+    queries, db = queries.contiguous().float(), db.contiguous().float()
+    Q, D = queries.shape
+    N = db.shape[0]
+    idx = torch.empty((Q,), dtype=torch.int32, device=dev)
+    best = torch.empty((Q,), dtype=torch.float32, device=dev) if return_best else None
+    if Q == 0:
+        return (idx.long(), best) if return_best else idx.long()
+    with _nn_lock:
+        ws = _nn_ws.get(lib.imcui_hip_nn_argmax_workspace_bytes(Q, N), dev)
+        with torch.cuda.device(dev):
+            rc = lib.imcui_hip_nn_argmax_f32(hd.h, _ptr(queries), _ptr(db), Q, N, D, _ptr(idx), _ptr(best), _ptr(ws), ws.numel(), _stream_ptr())
+            hd.check(rc, "imcui_hip_nn_argmax_f32")
+    return (idx.long(), best) if return_best else idx.long()
+
+
 def dual_softmax(desc0: torch.Tensor, desc1: torch.Tensor, threshold: float = 0.2, inv_temperature: float = 20.0, normalize: bool = True):
     """desc0 [B,C,N], desc1 [B,C,M] (channels-first, as the plugin receives them) -> matches0 [B,N] int32, scores0 [B,N]."""
     dev = desc0.device

@@ -6,10 +6,14 @@ through `inference(pairs, self.net, DEVICE, batch_size=1)` (:56) -- `AsymmetricM
 (imcui_hip_dust3r_forward with desc_dim = 24).  `inference_output()` returns upstream's `{view1, view2, pred1, pred2}` with
 `pts3d` / `pts3d_in_other_view`, `conf`, `desc`, `desc_conf`; every image is encoded once.
 
-The matching step (`fast_reciprocal_NNs(desc1, desc2, subsample_or_initxy1=2, dist="dot", block_size=2**13)`, :68-75: an
-iterated nearest-neighbour search between the two 512x512x24 descriptor maps) and the linspace sub-sampling (:88-92) run with
-upstream's `mast3r` package when it is importable; without it `_forward` raises ImportError after the network has run (a
-device-side reciprocal search is the next step of this path).
+The matching step -- `fast_reciprocal_NNs(desc1, desc2, subsample_or_initxy1=2, dist="dot", block_size=2**13)` (:68-75) of the
+un-vendored `third_party/mast3r` (mast3r/fast_nn.py) -- is restated in `fast_reciprocal_nns` below: start from every second
+pixel of image 1, hop to the nearest neighbour (largest dot product) in image 2 and back, up to 10 rounds, keep the chains that
+closed on themselves (reciprocal pairs), unique pairs ordered by (position in image 1, position in image 2).  The nearest
+neighbour searches (up to 65 536 queries against the 262 144 descriptors of a 512x512 map) run in libimcui_hip
+(`imcui_hip_nn_argmax_f32`: similarity on the matrix cores fused with the running arg-max); the bookkeeping between two searches is
+index arithmetic on device tensors, one host read of "any chain still open" per round (upstream reads the same through numpy).
+Then the linspace sub-sampling to `max_keypoints` (:88-92).
 """
 from __future__ import annotations
 
@@ -44,20 +48,51 @@ class Mast3r(Duster):
 
     def _forward(self, data):
         output = self.inference_output(data)
-        try:
-            from mast3r.fast_nn import fast_reciprocal_NNs
-        except ImportError as e:
-            raise ImportError(
-                "the MASt3R network ran on the HIP backend (see inference_output()); the reciprocal matching of "
-                "imcui/hloc/matchers/mast3r.py:68-75 uses upstream's `mast3r` package (third_party/mast3r), which is not installed"
-            ) from e
         # the reference matches the descriptors of the SECOND directed pair (image1 as view 1, image0 as view 2), mast3r.py:61-64
         desc1, desc2 = output["pred1"]["desc"][1], output["pred2"]["desc"][1]
-        k0, k1 = fast_reciprocal_NNs(desc1, desc2, subsample_or_initxy1=2, device=desc1.device, dist="dot", block_size=2**13)
+        k0, k1 = fast_reciprocal_nns(desc1, desc2, subsample=2)
         if len(k0) == 0:
             return {"keypoints0": torch.zeros([0, 2]), "keypoints1": torch.zeros([0, 2])}
+        k0, k1 = k0.cpu().numpy(), k1.cpu().numpy()
         limit = self.conf["max_keypoints"]
         if limit is not None and len(k0) > limit:
             pick = np.round(np.linspace(0, len(k0) - 1, limit)).astype(int)
             k0, k1 = k0[pick], k1[pick]
         return {"keypoints0": torch.from_numpy(np.ascontiguousarray(k0)), "keypoints1": torch.from_numpy(np.ascontiguousarray(k1))}
+
+
+def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int = 2, max_iter: int = 10, nn=None):
+    """desc1 [H1,W1,D], desc2 [H2,W2,D] (device) -> (xy1 [K,2], xy2 [K,2]) int64 pixel (x, y) of the reciprocal matches, ordered by
+    (linear position in image 1, linear position in image 2).  `nn(queries, db)` = first arg-max of the dot products (default: the
+    HIP kernel); the loop is upstream's `fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=S, ret_xy=True, pixel_tol=0)`."""
+    from ... import backend
+
+    nn = nn or backend.nn_argmax
+    H1, W1, D = desc1.shape
+    H2, W2, _ = desc2.shape
+    dev = desc1.device
+    p1, p2 = desc1.reshape(-1, D), desc2.reshape(-1, D)
+    S = subsample
+    ys, xs = torch.meshgrid(torch.arange(S // 2, H1, S, device=dev), torch.arange(S // 2, W1, S, device=dev), indexing="ij")
+    xy1 = torch.unique((xs + W1 * ys).reshape(-1))  # sorted start positions (np.unique in upstream)
+    xy2 = torch.full_like(xy1, -1)
+    old_xy1, old_xy2 = xy1.clone(), xy2.clone()
+    notyet = torch.ones_like(xy1, dtype=torch.bool)
+    niter = 0
+    while bool(notyet.any()):
+        act = notyet.nonzero()[:, 0]
+        xy2[act] = nn(p1[xy1[act]], p2)
+        notyet &= old_xy2 != xy2  # chains whose image-2 end did not move have converged
+        act = notyet.nonzero()[:, 0]
+        if len(act):
+            xy1[act] = nn(p2[xy2[act]], p1)
+        notyet &= old_xy1 != xy1
+        niter += 1
+        if niter >= max_iter:
+            break
+        old_xy2.copy_(xy2)
+        old_xy1.copy_(xy1)
+    done = ~notyet
+    key = torch.unique((xy1[done] << 32) | xy2[done])  # unique pairs, ordered by position in image 1, then in image 2
+    a, b = key >> 32, key & 0xFFFFFFFF
+    return torch.stack((a % W1, a // W1), 1), torch.stack((b % W2, b // W2), 1)

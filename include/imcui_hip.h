@@ -235,6 +235,14 @@ int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* i
  * 4 fused 1/2-resolution fine map [.,H/2,W/2,64], 5 fine windows [B*L0][64 + 100][64] (debug_windows)  (parity tests) */
 size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);
 
+/* ---- nearest neighbour by dot product (the primitive of MASt3R's `fast_reciprocal_NNs(..., dist="dot")`,
+ * imcui/hloc/matchers/mast3r.py:68-75 -> upstream mast3r/fast_nn.py `cdistMatcher.query`) --------------------------------- */
+/* idx [dev, Q] int32 = FIRST arg-max over n of <queries[q], db[n]>, best [dev, Q] (may be NULL) the maximum; queries [dev, Q,D], db [dev,
+ * N,D] f32 rows, D in {16, 24, 32}.  Exact-f32 MFMA, similarity and running arg-max fused (no Q x N matrix). */
+size_t imcui_hip_nn_argmax_workspace_bytes(int Q, int N);
+int imcui_hip_nn_argmax_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* ---- DUSt3R pair network (BASELINE config 5; what `dust3r.inference.inference(pairs, self.net, ...)`
  * computes at imcui/hloc/matchers/duster.py:73 with self.net = AsymmetricCroCo3DStereo (duster.py:37): ViT encoder with 2-D rotary
  * embedding, two-stream cross-attention decoder, DPT point-map head; the un-vendored `third_party/dust3r` submodule) -------- */

@@ -284,6 +284,55 @@ class MASt3ROracle(DUSt3ROracle):
         return res
 
 
+def nn_dot_first_argmax(queries: torch.Tensor, db: torch.Tensor, block: int = 2**13) -> torch.Tensor:
+    """`cdistMatcher(db, dist='dot').query(queries)` of upstream's mast3r/fast_nn.py: per query the index of the largest dot product,
+    the first one on ties (blocks of `block` x `block` similarities, a later block only wins with a strictly larger value)."""
+    best = torch.full((len(queries),), -float("inf"))
+    arg = torch.full((len(queries),), -1, dtype=torch.int64)
+    for i in range(0, len(queries), block):
+        for j in range(0, len(db), block):
+            v, k = (queries[i : i + block] @ db[j : j + block].T).max(dim=1)
+            upd = v > best[i : i + block]
+            best[i : i + block][upd] = v[upd]
+            arg[i : i + block][upd] = k[upd] + j
+    return arg
+
+
+def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int = 2, max_iter: int = 10):
+    """`fast_reciprocal_NNs(desc1, desc2, subsample_or_initxy1=S, ret_xy=True, pixel_tol=0, dist='dot')` as called at
+    imcui/hloc/matchers/mast3r.py:68-75 (upstream mast3r/fast_nn.py, restated with numpy bookkeeping as upstream has it): chains
+    start on the grid S//2::S of image 1 and alternate nearest-neighbour hops image 1 -> 2 -> 1; a chain is done when a hop returns
+    to where the previous round left it; after at most `max_iter` rounds the closed chains give the matches, de-duplicated and
+    sorted by (y1 * W1 + x1, y2 * W2 + x2).  Returns (xy1 [K,2], xy2 [K,2]) int64 (x, y)."""
+    import numpy as np
+
+    H1, W1, D = desc1.shape
+    H2, W2, _ = desc2.shape
+    pts1, pts2 = desc1.reshape(-1, D), desc2.reshape(-1, D)
+    y1, x1 = np.mgrid[subsample // 2 : H1 : subsample, subsample // 2 : W1 : subsample].reshape(2, -1)
+    xy1 = np.int32(np.unique(x1 + W1 * y1))
+    xy2 = np.full_like(xy1, -1)
+    old_xy1, old_xy2 = xy1.copy(), xy2.copy()
+    notyet = np.ones(len(xy1), dtype=bool)
+    niter = 0
+    while notyet.any():
+        xy2[notyet] = nn_dot_first_argmax(pts1[torch.from_numpy(xy1[notyet]).long()], pts2).numpy()
+        notyet &= old_xy2 != xy2
+        if notyet.any():
+            xy1[notyet] = nn_dot_first_argmax(pts2[torch.from_numpy(xy2[notyet]).long()], pts1).numpy()
+        notyet &= old_xy1 != xy1
+        niter += 1
+        if niter >= max_iter:
+            break
+        old_xy2[:] = xy2
+        old_xy1[:] = xy1
+    conv = ~notyet
+    corres = np.unique(np.c_[xy2[conv], xy1[conv]].view(np.int64))  # low word xy2, high word xy1: sorted by xy1, then xy2
+    b, a = corres[:, None].view(np.int32).T
+    a, b = a.astype(np.int64), b.astype(np.int64)
+    return torch.from_numpy(np.c_[a % W1, a // W1]), torch.from_numpy(np.c_[b % W2, b // W2])
+
+
 def num_params(cfg: dict | None = None) -> int:
     c = {**DEFAULT_CFG, **(cfg or {})}
     E, D = c["enc_dim"], c["dec_dim"]

@@ -177,8 +177,61 @@ def test_mast3r_descriptors_vs_oracle():
         assert out[pred]["desc"].shape == (2, 128, 192, 24)
         assert (out[pred]["desc"].cpu() - want["desc"]).abs().max().item() < 1e-4  # unit vectors
         assert ((out[pred]["desc_conf"].cpu() - want["desc_conf"]).abs() / want["desc_conf"]).max().item() < 1e-4
-    with pytest.raises(ImportError):
-        model({"image0": i0.cuda(), "image1": i1.cuda()})  # upstream's reciprocal matcher is not installed here
+
+
+@pytest.mark.parametrize("D,Q,N", [(24, 5000, 20001), (32, 300, 70000), (16, 1, 63), (24, 20000, 4100)])
+def test_nn_argmax_vs_float64(D, Q, N):
+    """The search primitive of MASt3R's matcher: first arg-max of the dot products.  Differences from a float64 evaluation must be
+    near-ties (the two candidates within 2e-6 in float64); duplicated data-base rows must resolve to the first copy."""
+    import torch.nn.functional as F
+
+    from imcui_hip import backend
+
+    g = torch.Generator().manual_seed(D + Q)
+    db = F.normalize(torch.randn(N, D, generator=g), dim=-1)
+    ndup = min(N, 500)
+    db = torch.cat((db, db[:ndup]), 0)  # duplicates behind the originals
+    q = F.normalize(db[torch.randint(0, N, (Q,), generator=g)] + 0.2 * torch.randn(Q, D, generator=g), dim=-1)
+    ncopy = min(Q, 50, ndup)
+    q[:ncopy] = db[:ncopy]  # queries equal to rows that exist twice
+    idx, best = backend.nn_argmax(q.cuda(), db.cuda(), return_best=True)
+    idx, best = idx.cpu(), best.cpu()
+    sim = q.double() @ db.double().T
+    want = sim.argmax(1)
+    assert (best - sim.max(1).values.float()).abs().max().item() < 1e-5
+    diff = (idx != want).nonzero()[:, 0]
+    for i in diff.tolist():
+        assert abs(sim[i, idx[i]].item() - sim[i, want[i]].item()) < 2e-6, (i, idx[i].item(), want[i].item())
+    assert len(diff) <= ncopy + max(2, Q // 1000), len(diff)
+    # a query equal to a duplicated row: both copies give the same value bit for bit -> the first index wins
+    assert (idx[:ncopy] == torch.arange(ncopy)).all()
+
+
+def test_mast3r_matches_vs_oracle():
+    """`Mast3r._forward` end to end (network -> descriptors of the swapped pair -> reciprocal matching -> linspace sub-sampling, mast3r.py:
+    56-96) against the oracle's `fast_reciprocal_nns` on the SAME descriptors: identical match lists (the descriptors themselves are
+    checked in test_mast3r_descriptors_vs_oracle)."""
+    import numpy as np
+
+    from imcui_hip.hloc.matchers.mast3r import Mast3r
+    from oracle.dust3r import fast_reciprocal_nns
+
+    torch.set_num_threads(16)
+    cfg = {**SMALL, "desc_dim": 24}
+    sd = dust3r_state_dict(2, cfg)
+    model = Mast3r({"state_dict": sd, "max_keypoints": 300}).eval().to("cuda:0")
+    i0, i1 = _images(96, 128, 13)
+    data = {"image0": i0.cuda(), "image1": i1.cuda()}
+    pred = model(data)
+    out = model.inference_output(data)
+    d1, d2 = out["pred1"]["desc"][1].cpu(), out["pred2"]["desc"][1].cpu()
+    k0, k1 = fast_reciprocal_nns(d1, d2, subsample=2)
+    assert len(k0) > 20, len(k0)
+    if len(k0) > 300:
+        keep = np.round(np.linspace(0, len(k0) - 1, 300)).astype(int)
+        k0, k1 = k0[keep], k1[keep]
+    assert pred["keypoints0"].shape == k0.shape and pred["keypoints0"].dtype == torch.int64
+    assert torch.equal(pred["keypoints0"], k0) and torch.equal(pred["keypoints1"], k1)
 
 
 def test_dust3r_plugin_output_structure():

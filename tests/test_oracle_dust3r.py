@@ -157,3 +157,30 @@ def test_mast3r_local_features_are_a_pixel_shuffle_of_the_token_mlp():
         v = torch.stack([lf[t, c * 256 + (y % 16) * 16 + x % 16] for c in range(6)])
         assert torch.allclose(res1["desc"][0, y, x], v[:5] / v[:5].norm(), atol=1e-6)
         assert torch.allclose(res1["desc_conf"][0, y, x], v[5].exp(), rtol=1e-5)
+
+
+def test_fast_reciprocal_nns_restatement():
+    """MASt3R's matching step (mast3r.py:68-75): every returned pair is a reciprocal nearest neighbour by dot product, pairs are unique and
+    ordered by (position in image 1, position in image 2), a shifted copy of a descriptor field is matched with the shift; the
+    plugin's device-tensor loop gives the same result as the numpy-style restatement when both use the same search primitive."""
+    from imcui_hip.hloc.matchers.mast3r import fast_reciprocal_nns as plugin_loop
+    from oracle.dust3r import fast_reciprocal_nns, nn_dot_first_argmax
+
+    g = torch.Generator().manual_seed(0)
+    H, W, D = 40, 56, 24
+    base = torch.randn(H + 8, W + 8, D, generator=g)
+    d1 = F.normalize(base[:H, :W], dim=-1)
+    d2 = F.normalize(base[4 : H + 4, 2 : W + 2] + 0.3 * torch.randn(H, W, D, generator=g), dim=-1)  # d2[y, x] ~ d1[y + 4, x + 2]
+    xy1, xy2 = fast_reciprocal_nns(d1, d2, subsample=2)
+    assert len(xy1) > 200
+    assert ((xy1 - xy2) == torch.tensor([2, 4])).all(1).float().mean().item() > 0.9
+    lin1, lin2 = xy1[:, 1] * W + xy1[:, 0], xy2[:, 1] * W + xy2[:, 0]
+    key = lin1 * (H * W) + lin2
+    assert (key[1:] > key[:-1]).all()  # unique and sorted
+    p1, p2 = d1.reshape(-1, D), d2.reshape(-1, D)
+    assert torch.equal(nn_dot_first_argmax(p1[lin1], p2), lin2) and torch.equal(nn_dot_first_argmax(p2[lin2], p1), lin1)
+    # blocks: a later block only wins with a strictly larger value -> first arg-max (duplicated rows)
+    db = torch.cat((p2[:100], p2[:100]), 0)
+    assert (nn_dot_first_argmax(p2[:100], db, block=64) == torch.arange(100)).all()
+    b1, b2 = plugin_loop(d1, d2, subsample=2, nn=nn_dot_first_argmax)
+    assert torch.equal(b1, xy1) and torch.equal(b2, xy2)
