@@ -306,12 +306,13 @@ def bench_dust3r(args, dev, rank, world):
 
     Hh, Ww = args.size if args.size else (512, 512)
     B = args.batch
-    cfg = dict(DUST3R_CFG)
+    mast = args.workload == "mast3r"  # the same network with the 'catmlp+dpt' head + the reciprocal descriptor matching of mast3r.py:68-75
+    cfg = {**DUST3R_CFG, "desc_dim": 24 if mast else 0}
     # generating and packing the 578 M seeded parameters takes ~30 s of host time: the packed buffer (a pure function of the seed) is
     # kept in the temp directory so that profiler passes of the same command line do not repeat it
     import tempfile
 
-    cache = os.path.join(tempfile.gettempdir(), f"imcui_hip_dust3r_seed0_rank{rank}.pt")
+    cache = os.path.join(tempfile.gettempdir(), f"imcui_hip_{'mast3r' if mast else 'dust3r'}_seed0_rank{rank}.pt")
     sd = None
     if os.path.exists(cache):
         packed = torch.load(cache)
@@ -322,7 +323,12 @@ def bench_dust3r(args, dev, rank, world):
             torch.save(packed, cache)
         except OSError:
             pass
-    model = Duster({"packed": (packed, cfg)}).eval().to(dev)
+    if mast:
+        from imcui_hip.hloc.matchers.mast3r import Mast3r, fast_reciprocal_nns
+
+        model = Mast3r({"packed": (packed, cfg)}).eval().to(dev)
+    else:
+        model = Duster({"packed": (packed, cfg)}).eval().to(dev)
     del packed
     base, _, _ = make_pair(91 + rank, Hh + 16, Ww + 16, n_blobs=Hh * Ww // 150)
     g = torch.Generator().manual_seed(5 + rank)
@@ -333,8 +339,20 @@ def bench_dust3r(args, dev, rank, world):
 
     model.conf["arithmetic"] = args.arith
 
+    nmatch = [0]
+
     def step():
-        return model.forward_pairs(images, pairs)
+        out = model.forward_pairs(images, pairs)
+        if mast:  # per image pair: descriptors of its second directed pair (mast3r.py:61-64), reciprocal matching, 2000 kept
+            n = 0
+            for b in range(B):
+                k0, k1 = fast_reciprocal_nns(out["desc"][0][2 * b + 1], out["desc"][1][2 * b + 1], subsample=2)
+                if len(k0) > 2000:
+                    keep = torch.linspace(0, len(k0) - 1, 2000, device=dev).round().long()
+                    k0, k1 = k0[keep], k1[keep]
+                n += len(k0)
+            nmatch[0] = n
+        return out
 
     for _ in range(args.warmup):
         out = step()
@@ -351,6 +369,14 @@ def bench_dust3r(args, dev, rank, world):
     dt = time.perf_counter() - t0
     cls_ms = {k: backend.profile_read(dev, k) for k in ("gemm", "conv3x3", "attention")}
     backend.profile_enable(dev, False)
+    net_ms = None
+    if mast:  # the network alone, same batch (the matching step = the rest of a step)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            model.forward_pairs(images, pairs)
+        torch.cuda.synchronize()
+        net_ms = (time.perf_counter() - t1) / 3 * 1e3
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -370,16 +396,18 @@ def bench_dust3r(args, dev, rank, world):
                 tj = json.load(fh)
             traffic = tj["traffic_bytes_per_step_gemm_kernels"] * B / tj["pairs_per_step"] / (mat_n / args.steps)
         line = {
-            "metric": "image-pairs/sec DUSt3R pair network @512x512", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "metric": ("image-pairs/sec MASt3R pair network + reciprocal matching @512x512" if mast else "image-pairs/sec DUSt3R pair network @512x512"), "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32 via 3xf16 split MFMA, f32 accumulate (the reference config names bf16; this path keeps fp32-grade results)" if args.arith == "fp32" else
                       "f16 operands (one MFMA product, 11-bit mantissa), f32 accumulate in the GEMMs and convolutions; attention in 3xf16 split (the reference config names bf16)"),
             "data": "synthetic",
-            "config": {"workload": f"configs[4]: DUSt3R ViT-L/16 encoder (24 x 1024) + 2 x 12 x 768 cross-attention decoder + DPT point-map heads on synthetic {Ww}x{Hh} "
+            "config": {"workload": ("MASt3R = the same network with the catmlp+dpt head, then reciprocal descriptor matching; " if mast else "") + f"configs[4]: DUSt3R ViT-L/16 encoder (24 x 1024) + 2 x 12 x 768 cross-attention decoder + DPT point-map heads on synthetic {Ww}x{Hh} "
                                    "pairs resident in HBM; one pair = the symmetrised call of duster.py (directed pairs (0,1) and (1,0), each image encoded once)",
                        "pairs_per_step_per_gpu": B, "weights": "seeded random (imcui_hip/synth_weights.py), AsymmetricCroCo3DStereo architecture, 578 M parameters",
-                       "mean_confidence": float(out["conf"].mean())},
+                       "mean_confidence": float(out["conf"].mean()),
+                       **({"head": "catmlp+dpt, 24-d descriptors; matching: fast_reciprocal_NNs(subsample 2, dot, 10 rounds) on the device, 2000 matches kept",
+                           "matches_per_pair": nmatch[0] / B, "network_ms_per_step": net_ms, "matching_ms_per_step": dt / args.steps * 1e3 - net_ms} if mast else {})},
             "roofline": {"kernel": "gemm_split_kernel + conv3x3_split_kernel + attn_split_kernel (matrix class)", "bound": "mfma", "achieved": ach,
                          "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": traffic,
                          "class_ms_per_step": {k: v[0] / args.steps for k, v in cls_ms.items()}, "launches_per_step": mat_n / args.steps,
@@ -389,17 +417,17 @@ def bench_dust3r(args, dev, rank, world):
             "algorithmic_tflops_end_to_end": tf["total"] * B / (dt / args.steps),
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.dust3r import DUSt3ROracle
+            from oracle.dust3r import DUSt3ROracle, MASt3ROracle
 
             ncpu = os.cpu_count() or 1
             torch.set_num_threads(min(ncpu, 32))
-            ora = DUSt3ROracle(sd if sd is not None else dust3r_state_dict(0, cfg), cfg)
+            ora = (MASt3ROracle if mast else DUSt3ROracle)(sd if sd is not None else dust3r_state_dict(0, cfg), cfg)
             t0 = time.perf_counter()
             ora.inference_symmetrized(i0, i1)
             el = time.perf_counter() - t0
             line["cpu_baseline"] = {"value": 1.0 / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
                                     "sample": f"ONE synthetic {Ww}x{Hh} pair, no warm-up, fp32, the oracle's restatement of duster.py:66-73 (two forward passes, "
-                                              f"both images encoded in each, as upstream's inference does), torch {torch.__version__} CPU, "
+                                              f"both images encoded in each, as upstream's inference does{'; the NETWORK only -- the reciprocal matching (TFLOPs of dot products per round on the CPU) is not in the sample' if mast else ''}), torch {torch.__version__} CPU, "
                                               f"{torch.get_num_threads()} of {ncpu} host CPUs"}  # fmt: skip
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -588,7 +616,7 @@ def main():
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "dust3r", "superpoint", "superglue", "launchcheck"],
+    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "dust3r", "mast3r", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
@@ -599,7 +627,7 @@ def main():
                     help="0 = exact f32 MFMA, 1 = 3 x f16 split MFMA with f32 accumulate (default, parity-tested)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 4 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 8 if args.workload == "dust3r" else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels)
+        args.batch = 4 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 8 if args.workload in ("dust3r", "mast3r") else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels)
 
     if args.workload == "launchcheck":
         return launchcheck(args)
@@ -623,7 +651,7 @@ def main():
     backend.set_precision(dev, args.precision)
     if args.workload in ("loftr", "eloftr"):
         return bench_loftr(args, dev, rank, world)
-    if args.workload == "dust3r":
+    if args.workload in ("dust3r", "mast3r"):
         return bench_dust3r(args, dev, rank, world)
     if args.workload == "superpoint":
         return bench_superpoint(args, dev, rank, world)
