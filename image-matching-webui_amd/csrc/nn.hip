@@ -205,22 +205,30 @@ __global__ __launch_bounds__(256) void nn_argmax_kernel(const float* __restrict_
             acc[1][0] = mfma32(a1, bq[0][s], acc[1][0]);
             acc[1][1] = mfma32(a1, bq[1][s], acc[1][1]);
         }
+        // a tile rarely holds a new maximum once a few tiles have been seen: compare the tile's maximum first (a v_max3 tree, 8
+        // instructions per column) and walk the 32 candidates of a column, in increasing row order with a strict compare (= first
+        // maximum), only where it beats the running one.  Rows past the range are zero in LDS: they can only trigger the walk.
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int c = 0; c < 2; ++c) {
+            float tmax = acc[0][c][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = base + rt * 32 + frag_row(r, hi);  // increasing in (rt, r) for a lane
-                if (row < n1) {
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[rt][c][r]);
+            if (tmax > best[c]) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = base + rt * 32 + frag_row(r, hi);  // increasing in (rt, r) for a lane
                         const float v = acc[rt][c][r];
-                        if (v > best[c]) {
+                        if (row < n1 && v > best[c]) {
                             best[c] = v;
                             bidx[c] = row;
                         }
                     }
-                }
             }
+        }
         __syncthreads();
     }
 #pragma unroll

@@ -18,6 +18,8 @@ OVERLAYS = {  # verbatim from INTEGRATION.md section 2
     "matchers/lightglue.py": "from imcui_hip.hloc.matchers.lightglue import LightGlue as _HipLightGlue\nclass LightGlue(_HipLightGlue):\n    pass\n",
     "matchers/loftr.py": "from imcui_hip.hloc.matchers.loftr import LoFTR as _HipLoFTR\nclass LoFTR(_HipLoFTR):\n    pass\n",
     "matchers/superglue.py": "from imcui_hip.hloc.matchers.superglue import SuperGlue as _HipSuperGlue\nclass SuperGlue(_HipSuperGlue):\n    pass\n",
+    "matchers/duster.py": "from imcui_hip.hloc.matchers.duster import Duster as _HipDuster\nclass Duster(_HipDuster):  # AsymmetricCroCo3DStereo state dict (duster_vit_large.pth); the network runs in libimcui_hip, the aligner stays upstream's\n    pass\n",
+    "matchers/mast3r.py": "from imcui_hip.hloc.matchers.mast3r import Mast3r as _HipMast3r\nclass Mast3r(_HipMast3r):  # AsymmetricMASt3R state dict ('catmlp+dpt' head); network and reciprocal matching on the device\n    pass\n",
     "matchers/dual_softmax.py": "from imcui_hip.hloc.matchers.dual_softmax import DualSoftMax as _HipDS\nclass DualSoftMax(_HipDS):\n    pass\n",
     "matchers/nearest_neighbor.py": "from imcui_hip.hloc.matchers.nearest_neighbor import NearestNeighbor as _HipNN\nclass NearestNeighbor(_HipNN):\n    pass\n",
 }
@@ -28,7 +30,7 @@ DRIVER = textwrap.dedent(
     from imcui.hloc.utils.base_model import BaseModel, dynamic_load          # the reference's own seam
     import overlay.extractors as extractors, overlay.matchers as matchers
     from imcui_hip import ImcuiHipError
-    from imcui_hip.synth_weights import lightglue_state_dict, loftr_state_dict, superglue_state_dict, superpoint_state_dict
+    from imcui_hip.synth_weights import dust3r_state_dict, lightglue_state_dict, loftr_state_dict, superglue_state_dict, superpoint_state_dict
 
     def model_size(m):  # imcui/ui/modelcache.py:84-87
         return sum(p.numel() * p.element_size() for p in m.parameters()) + sum(b.numel() * b.element_size() for b in m.buffers())
@@ -39,6 +41,20 @@ DRIVER = textwrap.dedent(
     SG = dynamic_load(matchers, "superglue")
     DS = dynamic_load(matchers, "dual_softmax")
     NN = dynamic_load(matchers, "nearest_neighbor")
+    DU = dynamic_load(matchers, "duster")      # exactly one BaseModel subclass DEFINED in the overlay module (base_model.py:49-55)
+    MA = dynamic_load(matchers, "mast3r")
+    assert DU.__module__ == "overlay.matchers.duster" and MA.__module__ == "overlay.matchers.mast3r"
+    small = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4}
+    du = DU({"state_dict": dust3r_state_dict(0, small)}).eval().to("cpu")
+    ma = MA({"state_dict": dust3r_state_dict(0, {**small, "desc_dim": 24})}).eval().to("cpu")
+    assert du.conf["max_keypoints"] == 3000 and ma.conf["max_keypoints"] == 2000 and du.conf["vit_patch_size"] == 16  # duster.py:24-29, mast3r.py:24-29
+    assert ma.net_cfg["desc_dim"] == 24 and du.net_cfg["desc_dim"] == 0
+    try:
+        MA({"state_dict": dust3r_state_dict(0, small)})
+    except KeyError as e:
+        assert "head_local_features" in str(e)
+    else:
+        raise SystemExit("a DUSt3R state dict was accepted as MASt3R weights")
     for cls, mod in ((SP, "overlay.extractors.superpoint"), (LG, "overlay.matchers.lightglue"), (LF, "overlay.matchers.loftr"),
                      (SG, "overlay.matchers.superglue"), (DS, "overlay.matchers.dual_softmax"), (NN, "overlay.matchers.nearest_neighbor")):
         assert issubclass(cls, BaseModel) and cls.__module__ == mod, (cls, cls.__mro__)
@@ -54,7 +70,9 @@ DRIVER = textwrap.dedent(
     assert all(model_size(m) == sum(b.numel() * b.element_size() for b in m.buffers()) for m in (sp, lg, lf, sg))  # no parameters, only buffers
     # no CPU fallback: a CPU tensor fails loudly and cleanly through the reference's BaseModel.forward
     for model, data in ((sp, {"image": torch.zeros(1, 1, 64, 64)}),
-                        (lf, {"image0": torch.zeros(1, 1, 64, 64), "image1": torch.zeros(1, 1, 64, 64)})):
+                        (lf, {"image0": torch.zeros(1, 1, 64, 64), "image1": torch.zeros(1, 1, 64, 64)}),
+                        (du, {"image0": torch.zeros(1, 3, 64, 64), "image1": torch.zeros(1, 3, 64, 64)}),
+                        (ma, {"image0": torch.zeros(1, 3, 64, 64), "image1": torch.zeros(1, 3, 64, 64)})):
         try:
             model(data)
         except ImcuiHipError as e:

@@ -17,6 +17,8 @@ if [ "${QUICK:-0}" = 1 ]; then
   ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 --no-cpu-baseline > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
   ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
   ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
+  ( cd $R && timeout 300 python bench.py --workload dust3r --arith fp16 --no-cpu-baseline > $O/bench_dust3r_512_fp16.json.log 2>&1; tail -1 $O/bench_dust3r_512_fp16.json.log | cut -c1-160 )
+  ( cd $R && timeout 300 python bench.py --workload mast3r --no-cpu-baseline > $O/bench_mast3r_512.json.log 2>&1; tail -1 $O/bench_mast3r_512.json.log | cut -c1-160 )
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_loftr.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_eloftr.log 2>&1
@@ -62,6 +64,8 @@ done
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 > $O/rocprof_eloftr.log 2>&1
 [ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r --arith fp16 --no-cpu-baseline > $O/bench_dust3r_512_fp16.json.log 2>&1; tail -1 $O/bench_dust3r_512_fp16.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload mast3r --no-cpu-baseline > $O/bench_mast3r_512.json.log 2>&1; tail -1 $O/bench_mast3r_512.json.log | cut -c1-160 )
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_dust3r.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_$c.log 2>&1

@@ -97,6 +97,8 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_eloftr_640x480.json.log", f"{tag}_bench_eloftr_640x480.json.log"),
                  ("stats_eloftr/eloftr_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_eloftr_640x480.csv"),
                  ("bench_dust3r_512.json.log", f"{tag}_bench_dust3r_512.json.log"),
+                 ("bench_dust3r_512_fp16.json.log", f"{tag}_bench_dust3r_512_fp16.json.log"),
+                 ("bench_mast3r_512.json.log", f"{tag}_bench_mast3r_512.json.log"),
                  ("stats_dust3r/dust3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_dust3r_512.csv"),
                  ("bench_splg_unfused_ffn.json.log", f"{tag}_bench_splg_unfused_ffn.json.log"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
