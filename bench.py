@@ -306,6 +306,8 @@ def bench_dust3r(args, dev, rank, world):
 
     Hh, Ww = args.size if args.size else (512, 512)
     B = args.batch
+    if args.nn_arith == "auto":
+        args.nn_arith = "split" if args.precision == 1 else "fp32"
     mast = args.workload == "mast3r"  # the same network with the 'catmlp+dpt' head + the reciprocal descriptor matching of mast3r.py:68-75
     cfg = {**DUST3R_CFG, "desc_dim": 24 if mast else 0}
     # generating and packing the 578 M seeded parameters takes ~30 s of host time: the packed buffer (a pure function of the seed) is
@@ -346,7 +348,7 @@ def bench_dust3r(args, dev, rank, world):
         if mast:  # per image pair: descriptors of its second directed pair (mast3r.py:61-64), reciprocal matching, 2000 kept
             n = 0
             for b in range(B):
-                k0, k1 = fast_reciprocal_nns(out["desc"][0][2 * b + 1], out["desc"][1][2 * b + 1], subsample=2)
+                k0, k1 = fast_reciprocal_nns(out["desc"][0][2 * b + 1], out["desc"][1][2 * b + 1], subsample=2, split=args.nn_arith == "split")
                 if len(k0) > 2000:
                     keep = torch.linspace(0, len(k0) - 1, 2000, device=dev).round().long()
                     k0, k1 = k0[keep], k1[keep]
@@ -407,7 +409,7 @@ def bench_dust3r(args, dev, rank, world):
                        "pairs_per_step_per_gpu": B, "weights": "seeded random (imcui_hip/synth_weights.py), AsymmetricCroCo3DStereo architecture, 578 M parameters",
                        "mean_confidence": float(out["conf"].mean()),
                        **({"head": "catmlp+dpt, 24-d descriptors; matching: fast_reciprocal_NNs(subsample 2, dot, 10 rounds) on the device, 2000 matches kept",
-                           "matches_per_pair": nmatch[0] / B, "network_ms_per_step": net_ms, "matching_ms_per_step": dt / args.steps * 1e3 - net_ms} if mast else {})},
+                           "matcher_arithmetic": args.nn_arith, "matches_per_pair": nmatch[0] / B, "network_ms_per_step": net_ms, "matching_ms_per_step": dt / args.steps * 1e3 - net_ms} if mast else {})},
             "roofline": {"kernel": "gemm_split_kernel + conv3x3_split_kernel + attn_split_kernel (matrix class)", "bound": "mfma", "achieved": ach,
                          "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": traffic,
                          "class_ms_per_step": {k: v[0] / args.steps for k, v in cls_ms.items()}, "launches_per_step": mat_n / args.steps,
@@ -621,6 +623,8 @@ def main():
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
+    ap.add_argument("--nn-arith", default="auto", choices=["auto", "fp32", "split"],
+                    help="mast3r: arithmetic of the nearest-neighbour searches (auto = follows --precision: split by default; fp32 = exact-f32 MFMA)")
     ap.add_argument("--arith", default="fp32", choices=["fp32", "fp16"],
                     help="dust3r: fp32 = 3 x f16 split products (default, the parity mode), fp16 = one f16 product per element pair (bf16-class)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],

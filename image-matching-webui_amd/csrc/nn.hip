@@ -301,3 +301,160 @@ extern "C" int imcui_hip_nn_argmax_f32(imcui_hip_t* h, const float* queries, con
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }
+
+// ------------------------------------------------------------------ the same search in the 3 x f16 split arithmetic (opt-in)
+// Rows are scaled by 2^8 (keeps the low parts of unit-norm descriptors out of the f16 subnormal range; a common factor does not
+// move an arg-max), split once into f16 hi / lo planes padded to 32 components ([rows][32] halves per plane), and a dot product is
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16: a quarter of the matrix cycles of the exact-f32 instruction.  The results
+// are fp32-grade (dropped lo.lo term 2^-22 relative), NOT the fmaf chain of the f32 instruction: an arg-max between candidates
+// closer than ~3e-7 may differ from the exact-f32 kernel's.  Workgroup = 512 queries (4 waves x 4 column tiles) x one row range.
+__global__ __launch_bounds__(256) void nn_split_rows_kernel(const float* __restrict__ src, int N, int D, unsigned short* __restrict__ hi,
+                                                            unsigned short* __restrict__ lo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (row, chunk of 8 components)
+    if (i >= (long)N * 4) return;
+    const long row = i >> 2;
+    const int c0 = (int)(i & 3) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (c0 + j < D) ? src[row * D + c0 + j] * 256.0f : 0.0f;
+    uint4 h, l;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, l);
+    *reinterpret_cast<uint4*>(hi + row * 32 + c0) = h;
+    *reinterpret_cast<uint4*>(lo + row * 32 + c0) = l;
+}
+
+__global__ __launch_bounds__(256, 2) void nn_argmax_split_kernel(const unsigned short* __restrict__ qh, const unsigned short* __restrict__ ql,
+                                                                const unsigned short* __restrict__ dh, const unsigned short* __restrict__ dl, int Q,
+                                                                int N, int chunk, float* __restrict__ pbest, int* __restrict__ pidx) {
+    constexpr int RSB = 80;  // bytes per staged row (64 + 16 padding: 16-lane groups of a ds_read_b128 cover all banks once)
+    __shared__ uint4 tile4[2][2][64 * RSB / 16];  // [buffer][plane][row]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.x * 512 + wid * 128;
+    const int split = blockIdx.y;
+    const int n0 = split * chunk, n1 = min(N, n0 + chunk);
+    // B operand: query column lo of column tile c: 8 halves k = 16 ks + 8 hi .. + 7 of either plane
+    uint4 bh[4][2], bl[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const size_t qi = (size_t)min(q0 + c * 32 + lo, Q - 1) * 32;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bh[c][ks] = *reinterpret_cast<const uint4*>(qh + qi + ks * 16 + hi * 8);
+            bl[c][ks] = *reinterpret_cast<const uint4*>(ql + qi + ks * 16 + hi * 8);
+        }
+    }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bidx[4] = {n0, n0, n0, n0};
+    // staging: 64 rows x 64 bytes per plane = 256 uint4 per plane: one per thread and plane
+    auto stage = [&](int buf, int base) {
+        const int r = tid >> 2, g = tid & 3;
+        uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
+        if (base + r < n1) {
+            vh = *reinterpret_cast<const uint4*>(dh + (size_t)(base + r) * 32 + g * 8);
+            vl = *reinterpret_cast<const uint4*>(dl + (size_t)(base + r) * 32 + g * 8);
+        }
+        tile4[buf][0][(r * RSB + g * 16) / 16] = vh;
+        tile4[buf][1][(r * RSB + g * 16) / 16] = vl;
+    };
+    if (n0 < n1) stage(0, n0);
+    __syncthreads();
+    int buf = 0;
+    for (int base = n0; base < n1; base += 64, buf ^= 1) {
+        if (base + 64 < n1) stage(buf ^ 1, base + 64);
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][c][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int o = ((rt * 32 + lo) * RSB + ks * 32 + hi * 16) / 16;
+                const uint4 ah = tile4[buf][0][o], al = tile4[buf][1][o];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[rt][c] = mfma16(ah, bl[c][ks], acc[rt][c]);
+                    acc[rt][c] = mfma16(al, bh[c][ks], acc[rt][c]);
+                    acc[rt][c] = mfma16(ah, bh[c][ks], acc[rt][c]);
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float tmax = acc[0][c][0];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[rt][c][r]);
+            if (tmax > best[c]) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = base + rt * 32 + frag_row(r, hi);
+                        const float v = acc[rt][c][r];
+                        if (row < n1 && v > best[c]) {
+                            best[c] = v;
+                            bidx[c] = row;
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float ov = __shfl_xor(best[c], 32, 64);
+        const int oi = __shfl_xor(bidx[c], 32, 64);
+        if (ov > best[c] || (ov == best[c] && oi < bidx[c])) {
+            best[c] = ov;
+            bidx[c] = oi;
+        }
+        const int qi = q0 + c * 32 + lo;
+        if (hi == 0 && qi < Q) {
+            pbest[(size_t)split * Q + qi] = best[c] * (1.0f / 65536.0f);  // both operands carry 2^8
+            pidx[(size_t)split * Q + qi] = bidx[c];
+        }
+    }
+}
+
+static int nn_argmax_split_nsplit(int Q, int N) {
+    const int qb = (Q + 511) / 512;
+    int ns = (1024 + qb - 1) / qb;
+    const int maxs = (N + 1023) / 1024;
+    if (ns > maxs) ns = maxs;
+    if (ns > 256) ns = 256;
+    return ns < 1 ? 1 : ns;
+}
+// workspace: partial results + the f16 planes of both operands
+extern "C" size_t imcui_hip_nn_argmax_split_workspace_bytes(int Q, int N) {
+    if (Q <= 0 || N <= 0) return 256;
+    return (size_t)nn_argmax_split_nsplit(Q, N) * Q * 8 + ((size_t)Q + N) * 128 + 2048;
+}
+extern "C" int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best,
+                                             void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (Q <= 0) return IMCUI_OK;
+    if (N <= 0 || !queries || !db || !idx) return imcui_set_err(h, IMCUI_ERR_ARG, "nn_argmax_split: empty data base or null argument");
+    if (D <= 0 || D > 32) return imcui_set_err(h, IMCUI_ERR_ARG, "nn_argmax_split: D=%d (1..32)", D);
+    const int ns = nn_argmax_split_nsplit(Q, N);
+    WsAlloc a(ws, ws_bytes);
+    float* pbest = a.get<float>((size_t)ns * Q);
+    int* pidx = a.get<int>((size_t)ns * Q);
+    unsigned short* qh = a.get<unsigned short>((size_t)Q * 32);
+    unsigned short* ql = a.get<unsigned short>((size_t)Q * 32);
+    unsigned short* dh = a.get<unsigned short>((size_t)N * 32);
+    unsigned short* dl = a.get<unsigned short>((size_t)N * 32);
+    if (!ws || !a.ok) return imcui_set_err(h, IMCUI_ERR_WS, "nn_argmax_split: workspace too small (%zu < %zu)", ws_bytes, a.off);
+    hipLaunchKernelGGL(nn_split_rows_kernel, dim3((unsigned)(((long)Q * 4 + 255) / 256)), dim3(256), 0, stream, queries, Q, D, qh, ql);
+    hipLaunchKernelGGL(nn_split_rows_kernel, dim3((unsigned)(((long)N * 4 + 255) / 256)), dim3(256), 0, stream, db, N, D, dh, dl);
+    const int chunk = (((N + ns - 1) / ns) + 63) / 64 * 64;
+    hipLaunchKernelGGL(nn_argmax_split_kernel, dim3((Q + 511) / 512, ns), dim3(256), 0, stream, qh, ql, dh, dl, Q, N, chunk, pbest, pidx);
+    hipLaunchKernelGGL(nn_argmax_fold_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, pbest, pidx, Q, ns, idx, best);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}

@@ -834,9 +834,10 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
-def nn_argmax(queries: torch.Tensor, db: torch.Tensor, return_best: bool = False):
+def nn_argmax(queries: torch.Tensor, db: torch.Tensor, return_best: bool = False, split: bool = False):
     """queries [Q,D], db [N,D] (D in 16 / 24 / 32) -> int64 [Q]: the FIRST arg-max over n of <queries[q], db[n]> (what
-    `cdistMatcher(dist="dot").query` of upstream's mast3r/fast_nn.py returns; imcui/hloc/matchers/mast3r.py:68-75)."""
+    `cdistMatcher(dist="dot").query` of upstream's mast3r/fast_nn.py returns; imcui/hloc/matchers/mast3r.py:68-75).
+    split=True: the 3 x f16 split arithmetic (4 x fewer matrix cycles, fp32-grade values; near-ties may resolve differently)."""
     dev = queries.device
     hd = get_handle(dev)
     lib = hd.lib
@@ -848,9 +849,11 @@ def nn_argmax(queries: torch.Tensor, db: torch.Tensor, return_best: bool = False
     if Q == 0:
         return (idx.long(), best) if return_best else idx.long()
     with _nn_lock:
-        ws = _nn_ws.get(lib.imcui_hip_nn_argmax_workspace_bytes(Q, N), dev)
+        fn_ws, fn = ((lib.imcui_hip_nn_argmax_split_workspace_bytes, lib.imcui_hip_nn_argmax_split_f32) if split else
+                     (lib.imcui_hip_nn_argmax_workspace_bytes, lib.imcui_hip_nn_argmax_f32))
+        ws = _nn_ws.get(fn_ws(Q, N), dev)
         with torch.cuda.device(dev):
-            rc = lib.imcui_hip_nn_argmax_f32(hd.h, _ptr(queries), _ptr(db), Q, N, D, _ptr(idx), _ptr(best), _ptr(ws), ws.numel(), _stream_ptr())
+            rc = fn(hd.h, _ptr(queries), _ptr(db), Q, N, D, _ptr(idx), _ptr(best), _ptr(ws), ws.numel(), _stream_ptr())
             hd.check(rc, "imcui_hip_nn_argmax_f32")
     return (idx.long(), best) if return_best else idx.long()
 

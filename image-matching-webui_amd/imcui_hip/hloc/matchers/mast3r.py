@@ -20,6 +20,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from ... import backend
 from .duster import Duster
 
 
@@ -30,6 +31,10 @@ class Mast3r(Duster):
         "max_keypoints": 2000,
         "vit_patch_size": 16,
         "arithmetic": "fp32",
+        # HIP backend only: arithmetic of the nearest-neighbour searches -- "auto" = the library's mode (imcui_hip_set_precision: 3 x f16 split
+        # products by default, the exact-f32 matrix instruction in precision 0), "split" / "fp32" force one.  Split: 4 x fewer matrix
+        # cycles, fp32-grade similarities; candidates closer than ~3e-7 may resolve differently from the exact-f32 instruction.
+        "matcher_arithmetic": "auto",
     }
     weights_subdir = "mast3r"
 
@@ -50,7 +55,9 @@ class Mast3r(Duster):
         output = self.inference_output(data)
         # the reference matches the descriptors of the SECOND directed pair (image1 as view 1, image0 as view 2), mast3r.py:61-64
         desc1, desc2 = output["pred1"]["desc"][1], output["pred2"]["desc"][1]
-        k0, k1 = fast_reciprocal_nns(desc1, desc2, subsample=2)
+        mode = self.conf.get("matcher_arithmetic", "auto")
+        split = backend.get_precision(desc1.device) == 1 if mode == "auto" else mode == "split"
+        k0, k1 = fast_reciprocal_nns(desc1, desc2, subsample=2, split=split)
         if len(k0) == 0:
             return {"keypoints0": torch.zeros([0, 2]), "keypoints1": torch.zeros([0, 2])}
         k0, k1 = k0.cpu().numpy(), k1.cpu().numpy()
@@ -61,13 +68,11 @@ class Mast3r(Duster):
         return {"keypoints0": torch.from_numpy(np.ascontiguousarray(k0)), "keypoints1": torch.from_numpy(np.ascontiguousarray(k1))}
 
 
-def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int = 2, max_iter: int = 10, nn=None):
+def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int = 2, max_iter: int = 10, nn=None, split: bool = False):
     """desc1 [H1,W1,D], desc2 [H2,W2,D] (device) -> (xy1 [K,2], xy2 [K,2]) int64 pixel (x, y) of the reciprocal matches, ordered by
     (linear position in image 1, linear position in image 2).  `nn(queries, db)` = first arg-max of the dot products (default: the
     HIP kernel); the loop is upstream's `fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=S, ret_xy=True, pixel_tol=0)`."""
-    from ... import backend
-
-    nn = nn or backend.nn_argmax
+    nn = nn or (lambda q, db: backend.nn_argmax(q, db, split=split))
     H1, W1, D = desc1.shape
     H2, W2, _ = desc2.shape
     dev = desc1.device

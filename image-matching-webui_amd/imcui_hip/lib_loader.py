@@ -121,6 +121,8 @@ SIGNATURES = {
     ),
     "imcui_hip_conv_gemm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]),
     "imcui_hip_nn_argmax_workspace_bytes": (C.c_size_t, [C.c_int] * 2),
+    "imcui_hip_nn_argmax_split_workspace_bytes": (C.c_size_t, [C.c_int] * 2),
+    "imcui_hip_nn_argmax_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_nn_argmax_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_mutual_nn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "imcui_hip_mutual_nn": (

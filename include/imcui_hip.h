@@ -242,6 +242,12 @@ size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, i
 size_t imcui_hip_nn_argmax_workspace_bytes(int Q, int N);
 int imcui_hip_nn_argmax_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best, void* ws,
                             size_t ws_bytes, void* stream);
+/* The same search in the 3 x f16 split arithmetic (rows scaled by 2^8, split into f16 hi / lo planes, three products per pair,
+ * f32 accumulate; D <= 32): a quarter of the matrix cycles.  fp32-grade values, but not the exact-f32 instruction's fmaf chain:
+ * between candidates closer than ~3e-7 the arg-max may differ from imcui_hip_nn_argmax_f32's (opt-in, conf "matcher_arithmetic"). */
+size_t imcui_hip_nn_argmax_split_workspace_bytes(int Q, int N);
+int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best, void* ws,
+                                  size_t ws_bytes, void* stream);
 
 /* ---- DUSt3R pair network (BASELINE config 5; what `dust3r.inference.inference(pairs, self.net, ...)`
  * computes at imcui/hloc/matchers/duster.py:73 with self.net = AsymmetricCroCo3DStereo (duster.py:37): ViT encoder with 2-D rotary

@@ -179,8 +179,9 @@ def test_mast3r_descriptors_vs_oracle():
         assert ((out[pred]["desc_conf"].cpu() - want["desc_conf"]).abs() / want["desc_conf"]).max().item() < 1e-4
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["f32", "split"])
 @pytest.mark.parametrize("D,Q,N", [(24, 5000, 20001), (32, 300, 70000), (16, 1, 63), (24, 20000, 4100)])
-def test_nn_argmax_vs_float64(D, Q, N):
+def test_nn_argmax_vs_float64(D, Q, N, split):
     """The search primitive of MASt3R's matcher: first arg-max of the dot products.  Differences from a float64 evaluation must be
     near-ties (the two candidates within 2e-6 in float64); duplicated data-base rows must resolve to the first copy."""
     import torch.nn.functional as F
@@ -194,7 +195,7 @@ def test_nn_argmax_vs_float64(D, Q, N):
     q = F.normalize(db[torch.randint(0, N, (Q,), generator=g)] + 0.2 * torch.randn(Q, D, generator=g), dim=-1)
     ncopy = min(Q, 50, ndup)
     q[:ncopy] = db[:ncopy]  # queries equal to rows that exist twice
-    idx, best = backend.nn_argmax(q.cuda(), db.cuda(), return_best=True)
+    idx, best = backend.nn_argmax(q.cuda(), db.cuda(), return_best=True, split=split)
     idx, best = idx.cpu(), best.cpu()
     sim = q.double() @ db.double().T
     want = sim.argmax(1)
@@ -207,7 +208,8 @@ def test_nn_argmax_vs_float64(D, Q, N):
     assert (idx[:ncopy] == torch.arange(ncopy)).all()
 
 
-def test_mast3r_matches_vs_oracle():
+@pytest.mark.parametrize("matcher_arithmetic", ["auto", "fp32", "split"])
+def test_mast3r_matches_vs_oracle(matcher_arithmetic):
     """`Mast3r._forward` end to end (network -> descriptors of the swapped pair -> reciprocal matching -> linspace sub-sampling, mast3r.py:
     56-96) against the oracle's `fast_reciprocal_nns` on the SAME descriptors: identical match lists (the descriptors themselves are
     checked in test_mast3r_descriptors_vs_oracle)."""
@@ -219,7 +221,7 @@ def test_mast3r_matches_vs_oracle():
     torch.set_num_threads(16)
     cfg = {**SMALL, "desc_dim": 24}
     sd = dust3r_state_dict(2, cfg)
-    model = Mast3r({"state_dict": sd, "max_keypoints": 300}).eval().to("cuda:0")
+    model = Mast3r({"state_dict": sd, "max_keypoints": 300, "matcher_arithmetic": matcher_arithmetic}).eval().to("cuda:0")
     i0, i1 = _images(96, 128, 13)
     data = {"image0": i0.cuda(), "image1": i1.cuda()}
     pred = model(data)
