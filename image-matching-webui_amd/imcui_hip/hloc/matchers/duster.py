@@ -61,6 +61,11 @@ class Duster(BaseModel):
 
     def inference_output(self, data: dict) -> dict:
         """What `inference(pairs, self.net, device, batch_size=1)` returns for the symmetrised pair (duster.py:66-73)."""
+        return self._symmetrised(data)[1]
+
+    def _symmetrised(self, data: dict):
+        """-> (raw network outputs [2 views, 2 directed pairs, ...], upstream's inference dictionary); no state is kept on the
+        plugin object: the UI calls one model from several worker threads."""
         img0, img1 = data["image0"], data["image1"]
         if img0.shape != img1.shape or img0.shape[0] != 1:
             raise ValueError("DUSt3R expects one pair of images of one size (the wrapper's preprocess guarantees it)")
@@ -68,14 +73,13 @@ class Duster(BaseModel):
         if H % 32 or W % 32:
             raise ValueError(f"the HIP DUSt3R path needs image sizes that are multiples of 32, got {W}x{H}")
         out = self.forward_pairs(torch.cat((img0, img1), 0), [[0, 1], [1, 0]])
-        self._last_forward = out
         norm = [(img0 - 0.5) / 0.5, (img1 - 0.5) / 0.5]
         shape = torch.tensor([[H, W], [H, W]])
 
         def view(a, b):  # collated views of the two directed pairs
             return {"img": torch.cat((norm[a], norm[b]), 0), "true_shape": shape, "idx": [a, b], "instance": [str(a), str(b)]}
 
-        return {
+        return out, {
             "view1": view(0, 1),
             "view2": view(1, 0),
             "pred1": {"pts3d": out["pts3d"][0], "conf": out["conf"][0]},

@@ -44,8 +44,7 @@ class Mast3r(Duster):
             raise KeyError("MASt3R weights must hold downstream_head{1,2}.head_local_features.* (the 'catmlp+dpt' head)")
 
     def inference_output(self, data: dict) -> dict:
-        out = super().inference_output(data)
-        raw = self._last_forward
+        raw, out = self._symmetrised(data)
         for v, pred in enumerate(("pred1", "pred2")):
             out[pred]["desc"] = raw["desc"][v]
             out[pred]["desc_conf"] = raw["desc_conf"][v]
