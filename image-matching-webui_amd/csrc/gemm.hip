@@ -1087,22 +1087,53 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ host-side weight split
-static unsigned short f32_to_f16_rtz(float f) {
+// f32 -> f16 on the host, integer arithmetic (exhaustively identical, over all 2^32 inputs, to the float-compare formulation
+// they replaced: truncate, then pick the nearer of the two neighbours, ties to even; inf / nan / overflow saturate to the
+// largest finite value, like v_cvt_pkrtz_f16_f32).  mag = magnitude truncated toward zero, rem = the dropped bits, half = half a
+// unit of the last kept place.
+static inline void f16_parts(float f, unsigned& sign, unsigned& mag, unsigned& rem, unsigned& half) {
     unsigned x;
     memcpy(&x, &f, 4);
-    const unsigned sign = (x >> 16) & 0x8000u;
-    const int e = (int)((x >> 23) & 0xFF) - 127 + 15;
+    sign = (x >> 16) & 0x8000u;
+    const unsigned ex = (x >> 23) & 0xFFu;
+    const int e = (int)ex - 112;
     unsigned m = x & 0x7FFFFFu;
-    if (((x >> 23) & 0xFF) == 0xFF) return (unsigned short)(sign | 0x7BFFu);  // inf/nan -> max finite
-    if (e >= 31) return (unsigned short)(sign | 0x7BFFu);                      // saturate
-    if (e <= 0) {
-        if (e < -10) return (unsigned short)sign;
-        m |= 0x800000u;
-        return (unsigned short)(sign | (m >> (14 - e)));  // subnormal, truncate
+    rem = 0;
+    half = 0;
+    if (ex == 0xFFu || e >= 31) {
+        mag = 0x7BFFu;
+        return;
     }
-    return (unsigned short)(sign | (e << 10) | (m >> 13));
+    if (e <= 0) {
+        if (e < -10) {  // below half of the smallest subnormal: rounds to zero either way
+            mag = 0;
+            rem = (ex == 0 && m == 0) ? 0u : 1u;
+            half = 2u;
+            return;
+        }
+        m |= 0x800000u;
+        const int sh = 14 - e;  // 14 .. 24
+        mag = m >> sh;
+        rem = m & ((1u << sh) - 1u);
+        half = 1u << (sh - 1);
+        return;
+    }
+    mag = ((unsigned)e << 10) | (m >> 13);
+    rem = m & 0x1FFFu;
+    half = 0x1000u;
 }
-static float f16_to_f32(unsigned short hv) {
+static inline unsigned short f32_to_f16_rtz(float f) {
+    unsigned s, g, r, h;
+    f16_parts(f, s, g, r, h);
+    return (unsigned short)(s | g);
+}
+static inline unsigned short f32_to_f16_rtn(float f) {
+    unsigned s, g, r, h;
+    f16_parts(f, s, g, r, h);
+    if (g < 0x7BFFu && (r > h || (r == h && (g & 1u)))) g += 1u;
+    return (unsigned short)(s | g);
+}
+static inline float f16_to_f32(unsigned short hv) {
     const unsigned sign = (hv & 0x8000u) << 16;
     int e = (hv >> 10) & 0x1F;
     unsigned m = hv & 0x3FFu;
@@ -1126,40 +1157,43 @@ static float f16_to_f32(unsigned short hv) {
     memcpy(&f, &x, 4);
     return f;
 }
-static unsigned short f32_to_f16_rtn(float f) {
-    // round to nearest even via the truncated value and its successor
-    const unsigned short t = f32_to_f16_rtz(f);
-    if ((t & 0x7FFFu) >= 0x7BFFu) return t;
-    const unsigned short u = (unsigned short)(t + 1);  // next magnitude, same sign
-    const float ft = f16_to_f32(t), fu = f16_to_f32(u);
-    const float dt = fabsf(f - ft), du = fabsf(fu - f);
-    if (dt < du) return t;
-    if (du < dt) return u;
-    return (t & 1) ? u : t;
+// scale 2^e that puts max |w| into [4096, 8192] (keeps the low parts out of the f16 subnormal range); e in [-8, 24]
+static inline int split_scale_exp(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    int e = 0;
+    if (mx > 0.f) {
+        e = (int)floorf(log2f(8192.0f / mx));
+        if (e > 24) e = 24;
+        if (e < -8) e = -8;
+    }
+    return e;
+}
+static inline void split_one(float x, unsigned short& hi, unsigned short& lo) {
+    hi = f32_to_f16_rtz(x);
+    lo = f32_to_f16_rtn(x - f16_to_f32(hi));
 }
 
 float split_weights_frag_host(const float* w, int N, int K, unsigned short* hi, unsigned short* lo) {
     // planes [ceil(N/32)][K/16][2][32][8]: element (nf, ks, h, r, j) = W[nf*32 + r][ks*16 + h*8 + j]
-    const size_t n = (size_t)N * K;
-    unsigned short* th = (unsigned short*)malloc(n * sizeof(unsigned short));
-    unsigned short* tl = (unsigned short*)malloc(n * sizeof(unsigned short));
-    const float sc = split_weights_host(w, n, th, tl);
+    const int e = split_scale_exp(w, (size_t)N * K);
+    const float sc = ldexpf(1.0f, e);
     const int nfr = (N + 31) / 32, nks = K / 16;
     for (int nf = 0; nf < nfr; ++nf)
-        for (int ks = 0; ks < nks; ++ks)
-            for (int hh = 0; hh < 2; ++hh)
-                for (int r = 0; r < 32; ++r) {
-                    const int row = nf * 32 + r;
+        for (int r = 0; r < 32; ++r) {
+            const int row = nf * 32 + r;
+            for (int ks = 0; ks < nks; ++ks)
+                for (int hh = 0; hh < 2; ++hh) {
                     const size_t dst = ((((size_t)nf * nks + ks) * 2 + hh) * 32 + r) * 8;
-                    for (int j = 0; j < 8; ++j) {
-                        const size_t src = (size_t)row * K + ks * 16 + hh * 8 + j;
-                        hi[dst + j] = row < N ? th[src] : 0;
-                        lo[dst + j] = row < N ? tl[src] : 0;
+                    if (row < N) {
+                        const float* src = w + (size_t)row * K + ks * 16 + hh * 8;
+                        for (int j = 0; j < 8; ++j) split_one(src[j] * sc, hi[dst + j], lo[dst + j]);  // the scaling is exact (power of two)
+                    } else {
+                        for (int j = 0; j < 8; ++j) hi[dst + j] = lo[dst + j] = 0;
                     }
                 }
-    free(th);
-    free(tl);
-    return sc;
+        }
+    return ldexpf(1.0f, -e);
 }
 
 void pack_conv_gemm(const float* w, int Cout, int Cin, int ks, int Cin_pad, float* dst) {
@@ -1172,20 +1206,8 @@ void pack_conv_gemm(const float* w, int Cout, int Cin, int ks, int Cin_pad, floa
 }
 
 float split_weights_host(const float* w, size_t n, unsigned short* hi, unsigned short* lo) {
-    float mx = 0.f;
-    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
-    int e = 0;
-    if (mx > 0.f) {
-        e = (int)floorf(log2f(8192.0f / mx));  // max |w| * 2^e in [4096, 8192]
-        if (e > 24) e = 24;
-        if (e < -8) e = -8;
-    }
+    const int e = split_scale_exp(w, n);
     const float sc = ldexpf(1.0f, e);
-    for (size_t i = 0; i < n; ++i) {
-        const float x = w[i] * sc;  // exact (power of two)
-        const unsigned short hh = f32_to_f16_rtz(x);
-        hi[i] = hh;
-        lo[i] = f32_to_f16_rtn(x - f16_to_f32(hh));
-    }
+    for (size_t i = 0; i < n; ++i) split_one(w[i] * sc, hi[i], lo[i]);  // exact scaling (power of two)
     return ldexpf(1.0f, -e);
 }
