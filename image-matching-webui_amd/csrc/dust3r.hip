@@ -284,7 +284,7 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     w.ok = a.ok;
     return w;
 }
-static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0; }
+static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0; }
 
 extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W) {
     const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
@@ -300,7 +300,7 @@ extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int d
     if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
     const size_t R = du_R(H, W), h = H / 16, w = W / 16, p = P;
     size_t n = (size_t)(c.enc_depth + 2) * NI * R * c.E + (size_t)(c.dec_depth + 2) * 2 * P * R * c.D;
-    const size_t per_view = p * 256 * (16 * h * w + 4 * h * w + h * w + (h / 2) * (w / 2))   // layer_rn
+    const size_t per_view = p * 256 * (16 * h * w + 4 * h * w + h * w + ((h + 1) / 2) * ((w + 1) / 2))   // layer_rn
                             + p * 256 * (h * w + 4 * h * w + 16 * h * w + 64 * h * w)          // paths 4, 3, 2, 1
                             + p * (size_t)H * W * 128 + p * (size_t)H * W * 4;
     return n + 2 * per_view;
@@ -323,7 +323,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
     if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: arith = %d (0: 3 x f16 split products, 1: one f16 product)", arith);
     const int single = arith;  // GEMMs and 3x3 convolutions with ONE f16 product per element pair; attention stays in the split arithmetic
-    if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 32", NI, W, H, P);
+    if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 16", NI, W, H, P);
     if (!packed || !images || !pairs || !pts3d || !conf || (c.desc > 0 && (!desc || !desc_conf)))
         return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
     if (((size_t)(c.E / 64) * NI) % 8 != 0 || ((size_t)(c.D / 64) * 2 * P) % 8 != 0)
@@ -583,7 +583,9 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         };
         const float* tok0 = w.tok0 + (size_t)v * pt * E;
         const float* hk[3] = {w.hook[0] + (size_t)v * pt * D, w.hook[1] + (size_t)v * pt * D, w.hook[2] + (size_t)v * pt * D};
-        // reassemble: 1/4, 1/8, 1/16, 1/32
+        // reassemble: 1/4, 1/8, 1/16, 1/32 (an odd token grid rounds the 1/32 level up: 3x3 stride 2 with padding 1; the x2 of the first
+        // fusion block is then cropped back to the token grid, upstream's `[:, :, :layers[2].shape[2], :layers[2].shape[3]]`)
+        const int h3 = (hg + 1) / 2, w3 = (wg + 1) / 2;
         DURUN(lin_dense(L0 + 0, tok0, w.ta, pt));
         DURUN(lin_dense(L0 + 1, w.ta, w.tb, pt));
         shuffle(w.tb, w.tm, 4, 96);
@@ -613,17 +615,17 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             g.conv_pad = 1;
             g.conv_hin = hg;
             g.conv_win = wg;
-            g.conv_hout = hg / 2;
-            g.conv_wout = wg / 2;
+            g.conv_hout = h3;
+            g.conv_wout = w3;
             g.conv_cin = 768;
-            g.M = P * (hg / 2) * (wg / 2);
+            g.M = P * h3 * w3;
             g.C = w.tm;
             g.ldc = N;
             g.single = single;
             DURUN(gemm_launch(h, g, stream));
         }
-        DURUN(conv3(L0 + 10, w.tm, w.rn[3], hg / 2, wg / 2, 0, nullptr));
-        const int rh[4] = {4 * hg, 2 * hg, hg, hg / 2}, rw[4] = {4 * wg, 2 * wg, wg, wg / 2};
+        DURUN(conv3(L0 + 10, w.tm, w.rn[3], h3, w3, 0, nullptr));
+        const int rh[4] = {4 * hg, 2 * hg, hg, h3}, rw[4] = {4 * wg, 2 * wg, wg, w3};
         for (int k = 0; k < 4; ++k) dump_copy(w.rn[k], (size_t)P * rh[k] * rw[k] * 256);
         // fusion: refinenet 4, 3, 2, 1
         const float* path = nullptr;
@@ -648,7 +650,15 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             float* out = (q & 1) ? w.pb : w.pa;
             DURUN(lin_dense(Lq + 4, w.s3, out, (long)P * 4 * hh * ww));
             path = out;
-            dump_copy(out, (size_t)P * 4 * hh * ww * 256);
+            int ph = 2 * hh, pw = 2 * ww;
+            if (q == 0 && (ph != hg || pw != wg)) {
+                const long c4 = (long)P * hg * wg * 64;
+                hipLaunchKernelGGL(du_crop_kernel, blocks(c4), blk, 0, stream, out, w.hd0, ph, pw, hg, wg, 64, c4);
+                path = w.hd0;
+                ph = hg;
+                pw = wg;
+            }
+            dump_copy(path, (size_t)P * ph * pw * 256);
         }
         // head: 3x3 256 -> 128 at 1/2, x2, 3x3 128 -> 128 + ReLU, 1x1 128 -> 4 + post-processing
         DURUN(conv3(L0 + 31, path, w.hd0, H / 2, W / 2, 0, nullptr));

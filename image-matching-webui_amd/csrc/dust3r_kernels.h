@@ -193,6 +193,20 @@ __global__ __launch_bounds__(256) void du_pixel_shuffle_kernel(const float* __re
     }
 }
 
+// top-left crop of NHWC maps: dst [B][h][w][C] = src [B][hs][ws][C][:, :h, :w]
+__global__ __launch_bounds__(256) void du_crop_kernel(const float* __restrict__ src, float* __restrict__ dst, int hs, int ws, int h, int w, int C4,
+                                                      long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h);
+        const long b = r / h;
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[((b * hs + y) * ws + x) * C4 + c];
+    }
+}
+
 // ------------------------------------------------------------------ element-wise pieces of the fusion blocks
 __global__ __launch_bounds__(256) void du_relu_kernel(const float* __restrict__ x, float* __restrict__ out, long n4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {

@@ -743,7 +743,7 @@ class DUSt3RHIP:
         self.last_dump = None
 
     def forward(self, packed, cfg, images, pairs, dump=False, arith=0):
-        """images [NI,3,H,W] in [0,1] (H, W multiples of 32), pairs [P,2] int (view-1 image, view-2 image) ->
+        """images [NI,3,H,W] in [0,1] (H, W multiples of 16), pairs [P,2] int (view-1 image, view-2 image) ->
         {"pts3d": [2,P,H,W,3], "conf": [2,P,H,W]} (view 1 in its own frame, view 2 in view 1's frame); a MASt3R network
         (cfg["desc_dim"] > 0) also returns "desc" [2,P,H,W,desc_dim] and "desc_conf" [2,P,H,W].
         arith: 0 = 3 x f16 split products (fp32-grade), 1 = one f16 product per element pair (bf16-class)."""
@@ -770,7 +770,7 @@ class DUSt3RHIP:
         with self._lock:
             nbytes = lib.imcui_hip_dust3r_workspace_bytes(*c4, NI, P, H, W)
             if nbytes == 0:
-                raise ImcuiHipError(f"DUSt3R: unsupported sizes ({NI} images of {W}x{H}, {P} pairs; multiples of 32)")
+                raise ImcuiHipError(f"DUSt3R: unsupported sizes ({NI} images of {W}x{H}, {P} pairs; multiples of 16)")
             ws = self._ws.get(nbytes, dev)
             with torch.cuda.device(dev):
                 rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), _ptr(images), NI, H, W, _ptr(pairs), P, int(arith), _ptr(pts), _ptr(conf),

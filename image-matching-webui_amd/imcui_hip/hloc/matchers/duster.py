@@ -70,8 +70,8 @@ class Duster(BaseModel):
         if img0.shape != img1.shape or img0.shape[0] != 1:
             raise ValueError("DUSt3R expects one pair of images of one size (the wrapper's preprocess guarantees it)")
         H, W = img0.shape[-2:]
-        if H % 32 or W % 32:
-            raise ValueError(f"the HIP DUSt3R path needs image sizes that are multiples of 32, got {W}x{H}")
+        if H % 16 or W % 16:
+            raise ValueError(f"DUSt3R needs image sizes that are multiples of the patch size 16 (the wrapper's preprocess rounds to it), got {W}x{H}")
         out = self.forward_pairs(torch.cat((img0, img1), 0), [[0, 1], [1, 0]])
         norm = [(img0 - 0.5) / 0.5, (img1 - 0.5) / 0.5]
         shape = torch.tensor([[H, W], [H, W]])

@@ -91,15 +91,16 @@ def _compare(cfg, h, w, seed=0, tol=2e-4, arithmetic="fp32", out_tol=1e-4):
     got = take((2 * P, R, D))[:, :T]
     check("decoder output (dec_norm)", got, torch.cat([passes[p][v]["_dec"][nd] for v in (0, 1) for p in (0, 1)], 0))
     # heads
-    rh = (4 * hg, 2 * hg, hg, hg // 2)
-    rw = (4 * wg, 2 * wg, wg, wg // 2)
+    rh = (4 * hg, 2 * hg, hg, (hg + 1) // 2)
+    rw = (4 * wg, 2 * wg, wg, (wg + 1) // 2)
+    ph, pw = (hg, 2 * hg, 4 * hg, 8 * hg), (wg, 2 * wg, 4 * wg, 8 * wg)  # fusion outputs (the first one cropped to the token grid)
     for v in (0, 1):
         for k in range(4):
             want = torch.cat([passes[p][v]["_layers"][k] for p in (0, 1)], 0).permute(0, 2, 3, 1)
             check(f"view {v + 1} layer_rn {k}", take((P, rh[k], rw[k], 256)), want)
         for q, name in enumerate(("_path4", "_path3", "_path2", "_path1")):
             want = torch.cat([passes[p][v][name] for p in (0, 1)], 0).permute(0, 2, 3, 1)
-            check(f"view {v + 1} {name[1:]}", take((P, 2 * rh[3 - q], 2 * rw[3 - q], 256)), want)
+            check(f"view {v + 1} {name[1:]}", take((P, ph[q], pw[q], 256)), want)
         want = torch.cat([passes[p][v]["_feat"] for p in (0, 1)], 0).permute(0, 2, 3, 1)
         check(f"view {v + 1} head features", take((P, h, w, 128)), want)
         want = torch.cat([passes[p][v]["_raw"] for p in (0, 1)], 0)
@@ -124,6 +125,12 @@ def _compare(cfg, h, w, seed=0, tol=2e-4, arithmetic="fp32", out_tol=1e-4):
 def test_dust3r_small_config_vs_oracle():
     """2 + 4 blocks, 512 / 256 wide, 224 x 160 images: 140 tokens per image (padding rows in every sequence)."""
     _compare(SMALL, 160, 224)
+
+
+def test_dust3r_odd_token_grid():
+    """144 x 112 = 9 x 7 tokens (what `dfactor: 16` of the zoo conf produces for 3:2 images): the 1/32 level rounds up to 5 x 4 and the
+    first fusion output is cropped back to 9 x 7."""
+    _compare(SMALL, 112, 144, seed=4)
 
 
 def test_dust3r_small_config_full_tiles():

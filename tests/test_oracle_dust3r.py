@@ -132,7 +132,7 @@ def test_pack_dust3r_layout_matches_the_library():
         assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, dd, 2, 2, 96, 128) > 0
     assert lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 24) == lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 0) + 4
     assert lib.imcui_hip_dust3r_num_layers(100, 1, 64, 4, 0) == 0  # widths must be multiples of 64
-    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 0, 2, 2, 100, 128) == 0  # sizes must be multiples of 32
+    assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 0, 2, 2, 100, 128) == 0  # sizes must be multiples of 16
 
 
 def test_mast3r_local_features_are_a_pixel_shuffle_of_the_token_mlp():
