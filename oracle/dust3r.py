@@ -35,7 +35,8 @@ scratch.refinenet{1..4}.{resConfUnit{1,2}.conv{1,2},out_conv},head.{0,2,4}}`).
 
 Pinning: PARITY UNPINNED -- the reference holds neither the sources nor golden vectors for this path.  Independent checks
 that ARE possible in the container (tests/test_oracle_dust3r.py): the fusion blocks and the reassemble stage against
-`transformers.models.dpt.modeling_dpt` (an independent restatement of the same DPT blocks), the attention block against
+`transformers.models.dpt.modeling_dpt` (an independent restatement of the same DPT blocks), the encoder block without its
+rotation against `transformers`' ViTLayer, the attention block against
 `torch.nn.functional.scaled_dot_product_attention`, the rotary embedding against a complex-number formulation.
 """
 from __future__ import annotations

@@ -184,3 +184,42 @@ def test_fast_reciprocal_nns_restatement():
     assert (nn_dot_first_argmax(p2[:100], db, block=64) == torch.arange(100)).all()
     b1, b2 = plugin_loop(d1, d2, subsample=2, nn=nn_dot_first_argmax)
     assert torch.equal(b1, xy1) and torch.equal(b2, xy2)
+
+
+def test_encoder_block_against_the_transformers_vit_layer():
+    """The CroCo encoder block without its rotary embedding (all positions 0 -> the rotation is the identity) is the standard pre-norm
+    ViT block: transformers' ViTLayer loaded with the same tensors (fused qkv split into its q / k / v Linears) gives the same output."""
+    vit = pytest.importorskip("transformers.models.vit.modeling_vit")
+    from transformers import ViTConfig
+
+    sd = dust3r_state_dict(13, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    E = CFG["enc_dim"]
+    conf = ViTConfig(hidden_size=E, num_attention_heads=E // 64, intermediate_size=4 * E, hidden_act="gelu", layer_norm_eps=1e-6, qkv_bias=True,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    conf._attn_implementation = "eager"
+    layer = vit.ViTLayer(conf).eval()
+    p = "enc_blocks.1."
+    qkv_w, qkv_b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+    tens = {"layernorm_before.weight": sd[p + "norm1.weight"], "layernorm_before.bias": sd[p + "norm1.bias"],
+            "layernorm_after.weight": sd[p + "norm2.weight"], "layernorm_after.bias": sd[p + "norm2.bias"]}
+    names = set(layer.state_dict())
+    if "attention.q_proj.weight" in names:  # current module tree of the port
+        out_proj, fc1, fc2, qkv = "attention.o_proj", "mlp.fc1", "mlp.fc2", ("attention.q_proj", "attention.k_proj", "attention.v_proj")
+    else:  # older releases
+        out_proj, fc1, fc2 = "attention.output.dense", "intermediate.dense", "output.dense"
+        qkv = ("attention.attention.query", "attention.attention.key", "attention.attention.value")
+    for dst, src in ((out_proj, "attn.proj"), (fc1, "mlp.fc1"), (fc2, "mlp.fc2")):
+        tens[dst + ".weight"], tens[dst + ".bias"] = sd[p + src + ".weight"], sd[p + src + ".bias"]
+    for i, n in enumerate(qkv):
+        tens[n + ".weight"] = qkv_w[i * E : (i + 1) * E]
+        tens[n + ".bias"] = qkv_b[i * E : (i + 1) * E]
+    layer.load_state_dict(tens)
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 35, E, generator=g)
+    pos = torch.zeros(2, 35, 2, dtype=torch.long)
+    with torch.no_grad():
+        want = layer(x)
+    want = want[0] if isinstance(want, tuple) else want
+    got = o._enc_block(x, pos, "enc_blocks.1")
+    assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
