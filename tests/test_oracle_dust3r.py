@@ -223,3 +223,25 @@ def test_encoder_block_against_the_transformers_vit_layer():
     want = want[0] if isinstance(want, tuple) else want
     got = o._enc_block(x, pos, "enc_blocks.1")
     assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_cross_attention_against_torch_multihead_attention():
+    """The decoder's cross attention without rotation (positions 0): queries from x, keys / values from the other view's tokens,
+    separate projections with biases, 64-wide heads, output projection -- torch.nn.MultiheadAttention with the same tensors."""
+    sd = dust3r_state_dict(15, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    D = CFG["dec_dim"]
+    p = "dec_blocks2.2.cross_attn"
+    mha = torch.nn.MultiheadAttention(D, D // 64, bias=True, batch_first=True).eval()
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.cat([sd[f"{p}.proj{n}.weight"] for n in "qkv"], 0))
+        mha.in_proj_bias.copy_(torch.cat([sd[f"{p}.proj{n}.bias"] for n in "qkv"], 0))
+        mha.out_proj.weight.copy_(sd[p + ".proj.weight"])
+        mha.out_proj.bias.copy_(sd[p + ".proj.bias"])
+    g = torch.Generator().manual_seed(16)
+    x, y = torch.randn(2, 20, D, generator=g), torch.randn(2, 28, D, generator=g)
+    zx, zy = torch.zeros(2, 20, 2, dtype=torch.long), torch.zeros(2, 28, 2, dtype=torch.long)
+    with torch.no_grad():
+        want = mha(x, y, y, need_weights=False)[0]
+    got = o._cross_attn(x, y, zx, zy, p)
+    assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
