@@ -297,7 +297,7 @@ def dust3r_tflop_per_pair(cfg: dict, H: int, W: int) -> dict:
 
 def bench_dust3r(args, dev, rank, world):
     """configs[4]: DUSt3R ViT-L pair encoder + DPT regression head on 512x512 pairs; symmetrised image pairs/s (what one call of
-    imcui/hloc/matchers/duster.py processes: the directed pairs (0, 1) and (1, 0)), weak scaling, pairs sharded over the ranks,
+    imcui/hloc/matchers/duster.py processes: the directed pairs (1, 0) and (0, 1)), weak scaling, pairs sharded over the ranks,
     no collective (the outputs are dense point maps consumed by the host-side aligner of the rank that owns the pair)."""
     from imcui_hip import backend
     from imcui_hip.hloc.matchers.duster import Duster
@@ -337,7 +337,7 @@ def bench_dust3r(args, dev, rank, world):
     i0 = torch.cat((base[..., 0:Hh, 0:Ww], base[..., 4 : Hh + 4, 2 : Ww + 2] * 0.8 + 0.1, torch.rand(1, 1, Hh, Ww, generator=g)), 1)
     i1 = torch.cat((base[..., 8 : Hh + 8, 16 : Ww + 16], base[..., 12 : Hh + 12, 6 : Ww + 6] * 0.8 + 0.1, torch.rand(1, 1, Hh, Ww, generator=g)), 1)
     images = torch.cat((i0, i1), 0).repeat(B, 1, 1, 1).contiguous().to(dev)  # [2B,3,H,W]: images 2b, 2b+1 form pair b
-    pairs = torch.tensor([[2 * b + a, 2 * b + 1 - a] for b in range(B) for a in (0, 1)], dtype=torch.int32, device=dev)
+    pairs = torch.tensor([[2 * b + 1 - a, 2 * b + a] for b in range(B) for a in (0, 1)], dtype=torch.int32, device=dev)  # (1, 0), (0, 1) per image pair
 
     model.conf["arithmetic"] = args.arith
 
@@ -405,7 +405,7 @@ def bench_dust3r(args, dev, rank, world):
                       "f16 operands (one MFMA product, 11-bit mantissa), f32 accumulate in the GEMMs and convolutions; attention in 3xf16 split (the reference config names bf16)"),
             "data": "synthetic",
             "config": {"workload": ("MASt3R = the same network with the catmlp+dpt head, then reciprocal descriptor matching; " if mast else "") + f"configs[4]: DUSt3R ViT-L/16 encoder (24 x 1024) + 2 x 12 x 768 cross-attention decoder + DPT point-map heads on synthetic {Ww}x{Hh} "
-                                   "pairs resident in HBM; one pair = the symmetrised call of duster.py (directed pairs (0,1) and (1,0), each image encoded once)",
+                                   "pairs resident in HBM; one pair = the symmetrised call of duster.py (directed pairs (1,0) and (0,1), each image encoded once)",
                        "pairs_per_step_per_gpu": B, "weights": "seeded random (imcui_hip/synth_weights.py), AsymmetricCroCo3DStereo architecture, 578 M parameters",
                        "mean_confidence": float(out["conf"].mean()),
                        **({"head": "catmlp+dpt, 24-d descriptors; matching: fast_reciprocal_NNs(subsample 2, dot, 10 rounds) on the device, 2000 matches kept",

@@ -5,7 +5,8 @@ Drop-in for imcui/hloc/matchers/duster.py: module name `duster`, same `default_c
 device, batch_size=1)` (:73) on the two directed pairs (image0, image1), (image1, image0) (`make_pairs(..., symmetrize=True)`,
 :70-72): `AsymmetricCroCo3DStereo` = ViT-L encoder + two-stream ViT-B decoder + DPT point-map heads, in libimcui_hip
 (imcui_hip_dust3r_forward).  `inference_output()` returns the dictionary upstream's `inference` returns -- `view1`, `view2`,
-`pred1 = {pts3d, conf}`, `pred2 = {pts3d_in_other_view, conf}`, batch entries (0 -> 1), (1 -> 0) -- so the host-side steps of
+`pred1 = {pts3d, conf}`, `pred2 = {pts3d_in_other_view, conf}`, batch entries in `make_pairs`' order: (image1, image0), then
+(image0, image1) (the 'complete' scene graph lists (i, j < i) first, `symmetrize` appends the swapped pairs) -- so the host-side steps of
 the wrapper consume it unchanged.  Every image is encoded once (upstream encodes both images again for the swapped pair).
 
 Host-side steps (duster.py:74-108): `global_aligner(mode=PairViewer)` (focal estimation + `cv2.solvePnPRansac`), confidence
@@ -72,7 +73,7 @@ class Duster(BaseModel):
         H, W = img0.shape[-2:]
         if H % 16 or W % 16:
             raise ValueError(f"DUSt3R needs image sizes that are multiples of the patch size 16 (the wrapper's preprocess rounds to it), got {W}x{H}")
-        out = self.forward_pairs(torch.cat((img0, img1), 0), [[0, 1], [1, 0]])
+        out = self.forward_pairs(torch.cat((img0, img1), 0), [[1, 0], [0, 1]])  # make_pairs' order: (image1, image0), (image0, image1)
         norm = [(img0 - 0.5) / 0.5, (img1 - 0.5) / 0.5]
         shape = torch.tensor([[H, W], [H, W]])
 
@@ -80,8 +81,8 @@ class Duster(BaseModel):
             return {"img": torch.cat((norm[a], norm[b]), 0), "true_shape": shape, "idx": [a, b], "instance": [str(a), str(b)]}
 
         return out, {
-            "view1": view(0, 1),
-            "view2": view(1, 0),
+            "view1": view(1, 0),
+            "view2": view(0, 1),
             "pred1": {"pts3d": out["pts3d"][0], "conf": out["conf"][0]},
             "pred2": {"pts3d_in_other_view": out["pts3d"][1], "conf": out["conf"][1]},
             "loss": None,

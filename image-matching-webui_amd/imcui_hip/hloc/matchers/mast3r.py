@@ -52,7 +52,8 @@ class Mast3r(Duster):
 
     def _forward(self, data):
         output = self.inference_output(data)
-        # the reference matches the descriptors of the SECOND directed pair (image1 as view 1, image0 as view 2), mast3r.py:61-64
+        # the reference matches the descriptors of the SECOND batch entry = the pair (image0 as view 1, image1 as view 2): mast3r.py:61-64
+        # -> keypoints0 are pixels of image0, keypoints1 of image1
         desc1, desc2 = output["pred1"]["desc"][1], output["pred2"]["desc"][1]
         mode = self.conf.get("matcher_arithmetic", "auto")
         split = backend.get_precision(desc1.device) == 1 if mode == "auto" else mode == "split"

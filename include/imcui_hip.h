@@ -276,7 +276,7 @@ size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim,
 size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);
 /* `AsymmetricCroCo3DStereo.forward(view1, view2)` for P directed pairs over NI images: images [dev, NI,3,H,W] in [0,1] (the
  * wrapper's mean = std = 0.5 normalisation, duster.py:60-64, is applied inside), H and W multiples of 16 (the patch size); pairs [dev, P,2] int32 =
- * (view-1 image, view-2 image) -- duster.py:70-72 asks for (0,1) and (1,0).  Every image is encoded once.  Outputs, view-major:
+ * (view-1 image, view-2 image) -- duster.py:70-72 asks for (1,0) then (0,1) (`make_pairs`' order).  Every image is encoded once.  Outputs, view-major:
  * pts3d [dev, 2,P,H,W,3] (view 1: `pts3d`; view 2: `pts3d_in_other_view`, i.e. in view 1's frame), conf [dev, 2,P,H,W]; with
  * desc_dim > 0 also desc [dev, 2,P,H,W,desc_dim] (unit-norm local descriptors: MLP on [encoder | decoder] tokens, pixel shuffle
  * 16, `desc / |desc|`) and desc_conf [dev, 2,P,H,W] = exp(.) (mast3r.py:61-64 reads `pred1["desc"]`, `pred2["desc"]`); NULL otherwise.

@@ -233,10 +233,13 @@ class DUSt3ROracle:
 
     def inference_symmetrized(self, image0, image1, return_intermediates=False):
         """What duster.py:60-73 hands to the global aligner: images in [0, 1], the two directed pairs collated
-        -> {'pred1': {pts3d, conf}, 'pred2': {pts3d_in_other_view, conf}} with batch entries (0 -> 1), (1 -> 0)."""
+        -> {'pred1': {pts3d, conf}, 'pred2': {pts3d_in_other_view, conf}} with the batch entries in upstream's order: `make_pairs(images,
+        scene_graph="complete", symmetrize=True)` lists (image1, image0) first (`for i in range(n): for j in range(i)`), then the
+        swapped pairs, so entry 0 = (image1 as view 1, image0 as view 2) and entry 1 = (image0, image1) -- the entry mast3r.py:61-64 reads
+        its descriptors from (`pred1["desc"][1]` = image0's, `pred2["desc"][1]` = image1's)."""
         n0, n1 = (image0 - 0.5) / 0.5, (image1 - 0.5) / 0.5
         out = []
-        for a, b in ((n0, n1), (n1, n0)):  # batch_size = 1: one forward per directed pair
+        for a, b in ((n1, n0), (n0, n1)):  # batch_size = 1: one forward per directed pair, in make_pairs' order
             out.append(self.forward(a, b, return_intermediates))
         keys1 = ("pts3d", "conf")
         keys2 = ("pts3d_in_other_view", "conf")

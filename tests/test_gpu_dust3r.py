@@ -42,7 +42,7 @@ def _compare(cfg, h, w, seed=0, tol=2e-4, arithmetic="fp32", out_tol=1e-4):
     sd, model = _model(cfg)
     i0, i1 = _images(h, w, seed)
     imgs = torch.cat((i0, i1), 0).cuda()
-    pairs = [[0, 1], [1, 0]]
+    pairs = [[1, 0], [0, 1]]  # the order of upstream's make_pairs (and of the oracle's passes)
     model.conf["arithmetic"] = arithmetic
     try:
         out = model.forward_pairs(imgs, pairs, dump=True)
@@ -51,7 +51,7 @@ def _compare(cfg, h, w, seed=0, tol=2e-4, arithmetic="fp32", out_tol=1e-4):
     torch.cuda.synchronize()
     dump = model._impl.last_dump.cpu()
     ref = DUSt3ROracle(sd, cfg).inference_symmetrized(i0, i1, return_intermediates=True)
-    passes = ref["_passes"]  # [(res1, res2) of (0 -> 1), of (1 -> 0)]
+    passes = ref["_passes"]  # [(res1, res2) of the pair (image1, image0), of (image0, image1)]
     E, D, ne, nd = cfg["enc_dim"], cfg["dec_dim"], cfg["enc_depth"], cfg["dec_depth"]
     NI, P = 2, 2
     hg, wg = h // 16, w // 16
@@ -76,11 +76,11 @@ def _compare(cfg, h, w, seed=0, tol=2e-4, arithmetic="fp32", out_tol=1e-4):
         if not (err < t * max(mag, 1e-6)) or not torch.isfinite(got).all():
             bad.append(report[-1])
 
-    # encoder: image 0 = view 1 of pass 0, image 1 = view 2 of pass 0
-    enc_ref = [torch.cat((a, b), 0) for a, b in zip(passes[0][0]["_enc_layers"], passes[0][1]["_enc_layers"])]
+    # encoder: image 0 = view 2 of pass 0, image 1 = view 1 of pass 0
+    enc_ref = [torch.cat((a, b), 0) for a, b in zip(passes[0][1]["_enc_layers"], passes[0][0]["_enc_layers"])]
     for i in range(ne + 1):
         check(f"encoder state {i}", take((NI, R, E))[:, :T], enc_ref[i])
-    check("encoder output (enc_norm)", take((NI, R, E))[:, :T], torch.cat((passes[0][0]["_dec"][0], passes[0][1]["_dec"][0]), 0))
+    check("encoder output (enc_norm)", take((NI, R, E))[:, :T], torch.cat((passes[0][1]["_dec"][0], passes[0][0]["_dec"][0]), 0))
     # decoder streams: [view 1 of pass 0, view 1 of pass 1 | view 2 of pass 0, view 2 of pass 1]
     take((2 * P, R, D))  # embedded tokens (checked through block 1)
     for i in range(1, nd + 1):

@@ -245,3 +245,50 @@ def test_cross_attention_against_torch_multihead_attention():
         want = mha(x, y, y, need_weights=False)[0]
     got = o._cross_attn(x, y, zx, zy, p)
     assert (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_plugin_host_logic_on_a_mocked_device(monkeypatch):
+    """The duster / mast3r plugins' host side with the device call replaced by the oracle (CPU only): `inference_output` lists the
+    directed pairs in `make_pairs`' order -- (image1, image0) first, then (image0, image1) -- and `Mast3r._forward` matches the
+    descriptors of the (image0, image1) entry, so keypoints0 are pixels of image0 and keypoints1 of image1 (mast3r.py:61-96)."""
+    import numpy as np
+
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.mast3r import Mast3r
+    from oracle.dust3r import MASt3ROracle, fast_reciprocal_nns, nn_dot_first_argmax
+
+    cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4, "desc_dim": 24}
+    sd = dust3r_state_dict(21, cfg)
+    ora = MASt3ROracle(sd, cfg)
+
+    def fake_forward(self, packed, net_cfg, images, pairs, dump=False, arith=0):
+        norm = (images - 0.5) / 0.5
+        res = [ora.forward(norm[a : a + 1], norm[b : b + 1]) for a, b in pairs]
+        out = {"pts3d": torch.stack([torch.cat([r[0]["pts3d"] for r in res]), torch.cat([r[1]["pts3d_in_other_view"] for r in res])]),
+               "conf": torch.stack([torch.cat([r[0]["conf"] for r in res]), torch.cat([r[1]["conf"] for r in res])]),
+               "desc": torch.stack([torch.cat([r[0]["desc"] for r in res]), torch.cat([r[1]["desc"] for r in res])]),
+               "desc_conf": torch.stack([torch.cat([r[0]["desc_conf"] for r in res]), torch.cat([r[1]["desc_conf"] for r in res])])}
+        return out
+
+    monkeypatch.setattr(backend.DUSt3RHIP, "forward", fake_forward)
+    monkeypatch.setattr(backend, "nn_argmax", lambda q, db, return_best=False, split=False: nn_dot_first_argmax(q, db))
+    monkeypatch.setattr(backend, "get_precision", lambda dev: 1)
+    model = Mast3r({"state_dict": sd, "max_keypoints": 50}).eval()
+    g = torch.Generator().manual_seed(22)
+    i0, i1 = torch.rand(1, 3, 48, 64, generator=g), torch.rand(1, 3, 48, 64, generator=g)
+    data = {"image0": i0, "image1": i1}
+    out = model.inference_output(data)
+    ref = ora.inference_symmetrized(i0, i1)
+    for pred, keys in (("pred1", ("pts3d", "conf", "desc", "desc_conf")), ("pred2", ("pts3d_in_other_view", "conf", "desc", "desc_conf"))):
+        for k in keys:
+            assert torch.equal(out[pred][k], ref[pred][k]), (pred, k)
+    assert out["view1"]["idx"] == [1, 0] and out["view2"]["idx"] == [0, 1]
+    assert torch.equal(out["view1"]["img"][1], ((i0 - 0.5) / 0.5)[0])  # entry 1: image0 is view 1
+    # the matcher: image0's descriptors as seen in the pair (image0, image1), against image1's
+    r1, r2 = ora.forward((i0 - 0.5) / 0.5, (i1 - 0.5) / 0.5)
+    k0, k1 = fast_reciprocal_nns(r1["desc"][0], r2["desc"][0], subsample=2)
+    if len(k0) > 50:
+        keep = np.round(np.linspace(0, len(k0) - 1, 50)).astype(int)
+        k0, k1 = k0[keep], k1[keep]
+    pred = model(data)
+    assert len(k0) > 5 and torch.equal(pred["keypoints0"], k0) and torch.equal(pred["keypoints1"], k1)
