@@ -620,7 +620,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
     ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "dust3r", "mast3r", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
-                         "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs")
+                         "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs; eloftr = EfficientLoFTR 640x480; "
+                         "dust3r = configs[4] DUSt3R pair network 512x512; mast3r = the same network with the descriptor head + reciprocal matching")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
     ap.add_argument("--size", type=int, nargs=2, default=None, metavar=("H", "W"), help="loftr image size (default 1024 1024)")
     ap.add_argument("--nn-arith", default="auto", choices=["auto", "fp32", "split"],
