@@ -80,6 +80,27 @@ if os.path.exists(sqp):
               open(os.path.join(P, f"{tag}_pmc_sq.json"), "w"), indent=1)
     for k, v in sorted(sq.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])[:6]:
         print(f"{k[:50]:50s} mfma_busy {v['mfma_busy_frac']:.3f} wait_any {v['wait_any_frac']:.2f} wait_inst {v['wait_inst_frac']:.2f}")
+# the same SQ pass on the DUSt3R workload; its GEMM launches are grouped by grid size (= shape class: encoder / decoder, N, merged sides)
+dsq = os.path.join(F, "pmc_dust3r_SQ", "dust3r_counter_collection.csv")
+if os.path.exists(dsq):
+    by = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(dsq)):
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        if k.startswith("gemm_split_kernel"):
+            k = f"{k} grid {r['Grid_Size']}"
+        by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dq = {}
+    for k, c in by.items():
+        g = lambda n: sum(c.get(n, [0.0])) / max(len(c.get(n, [0.0])), 1)  # noqa: E731
+        kc = g("SQ_BUSY_CYCLES") / 32.0
+        wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+        dq[k] = {"launches": len(c["SQ_BUSY_CYCLES"]), "kernel_cycles": kc, "mfma_busy_frac": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / max(kc, 1.0),
+                 "valu_active_frac_of_wave_cycles": g("SQ_ACTIVE_INST_VALU") / wc, "wait_any_frac": g("SQ_WAIT_ANY") / wc,
+                 "wait_inst_frac": g("SQ_WAIT_INST_ANY") / wc, "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT")}
+    json.dump({"note": "rocprofv3 --pmc SQ_* (one pass), bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 8 pairs per step, 3 x f16 split "
+                       "arithmetic); kernel_cycles = SQ_BUSY_CYCLES / 32 shader engines, mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; per-launch "
+                       "averages; GEMM launches grouped by grid size (= shape class)", "kernels": dq},
+              open(os.path.join(P, f"{tag}_pmc_sq_dust3r.json"), "w"), indent=1)
 for opt in ("adaptive", "b1", "adaptive_b1_eager", "adaptive_b1_graph", "adaptive_b4_eager", "adaptive_b4_graph"):  # operating points beside the headline line
     if os.path.exists(os.path.join(F, f"bench_splg_{opt}.json.log")):
         shutil.copy(os.path.join(F, f"bench_splg_{opt}.json.log"), os.path.join(P, f"{tag}_bench_splg_{opt}.json.log"))
