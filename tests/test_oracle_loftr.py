@@ -1,7 +1,9 @@
-"""LoFTR oracle self-consistency on CPU (parity unpinned: no reference implementation is available).
+"""LoFTR oracle on CPU (parity unpinned: no reference implementation of the whole network is available).
 
-Property checked: two crops of one image offset by a multiple of the coarse stride must match
-cell-to-cell with the known displacement (a wrong unfold / transposition / image swap breaks it).
+End to end: two crops of one image offset by a multiple of the coarse stride must match cell-to-cell with the known displacement
+(a wrong unfold / transposition / image swap breaks it).  Components: the ResNet block against transformers' ResNetBasicLayer, linear
+attention against its quadratic formulation, fine matching against the copy of kornia's `spatial_expectation2d` in transformers,
+coarse matching's border / mutual-maximum logic against transformers' copy of LoFTR's `mask_border`.
 """
 import torch
 
@@ -26,3 +28,100 @@ def test_loftr_oracle_recovers_known_translation():
     assert (out["keypoints1"] % 8 == 0).all()
     top = LoFTROracle(sd, {"match_threshold": 0.01, "max_keypoints": 20})({"image0": img0, "image1": img1})
     assert len(top["scores"]) == 20 and torch.all(top["scores"][:-1] >= top["scores"][1:])  # top-k by confidence
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Component checks against independent formulations available in the container (the network as a whole stays unpinned).
+import math
+
+import pytest
+import torch.nn.functional as F
+
+SD = None
+
+
+def _sd():
+    global SD
+    if SD is None:
+        SD = loftr_state_dict(3, structured=False)
+    return SD
+
+
+def test_basic_block_against_the_transformers_resnet_layer():
+    """ResNetFPN's BasicBlock (conv3x3-BN-ReLU, conv3x3-BN, 1x1-conv-BN shortcut when the shape changes, ReLU after the sum) is
+    transformers' ResNetBasicLayer: same tensors, eval-mode BatchNorm, same output -- for a stride-2 and a stride-1 block."""
+    resnet = pytest.importorskip("transformers.models.resnet.modeling_resnet")
+    sd = _sd()
+    o = LoFTROracle(sd)
+    g = torch.Generator().manual_seed(1)
+    for p, cin, cout, stride in (("backbone.layer2.0", 128, 196, 2), ("backbone.layer2.1", 196, 196, 1)):
+        layer = resnet.ResNetBasicLayer(cin, cout, stride=stride).eval()
+        tens = {}
+        for k, (conv, bn) in enumerate(((".conv1", ".bn1"), (".conv2", ".bn2"))):
+            tens[f"layer.{k}.convolution.weight"] = sd[p + conv + ".weight"]
+            for t in ("weight", "bias", "running_mean", "running_var"):
+                tens[f"layer.{k}.normalization.{t}"] = sd[p + bn + "." + t]
+        if stride != 1 or cin != cout:
+            tens["shortcut.convolution.weight"] = sd[p + ".downsample.0.weight"]
+            for t in ("weight", "bias", "running_mean", "running_var"):
+                tens[f"shortcut.normalization.{t}"] = sd[p + ".downsample.1." + t]
+        layer.load_state_dict(tens, strict=False)  # num_batches_tracked stays at its default
+        x = torch.randn(2, cin, 12, 16, generator=g)
+        with torch.no_grad():
+            want = layer(x.clone())
+        got = o._block(x, p, stride)
+        assert got.shape == want.shape and (got - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_linear_attention_is_normalised_kernel_attention():
+    """`LinearAttention` (Q' (K'^T V) / (Q' sum K')) equals the quadratic formulation out_l = sum_s k(q_l, k_s) v_s / sum_s k(q_l, k_s) with
+    k(q, k) = (elu(q) + 1) . (elu(k) + 1), per head -- evaluated here the slow way through an encoder layer's projections."""
+    sd = _sd()
+    o = LoFTROracle(sd)
+    g = torch.Generator().manual_seed(2)
+    x, src = torch.randn(1, 40, 256, generator=g), torch.randn(1, 56, 256, generator=g)
+    p = "loftr_coarse.layers.1"
+    got = o._encoder_layer(p, x, src, 8)
+    q = F.linear(x, sd[p + ".q_proj.weight"]).view(1, 40, 8, 32)
+    k = F.linear(src, sd[p + ".k_proj.weight"]).view(1, 56, 8, 32)
+    v = F.linear(src, sd[p + ".v_proj.weight"]).view(1, 56, 8, 32)
+    kern = torch.einsum("nlhd,nshd->nhls", F.elu(q) + 1, F.elu(k) + 1).double()
+    msg = (torch.einsum("nhls,nshd->nlhd", kern, v.double()) / (kern.sum(-1).permute(0, 2, 1)[..., None] + 1e-6)).float()
+    msg = F.linear(msg.reshape(1, 40, 256), sd[p + ".merge.weight"])
+    msg = F.layer_norm(msg, (256,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+    msg = F.linear(F.relu(F.linear(torch.cat([x, msg], 2), sd[p + ".mlp.0.weight"])), sd[p + ".mlp.2.weight"])
+    want = x + F.layer_norm(msg, (256,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+    assert (got - want).abs().max().item() < 2e-4 * want.abs().max().item()
+
+
+def test_fine_matching_expectation_against_the_kornia_copy_in_transformers():
+    """FineMatching: soft-max of the centre-vs-window similarities / sqrt(C), then kornia's `spatial_expectation2d` -- the copy of that
+    kornia function shipped in transformers' EfficientLoFTR port gives the same sub-pixel offsets."""
+    elo = pytest.importorskip("transformers.models.efficientloftr.modeling_efficientloftr")
+    o = LoFTROracle(_sd())
+    g = torch.Generator().manual_seed(3)
+    M, C = 37, 128
+    f0, f1 = torch.randn(M, 25, C, generator=g), torch.randn(M, 25, C, generator=g)
+    cm = {"mkpts0_c": torch.rand(M, 2, generator=g) * 100, "mkpts1_c": torch.rand(M, 2, generator=g) * 100, "mconf": torch.rand(M, generator=g)}
+    k0, k1 = o.fine_matching(f0, f1, cm, scale=2.0)
+    heat = torch.softmax(torch.einsum("mc,mrc->mr", f0[:, 12], f1) / C**0.5, 1).view(1, M, 5, 5)
+    coords = elo.spatial_expectation2d(heat, True)[0]  # [M, 2] (x, y) in [-1, 1]
+    assert torch.equal(k0, cm["mkpts0_c"])
+    assert (k1 - (cm["mkpts1_c"] + coords * 2 * 2.0)).abs().max().item() < 1e-4
+
+
+def test_coarse_matching_border_and_mutual_maximum():
+    """CoarseMatching on features built so that cell i of image 0 matches cell i of image 1 with confidence ~1: the match list is
+    exactly the cells inside the 2-cell border (transformers' copy of LoFTR's `mask_border` on the 4-D grid), in row-major order,
+    with pixel coordinates = grid x 8."""
+    elo = pytest.importorskip("transformers.models.efficientloftr.modeling_efficientloftr")
+    o = LoFTROracle(_sd())
+    h, w = 7, 9
+    L = h * w
+    f = F.pad(torch.eye(L), (0, 256 - L)) * 16.0 * math.sqrt(12.0)  # sim = 12 on the diagonal / temperature 0.1 -> soft-max ~ 1
+    cm = o.coarse_matching(f[None], f[None], (h, w), (h, w), (h * 8, w * 8), 0.2)
+    mask = torch.ones(1, h, w, h, w, dtype=torch.bool)
+    mask = elo.mask_border(mask, 2, False)
+    inner = mask[0].reshape(L, L).diagonal().nonzero()[:, 0]
+    assert torch.equal(cm["i_ids"], inner) and torch.equal(cm["j_ids"], inner) and (cm["mconf"] > 0.99).all()
+    assert torch.equal(cm["mkpts0_c"], torch.stack([inner % w, inner // w], 1) * 8.0)
