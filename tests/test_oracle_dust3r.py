@@ -292,3 +292,28 @@ def test_plugin_host_logic_on_a_mocked_device(monkeypatch):
         k0, k1 = k0[keep], k1[keep]
     pred = model(data)
     assert len(k0) > 5 and torch.equal(pred["keypoints0"], k0) and torch.equal(pred["keypoints1"], k1)
+
+
+def test_decoder_is_symmetric_under_exchanging_views_and_weight_sets():
+    """Both decoder stacks read the OTHER view's tokens as they were BEFORE the block.  Then exchanging the two images together with
+    `dec_blocks` <-> `dec_blocks2` and `downstream_head1` <-> `downstream_head2` exchanges the outputs exactly; an implementation in
+    which the second stack saw the first stack's already-updated tokens would break this."""
+    sd = dust3r_state_dict(17, CFG)
+    swapped = {}
+    for k, v in sd.items():
+        if k.startswith("dec_blocks2."):
+            swapped["dec_blocks." + k[len("dec_blocks2.") :]] = v
+        elif k.startswith("dec_blocks."):
+            swapped["dec_blocks2." + k[len("dec_blocks.") :]] = v
+        elif k.startswith("downstream_head1."):
+            swapped["downstream_head2." + k[len("downstream_head1.") :]] = v
+        elif k.startswith("downstream_head2."):
+            swapped["downstream_head1." + k[len("downstream_head2.") :]] = v
+        else:
+            swapped[k] = v
+    g = torch.Generator().manual_seed(18)
+    a, b = torch.randn(1, 3, 48, 64, generator=g), torch.randn(1, 3, 48, 64, generator=g)
+    r1, r2 = DUSt3ROracle(sd, CFG).forward(a, b)
+    s1, s2 = DUSt3ROracle(swapped, CFG).forward(b, a)
+    assert torch.allclose(r1["pts3d"], s2["pts3d_in_other_view"], rtol=1e-5, atol=1e-6) and torch.allclose(r2["pts3d_in_other_view"], s1["pts3d"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(r1["conf"], s2["conf"], rtol=1e-5) and torch.allclose(r2["conf"], s1["conf"], rtol=1e-5)
