@@ -142,14 +142,15 @@ class ELoFTROracle:
         conf = F.softmax(sim, 1) * F.softmax(sim, 2)
         mask = (conf > thr).view(n, h, w, h1, w1).clone()
         b = self.border_rm
-        mask[:, :b] = False
-        mask[:, :, :b] = False
-        mask[:, :, :, :b] = False
-        mask[:, :, :, :, :b] = False
-        mask[:, -b:] = False
-        mask[:, :, -b:] = False
-        mask[:, :, :, -b:] = False
-        mask[:, :, :, :, -b:] = False
+        if b > 0:
+            mask[:, :b] = False
+            mask[:, :, :b] = False
+            mask[:, :, :, :b] = False
+            mask[:, :, :, :, :b] = False
+            mask[:, -b:] = False
+            mask[:, :, -b:] = False
+            mask[:, :, :, -b:] = False
+            mask[:, :, :, :, -b:] = False
         mask = mask.view(n, h * w, h1 * w1)
         mask = mask * (conf == conf.max(dim=2, keepdim=True)[0]) * (conf == conf.max(dim=1, keepdim=True)[0])
         mask_v, all_j = mask.max(dim=2)

@@ -64,3 +64,48 @@ def test_dual_softmax_oracle_matches_reference(path):
 
 def test_ds_golden_present():
     assert len(ds_golden_files()) >= 6
+
+
+def coarse_golden_files():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return sorted(glob.glob(os.path.join(here, "coarse_*.npz")))
+
+
+@pytest.mark.parametrize("family", ["loftr", "eloftr"])
+@pytest.mark.parametrize("path", coarse_golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_coarse_matching_rule_matches_reference_dual_softmax(path, family):
+    """tests/golden/coarse_*.npz: the REFERENCE's own `dual_softmax_matcher` (imcui/hloc/matchers/dual_softmax.py:8-41) run on LoFTR-style
+    coarse features with `normalize=False, inv_temperature = 1 / (C * temperature)` (make_coarse_golden.py).  The dual-softmax
+    confidence, the mutual-maximum test and the threshold of the LoFTR / EfficientLoFTR oracles' coarse matching (border removal
+    switched off: it is not part of the reference function) must give the same matches and confidences."""
+    torch.set_num_threads(1)
+    z = np.load(path)
+    f0, f1 = torch.from_numpy(z["feat0"]), torch.from_numpy(z["feat1"])
+    (h0, w0), (h1, w1) = z["grid0"].tolist(), z["grid1"].tolist()
+    thr = float(z["threshold"])
+    if family == "loftr":
+        from imcui_hip.synth_weights import loftr_state_dict
+        from oracle.loftr import LoFTROracle
+
+        o = LoFTROracle(loftr_state_dict(0))
+        o.border_rm, o.temperature = 0, float(z["temperature"])
+        cm = o.coarse_matching(f0, f1, (h0, w0), (h1, w1), (h0 * 8, w0 * 8), thr)
+    else:
+        from imcui_hip.synth_weights import eloftr_state_dict
+        from oracle.eloftr import ELoFTROracle
+
+        o = ELoFTROracle(eloftr_state_dict(0))
+        o.border_rm, o.temperature = 0, float(z["temperature"])
+        C = f0.shape[-1]
+        cm = o.coarse_matching(f0.transpose(1, 2).reshape(1, C, h0, w0), f1.transpose(1, 2).reshape(1, C, h1, w1), (h0 * 8, w0 * 8), thr)
+    m0 = torch.full((f0.shape[1],), -1, dtype=torch.int64)
+    s0 = torch.zeros(f0.shape[1], dtype=torch.float64)
+    m0[cm["i_ids"]] = cm["j_ids"]
+    s0[cm["i_ids"]] = cm["mconf"].double()
+    assert (z["matches0"][0] > -1).sum() >= 10
+    assert np.array_equal(m0.numpy(), z["matches0"][0])
+    assert np.abs(s0.numpy() - z["scores0"][0]).max() <= 1e-6
+
+
+def test_coarse_golden_present():
+    assert len(coarse_golden_files()) >= 3
