@@ -109,3 +109,22 @@ def test_coarse_matching_rule_matches_reference_dual_softmax(path, family):
 
 def test_coarse_golden_present():
     assert len(coarse_golden_files()) >= 3
+
+
+def test_reciprocal_matcher_from_every_pixel_equals_reference_mutual_nn():
+    """MASt3R's `fast_reciprocal_NNs` started from EVERY position (subsample 1) returns exactly the mutual nearest neighbours: a chain
+    a -> nn(a) -> nn(nn(a)) closes at once on a mutual pair and only on one.  The reference's own mutual-NN matcher
+    (imcui/hloc/matchers/nearest_neighbor.py, golden vectors nn_mutual.npz) therefore pins the oracle's restatement of the matcher."""
+    from oracle.dust3r import fast_reciprocal_nns
+
+    torch.set_num_threads(1)
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "nn_mutual.npz"))
+    d0, d1 = torch.from_numpy(z["descriptors0"]), torch.from_numpy(z["descriptors1"])  # [B, D, N], [B, D, M]
+    for b in range(d0.shape[0]):
+        a = d0[b].t().reshape(15, 20, -1)  # 300 descriptors as a 15 x 20 map
+        c = d1[b].t().reshape(14, 20, -1)  # 280 as 14 x 20
+        xy1, xy2 = fast_reciprocal_nns(a, c, subsample=1)
+        got = {(int(y) * 20 + int(x), int(v) * 20 + int(u)) for (x, y), (u, v) in zip(xy1.tolist(), xy2.tolist())}
+        want = {(i, int(j)) for i, j in enumerate(z["matches0"][b]) if j > -1}
+        assert len(want) > 100 and got == want
