@@ -187,6 +187,22 @@ extern "C" int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_d
     return du_vec_len(c, i);
 }
 
+// float offsets of layer i inside the packed buffer (inspection / tests): bias [N], the two f16 planes, the 2^-e scale; kind = 0
+// fragment-major GEMM planes ([ceil(N/32)][K/16][2][32][8] halves), 1 = planes of the 3x3 patch-staging convolution kernel
+extern "C" int imcui_hip_dust3r_layer_offsets(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i, size_t* bias,
+                                              size_t* plane_hi, size_t* plane_lo, size_t* scale, int* kind) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    if (!du_cfg_ok(c) || i < 0 || i >= du_nlayers(c) || !bias || !plane_hi || !plane_lo || !scale || !kind) return IMCUI_ERR_ARG;
+    const DuLayout l = du_layout(c);
+    int N, K;
+    du_shape(c, i, &N, &K, kind);
+    *bias = l.b[i];
+    *plane_hi = l.wh[i];
+    *plane_lo = l.wl[i];
+    *scale = l.ws[i];
+    return IMCUI_OK;
+}
+
 // w[i]: [N][K] f32 (convolutions in the implicit-GEMM order [Cout][tap][Cin], transposed convolutions as [(dy, dx, cout)][cin]),
 // b[i]: [N] or null (zero), vec[i]: the f32 vectors in the order above.  The layers are split on a few host threads.
 extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* const* w,

@@ -634,16 +634,11 @@ def dust3r_cfg_of(state_dict: dict) -> dict:
     }
 
 
-def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
-    """`AsymmetricCroCo3DStereo` state dict (head_type 'dpt', upstream names; imcui/hloc/matchers/duster.py:37) -> (packed
-    float32 host buffer, cfg).  Layer order and layouts: include/imcui_hip.h, the DUSt3R section."""
-    lib = load_library()
+def dust3r_matrices(state_dict: dict):
+    """The matrices [N, K], biases and f32 vectors of a DUSt3R / MASt3R state dict in the order of the C layer table (what
+    `pack_dust3r` hands to imcui_hip_dust3r_pack_weights) -> (cfg, matrices, biases, vectors)."""
     sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
     cfg = dust3r_cfg_of(sd)
-    c4 = _dust3r_c5(cfg)
-    nl = lib.imcui_hip_dust3r_num_layers(*c4)
-    if nl == 0:
-        raise ImcuiHipError(f"DUSt3R configuration {cfg} is not supported (dims multiples of 64 up to 1024, dec_depth a multiple of 4)")
     ws, bs, vecs = [], [], []
 
     def lin(name):
@@ -712,6 +707,18 @@ def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
         p = f"downstream_head{hd}.dpt.head.4"
         vecs.extend([sd[p + ".weight"].reshape(4, 128).contiguous(), sd[p + ".bias"]])
     vecs.append(1.0 / (100.0 ** (torch.arange(0, 32, 2, dtype=torch.float32) / 32)))  # RoPE2D(freq=100), D = 32 per axis
+    return cfg, ws, bs, vecs
+
+
+def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
+    """`AsymmetricCroCo3DStereo` state dict (head_type 'dpt', upstream names; imcui/hloc/matchers/duster.py:37) -> (packed
+    float32 host buffer, cfg).  Layer order and layouts: include/imcui_hip.h, the DUSt3R section."""
+    lib = load_library()
+    cfg, ws, bs, vecs = dust3r_matrices(state_dict)
+    c4 = _dust3r_c5(cfg)
+    nl = lib.imcui_hip_dust3r_num_layers(*c4)
+    if nl == 0:
+        raise ImcuiHipError(f"DUSt3R configuration {cfg} is not supported (dims multiples of 64 up to 1024, dec_depth a multiple of 4)")
     nv = lib.imcui_hip_dust3r_num_vectors(*c4)
     assert len(ws) == nl and len(vecs) == nv, (len(ws), nl, len(vecs), nv)
     N, K = C.c_int(), C.c_int()

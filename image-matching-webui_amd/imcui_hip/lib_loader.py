@@ -111,6 +111,7 @@ SIGNATURES = {
     "imcui_hip_dust3r_num_vectors": (C.c_int, [C.c_int] * 5),
     "imcui_hip_dust3r_layer_shape": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "imcui_hip_dust3r_vector_len": (C.c_int, [C.c_int] * 6),
+    "imcui_hip_dust3r_layer_offsets": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_size_t)] * 4 + [C.POINTER(C.c_int)]),
     "imcui_hip_dust3r_pack_weights": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "imcui_hip_dust3r_workspace_bytes": (C.c_size_t, [C.c_int] * 9),
     "imcui_hip_dust3r_dump_floats": (C.c_size_t, [C.c_int] * 9),

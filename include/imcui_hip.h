@@ -270,6 +270,10 @@ int imcui_hip_dust3r_num_layers(int enc_dim, int enc_depth, int dec_dim, int dec
 int imcui_hip_dust3r_num_vectors(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim);
 int imcui_hip_dust3r_layer_shape(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i, int* N, int* K);
 int imcui_hip_dust3r_vector_len(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i);
+/* float offsets of layer i inside the packed buffer (inspection / tests): bias, f16 hi / lo planes, 2^-e scale; kind 0 = fragment-major
+ * GEMM planes, 1 = 3x3 convolution planes */
+int imcui_hip_dust3r_layer_offsets(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int i, size_t* bias, size_t* plane_hi,
+                                   size_t* plane_lo, size_t* scale, int* kind);
 int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* const* w,
                                   const float* const* b, const float* const* vec, float* packed);
 size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);

@@ -317,3 +317,52 @@ def test_decoder_is_symmetric_under_exchanging_views_and_weight_sets():
     s1, s2 = DUSt3ROracle(swapped, CFG).forward(b, a)
     assert torch.allclose(r1["pts3d"], s2["pts3d_in_other_view"], rtol=1e-5, atol=1e-6) and torch.allclose(r2["pts3d_in_other_view"], s1["pts3d"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(r1["conf"], s2["conf"], rtol=1e-5) and torch.allclose(r2["conf"], s1["conf"], rtol=1e-5)
+
+
+def test_packed_gemm_planes_reconstruct_the_state_dict():
+    """Every GEMM layer of the packed DUSt3R / MASt3R buffer, read back through imcui_hip_dust3r_layer_offsets: (hi + lo) x scale in the
+    fragment-major order [ceil(N/32)][K/16][2][32][8] is the matrix the packer was given (to 2^-21 of its largest entry), the bias
+    follows, and the scale of a `dec_blocks2` layer also sits right behind its `dec_blocks` twin's (one launch serves both sides)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from imcui_hip.backend import dust3r_matrices, pack_dust3r
+    from imcui_hip.lib_loader import load_library
+
+    lib = load_library()
+    cfg = {"enc_dim": 128, "enc_depth": 2, "dec_dim": 64, "dec_depth": 4, "desc_dim": 24}
+    sd = dust3r_state_dict(31, cfg)
+    packed, c = pack_dust3r(sd)
+    _, ws, bs, _ = dust3r_matrices(sd)
+    c5 = (128, 2, 64, 4, 24)
+    raw = packed.numpy()
+    halves = raw.view(np.float16)
+    off = [C.c_size_t() for _ in range(4)]
+    kind = C.c_int()
+    scales = {}
+    checked = 0
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        assert lib.imcui_hip_dust3r_layer_offsets(*c5, i, *[C.byref(o) for o in off], C.byref(kind)) == 0
+        ob, oh, ol, osc = (o.value for o in off)
+        N, K = w.shape
+        scales[i] = raw[osc]
+        if b is not None:
+            assert np.array_equal(raw[ob : ob + N], b.numpy())
+        if kind.value != 0:
+            continue
+        nfr = (N + 31) // 32
+        n = nfr * 32 * K
+        rec = (halves[2 * oh : 2 * oh + n].astype(np.float64) + halves[2 * ol : 2 * ol + n].astype(np.float64)) * float(raw[osc])
+        full = rec.reshape(nfr, K // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(nfr * 32, K)
+        assert np.abs(full[:N] - w.numpy().astype(np.float64)).max() <= np.abs(w.numpy()).max() * 2.0**-21, i
+        assert np.all(full[N:] == 0.0)
+        checked += 1
+    assert checked > 40
+    # decoder twins: layer index of (side 0, block i, j) = 2 + 4 enc_depth + 7 i + j, side 1 = + 7 dec_depth
+    base, nd = 2 + 4 * 2, 4
+    for i in range(nd):
+        for j in range(7):
+            l0 = base + 7 * i + j
+            assert lib.imcui_hip_dust3r_layer_offsets(*c5, l0, *[C.byref(o) for o in off], C.byref(kind)) == 0
+            assert raw[off[3].value + 1] == scales[l0 + 7 * nd]
