@@ -9,6 +9,8 @@
 // touch only that lane (plus one cross-half exchange), and the S^T accumulator registers are
 // already the B operand of the second product (its k index = key = the register's row).
 // K/V tiles of 64 keys are prefetched through registers while the previous tile is multiplied.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "attention.h"
@@ -236,7 +238,11 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     return (const void*)((size_t)lo32 | ((size_t)hi32 << 32));
 }
 
-template <bool L2D>
+// VAR (IMCUI_ATTN_VARIANT, A/B runs): wave priority around the two MFMA clusters of a key tile.  Two workgroups share a CU,
+// so every SIMD holds two waves that are in different phases most of the time; priority decides whose instruction issues when
+// both are ready (guide T5).  0: none; 1: the K.Q^T and V^T.P^T clusters at priority 1, the soft-max at 0; 2: only V^T.P^T
+// raised; 3: the soft-max raised instead.
+template <bool L2D, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         // fragments; kept in registers across tiles, rewritten only when the reference moves): the MFMAs deliver the
         // exponent directly
         f32x16 s[2];
+        if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -378,6 +385,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                 s[f] = mfma16(ah, qh[st], s[f]);
             }
         }
+        if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
+        if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(1);
         if (TAIL) {  // only the last tile can hold keys past the sequence end
 #pragma unroll
             for (int f = 0; f < 2; ++f)
@@ -472,6 +481,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             l_run += (la[0] + la[1]) + (lb[0] + lb[1]);
         }
         // step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
+        if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
+        if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -491,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                     o[df] = mfma16(vh, ph, o[df]);
                 }
             }
+        if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(0);
     };
 
     const int ntile = (nk + KT - 1) / KT;
@@ -550,10 +562,19 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if ((p.heads * p.nseq) % 8 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention: heads*nseq=%d must be a multiple of 8", p.heads * p.nseq);
     dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
-    if (h->precision == 1 && p.log2_domain)
-        hipLaunchKernelGGL(attn_split_kernel<true>, grid, dim3(256), 0, stream, p);
-    else if (h->precision == 1)
-        hipLaunchKernelGGL(attn_split_kernel<false>, grid, dim3(256), 0, stream, p);
+    if (h->precision == 1 && p.log2_domain) {
+        const char* ve = getenv("IMCUI_ATTN_VARIANT");
+        const int var = ve ? atoi(ve) : 0;
+        if (var == 1)
+            hipLaunchKernelGGL((attn_split_kernel<true, 1>), grid, dim3(256), 0, stream, p);
+        else if (var == 2)
+            hipLaunchKernelGGL((attn_split_kernel<true, 2>), grid, dim3(256), 0, stream, p);
+        else if (var == 3)
+            hipLaunchKernelGGL((attn_split_kernel<true, 3>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((attn_split_kernel<true, 0>), grid, dim3(256), 0, stream, p);
+    } else if (h->precision == 1)
+        hipLaunchKernelGGL((attn_split_kernel<false, 0>), grid, dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
     imcui_prof_end(h, PROF_ATTN, stream);

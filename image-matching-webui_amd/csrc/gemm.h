@@ -13,6 +13,10 @@ enum GemmEpi {
     EPI_QKV = 3,    // LightGlue SelfBlock: bias, RoPE on q/k, q *= alpha, head-major split
     EPI_CROSS = 4,  // LightGlue CrossBlock: [qk | v] = bias, qk *= alpha, head-major split
     EPI_CONV = 5,   // C = act(acc + bias + resid): act 0 none / 1 ReLU / 2 LeakyReLU(0.01) / 3 GELU (erf)
+    // C = acc (similarity matrix of two activation matrices, batched) AND, from the same parked tile, the soft-max partials of
+    // the assignment: per row (max, sum exp) over the tile's 128 columns -> st_rpm / st_rps [batch][N/128][ldc], per column over
+    // each 64-row half -> st_cpm / st_cps [batch][M/64][ldc]  (split mode, f32 B operand; LightGlue's log-assignment, a11)
+    EPI_SIMSTAT = 6,
 };
 
 struct GemmP {
@@ -72,12 +76,18 @@ struct GemmP {
     // 1: ONE f16 product per element pair (hi planes only, f32 accumulate) instead of the three of the split arithmetic: 11-bit
     // operands, the class of a bf16 / fp16 autocast run.  EPI_CONV with pre-split weight planes only.
     int single = 0;
+    float *st_rpm = nullptr, *st_rps = nullptr, *st_cpm = nullptr, *st_cps = nullptr;  // EPI_SIMSTAT partials
+    int st_nct = 0, st_nrh = 0;                                                         // partial slots per row / per column
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;
 };
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);
+// gemm_wreg.hip: the weights-in-registers kernel for projection layers (split mode, pre-split weight planes); gemm_launch
+// routes eligible launches to it
+bool gemm_wreg_ok(const GemmP& p);
+void gemm_wreg_launch(const GemmP& p, hipStream_t stream);
 
 // host: OIHW conv weight -> GEMM weight [Cout][tap][Cin] (K order of the implicit im2col)
 void pack_conv_gemm(const float* w_oihw, int Cout, int Cin, int ksize, int Cin_pad, float* dst);

@@ -12,55 +12,9 @@
 #include <string.h>
 
 #include "gemm.h"
+#include "gemm_tile.h"
 
-#define BM 128
-#define BN 128
 #define LDS_ROWS 129  // padded row count per k-granule (16-byte units)
-
-struct TileCtx {
-    int M, N, row0, col0, seq, z;
-    const float* bias;
-    long wsel;  // selected weight index (per-pair heads)
-};
-
-// returns false when the workgroup has nothing to do
-__device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int bn = BN) {
-    c.z = blockIdx.z;
-    c.M = p.mcnt ? p.mcnt[c.z * p.cnt_stride] : p.M;
-    c.N = p.ncnt ? p.ncnt[c.z * p.cnt_stride] : p.N;
-    const int ncol = (p.N + bn - 1) / bn;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    if (p.group_rows > 1) {
-        // both operands are large (similarity matrices): walk the tiles group by group of `group_rows` row panels, column
-        // panel by column panel inside a group, so a weight-side panel is re-used by the whole group while it is in L2 and
-        // the group's row panels stay resident across the columns (row-major order streams the whole second operand once
-        // per row panel: 2.1 GB per 16384 x 16384 x 256 product instead of 0.27 GB)
-        const int nrow = (p.M + BM - 1) / BM;
-        const int per = p.group_rows * ncol;
-        const int g = tile / per, t = tile - g * per;
-        const int rows = min(p.group_rows, nrow - g * p.group_rows);
-        c.row0 = (g * p.group_rows + t % rows) * BM;
-        c.col0 = (t / rows) * bn;
-    } else {
-        c.row0 = (tile / ncol) * BM;
-        c.col0 = (tile % ncol) * bn;
-    }
-    if (c.row0 >= c.M || c.col0 >= c.N) return false;
-    c.bias = p.bias;
-    c.seq = 0;
-    c.wsel = 0;
-    if (p.rows_per_seq > 0) {
-        c.seq = c.row0 / p.rows_per_seq;
-        const int i0 = c.row0 - c.seq * p.rows_per_seq;
-        if (p.cnt && i0 >= p.cnt[c.seq]) return false;
-        if (p.active && p.active[c.seq >> 1] == 0) return false;
-        if (p.wsel) {
-            c.wsel = p.wsel[c.seq >> 1] + p.wsel_off;
-            if (c.bias) c.bias += (size_t)c.wsel * p.b_stride;
-        }
-    }
-    return true;
-}
 
 // Epilogue.  The products are issued with the WEIGHT fragment as the MFMA A operand and the
 // activation fragment as B, i.e. the accumulators hold C^T: column (lane & 31) = token row,
@@ -526,7 +480,73 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                     }
         }
         __syncthreads();
-        if (colok) {
+        if constexpr (EPI == EPI_SIMSTAT) {
+            // similarity tile: store it, and reduce it to soft-max partials while it is in LDS.  A row of the half is held by
+            // the 32 lanes of one half-wave (4 columns each): row (max, sum exp) by five xor-shuffles; a thread sees 8 rows of
+            // its 4 columns: online (max, sum) per column, the 8 row groups combined through LDS in group order.
+            float cm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+            const int ctile = (cc.col0 >> 7) + PASS_C2(ps);
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {
+                const int tl = (tid >> 5) + 8 * it;
+                const int row = cc.row0 + h * 64 + tl;
+                if (row < cc.M) {  // uniform over the half-wave
+                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + 4 * (tid & 31));
+                    if (full)
+                        *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + f0) = t4;
+                    else if (colok) {
+                        const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < cc.N) C[(size_t)row * p.ldc + f0 + j] = tv[j];
+                    }
+                    float x[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (f0 + j >= cc.N) x[j] = -INFINITY;
+                    float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                    float s = 0.0f;  // m is finite: the tile holds at least one valid column
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s += (x[j] > -INFINITY) ? __expf(x[j] - m) : 0.0f;
+                        const float mn = fmaxf(cm[j], x[j]);
+                        if (mn > -INFINITY) cs[j] = cs[j] * __expf(cm[j] - mn) + ((x[j] > -INFINITY) ? __expf(x[j] - mn) : 0.0f);
+                        cm[j] = mn;
+                    }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    if ((tid & 31) == 0) {
+                        const size_t o = ((size_t)cc.z * p.st_nct + ctile) * p.ldc + row;
+                        p.st_rpm[o] = m;
+                        p.st_rps[o] = s;
+                    }
+                }
+            }
+            float* clm = st + 64 * STG_C_ROW;  // [8 row groups][128 columns] max, then sums (behind the parked half)
+            float* cls = clm + 8 * 128;
+            *reinterpret_cast<float4*>(clm + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cm[0], cm[1], cm[2], cm[3]);
+            *reinterpret_cast<float4*>(cls + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            __syncthreads();
+            if (tid < 128) {
+                const int col = cc.col0 + PASS_C2(ps) * 128 + tid;
+                if (col < cc.N) {
+                    float m = clm[tid];
+#pragma unroll
+                    for (int gq = 1; gq < 8; ++gq) m = fmaxf(m, clm[gq * 128 + tid]);
+                    float s = 0.0f;
+#pragma unroll
+                    for (int gq = 0; gq < 8; ++gq) {
+                        const float q = clm[gq * 128 + tid];
+                        if (q > -INFINITY) s += cls[gq * 128 + tid] * __expf(q - m);
+                    }
+                    const size_t o = ((size_t)cc.z * p.st_nrh + (cc.row0 >> 6) + h) * p.ldc + col;
+                    p.st_cpm[o] = m;
+                    p.st_cps[o] = s;
+                }
+            }
+        } else if (colok) {
 #pragma unroll 4
             for (int it = 0; it < 8; ++it) {
                 const int tl = (tid >> 5) + 8 * it;
@@ -1062,12 +1082,23 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         fflush(stderr);
     }
     imcui_prof_begin(h, PROF_GEMM, stream);
+    if (split && gemm_wreg_ok(p)) {
+        gemm_wreg_launch(p, stream);
+        imcui_prof_end(h, PROF_GEMM, stream);
+        IMCUI_CHECK_LAUNCH(h);
+        return IMCUI_OK;
+    }
     switch (p.epi) {
         case EPI_BIAS: launch_one<EPI_BIAS>(p, split, stream); break;
         case EPI_RELU: launch_one<EPI_RELU>(p, split, stream); break;
         case EPI_RESID: launch_one<EPI_RESID>(p, split, stream); break;
         case EPI_QKV: launch_one<EPI_QKV>(p, split, stream); break;
         case EPI_CROSS: launch_one<EPI_CROSS>(p, split, stream); break;
+        case EPI_SIMSTAT:
+            if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_cpm || !p.st_cps || p.bias != nullptr || (p.ldc & 3) != 0)
+                return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: EPI_SIMSTAT needs the split mode, an f32 B operand, no bias and the four partial buffers");
+            hipLaunchKernelGGL((gemm_split_kernel<EPI_SIMSTAT, 0, false, 2>), dim3(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.batch), dim3(256), 0, stream, p);
+            break;
         case EPI_CONV:
             if (p.conv_k > 0)
                 launch_conv(p, split, stream);

@@ -1,0 +1,322 @@
+// Weight-stationary-in-registers GEMM for the projection layers (3 x f16 split arithmetic, gfx950).
+//
+// gemm_split_kernel (gemm.hip) moves BOTH operands through LDS and pays two barriers per 32-wide K tile; on the short-K
+// projections (LightGlue / SuperGlue QKV and cross projections: K = 256, eight tiles between a prologue and a plane-writing
+// epilogue) its matrix pipe was busy 0.27-0.30 of the time.  This kernel is the first GEMM of the fused FFN (ffn.hip) as a
+// stand-alone launch:
+//   * workgroup = 128 tokens x 256 output features, 4 waves; wave w owns features [64 w, 64 w + 64) of ALL 128 tokens
+//     (2 x 4 accumulator fragments, 128 VGPRs), so no two waves share a weight fragment and the pre-split fragment-major
+//     weight planes go global -> registers directly (one coalesced 16-byte load per lane = one 1 KiB MFMA fragment), one
+//     k-step ahead.  The weights never touch LDS;
+//   * the activations (f32) are split while they are staged into a double-buffered swizzled LDS image (gemm.hip's
+//     fragment order): ONE barrier per K tile, 8 fragment reads per 24 MFMAs;
+//   * for the attention layouts a 256-feature tile is exactly one of q / k / v and wave w is head w: the epilogue is
+//     wave-private (no workgroup barrier) -- the wave parks 32 tokens x 64 features in its own 9 KB of LDS, reads them back
+//     row-contiguous (RoPE with one float4 of cos / sin, scale, split) and stores whole 128-byte plane rows; V is parked
+//     transposed and leaves as [feature][token] runs.
+// Row-major epilogues (bias / ReLU / residual / activation codes of EPI_CONV) leave through the same wave-private staging
+// as 256-byte row segments.
+#include <stdlib.h>
+
+#include "gemm.h"
+#include "gemm_tile.h"
+
+#define WR_BN 256
+#define WR_STG_ROW 68    // floats per parked [token][64 features] row (272 B: conflict-free 16-byte writes)
+#define WR_STG_TROW 36   // floats per parked [feature][32 tokens] row (144 B)
+#define WR_WAVE_LDS 9216  // staging bytes per wave (32 x 68 x 4 = 8704; 64 x 36 x 4 = 9216)
+
+__device__ __forceinline__ void wr_wave_fence() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS traffic is done
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int EPI, bool SINGLE>
+__global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
+    __shared__ uint4 smem[(4 * WR_WAVE_LDS) / 16];  // main loop: two 16 KB activation stages; epilogue: 4 x 9 KB wave staging
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    TileCtx c;
+    if (!gemm_tile_setup(p, c, WR_BN)) return;
+    const float* A = p.A + (size_t)c.z * p.a_bs;
+    const float wsc = p.wscale ? p.wscale[c.wsel] : 1.0f;
+    const int nkt = p.K >> 5, nks = p.K >> 4;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
+
+    // ---- activation staging: thread -> k-octet g (8 consecutive k of the 32-wide tile) of rows tid >> 2 and + 64
+    const int g = tid & 3;
+    const int rl0 = tid >> 2, rl1 = 64 + (tid >> 2);
+    const int wo0 = (((g >> 1) * 4 + (rl0 >> 5)) * 64 + (g & 1) * 32 + ((rl0 & 31) ^ (2 * g))) * 16;
+    const int wo1 = (((g >> 1) * 4 + (rl1 >> 5)) * 64 + (g & 1) * 32 + ((rl1 & 31) ^ (2 * g))) * 16;
+    const float* pa0 = A + (size_t)min(c.row0 + rl0, c.M - 1) * p.lda + g * 8;
+    const float* pa1 = A + (size_t)min(c.row0 + rl1, c.M - 1) * p.lda + g * 8;
+    f32x4 xa0, xb0, xa1, xb1;
+    auto issue = [&](int kt) __attribute__((always_inline)) {
+        xa0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32);
+        xb0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32 + 4);
+        xa1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32);
+        xb1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32 + 4);
+    };
+    auto store = [&](int stg) __attribute__((always_inline)) {
+        uint4 h, l;
+        split8(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0), h, l);
+        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = h;
+        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo0) = l;
+        split8(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1), h, l);
+        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = h;
+        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo1) = l;
+    };
+    // ---- weights: fragments (nf, ks) of the planes [ceil(N/32)][K/16][64 lanes][8 halves] at ((nf * nks) + ks) * 64 + lane
+    const int nfr = (p.N + 31) >> 5;
+    const uint4 *whp[2], *wlp[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int nf = min((c.col0 >> 5) + 2 * wid + n, nfr - 1);
+        whp[n] = reinterpret_cast<const uint4*>(p.Wh + (size_t)c.wsel * p.w_stride) + ((size_t)nf * nks) * 64 + lane;
+        wlp[n] = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nf * nks) * 64 + lane;
+    }
+    uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step
+    auto loadw = [&](int s, uint4(&w)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            w[n][0] = whp[n][(size_t)s * 64];
+            if constexpr (!SINGLE) w[n][1] = wlp[n][(size_t)s * 64];
+        }
+    };
+    auto kstep = [&](int stg, int ks, uint4(&w)[2][2]) __attribute__((always_inline)) {
+        const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
+        uint4 ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int fo = stg * 16384 + (ks * 4 + m) * 1024 + apos;
+            ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
+            if constexpr (!SINGLE) al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                // weight fragment = MFMA A operand (rows = features), activations = B (columns = tokens)
+                if constexpr (!SINGLE) {
+                    acc[n][m] = mfma16(w[n][0], al[m], acc[n][m]);
+                    acc[n][m] = mfma16(w[n][1], ah[m], acc[n][m]);
+                }
+                acc[n][m] = mfma16(w[n][0], ah[m], acc[n][m]);
+            }
+    };
+
+    issue(0);
+    loadw(0, wc);
+    store(0);
+    if (nkt > 1) issue(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int stg = kt & 1;
+        loadw(2 * kt + 1, wn);
+        kstep(stg, 0, wc);
+        if (kt + 1 < nkt) {
+            store(stg ^ 1);  // its readers finished before the barrier that ended iteration kt - 1
+            if (kt + 2 < nkt) issue(kt + 2);
+            loadw(2 * kt + 2, wc);
+        }
+        kstep(stg, 1, wn);
+        __syncthreads();
+    }
+
+    // ================================================================== epilogue (wave-private staging)
+    // accumulator (n, m, r) of lane (lo, hi): feature col0 + 64 wid + 32 n + 8 (r >> 2) + 4 hi + (r & 3), token row0 + 32 m + lo
+    float* st = reinterpret_cast<float*>(sm + wid * WR_WAVE_LDS);
+    const int fw0 = c.col0 + 64 * wid;  // first feature of this wave
+    if (fw0 >= c.N) return;            // (no workgroup barrier below)
+    auto park_rows = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(st + lo * WR_STG_ROW + 32 * n + 8 * q + 4 * hi) =
+                    make_float4(acc[n][m][4 * q + 0] * wsc, acc[n][m][4 * q + 1] * wsc, acc[n][m][4 * q + 2] * wsc, acc[n][m][4 * q + 3] * wsc);
+    };
+    if constexpr (EPI == EPI_QKV || EPI == EPI_CROSS) {
+        // the 256 features of the tile are the four heads of ONE of q / k / v; this wave is head `hd`
+        const int t = c.col0 >> 8, hd = ((c.col0 >> 6) + wid) & 3;
+        float* dst;
+        bool vt, rope, scale;
+        if (EPI == EPI_QKV) {
+            dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
+            vt = (t == 2);
+            rope = (t < 2);
+            scale = (t == 0);
+        } else {
+            dst = (t == 0) ? p.Q : p.V;
+            vt = (t == 1);
+            rope = false;
+            scale = (t == 0);
+        }
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        const int R = p.rows_per_seq;
+        const int i0 = c.row0 - c.seq * R;
+        if (!vt) {
+            const int d0 = (lane & 7) * 8;
+            float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
+            if (c.bias != nullptr) {
+                ba = *reinterpret_cast<const float4*>(c.bias + fw0 + d0);
+                bb = *reinterpret_cast<const float4*>(c.bias + fw0 + d0 + 4);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                park_rows(m);
+                wr_wave_fence();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int tl = pass * 8 + (lane >> 3);
+                    const int row = c.row0 + 32 * m + tl;
+                    const float4 va = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0);
+                    const float4 vb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0 + 4);
+                    float v[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
+                    if (rope) {
+                        const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
+                        const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                        const float cw[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)   (same expression as gemm.hip)
+                            const float a0 = v[2 * j], a1 = v[2 * j + 1];
+                            v[2 * j] = a0 * cw[j] + (-a1) * ss[j];
+                            v[2 * j + 1] = a1 * cw[j] + a0 * ss[j];
+                        }
+                    }
+                    if (scale) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+                    }
+                    uint4 hv, lv;
+                    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
+                    unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * R + i0 + 32 * m + tl) * 64 + d0;
+                    *reinterpret_cast<uint4*>(o) = hv;
+                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                }
+                wr_wave_fence();
+            }
+        } else {
+            // V^T [seq][head][64][rows]: park [feature][32 tokens], read 8 consecutive tokens of one feature per lane
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[(32 * n + 8 * (r >> 2) + 4 * hi + (r & 3)) * WR_STG_TROW + lo] = acc[n][m][r] * wsc;
+                wr_wave_fence();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int d = pass * 16 + (lane >> 2), tk = (lane & 3) * 8;
+                    const float bd = c.bias ? c.bias[fw0 + d] : 0.0f;
+                    const float4 va = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk);
+                    const float4 vb = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk + 4);
+                    uint4 hv, lv;
+                    split8(make_float4(va.x + bd, va.y + bd, va.z + bd, va.w + bd), make_float4(vb.x + bd, vb.y + bd, vb.z + bd, vb.w + bd), hv, lv);
+                    unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * 64 + d) * R + i0 + 32 * m + tk;
+                    *reinterpret_cast<uint4*>(o) = hv;
+                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                }
+                wr_wave_fence();
+            }
+        }
+    } else {
+        // ---- row-major f32 output: 16 lanes cover the wave's 64 features of one token (256-byte segments)
+        float* C = p.C + (size_t)c.z * p.c_bs;
+        const int fl = (lane & 15) * 4;
+        const int f0 = fw0 + fl;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c.bias != nullptr) b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            park_rows(m);
+            wr_wave_fence();
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int tl = pass * 4 + (lane >> 4);
+                const int row = c.row0 + 32 * m + tl;
+                if (row < c.M) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + fl);
+                    float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
+                    float* dstp = C + (size_t)row * p.ldc + f0;
+                    if (EPI == EPI_CONV) {
+                        if (p.resid != nullptr) {
+                            const float4 r4 = *reinterpret_cast<const float4*>(p.resid + (size_t)row * p.ldr + f0);
+                            v[0] += r4.x;
+                            v[1] += r4.y;
+                            v[2] += r4.z;
+                            v[3] += r4.w;
+                        }
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                        } else if (p.act == 2) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.01f * v[j];
+                        } else if (p.act == 3) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = gelu_poly(v[j]);
+                        }
+                    } else if (EPI == EPI_BIAS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                    } else if (EPI == EPI_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    } else if (EPI == EPI_RESID) {
+                        const float4 o4 = *reinterpret_cast<const float4*>(dstp);
+                        v[0] += o4.x;
+                        v[1] += o4.y;
+                        v[2] += o4.z;
+                        v[3] += o4.w;
+                    }
+                    *reinterpret_cast<float4*>(dstp) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            wr_wave_fence();
+        }
+    }
+}
+
+// Which launches take this kernel: pre-split weight planes, one K slab, plain (non-batched, non-conv) A, whole 64-feature
+// wave tiles and 16-byte aligned rows.  IMCUI_GEMM_WREG=0 keeps everything on gemm_split_kernel (A/B runs).
+bool gemm_wreg_ok(const GemmP& p) {
+    const char* env = getenv("IMCUI_GEMM_WREG");  // read per launch: tests flip it between two calls
+    const int mode = env ? atoi(env) : 2;         // 0: off; 1: attention-layout projections only; 2: every eligible launch
+    if (mode == 0 || (mode == 1 && p.epi != EPI_QKV && p.epi != EPI_CROSS) || p.Wh == nullptr || p.Wl == nullptr || p.A2 != nullptr || p.conv_k > 0 || p.batch != 1 || p.mcnt || p.ncnt || p.group_rows > 1 ||
+        p.rup_h > 0)
+        return false;
+    if (p.K % 32 != 0 || p.N % 64 != 0 || (p.lda & 3) != 0) return false;
+    if (p.epi == EPI_QKV || p.epi == EPI_CROSS)
+        return p.split_out && p.v_transposed && p.heads == 4 && p.N % 256 == 0 && p.rows_per_seq > 0 && p.M % 128 == 0;
+    if (p.single && p.epi != EPI_CONV) return false;
+    if ((p.ldc & 3) != 0 || (p.epi == EPI_CONV && p.resid != nullptr && (p.ldr & 3) != 0)) return false;
+    return p.epi == EPI_BIAS || p.epi == EPI_RELU || p.epi == EPI_RESID || p.epi == EPI_CONV;
+}
+
+void gemm_wreg_launch(const GemmP& p, hipStream_t stream) {
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, WR_BN), 1, 1);
+    switch (p.epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_BIAS, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_RELU: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RELU, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RESID, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_CROSS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CROSS, false>), grid, dim3(256), 0, stream, p); break;
+        default:
+            if (p.single)
+                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, true>), grid, dim3(256), 0, stream, p);
+            else
+                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, false>), grid, dim3(256), 0, stream, p);
+    }
+}

@@ -9,6 +9,7 @@
 // host synchronisation.  All contractions run on the matrix cores (gemm.h: exact f32 or 3 x f16 split).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -17,6 +18,7 @@
 #include "ffn.h"
 #include "gemm.h"
 #include "imcui_hip.h"
+#include "lightglue_assign.h"
 
 #define LG_LAYERS 9
 #define LG_DIM 256
@@ -245,6 +247,8 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
 struct LgWs {
     float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls, *sim;
     float *rmax, *rls, *cmax, *cls, *max0, *ms0;
+    float *rpm, *rps, *cpm, *cps;  // assignment partials: rows [B][R/128][R], columns [B][R/64][R] (lightglue_assign.h)
+    int *rpj, *cpi;
     int *cntA, *cntB, *active, *ind, *indt, *pos, *prune, *m0, *m1, *valid0, *norig, *pflag;
     size_t total;
     bool ok;
@@ -276,6 +280,12 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.cls = a.get<float>((size_t)B * R);
     w.max0 = a.get<float>((size_t)B * R);
     w.ms0 = a.get<float>((size_t)B * R);
+    w.rpm = a.get<float>((size_t)B * (R / 128) * R);
+    w.rps = a.get<float>((size_t)B * (R / 128) * R);
+    w.cpm = a.get<float>((size_t)B * (R / 64) * R);
+    w.cps = a.get<float>((size_t)B * (R / 64) * R);
+    w.rpj = a.get<int>((size_t)B * (R / 128) * R);
+    w.cpi = a.get<int>((size_t)B * (R / 64) * R);
     w.cntA = a.get<int>(2 * B);
     w.cntB = a.get<int>(2 * B);
     w.active = a.get<int>(B);
@@ -633,168 +643,6 @@ __global__ void lg_finish_stop_kernel(int* __restrict__ stop, const int* __restr
     if (b < B && active[b]) stop[b] = LG_LAYERS;
 }
 
-// row statistics of sim[b] (n0 x n1): max and log-sum-exp remainder, one wave per row
-__global__ __launch_bounds__(256) void lg_rowstat_kernel(const float* __restrict__ sim, const int* __restrict__ cnt, int R,
-                                                         float* __restrict__ rmax, float* __restrict__ rls) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
-    if (i >= n0) return;
-    const float* row = sim + ((size_t)b * R + i) * R;
-    float m = -INFINITY;
-    for (int j = lane; j < n1; j += 64) m = fmaxf(m, row[j]);
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int j = lane; j < n1; j += 64) s += expf(row[j] - m);
-    s = wave_sum(s);
-    if (lane == 0) {
-        rmax[(size_t)b * R + i] = m;
-        rls[(size_t)b * R + i] = logf(s);
-    }
-}
-
-// column statistics: block = 64 columns x 4 row groups
-__global__ __launch_bounds__(256) void lg_colstat_kernel(const float* __restrict__ sim, const int* __restrict__ cnt, int R,
-                                                         float* __restrict__ cmax, float* __restrict__ cls) {
-    __shared__ float sm[4][64], ss[4][64];
-    const int b = blockIdx.y;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
-    if (blockIdx.x * 64 >= n1) return;
-    const float* base = sim + (size_t)b * R * R;
-    // 8 independent loads per trip (a column walk is a dependent 256-byte-per-wave load chain otherwise:
-    // latency bound at 4x the HBM time); values are folded in the original row order
-    float m = -INFINITY;
-    if (j < n1)
-        for (int i = g; i < n0; i += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < n0) ? base[(size_t)(i + 4 * u) * R + j] : -INFINITY;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
-        }
-    sm[g][c] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
-    float s = 0.0f;
-    if (j < n1)
-        for (int i = g; i < n0; i += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < n0) ? base[(size_t)(i + 4 * u) * R + j] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + 4 * u < n0) s += expf(v[u] - m);
-        }
-    ss[g][c] = s;
-    __syncthreads();
-    if (g == 0 && j < n1) {
-        cmax[(size_t)b * R + j] = m;
-        cls[(size_t)b * R + j] = logf(ss[0][c] + ss[1][c] + ss[2][c] + ss[3][c]);
-    }
-}
-
-// log assignment score of (i, j) exactly as the reference associates it:
-//   (log_softmax_row + log_softmax_col) + (logsigmoid(z0_i) + logsigmoid(z1_j))
-__device__ __forceinline__ float lg_score(float s, float rm, float rl, float cm, float cl, float l0, float l1) {
-    return (((s - rm) - rl) + ((s - cm) - cl)) + (l0 + l1);
-}
-
-__global__ __launch_bounds__(256) void lg_rowarg_kernel(const float* __restrict__ sim, const int* __restrict__ cnt, int R,
-                                                        const float* __restrict__ rmax, const float* __restrict__ rls,
-                                                        const float* __restrict__ cmax, const float* __restrict__ cls,
-                                                        const float* __restrict__ ls, float* __restrict__ max0,
-                                                        int* __restrict__ m0) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
-    if (i >= n0) return;
-    const float* row = sim + ((size_t)b * R + i) * R;
-    const float rm = rmax[(size_t)b * R + i], rl = rls[(size_t)b * R + i];
-    const float l0 = ls[((size_t)2 * b) * R + i];
-    const float* l1 = ls + ((size_t)2 * b + 1) * R;
-    const float* cm = cmax + (size_t)b * R;
-    const float* cl = cls + (size_t)b * R;
-    float best = -INFINITY;
-    int bj = 0x7fffffff;
-    for (int j = lane; j < n1; j += 64) {
-        const float v = lg_score(row[j], rm, rl, cm[j], cl[j], l0, l1[j]);
-        if (v > best) {
-            best = v;
-            bj = j;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oj = __shfl_xor(bj, o, 64);
-        if (ov > best || (ov == best && oj < bj)) {
-            best = ov;
-            bj = oj;
-        }
-    }
-    if (lane == 0) {
-        max0[(size_t)b * R + i] = best;
-        m0[(size_t)b * R + i] = bj;
-    }
-}
-
-__global__ __launch_bounds__(256) void lg_colarg_kernel(const float* __restrict__ sim, const int* __restrict__ cnt, int R,
-                                                        const float* __restrict__ rmax, const float* __restrict__ rls,
-                                                        const float* __restrict__ cmax, const float* __restrict__ cls,
-                                                        const float* __restrict__ ls, int* __restrict__ m1) {
-    __shared__ float sv[4][64];
-    __shared__ int si[4][64];
-    const int b = blockIdx.y;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
-    if (blockIdx.x * 64 >= n1) return;
-    const float* base = sim + (size_t)b * R * R;
-    const float* rm = rmax + (size_t)b * R;
-    const float* rl = rls + (size_t)b * R;
-    const float* l0 = ls + ((size_t)2 * b) * R;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    if (j < n1) {
-        const float cmj = cmax[(size_t)b * R + j], clj = cls[(size_t)b * R + j];
-        const float l1 = ls[((size_t)2 * b + 1) * R + j];
-        for (int i0 = g; i0 < n0; i0 += 32) {
-            float sv8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sv8[u] = (i0 + 4 * u < n0) ? base[(size_t)(i0 + 4 * u) * R + j] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 4 * u;
-                if (i < n0) {
-                    const float v = lg_score(sv8[u], rm[i], rl[i], cmj, clj, l0[i], l1);
-                    if (v > best) {
-                        best = v;
-                        bi = i;
-                    }
-                }
-            }
-        }
-    }
-    sv[g][c] = best;
-    si[g][c] = bi;
-    __syncthreads();
-    if (g == 0 && j < n1) {
-        for (int gg = 1; gg < 4; ++gg) {
-            const float ov = sv[gg][c];
-            const int oi = si[gg][c];
-            if (ov > best || (ov == best && oi < bi)) {
-                best = ov;
-                bi = oi;
-            }
-        }
-        m1[(size_t)b * R + j] = bi;
-    }
-}
-
 // filter_matches + mapping through the pruning index maps, one block per pair
 __global__ __launch_bounds__(256) void lg_filter_kernel(const int* __restrict__ cnt, const int* __restrict__ norig, int R,
                                                         int ncap, const int* __restrict__ m0, const int* __restrict__ m1,
@@ -1112,9 +960,14 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     }
     hipLaunchKernelGGL(lg_match_logit_kernel, rowgrid, blk, 0, stream, w.x, P + l.wmatch, P + l.bmatch, stop, cnt_cur, R,
                        w.ls);
+    // sim[b] = md0[b] . md1[b]^T, reduced to soft-max partials by the GEMM's own epilogue (split mode) or by one extra
+    // pass (exact-f32 mode; IMCUI_LG_ASSIGN_STATS=pass for A/B runs), then ONE pass for both arg-maxes (lightglue_assign.h)
+    const char* stats_env = getenv("IMCUI_LG_ASSIGN_STATS");
+    const bool epi_stats = split && !(stats_env && strcmp(stats_env, "pass") == 0);
+    const int nrp = R / 128, ncp = R / 64, nch = (R + LG2_COLS - 1) / LG2_COLS, nbd = R / LG2_ROWS;
     {
-        GemmP g;  // sim[b] = md0[b] . md1[b]^T
-        g.epi = EPI_BIAS;
+        GemmP g;
+        g.epi = epi_stats ? EPI_SIMSTAT : EPI_BIAS;
         g.batch = B;
         g.A = w.md;
         g.lda = 256;
@@ -1131,14 +984,22 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
         g.mcnt = cnt_cur;
         g.ncnt = cnt_cur + 1;
         g.cnt_stride = 2;
+        g.st_rpm = w.rpm;
+        g.st_rps = w.rps;
+        g.st_cpm = w.cpm;
+        g.st_cps = w.cps;
+        g.st_nct = nrp;
+        g.st_nrh = ncp;
         LGRUN(gemm_launch(h, g, stream));
     }
-    const dim3 rg(R / 4, B), cg(R / 64, B);
-    hipLaunchKernelGGL(lg_rowstat_kernel, rg, blk, 0, stream, w.sim, cnt_cur, R, w.rmax, w.rls);
-    hipLaunchKernelGGL(lg_colstat_kernel, cg, blk, 0, stream, w.sim, cnt_cur, R, w.cmax, w.cls);
-    hipLaunchKernelGGL(lg_rowarg_kernel, rg, blk, 0, stream, w.sim, cnt_cur, R, w.rmax, w.rls, w.cmax, w.cls, w.ls, w.max0,
-                       w.m0);
-    hipLaunchKernelGGL(lg_colarg_kernel, cg, blk, 0, stream, w.sim, cnt_cur, R, w.rmax, w.rls, w.cmax, w.cls, w.ls, w.m1);
+    const dim3 tg(nch, nbd, B), mg(cdiv(R, 256), B, 2);
+    if (!epi_stats) hipLaunchKernelGGL(lg_stats2_kernel, tg, blk, 0, stream, w.sim, cnt_cur, R, nrp, ncp, w.rpm, w.rps, w.cpm, w.cps);
+    hipLaunchKernelGGL(lg_stat_merge_kernel, mg, blk, 0, stream, w.rpm, w.rps, w.cpm, w.cps, cnt_cur, R, nrp, ncp, epi_stats ? 128 : LG2_COLS, 64,
+                       epi_stats ? 128 : 64, w.rmax, w.rls, w.cmax, w.cls);
+    // the best-partials reuse the statistic partial buffers (values) next to their index arrays
+    hipLaunchKernelGGL(lg_best2_kernel, tg, blk, 0, stream, w.sim, cnt_cur, R, nch, nbd, w.rmax, w.rls, w.cmax, w.cls, w.ls, w.rpm, w.rpj, w.cpm,
+                       w.cpi);
+    hipLaunchKernelGGL(lg_best_merge_kernel, mg, blk, 0, stream, w.rpm, w.rpj, w.cpm, w.cpi, cnt_cur, R, nch, nbd, w.max0, w.m0, w.m1);
     hipLaunchKernelGGL(lg_filter_kernel, dim3(B), blk, 0, stream, cnt_cur, w.norig, R, ncap, w.m0, w.m1, w.max0, w.ind,
                        w.prune, w.ms0, w.valid0, filt_f, matches0, matches1, mscores0, mscores1, prune0, prune1);
     IMCUI_CHECK_LAUNCH(h);
