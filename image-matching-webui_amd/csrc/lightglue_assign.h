@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void lg_stats2_kernel(const float* __restrict_
         cm[e] = -INFINITY;
         cs[e] = 0.0f;
     }
+#pragma unroll 2
     for (int r = 0; r < 16; ++r) {
         const int i = i0 + r;
         if (i >= n0) break;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void lg_best2_kernel(const float* __restrict__
             cbv[4 * k + e] = -INFINITY;
             cbi[4 * k + e] = 0x7fffffff;
         }
+#pragma unroll 2
     for (int r = 0; r < 16; ++r) {
         const int i = i0 + r;
         if (i >= n0) break;
@@ -170,17 +172,14 @@ __global__ __launch_bounds__(256) void lg_best2_kernel(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = c0 + k * 256 + lane * 4 + e;
-                const float v = lg_score(x[4 * k + e], rm, rl, cmx[4 * k + e], clx[4 * k + e], l0, l1x[4 * k + e]);
-                if (j < n1) {
-                    if (v > bv) {  // j ascends within a lane: the first maximum is kept
-                        bv = v;
-                        bj = j;
-                    }
-                    if (v > cbv[4 * k + e]) {  // i ascends within a wave
-                        cbv[4 * k + e] = v;
-                        cbi[4 * k + e] = i;
-                    }
-                }
+                // columns past the pair's edge score -inf: they never win a strict comparison (branch-free selects)
+                const float v = (j < n1) ? lg_score(x[4 * k + e], rm, rl, cmx[4 * k + e], clx[4 * k + e], l0, l1x[4 * k + e]) : -INFINITY;
+                const bool rw = v > bv;  // j ascends within a lane: the first maximum is kept
+                bv = rw ? v : bv;
+                bj = rw ? j : bj;
+                const bool cw = v > cbv[4 * k + e];  // i ascends within a wave
+                cbv[4 * k + e] = cw ? v : cbv[4 * k + e];
+                cbi[4 * k + e] = cw ? i : cbi[4 * k + e];
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {

@@ -9,11 +9,20 @@ device, batch_size=1)` (:73) on the two directed pairs (image0, image1), (image1
 (image0, image1) (the 'complete' scene graph lists (i, j < i) first, `symmetrize` appends the swapped pairs) -- so the host-side steps of
 the wrapper consume it unchanged.  Every image is encoded once (upstream encodes both images again for the swapped pair).
 
-Host-side steps (duster.py:74-108): `global_aligner(mode=PairViewer)` (focal estimation + `cv2.solvePnPRansac`), confidence
-masks, `find_reciprocal_matches` (3-D nearest neighbours with a KD-tree) and the linspace sub-sampling to `max_keypoints`.
-That is RANSAC geometry on the host in the reference and stays there (north_star): `_forward` runs those steps with
-upstream's own `dust3r` package when it is importable (the `third_party/dust3r` submodule of the reference checkout) and
-raises a clear ImportError otherwise -- neither the package nor cv2 exist offline, so they are not restated here.
+Host-side steps (duster.py:74-108).  `global_aligner(mode=PairViewer)` (focal estimation + `cv2.solvePnPRansac`) is RANSAC
+geometry on the host in the reference and stays there (north_star): `_forward` obtains the scene through `self.aligner(output,
+device)`, by default upstream's own `dust3r.cloud_opt.global_aligner` (the `third_party/dust3r` submodule of the reference
+checkout; a clear ImportError when it is not installed -- neither the package nor cv2 exist offline).  Everything AFTER the
+aligner is restated here and needs nothing of upstream's: confidence masks -> pixel grids (`xy_grid`) -> reciprocal 3-D nearest
+neighbours (`find_reciprocal_matches`: two KD-trees, image-1 points whose nearest image-0 point names them back) -> the
+`np.linspace` sub-sampling to `max_keypoints` (`matches_from_scene`; tested on CPU against the brute-force restatement
+`oracle/dust3r.py: duster_matches_from_scene` with the aligner mocked).
+
+Image sizes: the two images of a pair must have ONE size (multiples of 16).  The reference's `Duster.preprocess` is never
+called by its callers; `match_dense.match_images` / `ImagePairDataset.preprocess` resize each image on its own (resize_max 512,
+dfactor 16), so two photos of different aspect ratio reach upstream's net at different sizes, which `dust3r.inference`
+handles by encoding the views separately.  The HIP entry point has one token grid per call: pairs of unequal size are refused
+with a message that says so (restriction listed in INTEGRATION.md).
 
 Weights: conf["state_dict"] / conf["weights_path"] (or conf["packed"], the result of an earlier `backend.pack_dust3r`: packing
 the 578 M parameters takes ~20 s) with upstream's parameter names (`duster_vit_large.pth` holds them under
@@ -68,8 +77,12 @@ class Duster(BaseModel):
         """-> (raw network outputs [2 views, 2 directed pairs, ...], upstream's inference dictionary); no state is kept on the
         plugin object: the UI calls one model from several worker threads."""
         img0, img1 = data["image0"], data["image1"]
-        if img0.shape != img1.shape or img0.shape[0] != 1:
-            raise ValueError("DUSt3R expects one pair of images of one size (the wrapper's preprocess guarantees it)")
+        if img0.shape[0] != 1 or img1.shape[0] != 1:
+            raise ValueError("DUSt3R matches one image pair per call (batch 1, as the reference wrapper)")
+        if img0.shape != img1.shape:
+            raise ValueError(f"the HIP DUSt3R path needs both images at ONE size (got {tuple(img0.shape[-2:])} and {tuple(img1.shape[-2:])}): "
+                             "upstream encodes views of different sizes separately, imcui_hip_dust3r_forward has one token grid per call -- "
+                             "resize the pair to a common size (multiples of 16) before the matcher")
         H, W = img0.shape[-2:]
         if H % 16 or W % 16:
             raise ValueError(f"DUSt3R needs image sizes that are multiples of the patch size 16 (the wrapper's preprocess rounds to it), got {W}x{H}")
@@ -88,24 +101,28 @@ class Duster(BaseModel):
             "loss": None,
         }
 
-    def _forward(self, data):
-        output = self.inference_output(data)
+    @staticmethod
+    def aligner(output: dict, device):
+        """duster.py:74: `global_aligner(output, device=device, mode=GlobalAlignerMode.PairViewer)` -- upstream's package (host
+        geometry: focal estimation, cv2.solvePnPRansac).  Replaceable (tests mock it; a deployment may bind its own)."""
         try:
             from dust3r.cloud_opt import GlobalAlignerMode, global_aligner
-            from dust3r.utils.geometry import find_reciprocal_matches, xy_grid
         except ImportError as e:
             raise ImportError(
-                "the DUSt3R network ran on the HIP backend (see inference_output()); the pose / reciprocal-matching steps of "
-                "imcui/hloc/matchers/duster.py:74-108 use upstream's `dust3r` package (third_party/dust3r) and cv2, which are not installed"
+                "the DUSt3R network ran on the HIP backend (see inference_output()); the pose step of imcui/hloc/matchers/duster.py:74 "
+                "(global_aligner, PairViewer) uses upstream's `dust3r` package (third_party/dust3r) and cv2, which are not installed"
             ) from e
-        scene = global_aligner(output, device=data["image0"].device, mode=GlobalAlignerMode.PairViewer)
-        masks = [m.cpu().numpy() for m in scene.get_masks()]
-        clouds = [p.detach().cpu().numpy()[m] for p, m in zip(scene.get_pts3d(), masks)]
-        empty = {"keypoints0": torch.zeros([0, 2]), "keypoints1": torch.zeros([0, 2])}
+        return global_aligner(output, device=device, mode=GlobalAlignerMode.PairViewer)
+
+    def matches_from_scene(self, imgs, masks, pts3d) -> dict:
+        """duster.py:76-108 after the aligner: `imgs` [2] arrays [H, W, 3], `masks` [2] boolean [H, W] (scene.get_masks()),
+        `pts3d` [2] arrays [H, W, 3] (scene.get_pts3d()) -> {"keypoints0", "keypoints1"} in pixels (x, y) of image0 / image1."""
+        masks = [np.asarray(m.cpu() if torch.is_tensor(m) else m, dtype=bool) for m in masks]
+        clouds = [np.asarray(p.detach().cpu() if torch.is_tensor(p) else p)[m] for p, m in zip(pts3d, masks)]
+        # pixel coordinates of the confident points of either image, in the order of `clouds` (xy_grid(W, H)[mask])
+        pixels = [xy_grid(im.shape[1], im.shape[0])[m] for im, m in zip(imgs, masks)]
         if len(clouds[1]) == 0:
-            return empty
-        # pixel coordinates of the confident points of either image, in the order of `clouds`
-        pixels = [xy_grid(im.shape[1], im.shape[0])[m] for im, m in zip(scene.imgs, masks)]
+            return {"keypoints0": torch.zeros([0, 2]), "keypoints1": torch.zeros([0, 2])}
         in_p2, nn_in_p1, _ = find_reciprocal_matches(clouds[0], clouds[1])
         k1 = pixels[1][in_p2]
         k0 = pixels[0][nn_in_p1][in_p2]
@@ -114,3 +131,27 @@ class Duster(BaseModel):
             pick = np.round(np.linspace(0, len(k0) - 1, limit)).astype(int)
             k0, k1 = k0[pick], k1[pick]
         return {"keypoints0": torch.from_numpy(k0), "keypoints1": torch.from_numpy(k1)}
+
+    def _forward(self, data):
+        output = self.inference_output(data)
+        scene = self.aligner(output, data["image0"].device)
+        return self.matches_from_scene(scene.imgs, scene.get_masks(), scene.get_pts3d())
+
+
+def xy_grid(W: int, H: int) -> np.ndarray:
+    """upstream dust3r.utils.geometry.xy_grid(W, H): [H, W, 2] int32 with out[j, i] = (i, j)."""
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.int32), np.arange(H, dtype=np.int32), indexing="xy")
+    return np.stack((xs, ys), -1)
+
+
+def find_reciprocal_matches(P1: np.ndarray, P2: np.ndarray):
+    """upstream dust3r.utils.geometry.find_reciprocal_matches: nearest neighbours both ways with two KD-trees (Euclidean, the
+    first of equal candidates as scipy's tree returns it); -> (reciprocal_in_P2 [len(P2)] bool, nn2_in_P1 [len(P2)] int, count)."""
+    from scipy.spatial import cKDTree
+
+    if len(P1) == 0:
+        return np.zeros(len(P2), dtype=bool), np.zeros(len(P2), dtype=np.int64), 0
+    _, nn1_in_p2 = cKDTree(P2).query(P1, workers=8)
+    _, nn2_in_p1 = cKDTree(P1).query(P2, workers=8)
+    reciprocal_in_p2 = nn1_in_p2[nn2_in_p1] == np.arange(len(nn2_in_p1))
+    return reciprocal_in_p2, nn2_in_p1, int(reciprocal_in_p2.sum())

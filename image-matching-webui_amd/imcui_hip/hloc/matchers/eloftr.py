@@ -6,11 +6,17 @@ image0", :69-78), the top-k matches by confidence are kept with `argsort(descend
 back (:100) and `mconf` becomes `scores`.  The model itself (the 'full' EfficientLoFTR, fp32, after `reparameter()`,
 :56-61) runs in libimcui_hip (imcui_hip_eloftr_forward).
 
-Weights: conf["state_dict"] / conf["weights_path"] with the parameter names of the maintained port
-(`transformers.EfficientLoFTRForKeypointMatching.state_dict()`, e.g. the `zju-community/efficientloftr` checkpoint).
-The upstream `eloftr_outdoor.ckpt` the reference downloads stores the same tensors under the upstream module names (its
-sources are an un-vendored submodule, absent from the reference tree, so the name mapping cannot be verified here): such
-a checkpoint is refused with a clear message rather than mapped by guesswork -- convert it once with the port.
+Weights: conf["state_dict"] / conf["weights_path"], in either naming:
+  * the UPSTREAM names of `eloftr_outdoor.ckpt`, the file the reference downloads and loads with
+    `torch.load(...)["state_dict"]` -> `ELoFTR_(config).load_state_dict` -> `reparameter()` (eloftr.py:56-61):
+    `matcher.backbone.layer{0..3}[.{block}].{rbr_dense,rbr_1x1}.{conv,bn}`, `.rbr_identity`, `matcher.loftr_coarse.layers.{0..7}.
+    {aggregate,norm1,q_proj,k_proj,v_proj,merge,mlp.0,mlp.2,norm2}`, `matcher.fine_preprocess.layer{3,2,1}_outconv[2.{0,1,3}]`
+    (with or without the Lightning `matcher.` prefix).  `upstream_to_port_names` maps them onto the port's names; the map is
+    total and one-to-one on the 447 tensors of the model (checked at load: every port key produced exactly once, no source key
+    left over, shapes confirmed by the packer against `imcui_hip_eloftr_layer_shape`), and `port_to_upstream_names` is its
+    inverse (round-trip test: tests/test_host_cpu.py).  Both trees use the interleaved rotary pairs (upstream
+    `x[..., ::2], x[..., 1::2]` = the port's Cohere-style `rotate_half`), so no projection rows are permuted;
+  * the names of the maintained port (`transformers.EfficientLoFTRForKeypointMatching.state_dict()`).
 
 Image pairs whose two images differ in size are accepted (the batch path of `match_dense.py` produces them).
 
@@ -19,22 +25,101 @@ hosts; the HIP path always computes the 'full' network with fp32-grade arithmeti
 """
 from __future__ import annotations
 
+import re
+
 import torch
 
 from ... import backend
 from ..utils.base_model import BaseModel
 from ..utils.weights import resolve_state_dict
 
-def check_port_names(sd: dict) -> dict:
-    """The HIP packer reads the port's parameter names.  An upstream-named checkpoint (`matcher.backbone...`,
-    `loftr_coarse...`) is refused with a pointer to the conversion instead of being mapped by guesswork: the upstream
-    module tree cannot be confirmed offline and a silent mis-assignment would produce plausible but wrong matches."""
-    if not any(k.startswith("efficientloftr.") for k in sd) or not any(k.startswith("refinement_layer.") for k in sd):
-        raise KeyError(
-            "EfficientLoFTR weights must use the parameter names of transformers.EfficientLoFTRForKeypointMatching "
-            f"(got keys like {next(iter(sd))!r}); load the upstream checkpoint into the port once and save its state_dict()"
-        )
-    return sd
+_BB = "efficientloftr.backbone.stages."
+_TR = "efficientloftr.local_feature_transformer.layers."
+_RF = "refinement_layer."
+# upstream module tree -> port module tree (prefix rewrites; the tensor suffix .weight / .bias / .running_* is kept)
+_LAYER_PARTS = {"aggregate": "aggregation.q_aggregation", "norm1": "aggregation.norm", "q_proj": "attention.q_proj", "k_proj": "attention.k_proj",
+                "v_proj": "attention.v_proj", "merge": "attention.o_proj", "mlp.0": "mlp.fc1", "mlp.2": "mlp.fc2", "norm2": "mlp.layer_norm"}
+_RBR = {"rbr_dense.conv": "conv1.conv", "rbr_dense.bn": "conv1.norm", "rbr_1x1.conv": "conv2.conv", "rbr_1x1.bn": "conv2.norm", "rbr_identity": "identity"}
+_FINE = {"layer3_outconv": "out_conv", "layer2_outconv": "out_conv_layers.0.out_conv1", "layer2_outconv2.0": "out_conv_layers.0.out_conv2",
+         "layer2_outconv2.1": "out_conv_layers.0.batch_norm", "layer2_outconv2.3": "out_conv_layers.0.out_conv3",
+         "layer1_outconv": "out_conv_layers.1.out_conv1", "layer1_outconv2.0": "out_conv_layers.1.out_conv2",
+         "layer1_outconv2.1": "out_conv_layers.1.batch_norm", "layer1_outconv2.3": "out_conv_layers.1.out_conv3"}  # fmt: skip
+
+
+def _upstream_key(k: str) -> str | None:
+    """One upstream parameter name -> the port's name (None: a key the network does not own, e.g. a loss buffer)."""
+    k = k[len("matcher."):] if k.startswith("matcher.") else k
+    m = re.fullmatch(r"backbone\.layer(\d+)\.(?:(\d+)\.)?(rbr_dense\.conv|rbr_dense\.bn|rbr_1x1\.conv|rbr_1x1\.bn|rbr_identity)\.(.+)", k)
+    if m:
+        stage, block, part, leaf = m.groups()
+        if (stage == "0") != (block is None):
+            return None  # layer0 is a single block, layers 1-3 are sequences
+        return f"{_BB}{stage}.blocks.{block or 0}.{_RBR[part]}.{leaf}"
+    m = re.fullmatch(r"loftr_coarse\.layers\.(\d+)\.(aggregate|norm1|q_proj|k_proj|v_proj|merge|mlp\.0|mlp\.2|norm2)\.(.+)", k)
+    if m:
+        i, part, leaf = int(m.group(1)), m.group(2), m.group(3)
+        return f"{_TR}{i // 2}.{'self_attention' if i % 2 == 0 else 'cross_attention'}.{_LAYER_PARTS[part]}.{leaf}"  # layer_names = [self, cross] x 4
+    m = re.fullmatch(r"fine_preprocess\.(layer3_outconv|layer[12]_outconv2\.[013]|layer[12]_outconv)\.(.+)", k)
+    if m:
+        return f"{_RF}{_FINE[m.group(1)]}.{m.group(2)}"
+    return None
+
+
+def upstream_to_port_names(sd: dict) -> dict:
+    """State dict of upstream `EfficientLoFTR/src/loftr.LoFTR` (what `eloftr_outdoor.ckpt["state_dict"]` holds) under the
+    parameter names the HIP packer reads.  Raises on any tensor of the three sub-networks it cannot place and on collisions."""
+    out, unknown = {}, []
+    for k, v in sd.items():
+        nk = _upstream_key(k)
+        if nk is None:
+            kk = k[len("matcher."):] if k.startswith("matcher.") else k
+            if kk.startswith(("backbone.", "loftr_coarse.", "fine_preprocess.")):
+                unknown.append(k)
+            continue  # anything else (position-encoding buffers, training-only heads) carries no inference weights
+        if nk in out:
+            raise KeyError(f"EfficientLoFTR checkpoint: {k!r} maps onto {nk!r} twice")
+        out[nk] = v
+    if unknown:
+        raise KeyError(f"EfficientLoFTR checkpoint: unrecognised tensors of the network, e.g. {unknown[:3]}")
+    return out
+
+
+def port_to_upstream_names(sd: dict, prefix: str = "matcher.") -> dict:
+    """Inverse of `upstream_to_port_names` (used by the round-trip test and to export weights for the reference wrapper)."""
+    inv_rbr = {v: k for k, v in _RBR.items()}
+    inv_parts = {v: k for k, v in _LAYER_PARTS.items()}
+    inv_fine = {v: k for k, v in _FINE.items()}
+    out = {}
+    for k, v in sd.items():
+        m = re.fullmatch(re.escape(_BB) + r"(\d+)\.blocks\.(\d+)\.(conv1\.conv|conv1\.norm|conv2\.conv|conv2\.norm|identity)\.(.+)", k)
+        if m:
+            stage, block, part, leaf = m.groups()
+            mid = "" if stage == "0" else f"{block}."
+            out[f"{prefix}backbone.layer{stage}.{mid}{inv_rbr[part]}.{leaf}"] = v
+            continue
+        m = re.fullmatch(re.escape(_TR) + r"(\d+)\.(self_attention|cross_attention)\.(.+)\.(weight|bias)", k)
+        if m:
+            i = 2 * int(m.group(1)) + (m.group(2) == "cross_attention")
+            out[f"{prefix}loftr_coarse.layers.{i}.{inv_parts[m.group(3)]}.{m.group(4)}"] = v
+            continue
+        m = re.fullmatch(re.escape(_RF) + r"(out_conv_layers\.\d\.(?:out_conv[123]|batch_norm)|out_conv)\.(.+)", k)
+        if m:
+            out[f"{prefix}fine_preprocess.{inv_fine[m.group(1)]}.{m.group(2)}"] = v
+            continue
+        raise KeyError(f"not a parameter of the EfficientLoFTR port: {k!r}")
+    return out
+
+
+def to_port_names(sd: dict) -> dict:
+    """Accept either naming; refuse anything else loudly (a silent mis-assignment would produce plausible but wrong matches)."""
+    if any(k.startswith("efficientloftr.") for k in sd) and any(k.startswith("refinement_layer.") for k in sd):
+        return sd
+    if any(re.match(r"(matcher\.)?backbone\.layer0\.rbr_dense\.conv\.weight$", k) for k in sd):
+        return upstream_to_port_names(sd)
+    raise KeyError(
+        "EfficientLoFTR weights must use the upstream names of eloftr_outdoor.ckpt (matcher.backbone.layer0.rbr_dense...) or those of "
+        f"transformers.EfficientLoFTRForKeypointMatching (got keys like {next(iter(sd))!r})"
+    )
 
 
 class ELoFTR(BaseModel):
@@ -53,7 +138,7 @@ class ELoFTR(BaseModel):
         sd = resolve_state_dict(conf, "eloftr")
         if "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
-        sd = check_port_names(sd)
+        sd = to_port_names(sd)
         self.conf.pop("state_dict", None)
         self.register_buffer("packed", backend.pack_eloftr(sd), persistent=False)
         self._impl = backend.ELoFTRHIP()

@@ -337,6 +337,45 @@ def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int
     return torch.from_numpy(np.c_[a % W1, a // W1]), torch.from_numpy(np.c_[b % W2, b // W2])
 
 
+def duster_matches_from_scene(imgs, masks, pts3d, max_keypoints=3000):
+    """The wrapper's steps after `global_aligner` (imcui/hloc/matchers/duster.py:76-108), restated with brute-force numpy:
+    confidence masks select points (:80-86: `xy_grid(W, H)[conf_i]`, `pts3d[i][conf_i]`), `find_reciprocal_matches(P1, P2)`
+    (upstream dust3r/utils/geometry.py: `nn1_in_P2 = tree2.query(P1)`, `nn2_in_P1 = tree1.query(P2)`, a point j of P2 is kept
+    when `nn1_in_P2[nn2_in_P1[j]] == j`), `mkpts1 = pts2d[1][reciprocal_in_P2]`, `mkpts0 = pts2d[0][nn2_in_P1][reciprocal_in_P2]`
+    (:97-98), then `np.round(np.linspace(0, n - 1, top_k))` (:100-103).  Nearest neighbours are exhaustive float64 distance
+    arg-mins (first index on ties), so the KD-trees of the product are checked by an independent search.  Test infrastructure."""
+    import numpy as np
+
+    px, pts = [], []
+    for im, m, p in zip(imgs, masks, pts3d):
+        m = np.asarray(m, dtype=bool)
+        H, W = im.shape[:2]
+        grid = np.zeros((H, W, 2), dtype=np.int32)
+        for y in range(H):
+            for x in range(W):
+                grid[y, x] = (x, y)
+        px.append(grid[m])
+        pts.append(np.asarray(p, dtype=np.float64)[m])
+    if len(pts[1]) == 0:
+        return np.zeros((0, 2), dtype=np.int32), np.zeros((0, 2), dtype=np.int32)
+
+    def nearest(q, db):
+        out = np.zeros(len(q), dtype=np.int64)
+        for i in range(len(q)):
+            out[i] = np.argmin(((db - q[i]) ** 2).sum(1))
+        return out
+
+    nn1_in_p2 = nearest(pts[0], pts[1]) if len(pts[0]) else np.zeros(0, dtype=np.int64)
+    nn2_in_p1 = nearest(pts[1], pts[0]) if len(pts[0]) else np.zeros(len(pts[1]), dtype=np.int64)
+    keep2 = np.array([len(pts[0]) > 0 and nn1_in_p2[nn2_in_p1[j]] == j for j in range(len(pts[1]))], dtype=bool)
+    k1 = px[1][keep2]
+    k0 = px[0][nn2_in_p1][keep2] if len(pts[0]) else np.zeros((0, 2), dtype=np.int32)
+    if max_keypoints is not None and len(k0) > max_keypoints:
+        sel = np.round(np.linspace(0, len(k0) - 1, max_keypoints)).astype(int)
+        k0, k1 = k0[sel], k1[sel]
+    return k0, k1
+
+
 def num_params(cfg: dict | None = None) -> int:
     c = {**DEFAULT_CFG, **(cfg or {})}
     E, D = c["enc_dim"], c["dec_dim"]

@@ -366,3 +366,69 @@ def test_packed_gemm_planes_reconstruct_the_state_dict():
             l0 = base + 7 * i + j
             assert lib.imcui_hip_dust3r_layer_offsets(*c5, l0, *[C.byref(o) for o in off], C.byref(kind)) == 0
             assert raw[off[3].value + 1] == scales[l0 + 7 * nd]
+
+
+def test_duster_forward_with_a_mocked_aligner(monkeypatch):
+    """`Duster._forward` end to end on CPU: the device call is replaced by the oracle network, `global_aligner` (cv2 PnP-RANSAC,
+    host geometry that stays upstream's) by a scene that hands the network's own point maps back -- view 1 of (image0, image1) and
+    view 2 expressed in view 1's frame, which is what PairViewer returns up to its re-projection -- with masks conf > median.
+    The plugin's mask / pixel-grid / reciprocal-3-D-neighbour / linspace steps (KD-trees) must equal the brute-force restatement
+    (`oracle/dust3r.py: duster_matches_from_scene`, imcui/hloc/matchers/duster.py:76-108)."""
+    import numpy as np
+
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.duster import Duster, find_reciprocal_matches, xy_grid
+    from oracle.dust3r import duster_matches_from_scene
+
+    cfg = {"enc_dim": 128, "enc_depth": 1, "dec_dim": 64, "dec_depth": 4}
+    sd = dust3r_state_dict(41, cfg)
+    ora = DUSt3ROracle(sd, cfg)
+
+    def fake_forward(self, packed, net_cfg, images, pairs, dump=False, arith=0):
+        norm = (images - 0.5) / 0.5
+        res = [ora.forward(norm[a : a + 1], norm[b : b + 1]) for a, b in pairs]
+        return {"pts3d": torch.stack([torch.cat([r[0]["pts3d"] for r in res]), torch.cat([r[1]["pts3d_in_other_view"] for r in res])]),
+                "conf": torch.stack([torch.cat([r[0]["conf"] for r in res]), torch.cat([r[1]["conf"] for r in res])])}
+
+    class Scene:
+        def __init__(self, output):
+            # batch entry 1 of the inference dictionary is the directed pair (image0, image1)
+            self.imgs = [np.zeros(tuple(output["view1"]["img"].shape[-2:]) + (3,), dtype=np.float32)] * 2
+            self._pts = [output["pred1"]["pts3d"][1], output["pred2"]["pts3d_in_other_view"][1]]
+            c = [output["pred1"]["conf"][1], output["pred2"]["conf"][1]]
+            self._masks = [ci > ci.median() for ci in c]
+
+        def get_masks(self):
+            return self._masks
+
+        def get_pts3d(self):
+            return self._pts
+
+    monkeypatch.setattr(backend.DUSt3RHIP, "forward", fake_forward)
+    monkeypatch.setattr(Duster, "aligner", staticmethod(lambda output, device: Scene(output)))
+    model = Duster({"state_dict": sd, "max_keypoints": 40}).eval()
+    g = torch.Generator().manual_seed(42)
+    i0, i1 = torch.rand(1, 3, 48, 64, generator=g), torch.rand(1, 3, 48, 64, generator=g)
+    pred = model({"image0": i0, "image1": i1})
+    sc = Scene(model.inference_output({"image0": i0, "image1": i1}))
+    k0, k1 = duster_matches_from_scene(sc.imgs, [m.numpy() for m in sc.get_masks()], [p.numpy() for p in sc.get_pts3d()], 40)
+    assert pred["keypoints0"].shape == pred["keypoints1"].shape and pred["keypoints0"].shape[1] == 2
+    assert 5 < len(k0) <= 40
+    assert np.array_equal(pred["keypoints0"].numpy(), k0) and np.array_equal(pred["keypoints1"].numpy(), k1)
+    # unlimited: every reciprocal pair, no sub-sampling
+    model.conf["max_keypoints"] = None
+    full = model({"image0": i0, "image1": i1})
+    f0, f1 = duster_matches_from_scene(sc.imgs, [m.numpy() for m in sc.get_masks()], [p.numpy() for p in sc.get_pts3d()], None)
+    assert np.array_equal(full["keypoints0"].numpy(), f0) and np.array_equal(full["keypoints1"].numpy(), f1) and len(f0) >= len(k0)
+    # building blocks: grid convention and the reciprocity rule on a hand-made case
+    assert xy_grid(3, 2).tolist() == [[[0, 0], [1, 0], [2, 0]], [[0, 1], [1, 1], [2, 1]]]
+    P1 = np.array([[0.0, 0, 0], [10, 0, 0], [5, 5, 0]])
+    P2 = np.array([[0.1, 0, 0], [9, 0, 0], [9.5, 0, 0], [100, 0, 0]])
+    rec, nn, n = find_reciprocal_matches(P1, P2)
+    assert nn.tolist() == [0, 1, 1, 1] and rec.tolist() == [True, False, True, False] and n == 2
+    # an empty second cloud is the reference's "Matched 0 points" branch
+    empty = model.matches_from_scene(sc.imgs, [sc.get_masks()[0], torch.zeros_like(sc.get_masks()[1])], sc.get_pts3d())
+    assert empty["keypoints0"].shape == (0, 2) and empty["keypoints1"].shape == (0, 2)
+    # unequal sizes are refused with a message that names the restriction
+    with pytest.raises(ValueError, match="ONE size"):
+        model({"image0": i0, "image1": torch.rand(1, 3, 64, 64)})
