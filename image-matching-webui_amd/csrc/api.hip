@@ -168,6 +168,40 @@ extern "C" int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const 
     return gemm_launch(h, g, (hipStream_t)stream);
 }
 
+extern "C" int imcui_hip_qkv_split_f32(imcui_hip_t* h, const float* x, const unsigned short* wh, const unsigned short* wl,
+                                       const float* wscale, const float* bias, const float* rope_cos, const float* rope_sin,
+                                       const int* cnt, int nseq, int rows_per_seq, float alpha, int cross, float* q, float* k, float* v,
+                                       void* stream) {
+    if (!h || !x || !wh || !wl || !wscale || !cnt || !q || !v || (!cross && (!k || !rope_cos || !rope_sin)))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "qkv_split: null argument");
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "qkv_split: needs precision 1 (3 x f16 split)");
+    GemmP g;
+    g.epi = cross ? EPI_CROSS : EPI_QKV;
+    g.M = nseq * rows_per_seq;
+    g.cnt = cnt;
+    g.rows_per_seq = rows_per_seq;
+    g.A = x;
+    g.lda = 256;
+    g.K = 256;
+    g.N = cross ? 512 : 768;
+    g.Wh = wh;
+    g.Wl = wl;
+    g.wscale = wscale;
+    g.ldw = 256;
+    g.bias = bias;
+    g.v_transposed = 1;
+    g.split_out = 1;
+    g.plane_halves = (size_t)nseq * rows_per_seq * 256;
+    g.Q = q;
+    g.Kt = k;
+    g.V = v;
+    g.rope_cos = rope_cos;
+    g.rope_sin = rope_sin;
+    g.alpha = alpha;
+    g.heads = 4;
+    return gemm_launch(h, g, (hipStream_t)stream);
+}
+
 extern "C" float imcui_hip_ffn_pack_w2(const float* w2, unsigned short* hi, unsigned short* lo) {
     if (!w2 || !hi || !lo) return 0.0f;
     float* perm = (float*)malloc((size_t)256 * 512 * sizeof(float));

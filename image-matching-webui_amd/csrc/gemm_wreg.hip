@@ -172,27 +172,44 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 ba = *reinterpret_cast<const float4*>(c.bias + fw0 + d0);
                 bb = *reinterpret_cast<const float4*>(c.bias + fw0 + d0 + 4);
             }
+            // rotary tables of the wave's next 32 tokens are requested one m-step ahead (two register sets): a lane needs
+            // cos / sin of 4 tokens x 4 frequencies per step, and with only two waves per SIMD nothing else hides the latency
+            float4 tc[2][4], ts[2][4];
+            auto load_tables = [&](int m, float4(&cs)[4], float4(&sn)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const size_t row = (size_t)(c.row0 + 32 * m + pass * 8 + (lane >> 3));
+                    cs[pass] = *reinterpret_cast<const float4*>(p.rope_cos + row * 32 + (d0 >> 1));
+                    sn[pass] = *reinterpret_cast<const float4*>(p.rope_sin + row * 32 + (d0 >> 1));
+                }
+            };
+            if (rope) load_tables(0, tc[0], ts[0]);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 park_rows(m);
                 wr_wave_fence();
+                if (rope && m + 1 < 4) load_tables(m + 1, tc[(m + 1) & 1], ts[(m + 1) & 1]);
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int tl = pass * 8 + (lane >> 3);
-                    const int row = c.row0 + 32 * m + tl;
                     const float4 va = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0);
                     const float4 vb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0 + 4);
                     float v[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
                     if (rope) {
-                        const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + (size_t)row * 32 + (d0 >> 1));
-                        const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (size_t)row * 32 + (d0 >> 1));
+                        const float4 cs = tc[m & 1][pass], sn = ts[m & 1][pass];
                         const float cw[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0)   (same expression as gemm.hip)
-                            const float a0 = v[2 * j], a1 = v[2 * j + 1];
-                            v[2 * j] = a0 * cw[j] + (-a1) * ss[j];
-                            v[2 * j + 1] = a1 * cw[j] + a0 * ss[j];
+                            // x*cos + rotate_half(x)*sin ; rotate_half: (x0,x1) -> (-x1, x0).  Written as explicit fused
+                            // multiply-adds on values made opaque to the vectoriser: hipcc's SLP pass packed these four
+                            // rotations into v_pk_fma_f32 / v_pk_mul_f32 with op_sel swizzles and in-place destinations, and
+                            // that sequence returned wrong even elements in lanes 48-63 of a few waves per launch on gfx950
+                            // (round 3, tools/r03_diag2.py: run-to-run differences, always element 2 of a lane's 8; the
+                            // scalar form is bit-stable).  The translation unit is also built with -fno-slp-vectorize.
+                            float a0 = v[2 * j], a1 = v[2 * j + 1];
+                            asm volatile("" : "+v"(a0), "+v"(a1));
+                            v[2 * j] = __builtin_fmaf(a0, cw[j], -(a1 * ss[j]));
+                            v[2 * j + 1] = __builtin_fmaf(a1, cw[j], a0 * ss[j]);
                         }
                     }
                     if (scale) {

@@ -1013,6 +1013,28 @@ def linear_split_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
     return c
 
 
+def qkv_split_f32(x: torch.Tensor, w: torch.Tensor, bias, cos, sin, cnt: torch.Tensor, rows_per_seq: int, alpha: float, cross: bool = False):
+    """Building block: the attention-layout projection (imcui_hip_qkv_split_f32).  x [nseq * R, 256] (device), w [768 | 512, 256]
+    (host, packed row order) -> int16 views of the planes: q, k [2, nseq, 4, R, 64], vt [2, nseq, 4, 64, R] (plane 0 = hi)."""
+    hd = get_handle(x.device)
+    x = x.contiguous().float()
+    R = int(rows_per_seq)
+    nseq = x.shape[0] // R
+    hi, lo, sc = pack_linear_split(w)
+    dev = x.device
+    dh = torch.from_numpy(hi.view(np.int16)).to(dev)
+    dl = torch.from_numpy(lo.view(np.int16)).to(dev)
+    ds = torch.tensor([sc], dtype=torch.float32, device=dev)
+    q = torch.zeros((2, nseq, 4, R, 64), dtype=torch.int16, device=dev)
+    k = torch.zeros((2, nseq, 4, R, 64), dtype=torch.int16, device=dev)
+    v = torch.zeros((2, nseq, 4, 64, R), dtype=torch.int16, device=dev)
+    cnt = cnt.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        hd.check(hd.lib.imcui_hip_qkv_split_f32(hd.h, _ptr(x), _ptr(dh), _ptr(dl), _ptr(ds), _ptr(bias), _ptr(cos), _ptr(sin), _ptr(cnt), nseq, R,
+                                                float(alpha), int(cross), _ptr(q), _ptr(k), _ptr(v), _stream_ptr()), "qkv_split")
+    return q, k, v
+
+
 def pack_ffn_w2(w2: torch.Tensor):
     """Host: ffn.3 weight [256, 512] -> planes in the K order of the fused FFN kernel, and the inverse scale."""
     from .lib_loader import load_library

@@ -17,7 +17,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
 # Per-source code-generation switches.  preprocess.hip restates host float32 arithmetic that rounds after every
 # multiply and every add: hipcc's default FMA contraction would change the last bit.
-EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"]}
+# gemm_wreg.hip: no SLP vectorisation -- hipcc packed the four rotary rotations of a lane into v_pk_fma_f32 / v_pk_mul_f32 with
+# op_sel swizzles and in-place destinations, and on gfx950 that sequence intermittently returned wrong even elements in lanes
+# 48-63 (found with tools/r03_diag2.py in round 3; scalar fused multiply-adds are bit-stable).
+EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"], "gemm_wreg.hip": ["-fno-slp-vectorize"]}
 
 
 def _newest_source_mtime() -> float:

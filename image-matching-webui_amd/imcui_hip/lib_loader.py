@@ -35,6 +35,7 @@ SIGNATURES = {
     "imcui_hip_preprocess_area_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_linear_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_linear_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
+    "imcui_hip_qkv_split_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4),
     "imcui_hip_ffn_pack_w2": (C.c_float, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "imcui_hip_ffn_set_debug": (C.c_int, [C.c_void_p, C.c_void_p]),
     "imcui_hip_ffn_split_f32": (C.c_int, [C.c_void_p] * 14 + [C.c_int, C.c_int, C.c_void_p]),

@@ -350,6 +350,17 @@ float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* 
 int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned short* wh, const unsigned short* wl,
                                const float* wscale, const float* bias, float* C, int M, int N, int K, int relu, void* stream);
 
+/* Projection of a transformer block into the attention kernels' operand layout (upstream LightGlue SelfBlock `Wqkv` + rotary
+ * encoding, CrossBlock `to_qk` / `to_v`; reached from imcui/hloc/matchers/lightglue.py:75): x [nseq * rows_per_seq][256] ->
+ * f16 hi / lo planes (hi plane first, lo plane nseq*rows_per_seq*256 halves behind it) of Q, K [seq][head][row][64] and of
+ * V^T [seq][head][64][row], 4 heads.  cross == 0: W [768][256] packed rows (q | k | v), rotary encoding (cos / sin
+ * [rows][32]) on q and k, q *= alpha.  cross == 1: W [512][256] rows (qk | v), no rotation, qk *= alpha, `k` unused.
+ * Weights as planes from imcui_hip_linear_pack_split; precision 1 only; rows_per_seq % 128 == 0; row tiles whose first row is
+ * >= cnt[seq] are skipped.  Building block of the parity tests (both GEMM kernels that implement it are compared). */
+int imcui_hip_qkv_split_f32(imcui_hip_t* h, const float* x, const unsigned short* wh, const unsigned short* wl, const float* wscale,
+                            const float* bias, const float* rope_cos, const float* rope_sin, const int* cnt, int nseq,
+                            int rows_per_seq, float alpha, int cross, float* q, float* k, float* v, void* stream);
+
 /* Fused transformer FFN of a LightGlue block (upstream TransformerLayer.ffn on cat([x, message]) with the attention
  * out-projection folded into W1; reached from imcui/hloc/matchers/lightglue.py:75):
  *   out = x + W2 * GELU(LayerNorm_512(W1 * [x | ctx] + b1)) + b2,   x, ctx, out [M][256] (out may alias x).

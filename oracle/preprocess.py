@@ -86,3 +86,112 @@ def area_resize_f32(image: np.ndarray, size) -> np.ndarray:
             acc = acc + hbuf[idx[k]] * beta[k]
         out[dy] = acc
     return out
+
+
+# ----------------------------------------------------------------------------- growing resize (cv2.INTER_LINEAR)
+def _linear_table(ssize: int, dsize: int):
+    """OpenCV `resize.cpp` (`resizeGeneric_` set-up for INTER_LINEAR, float images): per destination index the left source
+    index and the float32 weight of the RIGHT tap; half-pixel centres, `fx = (float)((dx + 0.5) * scale - 0.5)` with a double
+    `scale = 1 / (dsize / ssize)`, `sx = floor(fx)`, `fx -= sx`; a tap left of the image is pinned to pixel 0 with weight 0,
+    a tap at / beyond the last pixel to the last pixel with weight 0 (horizontal rule).  `clip_rows=True` gives the vertical
+    rule instead: the weight is kept and both row indices are clipped to the image."""
+    inv = dsize / ssize
+    scale = 1.0 / inv
+    idx = np.zeros(dsize, dtype=np.int64)
+    w1 = np.zeros(dsize, dtype=np.float32)
+    for d in range(dsize):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        idx[d], w1[d] = s, f
+    return idx, w1
+
+
+def linear_resize_f32(image: np.ndarray, size) -> np.ndarray:
+    """`cv2.resize(image.astype(float32), (w, h), interpolation=cv2.INTER_LINEAR)` for a 2-D image: what
+    imcui/hloc/extract_features.py:26-32 (`resize_image`, "cv2_area") really runs when either side GROWS.  float32
+    arithmetic in OpenCV's order: horizontal pass `S[sx] * (1 - fx) + S[sx + 1] * fx` per needed source row, then
+    `row0 * (1 - fy) + row1 * fy` (multiply, multiply, add: no fused multiply-add).
+
+    **Parity unpinned** (cv2 is absent): follows the published algorithm of OpenCV 4.x `resize.cpp` (HResizeLinear /
+    VResizeLinear with float weights); whether the library build contracts the two products into an FMA cannot be checked."""
+    w, h = int(size[0]), int(size[1])
+    src = np.ascontiguousarray(image, dtype=np.float32)
+    sh, sw = src.shape
+    xi, xw = _linear_table(sw, w)
+    yi, yw = _linear_table(sh, h)
+    # horizontal rule: out-of-range taps are pinned with weight 0
+    x0, x1, a1 = xi.copy(), xi + 1, xw.copy()
+    left = xi < 0
+    x0[left], x1[left], a1[left] = 0, 0, 0.0
+    right = xi >= sw - 1
+    x0[right], x1[right], a1[right] = sw - 1, sw - 1, 0.0
+    a0 = (np.float32(1.0) - a1).astype(np.float32)
+    hbuf = src[:, x0] * a0[None, :] + src[:, x1] * a1[None, :]
+    # vertical rule: weights kept, row indices clipped
+    y0, y1 = np.clip(yi, 0, sh - 1), np.clip(yi + 1, 0, sh - 1)
+    b1 = yw
+    b0 = (np.float32(1.0) - b1).astype(np.float32)
+    return (hbuf[y0] * b0[:, None] + hbuf[y1] * b1[:, None]).astype(np.float32)
+
+
+def resize_image_cv2_area(image_f32: np.ndarray, size) -> np.ndarray:
+    """`resize_image(image, size, "cv2_area")` (extract_features.py:26-32): INTER_AREA, or INTER_LINEAR as soon as a side grows."""
+    sh, sw = image_f32.shape
+    if sw < size[0] or sh < size[1]:
+        return linear_resize_f32(image_f32, size)
+    return area_resize_f32(image_f32, size)
+
+
+# ----------------------------------------------------------------------------- dfactor resize (torchvision F.resize, antialias=True)
+def aa_table(in_size: int, out_size: int):
+    """ATen `_compute_indices_weights_aa` for the bilinear (triangle) filter, align_corners=False, float32 throughout:
+    per output index the first source index and the normalised float32 weights.  What `torchvision.transforms.functional.resize(
+    image, size, antialias=True)` = `torch.nn.functional.interpolate(mode="bilinear", antialias=True)` evaluates for the float
+    image of extract_features.py:142-148 / match_dense.py:182."""
+    f = np.float32
+    scale = f(in_size) / f(out_size)
+    support = f(1.0) * scale if scale >= 1.0 else f(1.0)
+    invscale = f(1.0) / scale if scale >= 1.0 else f(1.0)
+    tab = []
+    for i in range(out_size):
+        center = scale * (f(i) + f(0.5))
+        xmin = max(int(center - support + f(0.5)), 0)
+        xsize = min(int(center + support + f(0.5)), in_size) - xmin
+        ws, tot = [], f(0)
+        for j in range(xsize):
+            x = (f(j + xmin) - center + f(0.5)) * invscale
+            wv = f(1.0) - abs(x) if abs(x) < 1.0 else f(0)
+            ws.append(f(wv))
+            tot = f(tot + f(wv))
+        tab.append((xmin, np.asarray([f(wv / tot) for wv in ws], dtype=np.float32)))
+    return tab
+
+
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64, one rounding to float64 then to float32."""
+    return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+
+def aa_resize_f32(image: np.ndarray, size_hw) -> np.ndarray:
+    """`F.interpolate(image[None, None], size=(h, w), mode="bilinear", align_corners=False, antialias=True)[0, 0]` on CPU,
+    restated: the separable kernel runs along the width first, then along the height; each output is `src[0] * w[0]`
+    followed by fused multiply-adds in tap order (ATen `basic_loop_aa_*`).  **Pinned**: tests/test_oracle_preprocess.py
+    requires bit-equality with torch itself (the arithmetic the reference runs through torchvision) on a range of sizes."""
+    h, w = int(size_hw[0]), int(size_hw[1])
+    src = np.ascontiguousarray(image, dtype=np.float32)
+    sh, sw = src.shape
+    if (h, w) == (sh, sw):
+        return src.copy()  # torchvision returns the image unchanged when the size already matches
+
+    def one_pass(a, tab):  # along the last axis
+        out = np.zeros((a.shape[0], len(tab)), dtype=np.float32)
+        for i, (xmin, ws) in enumerate(tab):
+            t = a[:, xmin] * ws[0]
+            for j in range(1, len(ws)):
+                t = _fma32(a[:, xmin + j], ws[j], t)
+            out[:, i] = t
+        return out
+
+    t = one_pass(src, aa_table(sw, w))
+    return np.ascontiguousarray(one_pass(np.ascontiguousarray(t.T), aa_table(sh, h)).T)

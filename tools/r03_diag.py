@@ -33,11 +33,14 @@ def run(problems):
     return {k: v.cpu() for k, v in out.items()}
 
 
+DBGS = os.environ.get("DIAG_DBGS", "0").split(",")
 for sizes in ((2048, 2048), (1500, 1300)):
     prob = [synthetic_matching_problem(5, sizes[0], sizes[1], 300)] * 8
-    for mode in ("0", "1", "2"):
-        os.environ["IMCUI_GEMM_WREG"] = mode
-        for stats in ("pass", None):
+    for mode in os.environ.get("DIAG_MODES", "0,1,2").split(","):
+      os.environ["IMCUI_GEMM_WREG"] = mode
+      for dbg in DBGS:
+        os.environ["IMCUI_WREG_DBG"] = dbg
+        for stats in ("pass",):
             if stats:
                 os.environ["IMCUI_LG_ASSIGN_STATS"] = stats
             else:
@@ -61,7 +64,7 @@ for sizes in ((2048, 2048), (1500, 1300)):
             rr = (outs[0]["_layers"] != outs[1]["_layers"])
             same_out = all(torch.equal(outs[0][k], outs[1][k]) for k in ("matches0", "matching_scores0"))
             rep_out = all(torch.equal(o["matching_scores0"][b], o["matching_scores0"][0]) and torch.equal(o["matches0"][b], o["matches0"][0]) for b in range(1, 8))
-            print(f"sizes {sizes} WREG={mode} stats={stats}: layer-replica diffs {len(msg)}; run-to-run layer diffs {int(rr[:, :, :min(sizes)].sum())}; outputs run-to-run equal {same_out}; replicas equal {rep_out}")
+            print(f"sizes {sizes} WREG={mode} DBG={dbg} stats={stats}: layer-replica diffs {len(msg)}; run-to-run layer diffs {int(rr[:, :, :min(sizes)].sum())}; outputs run-to-run equal {same_out}; replicas equal {rep_out}")
             for m in msg[:6]:
                 print("   ", m)
             if not rep_out:
