@@ -960,10 +960,12 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     }
     hipLaunchKernelGGL(lg_match_logit_kernel, rowgrid, blk, 0, stream, w.x, P + l.wmatch, P + l.bmatch, stop, cnt_cur, R,
                        w.ls);
-    // sim[b] = md0[b] . md1[b]^T, reduced to soft-max partials by the GEMM's own epilogue (split mode) or by one extra
-    // pass (exact-f32 mode; IMCUI_LG_ASSIGN_STATS=pass for A/B runs), then ONE pass for both arg-maxes (lightglue_assign.h)
+    // sim[b] = md0[b] . md1[b]^T, then the soft-max partials in one pass over the matrix (default) or from the GEMM's own epilogue
+    // (IMCUI_LG_ASSIGN_STATS=epilogue, split mode: one read of the matrix less, but the 128 v_exp_f32 per thread make the
+    // matrix-pipe-bound GEMM 320 us longer where the HBM-bound pass costs 260 us -- measured 928 vs 931 pairs/s, profiles/r03),
+    // then ONE pass for both arg-maxes (lightglue_assign.h)
     const char* stats_env = getenv("IMCUI_LG_ASSIGN_STATS");
-    const bool epi_stats = split && !(stats_env && strcmp(stats_env, "pass") == 0);
+    const bool epi_stats = split && stats_env && strcmp(stats_env, "epilogue") == 0;
     const int nrp = R / 128, ncp = R / 64, nch = (R + LG2_COLS - 1) / LG2_COLS, nbd = R / LG2_ROWS;
     {
         GemmP g;

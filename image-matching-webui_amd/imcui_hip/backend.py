@@ -979,6 +979,78 @@ def preprocess_area(img_u8: torch.Tensor, size) -> torch.Tensor:
     return out
 
 
+_linear_tables: dict = {}
+_aa_tables: dict = {}
+
+
+def linear_table_host(ssize: int, dsize: int, horizontal: bool):
+    """cv2.INTER_LINEAR tap table (host numpy): (i0, i1, w1)."""
+    lib = load_library()
+    i0, i1, w1 = np.zeros(dsize, dtype=np.int32), np.zeros(dsize, dtype=np.int32), np.zeros(dsize, dtype=np.float32)
+    if lib.imcui_hip_linear_table(ssize, dsize, int(horizontal), i0.ctypes.data, i1.ctypes.data, w1.ctypes.data) != 0:
+        raise ImcuiHipError(f"linear table {ssize} -> {dsize}")
+    return i0, i1, w1
+
+
+def aa_table_host(in_size: int, out_size: int):
+    """ATen anti-aliased bilinear tap table (host numpy): (first, count, weights [out_size, kmax])."""
+    lib = load_library()
+    kmax = lib.imcui_hip_aa_table(in_size, out_size, None, None, None, 0)
+    if kmax <= 0:
+        raise ImcuiHipError(f"aa table {in_size} -> {out_size}")
+    first, count = np.zeros(out_size, dtype=np.int32), np.zeros(out_size, dtype=np.int32)
+    w = np.zeros((out_size, kmax), dtype=np.float32)
+    if lib.imcui_hip_aa_table(in_size, out_size, first.ctypes.data, count.ctypes.data, w.ctypes.data, kmax) != kmax:
+        raise ImcuiHipError(f"aa table {in_size} -> {out_size}")
+    return first, count, w
+
+
+def preprocess_linear(img_u8: torch.Tensor, size) -> torch.Tensor:
+    """Device-side `resize_image(..., "cv2_area")` when a side GROWS (extract_features.py:29-31: cv2.INTER_LINEAR): uint8
+    [B,H,W] / [B,H,W,C] on the device -> gray (cv2 fixed point) -> float32 -> INTER_LINEAR to `size` = (w, h) -> / 255 ->
+    float32 [B,1,h,w]."""
+    if img_u8.dtype != torch.uint8 or img_u8.dim() not in (3, 4):
+        raise ImcuiHipError("preprocess_linear expects uint8 [B,H,W] or [B,H,W,C]")
+    if img_u8.dim() == 3:
+        img_u8 = img_u8[..., None]
+    hd = get_handle(img_u8.device)
+    img_u8 = img_u8.contiguous()
+    B, H, W, Cc = img_u8.shape
+    ow, oh = int(size[0]), int(size[1])
+    key = (W, ow, H, oh, str(img_u8.device))
+    if key not in _linear_tables:
+        _linear_tables[key] = tuple(torch.from_numpy(a).to(img_u8.device) for a in (*linear_table_host(W, ow, True), *linear_table_host(H, oh, False)))
+    tabs = _linear_tables[key]
+    out = torch.empty((B, 1, oh, ow), dtype=torch.float32, device=img_u8.device)
+    with torch.cuda.device(img_u8.device):
+        hd.check(hd.lib.imcui_hip_preprocess_linear_f32(hd.h, _ptr(img_u8), B, H, W, Cc, *[_ptr(t) for t in tabs], _ptr(out), oh, ow, _stream_ptr()),
+                 "preprocess_linear")
+    return out
+
+
+def resize_aa(image: torch.Tensor, size_hw) -> torch.Tensor:
+    """Device-side `torchvision.transforms.functional.resize(image, size, antialias=True)` of a float image [..., H, W]
+    (extract_features.py:142-148, match_dense.py:182): ATen's anti-aliased bilinear arithmetic, bit for bit.  Like torchvision,
+    returns the image unchanged when the size already matches."""
+    oh, ow = int(size_hw[0]), int(size_hw[1])
+    H, W = image.shape[-2:]
+    if (oh, ow) == (H, W):
+        return image
+    hd = get_handle(image.device)
+    src = image.contiguous().float()
+    planes = src.numel() // (H * W)
+    key = (W, ow, H, oh, str(image.device))
+    if key not in _aa_tables:
+        xt, yt = aa_table_host(W, ow), aa_table_host(H, oh)
+        _aa_tables[key] = (tuple(torch.from_numpy(a).to(image.device) for a in xt), xt[2].shape[1], tuple(torch.from_numpy(a).to(image.device) for a in yt), yt[2].shape[1])
+    xt, kx, yt, ky = _aa_tables[key]
+    out = torch.empty((*src.shape[:-2], oh, ow), dtype=torch.float32, device=image.device)
+    with torch.cuda.device(image.device):
+        hd.check(hd.lib.imcui_hip_resize_aa_f32(hd.h, _ptr(src), planes, H, W, _ptr(xt[0]), _ptr(xt[1]), _ptr(xt[2]), kx, _ptr(yt[0]), _ptr(yt[1]),
+                                                _ptr(yt[2]), ky, _ptr(out), oh, ow, _stream_ptr()), "resize_aa")
+    return out
+
+
 def pack_linear_split(w: torch.Tensor):
     """Host: nn.Linear weight [N, K] -> (hi, lo) uint16 fragment-major planes and the inverse scale 2^-e."""
     from .lib_loader import load_library

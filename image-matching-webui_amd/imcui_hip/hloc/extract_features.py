@@ -14,10 +14,12 @@ per `forward_batched` call and the preprocessing on the device:
   * one HDF5 group per image with a dataset per tensor + `image_size`, `keypoints.attrs["uncertainty"]` (:227-235),
     through `utils.h5lite.open_h5` (h5py when installed, the HDF5 C library otherwise).
 
-Differences from the reference, all on the host side of the boundary: colour images are decoded as RGB and reduced to
-gray with cv2's `cvtColor` fixed-point formula (the reference lets `cv2.imread(IMREAD_GRAYSCALE)` do it inside the
-decoder); a resize that GROWS a side (the reference switches to INTER_LINEAR there, :30-31) is not offered on the device
-and raises.
+A resize that GROWS a side runs cv2.INTER_LINEAR like the reference (`resize_image` :29-31), also on the device
+(`backend.preprocess_linear`); `superpoint_max` (force_resize to 640 x 480) therefore accepts images of any size.
+
+Difference from the reference, on the host side of the boundary: colour images are decoded as RGB and reduced to gray with
+cv2's `cvtColor` fixed-point formula (the reference lets `cv2.imread(IMREAD_GRAYSCALE)` do it inside the decoder, which uses
+the same 8-bit kernel for JPEG / PNG colour files).
 """
 from __future__ import annotations
 
@@ -48,24 +50,46 @@ def list_h5_names(path) -> List[str]:
     return list(dict.fromkeys(names))
 
 
-def read_image_u8(path) -> np.ndarray:
-    """Decoded image as uint8 [H,W] (gray files) or [H,W,3] RGB."""
+def read_image_u8(path, grayscale: bool = False) -> np.ndarray:
+    """`read_image(path, grayscale)` of imcui/hloc/utils/io.py:11-21 as uint8: [H,W] when `grayscale`, else [H,W,3] RGB.
+    cv2 (when installed) with the reference's own flags -- IMREAD_GRAYSCALE / IMREAD_COLOR: the decoder applies the EXIF
+    orientation, reduces 16-bit files to 8 bits and drops alpha, and for `grayscale` hands back ITS gray (libjpeg's luma for
+    JPEG), exactly what the reference feeds the extractor.  Without cv2, PIL reproduces those conversions: EXIF transpose,
+    16-bit -> 8-bit by dropping the low byte (cv2's 1/256 scaling), palette / alpha / CMYK -> RGB; gray is then left to the
+    device kernel (cv2's RGB2GRAY fixed point), which is what the UI path (`extract`, :158-161) does with its RGB input."""
     try:
         import cv2
-
-        img = cv2.imread(str(path), cv2.IMREAD_UNCHANGED)
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        img = cv2.imread(str(path), cv2.IMREAD_GRAYSCALE if grayscale else cv2.IMREAD_COLOR)
         if img is None:
             raise ValueError(f"Cannot read image {path}.")
-        if img.ndim == 3:
-            img = img[:, :, :3][:, :, ::-1]  # BGR(A) -> RGB
-        return np.ascontiguousarray(img.astype(np.uint8))
-    except ImportError:
-        from PIL import Image
+        if not grayscale and img.ndim == 3:
+            img = img[:, :, ::-1]  # BGR to RGB
+        return np.ascontiguousarray(img, dtype=np.uint8)
+    from PIL import Image, ImageOps
 
-        with Image.open(str(path)) as im:
-            if im.mode not in ("L", "RGB"):
-                im = im.convert("RGB")
-            return np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy)
+    try:
+        im = Image.open(str(path))
+        im.load()
+    except Exception as e:  # noqa: BLE001
+        raise ValueError(f"Cannot read image {path}.") from e
+    im = ImageOps.exif_transpose(im)
+    if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+        arr = np.asarray(im).astype(np.int64)
+        arr = (arr >> 8) if arr.max() > 255 else arr
+        return np.ascontiguousarray(arr.clip(0, 255).astype(np.uint8))  # a 16-bit gray file: [H,W]
+    if im.mode == "L":
+        arr = np.array(im, dtype=np.uint8)
+        return arr if grayscale else np.repeat(arr[:, :, None], 3, axis=2)  # IMREAD_COLOR replicates gray files
+    if im.mode == "LA":
+        im = im.convert("L")
+        arr = np.array(im, dtype=np.uint8)
+        return arr if grayscale else np.repeat(arr[:, :, None], 3, axis=2)
+    if im.mode != "RGB":
+        im = im.convert("RGB")  # palette, RGBA (alpha dropped), CMYK
+    return np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy); gray conversion runs on the device
 
 
 def image_names(root: Path, conf: SimpleNamespace, paths=None) -> List[str]:
@@ -109,7 +133,7 @@ def preprocess_on_device(img_u8: np.ndarray, conf: SimpleNamespace, device) -> t
     if new is None:
         new = (w, h)
     if new[0] > w or new[1] > h:
-        raise NotImplementedError(f"resize {w}x{h} -> {new[0]}x{new[1]} grows a side: the reference uses INTER_LINEAR there, not offered on the device")
+        return backend.preprocess_linear(t, new)  # resize_image :29-31: INTER_AREA becomes INTER_LINEAR as soon as a side grows
     if new == (w, h) and img_u8.ndim == 3:
         return backend.rgb_to_gray(t) if (h * w) % 4 == 0 else backend.preprocess_area(t, new)
     return backend.preprocess_area(t, new)
@@ -146,8 +170,12 @@ def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half
         items = pending.pop(key, [])
         if not items:
             return
-        out = model.forward_batched(torch.cat([it[1] for it in items], 0))
-        counts = out["num_keypoints"].tolist()
+        batch = torch.cat([it[1] for it in items], 0)
+        if hasattr(model, "forward_checked"):  # counts + selection status in one copy; capacity overflow retried, failures raise
+            out, counts = model.forward_checked(batch)
+        else:
+            out = model.forward_batched(batch)
+            counts = out["num_keypoints"].tolist()
         kp, sc, de = out["keypoints"].cpu().numpy(), out["scores"].cpu().numpy(), out["descriptors"].cpu().numpy()
         with open_h5(feature_path, "a") as fd:
             for b, (name, img, original_size) in enumerate(items):
@@ -171,7 +199,7 @@ def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half
                 grp["keypoints"].attrs["uncertainty"] = uncertainty
 
     for name in names:
-        img_u8 = read_image_u8(image_dir / name)
+        img_u8 = read_image_u8(image_dir / name, pconf.grayscale)
         original_size = np.array(img_u8.shape[:2][::-1])
         img = preprocess_on_device(img_u8, pconf, device)
         key = tuple(img.shape[-2:])

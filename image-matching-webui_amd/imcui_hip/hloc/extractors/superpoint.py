@@ -46,18 +46,23 @@ class SuperPoint(BaseModel):
             image = (image * scale).sum(1, keepdim=True)
         return image
 
-    def _forward(self, data):
-        out = self.forward_batched(data["image"])
-        # ragged lists are the reference contract: ONE device->host copy brings the counts and the status word
+    def forward_checked(self, image: torch.Tensor):
+        """`forward_batched` + the ONE device->host copy that brings the per-image counts and the selection status word; a
+        capacity overflow (status bit 1: `max_keypoints = -1` sizes the outputs by the NMS bound, which only exactly tied
+        scores of flat images can exceed) is retried with room for every pixel, any other non-zero status raises.
+        -> (outputs, counts).  Used by `_forward` and by the batched extraction driver."""
+        out = self.forward_batched(image)
         *counts, status = torch.cat([out["num_keypoints"], out["status"]]).tolist()
         if status & 2:
-            # max_keypoints = -1 sizes the outputs by the NMS bound, which only exactly tied scores (flat images)
-            # can exceed: redo the call with room for every pixel
-            image = data["image"]
             out = self._impl.forward(self.packed, self._gray(image), self.conf, kcap=image.shape[-2] * image.shape[-1])
             *counts, status = torch.cat([out["num_keypoints"], out["status"]]).tolist()
         if status:
             raise backend.ImcuiHipError(f"SuperPoint key-point selection failed (status {status})")
+        return out, counts
+
+    def _forward(self, data):
+        # ragged lists are the reference contract
+        out, counts = self.forward_checked(data["image"])
         kpts = [out["keypoints"][b, :n] for b, n in enumerate(counts)]
         scores = [out["scores"][b, :n] for b, n in enumerate(counts)]
         # reference layout is [256, N]: a transposed view of the row-per-keypoint buffer

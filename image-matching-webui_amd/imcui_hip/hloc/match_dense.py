@@ -23,8 +23,8 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
+from .. import backend
 from .extract_features import preprocess_on_device, read_image_u8
 from .match_features import names_to_pair
 from .utils.h5lite import open_h5
@@ -42,8 +42,7 @@ def preprocess_pair_image(img_u8: np.ndarray, conf: SimpleNamespace, device) -> 
     image = preprocess_on_device(img_u8, area, device)
     hh, ww = image.shape[-2:]
     size_new = (int(hh // conf.dfactor * conf.dfactor), int(ww // conf.dfactor * conf.dfactor))
-    if size_new != (hh, ww):
-        image = F.interpolate(image, size=size_new, mode="bilinear", antialias=True, align_corners=False)
+    image = backend.resize_aa(image, size_new)  # F.resize(image, size=size_new, antialias=True), match_dense.py:182
     scale = np.array([w, h], dtype=np.float64) / np.array(size_new[::-1], dtype=np.float64)
     return image.contiguous(), scale
 
@@ -76,7 +75,7 @@ def match_dense(conf: Dict, pairs: Sequence[Tuple[str, str]], image_dir: Path, m
         if name not in cache:
             if not pconf.cache_images and len(cache) >= 4 * batch_size:
                 cache.pop(next(iter(cache)))
-            cache[name] = preprocess_pair_image(read_image_u8(image_dir / name), pconf, device)
+            cache[name] = preprocess_pair_image(read_image_u8(image_dir / name, pconf.grayscale), pconf, device)
         return cache[name]
 
     pending: Dict[tuple, list] = {}

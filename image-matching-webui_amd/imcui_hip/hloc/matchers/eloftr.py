@@ -166,7 +166,18 @@ class ELoFTR(BaseModel):
             res.append({"keypoints0": k1, "keypoints1": k0, "scores": sc})
         return res
 
+    @staticmethod
+    def _refuse_masks(data):
+        """The reference renames `mask0` / `mask1` and hands them to the net (eloftr.py:70-78); upstream uses them on padded training
+        batches (coarse attention and `sim.masked_fill_(~mask, -inf)`).  No caller of the reference produces them for a
+        single pair (`match_dense.ImagePairDataset`, `match_images`): the HIP path has no masked kernels and refuses the keys
+        instead of silently ignoring them."""
+        for k in ("mask0", "mask1"):
+            if data.get(k) is not None:
+                raise NotImplementedError(f"{k}: padded-batch masks are not supported by the HIP dense matchers (pass un-padded images)")
+
     def _forward(self, data):
+        self._refuse_masks(data)
         out = self.forward_batched(data["image1"], data["image0"])  # the reference refines key-points in image0
         n = int(out["num_matches"][0])
         kp0, kp1, scores = out["keypoints0"][:n], out["keypoints1"][:n], out["confidence"][:n]

@@ -33,6 +33,10 @@ SIGNATURES = {
     "imcui_hip_rgb_to_gray_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_area_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "imcui_hip_preprocess_area_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
+    "imcui_hip_linear_table": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "imcui_hip_preprocess_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p]),
+    "imcui_hip_aa_table": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "imcui_hip_resize_aa_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_linear_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_linear_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
     "imcui_hip_qkv_split_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4),

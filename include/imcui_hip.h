@@ -340,6 +340,30 @@ int imcui_hip_preprocess_area_f32(imcui_hip_t* h, const unsigned char* src, int 
                                   const int* xindex, const float* xweight, const int* ystart, const int* yindex,
                                   const float* yweight, float* out, int oh, int ow, void* stream);
 
+/* Growing resize of the same preprocessing step: `resize_image(image, size, "cv2_area")` runs cv2.INTER_LINEAR as soon as a
+ * side grows (imcui/hloc/extract_features.py:29-31; `superpoint_max` force-resizes every image to 640 x 480).  Host table of
+ * OpenCV's float-image set-up (half-pixel centres, float weights): per destination index the two source indices and the weight
+ * of the second; horizontal = 1 pins out-of-range taps to the border with weight 0, horizontal = 0 (rows) clips the indices. */
+int imcui_hip_linear_table(int ssize, int dsize, int horizontal, int* i0, int* i1, float* w1);
+/* uint8 [B][H][W][C] (C = 1 gray, 3 RGB -> cv2's fixed-point gray) -> float32 [B][1][oh][ow] = INTER_LINEAR(float image) / 255:
+ * horizontal pass of the two rows, then the vertical weights; multiply, multiply, add in float32 (no fused multiply-add).
+ * Tables on the device.  Bit-exact against oracle/preprocess.py: linear_resize_f32 (parity unpinned: cv2 is absent). */
+int imcui_hip_preprocess_linear_f32(imcui_hip_t* h, const unsigned char* src, int B, int H, int W, int C, const int* x0, const int* x1,
+                                    const float* a1, const int* y0, const int* y1, const float* b1, float* out, int oh, int ow,
+                                    void* stream);
+
+/* The dfactor resize of the float image: `F.resize(image, size=size_new, antialias=True)` (extract_features.py:142-148,
+ * match_dense.py:182) = ATen's anti-aliased bilinear kernel.  Host table of `_compute_indices_weights_aa` (float32): first
+ * source index, tap count and normalised weights [out_size][kmax] per output index; returns the largest tap count (call with
+ * w == NULL to size kmax). */
+int imcui_hip_aa_table(int in_size, int out_size, int* first, int* count, float* w, int kmax);
+/* float32 [planes][H][W] -> [planes][oh][ow]: the width pass of every needed source row (src[0] * w[0], then fused
+ * multiply-adds in tap order), then the same along the height -- the arithmetic of ATen's CPU kernel, bit for bit
+ * (tests/test_oracle_preprocess.py pins the restatement to torch; tests/test_gpu_preprocess.py the kernel). */
+int imcui_hip_resize_aa_f32(imcui_hip_t* h, const float* src, int planes, int H, int W, const int* xfirst, const int* xcount,
+                            const float* xweight, int kx, const int* yfirst, const int* ycount, const float* yweight, int ky, float* out,
+                            int oh, int ow, void* stream);
+
 /* nn.Linear weight [N][K] (K % 16 == 0) -> f16 hi / lo planes of w * 2^e in the FRAGMENT-MAJOR order the split GEMM
  * streams ([ceil(N/32)][K/16][2][32][8] halves per plane, rows >= N zero: each 1 KiB block is one MFMA operand
  * fragment of a wave); returns 2^-e (0 on bad arguments).  Planes hold roundup(N,32) * K halves each. */

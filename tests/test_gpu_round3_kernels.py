@@ -111,9 +111,9 @@ def test_lightglue_assignment_epilogue_stats_vs_pass(dc, wc):
     """Soft-max partials from the similarity GEMM's epilogue vs the stand-alone statistics pass: same matches, scores within
     2e-6 (the partial sums are merged in a different grouping: 128-column tiles vs 1024-column chunks)."""
     problems = [synthetic_matching_problem(70 + i, n, m, o) for i, (n, m, o) in enumerate(PROBLEMS)]
-    with _env(IMCUI_LG_ASSIGN_STATS="pass"):
+    with _env(IMCUI_LG_ASSIGN_STATS=None):  # default: the stand-alone statistics pass
         a = _run(dc, wc, problems)
-    with _env(IMCUI_LG_ASSIGN_STATS=None):
+    with _env(IMCUI_LG_ASSIGN_STATS="epilogue"):
         b = _run(dc, wc, problems)
     for k in ("matches0", "matches1", "stop", "prune0", "prune1"):
         assert torch.equal(a[k], b[k]), k

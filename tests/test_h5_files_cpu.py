@@ -134,3 +134,59 @@ def test_extract_driver_host_logic(tmp_path):
     assert sorted(ef.list_h5_names(fpath)) == ["a.png", "sub/b.jpg"]
     out = ef.main({"output": "x", "preprocessing": {"grayscale": True}}, root, feature_path=fpath, model=object())
     assert out == fpath
+
+
+def test_read_image_follows_the_reference_reader(tmp_path):
+    """`read_image` (imcui/hloc/utils/io.py:11-21) decodes with IMREAD_GRAYSCALE / IMREAD_COLOR: the EXIF orientation is applied,
+    16-bit files are reduced to 8 bits, gray / gray+alpha / palette files come back as 3-channel RGB in colour mode.  The reader of
+    the batch drivers must do the same with whichever decoder is installed."""
+    from PIL import Image
+
+    from imcui_hip.hloc import extract_features as ef
+
+    g = np.random.default_rng(0)
+    rgb = (g.random((40, 60, 3)) * 255).astype(np.uint8)
+    # EXIF orientation 6 (rotate 90 degrees clockwise on display): a 60 x 40 file shows as 40 x 60
+    im = Image.fromarray(rgb)
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    im.save(tmp_path / "rot.png", exif=exif)
+    out = ef.read_image_u8(tmp_path / "rot.png")
+    assert out.shape == (60, 40, 3) and out.dtype == np.uint8
+    assert np.array_equal(out, np.rot90(rgb, k=-1))
+    # 16-bit gray PNG: value / 256, not a wrap-around
+    g16 = (g.random((20, 30)) * 65535).astype(np.uint16)
+    Image.fromarray(g16).save(tmp_path / "deep.png")
+    d = ef.read_image_u8(tmp_path / "deep.png", grayscale=True)
+    assert d.shape == (20, 30) and np.array_equal(d, (g16 >> 8).astype(np.uint8))
+    # gray + alpha and palette files: colour mode returns 3 channels, gray mode 2-D
+    la = Image.fromarray(np.stack([rgb[..., 0], np.full((40, 60), 128, np.uint8)], -1), mode="LA")
+    la.save(tmp_path / "la.png")
+    assert ef.read_image_u8(tmp_path / "la.png").shape == (40, 60, 3)
+    assert np.array_equal(ef.read_image_u8(tmp_path / "la.png", grayscale=True), rgb[..., 0])
+    Image.fromarray(rgb).convert("P").save(tmp_path / "pal.png")
+    assert ef.read_image_u8(tmp_path / "pal.png").shape == (40, 60, 3)
+    with pytest.raises(ValueError, match="Cannot read image"):
+        ef.read_image_u8(tmp_path / "missing.png")
+
+
+def test_resize_tables_of_the_library_equal_the_restatements():
+    """The host tap tables the device kernels consume (imcui_hip_linear_table, imcui_hip_aa_table; no GPU needed) against
+    oracle/preprocess.py -- the anti-aliased table is thereby pinned to torch (tests/test_oracle_preprocess.py)."""
+    from imcui_hip import backend
+    from oracle import preprocess as P
+
+    for s, d in ((240, 480), (320, 640), (100, 37), (517, 512)):
+        i0, i1, w1 = backend.linear_table_host(s, d, True)
+        xi, xw = P._linear_table(s, d)
+        x0, x1, a1 = xi.copy(), xi + 1, xw.copy()
+        x0[xi < 0], x1[xi < 0], a1[xi < 0] = 0, 0, 0.0
+        x0[xi >= s - 1], x1[xi >= s - 1], a1[xi >= s - 1] = s - 1, s - 1, 0.0
+        assert np.array_equal(i0, x0) and np.array_equal(i1, x1) and np.array_equal(w1, a1)
+        j0, j1, v1 = backend.linear_table_host(s, d, False)
+        assert np.array_equal(j0, np.clip(xi, 0, s - 1)) and np.array_equal(j1, np.clip(xi + 1, 0, s - 1)) and np.array_equal(v1, xw)
+    for s, d in ((487, 480), (653, 648), (100, 37), (33, 32), (31, 64), (1030, 1024)):
+        first, count, w = backend.aa_table_host(s, d)
+        tab = P.aa_table(s, d)
+        for i, (xmin, ws) in enumerate(tab):
+            assert first[i] == xmin and count[i] == len(ws) and np.array_equal(w[i, : len(ws)], ws) and not w[i, len(ws) :].any()
