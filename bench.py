@@ -115,8 +115,9 @@ def cpu_baseline_dense(eloftr: bool, Hh: int, Ww: int, sd: dict, img0, img1, max
     ora = (ELoFTROracle if eloftr else LoFTROracle)(sd, {"match_threshold": 0.2, "max_keypoints": 2000})
     data = {"image0": img0[:1].cpu(), "image1": img1[:1].cpu()}
     t0 = time.perf_counter()
-    ora(data)
+    ref = ora(data)
     warm = time.perf_counter() - t0
+    cpu_baseline_dense.last_ref = ref  # the warm-up run doubles as the parity reference of pair 0 (bench_loftr)
     times = []
     t_start = time.perf_counter()
     while len(times) < 3 and (not times or time.perf_counter() - t_start + warm < max_seconds):
@@ -127,6 +128,135 @@ def cpu_baseline_dense(eloftr: bool, Hh: int, Ww: int, sd: dict, img0, img1, max
     return {"value": 1.0 / times[len(times) // 2], "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
             "sample": f"median of {len(times)} synthetic {Ww}x{Hh} pair(s) after 1 warm-up, one pair per call, fp32, "
                       f"{'EfficientLoFTR' if eloftr else 'LoFTR'} oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} of {ncpu} host CPUs)"}  # fmt: skip
+
+
+def parity_splg(pipe, img0, img1, dc, wc) -> dict:
+    """"parity checks run with every benchmark".  After the timed region, pair 0 of the bench batch goes through
+    the CPU oracle (the restated reference path) and is compared with what the HIP pipeline returned for it: key-point sets equal or
+    every difference an audited round-off tie, the matcher run on the HIP key-points gives the same stop layer and matches (or
+    audited ties of the oracle's own log-assignment) and scores within 1e-4.  Raises on a violation; the returned record goes into
+    the JSON line so the number printed is bound to a checked output."""
+    from oracle.audit import assert_matches_equal_or_tied, audit_keypoint_differences
+    from oracle.lightglue import LightGlueOracle
+    from oracle.superpoint import SuperPointOracle
+    from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict
+
+    t0 = time.perf_counter()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    spc = dict(nms_radius=3, max_keypoints=MAXK, keypoint_threshold=0.005, remove_borders=4)
+    i0, i1 = img0[:1], img1[:1]
+    f = pipe.extractor.forward_batched(torch.cat([i0, i1]), want_score_map=True)
+    out = pipe(i0, i1)
+    torch.cuda.synchronize()
+    n0, n1 = int(out["num_keypoints0"][0]), int(out["num_keypoints1"][0])
+    sp = SuperPointOracle(superpoint_state_dict(0))
+    ties = 0
+    for b, (img, k, n) in enumerate(((i0, out["keypoints0"], n0), (i1, out["keypoints1"], n1))):
+        ref = sp({"image": img.cpu()}, spc, return_intermediates=True)
+        kp, kr = k[0, :n].cpu(), ref["keypoints"][0]
+        flat_h, flat_r = (kp[:, 1] * W + kp[:, 0]).long(), (kr[:, 1] * W + kr[:, 0]).long()
+        ties += audit_keypoint_differences(flat_h, flat_r, f["score_map"][b].cpu(), ref["_dense_scores"][0], spc, tag=f"bench image {b}")
+        if len(set(flat_h.tolist()) & set(flat_r.tolist())) < 0.99 * len(flat_r):
+            raise AssertionError(f"bench parity: image {b}: key-point sets differ ({n} vs {len(flat_r)})")
+    lg = LightGlueOracle(lightglue_state_dict(0), dict(depth_confidence=dc, width_confidence=wc, filter_threshold=0.1))
+    ref = lg({"image0": i0.cpu(), "image1": i1.cpu(), "keypoints0": out["keypoints0"][0, :n0].cpu()[None], "keypoints1": out["keypoints1"][0, :n1].cpu()[None],
+              "descriptors0": out["descriptors0"][0, :n0].cpu().t()[None], "descriptors1": out["descriptors1"][0, :n1].cpu().t()[None]},
+             return_intermediates=True)  # fmt: skip
+    if int(out["stop"][0]) != ref["stop"]:
+        raise AssertionError(f"bench parity: stop layer {int(out['stop'][0])} vs {ref['stop']}")
+    m_h = out["matches0"][0, :n0].cpu()
+    mt = assert_matches_equal_or_tied(m_h, ref["_log_assignment"][0], ref["matches0"][0], 0.1, tag="bench", ind0=ref.get("_ind0"), ind1=ref.get("_ind1"))
+    same = m_h.long() == ref["matches0"][0]
+    err = (out["matching_scores0"][0, :n0].cpu() - ref["matching_scores0"][0]).abs()[same].max().item()
+    if not err < 1e-4:
+        raise AssertionError(f"bench parity: matching score error {err:.2e}")
+    return {"status": "ok", "checked": "pair 0 of the bench batch vs the CPU oracle, after the timed region", "keypoints": [n0, n1], "keypoint_ties_audited": ties,
+            "matches": int((ref["matches0"] > -1).sum()), "match_ties_audited": mt, "max_score_error": err, "stop_layer": ref["stop"],
+            "seconds": round(time.perf_counter() - t0, 2)}  # fmt: skip
+
+
+def bench_nn(args, dev, rank, world):
+    """configs[0] (the plumbing config): mutual nearest-neighbour matcher on SIFT-like descriptors -- 5000 x 128-d RootSIFT-style rows
+    per image, the matcher zoo's `NN-mutual` conf (imcui/hloc/matchers/nearest_neighbor.py:38-66: ratio test
+    off, distance threshold off, mutual check).  One step = B independent pairs through imcui_hip_mutual_nn; the similarity
+    matrix [5000 x 5000] is written and read twice per pair: HBM-bound, priced against the 8 TB/s peak."""
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.nearest_neighbor import NearestNeighbor
+
+    N, D, B = 5000, 128, args.batch
+    g = torch.Generator().manual_seed(4321 + rank)
+    d0 = torch.rand(B, D, N, generator=g).sqrt()
+    d0 = d0 / d0.norm(dim=1, keepdim=True)  # RootSIFT: non-negative, unit L2 norm
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    d1 = torch.gather(d0, 2, perm[:, None, :].expand(B, D, N)) + 0.05 * torch.randn(B, D, N, generator=g)
+    d1 = d1 / d1.norm(dim=1, keepdim=True)
+    d0, d1 = d0.to(dev), d1.to(dev)
+    model = NearestNeighbor({"ratio_threshold": None, "distance_threshold": None, "do_mutual_check": True}).eval().to(dev)
+
+    def step():
+        return model({"descriptors0": d0, "descriptors1": d1})  # B pairs in one C-ABI call (the reference: one pair per call)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        # algorithmic HBM bytes per pair: descriptors read (2 x N x D x 4), similarity written once and read twice (row pass, column
+        # pass), match tables written
+        alg = 2 * N * D * 4 + 3 * N * N * 4 + 4 * N * 4
+        achieved = alg * B * args.steps / (gpu_ms * 1e-3) / 1e9
+        line = {
+            "metric": "image-pairs/sec mutual nearest-neighbour matcher (5000 x 128-d descriptors)", "value": world * B * args.steps / dt, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if args.precision == 1 else "f32", "data": "synthetic",
+            "config": {"workload": "configs[0] (matcher half): NN-mutual on 5000 x 128-d RootSIFT-like descriptors per image, resident in HBM",
+                       "pairs_per_step_per_gpu": B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), no collective",
+                       "matches_pair0": int((out["matches0"][0] > -1).sum())},
+            "roofline": {"kernel": "nn similarity GEMM + nn_find / nn_mutual passes", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_pair": alg,
+                         "note": "achieved = algorithmic bytes of a pair (similarity written once, read twice) / stream time (HIP events over the timed region)"},
+        }  # fmt: skip
+        # parity: pair 0 against the oracle (pinned to the reference's own module by tests/golden/nn_*.npz)
+        from oracle.mutual_nn import mutual_nn
+
+        nnc = {"ratio_threshold": None, "distance_threshold": None, "do_mutual_check": True}
+        ref = mutual_nn({"descriptors0": d0[:1].cpu(), "descriptors1": d1[:1].cpu()}, nnc)
+        ok = torch.equal(out["matches0"][:1].cpu().long(), ref["matches0"].long()) and (out["matching_scores0"][:1].cpu() - ref["matching_scores0"]).abs().max().item() < 1e-4
+        if not ok:
+            raise AssertionError("bench parity (nn): matches / scores differ from the oracle")
+        line["parity"] = {"status": "ok", "checked": "pair 0 vs oracle/mutual_nn.py (golden-pinned), matches bit-exact, scores within 1e-4"}
+        if not args.no_cpu_baseline and world == 1:
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            c0, c1 = d0.cpu(), d1.cpu()
+            mutual_nn({"descriptors0": c0[:1], "descriptors1": c1[:1]}, nnc)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 10.0 and n < 64:
+                mutual_nn({"descriptors0": c0[n % B : n % B + 1], "descriptors1": c1[n % B : n % B + 1]}, nnc)
+                n += 1
+            line["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+                                    "sample": f"{n} pairs of the same workload through oracle/mutual_nn.py (torch CPU), one pair per call"}  # fmt: skip
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def bench_superpoint(args, dev, rank, world):
@@ -275,6 +405,23 @@ def bench_loftr(args, dev, rank, world):
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_dense(eloftr, Hh, Ww, sd, img0, img1)
+            if not args.no_parity:
+                # parity of pair 0: the plugin's `_forward` (wrapper semantics: top-k by confidence) against the oracle's dictionary.  Rows
+                # are paired by their coarse cell (keypoints of the un-refined image are exact cell centres); near-threshold rows may
+                # differ (round-off ties), so >= 99.5 % of the oracle's rows must be present, refined points within 5e-3 px, scores 1e-3
+                ref = cpu_baseline_dense.last_ref
+                got = model({"image0": img0[:1], "image1": img1[:1]})
+                key = lambda k: {(int(round(float(x) * 4)), int(round(float(y) * 4))): i for i, (x, y) in enumerate(k.tolist())}
+                gk, rk = key(got["keypoints1"].cpu()), key(ref["keypoints1"])
+                common = [c for c in rk if c in gk]
+                gi, ri = [gk[c] for c in common], [rk[c] for c in common]
+                perr = (got["keypoints0"].cpu()[gi] - ref["keypoints0"][ri]).abs().max().item() if common else float("inf")
+                serr = (got["scores"].cpu()[gi] - ref["scores"][ri]).abs().max().item() if common else float("inf")
+                frac = len(common) / max(len(rk), 1)
+                if not (frac >= 0.995 and perr < 5e-3 and serr < 1e-3):
+                    raise AssertionError(f"bench parity (dense): {frac:.4f} of the oracle's matches found, refined-point error {perr:.2e} px, score error {serr:.2e}")
+                line["parity"] = {"status": "ok", "checked": "pair 0 through the plugin's _forward vs the CPU oracle (run timed for cpu_baseline)", "oracle_matches": len(rk),
+                                  "common_fraction": frac, "max_refined_point_error_px": perr, "max_score_error": serr}  # fmt: skip
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -425,8 +572,21 @@ def bench_dust3r(args, dev, rank, world):
             torch.set_num_threads(min(ncpu, 32))
             ora = (MASt3ROracle if mast else DUSt3ROracle)(sd if sd is not None else dust3r_state_dict(0, cfg), cfg)
             t0 = time.perf_counter()
-            ora.inference_symmetrized(i0, i1)
+            ref = ora.inference_symmetrized(i0, i1)
             el = time.perf_counter() - t0
+            if not args.no_parity and args.arith == "fp32":
+                # parity of pair 0 with the oracle run just timed (batch entries in make_pairs' order: (image1, image0), (image0, image1))
+                got = model.forward_pairs(images[:2], [[1, 0], [0, 1]])
+                worst = 0.0
+                for v, key in ((0, "pred1"), (1, "pred2")):
+                    rp = ref[key]["pts3d" if v == 0 else "pts3d_in_other_view"]
+                    err = (got["pts3d"][v].cpu() - rp).abs().max().item() / rp.abs().max().item()
+                    cerr = ((got["conf"][v].cpu() - ref[key]["conf"]).abs() / ref[key]["conf"]).max().item()
+                    worst = max(worst, err, cerr)
+                if not worst < 5e-4:
+                    raise AssertionError(f"bench parity (dust3r): point maps / confidences differ from the oracle by {worst:.2e}")
+                line["parity"] = {"status": "ok", "checked": "pair 0 vs the CPU oracle run timed for cpu_baseline: point maps within 5e-4 of the scene scale, confidences within 5e-4 relative",
+                                  "max_error": worst}  # fmt: skip
             line["cpu_baseline"] = {"value": 1.0 / el, "unit": "pairs/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port",
                                     "sample": f"ONE synthetic {Ww}x{Hh} pair, no warm-up, fp32, the oracle's restatement of duster.py:66-73 (two forward passes, "
                                               f"both images encoded in each, as upstream's inference does{'; the NETWORK only -- the reciprocal matching (TFLOPs of dot products per round on the CPU) is not in the sample' if mast else ''}), torch {torch.__version__} CPU, "
@@ -617,9 +777,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 64; loftr: 4, eloftr: 8, dust3r: 8)")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of one pair after the timed region (profiler passes)")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--workload", default="splg", choices=["splg", "loftr", "eloftr", "dust3r", "mast3r", "superpoint", "superglue", "launchcheck"],
-                    help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); loftr = configs[3] LoFTR dense matcher; "
+    ap.add_argument("--workload", default="splg", choices=["splg", "nn", "loftr", "eloftr", "dust3r", "mast3r", "superpoint", "superglue", "launchcheck"],
+                    help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); nn = configs[0] mutual-NN matcher on 5000 x 128-d descriptors; loftr = configs[3] LoFTR dense matcher; "
                          "superpoint = configs[1] extractor only (images/s); superglue = SuperPoint+SuperGlue pairs; eloftr = EfficientLoFTR 640x480; "
                          "dust3r = configs[4] DUSt3R pair network 512x512; mast3r = the same network with the descriptor head + reciprocal matching")
     ap.add_argument("--sinkhorn", type=int, default=50, help="superglue: Sinkhorn rounds (zoo conf `superglue` = 50, `superglue-fast` = 5)")
@@ -662,6 +823,8 @@ def main():
         return bench_superpoint(args, dev, rank, world)
     if args.workload == "superglue":
         return bench_superglue(args, dev, rank, world)
+    if args.workload == "nn":
+        return bench_nn(args, dev, rank, world)
     B = args.batch
     dc, wc = (0.95, 0.99) if args.adaptive else (-1.0, -1.0)
     pipe = SuperPointLightGluePipeline(
@@ -719,11 +882,15 @@ def main():
         # algorithmic flops of one attention launch: B pairs x 15.03 GF / 2 launches per layer
         attn_flops = B * ATTN_GF_PER_LAYER_PAIR * 1e9 / 2 * (nk0 * nk1 / (MAXK * MAXK))
         achieved = attn_flops / (attn_ms / max(attn_n, 1) * 1e-3) / 1e12 if attn_n else 0.0
+        if args.adaptive:
+            # early stopping and pruning skip work inside the launches (dead tiles exit): the full-size algorithmic flops above are NOT
+            # what the kernel did, so no roofline fraction is claimed for this operating point
+            achieved = None
         split = args.precision == 1
         peak = PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF
         # executed matrix flops: both cross directions recompute QK^T (8.59 + 8.59 vs 15.03 GF) and the
         # split mode issues 3 f16 MFMAs per product
-        executed = achieved * (17.18 / 15.03) * (3.0 if split else 1.0)
+        executed = achieved * (17.18 / 15.03) * (3.0 if split else 1.0) if achieved is not None else None
         # HBM-side bytes per attention launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs, FETCH doubled per MI355X_MICROARCH.md); scales with the batch
         traffic = None
@@ -756,14 +923,17 @@ def main():
             },
             "roofline": {
                 "kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel (f32 MFMA flash attention)",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "executed_tflops": executed, "executed_frac": executed / peak,
-                "executed_frac_of_sustained_peak": (executed / SUSTAINED_F16_MFMA_TF) if split else None,
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if achieved is not None else None, "traffic": traffic,
+                "executed_tflops": executed, "executed_frac": executed / peak if executed is not None else None,
+                "executed_frac_of_sustained_peak": (executed / SUSTAINED_F16_MFMA_TF) if split and executed is not None else None,
+                **({"note": "adaptive depth / width: the work per launch is data dependent, no roofline fraction is claimed"} if args.adaptive else {}),
                 "avg_launch_ms": attn_ms / max(attn_n, 1), "launches": attn_n, "algorithmic_gflop_per_launch": attn_flops / 1e9,
             },
             "kernel_time_ms_per_step": {"attention": attn_ms / args.steps, "conv3x3": conv_ms / args.steps, "gemm": gemm_ms / args.steps},
             "algorithmic_tflops_end_to_end": (2 * SP_GF_PER_IMAGE + 9 * LG_GF_PER_LAYER_PAIR + 2.7) * 1e9 * B / (ms_step * 1e-3) / 1e12,
         }  # fmt: skip
+        if not args.no_parity:
+            line["parity"] = parity_splg(pipe, img0, img1, dc, wc)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -35,6 +35,59 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
     h->err[0] = 0;
     h->precision = 1;
     *out = h;
+    const char* rc = getenv("IMCUI_HIP_CHECK_RANGE");
+    if (rc && atoi(rc) != 0) (void)imcui_hip_set_range_check(h, 1);
+    return IMCUI_OK;
+}
+
+// ---- opt-in range check of the split arithmetic ------------------------------------------------
+// split2 (common.h) saturates the hi part at 65504 and loses the fp32-grade product above twice that; activations are not
+// rescaled (weights are, at pack time).  Synthetic weights never come near; real checkpoints with outlier channels might.
+// With the check on, every split-mode GEMM / convolution / fused-FFN launch is preceded by a scan of its f32 activation
+// operand (a debugging aid: one extra read of the operand per launch); the status word is read with
+// imcui_hip_get_range_status.  Off by default: no kernel changes, no cost.
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long rows, int cols, long ld, const int* __restrict__ cnt,
+                                                          int rows_per_seq, int* __restrict__ flag) {
+    int bits = 0;
+    const long n4 = rows * (long)(cols >> 2);
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long)gridDim.x * 256) {
+        const long r = t / (cols >> 2);
+        const int c = (int)(t - r * (cols >> 2)) * 4;
+        if (cnt != nullptr && rows_per_seq > 0 && (int)(r % rows_per_seq) >= cnt[r / rows_per_seq]) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!(fabsf(a[j]) <= 3.4028234e38f)) bits |= 2;  // NaN or Inf
+            else if (fabsf(a[j]) > 65504.0f) bits |= 1;
+        }
+    }
+    if (bits) atomicOr(flag, bits);
+}
+void imcui_range_check(imcui_hip_s* h, const float* x, long rows, int cols, long ld, const int* cnt, int rows_per_seq, hipStream_t s) {
+    if (!h || !h->range_flag || !x || rows <= 0 || cols < 4 || (cols & 3) || (ld & 3)) return;
+    const long n4 = rows * (long)(cols >> 2);
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(range_check_kernel, dim3(blocks), dim3(256), 0, s, x, rows, cols, ld, cnt, rows_per_seq, h->range_flag);
+}
+extern "C" int imcui_hip_set_range_check(imcui_hip_t* h, int enable) {
+    if (!h) return IMCUI_ERR_ARG;
+    if (enable && !h->range_flag) {
+        if (hipMalloc((void**)&h->range_flag, sizeof(int)) != hipSuccess) return imcui_set_err(h, IMCUI_ERR_HIP, "range check: allocation failed");
+        (void)hipMemset(h->range_flag, 0, sizeof(int));
+    } else if (!enable && h->range_flag) {
+        (void)hipFree(h->range_flag);
+        h->range_flag = nullptr;
+    }
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_get_range_status(imcui_hip_t* h, int* status) {
+    if (!h || !status) return IMCUI_ERR_ARG;
+    *status = 0;
+    if (!h->range_flag) return IMCUI_OK;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(status, h->range_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return imcui_set_err(h, IMCUI_ERR_HIP, "range check: read failed");
+    (void)hipMemset(h->range_flag, 0, sizeof(int));
     return IMCUI_OK;
 }
 
@@ -44,6 +97,7 @@ extern "C" void imcui_hip_destroy(imcui_hip_t* h) {
         for (int i = 0; i < 2 * h->prof_alloc[c]; ++i) (void)hipEventDestroy(h->prof_ev[c][i]);
         free(h->prof_ev[c]);
     }
+    if (h->range_flag) (void)hipFree(h->range_flag);
     free(h);
 }
 

@@ -137,7 +137,12 @@ struct imcui_hip_s {
     float* lg_dump;  // parity-test hook (imcui_hip_lightglue_set_layer_dump): per-layer token states
     size_t lg_dump_floats;
     long long* ffn_dbg;  // lab hook (imcui_hip_ffn_set_debug): per-workgroup phase stamps of the fused FFN kernel
+    // opt-in range check of the split arithmetic (imcui_hip_set_range_check / IMCUI_HIP_CHECK_RANGE=1): device word, bit 0 = an
+    // f32 activation beyond the f16 range (|x| > 65504: the hi part saturates, the product is no longer fp32-grade), bit 1 = NaN / Inf
+    int* range_flag;
 };
+// scan `rows` x `cols` f32 values (row stride ld; rows of sequence s beyond cnt[s] are padding and skipped) into h->range_flag
+void imcui_range_check(imcui_hip_s* h, const float* x, long rows, int cols, long ld, const int* cnt, int rows_per_seq, hipStream_t s);
 void imcui_prof_begin(imcui_hip_s* h, int cls, hipStream_t s);
 void imcui_prof_end(imcui_hip_s* h, int cls, hipStream_t s);
 

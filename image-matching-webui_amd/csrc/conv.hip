@@ -483,6 +483,7 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     const bool wide = (Cout % 128 == 0) && !narrow_only;
     const long nwg = (long)tiles_x * tiles_y * (Cout / (wide ? 128 : 64)) * B;
     if (nwg <= 0) return IMCUI_OK;
+    if (h->range_flag) imcui_range_check(h, in, (long)B * H * W, Cin, cin_stride, nullptr, 0, stream);
     imcui_prof_begin(h, PROF_CONV, stream);
     if (wide && single)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,

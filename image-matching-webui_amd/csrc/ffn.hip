@@ -389,6 +389,10 @@ int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
             return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
         attr_set[v][a] = true;
     }
+    if (h->range_flag) {
+        imcui_range_check(h, p.x, p.M, 256, 256, p.cnt, p.rows_per_seq, stream);
+        imcui_range_check(h, p.ctx, p.M, 256, 256, p.cnt, p.rows_per_seq, stream);
+    }
     imcui_prof_begin(h, PROF_GEMM, stream);
     hipLaunchKernelGGL(kerns[v][a], dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
     imcui_prof_end(h, PROF_GEMM, stream);

@@ -1081,6 +1081,18 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
                 p.K, p.K1, p.batch, (int)split, p.Wh != nullptr, p.conv_k, p.rows_per_seq, p.split_out);
         fflush(stderr);
     }
+    if (split && h->range_flag && p.conv_k == 0) {  // opt-in debugging aid: scan the f32 operands the kernel is about to split
+        for (int z = 0; z < p.batch; ++z) {
+            // live rows: ragged sequences (cnt) or the device-side row count of a batched product (mcnt / ncnt)
+            const int* ac = p.mcnt ? p.mcnt + (size_t)z * p.cnt_stride : p.cnt;
+            const int arps = p.mcnt ? p.M : p.rows_per_seq;
+            imcui_range_check(h, p.A + (size_t)z * p.a_bs, p.M, p.A2 ? p.K1 : p.K, p.lda, ac, arps, stream);
+            if (p.A2) imcui_range_check(h, p.A2 + (size_t)z * p.a2_bs, p.M, p.K - p.K1, p.lda2, ac, arps, stream);
+            if (!p.Wh && p.W) imcui_range_check(h, p.W + (size_t)z * p.w_bs, p.N, p.K, p.ldw, p.ncnt ? p.ncnt + (size_t)z * p.cnt_stride : nullptr, p.N, stream);
+        }
+    } else if (split && h->range_flag) {
+        imcui_range_check(h, p.A, (long)p.M / (p.conv_hout * p.conv_wout) * p.conv_hin * p.conv_win, p.conv_cin, p.conv_cin, nullptr, 0, stream);
+    }
     imcui_prof_begin(h, PROF_GEMM, stream);
     if (split && gemm_wreg_ok(p)) {
         gemm_wreg_launch(p, stream);

@@ -1085,6 +1085,21 @@ def linear_split_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None
     return c
 
 
+def set_range_check(device, enable: bool = True) -> None:
+    """Debugging aid: scan the f32 activation operand of every split-mode GEMM / convolution / FFN launch for values the f16
+    split cannot carry (imcui_hip_set_range_check)."""
+    hd = get_handle(torch.device(device))
+    hd.check(hd.lib.imcui_hip_set_range_check(hd.h, int(bool(enable))), "set_range_check")
+
+
+def range_status(device) -> int:
+    """Accumulated range-check word since the last read (synchronises): bit 0 = |x| > 65504 seen, bit 1 = NaN / Inf seen."""
+    hd = get_handle(torch.device(device))
+    st = C.c_int(0)
+    hd.check(hd.lib.imcui_hip_get_range_status(hd.h, C.byref(st)), "get_range_status")
+    return int(st.value)
+
+
 def qkv_split_f32(x: torch.Tensor, w: torch.Tensor, bias, cos, sin, cnt: torch.Tensor, rows_per_seq: int, alpha: float, cross: bool = False):
     """Building block: the attention-layout projection (imcui_hip_qkv_split_f32).  x [nseq * R, 256] (device), w [768 | 512, 256]
     (host, packed row order) -> int16 views of the planes: q, k [2, nseq, 4, R, 64], vt [2, nseq, 4, 64, R] (plane 0 = hi)."""

@@ -39,6 +39,8 @@ SIGNATURES = {
     "imcui_hip_resize_aa_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_linear_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_linear_split_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p]),
+    "imcui_hip_set_range_check": (C.c_int, [C.c_void_p, C.c_int]),
+    "imcui_hip_get_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "imcui_hip_qkv_split_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_float, C.c_int] + [C.c_void_p] * 4),
     "imcui_hip_ffn_pack_w2": (C.c_float, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "imcui_hip_ffn_set_debug": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -374,6 +374,14 @@ float imcui_hip_linear_pack_split(const float* w, int N, int K, unsigned short* 
 int imcui_hip_linear_split_f32(imcui_hip_t* h, const float* A, const unsigned short* wh, const unsigned short* wl,
                                const float* wscale, const float* bias, float* C, int M, int N, int K, int relu, void* stream);
 
+/* Opt-in range check of the split arithmetic (debugging aid; also switched on by the environment variable
+ * IMCUI_HIP_CHECK_RANGE=1 at imcui_hip_create).  The 3 x f16 split of an f32 activation saturates its hi part at 65504 and is
+ * no longer fp32-grade above that; weights are rescaled at pack time, activations are not.  With the check enabled every
+ * split-mode GEMM / 3x3 convolution / fused-FFN launch first scans its f32 activation operand.  imcui_hip_get_range_status
+ * synchronises the device, returns the accumulated word (bit 0: a value beyond the f16 range, bit 1: NaN / Inf) and clears it. */
+int imcui_hip_set_range_check(imcui_hip_t* h, int enable);
+int imcui_hip_get_range_status(imcui_hip_t* h, int* status);
+
 /* Projection of a transformer block into the attention kernels' operand layout (upstream LightGlue SelfBlock `Wqkv` + rotary
  * encoding, CrossBlock `to_qk` / `to_v`; reached from imcui/hloc/matchers/lightglue.py:75): x [nseq * rows_per_seq][256] ->
  * f16 hi / lo planes (hi plane first, lo plane nseq*rows_per_seq*256 halves behind it) of Q, K [seq][head][row][64] and of

@@ -193,3 +193,34 @@ def test_attention_priority_variants_bitwise():
             outs.append(backend.attention_f32(q, k, v, cnt, True, True).cpu())
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+
+
+def test_split_range_check_reports_saturation():
+    """the 3 x f16 split saturates silently above 65504.  With the opt-in range check on, a projection
+    fed an activation of 1e5 sets bit 0, a NaN sets bit 1, ordinary data (a whole LightGlue forward with the strong weight set)
+    leaves the word at 0; padding rows of ragged batches are not scanned."""
+    from imcui_hip import backend
+
+    dev = torch.device("cuda:0")
+    backend.set_precision(dev, 1)
+    backend.set_range_check(dev, True)
+    try:
+        assert backend.range_status(dev) == 0
+        g = torch.Generator().manual_seed(3)
+        a = torch.randn(300, 256, generator=g).to(dev)
+        w = torch.randn(256, 256, generator=g) / 16.0
+        backend.linear_split_f32(a, w, None)
+        assert backend.range_status(dev) == 0
+        a[17, 5] = 1.0e5
+        backend.linear_split_f32(a, w, None)
+        assert backend.range_status(dev) == 1
+        assert backend.range_status(dev) == 0  # reading clears the word
+        a[17, 5] = float("nan")
+        backend.linear_split_f32(a, w, None)
+        assert backend.range_status(dev) == 2
+        problems = [synthetic_matching_problem(80 + i, n, m, o) for i, (n, m, o) in enumerate(PROBLEMS)]
+        out = _run(-1, -1, problems)
+        assert (out["matches0"] > -1).sum() > 100
+        assert backend.range_status(dev) == 0
+    finally:
+        backend.set_range_check(dev, False)

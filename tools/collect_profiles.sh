@@ -19,15 +19,15 @@ if [ "${QUICK:-0}" = 1 ]; then
   ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
   ( cd $R && timeout 300 python bench.py --workload dust3r --arith fp16 --no-cpu-baseline > $O/bench_dust3r_512_fp16.json.log 2>&1; tail -1 $O/bench_dust3r_512_fp16.json.log | cut -c1-160 )
   ( cd $R && timeout 300 python bench.py --workload mast3r --no-cpu-baseline > $O/bench_mast3r_512.json.log 2>&1; tail -1 $O/bench_mast3r_512.json.log | cut -c1-160 )
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_loftr.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_eloftr.log 2>&1
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_dust3r.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $O/rocprof_splg.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $O/rocprof_loftr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_eloftr.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_dust3r.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_$c.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_dust3r_$c.log 2>&1
     echo pmc dust3r $c rc $?
   done
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_dust3r_SQ -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_SQ.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_dust3r_SQ -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_dust3r_SQ.log 2>&1
   ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
   ls $O
   exit 0
@@ -38,16 +38,16 @@ fi
 ( cd $R && timeout 200 python bench.py --precision 0 --no-cpu-baseline > $O/bench_splg_f32.json.log 2>&1; tail -1 $O/bench_splg_f32.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 200 python bench.py --workload superglue > $O/bench_superglue.json.log 2>&1; tail -1 $O/bench_superglue.json.log | cut -c1-160 )
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_superglue -o superglue -- python $R/bench.py --workload superglue --steps 3 --warmup 1 > $O/rocprof_superglue.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/rocprof_splg.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_splg -o splg -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $O/rocprof_splg.log 2>&1
 [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 > $O/rocprof_loftr.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_$c.log 2>&1
   echo pmc $c rc $?
-  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_loftr_$c -o loftr -- python $R/bench.py --workload loftr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_loftr_$c.log 2>&1
-  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_eloftr_$c -o eloftr -- python $R/bench.py --workload eloftr --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_eloftr_$c.log 2>&1
+  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_loftr_$c -o loftr -- python $R/bench.py --workload loftr --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_loftr_$c.log 2>&1
+  [ $L = 1 ] || timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_eloftr_$c -o eloftr -- python $R/bench.py --workload eloftr --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_eloftr_$c.log 2>&1
 done
 # matrix-pipe occupancy and stall breakdown (one pass: 7 of the 8 SQ slots)
-timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_SQ -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_SQ.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_SQ -o splg -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_SQ.log 2>&1
 echo pmc SQ rc $?
 [ $K = 1 ] || timeout 60 $R/tools/clock_lab > $O/lab_clock.txt 2>&1
 [ $K = 1 ] || timeout 60 $R/tools/overlap_lab > $O/lab_overlap.txt 2>&1
@@ -67,11 +67,11 @@ done
 [ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r > $O/bench_dust3r_512.json.log 2>&1; tail -1 $O/bench_dust3r_512.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r --arith fp16 --no-cpu-baseline > $O/bench_dust3r_512_fp16.json.log 2>&1; tail -1 $O/bench_dust3r_512_fp16.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload mast3r --no-cpu-baseline > $O/bench_mast3r_512.json.log 2>&1; tail -1 $O/bench_mast3r_512.json.log | cut -c1-160 )
-[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline > $O/rocprof_dust3r.log 2>&1
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_dust3r.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_$c.log 2>&1
+  [ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_dust3r_$c.log 2>&1
 done
-[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_dust3r_SQ -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_dust3r_SQ.log 2>&1
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_dust3r_SQ -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_dust3r_SQ.log 2>&1
 # the fused FFN kernel: A/B against the three-launch path, and its phase breakdown
 ( cd $R && IMCUI_LG_FFN_UNFUSED=1 timeout 100 python bench.py --no-cpu-baseline > $O/bench_splg_unfused_ffn.json.log 2>&1; tail -1 $O/bench_splg_unfused_ffn.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_LF_MATCH_4PASS=1 timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024_4pass.json.log 2>&1; tail -1 $O/bench_loftr_1024_4pass.json.log | cut -c1-160 )
