@@ -243,6 +243,7 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
 struct DuWs {
     float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
     float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2, *lfh, *lfo;
+    float *rcos, *rsin;  // RoPE2D tables [R][32] of the token grid (the fused q / k / v projection epilogue reads them)
     int *cnt, *smap, *wsel, *wsel_rev;
     size_t total;
     bool ok;
@@ -292,6 +293,8 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     w.hd2 = a.get<float>(pt * 256 * 128);
     w.lfh = c.desc > 0 ? a.get<float>(pt * 4 * (E + D)) : nullptr;  // MASt3R: hidden layer and output of head_local_features
     w.lfo = c.desc > 0 ? a.get<float>(pt * (size_t)(c.desc + 1) * 256) : nullptr;
+    w.rcos = a.get<float>(R * 32);
+    w.rsin = a.get<float>(R * 32);
     w.cnt = a.get<int>((size_t)(NI > 2 * P ? NI : 2 * P) + 64);
     w.smap = a.get<int>((size_t)2 * P + 64);
     w.wsel = a.get<int>((size_t)P + 64);
@@ -480,6 +483,50 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         hipLaunchKernelGGL(du_vt_split_kernel, dim3((unsigned)(nseq * (C / 64) * (R / 64))), blk, 0, stream, src, ld, col0, C / 64, T, R,
                            reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0);
     };
+    // q / k / v projection with the attention operand planes written by the GEMM's own epilogue (EPI_QKV_VIT, gemm_wreg.hip:
+    // RoPE2D from the tables, q scaled, f16 hi / lo planes, V transposed) instead of an f32 [rows][N] round trip through
+    // du_rope_split_kernel / du_vt_split_kernel (5.5 % of a step in round 2).  li = layer (encoder) or (i, j) of a decoder block
+    // (both sides in one launch); role0 / nblk: which of q, k, v the N = nblk x C output columns are.  IMCUI_DUST3R_QKV_UNFUSED=1
+    // keeps the round-2 path (also taken when the weights-in-registers kernel is switched off or the single-product mode is on).
+    static const bool qkv_unfused_env = getenv("IMCUI_DUST3R_QKV_UNFUSED") != nullptr;
+    auto proj_planes = [&](int li0, int li1, bool swap, const float* A, int C, int nseq, int role0, int nblk, float* qpl, float* kpl, float* vpl,
+                           bool* done) -> int {
+        int N, K, kind;
+        du_shape(c, li0, &N, &K, &kind);
+        GemmP g;
+        g.epi = EPI_QKV_VIT;
+        g.N = N;
+        g.K = K;
+        g.ldw = K;
+        g.Wh = reinterpret_cast<const unsigned short*>(Pk + l.wh[li0]);
+        g.Wl = reinterpret_cast<const unsigned short*>(Pk + l.wl[li0]);
+        g.wscale = Pk + l.ws[li0];
+        g.bias = Pk + l.b[li0];
+        if (li1 >= 0) {  // decoder: weight set per sequence pair, as lin2
+            g.wsel = swap ? w.wsel_rev : w.wsel;
+            g.w_stride = (long)(l.wh[li1] - l.wh[li0]) * 2;
+            g.b_stride = (long)(l.b[li1] - l.b[li0]);
+        }
+        g.A = A;
+        g.lda = K;
+        g.M = nseq * R;
+        g.cnt = w.cnt;
+        g.rows_per_seq = R;
+        g.heads = C / 64;
+        g.role0 = role0;
+        g.split_out = 1;
+        g.v_transposed = 1;
+        g.plane_halves = (size_t)nseq * C * R;
+        g.Q = qpl;
+        g.Kt = kpl;
+        g.V = vpl;
+        g.rope_cos = w.rcos;
+        g.rope_sin = w.rsin;
+        g.alpha = q_alpha;
+        *done = li1 != -2 && !qkv_unfused_env && !single && N == nblk * C && gemm_wreg_ok(g);
+        if (!*done) return IMCUI_OK;
+        return gemm_launch(h, g, stream);
+    };
     auto attend = [&](const float* q, const float* k, const float* v, float* out, int nseq, int C, int cross) -> int {
         AttnP a;
         a.Q = q;
@@ -501,6 +548,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         // stream s < P: view 1 of pair s, stream P + s: view 2
         hipLaunchKernelGGL(du_smap_kernel, dim3((unsigned)cdiv(2 * P, 256)), blk, 0, stream, pairs, w.smap, P, NI);
         hipLaunchKernelGGL(du_wsel_kernel, dim3((unsigned)cdiv(P, 256)), blk, 0, stream, w.wsel, w.wsel_rev, P);
+        hipLaunchKernelGGL(du_rope_table_kernel, dim3((unsigned)cdiv(R * 32, 256)), blk, 0, stream, V(du_v_invf(c)), T, R, wg, w.rcos, w.rsin);
     }
 
     // ---- encoder: every image once
@@ -514,10 +562,14 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     }
     for (int i = 0; i < c.enc_depth; ++i) {
         layernorm(w.x, du_v_enc(c, i, 0), w.xn, me, E);
-        DURUN(lin(du_l_enc(c, i, 0), w.xn, w.qkv, NI, nullptr, 0));
-        rope_split(w.qkv, 3 * E, 0, E, NI, w.qp, NI, 0, q_alpha);
-        rope_split(w.qkv, 3 * E, E, E, NI, w.kp, NI, 0, 1.0f);
-        vt_split(w.qkv, 3 * E, 2 * E, E, NI, w.vp, NI, 0);
+        bool fused;
+        DURUN(proj_planes(du_l_enc(c, i, 0), -1, false, w.xn, E, NI, 0, 3, w.qp, w.kp, w.vp, &fused));
+        if (!fused) {
+            DURUN(lin(du_l_enc(c, i, 0), w.xn, w.qkv, NI, nullptr, 0));
+            rope_split(w.qkv, 3 * E, 0, E, NI, w.qp, NI, 0, q_alpha);
+            rope_split(w.qkv, 3 * E, E, E, NI, w.kp, NI, 0, 1.0f);
+            vt_split(w.qkv, 3 * E, 2 * E, E, NI, w.vp, NI, 0);
+        }
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, NI, E, 0));
         DURUN(lin(du_l_enc(c, i, 1), w.att, w.x, NI, w.x, 0));
@@ -547,22 +599,32 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block, normalised by
         // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o
         for (int o = 0; o < 2; ++o) layernorm(w.y + (size_t)o * ms * D, du_v_dec(c, 1 - o, i, 4), w.xn + (size_t)o * ms * D, ms, D);
-        DURUN(lin2(i, 3, w.xn, D, w.qkv, 2 * D, nullptr, 0, true));
-        rope_split(w.qkv, 2 * D, 0, D, 2 * P, w.kc, 2 * P, 0, 1.0f);
-        vt_split(w.qkv, 2 * D, D, D, 2 * P, w.vc, 2 * P, 0);
+        bool fused;
+        DURUN(proj_planes(du_l_dec(c, 0, i, 3), merged ? du_l_dec(c, 1, i, 3) : -2, true, w.xn, D, 2 * P, 1, 2, nullptr, w.kc, w.vc, &fused));
+        if (!fused) {
+            DURUN(lin2(i, 3, w.xn, D, w.qkv, 2 * D, nullptr, 0, true));
+            rope_split(w.qkv, 2 * D, 0, D, 2 * P, w.kc, 2 * P, 0, 1.0f);
+            vt_split(w.qkv, 2 * D, D, D, 2 * P, w.vc, 2 * P, 0);
+        }
         // self attention
         for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, ms, D);
-        DURUN(lin2(i, 0, w.xn, D, w.qkv, 3 * D, nullptr, 0, false));
-        rope_split(w.qkv, 3 * D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
-        rope_split(w.qkv, 3 * D, D, D, 2 * P, w.kp, 2 * P, 0, 1.0f);
-        vt_split(w.qkv, 3 * D, 2 * D, D, 2 * P, w.vp, 2 * P, 0);
+        DURUN(proj_planes(du_l_dec(c, 0, i, 0), merged ? du_l_dec(c, 1, i, 0) : -2, false, w.xn, D, 2 * P, 0, 3, w.qp, w.kp, w.vp, &fused));
+        if (!fused) {
+            DURUN(lin2(i, 0, w.xn, D, w.qkv, 3 * D, nullptr, 0, false));
+            rope_split(w.qkv, 3 * D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
+            rope_split(w.qkv, 3 * D, D, D, 2 * P, w.kp, 2 * P, 0, 1.0f);
+            vt_split(w.qkv, 3 * D, 2 * D, D, 2 * P, w.vp, 2 * P, 0);
+        }
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, 2 * P, D, 0));
         DURUN(lin2(i, 1, w.att, D, w.y, D, w.y, 0, false));
         // cross attention
         for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, ms, D);
-        DURUN(lin2(i, 2, w.xn, D, w.qc, D, nullptr, 0, false));
-        rope_split(w.qc, D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
+        DURUN(proj_planes(du_l_dec(c, 0, i, 2), merged ? du_l_dec(c, 1, i, 2) : -2, false, w.xn, D, 2 * P, 0, 1, w.qp, nullptr, nullptr, &fused));
+        if (!fused) {
+            DURUN(lin2(i, 2, w.xn, D, w.qc, D, nullptr, 0, false));
+            rope_split(w.qc, D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
+        }
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kc, w.vc, w.att, 2 * P, D, 2));
         DURUN(lin2(i, 4, w.att, D, w.y, D, w.y, 0, false));

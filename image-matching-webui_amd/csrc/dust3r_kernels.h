@@ -124,6 +124,24 @@ __global__ __launch_bounds__(256) void du_rope_split_kernel(const float* __restr
     }
 }
 
+// RoPE2D tables of the token grid for the fused projection epilogue (EPI_QKV_VIT): cos / sin [R][32], entry 16 half + i =
+// angle (row for half 0, column for half 1) x inv_freq[i], the same cosf / sinf of the same float angle as du_rope_split_kernel
+__global__ __launch_bounds__(256) void du_rope_table_kernel(const float* __restrict__ inv_freq, int T, int R, int wg, float* __restrict__ rcos,
+                                                            float* __restrict__ rsin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * 32) return;
+    const int t = i >> 5, e = i & 31;
+    float cs = 1.0f, sn = 0.0f;
+    if (t < T) {
+        const int ty = t / wg, tx = t - ty * wg;
+        const float ang = (float)((e >> 4) ? tx : ty) * inv_freq[e & 15];
+        cs = cosf(ang);
+        sn = sinf(ang);
+    }
+    rcos[i] = cs;
+    rsin[i] = sn;
+}
+
 // ------------------------------------------------------------------ v: f16 hi / lo planes of V^T [seq][head][64][R]
 // one workgroup = 64 tokens x one head: f32 tile through LDS, each thread writes 16 consecutive tokens of one feature
 __global__ __launch_bounds__(256) void du_vt_split_kernel(const float* __restrict__ src, long ld, int col0, int heads, int T, int R,

@@ -17,6 +17,13 @@ enum GemmEpi {
     // the assignment: per row (max, sum exp) over the tile's 128 columns -> st_rpm / st_rps [batch][N/128][ldc], per column over
     // each 64-row half -> st_cpm / st_cps [batch][M/64][ldc]  (split mode, f32 B operand; LightGlue's log-assignment, a11)
     EPI_SIMSTAT = 6,
+    // ViT blocks of the DUSt3R / MASt3R networks (gemm_wreg_kernel only): the output features are `heads` x 64 wide blocks of
+    // q / k / v in that order starting at block `role0` (0: q, 1: k, 2: v -- self attention [q | k | v]: role0 = 0, N = 3 C; the
+    // cross-attention key / value projection [k | v]: role0 = 1, N = 2 C; its query projection: role0 = 0, N = C).  q and k get
+    // CroCo's RoPE2D from the tables rope_cos / rope_sin [rows_per_seq][32] (entry 16 half + i = angle of the y (half 0) / x
+    // (half 1) position of the token times inv_freq[i]; inside a 32-feature half feature i < 16 pairs with i + 16), q *= alpha;
+    // everything leaves as f16 hi / lo planes, q / k [seq][head][row][64], v transposed [seq][head][64][row].
+    EPI_QKV_VIT = 7,
 };
 
 struct GemmP {
@@ -81,6 +88,7 @@ struct GemmP {
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;
+    int role0 = 0;  // EPI_QKV_VIT: role (0 q, 1 k, 2 v) of the first heads x 64 block of output features
 };
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);

@@ -1106,6 +1106,8 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         case EPI_RESID: launch_one<EPI_RESID>(p, split, stream); break;
         case EPI_QKV: launch_one<EPI_QKV>(p, split, stream); break;
         case EPI_CROSS: launch_one<EPI_CROSS>(p, split, stream); break;
+        case EPI_QKV_VIT:
+            return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "gemm: EPI_QKV_VIT is implemented by gemm_wreg_kernel only (split mode, pre-split weights, N %% (64 heads) == 0)");
         case EPI_SIMSTAT:
             if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_cpm || !p.st_cps || p.bias != nullptr || (p.ldc & 3) != 0)
                 return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: EPI_SIMSTAT needs the split mode, an f32 B operand, no bias and the four partial buffers");

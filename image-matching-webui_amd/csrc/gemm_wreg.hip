@@ -146,16 +146,18 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 *reinterpret_cast<float4*>(st + lo * WR_STG_ROW + 32 * n + 8 * q + 4 * hi) =
                     make_float4(acc[n][m][4 * q + 0] * wsc, acc[n][m][4 * q + 1] * wsc, acc[n][m][4 * q + 2] * wsc, acc[n][m][4 * q + 3] * wsc);
     };
-    if constexpr (EPI == EPI_QKV || EPI == EPI_CROSS) {
-        // the 256 features of the tile are the four heads of ONE of q / k / v; this wave is head `hd`
-        const int t = c.col0 >> 8, hd = ((c.col0 >> 6) + wid) & 3;
+    if constexpr (EPI == EPI_QKV || EPI == EPI_CROSS || EPI == EPI_QKV_VIT) {
+        // the 256 features of the tile are four heads of ONE of q / k / v; this wave is head `hd` of block `t`
+        const int CW = p.heads * 64;
+        const int t = fw0 / CW, hd = (fw0 - t * CW) >> 6;
         float* dst;
         bool vt, rope, scale;
-        if (EPI == EPI_QKV) {
-            dst = (t == 0) ? p.Q : (t == 1) ? p.Kt : p.V;
-            vt = (t == 2);
-            rope = (t < 2);
-            scale = (t == 0);
+        if (EPI == EPI_QKV || EPI == EPI_QKV_VIT) {
+            const int role = t + (EPI == EPI_QKV_VIT ? p.role0 : 0);
+            dst = (role == 0) ? p.Q : (role == 1) ? p.Kt : p.V;
+            vt = (role == 2);
+            rope = (role < 2);
+            scale = (role == 0);
         } else {
             dst = (t == 0) ? p.Q : p.V;
             vt = (t == 1);
@@ -165,7 +167,60 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
         const int R = p.rows_per_seq;
         const int i0 = c.row0 - c.seq * R;
-        if (!vt) {
+        if (EPI == EPI_QKV_VIT && !vt) {
+            // RoPE2D: a lane finishes 8 consecutive features of one token; their rotation partners sit 16 features away in the same
+            // 32-feature half (read from the parked row as well).  `first` lanes hold the a of (a, b) -> (a cos - b sin, b cos + a sin).
+            const int d0 = (lane & 7) * 8, dp = d0 ^ 16;
+            const bool first = (d0 & 16) == 0;
+            const int ti = (d0 >> 5) * 16 + (d0 & 8);  // table column: 16 per half, this lane's 8 frequencies
+            float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba, pa = ba, pb = ba;
+            if (c.bias != nullptr) {
+                ba = *reinterpret_cast<const float4*>(c.bias + fw0 + d0);
+                bb = *reinterpret_cast<const float4*>(c.bias + fw0 + d0 + 4);
+                pa = *reinterpret_cast<const float4*>(c.bias + fw0 + dp);
+                pb = *reinterpret_cast<const float4*>(c.bias + fw0 + dp + 4);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float4 tc[4][2], ts[4][2];
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {  // tables of this step's tokens, requested before the tile is parked
+                    const size_t ir = (size_t)(i0 + 32 * m + pass * 8 + (lane >> 3)) * 32 + ti;
+                    tc[pass][0] = *reinterpret_cast<const float4*>(p.rope_cos + ir);
+                    tc[pass][1] = *reinterpret_cast<const float4*>(p.rope_cos + ir + 4);
+                    ts[pass][0] = *reinterpret_cast<const float4*>(p.rope_sin + ir);
+                    ts[pass][1] = *reinterpret_cast<const float4*>(p.rope_sin + ir + 4);
+                }
+                park_rows(m);
+                wr_wave_fence();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int tl = pass * 8 + (lane >> 3);
+                    const float4 va = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0);
+                    const float4 vb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0 + 4);
+                    const float4 wa = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + dp);
+                    const float4 wb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + dp + 4);
+                    const float mine[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
+                    const float part[8] = {wa.x + pa.x, wa.y + pa.y, wa.z + pa.z, wa.w + pa.w, wb.x + pb.x, wb.y + pb.y, wb.z + pb.z, wb.w + pb.w};
+                    const float cw[8] = {tc[pass][0].x, tc[pass][0].y, tc[pass][0].z, tc[pass][0].w, tc[pass][1].x, tc[pass][1].y, tc[pass][1].z, tc[pass][1].w};
+                    const float ss[8] = {ts[pass][0].x, ts[pass][0].y, ts[pass][0].z, ts[pass][0].w, ts[pass][1].x, ts[pass][1].y, ts[pass][1].z, ts[pass][1].w};
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float x = mine[j], y = part[j];
+                        asm volatile("" : "+v"(x), "+v"(y));  // scalar fused multiply-adds, never packed (see the LightGlue branch)
+                        const float r = first ? __builtin_fmaf(x, cw[j], -(y * ss[j])) : __builtin_fmaf(x, cw[j], y * ss[j]);
+                        v[j] = scale ? r * p.alpha : r;
+                    }
+                    uint4 hv, lv;
+                    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
+                    unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * R + i0 + 32 * m + tl) * 64 + d0;
+                    *reinterpret_cast<uint4*>(o) = hv;
+                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                }
+                wr_wave_fence();
+            }
+        } else if (!vt) {
             const int d0 = (lane & 7) * 8;
             float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bb = ba;
             if (c.bias != nullptr) {
@@ -311,10 +366,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
 bool gemm_wreg_ok(const GemmP& p) {
     const char* env = getenv("IMCUI_GEMM_WREG");  // read per launch: tests flip it between two calls
     const int mode = env ? atoi(env) : 2;         // 0: off; 1: attention-layout projections only; 2: every eligible launch
-    if (mode == 0 || (mode == 1 && p.epi != EPI_QKV && p.epi != EPI_CROSS) || p.Wh == nullptr || p.Wl == nullptr || p.A2 != nullptr || p.conv_k > 0 || p.batch != 1 || p.mcnt || p.ncnt || p.group_rows > 1 ||
+    if (mode == 0 || (mode == 1 && p.epi != EPI_QKV && p.epi != EPI_CROSS && p.epi != EPI_QKV_VIT) || p.Wh == nullptr || p.Wl == nullptr || p.A2 != nullptr || p.conv_k > 0 || p.batch != 1 || p.mcnt || p.ncnt || p.group_rows > 1 ||
         p.rup_h > 0)
         return false;
     if (p.K % 32 != 0 || p.N % 64 != 0 || (p.lda & 3) != 0) return false;
+    if (p.epi == EPI_QKV_VIT)
+        return p.split_out && p.v_transposed && p.heads % 4 == 0 && p.N % (p.heads * 64) == 0 && p.rows_per_seq > 0 && p.M % 128 == 0 && !p.single;
     if (p.epi == EPI_QKV || p.epi == EPI_CROSS)
         return p.split_out && p.v_transposed && p.heads == 4 && p.N % 256 == 0 && p.rows_per_seq > 0 && p.M % 128 == 0;
     if (p.single && p.epi != EPI_CONV) return false;
@@ -330,6 +387,7 @@ void gemm_wreg_launch(const GemmP& p, hipStream_t stream) {
         case EPI_RESID: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RESID, false>), grid, dim3(256), 0, stream, p); break;
         case EPI_QKV: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV, false>), grid, dim3(256), 0, stream, p); break;
         case EPI_CROSS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CROSS, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_QKV_VIT: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV_VIT, false>), grid, dim3(256), 0, stream, p); break;
         default:
             if (p.single)
                 hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, true>), grid, dim3(256), 0, stream, p);

@@ -63,7 +63,14 @@ def audit_keypoint_differences(flat_hip, flat_ref, dense_hip, dense_ref, conf, t
     eps = 2.0 * d + 1e-7
     assert eps < 1e-4, f"{tag}: dense score maps differ by {d:.3e}"
     nms_ref = simple_nms(dense_ref[None], r)[0]
-    cand = nms_ref[nms_ref > thr]
+    keep = nms_ref > thr
+    bd = int(conf.get("remove_borders", 0) or 0)
+    if bd > 0:  # `remove_borders` runs BEFORE the top-k: the k-th score is taken among the interior candidates
+        keep[:bd] = False
+        keep[H - bd :] = False
+        keep[:, :bd] = False
+        keep[:, W - bd :] = False
+    cand = nms_ref[keep]
     kth = float(torch.topk(cand.flatten(), k).values[-1]) if (k >= 0 and cand.numel() > k) else None
     kth_next = float(torch.topk(cand.flatten(), k + 1).values[-1]) if (k >= 0 and cand.numel() > k) else None
     for p in diff:

@@ -52,3 +52,29 @@ def test_match_audit_accepts_ties_only():
     S[2, 5] = -2.0  # no longer a tie
     with pytest.raises(AssertionError, match="is not a tie"):
         assert_matches_equal_or_tied(m_hip, S, m_ref, 0.1)
+
+
+def test_keypoint_audit_takes_the_kth_score_among_interior_candidates():
+    """`remove_borders` runs before the top-k (upstream SuperPoint): with more candidates than `max_keypoints` the k-th score of
+    the audit must be the k-th INTERIOR candidate's.  Found by bench.py's parity check in round 3 (9292 candidates, 271 of them in
+    the border strip: the helper used the k-th of all candidates, 1.2e-3 above the real boundary, and rejected a 6.6e-7 tie)."""
+    g = torch.Generator().manual_seed(4)
+    dense = torch.rand(64, 96, generator=g) * 0.05
+    conf = dict(CONF, max_keypoints=20)
+    # strong maxima inside the border strip: candidates that never reach the top-k
+    for x in range(8, 90, 9):
+        dense[1, x] = 0.9
+    (sel, _, _), _ = oracle_select_on(dense, conf)
+    assert len(sel) == 20
+    # the weakest selected point and the strongest rejected one, made a near tie that flips between the two maps
+    nms_scores = dense.flatten()[sel]
+    weakest = int(sel[nms_scores.argmin()])
+    ref, hip = dense.clone(), dense.clone()
+    (sel_all, _, _), _ = oracle_select_on(dense, dict(conf, max_keypoints=21))
+    runner_up = (set(sel_all.tolist()) - set(sel.tolist())).pop()
+    ref.view(-1)[runner_up] = ref.view(-1)[weakest] - 3e-8
+    hip.view(-1)[runner_up] = ref.view(-1)[weakest] + 3e-8
+    (sr, _, _), _ = oracle_select_on(ref, conf)
+    (sh, _, _), _ = oracle_select_on(hip, conf)
+    assert set(sr.tolist()) ^ set(sh.tolist()) == {weakest, runner_up}
+    assert audit_keypoint_differences(sh, sr, hip, ref, conf) == 2
