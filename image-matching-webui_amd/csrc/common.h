@@ -62,6 +62,15 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     split2(b.z, b.w, hi.w, lo.w);
 }
 
+// the nearest f16 (round to nearest even, saturating) of 8 floats: the operand of the single-product arithmetic
+__device__ __forceinline__ unsigned half2_rtn(float x0, float x1) {
+    const f16x2 h = {(_Float16)fminf(fmaxf(x0, -65504.0f), 65504.0f), (_Float16)fminf(fmaxf(x1, -65504.0f), 65504.0f)};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ uint4 half8_rtn(const float4& a, const float4& b) {
+    return make_uint4(half2_rtn(a.x, a.y), half2_rtn(a.z, a.w), half2_rtn(b.x, b.y), half2_rtn(b.z, b.w));
+}
+
 // row inside a 32x32 C/D fragment held by (reg r, half hi)
 __device__ __forceinline__ int frag_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -247,7 +247,12 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
             const int idx = tid + 256 * k;
             if (idx < SNPIX * 4) {
                 uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
-                if ((pvalid >> k) & 1u) split8(pa[k], pc[k], hq, lq);
+                if ((pvalid >> k) & 1u) {
+                    if constexpr (SINGLE)
+                        hq = half8_rtn(pa[k], pc[k]);  // one product: the nearest f16 of either operand
+                    else
+                        split8(pa[k], pc[k], hq, lq);
+                }
                 Ph[(idx & 3) * SPSTR + (idx >> 2)] = hq;
                 if constexpr (!SINGLE) Pl[(idx & 3) * SPSTR + (idx >> 2)] = lq;
             }

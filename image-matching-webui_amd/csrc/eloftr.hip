@@ -254,8 +254,23 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
                                         int W0, int H1, int W1, double match_threshold, float* keypoints0, float* keypoints1,
                                         float* confidence, int* batch_indexes, int* num_matches, int debug_windows, void* ws,
                                         size_t ws_bytes, void* stream_) {
+    return imcui_hip_eloftr_forward_ex(h, packed, image0, image1, B, H0, W0, H1, W1, match_threshold, 0, keypoints0, keypoints1, confidence,
+                                       batch_indexes, num_matches, debug_windows, ws, ws_bytes, stream_);
+}
+
+// arith 1: the reference wrapper's `precision: "fp16"` / `"mp"` (eloftr.py:32-33,43-47,63-64: `self.net.half()` / autocast) as ONE f16
+// product per element pair, f32 accumulate, in the backbone and fine-fusion convolutions (the 0.36 of 0.42 TF of a pair that is
+// convolution work); the transformer blocks, similarity, matching and fine stages keep the 3 x f16 split arithmetic (their
+// soft-max / arg-max decisions are what the match list depends on).  arith 0 = the parity arithmetic.
+extern "C" int imcui_hip_eloftr_forward_ex(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0,
+                                           int W0, int H1, int W1, double match_threshold, int arith, float* keypoints0, float* keypoints1,
+                                           float* confidence, int* batch_indexes, int* num_matches, int debug_windows, void* ws,
+                                           size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!h) return IMCUI_ERR_ARG;
+    if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "eloftr: arith=%d (0 = 3 x f16 split products, 1 = one f16 product in the convolutions)", arith);
+    if (arith == 1 && h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "eloftr: the single-product arithmetic needs precision 1");
+    const int single = arith;
     if (B <= 0) return IMCUI_OK;
     if (H0 % 32 || W0 % 32 || H0 < 64 || W0 < 64 || H1 % 32 || W1 % 32 || H1 < 64 || W1 < 64)
         return imcui_set_err(h, IMCUI_ERR_ARG, "eloftr: image sizes %dx%d / %dx%d must be multiples of 32 (>= 64): the 1/8 grid is aggregated 4x4", W0, H0, W1, H1);
@@ -314,7 +329,8 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
                 const size_t off = s ? (size_t)B * npx(0, div) : 0;
                 const int r = conv3x3_split_launch(h, in + off * cin, reinterpret_cast<const unsigned short*>(P + l.c3h[li]),
                                                    reinterpret_cast<const unsigned short*>(P + l.c3l[li]), P + l.c3s[li], P + l.b[li], out + off * N,
-                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, cin, N, act, 0, stream, resid ? resid + off * N : nullptr);
+                                                   same ? 2 * B : B, Hs[s] / div, Ws[s] / div, cin, N, act, 0, stream, resid ? resid + off * N : nullptr, 0, 0,
+                                                   single);
                 if (r != IMCUI_OK) return r;
                 continue;
             }
@@ -347,6 +363,7 @@ extern "C" int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, con
                 g.rup_align = 0;
             }
             g.act = act;
+            g.single = (single && g.Wh != nullptr && g.rup_h == 0) ? 1 : 0;
             const int r = gemm_launch(h, g, stream);
             if (r != IMCUI_OK) return r;
         }

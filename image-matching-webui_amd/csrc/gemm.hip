@@ -762,6 +762,16 @@ __global__ __launch_bounds__(256, (WDMA && NW == 2) ? 3 : 2) void gemm_split_ker
         uint4 h, l;
         float4 fa = __builtin_bit_cast(float4, a0), fb = __builtin_bit_cast(float4, b0);
         if (ASRC == 1 && !v0) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SINGLE) {  // one product: the nearest f16 of either operand (common.h)
+            h = half8_rtn(fa, fb);
+            *reinterpret_cast<uint4*>(sm + wo0) = h;
+            fa = __builtin_bit_cast(float4, a1);
+            fb = __builtin_bit_cast(float4, b1);
+            if (ASRC == 1 && !v1) fa = fb = make_float4(0.f, 0.f, 0.f, 0.f);
+            h = half8_rtn(fa, fb);
+            *reinterpret_cast<uint4*>(sm + wo1) = h;
+            return;
+        }
         split8(fa, fb, h, l);
         *reinterpret_cast<uint4*>(sm + wo0) = h;
         if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + 8192 + wo0) = l;
@@ -1167,11 +1177,6 @@ static inline void f16_parts(float f, unsigned& sign, unsigned& mag, unsigned& r
     rem = m & 0x1FFFu;
     half = 0x1000u;
 }
-static inline unsigned short f32_to_f16_rtz(float f) {
-    unsigned s, g, r, h;
-    f16_parts(f, s, g, r, h);
-    return (unsigned short)(s | g);
-}
 static inline unsigned short f32_to_f16_rtn(float f) {
     unsigned s, g, r, h;
     f16_parts(f, s, g, r, h);
@@ -1214,8 +1219,13 @@ static inline int split_scale_exp(const float* w, size_t n) {
     }
     return e;
 }
+// Weights: hi = the NEAREST f16 (round to nearest even), lo = the nearest f16 of the exact remainder (|lo| <= half an ulp of hi).
+// Either rounding of hi gives an fp32-grade three-product split; nearest also makes the hi plane alone -- what the single-product
+// arithmetic of the DUSt3R / EfficientLoFTR "fp16" options multiplies -- an UNBIASED 11-bit operand (round 2 truncated it toward
+// zero: a coherent shrink that grew through the ~40 sequential layers of the ViT and left that mode slightly farther from the fp32
+// result than a bf16-autocast run; with nearest rounding on both operands it is closer, tests/test_gpu_dust3r.py anchor).
 static inline void split_one(float x, unsigned short& hi, unsigned short& lo) {
-    hi = f32_to_f16_rtz(x);
+    hi = f32_to_f16_rtn(x);
     lo = f32_to_f16_rtn(x - f16_to_f32(hi));
 }
 

@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     };
     auto store = [&](int stg) __attribute__((always_inline)) {
         uint4 h, l;
+        if constexpr (SINGLE) {  // one product: the nearest f16 of either operand (common.h)
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = half8_rtn(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0));
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = half8_rtn(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1));
+            return;
+        }
         split8(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0), h, l);
         *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = h;
         if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo0) = l;

@@ -575,9 +575,10 @@ class ELoFTRHIP:
         self._lock = threading.Lock()
         self.last_ws = None
 
-    def forward(self, packed, image0, image1, match_threshold, debug_windows=False):
+    def forward(self, packed, image0, image1, match_threshold, debug_windows=False, arith=0):
         """Upstream EfficientLoFTR forward on image0 [B,1,H0,W0] / image1 [B,1,H1,W1] (multiples of 32; the two sizes may
-        differ); fixed-capacity outputs + device match count."""
+        differ); fixed-capacity outputs + device match count.  arith 1 = the wrapper's precision "fp16" / "mp" (one f16
+        product per element pair in the convolutions)."""
         dev = image0.device
         hd = get_handle(dev)
         lib = hd.lib
@@ -597,8 +598,8 @@ class ELoFTRHIP:
             self.last_ws = ws
             self.last_dims = (B, H0, W0, H1, W1)
             with torch.cuda.device(dev):
-                rc = lib.imcui_hip_eloftr_forward(
-                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H0, W0, H1, W1, float(match_threshold), _ptr(kp0), _ptr(kp1),
+                rc = lib.imcui_hip_eloftr_forward_ex(
+                    hd.h, _ptr(packed), _ptr(image0), _ptr(image1), B, H0, W0, H1, W1, float(match_threshold), int(arith), _ptr(kp0), _ptr(kp1),
                     _ptr(conf), _ptr(bidx), _ptr(nm), int(bool(debug_windows)), _ptr(ws), ws.numel(), _stream_ptr(),
                 )  # fmt: skip
                 hd.check(rc, "imcui_hip_eloftr_forward")

@@ -20,8 +20,13 @@ Weights: conf["state_dict"] / conf["weights_path"], in either naming:
 
 Image pairs whose two images differ in size are accepted (the batch path of `match_dense.py` produces them).
 
-`model_type: "opt"` and `precision: "mp" / "fp16"` (eloftr.py:39-47) are speed variants of the same network for CUDA
-hosts; the HIP path always computes the 'full' network with fp32-grade arithmetic and rejects other settings loudly.
+`precision` (eloftr.py:32-33,43-47,63-64): "fp32" = the parity arithmetic (3 x f16 split products, fp32-grade); "fp16" (the
+reference's `self.net.half()`) and "mp" (its autocast flag) both select ONE f16 product per element pair, f32 accumulate, in the
+backbone and fine-fusion convolutions -- 11-bit operands where the reference's half run carries 11 and an autocast-bf16 run 8 --
+while the transformer, the similarity, the matching and the fine stages stay in the split arithmetic
+(`imcui_hip_eloftr_forward_ex`, arith 1; tests/test_gpu_eloftr.py compares it with the fp32 oracle).
+`model_type: "opt"` (eloftr.py:38-41: upstream's `opt_default_cfg`, a different coarse-matching rule without the dual soft-max)
+is refused: its semantics cannot be confirmed offline (the EfficientLoFTR sources are an un-vendored submodule).
 """
 from __future__ import annotations
 
@@ -133,8 +138,10 @@ class ELoFTR(BaseModel):
     required_inputs = ["image0", "image1"]
 
     def _init(self, conf):
-        if conf.get("model_type", "full") != "full" or conf.get("precision", "fp32") != "fp32":
-            raise NotImplementedError("the HIP EfficientLoFTR computes the 'full' model in fp32-grade arithmetic (model_type / precision are CUDA speed knobs)")
+        if conf.get("model_type", "full") != "full":
+            raise NotImplementedError("the HIP EfficientLoFTR computes the 'full' model (model_type 'opt' changes the coarse matching rule; not restated)")
+        if conf.get("precision", "fp32") not in ("fp32", "fp16", "mp"):
+            raise ValueError(f"precision {conf.get('precision')!r}: one of 'fp32', 'mp', 'fp16' (imcui/hloc/matchers/eloftr.py:32-33)")
         sd = resolve_state_dict(conf, "eloftr")
         if "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
@@ -145,7 +152,8 @@ class ELoFTR(BaseModel):
 
     def forward_batched(self, image0: torch.Tensor, image1: torch.Tensor, debug_windows: bool = False) -> dict:
         """Upstream forward(image0, image1) on a batch: fixed-capacity outputs, no host sync."""
-        return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], debug_windows)
+        arith = 0 if self.conf.get("precision", "fp32") == "fp32" else 1  # read per call: conf is mutable at run time
+        return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], debug_windows, arith)
 
     def forward_pairs(self, image0: torch.Tensor, image1: torch.Tensor) -> list:
         """`_forward` on B pairs at once (the batched dense driver): the per-pair dictionaries the wrapper would return for

@@ -112,6 +112,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_double] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "imcui_hip_eloftr_forward_ex": (
+        C.c_int,
+        [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_double, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "imcui_hip_eloftr_debug_offset": (C.c_size_t, [C.c_int] * 6),
     "imcui_hip_dust3r_packed_floats": (C.c_size_t, [C.c_int] * 5),
     "imcui_hip_dust3r_num_layers": (C.c_int, [C.c_int] * 5),

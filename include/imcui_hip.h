@@ -230,6 +230,13 @@ size_t imcui_hip_eloftr_workspace_bytes(int B, int H0, int W0, int H1, int W1, i
 int imcui_hip_eloftr_forward(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0, int W0,
                              int H1, int W1, double match_threshold, float* keypoints0, float* keypoints1, float* confidence,
                              int* batch_indexes, int* num_matches, int debug_windows, void* ws, size_t ws_bytes, void* stream);
+/* The same with the arithmetic of the reference wrapper's `precision` switch (imcui/hloc/matchers/eloftr.py:32-33,43-47,63-64):
+ * arith 0 = the call above ("fp32": 3 x f16 split products, fp32-grade); arith 1 = "fp16" / "mp": one f16 product per element pair
+ * (f32 accumulate) in the backbone and fine-fusion convolutions, everything that decides a match in the split arithmetic. */
+int imcui_hip_eloftr_forward_ex(imcui_hip_t* h, const float* packed, const float* image0, const float* image1, int B, int H0, int W0,
+                                int H1, int W1, double match_threshold, int arith, float* keypoints0, float* keypoints1,
+                                float* confidence, int* batch_indexes, int* num_matches, int debug_windows, void* ws, size_t ws_bytes,
+                                void* stream);
 /* byte offset inside the workspace of (per-image buffers: the B maps of image 0, then the B maps of image 1): 0 backbone 1/2
  * features [.,H/2,W/2,64], 1 1/4 features [.,H/4,W/4,128], 2 coarse features after the transformer [.,L,256], 3 sim [B,L0,L1],
  * 4 fused 1/2-resolution fine map [.,H/2,W/2,64], 5 fine windows [B*L0][64 + 100][64] (debug_windows)  (parity tests) */

@@ -155,3 +155,40 @@ def test_eloftr_plugin_contract():
     a = {tuple(r) for r in torch.cat([pred["keypoints0"].cpu(), pred["keypoints1"].cpu()], 1).round().int().tolist()}
     b = {tuple(r) for r in torch.cat([ref["keypoints0"], ref["keypoints1"]], 1).round().int().tolist()}
     assert len(a & b) >= 198
+
+
+@pytest.mark.parametrize("prec", ["fp16", "mp"])
+def test_eloftr_precision_fp16(prec):
+    """`precision: "fp16"` / `"mp"` of the reference wrapper (eloftr.py:32-33,43-47,63-64) = one f16 product per element pair in the
+    convolutions (imcui_hip_eloftr_forward_ex, arith 1).  Not a parity mode: against the fp32 oracle the backbone features are off
+    by the 11-bit operand class (< 5e-3 of their magnitude, where the parity arithmetic holds 2e-4), the known displacement of the
+    shifted pair is still recovered by > 90 % of the matches, and the match count stays within 10 % of the fp32 run's.  Anchor: the
+    same oracle under `torch.autocast("cpu", torch.bfloat16)` is farther from the fp32 oracle on the backbone features."""
+    from imcui_hip.hloc.matchers.eloftr import ELoFTR
+
+    torch.set_num_threads(16)
+    h, w = 256, 320
+    i0, i1, (dx, dy) = make_shifted_pair(2, h, w, (16, 24), 600)
+    m32 = ELoFTR({"match_threshold": 0.2, "max_keypoints": None, "state_dict": SD}).eval().to("cuda:0")
+    m16 = ELoFTR({"match_threshold": 0.2, "max_keypoints": None, "state_dict": SD, "precision": prec}).eval().to("cuda:0")
+    p32 = m32({"image0": i0.cuda(), "image1": i1.cuda()})
+    p16 = m16({"image0": i0.cuda(), "image1": i1.cuda()})
+    x1 = m16._impl.debug_buffer(0, (2 * h * w // 4 * 64,)).cpu()
+    ora = ELoFTROracle(SD, {"match_threshold": 0.2, "max_keypoints": None})
+    ref = ora.net(i1, i0, return_intermediates=True)  # the wrapper swaps the images before the net
+    want = torch.cat([x.permute(0, 2, 3, 1).reshape(-1) for x in ref["_x1"]], 0)
+    e16 = (x1 - want).abs().max().item() / want.abs().max().item()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        rb = ora.net(i1, i0, return_intermediates=True)
+    wb = torch.cat([x.float().permute(0, 2, 3, 1).reshape(-1) for x in rb["_x1"]], 0)
+    ebf = (wb - want).abs().max().item() / want.abs().max().item()
+    print(f"[anchor] ELoFTR {prec}: 1/2 backbone features HIP {e16:.2e} vs bf16 autocast {ebf:.2e} (relative to the fp32 oracle)")
+    assert 1e-5 < e16 < 5e-3 and e16 <= ebf
+    n32, n16 = len(p32["scores"]), len(p16["scores"])
+    assert n32 > 300 and abs(n16 - n32) <= 0.1 * n32, (n32, n16)
+    d = p16["keypoints0"].cpu() - p16["keypoints1"].cpu()
+    assert ((d - torch.tensor([float(dx), float(dy)])).norm(dim=1) < 2).float().mean().item() > 0.9
+    with pytest.raises(NotImplementedError):
+        ELoFTR({"state_dict": SD, "model_type": "opt"})
+    with pytest.raises(ValueError):
+        ELoFTR({"state_dict": SD, "precision": "int8"})

@@ -265,3 +265,42 @@ def test_superglue_packing_folds_bn_merge_and_heads(lib):
     assert (ref["matches0"] > -1).sum() > 60
     assert torch.equal(m0, ref["matches0"])
     assert (ms - ref["matching_scores0"]).abs().max().item() < 1e-4
+
+
+def test_eloftr_upstream_checkpoint_names_round_trip():
+    """The zoo's `eloftr` entry downloads `eloftr_outdoor.ckpt` and loads `["state_dict"]` with the UPSTREAM module names
+    (imcui/hloc/matchers/eloftr.py:56-61).  The plugin's name map must be a bijection onto the names the packer reads: port
+    state dict -> upstream names (with the Lightning `matcher.` prefix, inside a {"state_dict": ...} container, plus keys a
+    training checkpoint carries) -> plugin -> the SAME packed buffer as the port's own names give (missing #3a)."""
+    import torch
+    from transformers import EfficientLoFTRConfig, EfficientLoFTRForKeypointMatching
+
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers import eloftr as E
+
+    torch.manual_seed(0)
+    net = EfficientLoFTRForKeypointMatching(EfficientLoFTRConfig())
+    with torch.no_grad():  # non-trivial BatchNorm statistics so that a swapped branch cannot hide
+        for name, buf in net.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(torch.randn_like(buf) * 0.1)
+            elif name.endswith("running_var"):
+                buf.copy_(torch.rand_like(buf) + 0.5)
+    sd = net.state_dict()
+    up = E.port_to_upstream_names(sd)
+    assert len(up) == len(sd) == 447 and all(k.startswith("matcher.") for k in up)
+    assert "matcher.backbone.layer0.rbr_dense.conv.weight" in up and "matcher.backbone.layer3.13.rbr_identity.running_var" in up
+    assert "matcher.loftr_coarse.layers.7.mlp.2.weight" in up and "matcher.fine_preprocess.layer1_outconv2.3.weight" in up
+    back = E.upstream_to_port_names(up)
+    assert set(back) == set(sd) and all(back[k] is sd[k] for k in sd)
+    # as the reference loads it: a Lightning container with extra keys, names with and without the prefix
+    ckpt = {"state_dict": {**up, "matcher.pos_encoding.sin": torch.zeros(3)}, "epoch": 29}
+    want = backend.pack_eloftr(sd)
+    for container in (ckpt, {k[len("matcher."):]: v for k, v in up.items()}):
+        model_sd = container["state_dict"] if "state_dict" in container else container
+        got = backend.pack_eloftr(E.to_port_names(model_sd))
+        assert torch.equal(got, want)
+    with pytest.raises(KeyError, match="unrecognised tensors"):
+        E.upstream_to_port_names({**up, "matcher.backbone.layer9.rbr_dense.conv.weight": torch.zeros(1)})
+    with pytest.raises(KeyError, match="must use the upstream names"):
+        E.to_port_names({"foo.weight": torch.zeros(1)})
