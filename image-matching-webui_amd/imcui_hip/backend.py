@@ -758,6 +758,9 @@ class DUSt3RHIP:
         dev = images.device
         hd = get_handle(dev)
         lib = hd.lib
+        if lib.imcui_hip_get_precision(hd.h) != 1:  # imcui_hip_dust3r_forward exists in the 3 x f16 split arithmetic only
+            raise ImcuiHipError("DUSt3R / MASt3R run in the library's default arithmetic (imcui_hip_set_precision(h, 1)): the exact-f32 matrix "
+                                "mode has no ViT kernels (for an exact-f32 nearest-neighbour search set conf['matcher_arithmetic'] = 'fp32')")
         images = images.contiguous().float()
         NI, Cc, H, W = images.shape
         if Cc != 3:

@@ -31,9 +31,10 @@ class Mast3r(Duster):
         "max_keypoints": 2000,
         "vit_patch_size": 16,
         "arithmetic": "fp32",
-        # HIP backend only: arithmetic of the nearest-neighbour searches -- "auto" = the library's mode (imcui_hip_set_precision: 3 x f16 split
-        # products by default, the exact-f32 matrix instruction in precision 0), "split" / "fp32" force one.  Split: 4 x fewer matrix
-        # cycles, fp32-grade similarities; candidates closer than ~3e-7 may resolve differently from the exact-f32 instruction.
+        # HIP backend only: arithmetic of the nearest-neighbour searches -- "auto" / "split" = 3 x f16 split products (the arithmetic the
+        # network itself runs in; 4 x fewer matrix cycles, fp32-grade similarities), "fp32" = the exact-f32 matrix instruction
+        # (candidates closer than ~3e-7 may resolve differently between the two).  The NETWORK has no exact-f32 mode: with
+        # imcui_hip_set_precision(h, 0) the plugin raises a clear error at the first call.
         "matcher_arithmetic": "auto",
     }
     weights_subdir = "mast3r"

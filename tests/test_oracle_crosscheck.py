@@ -299,7 +299,9 @@ def test_eloftr_reparameterisation_and_packing():
             w, bias = backend._repvgg_reparam(orc.sd, f"efficientloftr.backbone.stages.{s}.blocks.{b}")
             y = F.relu(F.conv2d(y, w, bias, st if b == 0 else 1, 1))
     assert (y - x3).abs().max().item() < 2e-5 * x3.abs().max().item()
-    from imcui_hip.hloc.matchers.eloftr import check_port_names
+    from imcui_hip.hloc.matchers.eloftr import to_port_names
 
+    # upstream-named checkpoints are mapped (tests/test_host_cpu.py round-trips the map); anything else is refused
+    assert "efficientloftr.backbone.stages.0.blocks.0.conv1.conv.weight" in to_port_names({"matcher.backbone.layer0.rbr_dense.conv.weight": torch.zeros(1)})
     with pytest.raises(KeyError):
-        check_port_names({"matcher.backbone.layer0.rbr_dense.conv.weight": torch.zeros(1)})
+        to_port_names({"net.conv.weight": torch.zeros(1)})
