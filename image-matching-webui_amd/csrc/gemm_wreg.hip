@@ -26,12 +26,23 @@
 #define WR_STG_TROW 36   // floats per parked [feature][32 tokens] row (144 B)
 #define WR_WAVE_LDS 9216  // staging bytes per wave (32 x 68 x 4 = 8704; 64 x 36 x 4 = 9216)
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// the pointer only depends on the workgroup: tell the compiler (buffer descriptors must live in SGPRs; cf. attention.hip)
+__device__ __forceinline__ const void* wr_uniform_ptr(const void* p) {
+    const size_t v = (size_t)p;
+    const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffu));
+    const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const void*)((size_t)lo32 | ((size_t)hi32 << 32));
+}
 __device__ __forceinline__ void wr_wave_fence() {
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS traffic is done
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int EPI, bool SINGLE>
+// PIPE: the K loop with the weight fragments requested TWO k-steps ahead in three rotating register sets (the schedule of the fused
+// FFN's first GEMM, ffn.hip VAR 1: vmcnt retires in order, so an activation tile gets exactly the lead of the weights requested after
+// it); unrolled over three K tiles so that the set of a k-step is static.  PIPE = false keeps the rolled loop, one k-step ahead.
+template <int EPI, bool SINGLE, bool PIPE = true>
 __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     __shared__ uint4 smem[(4 * WR_WAVE_LDS) / 16];  // main loop: two 16 KB activation stages; epilogue: 4 x 9 KB wave staging
     char* sm = reinterpret_cast<char*>(smem);
@@ -80,45 +91,99 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = h;
         if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo1) = l;
     };
-    // ---- weights: fragments (nf, ks) of the planes [ceil(N/32)][K/16][64 lanes][8 halves] at ((nf * nks) + ks) * 64 + lane
+    // ---- weights: fragments (nf, ks) of the planes [ceil(N/32)][K/16][64 lanes][8 halves] at ((nf * nks) + ks) * 64 + lane.
+    // Buffer loads: two wave-uniform descriptors (hi / lo plane of the selected weight set), one 32-bit lane offset per feature
+    // fragment and a scalar k-step offset -- no 64-bit address registers in the loop (the pipelined loop needs the registers)
     const int nfr = (p.N + 31) >> 5;
-    const uint4 *whp[2], *wlp[2];
+    const size_t plane_bytes = (size_t)nfr * 32 * p.K * 2;
+    const __amdgpu_buffer_rsrc_t rWh =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wr_uniform_ptr(p.Wh + (size_t)c.wsel * p.w_stride)), 0, (unsigned)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rWl =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wr_uniform_ptr(p.Wl + (size_t)c.wsel * p.w_stride)), 0, (unsigned)plane_bytes, 0x00020000);
+    unsigned wof[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int nf = min((c.col0 >> 5) + 2 * wid + n, nfr - 1);
-        whp[n] = reinterpret_cast<const uint4*>(p.Wh + (size_t)c.wsel * p.w_stride) + ((size_t)nf * nks) * 64 + lane;
-        wlp[n] = reinterpret_cast<const uint4*>(p.Wl + (size_t)c.wsel * p.w_stride) + ((size_t)nf * nks) * 64 + lane;
+        wof[n] = (unsigned)((nf * nks) * 64 + lane) * 16u;
     }
-    uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step
+    uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step (rolled loop)
     auto loadw = [&](int s, uint4(&w)[2][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            w[n][0] = whp[n][(size_t)s * 64];
-            if constexpr (!SINGLE) w[n][1] = wlp[n][(size_t)s * 64];
+            const u32x4_t vh = __builtin_amdgcn_raw_buffer_load_b128(rWh, wof[n], (unsigned)s * 1024u, 0);
+            w[n][0] = make_uint4(vh.x, vh.y, vh.z, vh.w);
+            if constexpr (!SINGLE) {
+                const u32x4_t vl = __builtin_amdgcn_raw_buffer_load_b128(rWl, wof[n], (unsigned)s * 1024u, 0);
+                w[n][1] = make_uint4(vl.x, vl.y, vl.z, vl.w);
+            }
         }
     };
     auto kstep = [&](int stg, int ks, uint4(&w)[2][2]) __attribute__((always_inline)) {
         const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
-        uint4 ah[4], al[4];
+        // two halves of two token fragments each: 16 instead of 32 fragment registers live (the pipelined loop needs them for
+        // its third weight set)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int fo = stg * 16384 + (ks * 4 + m) * 1024 + apos;
-            ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
-            if constexpr (!SINGLE) al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
-        }
+        for (int mh = 0; mh < 2; ++mh) {
+            uint4 ah[2], al[2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                // weight fragment = MFMA A operand (rows = features), activations = B (columns = tokens)
-                if constexpr (!SINGLE) {
-                    acc[n][m] = mfma16(w[n][0], al[m], acc[n][m]);
-                    acc[n][m] = mfma16(w[n][1], ah[m], acc[n][m]);
-                }
-                acc[n][m] = mfma16(w[n][0], ah[m], acc[n][m]);
+            for (int m = 0; m < 2; ++m) {
+                const int fo = stg * 16384 + (ks * 4 + 2 * mh + m) * 1024 + apos;
+                ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
+                if constexpr (!SINGLE) al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
             }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // weight fragment = MFMA A operand (rows = features), activations = B (columns = tokens)
+                    if constexpr (!SINGLE) {
+                        acc[n][2 * mh + m] = mfma16(w[n][0], al[m], acc[n][2 * mh + m]);
+                        acc[n][2 * mh + m] = mfma16(w[n][1], ah[m], acc[n][2 * mh + m]);
+                    }
+                    acc[n][2 * mh + m] = mfma16(w[n][0], ah[m], acc[n][2 * mh + m]);
+                }
+            if constexpr (PIPE) {
+                if (mh == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
 
+    if constexpr (PIPE) {
+        uint4 w0[2][2], w1[2][2], w2[2][2];
+        issue(0);
+        loadw(0, w0);
+        if (nks > 1) loadw(1, w1);
+        store(0);
+        if (nkt > 1) issue(1);
+        __syncthreads();
+        // tile kt (k-steps s = 2 kt, s + 1): W(s+2) | MFMAs of s | store tile kt+1, request X(kt+2) | W(s+3) | MFMAs of s+1 | barrier
+#define WR_TILE(KT, WA, WB, WC)                                  \
+    {                                                            \
+        const int kt_ = (KT), stg_ = kt_ & 1, s_ = 2 * kt_;      \
+        if (s_ + 2 < nks) loadw(s_ + 2, WC);                     \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        kstep(stg_, 0, WA);                                      \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        if (kt_ + 1 < nkt) {                                     \
+            store(stg_ ^ 1);                                     \
+            if (kt_ + 2 < nkt) issue(kt_ + 2);                   \
+        }                                                        \
+        if (s_ + 3 < nks) loadw(s_ + 3, WA);                     \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        kstep(stg_, 1, WB);                                      \
+        __syncthreads();                                         \
+    }
+        int kt = 0;
+#pragma unroll 1
+        for (; kt + 3 <= nkt; kt += 3) {
+            WR_TILE(kt, w0, w1, w2)
+            WR_TILE(kt + 1, w2, w0, w1)
+            WR_TILE(kt + 2, w1, w2, w0)
+        }
+        if (kt < nkt) WR_TILE(kt, w0, w1, w2)
+        if (kt + 1 < nkt) WR_TILE(kt + 1, w2, w0, w1)
+#undef WR_TILE
+    } else {
     issue(0);
     loadw(0, wc);
     store(0);
@@ -136,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         }
         kstep(stg, 1, wn);
         __syncthreads();
+    }
     }
 
     // ================================================================== epilogue (wave-private staging)
@@ -384,19 +450,27 @@ bool gemm_wreg_ok(const GemmP& p) {
     return p.epi == EPI_BIAS || p.epi == EPI_RELU || p.epi == EPI_RESID || p.epi == EPI_CONV;
 }
 
-void gemm_wreg_launch(const GemmP& p, hipStream_t stream) {
+template <bool PIPE>
+static void wreg_launch(const GemmP& p, hipStream_t stream) {
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, WR_BN), 1, 1);
     switch (p.epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_BIAS, false>), grid, dim3(256), 0, stream, p); break;
-        case EPI_RELU: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RELU, false>), grid, dim3(256), 0, stream, p); break;
-        case EPI_RESID: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RESID, false>), grid, dim3(256), 0, stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV, false>), grid, dim3(256), 0, stream, p); break;
-        case EPI_CROSS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CROSS, false>), grid, dim3(256), 0, stream, p); break;
-        case EPI_QKV_VIT: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV_VIT, false>), grid, dim3(256), 0, stream, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_BIAS, false, PIPE>), grid, dim3(256), 0, stream, p); break;
+        case EPI_RELU: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RELU, false, PIPE>), grid, dim3(256), 0, stream, p); break;
+        case EPI_RESID: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_RESID, false, PIPE>), grid, dim3(256), 0, stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV, false, PIPE>), grid, dim3(256), 0, stream, p); break;
+        case EPI_CROSS: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CROSS, false, PIPE>), grid, dim3(256), 0, stream, p); break;
+        case EPI_QKV_VIT: hipLaunchKernelGGL((gemm_wreg_kernel<EPI_QKV_VIT, false, PIPE>), grid, dim3(256), 0, stream, p); break;
         default:
             if (p.single)
-                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, true>), grid, dim3(256), 0, stream, p);
+                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, true, PIPE>), grid, dim3(256), 0, stream, p);
             else
-                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, false>), grid, dim3(256), 0, stream, p);
+                hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, false, PIPE>), grid, dim3(256), 0, stream, p);
     }
+}
+void gemm_wreg_launch(const GemmP& p, hipStream_t stream) {
+    const char* e = getenv("IMCUI_WREG_PIPE");  // A/B switch: 0 = the rolled K loop
+    if (e && atoi(e) == 0)
+        wreg_launch<false>(p, stream);
+    else
+        wreg_launch<true>(p, stream);
 }
