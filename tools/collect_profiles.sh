@@ -2,7 +2,7 @@
 # Round evidence collector: run on the GPU box (gpurun), writes under gpurun_out/final/.
 # rocprofv3 needs cwd=/tmp and TMPDIR=/tmp on this pool; counters are collected one per pass.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/final
+O=$R/gpurun_out/${OUT:-final_r03}
 mkdir -p $O
 # LG_ONLY=1: only the SuperPoint+LightGlue legs (use after a change that cannot affect LoFTR / SuperGlue / the lab binaries)
 # SKIP_LABS=1: everything except the stand-alone lab programs (their output does not depend on the library)
@@ -75,6 +75,13 @@ done
 # the fused FFN kernel: A/B against the three-launch path, and its phase breakdown
 ( cd $R && IMCUI_LG_FFN_UNFUSED=1 timeout 100 python bench.py --no-cpu-baseline > $O/bench_splg_unfused_ffn.json.log 2>&1; tail -1 $O/bench_splg_unfused_ffn.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_LF_MATCH_4PASS=1 timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024_4pass.json.log 2>&1; tail -1 $O/bench_loftr_1024_4pass.json.log | cut -c1-160 )
+# ---- round 3 A/B legs: projection GEMMs on the round-2 kernel, rolled K loop, soft-max partials from the GEMM epilogue, ViT q/k/v round trip
+( cd $R && IMCUI_GEMM_WREG=0 timeout 100 python bench.py --no-cpu-baseline --no-parity > $O/bench_splg_wreg_off.json.log 2>&1; tail -1 $O/bench_splg_wreg_off.json.log | cut -c1-160 )
+( cd $R && IMCUI_WREG_PIPE=0 timeout 100 python bench.py --no-cpu-baseline --no-parity > $O/bench_splg_wreg_rolled.json.log 2>&1; tail -1 $O/bench_splg_wreg_rolled.json.log | cut -c1-160 )
+( cd $R && IMCUI_LG_ASSIGN_STATS=epilogue timeout 100 python bench.py --no-cpu-baseline --no-parity > $O/bench_splg_assign_epilogue.json.log 2>&1; tail -1 $O/bench_splg_assign_epilogue.json.log | cut -c1-160 )
+( cd $R && timeout 200 python bench.py --workload nn > $O/bench_nn.json.log 2>&1; tail -1 $O/bench_nn.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && IMCUI_DUST3R_QKV_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_qkv_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_qkv_unfused.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && IMCUI_GEMM_WREG=0 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_wreg_off.json.log 2>&1; tail -1 $O/bench_dust3r_512_wreg_off.json.log | cut -c1-160 )
 ( cd $R && timeout 100 python tools/ffn_bench.py > $O/lab_ffn_phases.txt 2>&1 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 ls $O

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", "final")
+F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r03"))
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
@@ -86,7 +86,7 @@ if os.path.exists(dsq):
     by = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(dsq)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        if k.startswith("gemm_split_kernel"):
+        if k.startswith("gemm_split_kernel") or k.startswith("gemm_wreg_kernel"):
             k = f"{k} grid {r['Grid_Size']}"
         by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dq = {}
@@ -122,6 +122,10 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_mast3r_512.json.log", f"{tag}_bench_mast3r_512.json.log"),
                  ("stats_dust3r/dust3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_dust3r_512.csv"),
                  ("bench_splg_unfused_ffn.json.log", f"{tag}_bench_splg_unfused_ffn.json.log"),
+                 ("bench_splg_wreg_off.json.log", f"{tag}_bench_splg_wreg_off.json.log"), ("bench_splg_wreg_rolled.json.log", f"{tag}_bench_splg_wreg_rolled.json.log"),
+                 ("bench_splg_assign_epilogue.json.log", f"{tag}_bench_splg_assign_epilogue.json.log"), ("bench_nn.json.log", f"{tag}_bench_nn.json.log"),
+                 ("bench_dust3r_512_qkv_unfused.json.log", f"{tag}_bench_dust3r_512_qkv_unfused.json.log"),
+                 ("bench_dust3r_512_wreg_off.json.log", f"{tag}_bench_dust3r_512_wreg_off.json.log"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
