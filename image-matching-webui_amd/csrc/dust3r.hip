@@ -240,20 +240,25 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
 }
 
 // ------------------------------------------------------------------ workspace
+constexpr int DU_MAX_CLASSES = 4;  // distinct image sizes of one call (the wrapper's symmetrised pair has at most two)
 struct DuWs {
     float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
     float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2, *lfh, *lfo;
-    float *rcos, *rsin;  // RoPE2D tables [R][32] of the token grid (the fused q / k / v projection epilogue reads them)
+    float *rcos, *rsin;  // RoPE2D tables [class][R][32] of the token grids (the fused q / k / v projection epilogue reads them)
     int *cnt, *smap, *wsel, *wsel_rev;
+    int* geo;  // images of several sizes: per-sequence token counts / grid widths / table rows, head gather maps (du_forward_impl)
+    size_t geo_ints;
     size_t total;
     bool ok;
 };
-static int du_R(int H, int W) { return ((H / 16) * (W / 16) + 127) / 128 * 128; }
-static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int H, int W) {
+static int du_R_tokens(size_t T) { return (int)((T + 127) / 128 * 128); }
+static int du_R(int H, int W) { return du_R_tokens((size_t)(H / 16) * (W / 16)); }
+// T = tokens of the LARGEST image of the call: every sequence is padded to R rows, the head buffers hold P maps of T cells
+static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, size_t T) {
     WsAlloc a(ws, bytes);
     DuWs w;
     const size_t E = c.E, D = c.D;
-    const size_t T = (size_t)(H / 16) * (W / 16), R = du_R(H, W);
+    const size_t R = du_R_tokens(T);
     const size_t me = (size_t)NI * R, md = (size_t)2 * P * R;
     const size_t mx = me * E > md * D ? me * E : md * D;  // largest token buffer of either stage
     w.A0 = a.get<float>(me * 768);
@@ -274,7 +279,7 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     const size_t bt = (size_t)2 * P * T;  // dense token rows of both views
     w.tok0 = a.get<float>(bt * E);
     for (int k = 0; k < 3; ++k) w.hook[k] = a.get<float>(bt * D);
-    const size_t pt = (size_t)P * T;  // one view: P maps of T cells
+    const size_t pt = (size_t)P * T + 64;  // one view: P maps of T cells (+ slack: an odd grid rounds its 1/32 level up)
     w.ta = a.get<float>(pt * 768);
     w.tb = a.get<float>(pt * 1536);
     w.tm = a.get<float>(pt * 16 * 96 > pt * 768 ? pt * 16 * 96 : pt * 768);
@@ -293,22 +298,26 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, int 
     w.hd2 = a.get<float>(pt * 256 * 128);
     w.lfh = c.desc > 0 ? a.get<float>(pt * 4 * (E + D)) : nullptr;  // MASt3R: hidden layer and output of head_local_features
     w.lfo = c.desc > 0 ? a.get<float>(pt * (size_t)(c.desc + 1) * 256) : nullptr;
-    w.rcos = a.get<float>(R * 32);
-    w.rsin = a.get<float>(R * 32);
-    w.cnt = a.get<int>((size_t)(NI > 2 * P ? NI : 2 * P) + 64);
+    w.rcos = a.get<float>((size_t)DU_MAX_CLASSES * R * 32);
+    w.rsin = a.get<float>((size_t)DU_MAX_CLASSES * R * 32);
+    const size_t nseq = (size_t)(NI > 2 * P ? NI : 2 * P) + 64;
+    w.cnt = a.get<int>(nseq);
     w.smap = a.get<int>((size_t)2 * P + 64);
     w.wsel = a.get<int>((size_t)P + 64);
     w.wsel_rev = a.get<int>((size_t)P + 64);
+    w.geo_ints = 8 * nseq;
+    w.geo = a.get<int>(w.geo_ints);
     w.total = a.off;
     w.ok = a.ok;
     return w;
 }
-static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0; }
+static bool du_size_ok(int H, int W) { return H >= 32 && W >= 32 && H % 16 == 0 && W % 16 == 0 && H <= 4096 && W <= 4096; }
+static bool du_dims_ok(int NI, int P, int H, int W) { return NI > 0 && P > 0 && du_size_ok(H, W); }
 
 extern "C" size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W) {
     const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
     if (!du_cfg_ok(c) || !du_dims_ok(NI, P, H, W)) return 0;
-    return du_carve(nullptr, 0, c, NI, P, H, W).total;
+    return du_carve(nullptr, 0, c, NI, P, (size_t)(H / 16) * (W / 16)).total;
 }
 
 // floats the optional dump of the forward holds: (enc_depth + 2) x [NI R E] (patch embedding, every block, enc_norm), (dec_depth + 2) x
@@ -325,33 +334,36 @@ extern "C" size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int d
     return n + 2 * per_view;
 }
 
-// ------------------------------------------------------------------ forward
-// images [NI,3,H,W] in [0,1]; pairs (device) [P][2]: directed pair p = (view 1 image, view 2 image), indices clamped to [0, NI).
-// arith: 0 = the 3 x f16 split products of the library's default mode (fp32-grade results), 1 = ONE f16 product per element pair in the
-// GEMMs and convolutions (f32 accumulate; 11-bit operands: the class of the bf16 run BASELINE's configs[4] names).  Outputs, view-major:
-// pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W];
-// MASt3R (desc_dim > 0): desc [2][P][H][W][desc_dim] (unit norm), desc_conf [2][P][H][W].
-extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
-                                        const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d,
-                                        float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes,
-                                        void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!h) return IMCUI_ERR_ARG;
-    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
-    if (!du_cfg_ok(c)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: unsupported configuration (dims multiples of 64 up to 1024, dec_depth a multiple of 4)");
-    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
-    if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: arith = %d (0: 3 x f16 split products, 1: one f16 product)", arith);
+// ------------------------------------------------------------------ geometry of a call
+// Upstream's `inference` accepts views of different sizes (it then encodes the two views of a pair separately and runs one pair
+// per batch, dust3r/inference.py; the reference's drivers resize each image on its own, so two photos of different aspect ratio
+// DO arrive at two sizes).  Here every image belongs to one of K <= DU_MAX_CLASSES size classes; all sequences are padded to the
+// R rows of the largest grid and carry their own token count (GEMM tile skipping, attention masks), grid width and RoPE2D table;
+// the DPT heads run once per (view, class) on the densely gathered maps of that class.
+struct DuGeom {
+    int K = 1;
+    int H[DU_MAX_CLASSES], W[DU_MAX_CLASSES];
+    size_t Tmax = 0;
+    const int* img_class = nullptr;    // host [NI]            (K > 1)
+    const int* pairs_host = nullptr;   // host [P][2]          (K > 1)
+    const size_t* img_off = nullptr;   // host [NI]: float offset of image i in `images` (K > 1)
+    const size_t* map_pix = nullptr;   // host [2][P]: pixel offset of the output map of (view, pair) (K > 1)
+};
+
+// images in [0,1]; pairs (device) [P][2]: directed pair p = (view 1 image, view 2 image), indices clamped to [0, NI).
+static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, const float* images, int NI, const DuGeom& geo, const int* pairs, int P,
+                           int arith, float* pts3d, float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws,
+                           size_t ws_bytes, hipStream_t stream) {
     const int single = arith;  // GEMMs and 3x3 convolutions with ONE f16 product per element pair; attention stays in the split arithmetic
-    if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 16", NI, W, H, P);
-    if (!packed || !images || !pairs || !pts3d || !conf || (c.desc > 0 && (!desc || !desc_conf)))
-        return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
     if (((size_t)(c.E / 64) * NI) % 8 != 0 || ((size_t)(c.D / 64) * 2 * P) % 8 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: heads x sequences must be a multiple of 8 (encoder %d x %d, decoder %d x %d)", c.E / 64, NI, c.D / 64, 2 * P);
-    DuWs w = du_carve(ws, ws_bytes, c, NI, P, H, W);
+    DuWs w = du_carve(ws, ws_bytes, c, NI, P, geo.Tmax);
     if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "dust3r: workspace too small (%zu < %zu)", ws_bytes, w.total);
     const DuLayout l = du_layout(c);
     const float* Pk = packed;
-    const int E = c.E, D = c.D, hg = H / 16, wg = W / 16, T = hg * wg, R = du_R(H, W);
+    const bool mixed = geo.K > 1;
+    const int E = c.E, D = c.D, R = du_R_tokens(geo.Tmax);
+    const int H = geo.H[0], W = geo.W[0], hg = H / 16, wg = W / 16, T = hg * wg;  // THE grid of a one-size call (mixed: class 0 only)
     const dim3 blk(256);
     int rc;
 #define DURUN(x)                       \
@@ -379,7 +391,12 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     const float* vecs = Pk;
     auto V = [&](int vi) { return vecs + l.vec[vi]; };
 
-    // linear layer li on `nseq` sequences of R rows (T live): C = act(A W^T + b + resid)
+    // per-sequence geometry of the stage that is running (encoder: one sequence per image, decoder: one per stream): token counts
+    // for the GEMMs' tile skipping and the attention masks; with several image sizes also the first RoPE2D table row, the token
+    // count and the grid width of every sequence (nullptr in a one-size call: the scalars T / wg / table row 0 hold for all)
+    const int *cur_cnt = w.cnt, *cur_row0 = nullptr, *cur_T = nullptr, *cur_wg = nullptr;
+
+    // linear layer li on `nseq` sequences of R rows (cnt live): C = act(A W^T + b + resid)
     auto lin = [&](int li, const float* A, float* C, int nseq, const float* resid, int act) -> int {
         int N, K, kind;
         du_shape(c, li, &N, &K, &kind);
@@ -401,7 +418,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.act = act;
         g.single = single;
         g.M = nseq * R;
-        g.cnt = w.cnt;
+        g.cnt = cur_cnt;
         g.rows_per_seq = R;
         return gemm_launch(h, g, stream);
     };
@@ -413,10 +430,13 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     auto lin2 = [&](int i, int j, const float* A, long lda_rows, float* C, long ldc_rows, const float* resid, int act, bool swap) -> int {
         const int L0 = du_l_dec(c, 0, i, j), L1 = du_l_dec(c, 1, i, j);
         if (!merged) {
+            const int* cnt_all = cur_cnt;
             for (int s = 0; s < 2; ++s) {
                 const int li = swap ? (s ? L0 : L1) : (s ? L1 : L0);
+                cur_cnt = cnt_all + (size_t)s * P;
                 const int r = lin(li, A + (size_t)s * P * R * lda_rows, C + (size_t)s * P * R * ldc_rows, P,
                                   resid ? resid + (size_t)s * P * R * ldc_rows : nullptr, act);
+                cur_cnt = cnt_all;
                 if (r != IMCUI_OK) return r;
             }
             return IMCUI_OK;
@@ -444,7 +464,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.act = act;
         g.single = single;
         g.M = 2 * P * R;
-        g.cnt = w.cnt;
+        g.cnt = cur_cnt;
         g.rows_per_seq = R;
         return gemm_launch(h, g, stream);
     };
@@ -477,11 +497,11 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     auto rope_split = [&](const float* src, long ld, int col0, int C, int nseq, float* planes, int nseq_planes, int seq_out0, float alpha) {
         const long n = (long)nseq * R * (C / 64) * 4;
         hipLaunchKernelGGL(du_rope_split_kernel, blocks(n), blk, 0, stream, src, ld, col0, C / 64, T, R, wg, V(du_v_invf(c)), alpha, 1,
-                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0, n);
+                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0, n, cur_T, cur_wg);
     };
     auto vt_split = [&](const float* src, long ld, int col0, int C, int nseq, float* planes, int nseq_planes, int seq_out0) {
         hipLaunchKernelGGL(du_vt_split_kernel, dim3((unsigned)(nseq * (C / 64) * (R / 64))), blk, 0, stream, src, ld, col0, C / 64, T, R,
-                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0);
+                           reinterpret_cast<unsigned short*>(planes), (size_t)nseq_planes * C * R, seq_out0, cur_T);
     };
     // q / k / v projection with the attention operand planes written by the GEMM's own epilogue (EPI_QKV_VIT, gemm_wreg.hip:
     // RoPE2D from the tables, q scaled, f16 hi / lo planes, V transposed) instead of an f32 [rows][N] round trip through
@@ -510,7 +530,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.A = A;
         g.lda = K;
         g.M = nseq * R;
-        g.cnt = w.cnt;
+        g.cnt = cur_cnt;
         g.rows_per_seq = R;
         g.heads = C / 64;
         g.role0 = role0;
@@ -522,6 +542,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         g.V = vpl;
         g.rope_cos = w.rcos;
         g.rope_sin = w.rsin;
+        g.rope_seq_row0 = cur_row0;
         g.alpha = q_alpha;
         *done = li1 != -2 && !qkv_unfused_env && !single && N == nblk * C && gemm_wreg_ok(g);
         if (!*done) return IMCUI_OK;
@@ -533,7 +554,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         a.K = k;
         a.V = v;
         a.O = out;
-        a.cnt = w.cnt;
+        a.cnt = cur_cnt;
         a.nseq = nseq;
         a.heads = C / 64;
         a.rows_per_seq = R;
@@ -542,20 +563,98 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         return attention_launch(h, a, stream);
     };
 
+    // ---- tables
+    // several sizes: groups of the DPT heads.  Group (v, k) = the streams of view v whose image is of class k, in pair order;
+    // their maps sit densely (T_k rows each) behind each other in tok0 / hook[], groups in (v, k) order.
+    struct Group {
+        int v, k, n, first;  // first: index of the group's first entry in hmap / imap
+        size_t row0;         // first dense token row
+    };
+    std::vector<Group> groups;
+    std::vector<int> hmap_host;  // stream of every dense map
+    const int *cnt_enc = w.cnt, *cnt_dec = w.cnt, *row0_enc = nullptr, *row0_dec = nullptr, *T_enc = nullptr, *T_dec = nullptr, *wg_enc = nullptr,
+              *wg_dec = nullptr, *hmap_dev = nullptr, *imap_dev = nullptr;
     {
         const int ncnt = NI > 2 * P ? NI : 2 * P;
-        hipLaunchKernelGGL(du_fill_int_kernel, dim3((unsigned)cdiv(ncnt, 256)), blk, 0, stream, w.cnt, T, ncnt);
         // stream s < P: view 1 of pair s, stream P + s: view 2
         hipLaunchKernelGGL(du_smap_kernel, dim3((unsigned)cdiv(2 * P, 256)), blk, 0, stream, pairs, w.smap, P, NI);
         hipLaunchKernelGGL(du_wsel_kernel, dim3((unsigned)cdiv(P, 256)), blk, 0, stream, w.wsel, w.wsel_rev, P);
-        hipLaunchKernelGGL(du_rope_table_kernel, dim3((unsigned)cdiv(R * 32, 256)), blk, 0, stream, V(du_v_invf(c)), T, R, wg, w.rcos, w.rsin);
+        if (!mixed) {
+            hipLaunchKernelGGL(du_fill_int_kernel, dim3((unsigned)cdiv(ncnt, 256)), blk, 0, stream, w.cnt, T, ncnt);
+            hipLaunchKernelGGL(du_rope_table_kernel, dim3((unsigned)cdiv(R * 32, 256)), blk, 0, stream, V(du_v_invf(c)), T, R, wg, w.rcos, w.rsin);
+        } else {
+            const size_t ns = (size_t)ncnt + 64;  // slot length of the carve
+            std::vector<int> g(8 * ns, 0);
+            int *h_cnt_enc = g.data(), *h_cnt_dec = g.data() + ns, *h_row_enc = g.data() + 2 * ns, *h_row_dec = g.data() + 3 * ns,
+                *h_wg_enc = g.data() + 4 * ns, *h_wg_dec = g.data() + 5 * ns, *h_hmap = g.data() + 6 * ns, *h_imap = g.data() + 7 * ns;
+            auto Tk = [&](int k) { return (geo.H[k] / 16) * (geo.W[k] / 16); };
+            for (int i = 0; i < NI; ++i) {
+                const int k = geo.img_class[i];
+                h_cnt_enc[i] = Tk(k);
+                h_row_enc[i] = k * R;
+                h_wg_enc[i] = geo.W[k] / 16;
+            }
+            for (int s = 0; s < 2 * P; ++s) {
+                const int img = geo.pairs_host[2 * (s % P) + s / P], k = geo.img_class[img];
+                h_cnt_dec[s] = Tk(k);
+                h_row_dec[s] = k * R;
+                h_wg_dec[s] = geo.W[k] / 16;
+            }
+            size_t row = 0;
+            int n_maps = 0;
+            for (int v = 0; v < 2; ++v)
+                for (int k = 0; k < geo.K; ++k) {
+                    Group gr{v, k, 0, n_maps, row};
+                    for (int p = 0; p < P; ++p) {
+                        const int img = geo.pairs_host[2 * p + v];
+                        if (geo.img_class[img] != k) continue;
+                        h_hmap[n_maps] = v * P + p;
+                        h_imap[n_maps] = img;
+                        hmap_host.push_back(v * P + p);
+                        ++n_maps;
+                        ++gr.n;
+                    }
+                    row += (size_t)gr.n * Tk(k);
+                    if (gr.n) groups.push_back(gr);
+                }
+            // pageable host memory: the copy is staged before the call returns; the synchronisation makes that independent of the runtime
+            if (hipMemcpyAsync(w.geo, g.data(), g.size() * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                return imcui_set_err(h, IMCUI_ERR_HIP, "dust3r: upload of the sequence tables failed");
+            cnt_enc = w.geo;
+            cnt_dec = w.geo + ns;
+            row0_enc = w.geo + 2 * ns;
+            row0_dec = w.geo + 3 * ns;
+            wg_enc = w.geo + 4 * ns;
+            wg_dec = w.geo + 5 * ns;
+            hmap_dev = w.geo + 6 * ns;
+            imap_dev = w.geo + 7 * ns;
+            T_enc = cnt_enc;
+            T_dec = cnt_dec;
+            for (int k = 0; k < geo.K; ++k)
+                hipLaunchKernelGGL(du_rope_table_kernel, dim3((unsigned)cdiv(R * 32, 256)), blk, 0, stream, V(du_v_invf(c)), Tk(k), R, geo.W[k] / 16,
+                                   w.rcos + (size_t)k * R * 32, w.rsin + (size_t)k * R * 32);
+        }
     }
 
     // ---- encoder: every image once
+    cur_cnt = cnt_enc;
+    cur_row0 = row0_enc;
+    cur_T = T_enc;
+    cur_wg = wg_enc;
     const long me = (long)NI * R;
     {
-        const long n4 = me * 192;
-        hipLaunchKernelGGL(du_patchify_kernel, blocks(n4), blk, 0, stream, images, w.A0, H, W, T, R, n4);
+        if (!mixed) {
+            const long n4 = me * 192;
+            hipLaunchKernelGGL(du_patchify_kernel, blocks(n4), blk, 0, stream, images, w.A0, H, W, T, R, n4);
+        } else {
+            const long n4 = (long)R * 192;
+            for (int i = 0; i < NI; ++i) {
+                const int k = geo.img_class[i];
+                hipLaunchKernelGGL(du_patchify_kernel, blocks(n4), blk, 0, stream, images + geo.img_off[i], w.A0 + (size_t)i * R * 768, geo.H[k], geo.W[k],
+                                   (geo.H[k] / 16) * (geo.W[k] / 16), R, n4);
+            }
+        }
         IMCUI_CHECK_LAUNCH(h);
         DURUN(lin(0, w.A0, w.x, NI, nullptr, 0));
         dump_copy(w.x, (size_t)me * E);
@@ -584,6 +683,10 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     // ---- decoder
     const long md = (long)2 * P * R, ms = (long)P * R;  // rows of all streams / of one side
     DURUN(lin(du_l_demb(c), w.fenc, w.g, NI, nullptr, 0));
+    cur_cnt = cnt_dec;
+    cur_row0 = row0_dec;
+    cur_T = T_dec;
+    cur_wg = wg_dec;
     {
         const long n4 = md * (D / 4);
         hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, w.g, w.smap, w.y, R, R, D / 4, n4);
@@ -591,10 +694,20 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         dump_copy(w.y, (size_t)md * D);
     }
     const int hooks[3] = {c.dec_depth * 2 / 4, c.dec_depth * 3 / 4, c.dec_depth};
-    auto save_hook = [&](const float* src, int k) {
-        const long n4 = (long)2 * P * T * (D / 4);
-        hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, src, (const int*)nullptr, w.hook[k], R, T, D / 4, n4);
+    // the live tokens of every stream, densely: src [2P][R][C] -> dst; one size: [2P][T][C] in stream order; several: group by group
+    auto gather_dense = [&](const float* src, const int* map_one_size, const int* map_groups, float* dst, int C) {
+        if (!mixed) {
+            const long n4 = (long)2 * P * T * (C / 4);
+            hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, src, map_one_size, dst, R, T, C / 4, n4);
+            return;
+        }
+        for (const Group& gr : groups) {
+            const int tk = (geo.H[gr.k] / 16) * (geo.W[gr.k] / 16);
+            const long n4 = (long)gr.n * tk * (C / 4);
+            hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, src, map_groups + gr.first, dst + gr.row0 * C, R, tk, C / 4, n4);
+        }
     };
+    auto save_hook = [&](const float* src, int k) { gather_dense(src, nullptr, hmap_dev, w.hook[k], D); };
     for (int i = 0; i < c.dec_depth; ++i) {
         // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block, normalised by
         // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o
@@ -639,28 +752,28 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
     layernorm(w.y, du_v_decn(c), w.xn, md, D);
     dump_copy(w.xn, (size_t)md * D);
     save_hook(w.xn, 2);
-    {
-        const long n4 = (long)2 * P * T * (E / 4);
-        hipLaunchKernelGGL(du_gather_seq_kernel, blocks(n4), blk, 0, stream, w.fenc, w.smap, w.tok0, R, T, E / 4, n4);
-    }
+    gather_dense(w.fenc, w.smap, imap_dev, w.tok0, E);
     IMCUI_CHECK_LAUNCH(h);
 
-    // ---- DPT heads (view v: downstream_head{v + 1} on the tokens of the streams [v P, (v + 1) P))
-    const long pt = (long)P * T;
-    for (int v = 0; v < 2; ++v) {
+    // ---- DPT heads: downstream_head{v + 1} on Pn maps of Hh x Wh pixels whose dense tokens start at row `row0` of tok0 / hook[].
+    // One size: Pn = P, the outputs of view v are one block.  Several sizes: one call per group, every map regressed into its own
+    // slot of the (view, pair)-ordered output.
+    auto run_head = [&](int v, int Pn, int Hh, int Wh, size_t row0, const int* streams) -> int {
+        const int hg = Hh / 16, wg = Wh / 16, T = hg * wg;
+        const long pt = (long)Pn * T;
         const int L0 = du_l_head(c, v);
         auto conv3 = [&](int li, const float* in, float* out, int hh, int ww, int act, const float* resid) -> int {
             int N, K, kind;
             du_shape(c, li, &N, &K, &kind);
             return conv3x3_split_launch(h, in, reinterpret_cast<const unsigned short*>(Pk + l.wh[li]), reinterpret_cast<const unsigned short*>(Pk + l.wl[li]),
-                                        Pk + l.ws[li], Pk + l.b[li], out, P, hh, ww, K / 9, N, act, 0, stream, resid, 0, 0, single);
+                                        Pk + l.ws[li], Pk + l.b[li], out, Pn, hh, ww, K / 9, N, act, 0, stream, resid, 0, 0, single);
         };
         auto shuffle = [&](const float* src, float* dst, int s, int C) {
             const long n4 = pt * s * s * (C / 4);
             hipLaunchKernelGGL(du_pixel_shuffle_kernel, blocks(n4), blk, 0, stream, src, dst, hg, wg, s, C / 4, n4);
         };
-        const float* tok0 = w.tok0 + (size_t)v * pt * E;
-        const float* hk[3] = {w.hook[0] + (size_t)v * pt * D, w.hook[1] + (size_t)v * pt * D, w.hook[2] + (size_t)v * pt * D};
+        const float* tok0 = w.tok0 + row0 * E;
+        const float* hk[3] = {w.hook[0] + row0 * D, w.hook[1] + row0 * D, w.hook[2] + row0 * D};
         // reassemble: 1/4, 1/8, 1/16, 1/32 (an odd token grid rounds the 1/32 level up: 3x3 stride 2 with padding 1; the x2 of the first
         // fusion block is then cropped back to the token grid, upstream's `[:, :, :layers[2].shape[2], :layers[2].shape[3]]`)
         const int h3 = (hg + 1) / 2, w3 = (wg + 1) / 2;
@@ -696,7 +809,7 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             g.conv_hout = h3;
             g.conv_wout = w3;
             g.conv_cin = 768;
-            g.M = P * h3 * w3;
+            g.M = Pn * h3 * w3;
             g.C = w.tm;
             g.ldc = N;
             g.single = single;
@@ -704,12 +817,13 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
         }
         DURUN(conv3(L0 + 10, w.tm, w.rn[3], h3, w3, 0, nullptr));
         const int rh[4] = {4 * hg, 2 * hg, hg, h3}, rw[4] = {4 * wg, 2 * wg, wg, w3};
-        for (int k = 0; k < 4; ++k) dump_copy(w.rn[k], (size_t)P * rh[k] * rw[k] * 256);
+        if (!mixed)
+            for (int k = 0; k < 4; ++k) dump_copy(w.rn[k], (size_t)Pn * rh[k] * rw[k] * 256);
         // fusion: refinenet 4, 3, 2, 1
         const float* path = nullptr;
         for (int q = 0; q < 4; ++q) {
             const int lv = 3 - q, hh = rh[lv], ww = rw[lv];
-            const long n4 = (long)P * hh * ww * 64;
+            const long n4 = (long)Pn * hh * ww * 64;
             const int Lq = L0 + 11 + 5 * q;
             const float* xres;
             if (q == 0) {
@@ -726,30 +840,38 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             DURUN(conv3(Lq + 3, w.s0, w.s1, hh, ww, 0, xres));
             hipLaunchKernelGGL(du_upsample2_kernel, blocks(4 * n4), blk, 0, stream, w.s1, w.s3, hh, ww, 64, 4 * n4);
             float* out = (q & 1) ? w.pb : w.pa;
-            DURUN(lin_dense(Lq + 4, w.s3, out, (long)P * 4 * hh * ww));
+            DURUN(lin_dense(Lq + 4, w.s3, out, (long)Pn * 4 * hh * ww));
             path = out;
             int ph = 2 * hh, pw = 2 * ww;
             if (q == 0 && (ph != hg || pw != wg)) {
-                const long c4 = (long)P * hg * wg * 64;
+                const long c4 = (long)Pn * hg * wg * 64;
                 hipLaunchKernelGGL(du_crop_kernel, blocks(c4), blk, 0, stream, out, w.hd0, ph, pw, hg, wg, 64, c4);
                 path = w.hd0;
                 ph = hg;
                 pw = wg;
             }
-            dump_copy(path, (size_t)P * ph * pw * 256);
+            if (!mixed) dump_copy(path, (size_t)Pn * ph * pw * 256);
         }
         // head: 3x3 256 -> 128 at 1/2, x2, 3x3 128 -> 128 + ReLU, 1x1 128 -> 4 + post-processing
-        DURUN(conv3(L0 + 31, path, w.hd0, H / 2, W / 2, 0, nullptr));
+        DURUN(conv3(L0 + 31, path, w.hd0, Hh / 2, Wh / 2, 0, nullptr));
         {
-            const long n4 = (long)P * H * W * 32;
-            hipLaunchKernelGGL(du_upsample2_kernel, blocks(n4), blk, 0, stream, w.hd0, w.hd1, H / 2, W / 2, 32, n4);
+            const long n4 = (long)Pn * Hh * Wh * 32;
+            hipLaunchKernelGGL(du_upsample2_kernel, blocks(n4), blk, 0, stream, w.hd0, w.hd1, Hh / 2, Wh / 2, 32, n4);
         }
-        DURUN(conv3(L0 + 32, w.hd1, w.hd2, H, W, 1, nullptr));
-        const long npix = (long)P * H * W;
-        dump_copy(w.hd2, (size_t)npix * 128);
-        float* raw = dump_take((size_t)npix * 4);
-        hipLaunchKernelGGL(du_regress_kernel, blocks(npix * 32), blk, 0, stream, w.hd2, V(du_v_head(c, v)), V(du_v_head(c, v) + 1),
-                           pts3d + (size_t)v * npix * 3, conf + (size_t)v * npix, raw, npix);
+        DURUN(conv3(L0 + 32, w.hd1, w.hd2, Hh, Wh, 1, nullptr));
+        const long npix = (long)Pn * Hh * Wh, mpix = (long)Hh * Wh;
+        if (!mixed) {
+            dump_copy(w.hd2, (size_t)npix * 128);
+            float* raw = dump_take((size_t)npix * 4);
+            hipLaunchKernelGGL(du_regress_kernel, blocks(npix * 32), blk, 0, stream, w.hd2, V(du_v_head(c, v)), V(du_v_head(c, v) + 1),
+                               pts3d + (size_t)v * npix * 3, conf + (size_t)v * npix, raw, npix);
+        } else {
+            for (int j = 0; j < Pn; ++j) {
+                const size_t o = geo.map_pix[streams[j]];
+                hipLaunchKernelGGL(du_regress_kernel, blocks(mpix * 32), blk, 0, stream, w.hd2 + (size_t)j * mpix * 128, V(du_v_head(c, v)),
+                                   V(du_v_head(c, v) + 1), pts3d + o * 3, conf + o, (float*)nullptr, mpix);
+            }
+        }
         IMCUI_CHECK_LAUNCH(h);
         if (c.desc > 0) {
             // MASt3R (mast3r.py:41-66): local features = MLP([encoder tokens | last decoder tokens]) per token, (desc + 1) x 16 x 16 values
@@ -777,11 +899,143 @@ extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_dep
             g.M = (int)pt;
             DURUN(gemm_launch(h, g, stream));
             DURUN(lin_dense(L0 + 34, w.lfh, w.lfo, pt));
-            hipLaunchKernelGGL(du_desc_kernel, blocks(npix), blk, 0, stream, w.lfo, desc + (size_t)v * npix * c.desc, desc_conf + (size_t)v * npix, H, W,
-                               c.desc, npix);
+            if (!mixed) {
+                hipLaunchKernelGGL(du_desc_kernel, blocks(npix), blk, 0, stream, w.lfo, desc + (size_t)v * npix * c.desc, desc_conf + (size_t)v * npix, Hh,
+                                   Wh, c.desc, npix);
+            } else {
+                for (int j = 0; j < Pn; ++j) {
+                    const size_t o = geo.map_pix[streams[j]];
+                    hipLaunchKernelGGL(du_desc_kernel, blocks(mpix), blk, 0, stream, w.lfo + (size_t)j * T * (c.desc + 1) * 256, desc + o * c.desc,
+                                       desc_conf + o, Hh, Wh, c.desc, mpix);
+                }
+            }
             IMCUI_CHECK_LAUNCH(h);
         }
+        return IMCUI_OK;
+    };
+    if (!mixed) {
+        for (int v = 0; v < 2; ++v) DURUN(run_head(v, P, H, W, (size_t)v * P * T, nullptr));
+    } else {
+        for (const Group& gr : groups) DURUN(run_head(gr.v, gr.n, geo.H[gr.k], geo.W[gr.k], gr.row0, hmap_host.data() + gr.first));
     }
     if (!dump_ok) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: dump buffer too small (%zu floats)", dump_floats);
     return IMCUI_OK;
+#undef DURUN
+}
+
+// ------------------------------------------------------------------ forward
+// images [NI,3,H,W] in [0,1]; pairs (device) [P][2]: directed pair p = (view 1 image, view 2 image), indices clamped to [0, NI).
+// arith: 0 = the 3 x f16 split products of the library's default mode (fp32-grade results), 1 = ONE f16 product per element pair in the
+// GEMMs and convolutions (f32 accumulate; 11-bit operands: the class of the bf16 run BASELINE's configs[4] names).  Outputs, view-major:
+// pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W];
+// MASt3R (desc_dim > 0): desc [2][P][H][W][desc_dim] (unit norm), desc_conf [2][P][H][W].
+static int du_check_common(imcui_hip_t* h, const DuCfg& c, int arith, const void* packed, const void* images, const void* pairs, const void* pts3d,
+                           const void* conf, const void* desc, const void* desc_conf) {
+    if (!du_cfg_ok(c)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: unsupported configuration (dims multiples of 64 up to 1024, dec_depth a multiple of 4)");
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
+    if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: arith = %d (0: 3 x f16 split products, 1: one f16 product)", arith);
+    if (!packed || !images || !pairs || !pts3d || !conf || (c.desc > 0 && (!desc || !desc_conf))) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
+    return IMCUI_OK;
+}
+
+extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
+                                        const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d,
+                                        float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes,
+                                        void* stream_) {
+    if (!h) return IMCUI_ERR_ARG;
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    const int rc = du_check_common(h, c, arith, packed, images, pairs, pts3d, conf, desc, desc_conf);
+    if (rc != IMCUI_OK) return rc;
+    if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 16", NI, W, H, P);
+    DuGeom geo;
+    geo.K = 1;
+    geo.H[0] = H;
+    geo.W[0] = W;
+    geo.Tmax = (size_t)(H / 16) * (W / 16);
+    return du_forward_impl(h, c, packed, images, NI, geo, pairs, P, arith, pts3d, conf, desc, desc_conf, dump, dump_floats, ws, ws_bytes,
+                           (hipStream_t)stream_);
+}
+
+// ---- images of several sizes (include/imcui_hip.h) ------------------------------------------------------------------
+static bool du_sizes_ok(int NI, const int* sizes, int P) {
+    if (NI <= 0 || P <= 0 || !sizes) return false;
+    for (int i = 0; i < NI; ++i)
+        if (!du_size_ok(sizes[2 * i], sizes[2 * i + 1])) return false;
+    return true;
+}
+static size_t du_max_tokens(int NI, const int* sizes) {
+    size_t t = 0;
+    for (int i = 0; i < NI; ++i) {
+        const size_t ti = (size_t)(sizes[2 * i] / 16) * (sizes[2 * i + 1] / 16);
+        t = ti > t ? ti : t;
+    }
+    return t;
+}
+
+extern "C" size_t imcui_hip_dust3r_workspace_bytes_sizes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI,
+                                                         const int* sizes, int P) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    if (!du_cfg_ok(c) || !du_sizes_ok(NI, sizes, P)) return 0;
+    return du_carve(nullptr, 0, c, NI, P, du_max_tokens(NI, sizes)).total;
+}
+
+extern "C" size_t imcui_hip_dust3r_token_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, const int* sizes,
+                                                     int P) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    if (!du_cfg_ok(c) || !du_sizes_ok(NI, sizes, P)) return 0;
+    const size_t R = du_R_tokens(du_max_tokens(NI, sizes));
+    return (size_t)(c.enc_depth + 2) * NI * R * c.E + (size_t)(c.dec_depth + 2) * 2 * P * R * c.D;
+}
+
+extern "C" int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
+                                              const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
+                                              float* pts3d, float* conf, float* desc, float* desc_conf, size_t* map_pixel_offsets, float* dump,
+                                              size_t dump_floats, void* ws, size_t ws_bytes, void* stream_) {
+    if (!h) return IMCUI_ERR_ARG;
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    const int rc = du_check_common(h, c, arith, packed, images, pairs, pts3d, conf, desc, desc_conf);
+    if (rc != IMCUI_OK) return rc;
+    if (!pairs_host) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
+    if (!du_sizes_ok(NI, sizes, P)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images, %d pairs: every size must be a multiple of 16 (32 .. 4096)", NI, P);
+    for (int i = 0; i < 2 * P; ++i)
+        if (pairs_host[i] < 0 || pairs_host[i] >= NI) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: pair table refers to image %d of %d", pairs_host[i], NI);
+    DuGeom geo;
+    geo.K = 0;
+    std::vector<int> cls(NI);
+    std::vector<size_t> off(NI), pix(2 * (size_t)P);
+    size_t o = 0;
+    for (int i = 0; i < NI; ++i) {
+        const int Hi = sizes[2 * i], Wi = sizes[2 * i + 1];
+        int k = 0;
+        while (k < geo.K && (geo.H[k] != Hi || geo.W[k] != Wi)) ++k;
+        if (k == geo.K) {
+            if (geo.K == DU_MAX_CLASSES)
+                return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: more than %d distinct image sizes in one call", DU_MAX_CLASSES);
+            geo.H[k] = Hi;
+            geo.W[k] = Wi;
+            ++geo.K;
+        }
+        cls[i] = k;
+        off[i] = o;
+        o += (size_t)3 * Hi * Wi;
+    }
+    o = 0;
+    for (int v = 0; v < 2; ++v)
+        for (int p = 0; p < P; ++p) {
+            const int img = pairs_host[2 * p + v];
+            pix[(size_t)v * P + p] = o;
+            o += (size_t)sizes[2 * img] * sizes[2 * img + 1];
+        }
+    if (map_pixel_offsets) {
+        for (size_t i = 0; i < pix.size(); ++i) map_pixel_offsets[i] = pix[i];
+        map_pixel_offsets[pix.size()] = o;
+    }
+    geo.Tmax = du_max_tokens(NI, sizes);
+    geo.img_class = cls.data();
+    geo.pairs_host = pairs_host;
+    geo.img_off = off.data();
+    geo.map_pix = pix.data();
+    // a call whose images all have one size takes the one-size path (same layouts: the offsets above are then the dense ones)
+    return du_forward_impl(h, c, packed, images, NI, geo, pairs, P, arith, pts3d, conf, desc, desc_conf, dump, dump_floats, ws, ws_bytes,
+                           (hipStream_t)stream_);
 }

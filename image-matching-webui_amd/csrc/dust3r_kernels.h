@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void du_layernorm_kernel(const float* __restri
 __global__ __launch_bounds__(256) void du_rope_split_kernel(const float* __restrict__ src, long ld, int col0, int heads, int T, int R, int wg,
                                                             const float* __restrict__ inv_freq, float alpha, int rope,
                                                             unsigned short* __restrict__ planes, size_t plane_halves, int seq_out0,
-                                                            long nthreads) {
+                                                            long nthreads, const int* __restrict__ seq_T, const int* __restrict__ seq_wg) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nthreads; i += (long)gridDim.x * 256) {
         const int sub = (int)(i & 3);  // (hf, c)
         const int hf = sub >> 1, c = sub & 1;
@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256) void du_rope_split_kernel(const float* __restr
         r /= heads;
         const int t = (int)(r % R);
         const int seq = (int)(r / R);
+        if (seq_T) {  // sequences on token grids of different shapes
+            T = seq_T[seq];
+            wg = seq_wg[seq];
+        }
         uint4 ha = make_uint4(0u, 0u, 0u, 0u), la = ha, hb = ha, lb = ha;
         if (t < T) {
             const float* s = src + ((long)seq * R + t) * ld + col0 + head * 64 + hf * 32 + c * 8;
@@ -145,13 +149,15 @@ __global__ __launch_bounds__(256) void du_rope_table_kernel(const float* __restr
 // ------------------------------------------------------------------ v: f16 hi / lo planes of V^T [seq][head][64][R]
 // one workgroup = 64 tokens x one head: f32 tile through LDS, each thread writes 16 consecutive tokens of one feature
 __global__ __launch_bounds__(256) void du_vt_split_kernel(const float* __restrict__ src, long ld, int col0, int heads, int T, int R,
-                                                          unsigned short* __restrict__ planes, size_t plane_halves, int seq_out0) {
+                                                          unsigned short* __restrict__ planes, size_t plane_halves, int seq_out0,
+                                                          const int* __restrict__ seq_T) {
     __shared__ float tile[64][65];
     const int tiles = R >> 6;
     int b = blockIdx.x;
     const int tt = b % tiles;
     b /= tiles;
     const int head = b % heads, seq = b / heads;
+    if (seq_T) T = seq_T[seq];
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {

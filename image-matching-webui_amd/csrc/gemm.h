@@ -89,6 +89,9 @@ struct GemmP {
     const float* rope_sin = nullptr;
     int heads = 4;
     int role0 = 0;  // EPI_QKV_VIT: role (0 q, 1 k, 2 v) of the first heads x 64 block of output features
+    // EPI_QKV_VIT with sequences on token grids of different shapes: first table row of each sequence's grid (device, per sequence);
+    // nullptr: every sequence reads the table from row 0
+    const int* rope_seq_row0 = nullptr;
 };
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         const int R = p.rows_per_seq;
         const int i0 = c.row0 - c.seq * R;
         if (EPI == EPI_QKV_VIT && !vt) {
+            const int tab0 = i0 + (p.rope_seq_row0 ? p.rope_seq_row0[c.seq] : 0);  // this tile's first row of the RoPE2D tables
             // RoPE2D: a lane finishes 8 consecutive features of one token; their rotation partners sit 16 features away in the same
             // 32-feature half (read from the parked row as well).  `first` lanes hold the a of (a, b) -> (a cos - b sin, b cos + a sin).
             const int d0 = (lane & 7) * 8, dp = d0 ^ 16;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 float4 tc[4][2], ts[4][2];
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {  // tables of this step's tokens, requested before the tile is parked
-                    const size_t ir = (size_t)(i0 + 32 * m + pass * 8 + (lane >> 3)) * 32 + ti;
+                    const size_t ir = (size_t)(tab0 + 32 * m + pass * 8 + (lane >> 3)) * 32 + ti;
                     tc[pass][0] = *reinterpret_cast<const float4*>(p.rope_cos + ir);
                     tc[pass][1] = *reinterpret_cast<const float4*>(p.rope_cos + ir + 4);
                     ts[pass][0] = *reinterpret_cast<const float4*>(p.rope_sin + ir);

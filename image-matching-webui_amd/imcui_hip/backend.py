@@ -793,6 +793,69 @@ class DUSt3RHIP:
             out.update(desc=desc, desc_conf=dconf)
         return out
 
+    def forward_sizes(self, packed, cfg, images, pairs, dump=False, arith=0):
+        """The same network on images of several sizes (imcui_hip_dust3r_forward_sizes): `images` = list of [3,H_i,W_i] (or
+        [1,3,H_i,W_i]) tensors in [0,1], every size a multiple of 16, at most 4 distinct sizes; pairs [P,2] ->
+        {"pts3d": [view][pair] -> [H,W,3], "conf": [view][pair] -> [H,W]} (+ "desc" / "desc_conf" for a MASt3R network) as nested
+        lists of views into ONE ragged device buffer per output: the map of (view v, pair p) has the size of image pairs[p][v]."""
+        import ctypes as C
+
+        imgs = [im.reshape(im.shape[-3:]).contiguous().float() for im in images]
+        dev = imgs[0].device
+        hd = get_handle(dev)
+        lib = hd.lib
+        if lib.imcui_hip_get_precision(hd.h) != 1:
+            raise ImcuiHipError("DUSt3R / MASt3R run in the library's default arithmetic (imcui_hip_set_precision(h, 1))")
+        NI = len(imgs)
+        if any(im.shape[0] != 3 for im in imgs):
+            raise ImcuiHipError("DUSt3R expects 3-channel images")
+        sizes = [(int(im.shape[1]), int(im.shape[2])) for im in imgs]
+        ptab = torch.as_tensor(pairs, dtype=torch.int32).reshape(-1, 2).cpu().contiguous()
+        if int(ptab.min()) < 0 or int(ptab.max()) >= NI:
+            raise ImcuiHipError(f"DUSt3R pair table refers to images outside [0, {NI})")
+        P = ptab.shape[0]
+        flat = torch.cat([im.reshape(-1) for im in imgs])
+        pairs_dev = ptab.to(dev)
+        c4 = _dust3r_c5(cfg)
+        dd = c4[4]
+        sz = (C.c_int * (2 * NI))(*[v for hw in sizes for v in hw])
+        ph = (C.c_int * (2 * P))(*[int(v) for v in ptab.reshape(-1)])
+        offs = (C.c_size_t * (2 * P + 1))()
+        total = sum(sizes[int(ptab[p, v])][0] * sizes[int(ptab[p, v])][1] for v in range(2) for p in range(P))
+        pts = torch.empty((total, 3), dtype=torch.float32, device=dev)
+        conf = torch.empty((total,), dtype=torch.float32, device=dev)
+        desc = torch.empty((total, dd), dtype=torch.float32, device=dev) if dd else None
+        dconf = torch.empty((total,), dtype=torch.float32, device=dev) if dd else None
+        nd = lib.imcui_hip_dust3r_token_dump_floats(*c4, NI, sz, P) if dump else 0
+        dbuf = torch.zeros((nd,), dtype=torch.float32, device=dev) if dump else None
+        with self._lock:
+            nbytes = lib.imcui_hip_dust3r_workspace_bytes_sizes(*c4, NI, sz, P)
+            if nbytes == 0:
+                raise ImcuiHipError(f"DUSt3R: unsupported sizes {sizes} (multiples of 16, 32 .. 4096)")
+            ws = self._ws.get(nbytes, dev)
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_dust3r_forward_sizes(hd.h, *c4, _ptr(packed), _ptr(flat), NI, sz, ph, _ptr(pairs_dev), P, int(arith), _ptr(pts), _ptr(conf),
+                                                        _ptr(desc), _ptr(dconf), offs, _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
+                hd.check(rc, "imcui_hip_dust3r_forward_sizes")
+        assert offs[2 * P] == total
+        self.last_dump = dbuf
+
+        def maps(buf, tail):
+            out = []
+            for v in range(2):
+                row = []
+                for p in range(P):
+                    Hh, Ww = sizes[int(ptab[p, v])]
+                    o = offs[v * P + p]
+                    row.append(buf[o : o + Hh * Ww].reshape((Hh, Ww) + tail))
+                out.append(row)
+            return out
+
+        out = {"pts3d": maps(pts, (3,)), "conf": maps(conf, ())}
+        if dd:
+            out.update(desc=maps(desc, (dd,)), desc_conf=maps(dconf, ()))
+        return out
+
 
 def conv_gemm_f32(x_nhwc, w_oihw, bias, resid=None, stride=1, act=0):
     """Building block: NHWC conv through the implicit-im2col GEMM (k in {1,3}, Cin % 32 == 0)."""

@@ -18,11 +18,13 @@ neighbours (`find_reciprocal_matches`: two KD-trees, image-1 points whose neares
 `np.linspace` sub-sampling to `max_keypoints` (`matches_from_scene`; tested on CPU against the brute-force restatement
 `oracle/dust3r.py: duster_matches_from_scene` with the aligner mocked).
 
-Image sizes: the two images of a pair must have ONE size (multiples of 16).  The reference's `Duster.preprocess` is never
-called by its callers; `match_dense.match_images` / `ImagePairDataset.preprocess` resize each image on its own (resize_max 512,
-dfactor 16), so two photos of different aspect ratio reach upstream's net at different sizes, which `dust3r.inference`
-handles by encoding the views separately.  The HIP entry point has one token grid per call: pairs of unequal size are refused
-with a message that says so (restriction listed in INTEGRATION.md).
+Image sizes: multiples of 16, and the two images of a pair may differ.  The reference's `Duster.preprocess` is never called by
+its callers; `match_dense.match_images` / `ImagePairDataset.preprocess` resize each image on its own (resize_max 512, dfactor 16),
+so two photos of different aspect ratio reach upstream's net at two sizes, which `dust3r.inference` handles by encoding the
+views separately and collating the per-pair results as lists.  Same here: one size -> imcui_hip_dust3r_forward and stacked
+tensors; two sizes -> imcui_hip_dust3r_forward_sizes (every sequence carries its own token grid; the heads run per size) and
+lists of per-pair maps, the structure upstream's `inference` returns in that case (restated from the published code of the
+un-vendored `third_party/dust3r`; `pred1["pts3d"][1]`-style indexing reads the same entry either way).
 
 Weights: conf["state_dict"] / conf["weights_path"] (or conf["packed"], the result of an earlier `backend.pack_dust3r`: packing
 the 578 M parameters takes ~20 s) with upstream's parameter names (`duster_vit_large.pth` holds them under
@@ -69,6 +71,12 @@ class Duster(BaseModel):
         arith = {"fp32": 0, "fp16": 1}[self.conf.get("arithmetic", "fp32")]  # read per call: conf is mutable at run time
         return self._impl.forward(self.packed, self.net_cfg, images, pairs, dump, arith)
 
+    def forward_pairs_sizes(self, images, pairs, dump: bool = False) -> dict:
+        """The same on a LIST of images [3,H_i,W_i] of up to four different sizes: nested lists [view][pair] of maps [H,W,3] / [H,W],
+        the map of (view v, pair p) at the size of image pairs[p][v]."""
+        arith = {"fp32": 0, "fp16": 1}[self.conf.get("arithmetic", "fp32")]
+        return self._impl.forward_sizes(self.packed, self.net_cfg, images, pairs, dump, arith)
+
     def inference_output(self, data: dict) -> dict:
         """What `inference(pairs, self.net, device, batch_size=1)` returns for the symmetrised pair (duster.py:66-73)."""
         return self._symmetrised(data)[1]
@@ -79,19 +87,27 @@ class Duster(BaseModel):
         img0, img1 = data["image0"], data["image1"]
         if img0.shape[0] != 1 or img1.shape[0] != 1:
             raise ValueError("DUSt3R matches one image pair per call (batch 1, as the reference wrapper)")
-        if img0.shape != img1.shape:
-            raise ValueError(f"the HIP DUSt3R path needs both images at ONE size (got {tuple(img0.shape[-2:])} and {tuple(img1.shape[-2:])}): "
-                             "upstream encodes views of different sizes separately, imcui_hip_dust3r_forward has one token grid per call -- "
-                             "resize the pair to a common size (multiples of 16) before the matcher")
-        H, W = img0.shape[-2:]
-        if H % 16 or W % 16:
-            raise ValueError(f"DUSt3R needs image sizes that are multiples of the patch size 16 (the wrapper's preprocess rounds to it), got {W}x{H}")
-        out = self.forward_pairs(torch.cat((img0, img1), 0), [[1, 0], [0, 1]])  # make_pairs' order: (image1, image0), (image0, image1)
+        for im in (img0, img1):
+            if im.shape[-2] % 16 or im.shape[-1] % 16:
+                raise ValueError(f"DUSt3R needs image sizes that are multiples of the patch size 16 (the wrapper's preprocess rounds to it), got {im.shape[-1]}x{im.shape[-2]}")
         norm = [(img0 - 0.5) / 0.5, (img1 - 0.5) / 0.5]
-        shape = torch.tensor([[H, W], [H, W]])
+        order = [[1, 0], [0, 1]]  # make_pairs' order: (image1, image0), (image0, image1)
+        if img0.shape == img1.shape:
+            H, W = img0.shape[-2:]
+            out = self.forward_pairs(torch.cat((img0, img1), 0), order)
+            shape = torch.tensor([[H, W], [H, W]])
 
-        def view(a, b):  # collated views of the two directed pairs
-            return {"img": torch.cat((norm[a], norm[b]), 0), "true_shape": shape, "idx": [a, b], "instance": [str(a), str(b)]}
+            def view(a, b):  # collated views of the two directed pairs
+                return {"img": torch.cat((norm[a], norm[b]), 0), "true_shape": shape, "idx": [a, b], "instance": [str(a), str(b)]}
+
+        else:
+            # two sizes (each image was resized on its own): upstream's `inference` runs such pairs one per batch and collates
+            # with `lists=True` -- every value is the LIST of the per-pair entries, the batch axis dropped
+            out = self.forward_pairs_sizes([img0, img1], order)
+
+            def view(a, b):
+                return {"img": [norm[a][0], norm[b][0]], "true_shape": [torch.tensor(norm[a].shape[-2:]), torch.tensor(norm[b].shape[-2:])],
+                        "idx": [a, b], "instance": [str(a), str(b)]}  # fmt: skip
 
         return out, {
             "view1": view(1, 0),

@@ -131,6 +131,13 @@ SIGNATURES = {
         [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "imcui_hip_dust3r_workspace_bytes_sizes": (C.c_size_t, [C.c_int] * 6 + [C.POINTER(C.c_int), C.c_int]),
+    "imcui_hip_dust3r_token_dump_floats": (C.c_size_t, [C.c_int] * 6 + [C.POINTER(C.c_int), C.c_int]),
+    "imcui_hip_dust3r_forward_sizes": (
+        C.c_int,
+        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "imcui_hip_conv_gemm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]),
     "imcui_hip_nn_argmax_workspace_bytes": (C.c_size_t, [C.c_int] * 2),
     "imcui_hip_nn_argmax_split_workspace_bytes": (C.c_size_t, [C.c_int] * 2),

@@ -299,6 +299,24 @@ int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec
                              const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d, float* conf,
                              float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
 
+/* The same network on images of SEVERAL sizes.  imcui/hloc/match_dense.py:match_images and ImagePairDataset.preprocess resize
+ * each image of a pair on its own (resize_max 512, dfactor 16), so two photos of different aspect ratio reach duster.py:73 at two
+ * sizes; upstream's `inference` then encodes the two views separately and runs one pair per batch (dust3r/inference.py).
+ * sizes [host, NI,2] = (H, W) of every image, multiples of 16, at most 4 distinct sizes per call; images [dev]: the NI images
+ * [3,H_i,W_i] one behind the other; pairs_host [host, P,2] and pairs [dev, P,2]: the same table twice (the host copy lays out the
+ * sequences, the device copy drives the gathers).  Outputs are ragged, map after map in (view, pair) order: the map of
+ * (view v, pair p) has the size of image pairs[p][v] and starts at pixel map_pixel_offsets[v P + p] -- pts3d at 3 x that offset,
+ * conf at it, desc at desc_dim x it; map_pixel_offsets [host, 2 P + 1] (may be NULL) is filled by the call, the last entry is the
+ * total number of pixels the output buffers must hold.  With one size this is exactly imcui_hip_dust3r_forward's layout.
+ * dump (may be NULL): imcui_hip_dust3r_token_dump_floats() floats -- the token states only ((enc_depth + 2) x [NI,R,E], (dec_depth + 2) x
+ * [2P,R,D], R = tokens of the largest image rounded up to 128; rows past a sequence's own token count are undefined). */
+size_t imcui_hip_dust3r_workspace_bytes_sizes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, const int* sizes, int P);
+size_t imcui_hip_dust3r_token_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, const int* sizes, int P);
+int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
+                                   const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
+                                   float* pts3d, float* conf, float* desc, float* desc_conf, size_t* map_pixel_offsets, float* dump,
+                                   size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /

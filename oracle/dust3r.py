@@ -216,18 +216,26 @@ class DUSt3ROracle:
 
     # -- the network and the wrapper's driver ------------------------------------------------------------------------
     def forward(self, img1, img2, return_intermediates=False):
-        """`AsymmetricCroCo3DStereo.forward` on normalised images [B, 3, H, W] of one size -> (res1, res2)."""
-        B, _, H, W = img1.shape
-        both, pos, enc_layers = self.encode(torch.cat((img1, img2), 0), return_layers=True)
-        f1, f2 = both[:B], both[B:]
-        pos1, pos2 = pos[:B], pos[B:]
+        """`AsymmetricCroCo3DStereo.forward` on normalised images [B, 3, H1, W1], [B, 3, H2, W2] -> (res1, res2).  Views of one size
+        are encoded as one batch, views of different sizes one after the other (upstream's `_encode_image_pairs`; per-sample the
+        same arithmetic); the decoder cross-attends token sequences of different lengths as they are, each head works at its
+        own view's size."""
+        B, _, H1, W1 = img1.shape
+        H2, W2 = img2.shape[-2:]
+        if (H1, W1) == (H2, W2):
+            both, pos, enc_layers = self.encode(torch.cat((img1, img2), 0), return_layers=True)
+            f1, f2 = both[:B], both[B:]
+            pos1, pos2 = pos[:B], pos[B:]
+            enc1, enc2 = [t[:B] for t in enc_layers], [t[B:] for t in enc_layers]
+        else:
+            f1, pos1, enc1 = self.encode(img1, return_layers=True)
+            f2, pos2, enc2 = self.encode(img2, return_layers=True)
         dec1, dec2 = self.decode(f1, pos1, f2, pos2)
-        res1 = self.head(dec1, 1, H, W, return_intermediates)
-        res2 = self.head(dec2, 2, H, W, return_intermediates)
+        res1 = self.head(dec1, 1, H1, W1, return_intermediates)
+        res2 = self.head(dec2, 2, H2, W2, return_intermediates)
         res2["pts3d_in_other_view"] = res2.pop("pts3d")
         if return_intermediates:
-            res1["_enc_layers"] = [t[:B] for t in enc_layers]
-            res2["_enc_layers"] = [t[B:] for t in enc_layers]
+            res1["_enc_layers"], res2["_enc_layers"] = enc1, enc2
             res1["_dec"], res2["_dec"] = dec1, dec2
         return res1, res2
 
@@ -236,15 +244,19 @@ class DUSt3ROracle:
         -> {'pred1': {pts3d, conf}, 'pred2': {pts3d_in_other_view, conf}} with the batch entries in upstream's order: `make_pairs(images,
         scene_graph="complete", symmetrize=True)` lists (image1, image0) first (`for i in range(n): for j in range(i)`), then the
         swapped pairs, so entry 0 = (image1 as view 1, image0 as view 2) and entry 1 = (image0, image1) -- the entry mast3r.py:61-64 reads
-        its descriptors from (`pred1["desc"][1]` = image0's, `pred2["desc"][1]` = image1's)."""
+        its descriptors from (`pred1["desc"][1]` = image0's, `pred2["desc"][1]` = image1's).  Images of one size: the entries are
+        concatenated ([2, H, W, ...] tensors); of two sizes: upstream's `inference` collates with `lists=True`, every value is a
+        LIST of the two per-entry maps ([H, W, ...], the batch axis dropped) -- indexing `[1]` reads the same entry either way."""
         n0, n1 = (image0 - 0.5) / 0.5, (image1 - 0.5) / 0.5
         out = []
         for a, b in ((n1, n0), (n0, n1)):  # batch_size = 1: one forward per directed pair, in make_pairs' order
             out.append(self.forward(a, b, return_intermediates))
+        same = image0.shape[-2:] == image1.shape[-2:]
+        collate = (lambda maps: torch.cat(maps, 0)) if same else (lambda maps: [m[0] for m in maps])
         keys1 = ("pts3d", "conf")
         keys2 = ("pts3d_in_other_view", "conf")
-        pred1 = {k: torch.cat([o[0][k] for o in out], 0) for k in keys1}
-        pred2 = {k: torch.cat([o[1][k] for o in out], 0) for k in keys2}
+        pred1 = {k: collate([o[0][k] for o in out]) for k in keys1}
+        pred2 = {k: collate([o[1][k] for o in out]) for k in keys2}
         res = {"pred1": pred1, "pred2": pred2}
         if return_intermediates:
             res["_passes"] = out
@@ -280,9 +292,11 @@ class MASt3ROracle(DUSt3ROracle):
     def inference_symmetrized(self, image0, image1, return_intermediates=False):
         res = super().inference_symmetrized(image0, image1, return_intermediates=True)
         out = res["_passes"]
+        same = image0.shape[-2:] == image1.shape[-2:]
+        collate = (lambda maps: torch.cat(maps, 0)) if same else (lambda maps: [m[0] for m in maps])
         for k, pred in ((0, "pred1"), (1, "pred2")):
-            res[pred]["desc"] = torch.cat([o[k]["desc"] for o in out], 0)
-            res[pred]["desc_conf"] = torch.cat([o[k]["desc_conf"] for o in out], 0)
+            res[pred]["desc"] = collate([o[k]["desc"] for o in out])
+            res[pred]["desc_conf"] = collate([o[k]["desc_conf"] for o in out])
         if not return_intermediates:
             res.pop("_passes")
         return res

@@ -183,7 +183,10 @@ def test_dust3r_fp16_arithmetic_is_at_least_as_accurate_as_a_bf16_autocast_run()
     with torch.autocast("cpu", dtype=torch.bfloat16):
         b1, b2 = ora.forward(n0, n1)
     model.conf["arithmetic"] = "fp16"
-    out = model.forward_pairs(torch.cat((i0, i1)).cuda(), [[0, 1]])
+    try:
+        out = model.forward_pairs(torch.cat((i0, i1)).cuda(), [[0, 1]])
+    finally:
+        model.conf["arithmetic"] = "fp32"  # the model object is shared by the tests of this file
     for v, (ref, bf, key) in enumerate(((r1, b1, "pts3d"), (r2, b2, "pts3d_in_other_view"))):
         scale = ref[key].abs().max().item()
         e_hip = (out["pts3d"][v, 0].cpu() - ref[key][0]).abs().max().item() / scale
@@ -294,3 +297,169 @@ def test_dust3r_full_model_512():
     from imcui_hip.synth_weights import DUST3R_CFG
 
     _compare(dict(DUST3R_CFG), 512, 512, seed=5, tol=5e-4, token_tol=5e-5)
+
+
+# ---- images of two sizes (the reference's drivers resize each image on its own; upstream encodes such views separately) ------------
+def _check_map(name, got, want, tol, bad, report, scale=None):
+    err = (got - want).abs().max().item()
+    mag = scale if scale is not None else want.abs().max().item()
+    report.append(f"{name}: err {err:.3e} / magnitude {mag:.3e}")
+    if not (err < tol * max(mag, 1e-6)) or not torch.isfinite(got).all():
+        bad.append(report[-1])
+
+
+@pytest.mark.parametrize("sizes", [((160, 224), (128, 96)), ((112, 144), (256, 256)), ((64, 64), (384, 512))],
+                         ids=["224x160+96x128", "144x112+256x256", "64x64+512x384"])  # fmt: skip
+def test_dust3r_two_sizes_vs_oracle(sizes):
+    """The symmetrised pair on images of DIFFERENT sizes: every token state of both images / all four streams (rows below each
+    sequence's own token count) and the four output maps against the oracle, which encodes the views one after the other as
+    upstream does.  The third case has sequences of 16 and 768 tokens in one launch: the short ones skip five of their six
+    128-row tiles."""
+    torch.set_num_threads(16)
+    cfg = SMALL
+    sd, model = _model(cfg)
+    (h0, w0), (h1, w1) = sizes
+    i0, _ = _images(h0, w0, 31)
+    _, i1 = _images(h1, w1, 32)
+    pairs = [[1, 0], [0, 1]]
+    out = model.forward_pairs_sizes([i0.cuda(), i1.cuda()], pairs, dump=True)
+    torch.cuda.synchronize()
+    dump = model._impl.last_dump.cpu()
+    ref = DUSt3ROracle(sd, cfg).inference_symmetrized(i0, i1, return_intermediates=True)
+    passes = ref["_passes"]  # pass 0 = (image1 as view 1, image0 as view 2), pass 1 = (image0, image1)
+    E, D, ne, nd = cfg["enc_dim"], cfg["dec_dim"], cfg["enc_depth"], cfg["dec_depth"]
+    Tn = [(h0 // 16) * (w0 // 16), (h1 // 16) * (w1 // 16)]
+    R = (max(Tn) + 127) // 128 * 128
+    bad, report = [], []
+    off = 0
+
+    def take(shape):
+        nonlocal off
+        n = 1
+        for s in shape:
+            n *= s
+        t = dump[off : off + n].view(*shape)
+        off += n
+        return t
+
+    enc_ref = [passes[0][1]["_enc_layers"], passes[0][0]["_enc_layers"]]  # image 0 = view 2 of pass 0, image 1 = view 1 of pass 0
+    for i in range(ne + 1):
+        got = take((2, R, E))
+        for img in (0, 1):
+            _check_map(f"encoder state {i} image {img}", got[img, : Tn[img]], enc_ref[img][i][0], 2e-4, bad, report)
+    got = take((2, R, E))
+    for img, want in ((0, passes[0][1]["_dec"][0]), (1, passes[0][0]["_dec"][0])):
+        _check_map(f"encoder output image {img}", got[img, : Tn[img]], want[0], 2e-4, bad, report)
+    # streams: [view 1 of pass 0 (image 1), view 1 of pass 1 (image 0) | view 2 of pass 0 (image 0), view 2 of pass 1 (image 1)]
+    streams = [(0, 0, 1), (1, 0, 0), (0, 1, 0), (1, 1, 1)]  # (pass, view, image)
+    take((4, R, D))
+    for i in range(1, nd + 1):
+        got = take((4, R, D))
+        for s, (p, v, img) in enumerate(streams):
+            if i < nd:
+                _check_map(f"decoder state {i} stream {s}", got[s, : Tn[img]], passes[p][v]["_dec"][i][0], 2e-4, bad, report)
+    got = take((4, R, D))
+    for s, (p, v, img) in enumerate(streams):
+        _check_map(f"decoder output stream {s}", got[s, : Tn[img]], passes[p][v]["_dec"][nd][0], 2e-4, bad, report)
+    assert off == dump.numel(), (off, dump.numel())
+    scale = torch.cat([m.reshape(-1, 3) for m in ref["pred1"]["pts3d"]]).norm(dim=-1).mean().item()
+    for v, (pk, pred) in enumerate((("pts3d", ref["pred1"]), ("pts3d_in_other_view", ref["pred2"]))):
+        for p in range(2):
+            want = pred[pk][p]
+            assert out["pts3d"][v][p].shape == want.shape, (v, p, out["pts3d"][v][p].shape, want.shape)
+            _check_map(f"view {v + 1} pair {p} pts3d", out["pts3d"][v][p].cpu(), want, 1e-4, bad, report, max(scale, want.abs().max().item()))
+            rel = ((out["conf"][v][p].cpu() - pred["conf"][p]).abs() / pred["conf"][p]).max().item()
+            report.append(f"view {v + 1} pair {p} conf: relative err {rel:.3e}")
+            if not rel < 1e-4:
+                bad.append(report[-1])
+    print("\n".join(report))
+    assert not bad, "\n" + "\n".join(bad)
+
+
+@pytest.mark.parametrize("pairs", [[[0, 1]], [[0, 1], [1, 2], [2, 0]], [[0, 1], [1, 0], [0, 2], [2, 1]], [[2, 2], [0, 3], [3, 1], [1, 1]]])
+@pytest.mark.parametrize("arithmetic", ["fp32", "fp16"])
+def test_dust3r_pair_lists_of_several_sizes(pairs, arithmetic):
+    """Any list of directed pairs over images of three sizes (two of them share one): 1 and 3 pairs take one GEMM launch per
+    decoder side, 4 the merged launches; "fp16" additionally takes the projections through du_rope_split / du_vt_split with
+    per-sequence grids.  Every pair equals the oracle's forward on that pair."""
+    torch.set_num_threads(16)
+    sd, model = _model(SMALL)
+    shapes = [(128, 160), (96, 224), (128, 160), (176, 112)]
+    imgs = [_images(h, w, 40 + k)[k % 2] for k, (h, w) in enumerate(shapes)]
+    model.conf["arithmetic"] = arithmetic
+    try:
+        out = model.forward_pairs_sizes([im.cuda() for im in imgs], pairs)
+    finally:
+        model.conf["arithmetic"] = "fp32"
+    tol = 1e-4 if arithmetic == "fp32" else 5e-3
+    ora = DUSt3ROracle(sd, SMALL)
+    for p, (a, b) in enumerate(pairs):
+        r1, r2 = ora.forward((imgs[a] - 0.5) / 0.5, (imgs[b] - 0.5) / 0.5)
+        for v, (want, wconf) in enumerate(((r1["pts3d"], r1["conf"]), (r2["pts3d_in_other_view"], r2["conf"]))):
+            got = out["pts3d"][v][p].cpu()
+            assert got.shape == want[0].shape
+            err = (got - want[0]).abs().max().item()
+            assert err < tol * want.abs().max().item(), (p, v, err)
+            assert ((out["conf"][v][p].cpu() - wconf[0]).abs() / wconf[0]).max().item() < tol
+
+
+def test_dust3r_forward_sizes_with_one_size_is_the_one_size_path():
+    """imcui_hip_dust3r_forward_sizes on images that all share one size: the same launches, bit for bit."""
+    sd, model = _model(SMALL)
+    i0, i1 = _images(160, 224, 1)
+    a = model.forward_pairs(torch.cat((i0, i1), 0).cuda(), [[1, 0], [0, 1]])
+    b = model.forward_pairs_sizes([i0.cuda(), i1.cuda()], [[1, 0], [0, 1]])
+    for v in range(2):
+        for p in range(2):
+            assert torch.equal(a["pts3d"][v, p], b["pts3d"][v][p]) and torch.equal(a["conf"][v, p], b["conf"][v][p])
+
+
+def test_dust3r_plugin_two_sizes_output_structure():
+    """Two sizes through the plugin: upstream's `inference` collates such results with `lists=True` -- lists of per-pair maps."""
+    sd, model = _model(SMALL)
+    i0, _ = _images(160, 224, 1)
+    _, i1 = _images(208, 144, 2)
+    out = model.inference_output({"image0": i0.cuda(), "image1": i1.cuda()})
+    # entry 0 = (image1 as view 1, image0 as view 2), entry 1 = (image0, image1)
+    assert [tuple(m.shape) for m in out["pred1"]["pts3d"]] == [(208, 144, 3), (160, 224, 3)]
+    assert [tuple(m.shape) for m in out["pred2"]["pts3d_in_other_view"]] == [(160, 224, 3), (208, 144, 3)]
+    assert [tuple(m.shape) for m in out["pred2"]["conf"]] == [(160, 224), (208, 144)]
+    assert [tuple(m.shape) for m in out["view1"]["img"]] == [(3, 208, 144), (3, 160, 224)]
+    assert all((m > 1).all() for m in out["pred1"]["conf"] + out["pred2"]["conf"])
+    swapped = model.inference_output({"image0": i1.cuda(), "image1": i0.cuda()})
+    assert torch.equal(swapped["pred1"]["pts3d"][0], out["pred1"]["pts3d"][1])
+    assert torch.equal(swapped["pred2"]["conf"][1], out["pred2"]["conf"][0])
+
+
+def test_mast3r_two_sizes_vs_oracle():
+    """MASt3R on images of two sizes: descriptors / confidences per map against the oracle and the plugin's match list against the
+    oracle's matcher on the same descriptors (the reciprocal search runs between maps of different sizes)."""
+    import numpy as np
+
+    from imcui_hip.hloc.matchers.mast3r import Mast3r
+    from oracle.dust3r import MASt3ROracle, fast_reciprocal_nns
+
+    torch.set_num_threads(16)
+    cfg = {**SMALL, "desc_dim": 24}
+    sd = dust3r_state_dict(2, cfg)
+    model = Mast3r({"state_dict": sd, "max_keypoints": 300}).eval().to("cuda:0")
+    i0, _ = _images(128, 192, 9)
+    _, i1 = _images(160, 112, 10)
+    data = {"image0": i0.cuda(), "image1": i1.cuda()}
+    out = model.inference_output(data)
+    ref = MASt3ROracle(sd, cfg).inference_symmetrized(i0, i1)
+    for pred, pk in (("pred1", "pts3d"), ("pred2", "pts3d_in_other_view")):
+        for p in range(2):
+            want = ref[pred]
+            assert (out[pred][pk][p].cpu() - want[pk][p]).abs().max().item() < 1e-4 * want[pk][p].abs().max().item()
+            assert out[pred]["desc"][p].shape == want["desc"][p].shape
+            assert (out[pred]["desc"][p].cpu() - want["desc"][p]).abs().max().item() < 1e-4
+            assert ((out[pred]["desc_conf"][p].cpu() - want["desc_conf"][p]).abs() / want["desc_conf"][p]).max().item() < 1e-4
+    pred = model(data)
+    d1, d2 = out["pred1"]["desc"][1].cpu(), out["pred2"]["desc"][1].cpu()
+    assert d1.shape == (128, 192, 24) and d2.shape == (160, 112, 24)
+    k0, k1 = fast_reciprocal_nns(d1, d2, subsample=2)
+    if len(k0) > 300:
+        keep = np.round(np.linspace(0, len(k0) - 1, 300)).astype(int)
+        k0, k1 = k0[keep], k1[keep]
+    assert torch.equal(pred["keypoints0"], k0) and torch.equal(pred["keypoints1"], k1)

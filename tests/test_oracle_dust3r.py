@@ -117,6 +117,32 @@ def test_symmetrised_driver_and_postprocessing():
     assert torch.equal(s["pred1"]["pts3d"][0], r["pred1"]["pts3d"][1]) and torch.equal(s["pred2"]["conf"][1], r["pred2"]["conf"][0])
 
 
+def test_views_of_two_sizes():
+    """Upstream's `_encode_image_pairs` encodes views of different sizes one after the other and `inference` collates the per-pair
+    results as lists.  Properties of the restatement: each view keeps its own size; the encoder states do not depend on the OTHER
+    view; exchanging the images exchanges the entries; a view-2 image cropped to whole patches changes view 1 only through the
+    cross attention (same shapes, different values)."""
+    sd = dust3r_state_dict(7, CFG)
+    o = DUSt3ROracle(sd, CFG)
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.rand(1, 3, 64, 96, generator=g), torch.rand(1, 3, 80, 48, generator=g)
+    r = o.inference_symmetrized(a, b, return_intermediates=True)
+    assert [tuple(m.shape) for m in r["pred1"]["pts3d"]] == [(80, 48, 3), (64, 96, 3)]
+    assert [tuple(m.shape) for m in r["pred2"]["pts3d_in_other_view"]] == [(64, 96, 3), (80, 48, 3)]
+    assert [tuple(m.shape) for m in r["pred2"]["conf"]] == [(64, 96), (80, 48)]
+    s = o.inference_symmetrized(b, a)
+    assert torch.equal(s["pred1"]["pts3d"][0], r["pred1"]["pts3d"][1]) and torch.equal(s["pred2"]["conf"][1], r["pred2"]["conf"][0])
+    # the encoder of image a is the same whoever it is paired with (and whichever view it is)
+    same = o.inference_symmetrized(a, a[..., :48, :], return_intermediates=True)
+    e1 = r["_passes"][1][0]["_enc_layers"][-1]     # a as view 1 of (a, b)
+    e2 = same["_passes"][1][0]["_enc_layers"][-1]  # a as view 1 of (a, crop of a)
+    e3 = r["_passes"][0][1]["_enc_layers"][-1]     # a as view 2 of (b, a)
+    assert torch.allclose(e1, e2, atol=1e-5) and torch.allclose(e1, e3, atol=1e-5)
+    assert not torch.allclose(r["pred1"]["pts3d"][1], same["pred1"]["pts3d"][1], atol=1e-3)
+    # the decoder's cross attention really runs between sequences of different length: 24 query tokens against 15 keys
+    assert r["_passes"][1][0]["_dec"][1].shape[1] == 24 and r["_passes"][1][1]["_dec"][1].shape[1] == 15
+
+
 def test_pack_dust3r_layout_matches_the_library():
     """The host packer walks the state dict in the order of the C layer table and every shape agrees (no GPU needed)."""
     from imcui_hip.backend import dust3r_cfg_of, pack_dust3r
@@ -270,7 +296,14 @@ def test_plugin_host_logic_on_a_mocked_device(monkeypatch):
                "desc_conf": torch.stack([torch.cat([r[0]["desc_conf"] for r in res]), torch.cat([r[1]["desc_conf"] for r in res])])}
         return out
 
+    def fake_forward_sizes(self, packed, net_cfg, images, pairs, dump=False, arith=0):
+        norm = [(im.reshape((1,) + tuple(im.shape[-3:])) - 0.5) / 0.5 for im in images]
+        res = [ora.forward(norm[a], norm[b]) for a, b in pairs]
+        return {"pts3d": [[r[0]["pts3d"][0] for r in res], [r[1]["pts3d_in_other_view"][0] for r in res]],
+                "conf": [[r[0]["conf"][0] for r in res], [r[1]["conf"][0] for r in res]]}
+
     monkeypatch.setattr(backend.DUSt3RHIP, "forward", fake_forward)
+    monkeypatch.setattr(backend.DUSt3RHIP, "forward_sizes", fake_forward_sizes)
     monkeypatch.setattr(backend, "nn_argmax", lambda q, db, return_best=False, split=False: nn_dot_first_argmax(q, db))
     monkeypatch.setattr(backend, "get_precision", lambda dev: 1)
     model = Mast3r({"state_dict": sd, "max_keypoints": 50}).eval()
@@ -393,7 +426,7 @@ def test_duster_forward_with_a_mocked_aligner(monkeypatch):
     class Scene:
         def __init__(self, output):
             # batch entry 1 of the inference dictionary is the directed pair (image0, image1)
-            self.imgs = [np.zeros(tuple(output["view1"]["img"].shape[-2:]) + (3,), dtype=np.float32)] * 2
+            self.imgs = [np.zeros(tuple(output[v]["img"][1].shape[-2:]) + (3,), dtype=np.float32) for v in ("view1", "view2")]
             self._pts = [output["pred1"]["pts3d"][1], output["pred2"]["pts3d_in_other_view"][1]]
             c = [output["pred1"]["conf"][1], output["pred2"]["conf"][1]]
             self._masks = [ci > ci.median() for ci in c]
@@ -404,7 +437,14 @@ def test_duster_forward_with_a_mocked_aligner(monkeypatch):
         def get_pts3d(self):
             return self._pts
 
+    def fake_forward_sizes(self, packed, net_cfg, images, pairs, dump=False, arith=0):
+        norm = [(im.reshape((1,) + tuple(im.shape[-3:])) - 0.5) / 0.5 for im in images]
+        res = [ora.forward(norm[a], norm[b]) for a, b in pairs]
+        return {"pts3d": [[r[0]["pts3d"][0] for r in res], [r[1]["pts3d_in_other_view"][0] for r in res]],
+                "conf": [[r[0]["conf"][0] for r in res], [r[1]["conf"][0] for r in res]]}
+
     monkeypatch.setattr(backend.DUSt3RHIP, "forward", fake_forward)
+    monkeypatch.setattr(backend.DUSt3RHIP, "forward_sizes", fake_forward_sizes)
     monkeypatch.setattr(Duster, "aligner", staticmethod(lambda output, device: Scene(output)))
     model = Duster({"state_dict": sd, "max_keypoints": 40}).eval()
     g = torch.Generator().manual_seed(42)
@@ -429,6 +469,19 @@ def test_duster_forward_with_a_mocked_aligner(monkeypatch):
     # an empty second cloud is the reference's "Matched 0 points" branch
     empty = model.matches_from_scene(sc.imgs, [sc.get_masks()[0], torch.zeros_like(sc.get_masks()[1])], sc.get_pts3d())
     assert empty["keypoints0"].shape == (0, 2) and empty["keypoints1"].shape == (0, 2)
-    # unequal sizes are refused with a message that names the restriction
-    with pytest.raises(ValueError, match="ONE size"):
-        model({"image0": i0, "image1": torch.rand(1, 3, 64, 64)})
+    # images of two sizes (the reference's drivers resize each image on its own): lists of per-pair maps, as upstream collates them;
+    # key-points of image0 / image1 live on their own pixel grids
+    j1 = torch.rand(1, 3, 64, 80, generator=g)
+    out2 = model.inference_output({"image0": i0, "image1": j1})
+    assert [tuple(m.shape) for m in out2["pred1"]["pts3d"]] == [(64, 80, 3), (48, 64, 3)]
+    assert [tuple(m.shape) for m in out2["pred2"]["pts3d_in_other_view"]] == [(48, 64, 3), (64, 80, 3)]
+    sc2 = Scene(out2)
+    assert [im.shape for im in sc2.imgs] == [(48, 64, 3), (64, 80, 3)]
+    model.conf["max_keypoints"] = 40
+    pred2 = model({"image0": i0, "image1": j1})
+    m0, m1 = duster_matches_from_scene(sc2.imgs, [m.numpy() for m in sc2.get_masks()], [p.numpy() for p in sc2.get_pts3d()], 40)
+    assert np.array_equal(pred2["keypoints0"].numpy(), m0) and np.array_equal(pred2["keypoints1"].numpy(), m1) and len(m0) > 5
+    assert pred2["keypoints0"][:, 0].max() < 64 and pred2["keypoints0"][:, 1].max() < 48
+    assert pred2["keypoints1"][:, 0].max() < 80 and pred2["keypoints1"][:, 1].max() < 64
+    with pytest.raises(ValueError, match="multiples of the patch size"):
+        model({"image0": i0, "image1": torch.rand(1, 3, 60, 64)})
