@@ -472,6 +472,290 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
     }
 }
 
+// ------------------------------------------------------------------ 16-row tiles for the layers with 64 output channels
+// The kernel above reads 16 LDS fragments per 24 MFMAs when a workgroup has only 64 output channels (NC = 2), against 24 per 48 with
+// 128 (NC = 4: matrix-pipe busy 0.63 against 0.45-0.51) -- LDS bandwidth is what the narrow layers wait for.  Here a wave owns FOUR
+// image rows (a 16 x 32 pixel tile per workgroup) x 64 channels: per tap and 16-channel step 8 pixel + 4 weight fragment reads feed
+// 24 MFMAs, the ratio of the wide kernel.  To keep two workgroups per CU the patch is staged 16 input channels at a time (612 pixels
+// x 2 octets x (hi, lo) = 39 KB), i.e. one MFMA k-step per tap and stage; 128 accumulators per lane as NC = 4.  The halo shrinks from
+// 1.33 to 1.20 patch pixels per output pixel, which is what the fused first layer (conv1a evaluated on the fly per patch pixel) pays
+// its VALU time for.  Summation order: 16-channel stage -> tap (the kernel above: 32-channel chunk -> tap -> two steps).
+#define TTH 16
+#define TNPIX ((TTH + 2) * SPW)  // 612
+#define TPSTR 618                // padded pixel stride (16-byte units)
+#define TITH (TTH + 4)
+
+template <bool FUSE1A, bool SINGLE = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __restrict__ in, const unsigned short* __restrict__ wh,
+                                                              const unsigned short* __restrict__ wl, const float* __restrict__ wscale,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int H, int W, int Cin,
+                                                              int Cout, int tiles_x, int tiles_y, int relu, int pool,
+                                                              const float* __restrict__ w1a, const float* __restrict__ b1a, int cin_stride) {
+    constexpr int WSN = 65;  // padded cout stride of the weight slab (16-byte units)
+    __shared__ uint4 smem[2 * 2 * TPSTR + 2 * 2 * 2 * WSN + (FUSE1A ? (TITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
+    uint4* Ph = smem;              // [octet 2][TPSTR]
+    uint4* Pl = smem + 2 * TPSTR;
+    uint4* Wb = smem + 4 * TPSTR;  // [buf][plane][octet 2][WSN]
+    float* img = reinterpret_cast<float*>(smem + 4 * TPSTR + 8 * WSN);  // [TITH][ITW] (FUSE1A)
+    float* w1 = img + TITH * ITW;                                       // [9][64] + bias [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int ncout = Cout >> 6;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = t % ncout;
+    int sp = t / ncout;
+    const int tx = sp % tiles_x;
+    sp /= tiles_x;
+    const int ty = sp % tiles_y;
+    const int b = sp / tiles_y;
+    const int y0 = ty * TTH, x0 = tx * STW, cout0 = ct * 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int nstage = Cin >> 4;
+    const uint4* wh4 = reinterpret_cast<const uint4*>(wh);
+    const uint4* wl4 = reinterpret_cast<const uint4*>(wl);
+
+    if (FUSE1A) {
+        for (int i = tid; i < TITH * ITW; i += 256) {
+            const int gy = y0 - 2 + i / ITW, gx = x0 - 2 + i % ITW;
+            img[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? in[((size_t)b * H + gy) * W + gx] : 0.0f;
+        }
+        for (int i = tid; i < 9 * 64; i += 256) w1[i] = w1a[i];
+        if (tid < 64) w1[9 * 64 + tid] = b1a[tid];
+    }
+
+    // input patch of a 16-channel stage: 612 pixels x 2 channel octets = 1224 granules, <= 5 per thread; fetched at the stage boundary
+    // (no registers to carry it across the nine taps), the co-resident workgroup covers the latency
+    constexpr int NPG = (TNPIX * 2 + 255) / 256;
+    for (int cs = 0; cs < nstage; ++cs) {
+        float4 pa[NPG], pc[NPG];
+        unsigned pvalid = 0;
+        if (!FUSE1A) {
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) {
+                const int idx = tid + 256 * k;
+                const int oc = idx & 1, pp = idx >> 1;
+                const int py = pp / SPW, px = pp - py * SPW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                if (idx < TNPIX * 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const float* src = in + (((size_t)b * H + gy) * W + gx) * cin_stride + cs * 16 + oc * 8;
+                    pa[k] = *reinterpret_cast<const float4*>(src);
+                    pc[k] = *reinterpret_cast<const float4*>(src + 4);
+                    pvalid |= 1u << k;
+                }
+            }
+        }
+        __syncthreads();  // everybody is done with the previous patch (and the image tile is visible)
+        if (!FUSE1A) {
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < TNPIX * 2) {
+                    uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
+                    if ((pvalid >> k) & 1u) {
+                        if constexpr (SINGLE)
+                            hq = half8_rtn(pa[k], pc[k]);
+                        else
+                            split8(pa[k], pc[k], hq, lq);
+                    }
+                    Ph[(idx & 1) * TPSTR + (idx >> 1)] = hq;
+                    if constexpr (!SINGLE) Pl[(idx & 1) * TPSTR + (idx >> 1)] = lq;
+                }
+            }
+        } else {
+            // fused first layer: a thread always works on the same channel octet (256 % 2 == 0): its 9 x 8 weights and bias once per stage
+            float4 kw0[9], kw1[9], kb0, kb1;
+            const int c0 = cs * 16 + (tid & 1) * 8;
+            kb0 = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0);
+            kb1 = *reinterpret_cast<const float4*>(w1 + 9 * 64 + c0 + 4);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                kw0[t9] = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0);
+                kw1[t9] = *reinterpret_cast<const float4*>(w1 + t9 * 64 + c0 + 4);
+            }
+            for (int idx = tid; idx < TNPIX * 2; idx += 256) {
+                const int oc = idx & 1, pp = idx >> 1;
+                const int py = pp / SPW, px = pp - py * SPW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    // relu(conv1a) for channels c0 .. c0 + 7 of this pixel (tap-major fmaf chain, as conv1a_kernel)
+                    float4 a = kb0, c = kb1;
+#pragma unroll
+                    for (int t9 = 0; t9 < 9; ++t9) {
+                        const float v = img[(py + t9 / 3) * ITW + px + t9 % 3];
+                        const float4 k0 = kw0[t9];
+                        const float4 k1 = kw1[t9];
+                        a.x = fmaf(v, k0.x, a.x);
+                        a.y = fmaf(v, k0.y, a.y);
+                        a.z = fmaf(v, k0.z, a.z);
+                        a.w = fmaf(v, k0.w, a.w);
+                        c.x = fmaf(v, k1.x, c.x);
+                        c.y = fmaf(v, k1.y, c.y);
+                        c.z = fmaf(v, k1.z, c.z);
+                        c.w = fmaf(v, k1.w, c.w);
+                    }
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    c.x = fmaxf(c.x, 0.f); c.y = fmaxf(c.y, 0.f); c.z = fmaxf(c.z, 0.f); c.w = fmaxf(c.w, 0.f);
+                    split8(a, c, hq, lq);
+                }
+                Ph[oc * TPSTR + pp] = hq;
+                Pl[oc * TPSTR + pp] = lq;
+            }
+        }
+        // weight slab of a tap and stage: 2 octets x 64 cout per plane = 128 x 16 B: threads 0..127 carry the hi plane, 128..255 the lo plane
+        uint4 rw;
+        const int wplane = tid >> 7, woct = (tid >> 6) & 1, wc = tid & 63;
+        auto wload = [&](int tap) __attribute__((always_inline)) {
+            const size_t o = ((size_t)((cs >> 1) * 9 + tap) * 4 + (cs & 1) * 2 + woct) * Cout + cout0 + wc;
+            if (wplane == 0)
+                rw = wh4[o];
+            else if constexpr (!SINGLE)
+                rw = wl4[o];
+        };
+        wload(0);
+        for (int tap = 0; tap < 9; ++tap) {
+            uint4* wb = Wb + (tap & 1) * (4 * WSN);
+            if (!SINGLE || wplane == 0) wb[wplane * (2 * WSN) + woct * WSN + wc] = rw;
+            __syncthreads();
+            if (tap + 1 < 9) wload(tap + 1);
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const uint4* wbh = wb + hi * WSN;
+            const uint4* wbl = wb + 2 * WSN + hi * WSN;
+            uint4 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int pp = (4 * wid + m + dy) * SPW + lo + dx;
+                ah[m] = Ph[hi * TPSTR + pp];
+                if constexpr (!SINGLE) al[m] = Pl[hi * TPSTR + pp];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bh[n] = wbh[n * 32 + lo];
+                if constexpr (!SINGLE) bl[n] = wbl[n * 32 + lo];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if constexpr (!SINGLE) {
+                        acc[m][n] = mfma16(bh[n], al[m], acc[m][n]);
+                        acc[m][n] = mfma16(bl[n], ah[m], acc[m][n]);
+                    }
+                    acc[m][n] = mfma16(bh[n], ah[m], acc[m][n]);
+                }
+        }
+    }
+
+    // ---- epilogue (as the kernel above): finished values parked in LDS [pixel][64 channels], out as whole 256-byte channel runs
+    const float wsc = wscale[0];
+    const float* resid = FUSE1A ? nullptr : w1a;
+    const bool late = resid != nullptr;
+    __syncthreads();
+    float* st = reinterpret_cast<float*>(smem);
+    constexpr int SROW = 68;
+    if (pool) {
+        // rows 4w .. 4w+3 of a wave pool to 2 rows x 16 columns: 8 x 16 pooled pixels per workgroup
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = n * 32 + 8 * q + 4 * hi;
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float tv = fmaxf(acc[2 * mp][n][4 * q + j], acc[2 * mp + 1][n][4 * q + j]);
+                        tv = fmaxf(tv, __shfl_xor(tv, 1, 64));
+                        v[j] = tv * wsc;
+                    }
+                    v[0] += b4.x;
+                    v[1] += b4.y;
+                    v[2] += b4.z;
+                    v[3] += b4.w;
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = conv_act(v[j], relu);
+                    }
+                    if ((lo & 1) == 0) *reinterpret_cast<float4*>(st + ((wid * 2 + mp) * 16 + (lo >> 1)) * SROW + cl) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {  // 128 pooled pixels x 16 channel quads
+            const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
+            const int oy = (y0 >> 1) + (px >> 4), pxo = (x0 >> 1) + (px & 15);
+            if (oy < Ho && pxo < Wo)
+                *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Wo + pxo) * Cout + cout0 + 4 * c4) =
+                    *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+        }
+    } else {
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) {  // image rows 4 h2 .. 4 h2 + 3 of the tile = wave h2
+            if (wid == h2) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = n * 32 + 8 * q + 4 * hi;
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias + cout0 + cl);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            float4 v = make_float4(acc[m][n][4 * q + 0] * wsc + b4.x, acc[m][n][4 * q + 1] * wsc + b4.y, acc[m][n][4 * q + 2] * wsc + b4.z,
+                                                   acc[m][n][4 * q + 3] * wsc + b4.w);
+                            if (relu && !late) {
+                                v.x = conv_act(v.x, relu);
+                                v.y = conv_act(v.y, relu);
+                                v.z = conv_act(v.z, relu);
+                                v.w = conv_act(v.w, relu);
+                            }
+                            *reinterpret_cast<float4*>(st + (m * 32 + lo) * SROW + cl) = v;
+                        }
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
+                const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
+                const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
+                if (oy < H && ox < W) {
+                    float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+                    const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4;
+                    if (late) {
+                        const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
+                        v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
+                    }
+                    *reinterpret_cast<float4*>(out + o) = v;
+                }
+            }
+            if (h2 < 3) __syncthreads();
+        }
+    }
+}
+
+// IMCUI_CONV_TALL: 0 = the 8-row kernel everywhere, 1 (default) = 16-row tiles for the fused first layer, 2 = also for plain layers
+// whose Cout is not a multiple of 128 (read per process).  Measured (profiles/r03_lab_conv_tall.txt): SuperPoint's convolutions 18.38 ms
+// per 128 images with 0, 17.60 with 1, 17.94 with 2 -- the plain layers LOSE with 16-channel stages (64-byte pieces of the 256-byte
+// pixel rows per stage, and no registers left to prefetch the next patch across the taps), the fused layer, whose patch is computed
+// from an LDS image tile, gains 10 %.
+static int conv_tall_mode() {
+    static const int mode = [] {
+        const char* e = getenv("IMCUI_CONV_TALL");
+        return e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
                          int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single) {
@@ -482,10 +766,27 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (Cin % 32 != 0 || Cout % 64 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
-    const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, STH);
+    const int tiles_x = cdiv(W, STW);
     // 128 output channels per workgroup when the layer has them (fewer LDS fragment reads and barriers per MFMA)
     static const bool narrow_only = getenv("IMCUI_CONV_NARROW") != nullptr;  // A/B switch
     const bool wide = (Cout % 128 == 0) && !narrow_only;
+    if (!wide && cout_live == Cout && conv_tall_mode() >= 2) {  // 64-channel layers: 16-row tiles (same LDS-read ratio as the wide kernel)
+        const int tiles_t = cdiv(H, TTH);
+        const long nwg_t = (long)tiles_x * tiles_t * (Cout / 64) * B;
+        if (nwg_t <= 0) return IMCUI_OK;
+        if (h->range_flag) imcui_range_check(h, in, (long)B * H * W, Cin, cin_stride, nullptr, 0, stream);
+        imcui_prof_begin(h, PROF_CONV, stream);
+        if (single)
+            hipLaunchKernelGGL((conv3x3_tall_kernel<false, true>), dim3((unsigned)nwg_t), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                               tiles_x, tiles_t, relu, pool, resid, (const float*)nullptr, cin_stride);
+        else
+            hipLaunchKernelGGL((conv3x3_tall_kernel<false>), dim3((unsigned)nwg_t), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
+                               tiles_x, tiles_t, relu, pool, resid, (const float*)nullptr, cin_stride);
+        imcui_prof_end(h, PROF_CONV, stream);
+        IMCUI_CHECK_LAUNCH(h);
+        return IMCUI_OK;
+    }
+    const int tiles_y = cdiv(H, STH);
     const long nwg = (long)tiles_x * tiles_y * (Cout / (wide ? 128 : 64)) * B;
     if (nwg <= 0) return IMCUI_OK;
     if (h->range_flag) imcui_range_check(h, in, (long)B * H * W, Cin, cin_stride, nullptr, 0, stream);
@@ -511,12 +812,17 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
                                const unsigned short* wh, const unsigned short* wl, const float* wscale, const float* bias,
                                float* out, int B, int H, int W, int pool, hipStream_t stream) {
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv1ab: pooled layer needs even H,W (%dx%d)", H, W);
-    const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, STH);
+    const bool tall = conv_tall_mode() >= 1;
+    const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, tall ? TTH : STH);
     const long nwg = (long)tiles_x * tiles_y * B;
     if (nwg <= 0) return IMCUI_OK;
     imcui_prof_begin(h, PROF_CONV, stream);
-    hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
-                       W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64, 64);
+    if (tall)
+        hipLaunchKernelGGL((conv3x3_tall_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H, W, 64, 64, tiles_x,
+                           tiles_y, 1, pool, w1a, b1a, 64);
+    else
+        hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
+                           W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64, 64);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

@@ -35,7 +35,7 @@ def needs_build() -> bool:
 # MFMA kernels whose register budget is part of the design: a build that spills them to scratch is rejected (two
 # experimental builds of the split GEMM that spilled -- 128-VGPR and 168-VGPR-with-20-B-scratch variants -- were
 # slower AND failed the parity / determinism tests on the GPU; hipcc is not to be trusted with spills around them).
-NO_SPILL_KERNELS = ("gemm_split_kernel", "gemm_wreg_kernel", "gemm_kernel", "attn_split_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_kernel", "lg_ffn_kernel")
+NO_SPILL_KERNELS = ("gemm_split_kernel", "gemm_wreg_kernel", "gemm_kernel", "attn_split_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_tall_kernel", "conv3x3_kernel", "lg_ffn_kernel")
 
 
 def _check_no_spills(src: str, remarks: str) -> None:
