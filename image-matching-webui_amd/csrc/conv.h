@@ -16,7 +16,9 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
                          int relu, int pool, hipStream_t stream, const float* resid = nullptr, int cin_stride = 0, int cout_live = 0,
-                         int single = 0);
+                         int single = 0, const float* resid2 = nullptr);
+// relu bit 2 (value 4): ReLU applied to the INPUT map while it is staged (the producer left it un-activated);  resid2: a second map
+// added after resid (out = act(conv + resid + resid2))
 // cin_stride: floats between two pixels of `in` when the map stores more channels than the Cin that are used (0 = Cin)
 // cout_live: output channels >= cout_live are zero padding of the layer (zero weights and bias): their 32-channel fragments
 // are not multiplied, the channels are stored as zeros (0 = Cout)

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
     // 32-channel fragments of this workgroup that hold live output channels (the rest is zero padding of the layer: its
     // products are skipped, the accumulators stay 0 and the padded channels are stored as act(0 + 0) = 0)
     const int nlive = min(NC, (cout_live - cout0 + 31) >> 5);
+    // `relu`: bits 0..1 = activation of the output (0 none, 1 ReLU, 2 LeakyReLU), bit 2 = ReLU applied to the INPUT while it is staged
+    const bool relu_in = !FUSE1A && (relu & 4) != 0;
+    relu &= 3;
 
     f32x16 acc[2][NC];
 #pragma unroll
@@ -248,6 +251,10 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
             if (idx < SNPIX * 4) {
                 uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
                 if ((pvalid >> k) & 1u) {
+                    if (relu_in) {  // the producer left the map un-activated (a residual sum that is also needed as it is)
+                        pa[k] = make_float4(fmaxf(pa[k].x, 0.f), fmaxf(pa[k].y, 0.f), fmaxf(pa[k].z, 0.f), fmaxf(pa[k].w, 0.f));
+                        pc[k] = make_float4(fmaxf(pc[k].x, 0.f), fmaxf(pc[k].y, 0.f), fmaxf(pc[k].z, 0.f), fmaxf(pc[k].w, 0.f));
+                    }
                     if constexpr (SINGLE)
                         hq = half8_rtn(pa[k], pc[k]);  // one product: the nearest f16 of either operand
                     else
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
     // `relu`: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  Plain layers pass a residual map (same shape as the output) in the
     // unused first-layer pointer: it is added before the activation, in the coalesced store loop.
     const float* resid = FUSE1A ? nullptr : w1a;
+    const float* resid2 = FUSE1A ? nullptr : b1a;  // a second map added with the first (DPT fusion blocks: conv + skip + path)
     const bool late = resid != nullptr;
     __syncthreads();  // every wave is done with the patch / weight buffers
     float* st = reinterpret_cast<float*>(smem);
@@ -460,8 +468,13 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                         float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
                         const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + coutH + 4 * c4;
                         if (late) {  // residual connection: added before the activation (BasicBlock: relu(conv + identity))
-                            const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
-                            v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
+                            float4 r4 = *reinterpret_cast<const float4*>(resid + o);
+                            v = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+                            if (resid2) {  // (conv + first) + second, in this order
+                                r4 = *reinterpret_cast<const float4*>(resid2 + o);
+                                v = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+                            }
+                            v = make_float4(conv_act(v.x, relu), conv_act(v.y, relu), conv_act(v.z, relu), conv_act(v.w, relu));
                         }
                         *reinterpret_cast<float4*>(out + o) = v;
                     }
@@ -510,6 +523,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
     const int ty = sp % tiles_y;
     const int b = sp / tiles_y;
     const int y0 = ty * TTH, x0 = tx * STW, cout0 = ct * 64;
+    const bool relu_in = !FUSE1A && (relu & 4) != 0;  // as conv3x3_split_kernel
+    relu &= 3;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -561,6 +576,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
                 if (idx < TNPIX * 2) {
                     uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
                     if ((pvalid >> k) & 1u) {
+                        if (relu_in) {
+                            pa[k] = make_float4(fmaxf(pa[k].x, 0.f), fmaxf(pa[k].y, 0.f), fmaxf(pa[k].z, 0.f), fmaxf(pa[k].w, 0.f));
+                            pc[k] = make_float4(fmaxf(pc[k].x, 0.f), fmaxf(pc[k].y, 0.f), fmaxf(pc[k].z, 0.f), fmaxf(pc[k].w, 0.f));
+                        }
                         if constexpr (SINGLE)
                             hq = half8_rtn(pa[k], pc[k]);
                         else
@@ -658,6 +677,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
     // ---- epilogue (as the kernel above): finished values parked in LDS [pixel][64 channels], out as whole 256-byte channel runs
     const float wsc = wscale[0];
     const float* resid = FUSE1A ? nullptr : w1a;
+    const float* resid2 = FUSE1A ? nullptr : b1a;
     const bool late = resid != nullptr;
     __syncthreads();
     float* st = reinterpret_cast<float*>(smem);
@@ -732,8 +752,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
                     float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
                     const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + cout0 + 4 * c4;
                     if (late) {
-                        const float4 r4 = *reinterpret_cast<const float4*>(resid + o);
-                        v = make_float4(conv_act(v.x + r4.x, relu), conv_act(v.y + r4.y, relu), conv_act(v.z + r4.z, relu), conv_act(v.w + r4.w, relu));
+                        float4 r4 = *reinterpret_cast<const float4*>(resid + o);
+                        v = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+                        if (resid2) {
+                            r4 = *reinterpret_cast<const float4*>(resid2 + o);
+                            v = make_float4(v.x + r4.x, v.y + r4.y, v.z + r4.z, v.w + r4.w);
+                        }
+                        v = make_float4(conv_act(v.x, relu), conv_act(v.y, relu), conv_act(v.z, relu), conv_act(v.w, relu));
                     }
                     *reinterpret_cast<float4*>(out + o) = v;
                 }
@@ -758,11 +783,12 @@ static int conv_tall_mode() {
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single) {
+                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single, const float* resid2) {
     if (cin_stride <= 0) cin_stride = Cin;
     if (cout_live <= 0 || cout_live > Cout) cout_live = Cout;
     if (cin_stride < Cin || cin_stride % 4 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pixel stride %d for %d input channels", cin_stride, Cin);
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
+    if (resid2 && !resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: a second residual map needs the first");
     if (Cin % 32 != 0 || Cout % 64 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
@@ -778,10 +804,10 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
         imcui_prof_begin(h, PROF_CONV, stream);
         if (single)
             hipLaunchKernelGGL((conv3x3_tall_kernel<false, true>), dim3((unsigned)nwg_t), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                               tiles_x, tiles_t, relu, pool, resid, (const float*)nullptr, cin_stride);
+                               tiles_x, tiles_t, relu, pool, resid, resid2, cin_stride);
         else
             hipLaunchKernelGGL((conv3x3_tall_kernel<false>), dim3((unsigned)nwg_t), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                               tiles_x, tiles_t, relu, pool, resid, (const float*)nullptr, cin_stride);
+                               tiles_x, tiles_t, relu, pool, resid, resid2, cin_stride);
         imcui_prof_end(h, PROF_CONV, stream);
         IMCUI_CHECK_LAUNCH(h);
         return IMCUI_OK;
@@ -793,16 +819,16 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     imcui_prof_begin(h, PROF_CONV, stream);
     if (wide && single)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
     else if (single)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
     else if (wide)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
     else
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, (const float*)nullptr, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

@@ -762,11 +762,12 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         const int hg = Hh / 16, wg = Wh / 16, T = hg * wg;
         const long pt = (long)Pn * T;
         const int L0 = du_l_head(c, v);
-        auto conv3 = [&](int li, const float* in, float* out, int hh, int ww, int act, const float* resid) -> int {
+        // act: output activation code, + 4 = ReLU on the input while it is staged; resid (+ resid2): maps added before the activation
+        auto conv3 = [&](int li, const float* in, float* out, int hh, int ww, int act, const float* resid, const float* resid2 = nullptr) -> int {
             int N, K, kind;
             du_shape(c, li, &N, &K, &kind);
             return conv3x3_split_launch(h, in, reinterpret_cast<const unsigned short*>(Pk + l.wh[li]), reinterpret_cast<const unsigned short*>(Pk + l.wl[li]),
-                                        Pk + l.ws[li], Pk + l.b[li], out, Pn, hh, ww, K / 9, N, act, 0, stream, resid, 0, 0, single);
+                                        Pk + l.ws[li], Pk + l.b[li], out, Pn, hh, ww, K / 9, N, act, 0, stream, resid, 0, 0, single, resid2);
         };
         auto shuffle = [&](const float* src, float* dst, int s, int C) {
             const long n4 = pt * s * s * (C / 4);
@@ -819,28 +820,46 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         const int rh[4] = {4 * hg, 2 * hg, hg, h3}, rw[4] = {4 * wg, 2 * wg, wg, w3};
         if (!mixed)
             for (int k = 0; k < 4; ++k) dump_copy(w.rn[k], (size_t)Pn * rh[k] * rw[k] * 256);
-        // fusion: refinenet 4, 3, 2, 1
+        // fusion: refinenet 4, 3, 2, 1.  FeatureFusionBlock(path, skip) = out_conv(up2(RCU2(path + RCU1(skip)))), RCU(x) = x + conv2(relu(conv1(
+        // relu(x)))).  The ReLU in front of a unit's first convolution is applied while that convolution stages its input, the sum
+        // path + RCU1(skip) leaves the second convolution of RCU1 as a double residual (conv + skip + path), and the 1x1 out_conv runs
+        // BEFORE the bilinear x2 (both are linear and the interpolation weights sum to 1, so the bias commutes; a quarter of the rows).
+        // IMCUI_DUST3R_HEAD_UNFUSED=1 keeps the element-wise kernels and upstream's order (A/B and parity of the commuted form).
+        static const bool head_unfused = getenv("IMCUI_DUST3R_HEAD_UNFUSED") != nullptr;
         const float* path = nullptr;
         for (int q = 0; q < 4; ++q) {
             const int lv = 3 - q, hh = rh[lv], ww = rw[lv];
             const long n4 = (long)Pn * hh * ww * 64;
             const int Lq = L0 + 11 + 5 * q;
-            const float* xres;
-            if (q == 0) {
-                hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[3], w.s1, n4);
-                xres = w.rn[3];
-            } else {
-                hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[lv], w.s0, n4);
-                DURUN(conv3(Lq + 0, w.s0, w.s1, hh, ww, 1, nullptr));
-                DURUN(conv3(Lq + 1, w.s1, w.s0, hh, ww, 0, w.rn[lv]));
-                hipLaunchKernelGGL(du_add_relu_kernel, blocks(n4), blk, 0, stream, path, w.s0, w.s2, w.s1, n4);
-                xres = w.s2;
-            }
-            DURUN(conv3(Lq + 2, w.s1, w.s0, hh, ww, 1, nullptr));
-            DURUN(conv3(Lq + 3, w.s0, w.s1, hh, ww, 0, xres));
-            hipLaunchKernelGGL(du_upsample2_kernel, blocks(4 * n4), blk, 0, stream, w.s1, w.s3, hh, ww, 64, 4 * n4);
             float* out = (q & 1) ? w.pb : w.pa;
-            DURUN(lin_dense(Lq + 4, w.s3, out, (long)Pn * 4 * hh * ww));
+            if (head_unfused) {
+                const float* xres;
+                if (q == 0) {
+                    hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[3], w.s1, n4);
+                    xres = w.rn[3];
+                } else {
+                    hipLaunchKernelGGL(du_relu_kernel, blocks(n4), blk, 0, stream, w.rn[lv], w.s0, n4);
+                    DURUN(conv3(Lq + 0, w.s0, w.s1, hh, ww, 1, nullptr));
+                    DURUN(conv3(Lq + 1, w.s1, w.s0, hh, ww, 0, w.rn[lv]));
+                    hipLaunchKernelGGL(du_add_relu_kernel, blocks(n4), blk, 0, stream, path, w.s0, w.s2, w.s1, n4);
+                    xres = w.s2;
+                }
+                DURUN(conv3(Lq + 2, w.s1, w.s0, hh, ww, 1, nullptr));
+                DURUN(conv3(Lq + 3, w.s0, w.s1, hh, ww, 0, xres));
+                hipLaunchKernelGGL(du_upsample2_kernel, blocks(4 * n4), blk, 0, stream, w.s1, w.s3, hh, ww, 64, 4 * n4);
+                DURUN(lin_dense(Lq + 4, w.s3, out, (long)Pn * 4 * hh * ww));
+            } else {
+                const float* x2 = w.rn[3];  // input of the second unit: rn[3] itself (refinenet4 has no skip), else path + RCU1(skip)
+                if (q > 0) {
+                    DURUN(conv3(Lq + 0, w.rn[lv], w.s1, hh, ww, 1 + 4, nullptr));
+                    DURUN(conv3(Lq + 1, w.s1, w.s2, hh, ww, 0, w.rn[lv], path));
+                    x2 = w.s2;
+                }
+                DURUN(conv3(Lq + 2, x2, w.s0, hh, ww, 1 + 4, nullptr));
+                DURUN(conv3(Lq + 3, w.s0, w.s1, hh, ww, 0, x2));
+                DURUN(lin_dense(Lq + 4, w.s1, w.s3, (long)Pn * hh * ww));
+                hipLaunchKernelGGL(du_upsample2_kernel, blocks(4 * n4), blk, 0, stream, w.s3, out, hh, ww, 64, 4 * n4);
+            }
             path = out;
             int ph = 2 * hh, pw = 2 * ww;
             if (q == 0 && (ph != hg || pw != wg)) {
