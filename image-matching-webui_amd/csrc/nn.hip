@@ -323,9 +323,16 @@ __global__ __launch_bounds__(256) void nn_split_rows_kernel(const float* __restr
     *reinterpret_cast<uint4*>(lo + row * 32 + c0) = l;
 }
 
+// Main pass: the running maximum of every query and the 64-ROW TILE that first reached it (per tile and column group: eight
+// v_max3 over the 32 accumulators + compare + two selects, no branch).  Finding the row inside the tile while scanning costs a
+// 32-way compare / select ladder whenever ANY of a wave's 64 lanes improves -- 38 % of the tiles of a 32 768-row range -- and
+// matrix and vector instructions do not overlap on a SIMD: round 2's kernel ran the data base of a 512 x 512 image against 65 536
+// queries in 4.0 ms at 0.35 of the matrix pipe.  The row is recovered afterwards by nn_argmax_fixup_kernel, which multiplies the
+// winning tile of every query again with the same instruction sequence (bitwise the same values) and takes the first row that
+// equals the maximum: 12 more MFMAs per query against 98 304 in the scan.
 __global__ __launch_bounds__(256, 2) void nn_argmax_split_kernel(const unsigned short* __restrict__ qh, const unsigned short* __restrict__ ql,
                                                                 const unsigned short* __restrict__ dh, const unsigned short* __restrict__ dl, int Q,
-                                                                int N, int chunk, float* __restrict__ pbest, int* __restrict__ pidx) {
+                                                                int N, int chunk, float* __restrict__ pbest, int* __restrict__ ptile) {
     constexpr int RSB = 80;  // bytes per staged row (64 + 16 padding: 16-lane groups of a ds_read_b128 cover all banks once)
     __shared__ uint4 tile4[2][2][64 * RSB / 16];  // [buffer][plane][row]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -345,23 +352,25 @@ __global__ __launch_bounds__(256, 2) void nn_argmax_split_kernel(const unsigned 
         }
     }
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bidx[4] = {n0, n0, n0, n0};
-    // staging: 64 rows x 64 bytes per plane = 256 uint4 per plane: one per thread and plane
-    auto stage = [&](int buf, int base) {
-        const int r = tid >> 2, g = tid & 3;
-        uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
-        if (base + r < n1) {
-            vh = *reinterpret_cast<const uint4*>(dh + (size_t)(base + r) * 32 + g * 8);
-            vl = *reinterpret_cast<const uint4*>(dl + (size_t)(base + r) * 32 + g * 8);
+    int btile[4] = {n0, n0, n0, n0};
+    // staging: 64 rows x 64 bytes per plane = 256 uint4 per plane: one per thread and plane.  The rows of tile t + 2 are requested
+    // before the MFMAs of tile t and written to LDS after the MFMAs of tile t + 1 (two register sets, loop unrolled by two): a load
+    // whose LDS write sits in front of the tile's own fragment reads exposed the whole L2 latency once per tile (2.9 ms per
+    // 65 536 x 262 144 search; the compiler keeps LDS stores and loads in program order).
+    const int sr = tid >> 2, sg = tid & 3;
+    auto gload = [&](int base, uint4& vh, uint4& vl) __attribute__((always_inline)) {
+        vh = make_uint4(0u, 0u, 0u, 0u);
+        vl = vh;
+        if (base + sr < n1) {
+            vh = *reinterpret_cast<const uint4*>(dh + (size_t)(base + sr) * 32 + sg * 8);
+            vl = *reinterpret_cast<const uint4*>(dl + (size_t)(base + sr) * 32 + sg * 8);
         }
-        tile4[buf][0][(r * RSB + g * 16) / 16] = vh;
-        tile4[buf][1][(r * RSB + g * 16) / 16] = vl;
     };
-    if (n0 < n1) stage(0, n0);
-    __syncthreads();
-    int buf = 0;
-    for (int base = n0; base < n1; base += 64, buf ^= 1) {
-        if (base + 64 < n1) stage(buf ^ 1, base + 64);
+    auto lwrite = [&](int buf, const uint4& vh, const uint4& vl) __attribute__((always_inline)) {
+        tile4[buf][0][(sr * RSB + sg * 16) / 16] = vh;
+        tile4[buf][1][(sr * RSB + sg * 16) / 16] = vl;
+    };
+    auto compute = [&](int base, int buf) __attribute__((always_inline)) {
         f32x16 acc[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -382,42 +391,118 @@ __global__ __launch_bounds__(256, 2) void nn_argmax_split_kernel(const unsigned 
                     acc[rt][c] = mfma16(ah, bh[c][ks], acc[rt][c]);
                 }
             }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float tmax = acc[0][c][0];
+        if (base + 64 > n1) {  // the last tile of the range: rows past its end were staged as zeros and must not win
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[rt][c][r]);
-            if (tmax > best[c]) {
+                for (int r = 0; r < 16; ++r)
+                    if (base + rt * 32 + frag_row(r, hi) >= n1) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = base + rt * 32 + frag_row(r, hi);
-                        const float v = acc[rt][c][r];
-                        if (row < n1 && v > best[c]) {
-                            best[c] = v;
-                            bidx[c] = row;
-                        }
+                        for (int c = 0; c < 4; ++c) acc[rt][c][r] = -INFINITY;
                     }
-            }
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float m[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x16& a = acc[rt][c];
+                const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]), m2 = fmaxf(fmaxf(a[6], a[7]), a[8]);
+                const float m3 = fmaxf(fmaxf(a[9], a[10]), a[11]), m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
+                m[rt] = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), a[15]));
+            }
+            const float tmax = fmaxf(m[0], m[1]);
+            const bool up = tmax > best[c];  // strict: the first tile that reaches the maximum keeps it
+            best[c] = up ? tmax : best[c];
+            btile[c] = up ? base : btile[c];
+        }
+    };
+    if (n0 < n1) {
+        uint4 rah, ral, rbh, rbl;
+        gload(n0, rah, ral);
+        lwrite(0, rah, ral);
+        gload(n0 + 64, rah, ral);  // tile 1 waits in registers
         __syncthreads();
+        for (int base = n0; base < n1; base += 128) {
+            gload(base + 128, rbh, rbl);
+            compute(base, 0);
+            lwrite(1, rah, ral);
+            __syncthreads();
+            if (base + 64 >= n1) break;
+            gload(base + 192, rah, ral);
+            compute(base + 64, 1);
+            lwrite(0, rbh, rbl);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float ov = __shfl_xor(best[c], 32, 64);
-        const int oi = __shfl_xor(bidx[c], 32, 64);
-        if (ov > best[c] || (ov == best[c] && oi < bidx[c])) {
+        const int ot = __shfl_xor(btile[c], 32, 64);
+        if (ov > best[c] || (ov == best[c] && ot < btile[c])) {
             best[c] = ov;
-            bidx[c] = oi;
+            btile[c] = ot;
         }
         const int qi = q0 + c * 32 + lo;
         if (hi == 0 && qi < Q) {
-            pbest[(size_t)split * Q + qi] = best[c] * (1.0f / 65536.0f);  // both operands carry 2^8
-            pidx[(size_t)split * Q + qi] = bidx[c];
+            pbest[(size_t)split * Q + qi] = best[c];  // raw (both operands carry 2^8): the fix-up pass compares against it bit for bit
+            ptile[(size_t)split * Q + qi] = btile[c];
         }
+    }
+}
+
+// idx[q] holds the first row of the 64-row tile that reached best[q] (fold of the ranges: largest value, first tile): find the first
+// row of that tile whose product equals best[q].  One wave = 32 queries; for query j the tile is multiplied against all 32
+// queries of the wave with the instruction sequence of the scan and lanes lo == j read their column.  best is rescaled on the way out.
+__global__ __launch_bounds__(256) void nn_argmax_fixup_kernel(const unsigned short* __restrict__ qh, const unsigned short* __restrict__ ql,
+                                                              const unsigned short* __restrict__ dh, const unsigned short* __restrict__ dl, int Q,
+                                                              int N, int* __restrict__ idx, const float* __restrict__ best_raw, float* __restrict__ best_out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wid) * 32;
+    if (q0 >= Q) return;
+    const int q = min(q0 + lo, Q - 1);
+    uint4 bh[2], bl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bh[ks] = *reinterpret_cast<const uint4*>(qh + (size_t)q * 32 + ks * 16 + hi * 8);
+        bl[ks] = *reinterpret_cast<const uint4*>(ql + (size_t)q * 32 + ks * 16 + hi * 8);
+    }
+    const int mytile = idx[q];
+    const float mybest = best_raw[q];
+    int found = 0x7fffffff;
+    for (int j = 0; j < 32 && q0 + j < Q; ++j) {
+        const int T = __builtin_amdgcn_readlane(mytile, j);
+        f32x16 acc[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+            const size_t row = (size_t)min(T + rt * 32 + lo, N - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 ah = *reinterpret_cast<const uint4*>(dh + row * 32 + ks * 16 + hi * 8);
+                const uint4 al = *reinterpret_cast<const uint4*>(dl + row * 32 + ks * 16 + hi * 8);
+                acc[rt] = mfma16(ah, bl[ks], acc[rt]);
+                acc[rt] = mfma16(al, bh[ks], acc[rt]);
+                acc[rt] = mfma16(ah, bh[ks], acc[rt]);
+            }
+        }
+        if (lo == j) {
+#pragma unroll
+            for (int rt = 1; rt >= 0; --rt)
+#pragma unroll
+                for (int r = 15; r >= 0; --r) {
+                    const int row = T + rt * 32 + frag_row(r, hi);
+                    if (acc[rt][r] == mybest && row < N) found = row;  // descending scan: the smallest row of this lane's half survives
+                }
+        }
+    }
+    const int other = __shfl_xor(found, 32, 64);
+    found = min(found, other);
+    if (hi == 0 && q0 + lo < Q) {
+        idx[q] = found != 0x7fffffff ? found : mytile;  // (a maximum that no row reproduces cannot happen: same data, same instructions)
+        if (best_out) best_out[q] = mybest * (1.0f / 65536.0f);
     }
 }
 
@@ -432,7 +517,7 @@ static int nn_argmax_split_nsplit(int Q, int N) {
 // workspace: partial results + the f16 planes of both operands
 extern "C" size_t imcui_hip_nn_argmax_split_workspace_bytes(int Q, int N) {
     if (Q <= 0 || N <= 0) return 256;
-    return (size_t)nn_argmax_split_nsplit(Q, N) * Q * 8 + ((size_t)Q + N) * 128 + 2048;
+    return (size_t)nn_argmax_split_nsplit(Q, N) * Q * 8 + (size_t)Q * 4 + ((size_t)Q + N) * 128 + 2560;
 }
 extern "C" int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* queries, const float* db, int Q, int N, int D, int* idx, float* best,
                                              void* ws, size_t ws_bytes, void* stream_) {
@@ -445,6 +530,7 @@ extern "C" int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* querie
     WsAlloc a(ws, ws_bytes);
     float* pbest = a.get<float>((size_t)ns * Q);
     int* pidx = a.get<int>((size_t)ns * Q);
+    float* fbest = a.get<float>((size_t)Q);  // raw maximum of every query after the fold of the ranges
     unsigned short* qh = a.get<unsigned short>((size_t)Q * 32);
     unsigned short* ql = a.get<unsigned short>((size_t)Q * 32);
     unsigned short* dh = a.get<unsigned short>((size_t)N * 32);
@@ -454,7 +540,9 @@ extern "C" int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* querie
     hipLaunchKernelGGL(nn_split_rows_kernel, dim3((unsigned)(((long)N * 4 + 255) / 256)), dim3(256), 0, stream, db, N, D, dh, dl);
     const int chunk = (((N + ns - 1) / ns) + 63) / 64 * 64;
     hipLaunchKernelGGL(nn_argmax_split_kernel, dim3((Q + 511) / 512, ns), dim3(256), 0, stream, qh, ql, dh, dl, Q, N, chunk, pbest, pidx);
-    hipLaunchKernelGGL(nn_argmax_fold_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, pbest, pidx, Q, ns, idx, best);
+    // fold of the ranges (largest value, first tile), then the row inside the winning tile
+    hipLaunchKernelGGL(nn_argmax_fold_kernel, dim3((Q + 255) / 256), dim3(256), 0, stream, pbest, pidx, Q, ns, idx, fbest);
+    hipLaunchKernelGGL(nn_argmax_fixup_kernel, dim3((Q + 127) / 128), dim3(256), 0, stream, qh, ql, dh, dl, Q, N, idx, fbest, best);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }
