@@ -74,6 +74,13 @@ def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int
     (linear position in image 1, linear position in image 2).  `nn(queries, db)` = first arg-max of the dot products (default: the
     HIP kernel); the loop is upstream's `fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=S, ret_xy=True, pixel_tol=0)`."""
     nn = nn or (lambda q, db: backend.nn_argmax(q, db, split=split))
+
+    def nn_of(points, which, db):
+        """nearest neighbour of every listed point: chains that stand on the SAME point are searched once (the answer is a
+        function of the point; upstream searches every chain, with the same result)."""
+        uq, inv = torch.unique(which, return_inverse=True)
+        return nn(points[uq], db)[inv]
+
     H1, W1, D = desc1.shape
     H2, W2, _ = desc2.shape
     dev = desc1.device
@@ -87,11 +94,11 @@ def fast_reciprocal_nns(desc1: torch.Tensor, desc2: torch.Tensor, subsample: int
     niter = 0
     while bool(notyet.any()):
         act = notyet.nonzero()[:, 0]
-        xy2[act] = nn(p1[xy1[act]], p2)
+        xy2[act] = nn_of(p1, xy1[act], p2)
         notyet &= old_xy2 != xy2  # chains whose image-2 end did not move have converged
         act = notyet.nonzero()[:, 0]
         if len(act):
-            xy1[act] = nn(p2[xy2[act]], p1)
+            xy1[act] = nn_of(p2, xy2[act], p1)
         notyet &= old_xy1 != xy1
         niter += 1
         if niter >= max_iter:

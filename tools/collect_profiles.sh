@@ -82,6 +82,13 @@ done
 ( cd $R && timeout 200 python bench.py --workload nn > $O/bench_nn.json.log 2>&1; tail -1 $O/bench_nn.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_DUST3R_QKV_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_qkv_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_qkv_unfused.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_GEMM_WREG=0 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_wreg_off.json.log 2>&1; tail -1 $O/bench_dust3r_512_wreg_off.json.log | cut -c1-160 )
+# ---- later in round 3: 16-row tiles of the fused first convolution, DPT head fusions, DUSt3R at 8 pairs per step (the round-2 operating
+# point), kernel table + SQ pass of the MASt3R workload (nn_argmax_* kernels)
+( cd $R && IMCUI_CONV_TALL=0 timeout 100 python bench.py --no-cpu-baseline --no-parity > $O/bench_splg_conv_tall_off.json.log 2>&1; tail -1 $O/bench_splg_conv_tall_off.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && IMCUI_DUST3R_HEAD_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_head_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_head_unfused.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r --batch 8 --no-cpu-baseline --no-parity > $O/bench_dust3r_512_b8.json.log 2>&1; tail -1 $O/bench_dust3r_512_b8.json.log | cut -c1-160 )
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mast3r -o mast3r -- python $R/bench.py --workload mast3r --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_mast3r.log 2>&1 < /dev/null
+[ $L = 1 ] || timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_mast3r_SQ -o mast3r -- python $R/bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_mast3r_SQ.log 2>&1 < /dev/null
 ( cd $R && timeout 100 python tools/ffn_bench.py > $O/lab_ffn_phases.txt 2>&1 )
 ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 ls $O

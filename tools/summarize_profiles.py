@@ -81,8 +81,11 @@ if os.path.exists(sqp):
     for k, v in sorted(sq.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])[:6]:
         print(f"{k[:50]:50s} mfma_busy {v['mfma_busy_frac']:.3f} wait_any {v['wait_any_frac']:.2f} wait_inst {v['wait_inst_frac']:.2f}")
 # the same SQ pass on the DUSt3R workload; its GEMM launches are grouped by grid size (= shape class: encoder / decoder, N, merged sides)
-dsq = os.path.join(F, "pmc_dust3r_SQ", "dust3r_counter_collection.csv")
-if os.path.exists(dsq):
+for wl, wl_note in (("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 16 pairs per step, 3 x f16 split arithmetic)"),
+                    ("mast3r", "bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 (512x512: network + reciprocal matching, nn_argmax_* kernels)")):
+    dsq = os.path.join(F, f"pmc_{wl}_SQ", f"{wl}_counter_collection.csv")
+    if not os.path.exists(dsq):
+        continue
     by = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(dsq)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
@@ -97,10 +100,9 @@ if os.path.exists(dsq):
         dq[k] = {"launches": len(c["SQ_BUSY_CYCLES"]), "kernel_cycles": kc, "mfma_busy_frac": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / max(kc, 1.0),
                  "valu_active_frac_of_wave_cycles": g("SQ_ACTIVE_INST_VALU") / wc, "wait_any_frac": g("SQ_WAIT_ANY") / wc,
                  "wait_inst_frac": g("SQ_WAIT_INST_ANY") / wc, "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT")}
-    json.dump({"note": "rocprofv3 --pmc SQ_* (one pass), bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 8 pairs per step, 3 x f16 split "
-                       "arithmetic); kernel_cycles = SQ_BUSY_CYCLES / 32 shader engines, mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; per-launch "
+    json.dump({"note": "rocprofv3 --pmc SQ_* (one pass), " + wl_note + "; kernel_cycles = SQ_BUSY_CYCLES / 32 shader engines, mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs; per-launch "
                        "averages; GEMM launches grouped by grid size (= shape class)", "kernels": dq},
-              open(os.path.join(P, f"{tag}_pmc_sq_dust3r.json"), "w"), indent=1)
+              open(os.path.join(P, f"{tag}_pmc_sq_{wl}.json"), "w"), indent=1)
 for opt in ("adaptive", "b1", "adaptive_b1_eager", "adaptive_b1_graph", "adaptive_b4_eager", "adaptive_b4_graph"):  # operating points beside the headline line
     if os.path.exists(os.path.join(F, f"bench_splg_{opt}.json.log")):
         shutil.copy(os.path.join(F, f"bench_splg_{opt}.json.log"), os.path.join(P, f"{tag}_bench_splg_{opt}.json.log"))
@@ -126,6 +128,10 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_splg_assign_epilogue.json.log", f"{tag}_bench_splg_assign_epilogue.json.log"), ("bench_nn.json.log", f"{tag}_bench_nn.json.log"),
                  ("bench_dust3r_512_qkv_unfused.json.log", f"{tag}_bench_dust3r_512_qkv_unfused.json.log"),
                  ("bench_dust3r_512_wreg_off.json.log", f"{tag}_bench_dust3r_512_wreg_off.json.log"),
+                 ("bench_splg_conv_tall_off.json.log", f"{tag}_bench_splg_conv_tall_off.json.log"),
+                 ("bench_dust3r_512_head_unfused.json.log", f"{tag}_bench_dust3r_512_head_unfused.json.log"),
+                 ("bench_dust3r_512_b8.json.log", f"{tag}_bench_dust3r_512_b8.json.log"),
+                 ("stats_mast3r/mast3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_mast3r_512.csv"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
