@@ -18,5 +18,7 @@ struct AttnP {
     // 1: Q (hence Q.K) was pre-multiplied by log2(e) by the producer, soft-max = exp2(s - max): the split kernel then needs no
     // multiply per probability (the layers set it; the C-ABI building block passes natural-log operands, 0)
     int log2_domain = 0;
+    // 1 (split mode + log2_domain only): one f16 product per element pair, hi planes only (DUSt3R's opt-in single-product arithmetic)
+    int single = 0;
 };
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);

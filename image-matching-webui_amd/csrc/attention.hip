@@ -242,8 +242,11 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // so every SIMD holds two waves that are in different phases most of the time; priority decides whose instruction issues when
 // both are ready (guide T5).  0: none; 1: the K.Q^T and V^T.P^T clusters at priority 1, the soft-max at 0; 2: only V^T.P^T
 // raised; 3: the soft-max raised instead.
+// VAR 4 (AttnP.single, DUSt3R's opt-in `arith = 1`): ONE f16 product per element pair -- only the hi planes of Q / K / V are loaded,
+// staged and multiplied, P is rounded to the nearest f16 (f32 accumulation and an f32 normaliser as before).  Not a parity mode.
 template <bool L2D, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
+    constexpr bool SINGLE = (VAR == 4);
     __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
     uint4* Kl = smem4 + 8 * KSTR;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             qh[s] = *reinterpret_cast<const uint4*>(qsrc + 16 * s);
-            ql[s] = *reinterpret_cast<const uint4*>(qsrc + plane + 16 * s);
+            if constexpr (!SINGLE) ql[s] = *reinterpret_cast<const uint4*>(qsrc + plane + 16 * s);
         }
     }
 
@@ -322,17 +325,19 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     auto load_tile = [&](int k0) __attribute__((always_inline)) {
         const unsigned sk = (unsigned)k0 * 128u, sv = (unsigned)k0 * 2u;
         rk0 = ld4(rKh, ko0, sk);
-        rk1 = ld4(rKl, ko0, sk);
         rk2 = ld4(rKh, ko1, sk);
-        rk3 = ld4(rKl, ko1, sk);
         rv0 = ld2(rVh, vo0, sv);
-        rv1 = ld2(rVl, vo0, sv);
         rv2 = ld2(rVh, vo1, sv);
-        rv3 = ld2(rVl, vo1, sv);
         rv4 = ld2(rVh, vo2, sv);
-        rv5 = ld2(rVl, vo2, sv);
         rv6 = ld2(rVh, vo3, sv);
-        rv7 = ld2(rVl, vo3, sv);
+        if constexpr (!SINGLE) {
+            rk1 = ld4(rKl, ko0, sk);
+            rk3 = ld4(rKl, ko1, sk);
+            rv1 = ld2(rVl, vo0, sv);
+            rv3 = ld2(rVl, vo1, sv);
+            rv5 = ld2(rVl, vo2, sv);
+            rv7 = ld2(rVl, vo3, sv);
+        }
     };
     // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
     const int v_u = ((v_kq >> 2) * 2 + (v_kq & 1)) * 2 + ((v_kq >> 1) & 1);
@@ -349,19 +354,21 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             rv4.x &= mx; rv4.y &= my; rv5.x &= mx; rv5.y &= my; rv6.x &= mx; rv6.y &= my; rv7.x &= mx; rv7.y &= my;
         }
         Kh[k_oc * KSTR + k_key] = rk0;
-        Kl[k_oc * KSTR + k_key] = rk1;
         Kh[k_oc * KSTR + k_key + 32] = rk2;
-        Kl[k_oc * KSTR + k_key + 32] = rk3;
         uint2* vh2 = reinterpret_cast<uint2*>(Vh);
         uint2* vl2 = reinterpret_cast<uint2*>(Vl);
         vh2[(v_d * VSTR) * 2 + v_u] = rv0;
-        vl2[(v_d * VSTR) * 2 + v_u] = rv1;
         vh2[((v_d + 16) * VSTR) * 2 + v_u] = rv2;
-        vl2[((v_d + 16) * VSTR) * 2 + v_u] = rv3;
         vh2[((v_d + 32) * VSTR) * 2 + v_u] = rv4;
-        vl2[((v_d + 32) * VSTR) * 2 + v_u] = rv5;
         vh2[((v_d + 48) * VSTR) * 2 + v_u] = rv6;
-        vl2[((v_d + 48) * VSTR) * 2 + v_u] = rv7;
+        if constexpr (!SINGLE) {
+            Kl[k_oc * KSTR + k_key] = rk1;
+            Kl[k_oc * KSTR + k_key + 32] = rk3;
+            vl2[(v_d * VSTR) * 2 + v_u] = rv1;
+            vl2[((v_d + 16) * VSTR) * 2 + v_u] = rv3;
+            vl2[((v_d + 32) * VSTR) * 2 + v_u] = rv5;
+            vl2[((v_d + 48) * VSTR) * 2 + v_u] = rv7;
+        }
     };
 
     // one 64-key tile: S^T = K.Q^T, online soft-max, O^T += V^T.P^T
@@ -379,10 +386,14 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const uint4 ah = Kh[(2 * st + hi) * KSTR + 32 * f + lo];
-                const uint4 al = Kl[(2 * st + hi) * KSTR + 32 * f + lo];
-                s[f] = mfma16(al, qh[st], st == 0 ? cinit : s[f]);
-                s[f] = mfma16(ah, ql[st], s[f]);
-                s[f] = mfma16(ah, qh[st], s[f]);
+                if constexpr (SINGLE) {
+                    s[f] = mfma16(ah, qh[st], st == 0 ? cinit : s[f]);
+                } else {
+                    const uint4 al = Kl[(2 * st + hi) * KSTR + 32 * f + lo];
+                    s[f] = mfma16(al, qh[st], st == 0 ? cinit : s[f]);
+                    s[f] = mfma16(ah, ql[st], s[f]);
+                    s[f] = mfma16(ah, qh[st], s[f]);
+                }
             }
         }
         if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
@@ -488,18 +499,29 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 uint4 ph, pl;
-                split2(s[f][8 * t + 0], s[f][8 * t + 1], ph.x, pl.x);
-                split2(s[f][8 * t + 2], s[f][8 * t + 3], ph.y, pl.y);
-                split2(s[f][8 * t + 4], s[f][8 * t + 5], ph.z, pl.z);
-                split2(s[f][8 * t + 6], s[f][8 * t + 7], ph.w, pl.w);
+                if constexpr (SINGLE) {
+                    ph.x = half2_rtn(s[f][8 * t + 0], s[f][8 * t + 1]);
+                    ph.y = half2_rtn(s[f][8 * t + 2], s[f][8 * t + 3]);
+                    ph.z = half2_rtn(s[f][8 * t + 4], s[f][8 * t + 5]);
+                    ph.w = half2_rtn(s[f][8 * t + 6], s[f][8 * t + 7]);
+                } else {
+                    split2(s[f][8 * t + 0], s[f][8 * t + 1], ph.x, pl.x);
+                    split2(s[f][8 * t + 2], s[f][8 * t + 3], ph.y, pl.y);
+                    split2(s[f][8 * t + 4], s[f][8 * t + 5], ph.z, pl.z);
+                    split2(s[f][8 * t + 6], s[f][8 * t + 7], ph.w, pl.w);
+                }
 #pragma unroll
                 for (int df = 0; df < 2; ++df) {
                     const int vi = (32 * df + lo) * VSTR + (2 * f + t) * 2 + hi;
                     const uint4 vh = Vh[vi];
-                    const uint4 vl = Vl[vi];
-                    o[df] = mfma16(vl, ph, o[df]);
-                    o[df] = mfma16(vh, pl, o[df]);
-                    o[df] = mfma16(vh, ph, o[df]);
+                    if constexpr (SINGLE) {
+                        o[df] = mfma16(vh, ph, o[df]);
+                    } else {
+                        const uint4 vl = Vl[vi];
+                        o[df] = mfma16(vl, ph, o[df]);
+                        o[df] = mfma16(vh, pl, o[df]);
+                        o[df] = mfma16(vh, ph, o[df]);
+                    }
                 }
             }
         if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(0);
@@ -565,7 +587,9 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (h->precision == 1 && p.log2_domain) {
         const char* ve = getenv("IMCUI_ATTN_VARIANT");
         const int var = ve ? atoi(ve) : 0;
-        if (var == 1)
+        if (p.single)
+            hipLaunchKernelGGL((attn_split_kernel<true, 4>), grid, dim3(256), 0, stream, p);
+        else if (var == 1)
             hipLaunchKernelGGL((attn_split_kernel<true, 1>), grid, dim3(256), 0, stream, p);
         else if (var == 2)
             hipLaunchKernelGGL((attn_split_kernel<true, 2>), grid, dim3(256), 0, stream, p);

@@ -9,6 +9,17 @@
 int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float* bias, float* out, int B, int H, int W,
                    int Cin, int Cout, int relu, int pool, hipStream_t stream);
 
+// DPT head fused into the epilogue of its last 3x3 convolution (128 channels, ReLU): 1x1 convolution to 4 channels (w [4][128], b [4])
+// + point-map post-processing -> pts [B*H*W][3] = xyz / |xyz| * expm1(|xyz|), conf [B*H*W] = 1 + exp(c), raw [B*H*W][4] optional.
+// With a head the 128-channel map is written only if `out` is not null.
+struct ConvHead {
+    const float* w = nullptr;
+    const float* b = nullptr;
+    float* pts = nullptr;
+    float* conf = nullptr;
+    float* raw = nullptr;
+};
+
 // split-precision variant (imcui_hip_s::precision == 1): weights pre-split into f16 hi / lo planes
 //   wh/wl : [Cin/32][9 taps][4 octets][Cout][8 halves] of w * 2^e ; wscale -> 2^-e (device scalar)
 //   relu  : activation code 0 none / 1 ReLU / 2 LeakyReLU(0.01);  resid (optional, no pooling): a map of the output's shape
@@ -16,7 +27,7 @@ int conv3x3_launch(imcui_hip_s* h, const float* in, const float* wp, const float
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
                          int relu, int pool, hipStream_t stream, const float* resid = nullptr, int cin_stride = 0, int cout_live = 0,
-                         int single = 0, const float* resid2 = nullptr);
+                         int single = 0, const float* resid2 = nullptr, const ConvHead* head = nullptr);
 // relu bit 2 (value 4): ReLU applied to the INPUT map while it is staged (the producer left it un-activated);  resid2: a second map
 // added after resid (out = act(conv + resid + resid2))
 // cin_stride: floats between two pixels of `in` when the map stores more channels than the Cin that are used (0 = Cin)

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cin, int Cout, int tiles_x, int tiles_y,
                                                             int relu, int pool, const float* __restrict__ w1a,
-                                                            const float* __restrict__ b1a, int cin_stride, int cout_live) {
+                                                            const float* __restrict__ b1a, int cin_stride, int cout_live, ConvHead hd) {
     constexpr int WSN = NC * 32 + 1;  // padded cout stride of the weight slab (16-byte units)
     static_assert(NC == 2 || (NC == 4 && !FUSE1A), "the fused first layer has 64 output channels");
     __shared__ uint4 smem[2 * 4 * SPSTR + 2 * 2 * 4 * WSN + (FUSE1A ? (ITH * ITW + 9 * 64 + 64 + 3) / 4 + 1 : 0)];
@@ -460,11 +460,55 @@ __global__ __launch_bounds__(256, NC == 4 ? 2 : 3) void conv3x3_split_kernel(con
                         }
                 }
                 __syncthreads();
+                if constexpr (NC == 4 && !FUSE1A) {
+                    if (hd.w != nullptr) {
+                        // DPT head: the 1x1 convolution to 4 channels + the point-map post-processing on the parked (activated) tile --
+                        // a thread's 4 channels x 4 outputs, summed over the 16 threads of a pixel, over the two 64-channel halves in
+                        // LDS; the 128-channel map itself is only written when the caller passes `out` (parity dumps)
+                        const int c4 = tid & 15;
+                        float4 hw[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) hw[c] = *reinterpret_cast<const float4*>(hd.w + c * 128 + 64 * half + 4 * c4);
+                        float* psum = st + 128 * SROW;  // [2 h2][128 px][4]
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int px = (tid >> 4) + 16 * it;
+                            const float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
+                            float d[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                d[c] = (v.x * hw[c].x + v.y * hw[c].y) + (v.z * hw[c].z + v.w * hw[c].w);
+#pragma unroll
+                                for (int o = 8; o > 0; o >>= 1) d[c] += __shfl_xor(d[c], o, 64);
+                            }
+                            if (c4 == 0) {
+                                float4* ps = reinterpret_cast<float4*>(psum + (h2 * 128 + px) * 4);
+                                if (half == 0) {
+                                    *ps = make_float4(d[0], d[1], d[2], d[3]);
+                                } else {
+                                    const float4 q = *ps;
+                                    const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
+                                    if (oy < H && ox < W) {
+                                        const float x = (q.x + d[0]) + hd.b[0], y = (q.y + d[1]) + hd.b[1], z = (q.z + d[2]) + hd.b[2], cf = (q.w + d[3]) + hd.b[3];
+                                        const size_t p = ((size_t)b * H + oy) * W + ox;
+                                        if (hd.raw) *reinterpret_cast<float4*>(hd.raw + p * 4) = make_float4(x, y, z, cf);
+                                        const float dn = sqrtf(x * x + y * y + z * z);
+                                        const float sc = expm1f(dn) / fmaxf(dn, 1e-8f);
+                                        hd.pts[p * 3 + 0] = x * sc;
+                                        hd.pts[p * 3 + 1] = y * sc;
+                                        hd.pts[p * 3 + 2] = z * sc;
+                                        hd.conf[p] = 1.0f + expf(cf);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {  // 128 pixels x 16 channel quads
                     const int px = (tid >> 4) + 16 * it, c4 = tid & 15;
                     const int oy = y0 + 4 * h2 + (px >> 5), ox = x0 + (px & 31);
-                    if (oy < H && ox < W) {
+                    if (oy < H && ox < W && out != nullptr) {
                         float4 v = *reinterpret_cast<const float4*>(st + px * SROW + 4 * c4);
                         const size_t o = (((size_t)b * H + oy) * W + ox) * Cout + coutH + 4 * c4;
                         if (late) {  // residual connection: added before the activation (BasicBlock: relu(conv + identity))
@@ -783,12 +827,17 @@ static int conv_tall_mode() {
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
-                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single, const float* resid2) {
+                         int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single, const float* resid2,
+                         const ConvHead* head) {
     if (cin_stride <= 0) cin_stride = Cin;
     if (cout_live <= 0 || cout_live > Cout) cout_live = Cout;
     if (cin_stride < Cin || cin_stride % 4 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pixel stride %d for %d input channels", cin_stride, Cin);
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (resid2 && !resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: a second residual map needs the first");
+    if (head && (Cout != 128 || pool || resid || (relu & 3) != 1 || cout_live != Cout || !head->w || !head->b || !head->pts || !head->conf ||
+                 getenv("IMCUI_CONV_NARROW") != nullptr))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: the fused point-map head needs a 128-channel ReLU layer without pooling / residual");
+    if (!head && !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: null output");
     if (Cin % 32 != 0 || Cout % 64 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
@@ -819,16 +868,16 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     imcui_prof_begin(h, PROF_CONV, stream);
     if (wide && single)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live, head ? *head : ConvHead{});
     else if (single)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2, true>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live, head ? *head : ConvHead{});
     else if (wide)
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live, head ? *head : ConvHead{});
     else
         hipLaunchKernelGGL((conv3x3_split_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, in, wh, wl, wscale, bias, out, H, W, Cin, Cout,
-                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live);
+                           tiles_x, tiles_y, relu, pool, resid, resid2, cin_stride, cout_live, head ? *head : ConvHead{});
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
@@ -848,7 +897,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
                            tiles_y, 1, pool, w1a, b1a, 64);
     else
         hipLaunchKernelGGL((conv3x3_split_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, stream, image, wh, wl, wscale, bias, out, H,
-                           W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64, 64);
+                           W, 64, 64, tiles_x, tiles_y, 1, pool, w1a, b1a, 64, 64, ConvHead{});
     imcui_prof_end(h, PROF_CONV, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

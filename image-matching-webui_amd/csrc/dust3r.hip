@@ -354,7 +354,7 @@ struct DuGeom {
 static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, const float* images, int NI, const DuGeom& geo, const int* pairs, int P,
                            int arith, float* pts3d, float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws,
                            size_t ws_bytes, hipStream_t stream) {
-    const int single = arith;  // GEMMs and 3x3 convolutions with ONE f16 product per element pair; attention stays in the split arithmetic
+    const int single = arith;  // GEMMs, 3x3 convolutions and attention with ONE f16 product per element pair
     if (((size_t)(c.E / 64) * NI) % 8 != 0 || ((size_t)(c.D / 64) * 2 * P) % 8 != 0)
         return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: heads x sequences must be a multiple of 8 (encoder %d x %d, decoder %d x %d)", c.E / 64, NI, c.D / 64, 2 * P);
     DuWs w = du_carve(ws, ws_bytes, c, NI, P, geo.Tmax);
@@ -560,6 +560,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         a.rows_per_seq = R;
         a.cross = cross;
         a.log2_domain = 1;
+        a.single = single;
         return attention_launch(h, a, stream);
     };
 
@@ -877,14 +878,30 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
             const long n4 = (long)Pn * Hh * Wh * 32;
             hipLaunchKernelGGL(du_upsample2_kernel, blocks(n4), blk, 0, stream, w.hd0, w.hd1, Hh / 2, Wh / 2, 32, n4);
         }
-        DURUN(conv3(L0 + 32, w.hd1, w.hd2, Hh, Wh, 1, nullptr));
         const long npix = (long)Pn * Hh * Wh, mpix = (long)Hh * Wh;
-        if (!mixed) {
+        // one size: head.4 (1x1, 128 -> 4) and the point-map post-processing run in the epilogue of head.2's convolution; the 128-channel
+        // full-resolution map is only written for the parity dump.  IMCUI_DUST3R_REGRESS_UNFUSED=1 keeps du_regress_kernel (A/B).
+        static const bool regress_unfused = getenv("IMCUI_DUST3R_REGRESS_UNFUSED") != nullptr;
+        if (!mixed && !regress_unfused) {
+            ConvHead hd;
+            hd.w = V(du_v_head(c, v));
+            hd.b = V(du_v_head(c, v) + 1);
+            hd.pts = pts3d + (size_t)v * npix * 3;
+            hd.conf = conf + (size_t)v * npix;
+            float* feat = dump_take((size_t)npix * 128);  // straight into the dump buffer
+            hd.raw = dump_take((size_t)npix * 4);
+            int N, K, kind;
+            du_shape(c, L0 + 32, &N, &K, &kind);
+            DURUN(conv3x3_split_launch(h, w.hd1, reinterpret_cast<const unsigned short*>(Pk + l.wh[L0 + 32]), reinterpret_cast<const unsigned short*>(Pk + l.wl[L0 + 32]),
+                                       Pk + l.ws[L0 + 32], Pk + l.b[L0 + 32], feat, Pn, Hh, Wh, K / 9, N, 1, 0, stream, nullptr, 0, 0, single, nullptr, &hd));
+        } else if (!mixed) {
+            DURUN(conv3(L0 + 32, w.hd1, w.hd2, Hh, Wh, 1, nullptr));
             dump_copy(w.hd2, (size_t)npix * 128);
             float* raw = dump_take((size_t)npix * 4);
             hipLaunchKernelGGL(du_regress_kernel, blocks(npix * 32), blk, 0, stream, w.hd2, V(du_v_head(c, v)), V(du_v_head(c, v) + 1),
                                pts3d + (size_t)v * npix * 3, conf + (size_t)v * npix, raw, npix);
         } else {
+            DURUN(conv3(L0 + 32, w.hd1, w.hd2, Hh, Wh, 1, nullptr));
             for (int j = 0; j < Pn; ++j) {
                 const size_t o = geo.map_pix[streams[j]];
                 hipLaunchKernelGGL(du_regress_kernel, blocks(mpix * 32), blk, 0, stream, w.hd2 + (size_t)j * mpix * 128, V(du_v_head(c, v)),

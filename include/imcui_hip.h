@@ -293,7 +293,7 @@ size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int
  * 16, `desc / |desc|`) and desc_conf [dev, 2,P,H,W] = exp(.) (mast3r.py:61-64 reads `pred1["desc"]`, `pred2["desc"]`); NULL otherwise.
  * dump (may be NULL; parity tests): imcui_hip_dust3r_dump_floats() floats of intermediate token states and head maps.
  * arith: 0 = 3 x f16 split products (fp32-grade results, the parity mode), 1 = one f16 product per element pair in the GEMMs and
- * convolutions with f32 accumulation (the class of the bf16 run the reference's configuration names; attention stays split).
+ * convolutions with f32 accumulation (the class of the bf16 run the reference's configuration names; since round 3 attention too: hi planes of Q / K / V, P rounded to f16).
  * The handle must be in the split mode (IMCUI_ERR_UNSUPPORTED in precision 0). */
 int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
                              const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d, float* conf,
