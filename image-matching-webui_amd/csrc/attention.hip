@@ -247,7 +247,11 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 template <bool L2D, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     constexpr bool SINGLE = (VAR == 4);
-    __shared__ uint4 smem4[2 * 8 * KSTR + 2 * 64 * VSTR];
+    // VAR 5: the K / V^T tile double-buffered in LDS (70 KB per workgroup, still two per CU): the next tile is written into the other
+    // buffer right after this tile's MFMAs, ONE workgroup barrier per key tile instead of two
+    constexpr bool DBUF = (VAR == 5);
+    constexpr int TILE_U4 = 2 * 8 * KSTR + 2 * 64 * VSTR;
+    __shared__ uint4 smem4[(DBUF ? 2 : 1) * TILE_U4];
     uint4* Kh = smem4;  // [d-octet][key] 8 halves
     uint4* Kl = smem4 + 8 * KSTR;
     uint4* Vh = smem4 + 2 * 8 * KSTR;  // [d][VSTR]
@@ -341,7 +345,11 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     };
     // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
     const int v_u = ((v_kq >> 2) * 2 + (v_kq & 1)) * 2 + ((v_kq >> 1) & 1);
-    auto store_tile = [&](int k0, auto tail) __attribute__((always_inline)) {
+    auto store_tile = [&](int k0, auto tail, int buf = 0) __attribute__((always_inline)) {
+        uint4* Kh = smem4 + buf * TILE_U4;
+        uint4* Kl = Kh + 8 * KSTR;
+        uint4* Vh = Kh + 2 * 8 * KSTR;
+        uint4* Vl = Vh + 64 * VSTR;
         if (decltype(tail)::value) {
             // keys past the sequence end may hold anything (even NaN bit patterns): zero them
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
@@ -374,8 +382,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     // one 64-key tile: S^T = K.Q^T, online soft-max, O^T += V^T.P^T
     //   FIRST: no reference maximum yet (accumulators start from 0, the tile's own maximum becomes the reference)
     //   TAIL : the tile may hold keys past the sequence end
-    auto compute_tile = [&](int k0, auto first, auto tail) __attribute__((always_inline)) {
+    auto compute_tile = [&](int k0, auto first, auto tail, int buf = 0) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value, TAIL = decltype(tail)::value;
+        const uint4* Kh = smem4 + buf * TILE_U4;
+        const uint4* Kl = Kh + 8 * KSTR;
+        const uint4* Vh = Kh + 2 * 8 * KSTR;
+        const uint4* Vl = Vh + 64 * VSTR;
         // with a reference the accumulation starts from cinit = 14 - m_ref (the C operand of the first MFMA of both
         // fragments; kept in registers across tiles, rewritten only when the reference moves): the MFMAs deliver the
         // exponent directly
@@ -528,6 +540,36 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     };
 
     const int ntile = (nk + KT - 1) / KT;
+    if constexpr (DBUF) {
+        if (ntile > 0) {
+            load_tile(0);
+            if (ntile == 1)
+                store_tile(0, std::true_type{}, 0);
+            else
+                store_tile(0, std::false_type{}, 0);
+            __syncthreads();
+            if (ntile == 1) {
+                compute_tile(0, std::true_type{}, std::true_type{}, 0);
+            } else {
+                load_tile(KT);
+                compute_tile(0, std::true_type{}, std::false_type{}, 0);
+                for (int tile = 1;; ++tile) {
+                    // buffer tile & 1 was last read two tiles ago: every wave finished that before the previous barrier
+                    if (tile == ntile - 1)
+                        store_tile(tile * KT, std::true_type{}, tile & 1);
+                    else
+                        store_tile(tile * KT, std::false_type{}, tile & 1);
+                    __syncthreads();
+                    if (tile == ntile - 1) {
+                        compute_tile(tile * KT, std::false_type{}, std::true_type{}, tile & 1);
+                        break;
+                    }
+                    load_tile((tile + 1) * KT);
+                    compute_tile(tile * KT, std::false_type{}, std::false_type{}, tile & 1);
+                }
+            }
+        }
+    } else {
     if (ntile > 0) load_tile(0);
     if (ntile > 1) {  // first tile sets the reference maximum
         __syncthreads();
@@ -551,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             compute_tile(0, std::true_type{}, std::true_type{});
         else
             compute_tile((ntile - 1) * KT, std::false_type{}, std::true_type{});
+    }
     }
 
     // ---- normalise and write (transpose through LDS so each query row is stored contiguously)
@@ -589,6 +632,8 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
         const int var = ve ? atoi(ve) : 0;
         if (p.single)
             hipLaunchKernelGGL((attn_split_kernel<true, 4>), grid, dim3(256), 0, stream, p);
+        else if (var == 5)
+            hipLaunchKernelGGL((attn_split_kernel<true, 5>), grid, dim3(256), 0, stream, p);
         else if (var == 1)
             hipLaunchKernelGGL((attn_split_kernel<true, 1>), grid, dim3(256), 0, stream, p);
         else if (var == 2)
