@@ -159,6 +159,17 @@ def test_pack_dust3r_layout_matches_the_library():
     assert lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 24) == lib.imcui_hip_dust3r_num_layers(128, 1, 64, 4, 0) + 4
     assert lib.imcui_hip_dust3r_num_layers(100, 1, 64, 4, 0) == 0  # widths must be multiples of 64
     assert lib.imcui_hip_dust3r_workspace_bytes(128, 1, 64, 4, 0, 2, 2, 100, 128) == 0  # sizes must be multiples of 16
+    # images of several sizes: the workspace is the one of the largest token grid, the token dump holds R rows per sequence
+    import ctypes as C
+
+    c5 = (128, 1, 64, 4, 0)
+    same = (C.c_int * 4)(96, 128, 96, 128)
+    assert lib.imcui_hip_dust3r_workspace_bytes_sizes(*c5, 2, same, 2) == lib.imcui_hip_dust3r_workspace_bytes(*c5, 2, 2, 96, 128)
+    mixed = (C.c_int * 4)(96, 128, 256, 64)  # 48 and 64 tokens -> the 256 x 64 image sizes everything
+    assert lib.imcui_hip_dust3r_workspace_bytes_sizes(*c5, 2, mixed, 2) == lib.imcui_hip_dust3r_workspace_bytes(*c5, 2, 2, 256, 64)
+    R = 128  # 64 tokens rounded up to the attention tile
+    assert lib.imcui_hip_dust3r_token_dump_floats(*c5, 2, mixed, 2) == (1 + 2) * 2 * R * 128 + (4 + 2) * 4 * R * 64
+    assert lib.imcui_hip_dust3r_workspace_bytes_sizes(*c5, 2, (C.c_int * 4)(96, 128, 100, 64), 2) == 0  # every size a multiple of 16
 
 
 def test_mast3r_local_features_are_a_pixel_shuffle_of_the_token_mlp():

@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 # counter passes only (after a change that leaves the other operating points, A/B legs and counters as they were)
 if [ "${QUICK:-0}" = 1 ]; then
   ( cd $R && timeout 300 python bench.py > $O/bench_splg.json.log 2>&1; tail -1 $O/bench_splg.json.log | cut -c1-160 )
+  ( cd $R && timeout 300 python bench.py --h2d --no-cpu-baseline > $O/bench_splg_h2d.json.log 2>&1; tail -1 $O/bench_splg_h2d.json.log | cut -c1-160 )
   ( cd $R && timeout 200 python bench.py --workload loftr > $O/bench_loftr_1024.json.log 2>&1; tail -1 $O/bench_loftr_1024.json.log | cut -c1-160 )
   ( cd $R && timeout 200 python bench.py --workload loftr --size 480 640 --no-cpu-baseline > $O/bench_loftr_640x480.json.log 2>&1; tail -1 $O/bench_loftr_640x480.json.log | cut -c1-160 )
   ( cd $R && timeout 200 python bench.py --workload eloftr > $O/bench_eloftr_640x480.json.log 2>&1; tail -1 $O/bench_eloftr_640x480.json.log | cut -c1-160 )
@@ -23,6 +24,8 @@ if [ "${QUICK:-0}" = 1 ]; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loftr -o loftr -- python $R/bench.py --workload loftr --steps 5 --warmup 2 --no-cpu-baseline --no-parity > $O/rocprof_loftr.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eloftr -o eloftr -- python $R/bench.py --workload eloftr --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_eloftr.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dust3r -o dust3r -- python $R/bench.py --workload dust3r --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_dust3r.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mast3r -o mast3r -- python $R/bench.py --workload mast3r --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rocprof_mast3r.log 2>&1 < /dev/null
+  ( cd $R && IMCUI_DUST3R_REGRESS_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_regress_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_regress_unfused.json.log | cut -c1-160 )
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dust3r_$c -o dust3r -- python $R/bench.py --workload dust3r --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/pmc_dust3r_$c.log 2>&1
     echo pmc dust3r $c rc $?
@@ -84,6 +87,8 @@ done
 [ $L = 1 ] || ( cd $R && IMCUI_GEMM_WREG=0 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_wreg_off.json.log 2>&1; tail -1 $O/bench_dust3r_512_wreg_off.json.log | cut -c1-160 )
 # ---- later in round 3: 16-row tiles of the fused first convolution, DPT head fusions, DUSt3R at 8 pairs per step (the round-2 operating
 # point), kernel table + SQ pass of the MASt3R workload (nn_argmax_* kernels)
+( cd $R && timeout 300 python bench.py --h2d --no-cpu-baseline > $O/bench_splg_h2d.json.log 2>&1; tail -1 $O/bench_splg_h2d.json.log | cut -c1-160 )
+[ $L = 1 ] || ( cd $R && IMCUI_DUST3R_REGRESS_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_regress_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_regress_unfused.json.log | cut -c1-160 )
 ( cd $R && IMCUI_CONV_TALL=0 timeout 100 python bench.py --no-cpu-baseline --no-parity > $O/bench_splg_conv_tall_off.json.log 2>&1; tail -1 $O/bench_splg_conv_tall_off.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && IMCUI_DUST3R_HEAD_UNFUSED=1 timeout 300 python bench.py --workload dust3r --no-cpu-baseline --no-parity > $O/bench_dust3r_512_head_unfused.json.log 2>&1; tail -1 $O/bench_dust3r_512_head_unfused.json.log | cut -c1-160 )
 [ $L = 1 ] || ( cd $R && timeout 300 python bench.py --workload dust3r --batch 8 --no-cpu-baseline --no-parity > $O/bench_dust3r_512_b8.json.log 2>&1; tail -1 $O/bench_dust3r_512_b8.json.log | cut -c1-160 )

@@ -129,6 +129,8 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_dust3r_512_qkv_unfused.json.log", f"{tag}_bench_dust3r_512_qkv_unfused.json.log"),
                  ("bench_dust3r_512_wreg_off.json.log", f"{tag}_bench_dust3r_512_wreg_off.json.log"),
                  ("bench_splg_conv_tall_off.json.log", f"{tag}_bench_splg_conv_tall_off.json.log"),
+                 ("bench_splg_h2d.json.log", f"{tag}_bench_splg_h2d.json.log"),
+                 ("bench_dust3r_512_regress_unfused.json.log", f"{tag}_bench_dust3r_512_regress_unfused.json.log"),
                  ("bench_dust3r_512_head_unfused.json.log", f"{tag}_bench_dust3r_512_head_unfused.json.log"),
                  ("bench_dust3r_512_b8.json.log", f"{tag}_bench_dust3r_512_b8.json.log"),
                  ("stats_mast3r/mast3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_mast3r_512.csv"),
