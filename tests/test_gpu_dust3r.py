@@ -463,3 +463,28 @@ def test_mast3r_two_sizes_vs_oracle():
         keep = np.round(np.linspace(0, len(k0) - 1, 300)).astype(int)
         k0, k1 = k0[keep], k1[keep]
     assert torch.equal(pred["keypoints0"], k0) and torch.equal(pred["keypoints1"], k1)
+
+
+def test_dust3r_full_model_two_sizes():
+    """The shipped architecture (ViT-L / ViT-B / DPT, 578 M parameters) on the pair the reference's drivers produce for a landscape
+    and a portrait photo (resize_max 512, dfactor 16): 512 x 384 and 384 x 512 pixels -- 768 tokens each on 32 x 24 and 24 x 32
+    grids, so the rotary tables, the grid widths and the head sizes differ per sequence while the token counts agree."""
+    from imcui_hip.synth_weights import DUST3R_CFG
+
+    torch.set_num_threads(16)
+    cfg = dict(DUST3R_CFG)
+    sd, model = _model(cfg)
+    i0, _ = _images(384, 512, 51)
+    _, i1 = _images(512, 384, 52)
+    out = model.forward_pairs_sizes([i0.cuda(), i1.cuda()], [[1, 0], [0, 1]])
+    ref = DUSt3ROracle(sd, cfg).inference_symmetrized(i0, i1)
+    scale = torch.cat([m.reshape(-1, 3) for m in ref["pred1"]["pts3d"]]).norm(dim=-1).mean().item()
+    for v, (pk, pred) in enumerate((("pts3d", ref["pred1"]), ("pts3d_in_other_view", ref["pred2"]))):
+        for p in range(2):
+            want = pred[pk][p]
+            got = out["pts3d"][v][p].cpu()
+            assert got.shape == want.shape
+            err = (got - want).abs().max().item()
+            assert err < 5e-4 * max(scale, want.abs().max().item()), (v, p, err, scale)
+            rel = ((out["conf"][v][p].cpu() - pred["conf"][p]).abs() / pred["conf"][p]).max().item()
+            assert rel < 5e-4, (v, p, rel)
