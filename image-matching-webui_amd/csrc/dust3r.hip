@@ -492,6 +492,11 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
     auto layernorm = [&](const float* x, int vi, float* out, long rows, int C) {
         hipLaunchKernelGGL(du_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, x, V(vi), V(vi + 1), out, rows, C, 1e-6f);
     };
+    // (x - mean) * rstd: the LayerNorms in front of the q / k / v and fc1 layers, whose gamma / beta are folded into those layers at pack time
+    auto normalise = [&](const float* x, float* out, long rows, int C) {
+        hipLaunchKernelGGL(du_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, x, (const float*)nullptr, (const float*)nullptr, out,
+                           rows, C, 1e-6f);
+    };
     const float q_alpha = 0.125f * 1.44269504088896340736f;  // 1 / sqrt(64) and log2(e): the attention kernel works in base 2
     // q / k planes of `nseq` sequences read from src[:, col0 : col0 + C]
     auto rope_split = [&](const float* src, long ld, int col0, int C, int nseq, float* planes, int nseq_planes, int seq_out0, float alpha) {
@@ -661,7 +666,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         dump_copy(w.x, (size_t)me * E);
     }
     for (int i = 0; i < c.enc_depth; ++i) {
-        layernorm(w.x, du_v_enc(c, i, 0), w.xn, me, E);
+        normalise(w.x, w.xn, me, E);  // norm1 (affine part inside attn.qkv)
         bool fused;
         DURUN(proj_planes(du_l_enc(c, i, 0), -1, false, w.xn, E, NI, 0, 3, w.qp, w.kp, w.vp, &fused));
         if (!fused) {
@@ -673,7 +678,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, NI, E, 0));
         DURUN(lin(du_l_enc(c, i, 1), w.att, w.x, NI, w.x, 0));
-        layernorm(w.x, du_v_enc(c, i, 2), w.xn, me, E);
+        normalise(w.x, w.xn, me, E);  // norm2 (inside mlp.fc1)
         DURUN(lin(du_l_enc(c, i, 2), w.xn, w.hid, NI, nullptr, 3));
         DURUN(lin(du_l_enc(c, i, 3), w.hid, w.x, NI, w.x, 0));
         dump_copy(w.x, (size_t)me * E);
@@ -711,8 +716,10 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
     auto save_hook = [&](const float* src, int k) { gather_dense(src, nullptr, hmap_dev, w.hook[k], D); };
     for (int i = 0; i < c.dec_depth; ++i) {
         // keys / values of the cross attention: side s reads the other side's tokens as they are BEFORE this block, normalised by
-        // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o
-        for (int o = 0; o < 2; ++o) layernorm(w.y + (size_t)o * ms * D, du_v_dec(c, 1 - o, i, 4), w.xn + (size_t)o * ms * D, ms, D);
+        // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o.  With the
+        // affine parts folded into the projections, norm_y (cross keys / values) and norm1 (self attention) are ONE normalisation
+        // of the block's input, for both sides at once
+        normalise(w.y, w.xn, md, D);
         bool fused;
         DURUN(proj_planes(du_l_dec(c, 0, i, 3), merged ? du_l_dec(c, 1, i, 3) : -2, true, w.xn, D, 2 * P, 1, 2, nullptr, w.kc, w.vc, &fused));
         if (!fused) {
@@ -720,8 +727,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
             rope_split(w.qkv, 2 * D, 0, D, 2 * P, w.kc, 2 * P, 0, 1.0f);
             vt_split(w.qkv, 2 * D, D, D, 2 * P, w.vc, 2 * P, 0);
         }
-        // self attention
-        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 0), w.xn + (size_t)s * ms * D, ms, D);
+        // self attention (w.xn still holds the normalised input of the block)
         DURUN(proj_planes(du_l_dec(c, 0, i, 0), merged ? du_l_dec(c, 1, i, 0) : -2, false, w.xn, D, 2 * P, 0, 3, w.qp, w.kp, w.vp, &fused));
         if (!fused) {
             DURUN(lin2(i, 0, w.xn, D, w.qkv, 3 * D, nullptr, 0, false));
@@ -733,7 +739,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         DURUN(attend(w.qp, w.kp, w.vp, w.att, 2 * P, D, 0));
         DURUN(lin2(i, 1, w.att, D, w.y, D, w.y, 0, false));
         // cross attention
-        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 2), w.xn + (size_t)s * ms * D, ms, D);
+        normalise(w.y, w.xn, md, D);  // norm2 (inside cross_attn.projq)
         DURUN(proj_planes(du_l_dec(c, 0, i, 2), merged ? du_l_dec(c, 1, i, 2) : -2, false, w.xn, D, 2 * P, 0, 1, w.qp, nullptr, nullptr, &fused));
         if (!fused) {
             DURUN(lin2(i, 2, w.xn, D, w.qc, D, nullptr, 0, false));
@@ -743,7 +749,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         DURUN(attend(w.qp, w.kc, w.vc, w.att, 2 * P, D, 2));
         DURUN(lin2(i, 4, w.att, D, w.y, D, w.y, 0, false));
         // MLP
-        for (int s = 0; s < 2; ++s) layernorm(w.y + (size_t)s * ms * D, du_v_dec(c, s, i, 6), w.xn + (size_t)s * ms * D, ms, D);
+        normalise(w.y, w.xn, md, D);  // norm3 (inside mlp.fc1)
         DURUN(lin2(i, 5, w.xn, D, w.hid, 4 * D, nullptr, 3, false));
         DURUN(lin2(i, 6, w.hid, 4 * D, w.y, D, w.y, 0, false));
         dump_copy(w.y, (size_t)md * D);

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void du_patchify_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ LayerNorm over C <= 1024 channels (C % 4 == 0), one wave per row
-// two-pass moments (mean, then the centred sum of squares), eps inside the square root: torch.nn.LayerNorm
+// two-pass moments (mean, then the centred sum of squares), eps inside the square root: torch.nn.LayerNorm.  gamma == nullptr: the
+// normalisation alone, (x - mean) * rstd -- the affine part of a LayerNorm that only feeds a linear layer is folded into that layer
+// at pack time (backend.py: dust3r_matrices)
 __global__ __launch_bounds__(256) void du_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ out, long M, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -63,6 +65,11 @@ __global__ __launch_bounds__(256) void du_layernorm_kernel(const float* __restri
     for (int k = 0; k < 4; ++k) {
         const int c = lane * 4 + 256 * k;
         if (c < C) {
+            if (gamma == nullptr) {
+                *reinterpret_cast<float4*>(out + row * C + c) =
+                    make_float4((v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd, (v[k].w - mean) * rstd);
+                continue;
+            }
             const float4 g = *reinterpret_cast<const float4*>(gamma + c);
             const float4 b = *reinterpret_cast<const float4*>(beta + c);
             *reinterpret_cast<float4*>(out + row * C + c) = make_float4((v[k].x - mean) * rstd * g.x + b.x, (v[k].y - mean) * rstd * g.y + b.y,

@@ -635,16 +635,35 @@ def dust3r_cfg_of(state_dict: dict) -> dict:
     }
 
 
+def _fold_layernorm(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor):
+    """(W, b) of a linear layer that reads LayerNorm(x; gamma, beta) -> (W * gamma, b + W beta): the layer then reads the plain
+    normalisation of x.  float64 for the bias sum, one f32 rounding per weight."""
+    w64 = w.double()
+    b64 = (b.double() if b is not None else torch.zeros(w.shape[0], dtype=torch.float64)) + w64 @ beta.double()
+    return (w64 * gamma.double()[None, :]).float(), b64.float()
+
+
 def dust3r_matrices(state_dict: dict):
     """The matrices [N, K], biases and f32 vectors of a DUSt3R / MASt3R state dict in the order of the C layer table (what
-    `pack_dust3r` hands to imcui_hip_dust3r_pack_weights) -> (cfg, matrices, biases, vectors)."""
+    `pack_dust3r` hands to imcui_hip_dust3r_pack_weights) -> (cfg, matrices, biases, vectors).
+
+    The affine part of every LayerNorm whose ONLY consumer is a linear layer is folded into that layer (round 3):
+    `LN(x) W^T + b = xhat (W * gamma)^T + (b + W beta)` with `xhat = (x - mean) / sqrt(var + eps)`, so the device normalises without
+    gamma / beta -- one pass serves `norm1` and the other side's `norm_y` of a decoder block (same input, different affine parts) and
+    both decoder sides at once.  Folded: encoder norm1 -> attn.qkv, norm2 -> mlp.fc1; decoder norm1 -> attn.qkv, norm2 ->
+    cross_attn.projq, norm_y -> cross_attn.projk / projv, norm3 -> mlp.fc1.  enc_norm and dec_norm feed the DPT heads as they are and stay
+    LayerNorms.  The folded vectors are still handed over (layout unchanged); the device ignores them."""
     sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if isinstance(v, torch.Tensor)}
     cfg = dust3r_cfg_of(sd)
     ws, bs, vecs = [], [], []
 
-    def lin(name):
-        ws.append(sd[name + ".weight"].reshape(sd[name + ".weight"].shape[0], -1).contiguous())
-        bs.append(sd.get(name + ".bias"))
+    def lin(name, ln=None):
+        w = sd[name + ".weight"].reshape(sd[name + ".weight"].shape[0], -1)
+        b = sd.get(name + ".bias")
+        if ln is not None:
+            w, b = _fold_layernorm(w, b, sd[ln + ".weight"], sd[ln + ".bias"])
+        ws.append(w.contiguous())
+        bs.append(b)
 
     def conv(name):  # OIHW -> [Cout][tap][Cin]
         w = sd[name + ".weight"]
@@ -663,8 +682,10 @@ def dust3r_matrices(state_dict: dict):
     lin("patch_embed.proj")
     for i in range(cfg["enc_depth"]):
         p = f"enc_blocks.{i}."
-        for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
-            lin(p + n)
+        lin(p + "attn.qkv", p + "norm1")
+        lin(p + "attn.proj")
+        lin(p + "mlp.fc1", p + "norm2")
+        lin(p + "mlp.fc2")
         norm(p + "norm1")
         norm(p + "norm2")
     norm("enc_norm")
@@ -672,13 +693,17 @@ def dust3r_matrices(state_dict: dict):
     for blocks in ("dec_blocks", "dec_blocks2"):
         for i in range(cfg["dec_depth"]):
             p = f"{blocks}.{i}."
-            lin(p + "attn.qkv")
+            lin(p + "attn.qkv", p + "norm1")
             lin(p + "attn.proj")
-            lin(p + "cross_attn.projq")
-            ws.append(torch.cat((sd[p + "cross_attn.projk.weight"], sd[p + "cross_attn.projv.weight"]), 0).contiguous())
-            bs.append(torch.cat((sd[p + "cross_attn.projk.bias"], sd[p + "cross_attn.projv.bias"]), 0).contiguous())
+            lin(p + "cross_attn.projq", p + "norm2")
+            # keys / values are projected from the OTHER stream's tokens, normalised by THIS block's norm_y
+            wkv, bkv = _fold_layernorm(torch.cat((sd[p + "cross_attn.projk.weight"], sd[p + "cross_attn.projv.weight"]), 0),
+                                       torch.cat((sd[p + "cross_attn.projk.bias"], sd[p + "cross_attn.projv.bias"]), 0),
+                                       sd[p + "norm_y.weight"], sd[p + "norm_y.bias"])  # fmt: skip
+            ws.append(wkv.contiguous())
+            bs.append(bkv.contiguous())
             lin(p + "cross_attn.proj")
-            lin(p + "mlp.fc1")
+            lin(p + "mlp.fc1", p + "norm3")
             lin(p + "mlp.fc2")
             for n in ("norm1", "norm2", "norm_y", "norm3"):
                 norm(p + n)
