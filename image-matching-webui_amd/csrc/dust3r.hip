@@ -127,6 +127,7 @@ static bool du_cfg_ok(const DuCfg& c) {
 
 struct DuLayout {
     std::vector<size_t> b, wh, wl, ws, vec;
+    std::vector<size_t> rs;  // GEMM layers: row sums sum_k W[n][k] of the packed matrix (folded LayerNorms, GemmP.ln_rowsum)
     size_t total;
 };
 static DuLayout du_layout(const DuCfg& c) {
@@ -154,6 +155,12 @@ static DuLayout du_layout(const DuCfg& c) {
     const int nv = du_nvec(c);
     l.vec.resize(nv);
     for (int i = 0; i < nv; ++i) l.vec[i] = take(du_vec_len(c, i));
+    l.rs.resize(nl);
+    for (int i = 0; i < nl; ++i) {  // (behind everything else: the offsets above are those of rounds 2 and 3)
+        int N, K, kind;
+        du_shape(c, i, &N, &K, &kind);
+        l.rs[i] = kind == 0 ? take((size_t)N) : (size_t)-1;
+    }
     l.total = off;
     return l;
 }
@@ -229,6 +236,12 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
                 unsigned short* hi = reinterpret_cast<unsigned short*>(packed + l.wh[i]);
                 unsigned short* lo = reinterpret_cast<unsigned short*>(packed + l.wl[i]);
                 packed[l.ws[i]] = kind == 1 ? pack_conv3x3_split_from_gemm(w[i], N, K / 9, hi, lo) : split_weights_frag_host(w[i], N, K, hi, lo);
+                if (kind == 0)
+                    for (int n = 0; n < N; ++n) {
+                        double acc = 0.0;
+                        for (int k = 0; k < K; ++k) acc += (double)w[i][(size_t)n * K + k];
+                        packed[l.rs[i] + n] = (float)acc;
+                    }
             }
         });
     for (auto& th : pool) th.join();
@@ -240,11 +253,13 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
 }
 
 // ------------------------------------------------------------------ workspace
+constexpr bool DU_LN_EPILOGUE_DEFAULT = false;  // until measured
 constexpr int DU_MAX_CLASSES = 4;  // distinct image sizes of one call (the wrapper's symmetrised pair has at most two)
 struct DuWs {
     float *A0, *x, *xn, *qkv, *qp, *kp, *vp, *kc, *vc, *att, *hid, *fenc, *g, *y, *qc;
     float *tok0, *hook[3], *ta, *tb, *tm, *rn[4], *s0, *s1, *s2, *s3, *pa, *pb, *hd0, *hd1, *hd2, *lfh, *lfo;
     float *rcos, *rsin;  // RoPE2D tables [class][R][32] of the token grids (the fused q / k / v projection epilogue reads them)
+    float* stats;        // (mean, rstd) per token row of the stage that runs (folded LayerNorms)
     int *cnt, *smap, *wsel, *wsel_rev;
     int* geo;  // images of several sizes: per-sequence token counts / grid widths / table rows, head gather maps (du_forward_impl)
     size_t geo_ints;
@@ -298,6 +313,7 @@ static DuWs du_carve(void* ws, size_t bytes, const DuCfg& c, int NI, int P, size
     w.hd2 = a.get<float>(pt * 256 * 128);
     w.lfh = c.desc > 0 ? a.get<float>(pt * 4 * (E + D)) : nullptr;  // MASt3R: hidden layer and output of head_local_features
     w.lfo = c.desc > 0 ? a.get<float>(pt * (size_t)(c.desc + 1) * 256) : nullptr;
+    w.stats = a.get<float>(2 * (me > md ? me : md));
     w.rcos = a.get<float>((size_t)DU_MAX_CLASSES * R * 32);
     w.rsin = a.get<float>((size_t)DU_MAX_CLASSES * R * 32);
     const size_t nseq = (size_t)(NI > 2 * P ? NI : 2 * P) + 64;
@@ -395,6 +411,8 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
     // for the GEMMs' tile skipping and the attention masks; with several image sizes also the first RoPE2D table row, the token
     // count and the grid width of every sequence (nullptr in a one-size call: the scalars T / wg / table row 0 hold for all)
     const int *cur_cnt = w.cnt, *cur_row0 = nullptr, *cur_T = nullptr, *cur_wg = nullptr;
+    // folded LayerNorm: (mean, rstd) rows of the raw input of the NEXT linear layer(s), applied in their epilogue; nullptr: plain layers
+    const float* cur_ln = nullptr;
 
     // linear layer li on `nseq` sequences of R rows (cnt live): C = act(A W^T + b + resid)
     auto lin = [&](int li, const float* A, float* C, int nseq, const float* resid, int act) -> int {
@@ -420,6 +438,10 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         g.M = nseq * R;
         g.cnt = cur_cnt;
         g.rows_per_seq = R;
+        if (cur_ln) {
+            g.ln_stats = cur_ln;
+            g.ln_rowsum = Pk + l.rs[li];
+        }
         return gemm_launch(h, g, stream);
     };
     // decoder layer j of block i on ALL 2P streams in one launch: sequences [0, P) use the weights of `dec_blocks`, [P, 2P) those of
@@ -431,12 +453,15 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         const int L0 = du_l_dec(c, 0, i, j), L1 = du_l_dec(c, 1, i, j);
         if (!merged) {
             const int* cnt_all = cur_cnt;
+            const float* ln_all = cur_ln;
             for (int s = 0; s < 2; ++s) {
                 const int li = swap ? (s ? L0 : L1) : (s ? L1 : L0);
                 cur_cnt = cnt_all + (size_t)s * P;
+                cur_ln = ln_all ? ln_all + 2 * (size_t)s * P * R : nullptr;
                 const int r = lin(li, A + (size_t)s * P * R * lda_rows, C + (size_t)s * P * R * ldc_rows, P,
                                   resid ? resid + (size_t)s * P * R * ldc_rows : nullptr, act);
                 cur_cnt = cnt_all;
+                cur_ln = ln_all;
                 if (r != IMCUI_OK) return r;
             }
             return IMCUI_OK;
@@ -466,6 +491,11 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         g.M = 2 * P * R;
         g.cnt = cur_cnt;
         g.rows_per_seq = R;
+        if (cur_ln) {
+            g.ln_stats = cur_ln;
+            g.ln_rowsum = Pk + l.rs[L0];
+            g.ln_stride = (long)(l.rs[L1] - l.rs[L0]);
+        }
         return gemm_launch(h, g, stream);
     };
     // the same on dense rows (DPT head)
@@ -496,6 +526,38 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
     auto normalise = [&](const float* x, float* out, long rows, int C) {
         hipLaunchKernelGGL(du_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, x, (const float*)nullptr, (const float*)nullptr, out,
                            rows, C, 1e-6f);
+    };
+    // The normalisation itself can move into the epilogue of the consuming GEMM: LN(x) W^T + b = rstd (x W'^T - mean s) + b' with s = the
+    // row sums of W' (packed behind the layers).  The K loop then runs on the RAW residual stream and the LayerNorm pass shrinks to the
+    // statistics (half the traffic).  Parity arithmetic with the weights-in-registers kernel only; IMCUI_DUST3R_LN_EPILOGUE=0 keeps the
+    // normalise-then-multiply path.
+    static const bool ln_epi_env = [] {
+        const char* e = getenv("IMCUI_DUST3R_LN_EPILOGUE");
+        return e ? atoi(e) != 0 : DU_LN_EPILOGUE_DEFAULT;
+    }();
+    bool fold = false;
+    if (ln_epi_env && !single) {  // would the layers take the kernel that knows the folded epilogue?
+        GemmP probe;
+        probe.epi = EPI_CONV;
+        probe.N = 4 * c.E;
+        probe.K = c.E;
+        probe.lda = c.E;
+        probe.ldc = 4 * c.E;
+        probe.Wh = reinterpret_cast<const unsigned short*>(Pk);
+        probe.Wl = probe.Wh;
+        probe.ln_stats = Pk;
+        probe.ln_rowsum = Pk;
+        fold = gemm_wreg_ok(probe);
+    }
+    // the input of the next linear layer(s): with `fold` the raw rows + their statistics, else the normalised copy in w.xn
+    auto ln_input = [&](const float* x, long rows, int C) -> const float* {
+        if (fold) {
+            hipLaunchKernelGGL(du_rowstats_kernel, dim3((unsigned)((rows + 3) / 4)), blk, 0, stream, x, w.stats, rows, C, 1e-6f);
+            cur_ln = w.stats;
+            return x;
+        }
+        normalise(x, w.xn, rows, C);
+        return w.xn;
     };
     const float q_alpha = 0.125f * 1.44269504088896340736f;  // 1 / sqrt(64) and log2(e): the attention kernel works in base 2
     // q / k planes of `nseq` sequences read from src[:, col0 : col0 + C]
@@ -549,6 +611,11 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         g.rope_sin = w.rsin;
         g.rope_seq_row0 = cur_row0;
         g.alpha = q_alpha;
+        if (cur_ln) {
+            g.ln_stats = cur_ln;
+            g.ln_rowsum = Pk + l.rs[li0];
+            if (li1 >= 0) g.ln_stride = (long)(l.rs[li1] - l.rs[li0]);
+        }
         *done = li1 != -2 && !qkv_unfused_env && !single && N == nblk * C && gemm_wreg_ok(g);
         if (!*done) return IMCUI_OK;
         return gemm_launch(h, g, stream);
@@ -666,20 +733,22 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         dump_copy(w.x, (size_t)me * E);
     }
     for (int i = 0; i < c.enc_depth; ++i) {
-        normalise(w.x, w.xn, me, E);  // norm1 (affine part inside attn.qkv)
+        const float* xin = ln_input(w.x, me, E);  // norm1 (affine part inside attn.qkv)
         bool fused;
-        DURUN(proj_planes(du_l_enc(c, i, 0), -1, false, w.xn, E, NI, 0, 3, w.qp, w.kp, w.vp, &fused));
+        DURUN(proj_planes(du_l_enc(c, i, 0), -1, false, xin, E, NI, 0, 3, w.qp, w.kp, w.vp, &fused));
         if (!fused) {
-            DURUN(lin(du_l_enc(c, i, 0), w.xn, w.qkv, NI, nullptr, 0));
+            DURUN(lin(du_l_enc(c, i, 0), xin, w.qkv, NI, nullptr, 0));
             rope_split(w.qkv, 3 * E, 0, E, NI, w.qp, NI, 0, q_alpha);
             rope_split(w.qkv, 3 * E, E, E, NI, w.kp, NI, 0, 1.0f);
             vt_split(w.qkv, 3 * E, 2 * E, E, NI, w.vp, NI, 0);
         }
+        cur_ln = nullptr;
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, NI, E, 0));
         DURUN(lin(du_l_enc(c, i, 1), w.att, w.x, NI, w.x, 0));
-        normalise(w.x, w.xn, me, E);  // norm2 (inside mlp.fc1)
-        DURUN(lin(du_l_enc(c, i, 2), w.xn, w.hid, NI, nullptr, 3));
+        xin = ln_input(w.x, me, E);  // norm2 (inside mlp.fc1)
+        DURUN(lin(du_l_enc(c, i, 2), xin, w.hid, NI, nullptr, 3));
+        cur_ln = nullptr;
         DURUN(lin(du_l_enc(c, i, 3), w.hid, w.x, NI, w.x, 0));
         dump_copy(w.x, (size_t)me * E);
     }
@@ -719,38 +788,41 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         // its own norm_y and projected by its own projk / projv -> the rows of side o carry the weights of side 1 - o.  With the
         // affine parts folded into the projections, norm_y (cross keys / values) and norm1 (self attention) are ONE normalisation
         // of the block's input, for both sides at once
-        normalise(w.y, w.xn, md, D);
+        const float* yin = ln_input(w.y, md, D);
         bool fused;
-        DURUN(proj_planes(du_l_dec(c, 0, i, 3), merged ? du_l_dec(c, 1, i, 3) : -2, true, w.xn, D, 2 * P, 1, 2, nullptr, w.kc, w.vc, &fused));
+        DURUN(proj_planes(du_l_dec(c, 0, i, 3), merged ? du_l_dec(c, 1, i, 3) : -2, true, yin, D, 2 * P, 1, 2, nullptr, w.kc, w.vc, &fused));
         if (!fused) {
-            DURUN(lin2(i, 3, w.xn, D, w.qkv, 2 * D, nullptr, 0, true));
+            DURUN(lin2(i, 3, yin, D, w.qkv, 2 * D, nullptr, 0, true));
             rope_split(w.qkv, 2 * D, 0, D, 2 * P, w.kc, 2 * P, 0, 1.0f);
             vt_split(w.qkv, 2 * D, D, D, 2 * P, w.vc, 2 * P, 0);
         }
         // self attention (w.xn still holds the normalised input of the block)
-        DURUN(proj_planes(du_l_dec(c, 0, i, 0), merged ? du_l_dec(c, 1, i, 0) : -2, false, w.xn, D, 2 * P, 0, 3, w.qp, w.kp, w.vp, &fused));
+        DURUN(proj_planes(du_l_dec(c, 0, i, 0), merged ? du_l_dec(c, 1, i, 0) : -2, false, yin, D, 2 * P, 0, 3, w.qp, w.kp, w.vp, &fused));
         if (!fused) {
-            DURUN(lin2(i, 0, w.xn, D, w.qkv, 3 * D, nullptr, 0, false));
+            DURUN(lin2(i, 0, yin, D, w.qkv, 3 * D, nullptr, 0, false));
             rope_split(w.qkv, 3 * D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
             rope_split(w.qkv, 3 * D, D, D, 2 * P, w.kp, 2 * P, 0, 1.0f);
             vt_split(w.qkv, 3 * D, 2 * D, D, 2 * P, w.vp, 2 * P, 0);
         }
+        cur_ln = nullptr;
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kp, w.vp, w.att, 2 * P, D, 0));
         DURUN(lin2(i, 1, w.att, D, w.y, D, w.y, 0, false));
         // cross attention
-        normalise(w.y, w.xn, md, D);  // norm2 (inside cross_attn.projq)
-        DURUN(proj_planes(du_l_dec(c, 0, i, 2), merged ? du_l_dec(c, 1, i, 2) : -2, false, w.xn, D, 2 * P, 0, 1, w.qp, nullptr, nullptr, &fused));
+        yin = ln_input(w.y, md, D);  // norm2 (inside cross_attn.projq)
+        DURUN(proj_planes(du_l_dec(c, 0, i, 2), merged ? du_l_dec(c, 1, i, 2) : -2, false, yin, D, 2 * P, 0, 1, w.qp, nullptr, nullptr, &fused));
         if (!fused) {
-            DURUN(lin2(i, 2, w.xn, D, w.qc, D, nullptr, 0, false));
+            DURUN(lin2(i, 2, yin, D, w.qc, D, nullptr, 0, false));
             rope_split(w.qc, D, 0, D, 2 * P, w.qp, 2 * P, 0, q_alpha);
         }
+        cur_ln = nullptr;
         IMCUI_CHECK_LAUNCH(h);
         DURUN(attend(w.qp, w.kc, w.vc, w.att, 2 * P, D, 2));
         DURUN(lin2(i, 4, w.att, D, w.y, D, w.y, 0, false));
         // MLP
-        normalise(w.y, w.xn, md, D);  // norm3 (inside mlp.fc1)
-        DURUN(lin2(i, 5, w.xn, D, w.hid, 4 * D, nullptr, 3, false));
+        yin = ln_input(w.y, md, D);  // norm3 (inside mlp.fc1)
+        DURUN(lin2(i, 5, yin, D, w.hid, 4 * D, nullptr, 3, false));
+        cur_ln = nullptr;
         DURUN(lin2(i, 6, w.hid, 4 * D, w.y, D, w.y, 0, false));
         dump_copy(w.y, (size_t)md * D);
         for (int k = 0; k < 2; ++k)

@@ -78,6 +78,38 @@ __global__ __launch_bounds__(256) void du_layernorm_kernel(const float* __restri
     }
 }
 
+// (mean, rstd) of every row, the same two-pass moments as du_layernorm_kernel: the statistics of a LayerNorm whose normalisation is
+// applied in the epilogue of the consuming GEMM (GemmP.ln_stats)
+__global__ __launch_bounds__(256) void du_rowstats_kernel(const float* __restrict__ x, float* __restrict__ stats, long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * C;
+    float4 v[4];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            v[k] = *reinterpret_cast<const float4*>(xr + c);
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < C) {
+            const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+}
+
 // ------------------------------------------------------------------ q / k: RoPE2D + scale + f16 hi / lo planes [seq][head][R][64]
 // src [nseq*R][ld] f32, the `heads` x 64 features of q (or k) start at column col0.  Head layout: a y half and an x half of 32
 // features; inside a half feature i < 16 pairs with i + 16: (a, b) -> (a cos - b sin, b cos + a sin), angle = position *

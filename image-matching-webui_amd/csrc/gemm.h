@@ -92,6 +92,13 @@ struct GemmP {
     // EPI_QKV_VIT with sequences on token grids of different shapes: first table row of each sequence's grid (device, per sequence);
     // nullptr: every sequence reads the table from row 0
     const int* rope_seq_row0 = nullptr;
+    // LayerNorm folded into the layer (DUSt3R; gemm_wreg_kernel, EPI_CONV and EPI_QKV_VIT only): A holds the RAW rows x, the weights carry
+    // gamma and the bias carries W beta (pack time), and the epilogue applies  out = rstd_row (acc - mean_row ln_rowsum[n]) + bias[n]
+    // where the plain layer computes acc + bias[n].  ln_stats [M][2] = (mean, rstd) of every row of A, ln_rowsum [N] = sum_k W[n][k] of
+    // the packed (gamma-folded) weights, + ln_stride floats per selected weight set (wsel)
+    const float* ln_stats = nullptr;
+    const float* ln_rowsum = nullptr;
+    long ln_stride = 0;
 };
 
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);

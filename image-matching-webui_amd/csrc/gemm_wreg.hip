@@ -209,6 +209,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     float* st = reinterpret_cast<float*>(sm + wid * WR_WAVE_LDS);
     const int fw0 = c.col0 + 64 * wid;  // first feature of this wave
     if (fw0 >= c.N) return;            // (no workgroup barrier below)
+    // LayerNorm folded into this layer: per-feature row sums of the (gamma-folded) weights, per-token (mean, rstd) of the raw input
+    const float* lrs = nullptr;
+    if constexpr (EPI == EPI_QKV_VIT || EPI == EPI_CONV) {
+        if (p.ln_stats != nullptr) lrs = p.ln_rowsum + (size_t)c.wsel * p.ln_stride;
+    }
     auto park_rows = [&](int m) __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -252,6 +257,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 pa = *reinterpret_cast<const float4*>(c.bias + fw0 + dp);
                 pb = *reinterpret_cast<const float4*>(c.bias + fw0 + dp + 4);
             }
+            float sm_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sp_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // row sums: mine / partner
+            if (lrs != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sm_[j] = lrs[fw0 + d0 + j];
+                    sp_[j] = lrs[fw0 + dp + j];
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 float4 tc[4][2], ts[4][2];
@@ -272,8 +285,18 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                     const float4 vb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + d0 + 4);
                     const float4 wa = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + dp);
                     const float4 wb = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + dp + 4);
-                    const float mine[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
-                    const float part[8] = {wa.x + pa.x, wa.y + pa.y, wa.z + pa.z, wa.w + pa.w, wb.x + pb.x, wb.y + pb.y, wb.z + pb.z, wb.w + pb.w};
+                    float mine[8] = {va.x + ba.x, va.y + ba.y, va.z + ba.z, va.w + ba.w, vb.x + bb.x, vb.y + bb.y, vb.z + bb.z, vb.w + bb.w};
+                    float part[8] = {wa.x + pa.x, wa.y + pa.y, wa.z + pa.z, wa.w + pa.w, wb.x + pb.x, wb.y + pb.y, wb.z + pb.z, wb.w + pb.w};
+                    if (lrs != nullptr) {
+                        const float2 mr = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)(c.row0 + 32 * m + tl));
+                        const float xa[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w}, xp[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                        const float ba8[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w}, pa8[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            mine[j] = mr.y * (xa[j] - mr.x * sm_[j]) + ba8[j];
+                            part[j] = mr.y * (xp[j] - mr.x * sp_[j]) + pa8[j];
+                        }
+                    }
                     const float cw[8] = {tc[pass][0].x, tc[pass][0].y, tc[pass][0].z, tc[pass][0].w, tc[pass][1].x, tc[pass][1].y, tc[pass][1].z, tc[pass][1].w};
                     const float ss[8] = {ts[pass][0].x, ts[pass][0].y, ts[pass][0].z, ts[pass][0].w, ts[pass][1].x, ts[pass][1].y, ts[pass][1].z, ts[pass][1].w};
                     float v[8];
@@ -364,8 +387,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 for (int pass = 0; pass < 4; ++pass) {
                     const int d = pass * 16 + (lane >> 2), tk = (lane & 3) * 8;
                     const float bd = c.bias ? c.bias[fw0 + d] : 0.0f;
-                    const float4 va = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk);
-                    const float4 vb = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk + 4);
+                    float4 va = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk);
+                    float4 vb = *reinterpret_cast<const float4*>(st + d * WR_STG_TROW + tk + 4);
+                    if (lrs != nullptr) {  // the lane's 8 consecutive tokens: (mean, rstd) pairs are 64 contiguous bytes
+                        const float sd = lrs[fw0 + d];
+                        const float4* ms4 = reinterpret_cast<const float4*>(p.ln_stats + 2 * (size_t)(c.row0 + 32 * m + tk));
+                        const float4 q0 = ms4[0], q1 = ms4[1], q2 = ms4[2], q3 = ms4[3];
+                        va = make_float4(q0.y * (va.x - q0.x * sd), q0.w * (va.y - q0.z * sd), q1.y * (va.z - q1.x * sd), q1.w * (va.w - q1.z * sd));
+                        vb = make_float4(q2.y * (vb.x - q2.x * sd), q2.w * (vb.y - q2.z * sd), q3.y * (vb.z - q3.x * sd), q3.w * (vb.w - q3.z * sd));
+                    }
                     uint4 hv, lv;
                     split8(make_float4(va.x + bd, va.y + bd, va.z + bd, va.w + bd), make_float4(vb.x + bd, vb.y + bd, vb.z + bd, vb.w + bd), hv, lv);
                     unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * 64 + d) * R + i0 + 32 * m + tk;
@@ -382,6 +412,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         const int f0 = fw0 + fl;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c.bias != nullptr) b4 = *reinterpret_cast<const float4*>(c.bias + f0);
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lrs != nullptr) s4 = *reinterpret_cast<const float4*>(lrs + f0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             park_rows(m);
@@ -391,7 +423,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 const int tl = pass * 4 + (lane >> 4);
                 const int row = c.row0 + 32 * m + tl;
                 if (row < c.M) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + fl);
+                    float4 t4 = *reinterpret_cast<const float4*>(st + tl * WR_STG_ROW + fl);
+                    if (lrs != nullptr) {
+                        const float2 mr = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)row);
+                        t4 = make_float4(mr.y * (t4.x - mr.x * s4.x), mr.y * (t4.y - mr.x * s4.y), mr.y * (t4.z - mr.x * s4.z), mr.y * (t4.w - mr.x * s4.w));
+                    }
                     float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
                     float* dstp = C + (size_t)row * p.ldc + f0;
                     if (EPI == EPI_CONV) {
@@ -442,6 +478,7 @@ bool gemm_wreg_ok(const GemmP& p) {
         p.rup_h > 0)
         return false;
     if (p.K % 32 != 0 || p.N % 64 != 0 || (p.lda & 3) != 0) return false;
+    if (p.ln_stats != nullptr && (p.ln_rowsum == nullptr || (p.epi != EPI_QKV_VIT && p.epi != EPI_CONV))) return false;
     if (p.epi == EPI_QKV_VIT)
         return p.split_out && p.v_transposed && p.heads % 4 == 0 && p.N % (p.heads * 64) == 0 && p.rows_per_seq > 0 && p.M % 128 == 0 && !p.single;
     if (p.epi == EPI_QKV || p.epi == EPI_CROSS)
