@@ -268,7 +268,11 @@ int imcui_hip_nn_argmax_split_f32(imcui_hip_t* h, const float* queries, const fl
  * convolutions in implicit-GEMM order [cout][tap][cin] (act_postprocess.3.1, layer_rn, refinenet 4..1 residual units + out_conv,
  * head.0, head.2).  imcui_hip_dust3r_num_vectors() f32 vectors of imcui_hip_dust3r_vector_len(i): the LayerNorm weights / biases in
  * module order, head.4 weight [4][128] and bias [4] per head, the 16 rotary frequencies 100^(-i/16).  Built from the upstream
- * state dict by imcui_hip/backend.py:pack_dust3r. */
+ * state dict by imcui_hip/backend.py:pack_dust3r.  CONTRACT since round 3: the q / k / v projections (attn.qkv, cross_attn.projq,
+ * [projk ; projv]) and mlp.fc1 are handed over with the affine part of the LayerNorm in front of them folded in -- W * gamma (per input
+ * column) and b + W beta for norm1 / norm2 / norm_y / norm3 -- because the device normalises those inputs WITHOUT gamma / beta (one
+ * pass serves several consumers); their LayerNorm vectors are still passed (layout unchanged) and ignored.  enc_norm and dec_norm
+ * are applied as they are. */
 /* desc_dim: 0 = DUSt3R; > 0 = MASt3R (`AsymmetricMASt3R`, imcui/hloc/matchers/mast3r.py:41 with the 'catmlp+dpt' head of
  * `MASt3R_ViTLarge_BaseDecoder_512_catmlpdpt_metric.pth`, desc_dim = 24): two more matrices per head, head_local_features.fc1
  * [4 (E + D)][E + D] and .fc2 [(desc_dim + 1) * 256][4 (E + D)], after head.2. */
