@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "attention.h"
 #include "conv.h"
@@ -19,7 +20,29 @@ int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int imcui_hip_version(void) { return 100; }
+// 400: round 4 -- imcui_hip_dust3r_forward[_sizes] take the size of the packed buffer and the buffer ends in a format trailer (a blob of
+// an older layout is rejected instead of running with its LayerNorm affine parts dropped); imcui_hip_set_option / _get_option.
+extern "C" int imcui_hip_version(void) { return 400; }
+
+static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "lg_assign_stats"};
+static int opt_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_NCNT; ++i)
+        if (strcmp(name, OPT_NAMES[i]) == 0) return i;
+    return -1;
+}
+extern "C" int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value) {
+    const int i = opt_index(name);
+    if (!h || i < 0) return imcui_set_err(h, IMCUI_ERR_ARG, "set_option: unknown option '%s'", name ? name : "(null)");
+    h->opt[i] = value;
+    return IMCUI_OK;
+}
+extern "C" int imcui_hip_get_option(imcui_hip_t* h, const char* name, int* value) {
+    const int i = opt_index(name);
+    if (!h || !value || i < 0) return imcui_set_err(h, IMCUI_ERR_ARG, "get_option: unknown option '%s'", name ? name : "(null)");
+    *value = h->opt[i];
+    return IMCUI_OK;
+}
 
 extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
     if (!out) return IMCUI_ERR_ARG;
@@ -34,6 +57,13 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
     h->num_cu = prop.multiProcessorCount;
     h->err[0] = 0;
     h->precision = 1;
+    {   // the A/B switches: environment -> handle, once (common.h)
+        const char* e;
+        h->opt[OPT_GEMM_WREG] = (e = getenv("IMCUI_GEMM_WREG")) ? atoi(e) : 2;
+        h->opt[OPT_WREG_PIPE] = (e = getenv("IMCUI_WREG_PIPE")) ? atoi(e) : 1;
+        h->opt[OPT_ATTN_VARIANT] = (e = getenv("IMCUI_ATTN_VARIANT")) ? atoi(e) : 0;
+        h->opt[OPT_LG_ASSIGN_STATS] = ((e = getenv("IMCUI_LG_ASSIGN_STATS")) && (strcmp(e, "epilogue") == 0 || atoi(e) == 1)) ? 1 : 0;
+    }
     *out = h;
     const char* rc = getenv("IMCUI_HIP_CHECK_RANGE");
     if (rc && atoi(rc) != 0) (void)imcui_hip_set_range_check(h, 1);
@@ -229,6 +259,8 @@ extern "C" int imcui_hip_qkv_split_f32(imcui_hip_t* h, const float* x, const uns
     if (!h || !x || !wh || !wl || !wscale || !cnt || !q || !v || (!cross && (!k || !rope_cos || !rope_sin)))
         return imcui_set_err(h, IMCUI_ERR_ARG, "qkv_split: null argument");
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "qkv_split: needs precision 1 (3 x f16 split)");
+    if (nseq <= 0 || rows_per_seq <= 0 || rows_per_seq % 128 != 0)  // the head-major planes are laid out (and consumed by the attention kernel) in 128-row tiles
+        return imcui_set_err(h, IMCUI_ERR_ARG, "qkv_split: rows_per_seq=%d must be a positive multiple of 128 (nseq=%d)", rows_per_seq, nseq);
     GemmP g;
     g.epi = cross ? EPI_CROSS : EPI_QKV;
     g.M = nseq * rows_per_seq;

@@ -244,9 +244,19 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // raised; 3: the soft-max raised instead.
 // VAR 4 (AttnP.single, DUSt3R's opt-in `arith = 1`): ONE f16 product per element pair -- only the hi planes of Q / K / V are loaded,
 // staged and multiplied, P is rounded to the nearest f16 (f32 accumulation and an f32 normaliser as before).  Not a parity mode.
+// VAR 6 (round 4, option attn_variant = 6; the audited "reduced-product P.V"): K.Q^T keeps its three products (an error there is an
+// error of the EXPONENT), V^T.P^T runs as (vh + vl) . ph with the probabilities rounded to the nearest f16: two MFMAs per product
+// instead of three (48 -> 40 per key tile) and one v_cvt_pk_f16_f32 per probability pair instead of v_cvt_pkrtz + two v_fma_mix.  The
+// normaliser is the sum of the ROUNDED probabilities (v_dot2_f32_f16 against (1, 1): exact products, f32 accumulation, the same
+// instruction count as the packed adds it replaces), so O = sum p~_j v_j / sum p~_j is an exact weighted mean with weights perturbed
+// by at most 2^-12 relative: the error is sum_j p_j e_j (v_j - O) -- it vanishes for a peaked row (one dominant key: v_j = O) and
+// averages down like 1 / sqrt(n) for a flat one; the worst case is two equal keys with different values, 2^-13 |v_0 - v_1|.
+// Measured against the per-layer parity harness in profiles/r04_lab_attention_pv2.txt.
 template <bool L2D, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     constexpr bool SINGLE = (VAR == 4);
+    constexpr bool PV2 = (VAR == 6 || VAR == 7);  // P rounded to f16, V split: two products per element pair in V^T.P^T
+    constexpr bool KPRE = (VAR == 7);             // + the K fragments of step i + 1 requested before the MFMAs of step i
     // VAR 5: the K / V^T tile double-buffered in LDS (70 KB per workgroup, still two per CU): the next tile is written into the other
     // buffer right after this tile's MFMAs, ONE workgroup barrier per key tile instead of two
     constexpr bool DBUF = (VAR == 5);
@@ -392,7 +402,34 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         // fragments; kept in registers across tiles, rewritten only when the reference moves): the MFMAs deliver the
         // exponent directly
         f32x16 s[2];
+        float m_pre = -INFINITY;  // KPRE: maximum of fragment 0, taken while fragment 1 is multiplied
         if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
+        if constexpr (KPRE) {
+            // hipcc's schedule of the plain loop below is read -> wait -> three MFMAs, eight times per fragment, on ONE register
+            // quad: every LDS latency is exposed.  Here the (hi, lo) fragments of step i + 1 are requested before the MFMAs of step
+            // i are issued (two register sets, order pinned with sched_barrier).
+            uint4 kh[2], kl[2];
+            kh[0] = Kh[hi * KSTR + lo];
+            kl[0] = Kl[hi * KSTR + lo];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = i >> 2, st = i & 3;
+                if (i + 1 < 8) {
+                    const int fn = (i + 1) >> 2, sn = (i + 1) & 3;
+                    kh[(i + 1) & 1] = Kh[(2 * sn + hi) * KSTR + 32 * fn + lo];
+                    kl[(i + 1) & 1] = Kl[(2 * sn + hi) * KSTR + 32 * fn + lo];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                s[f] = mfma16(kl[i & 1], qh[st], st == 0 ? cinit : s[f]);
+                s[f] = mfma16(kh[i & 1], ql[st], s[f]);
+                s[f] = mfma16(kh[i & 1], qh[st], s[f]);
+                if (!TAIL && i >= 4) {  // the maximum of the finished first fragment rides under the MFMAs of the second
+                    const int r0 = 4 * (i - 4);
+                    m_pre = fmaxf(fmaxf(m_pre, s[0][r0]), fmaxf(s[0][r0 + 1], fmaxf(s[0][r0 + 2], s[0][r0 + 3])));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -417,9 +454,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                 for (int r = 0; r < 16; ++r)
                     if (k0 + 32 * f + frag_row(r, hi) >= nk) s[f][r] = -INFINITY;
         }
-        float m_t = -INFINITY;
+        float m_t = m_pre;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = (KPRE && !TAIL) ? 1 : 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
@@ -488,6 +525,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                         for (int r = 0; r < 16; ++r) o[f][r] *= alpha;
                 }
             }
+            if constexpr (PV2) {
+                // the probabilities are summed AFTER their rounding to f16 (below, next to the conversion)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[f][r] = __builtin_amdgcn_exp2f(s[f][r]);
+            } else {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -502,8 +546,10 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                     s[f][r + 3] = g[1];
                 }
             l_run += (la[0] + la[1]) + (lb[0] + lb[1]);
+            }
         }
         // step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
+        float lsum0 = 0.0f, lsum1 = 0.0f;  // PV2: this tile's sum of the rounded probabilities
         if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
         if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -511,7 +557,17 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 uint4 ph, pl;
-                if constexpr (SINGLE) {
+                if constexpr (PV2) {
+                    // p * 2^14 <= 2^15.5 < 65504 by the deferred-maximum rule: no clamp; nearest-even
+                    ph.x = half2_rtn_nc(s[f][8 * t + 0], s[f][8 * t + 1]);
+                    ph.y = half2_rtn_nc(s[f][8 * t + 2], s[f][8 * t + 3]);
+                    ph.z = half2_rtn_nc(s[f][8 * t + 4], s[f][8 * t + 5]);
+                    ph.w = half2_rtn_nc(s[f][8 * t + 6], s[f][8 * t + 7]);
+                    lsum0 = fdot2_ones(ph.x, lsum0);
+                    lsum1 = fdot2_ones(ph.y, lsum1);
+                    lsum0 = fdot2_ones(ph.z, lsum0);
+                    lsum1 = fdot2_ones(ph.w, lsum1);
+                } else if constexpr (SINGLE) {
                     ph.x = half2_rtn(s[f][8 * t + 0], s[f][8 * t + 1]);
                     ph.y = half2_rtn(s[f][8 * t + 2], s[f][8 * t + 3]);
                     ph.z = half2_rtn(s[f][8 * t + 4], s[f][8 * t + 5]);
@@ -528,6 +584,10 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                     const uint4 vh = Vh[vi];
                     if constexpr (SINGLE) {
                         o[df] = mfma16(vh, ph, o[df]);
+                    } else if constexpr (PV2) {
+                        const uint4 vl = Vl[vi];
+                        o[df] = mfma16(vl, ph, o[df]);
+                        o[df] = mfma16(vh, ph, o[df]);
                     } else {
                         const uint4 vl = Vl[vi];
                         o[df] = mfma16(vl, ph, o[df]);
@@ -537,6 +597,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                 }
             }
         if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PV2) l_run += lsum0 + lsum1;
     };
 
     const int ntile = (nk + KT - 1) / KT;
@@ -628,10 +689,13 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
     if (h->precision == 1 && p.log2_domain) {
-        const char* ve = getenv("IMCUI_ATTN_VARIANT");
-        const int var = ve ? atoi(ve) : 0;
+        const int var = h->opt[OPT_ATTN_VARIANT];  // imcui_hip_set_option(h, "attn_variant", v)
         if (p.single)
             hipLaunchKernelGGL((attn_split_kernel<true, 4>), grid, dim3(256), 0, stream, p);
+        else if (var == 6)
+            hipLaunchKernelGGL((attn_split_kernel<true, 6>), grid, dim3(256), 0, stream, p);
+        else if (var == 7)
+            hipLaunchKernelGGL((attn_split_kernel<true, 7>), grid, dim3(256), 0, stream, p);
         else if (var == 5)
             hipLaunchKernelGGL((attn_split_kernel<true, 5>), grid, dim3(256), 0, stream, p);
         else if (var == 1)

@@ -67,6 +67,16 @@ __device__ __forceinline__ unsigned half2_rtn(float x0, float x1) {
     const f16x2 h = {(_Float16)fminf(fmaxf(x0, -65504.0f), 65504.0f), (_Float16)fminf(fmaxf(x1, -65504.0f), 65504.0f)};
     return __builtin_bit_cast(unsigned, h);
 }
+// two floats known to lie inside the f16 range -> packed f16, round to nearest even (v_cvt_pk_f16_f32), no clamp
+__device__ __forceinline__ unsigned half2_rtn_nc(float x0, float x1) {
+    const f16x2 h = {(_Float16)x0, (_Float16)x1};
+    return __builtin_bit_cast(unsigned, h);
+}
+// acc + h.x + h.y for a packed f16 pair: v_dot2_f32_f16 against (1, 1) -- exact products, f32 accumulation
+__device__ __forceinline__ float fdot2_ones(unsigned h, float acc) {
+    const f16x2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, h), one, acc, false);
+}
 __device__ __forceinline__ uint4 half8_rtn(const float4& a, const float4& b) {
     return make_uint4(half2_rtn(a.x, a.y), half2_rtn(a.z, a.w), half2_rtn(b.x, b.y), half2_rtn(b.z, b.w));
 }
@@ -131,6 +141,18 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 #define IMCUI_ERR_HIP -3
 #define IMCUI_ERR_UNSUPPORTED -4
 
+// A/B switches of the kernel routing.  Read from the environment ONCE, when the handle is created (imcui_hip_create), and changed
+// afterwards only through imcui_hip_set_option: the launch paths never call getenv (the plugins run in several UI worker threads, and
+// getenv concurrent with a setenv / putenv is a data race in glibc; a switch flipped in the middle of a forward pass would also route
+// two launches of one network to different kernels).  Names: the IMCUI_* environment variable without its prefix, lower case.
+enum {
+    OPT_GEMM_WREG = 0,     // IMCUI_GEMM_WREG: 0 = projections on gemm_split_kernel, 1 = attention-layout projections on gemm_wreg_kernel, 2 (default) = every eligible launch
+    OPT_WREG_PIPE,         // IMCUI_WREG_PIPE: 0 = rolled K loop, 1 (default) = three rotating register sets
+    OPT_ATTN_VARIANT,      // IMCUI_ATTN_VARIANT: 0 (default) .. 6, see attention.hip
+    OPT_LG_ASSIGN_STATS,   // IMCUI_LG_ASSIGN_STATS: 0 (default) = stand-alone statistics pass, 1 (`epilogue`) = soft-max partials from the similarity GEMM's epilogue
+    OPT_NCNT
+};
+
 // optional per-kernel-class HIP-event timing (bench.py's live roofline measurement)
 enum { PROF_ATTN = 0, PROF_CONV = 1, PROF_GEMM = 2, PROF_NCLS = 3 };
 #define PROF_MAX_EVENTS 4096
@@ -149,6 +171,7 @@ struct imcui_hip_s {
     // opt-in range check of the split arithmetic (imcui_hip_set_range_check / IMCUI_HIP_CHECK_RANGE=1): device word, bit 0 = an
     // f32 activation beyond the f16 range (|x| > 65504: the hi part saturates, the product is no longer fp32-grade), bit 1 = NaN / Inf
     int* range_flag;
+    int opt[OPT_NCNT];  // A/B switches (above)
 };
 // scan `rows` x `cols` f32 values (row stride ld; rows of sequence s beyond cnt[s] are padding and skipped) into h->range_flag
 void imcui_range_check(imcui_hip_s* h, const float* x, long rows, int cols, long ld, const int* cnt, int rows_per_seq, hipStream_t s);

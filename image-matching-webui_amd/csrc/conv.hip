@@ -825,6 +825,11 @@ static int conv_tall_mode() {
     return mode;
 }
 
+static bool conv_narrow_env() {  // (read once per process, like IMCUI_CONV_TALL)
+    static const bool on = getenv("IMCUI_CONV_NARROW") != nullptr;
+    return on;
+}
+
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
                          int relu, int pool, hipStream_t stream, const float* resid, int cin_stride, int cout_live, int single, const float* resid2,
@@ -835,7 +840,7 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (resid2 && !resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: a second residual map needs the first");
     if (head && (Cout != 128 || pool || resid || (relu & 3) != 1 || cout_live != Cout || !head->w || !head->b || !head->pts || !head->conf ||
-                 getenv("IMCUI_CONV_NARROW") != nullptr))
+                 conv_narrow_env()))
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: the fused point-map head needs a 128-channel ReLU layer without pooling / residual");
     if (!head && !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: null output");
     if (Cin % 32 != 0 || Cout % 64 != 0)

@@ -128,6 +128,7 @@ static bool du_cfg_ok(const DuCfg& c) {
 struct DuLayout {
     std::vector<size_t> b, wh, wl, ws, vec;
     std::vector<size_t> rs;  // GEMM layers: row sums sum_k W[n][k] of the packed matrix (folded LayerNorms, GemmP.ln_rowsum)
+    size_t trailer;          // 64 words at the very end: magic, format, total floats, the five configuration integers (round 4)
     size_t total;
 };
 static DuLayout du_layout(const DuCfg& c) {
@@ -161,9 +162,19 @@ static DuLayout du_layout(const DuCfg& c) {
         du_shape(c, i, &N, &K, &kind);
         l.rs[i] = kind == 0 ? take((size_t)N) : (size_t)-1;
     }
+    l.trailer = take(64);
     l.total = off;
     return l;
 }
+
+// Format of the packed buffer.  The CONTENT changed in round 3 without the size telling (LayerNorm gamma / beta folded into the
+// consuming matrices by the packer, row sums appended): a blob packed for an older layout, or packed from raw upstream weights by a
+// caller that skipped the fold, ran and returned plausible but wrong point maps.  Since round 4 the buffer ends in a trailer
+// (magic, DU_FORMAT, total size, configuration) written by imcui_hip_dust3r_pack_weights, the forward entry points take the size
+// of the caller's buffer and reject anything but this library's, and imcui_hip_dust3r_check_packed verifies the trailer of a HOST copy.
+// 4 = norms folded by the caller of pack_weights (backend.dust3r_matrices), row sums behind the vectors, trailer.
+#define DU_MAGIC 0x494D4455u /* 'IMDU' */
+#define DU_FORMAT 4u
 
 static DuCfg du_cfg(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim) {
     return DuCfg{enc_dim, enc_depth, dec_dim, dec_depth, desc_dim};
@@ -249,7 +260,28 @@ extern "C" int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec
     for (int i = 0; i < c.dec_depth; ++i)
         for (int j = 0; j < DU_DEC_J; ++j) packed[l.ws[du_l_dec(c, 0, i, j)] + 1] = packed[l.ws[du_l_dec(c, 1, i, j)]];
     for (int i = 0; i < nv; ++i) memcpy(packed + l.vec[i], vec[i], (size_t)du_vec_len(c, i) * sizeof(float));
+    {
+        const unsigned long long tot = (unsigned long long)l.total;
+        const unsigned t[9] = {DU_MAGIC, DU_FORMAT, (unsigned)(tot & 0xffffffffu), (unsigned)(tot >> 32), (unsigned)c.E, (unsigned)c.enc_depth, (unsigned)c.D, (unsigned)c.dec_depth, (unsigned)c.desc};
+        memcpy(packed + l.trailer, t, sizeof t);
+    }
     return IMCUI_OK;
+}
+
+extern "C" int imcui_hip_dust3r_format_version(void) { return (int)DU_FORMAT; }
+
+// 0 when `packed` (a HOST copy of `packed_floats` floats) is a buffer this library's imcui_hip_dust3r_pack_weights wrote for this
+// configuration; IMCUI_ERR_ARG otherwise (wrong size = another layout; missing / foreign trailer = not packed by this format).
+extern "C" int imcui_hip_dust3r_check_packed(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed, size_t packed_floats) {
+    const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
+    if (!du_cfg_ok(c) || !packed) return IMCUI_ERR_ARG;
+    const DuLayout l = du_layout(c);
+    if (packed_floats != l.total) return IMCUI_ERR_ARG;
+    unsigned t[9];
+    memcpy(t, packed + l.trailer, sizeof t);
+    const unsigned long long tot = (unsigned long long)l.total;
+    const unsigned want[9] = {DU_MAGIC, DU_FORMAT, (unsigned)(tot & 0xffffffffu), (unsigned)(tot >> 32), (unsigned)c.E, (unsigned)c.enc_depth, (unsigned)c.D, (unsigned)c.dec_depth, (unsigned)c.desc};
+    return memcmp(t, want, sizeof t) == 0 ? IMCUI_OK : IMCUI_ERR_ARG;
 }
 
 // ------------------------------------------------------------------ workspace
@@ -547,7 +579,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
         probe.Wl = probe.Wh;
         probe.ln_stats = Pk;
         probe.ln_rowsum = Pk;
-        fold = gemm_wreg_ok(probe);
+        fold = gemm_wreg_ok(h, probe);
     }
     // the input of the next linear layer(s): with `fold` the raw rows + their statistics, else the normalised copy in w.xn
     auto ln_input = [&](const float* x, long rows, int C) -> const float* {
@@ -616,7 +648,7 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
             g.ln_rowsum = Pk + l.rs[li0];
             if (li1 >= 0) g.ln_stride = (long)(l.rs[li1] - l.rs[li0]);
         }
-        *done = li1 != -2 && !qkv_unfused_env && !single && N == nblk * C && gemm_wreg_ok(g);
+        *done = li1 != -2 && !qkv_unfused_env && !single && N == nblk * C && gemm_wreg_ok(h, g);
         if (!*done) return IMCUI_OK;
         return gemm_launch(h, g, stream);
     };
@@ -1043,22 +1075,26 @@ static int du_forward_impl(imcui_hip_t* h, const DuCfg& c, const float* packed, 
 // GEMMs and convolutions (f32 accumulate; 11-bit operands: the class of the bf16 run BASELINE's configs[4] names).  Outputs, view-major:
 // pts3d [2][P][H][W][3] (view 1 in its own frame, view 2 in view 1's frame = upstream's `pts3d_in_other_view`), conf [2][P][H][W];
 // MASt3R (desc_dim > 0): desc [2][P][H][W][desc_dim] (unit norm), desc_conf [2][P][H][W].
-static int du_check_common(imcui_hip_t* h, const DuCfg& c, int arith, const void* packed, const void* images, const void* pairs, const void* pts3d,
-                           const void* conf, const void* desc, const void* desc_conf) {
+static int du_check_common(imcui_hip_t* h, const DuCfg& c, int arith, const void* packed, size_t packed_floats, const void* images, const void* pairs,
+                           const void* pts3d, const void* conf, const void* desc, const void* desc_conf) {
     if (!du_cfg_ok(c)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: unsupported configuration (dims multiples of 64 up to 1024, dec_depth a multiple of 4)");
     if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dust3r: only the 3 x f16 split mode (precision 1) is implemented");
     if (arith != 0 && arith != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: arith = %d (0: 3 x f16 split products, 1: one f16 product)", arith);
     if (!packed || !images || !pairs || !pts3d || !conf || (c.desc > 0 && (!desc || !desc_conf))) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
+    const size_t want = du_layout(c).total;
+    if (packed_floats != want)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: the packed buffer holds %zu floats, format %u of this library (imcui_hip_version %d) needs %zu: a blob of an "
+                             "older layout (or of another configuration) -- pack the state dict again", packed_floats, DU_FORMAT, imcui_hip_version(), want);
     return IMCUI_OK;
 }
 
 extern "C" int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
-                                        const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d,
+                                        size_t packed_floats, const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d,
                                         float* conf, float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes,
                                         void* stream_) {
     if (!h) return IMCUI_ERR_ARG;
     const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
-    const int rc = du_check_common(h, c, arith, packed, images, pairs, pts3d, conf, desc, desc_conf);
+    const int rc = du_check_common(h, c, arith, packed, packed_floats, images, pairs, pts3d, conf, desc, desc_conf);
     if (rc != IMCUI_OK) return rc;
     if (!du_dims_ok(NI, P, H, W)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images of %dx%d, %d pairs: sizes must be multiples of 16", NI, W, H, P);
     DuGeom geo;
@@ -1102,12 +1138,12 @@ extern "C" size_t imcui_hip_dust3r_token_dump_floats(int enc_dim, int enc_depth,
 }
 
 extern "C" int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
-                                              const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
+                                              size_t packed_floats, const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
                                               float* pts3d, float* conf, float* desc, float* desc_conf, size_t* map_pixel_offsets, float* dump,
                                               size_t dump_floats, void* ws, size_t ws_bytes, void* stream_) {
     if (!h) return IMCUI_ERR_ARG;
     const DuCfg c = du_cfg(enc_dim, enc_depth, dec_dim, dec_depth, desc_dim);
-    const int rc = du_check_common(h, c, arith, packed, images, pairs, pts3d, conf, desc, desc_conf);
+    const int rc = du_check_common(h, c, arith, packed, packed_floats, images, pairs, pts3d, conf, desc, desc_conf);
     if (rc != IMCUI_OK) return rc;
     if (!pairs_host) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: null argument");
     if (!du_sizes_ok(NI, sizes, P)) return imcui_set_err(h, IMCUI_ERR_ARG, "dust3r: %d images, %d pairs: every size must be a multiple of 16 (32 .. 4096)", NI, P);

@@ -104,8 +104,8 @@ struct GemmP {
 int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream);
 // gemm_wreg.hip: the weights-in-registers kernel for projection layers (split mode, pre-split weight planes); gemm_launch
 // routes eligible launches to it
-bool gemm_wreg_ok(const GemmP& p);
-void gemm_wreg_launch(const GemmP& p, hipStream_t stream);
+bool gemm_wreg_ok(const imcui_hip_s* h, const GemmP& p);
+void gemm_wreg_launch(const imcui_hip_s* h, const GemmP& p, hipStream_t stream);
 
 // host: OIHW conv weight -> GEMM weight [Cout][tap][Cin] (K order of the implicit im2col)
 void pack_conv_gemm(const float* w_oihw, int Cout, int Cin, int ksize, int Cin_pad, float* dst);

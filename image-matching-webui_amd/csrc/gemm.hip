@@ -1103,11 +1103,11 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
     } else if (split && h->range_flag) {
         imcui_range_check(h, p.A, (long)p.M / (p.conv_hout * p.conv_wout) * p.conv_hin * p.conv_win, p.conv_cin, p.conv_cin, nullptr, 0, stream);
     }
-    if (p.ln_stats != nullptr && !(split && gemm_wreg_ok(p)))
+    if (p.ln_stats != nullptr && !(split && gemm_wreg_ok(h, p)))
         return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "gemm: a folded LayerNorm (ln_stats) needs the weights-in-registers kernel (epi %d, N=%d, K=%d)", p.epi, p.N, p.K);
     imcui_prof_begin(h, PROF_GEMM, stream);
-    if (split && gemm_wreg_ok(p)) {
-        gemm_wreg_launch(p, stream);
+    if (split && gemm_wreg_ok(h, p)) {
+        gemm_wreg_launch(h, p, stream);
         imcui_prof_end(h, PROF_GEMM, stream);
         IMCUI_CHECK_LAUNCH(h);
         return IMCUI_OK;

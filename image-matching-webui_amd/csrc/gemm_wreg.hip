@@ -470,19 +470,20 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
 }
 
 // Which launches take this kernel: pre-split weight planes, one K slab, plain (non-batched, non-conv) A, whole 64-feature
-// wave tiles and 16-byte aligned rows.  IMCUI_GEMM_WREG=0 keeps everything on gemm_split_kernel (A/B runs).
-bool gemm_wreg_ok(const GemmP& p) {
-    const char* env = getenv("IMCUI_GEMM_WREG");  // read per launch: tests flip it between two calls
-    const int mode = env ? atoi(env) : 2;         // 0: off; 1: attention-layout projections only; 2: every eligible launch
+// wave tiles and 16-byte aligned rows; the attention layouts additionally need rows_per_seq % 128 == 0 (the plane-writing epilogue
+// takes seq = row0 / R for a whole 128-row tile: a tile must not straddle two sequences).  Option gemm_wreg = 0 keeps everything on
+// gemm_split_kernel (A/B runs).
+bool gemm_wreg_ok(const imcui_hip_s* h, const GemmP& p) {
+    const int mode = h ? h->opt[OPT_GEMM_WREG] : 2;  // 0: off; 1: attention-layout projections only; 2: every eligible launch (imcui_hip_set_option)
     if (mode == 0 || (mode == 1 && p.epi != EPI_QKV && p.epi != EPI_CROSS && p.epi != EPI_QKV_VIT) || p.Wh == nullptr || p.Wl == nullptr || p.A2 != nullptr || p.conv_k > 0 || p.batch != 1 || p.mcnt || p.ncnt || p.group_rows > 1 ||
         p.rup_h > 0)
         return false;
     if (p.K % 32 != 0 || p.N % 64 != 0 || (p.lda & 3) != 0) return false;
     if (p.ln_stats != nullptr && (p.ln_rowsum == nullptr || (p.epi != EPI_QKV_VIT && p.epi != EPI_CONV))) return false;
     if (p.epi == EPI_QKV_VIT)
-        return p.split_out && p.v_transposed && p.heads % 4 == 0 && p.N % (p.heads * 64) == 0 && p.rows_per_seq > 0 && p.M % 128 == 0 && !p.single;
+        return p.split_out && p.v_transposed && p.heads % 4 == 0 && p.N % (p.heads * 64) == 0 && p.rows_per_seq > 0 && p.rows_per_seq % 128 == 0 && p.M % 128 == 0 && !p.single;
     if (p.epi == EPI_QKV || p.epi == EPI_CROSS)
-        return p.split_out && p.v_transposed && p.heads == 4 && p.N % 256 == 0 && p.rows_per_seq > 0 && p.M % 128 == 0;
+        return p.split_out && p.v_transposed && p.heads == 4 && p.N % 256 == 0 && p.rows_per_seq > 0 && p.rows_per_seq % 128 == 0 && p.M % 128 == 0;
     if (p.single && p.epi != EPI_CONV) return false;
     if ((p.ldc & 3) != 0 || (p.epi == EPI_CONV && p.resid != nullptr && (p.ldr & 3) != 0)) return false;
     return p.epi == EPI_BIAS || p.epi == EPI_RELU || p.epi == EPI_RESID || p.epi == EPI_CONV;
@@ -505,9 +506,8 @@ static void wreg_launch(const GemmP& p, hipStream_t stream) {
                 hipLaunchKernelGGL((gemm_wreg_kernel<EPI_CONV, false, PIPE>), grid, dim3(256), 0, stream, p);
     }
 }
-void gemm_wreg_launch(const GemmP& p, hipStream_t stream) {
-    const char* e = getenv("IMCUI_WREG_PIPE");  // A/B switch: 0 = the rolled K loop
-    if (e && atoi(e) == 0)
+void gemm_wreg_launch(const imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
+    if (h && h->opt[OPT_WREG_PIPE] == 0)  // A/B switch: 0 = the rolled K loop
         wreg_launch<false>(p, stream);
     else
         wreg_launch<true>(p, stream);

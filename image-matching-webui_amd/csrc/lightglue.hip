@@ -964,8 +964,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     // (IMCUI_LG_ASSIGN_STATS=epilogue, split mode: one read of the matrix less, but the 128 v_exp_f32 per thread make the
     // matrix-pipe-bound GEMM 320 us longer where the HBM-bound pass costs 260 us -- measured 928 vs 931 pairs/s, profiles/r03),
     // then ONE pass for both arg-maxes (lightglue_assign.h)
-    const char* stats_env = getenv("IMCUI_LG_ASSIGN_STATS");
-    const bool epi_stats = split && stats_env && strcmp(stats_env, "epilogue") == 0;
+    const bool epi_stats = split && h->opt[OPT_LG_ASSIGN_STATS] == 1;  // imcui_hip_set_option(h, "lg_assign_stats", 1)
     const int nrp = R / 128, ncp = R / 64, nch = (R + LG2_COLS - 1) / LG2_COLS, nbd = R / LG2_ROWS;
     {
         GemmP g;

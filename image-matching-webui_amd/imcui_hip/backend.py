@@ -769,6 +769,28 @@ def pack_dust3r(state_dict: dict) -> tuple[torch.Tensor, dict]:
     return torch.from_numpy(packed), cfg
 
 
+def check_dust3r_packed(packed: torch.Tensor, cfg: dict) -> None:
+    """Raise unless `packed` is a buffer THIS library's packer wrote for `cfg` (size and format trailer; include/imcui_hip.h, the DUSt3R
+    section).  Called once when a module is built from conf["packed"] -- the documented way to skip the ~20 s of packing -- so that a blob
+    cached from an older layout is refused instead of running with its LayerNorm affine parts dropped."""
+    lib = load_library()
+    c4 = _dust3r_c5(cfg)
+    want = lib.imcui_hip_dust3r_packed_floats(*c4)
+    if packed.dtype != torch.float32 or packed.numel() != want:
+        raise ImcuiHipError(f"DUSt3R packed buffer: {packed.numel()} {packed.dtype} values, format {lib.imcui_hip_dust3r_format_version()} of this library needs "
+                            f"{want} float32 -- a blob of another layout / configuration; pack the state dict again (backend.pack_dust3r)")
+    if packed.device.type == "cpu":
+        rc = lib.imcui_hip_dust3r_check_packed(*c4, packed.contiguous().data_ptr(), want)
+    else:  # device-resident: bring the 64-word trailer (the last words of the buffer) to the host and compare it here
+        tail = packed.reshape(-1)[-64:].detach().cpu().contiguous().view(torch.int32)[:9].tolist()
+        fmt = lib.imcui_hip_dust3r_format_version()
+        expect = [0x494D4455, fmt, want & 0xFFFFFFFF, want >> 32, *c4]
+        rc = 0 if [v & 0xFFFFFFFF for v in tail] == [v & 0xFFFFFFFF for v in expect] else -1
+    if rc != 0:
+        raise ImcuiHipError(f"DUSt3R packed buffer: no format-{lib.imcui_hip_dust3r_format_version()} trailer for configuration {cfg} -- not written by this library's "
+                            "imcui_hip_dust3r_pack_weights; pack the state dict again (backend.pack_dust3r)")
+
+
 class DUSt3RHIP:
     def __init__(self):
         self._ws = _Workspace()
@@ -809,7 +831,7 @@ class DUSt3RHIP:
                 raise ImcuiHipError(f"DUSt3R: unsupported sizes ({NI} images of {W}x{H}, {P} pairs; multiples of 16)")
             ws = self._ws.get(nbytes, dev)
             with torch.cuda.device(dev):
-                rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), _ptr(images), NI, H, W, _ptr(pairs), P, int(arith), _ptr(pts), _ptr(conf),
+                rc = lib.imcui_hip_dust3r_forward(hd.h, *c4, _ptr(packed), packed.numel(), _ptr(images), NI, H, W, _ptr(pairs), P, int(arith), _ptr(pts), _ptr(conf),
                                                   _ptr(desc), _ptr(dconf), _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
                 hd.check(rc, "imcui_hip_dust3r_forward")
         self.last_dump = dbuf
@@ -851,7 +873,9 @@ class DUSt3RHIP:
         conf = torch.empty((total,), dtype=torch.float32, device=dev)
         desc = torch.empty((total, dd), dtype=torch.float32, device=dev) if dd else None
         dconf = torch.empty((total,), dtype=torch.float32, device=dev) if dd else None
-        nd = lib.imcui_hip_dust3r_token_dump_floats(*c4, NI, sz, P) if dump else 0
+        # (images that all share one size take the one-size path inside the library, which also dumps the DPT head tensors)
+        one_size = len(set(sizes)) == 1
+        nd = (lib.imcui_hip_dust3r_dump_floats(*c4, NI, P, *sizes[0]) if one_size else lib.imcui_hip_dust3r_token_dump_floats(*c4, NI, sz, P)) if dump else 0
         dbuf = torch.zeros((nd,), dtype=torch.float32, device=dev) if dump else None
         with self._lock:
             nbytes = lib.imcui_hip_dust3r_workspace_bytes_sizes(*c4, NI, sz, P)
@@ -859,7 +883,7 @@ class DUSt3RHIP:
                 raise ImcuiHipError(f"DUSt3R: unsupported sizes {sizes} (multiples of 16, 32 .. 4096)")
             ws = self._ws.get(nbytes, dev)
             with torch.cuda.device(dev):
-                rc = lib.imcui_hip_dust3r_forward_sizes(hd.h, *c4, _ptr(packed), _ptr(flat), NI, sz, ph, _ptr(pairs_dev), P, int(arith), _ptr(pts), _ptr(conf),
+                rc = lib.imcui_hip_dust3r_forward_sizes(hd.h, *c4, _ptr(packed), packed.numel(), _ptr(flat), NI, sz, ph, _ptr(pairs_dev), P, int(arith), _ptr(pts), _ptr(conf),
                                                         _ptr(desc), _ptr(dconf), offs, _ptr(dbuf), nd, _ptr(ws), ws.numel(), _stream_ptr())  # fmt: skip
                 hd.check(rc, "imcui_hip_dust3r_forward_sizes")
         assert offs[2 * P] == total
@@ -986,6 +1010,37 @@ def set_precision(device: torch.device, mode: int):
 def get_precision(device: torch.device) -> int:
     hd = get_handle(device)
     return hd.lib.imcui_hip_get_precision(hd.h)
+
+
+def lib_version() -> int:
+    """imcui_hip_version() of the loaded library (400 since round 4: packed-buffer formats are tied to it)."""
+    return int(load_library().imcui_hip_version())
+
+
+def set_option(device: torch.device, name: str, value: int) -> int:
+    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "lg_assign_stats"); returns
+    the previous value.  The IMCUI_* environment variables of the same names are only read when the handle is created."""
+    hd = get_handle(device)
+    old = C.c_int(0)
+    hd.check(hd.lib.imcui_hip_get_option(hd.h, name.encode(), C.byref(old)), "get_option")
+    hd.check(hd.lib.imcui_hip_set_option(hd.h, name.encode(), int(value)), "set_option")
+    return old.value
+
+
+class option:
+    """`with backend.option(dev, attn_variant=6): ...` -- set switches for a block of calls and restore them afterwards."""
+
+    def __init__(self, device: torch.device, **kw):
+        self.device, self.kw, self.old = device, kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = set_option(self.device, k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            set_option(self.device, k, v)
 
 
 # ------------------------------------------------------------------ live kernel timing

@@ -50,10 +50,27 @@ def _check_no_spills(src: str, remarks: str) -> None:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source and link the shared library. Returns its path."""
+    """Compile every HIP source and link the shared library. Returns its path.
+
+    Safe to call from several processes at once (the ranks of one `torch.distributed.run` launch on a clean checkout, pytest-xdist
+    workers): the build runs under an exclusive `flock` on lib/.build.lock, the freshness test is repeated once the lock is held, and
+    the library is linked under a temporary name and renamed into place, so a concurrent `dlopen` never sees a half-written file."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
+
     os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():  # (another process may have finished the build while this one waited)
+                _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB_PATH
+
+
+def _build_locked(verbose: bool) -> None:
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
 
@@ -68,13 +85,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    os.replace(tmp, LIB_PATH)
     if verbose:
         print(f"[imcui_hip] built {LIB_PATH}", file=sys.stderr)
-    return LIB_PATH
 
 
 if __name__ == "__main__":

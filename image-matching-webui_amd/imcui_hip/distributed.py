@@ -24,11 +24,44 @@ def padded_shard_size(num_pairs: int, world: int) -> int:
     return -(-num_pairs // world)
 
 
+class TableGather:
+    """THE exchange step of the path: all-gather of the per-rank fixed-stride match tables
+    (`all_gather_into_tensor`: one RCCL call on GPUs, gloo in the CPU tests), issued asynchronously -- PyTorch runs the
+    collective on its own communication stream behind the producing kernels, so the compute stream goes straight on to
+    the next batch; two receive buffers alternate and a buffer is only reused after the collective that last wrote it
+    has completed.  `bench.py` (every workload that has a table) and `gather_match_tables` / `run_sharded` below all go
+    through this class; with world == 1 it hands the local table back."""
+
+    def __init__(self, world: int, rows: int, stride: int, dtype, device, group=None):
+        self.world, self.group = world, group
+        self.bufs = [torch.empty((world * rows, stride), dtype=dtype, device=device) for _ in range(2)] if world > 1 else []
+        self.work = [None, None]
+        self.i = 0
+
+    def __call__(self, table: torch.Tensor) -> torch.Tensor:
+        """Start the gather of this step's table; returns the receive buffer (valid after `finish()` or after the
+        second following call)."""
+        if self.world == 1:
+            return table
+        j = self.i & 1
+        if self.work[j] is not None:
+            self.work[j].wait()
+        self.work[j] = dist.all_gather_into_tensor(self.bufs[j], table.contiguous(), group=self.group, async_op=True)
+        self.i += 1
+        return self.bufs[j]
+
+    def finish(self) -> None:
+        for w in self.work:
+            if w is not None:
+                w.wait()
+        self.work = [None, None]
+
+
 def gather_match_tables(local_table: torch.Tensor, num_pairs: int, group=None) -> torch.Tensor:
     """All-gather the per-rank match tables [n_local, S] into the global table [num_pairs, S].
 
     Every rank contributes a block padded to ceil(num_pairs / world) rows so a single
-    `all_gather_into_tensor` (one RCCL call) suffices; padding rows are dropped afterwards.
+    `all_gather_into_tensor` (one `TableGather` step) suffices; padding rows are dropped afterwards.
     """
     world = dist.get_world_size(group)
     per = padded_shard_size(num_pairs, world)
@@ -37,8 +70,11 @@ def gather_match_tables(local_table: torch.Tensor, num_pairs: int, group=None) -
     if local_table.shape[0] != per:
         send = local_table.new_zeros((per, stride))
         send[: local_table.shape[0]] = local_table
-    recv = local_table.new_empty((world * per, stride))
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if world == 1:
+        return send[:num_pairs]
+    tg = TableGather(world, per, stride, local_table.dtype, local_table.device, group)
+    recv = tg(send)
+    tg.finish()
     parts = []
     for r in range(world):
         s, e = shard_bounds(num_pairs, r, world)

@@ -54,6 +54,7 @@ class Duster(BaseModel):
     def _init(self, conf):
         if conf.get("packed") is not None:  # (packed buffer, architecture) of an earlier backend.pack_dust3r call
             packed, self.net_cfg = conf["packed"]
+            backend.check_dust3r_packed(packed, self.net_cfg)  # size + format trailer: refuses a blob of another library version
             self.conf.pop("packed", None)
             self.register_buffer("packed", packed, persistent=False)
             self._impl = backend.DUSt3RHIP()

@@ -27,6 +27,8 @@ SIGNATURES = {
     "imcui_hip_destroy": (None, [C.c_void_p]),
     "imcui_hip_last_error": (C.c_char_p, [C.c_void_p]),
     "imcui_hip_version": (C.c_int, []),
+    "imcui_hip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "imcui_hip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "imcui_hip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "imcui_hip_get_precision": (C.c_int, [C.c_void_p]),
     "imcui_hip_conv3x3_pack_split": (C.c_float, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -126,16 +128,18 @@ SIGNATURES = {
     "imcui_hip_dust3r_pack_weights": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "imcui_hip_dust3r_workspace_bytes": (C.c_size_t, [C.c_int] * 9),
     "imcui_hip_dust3r_dump_floats": (C.c_size_t, [C.c_int] * 9),
+    "imcui_hip_dust3r_format_version": (C.c_int, []),
+    "imcui_hip_dust3r_check_packed": (C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_size_t]),
     "imcui_hip_dust3r_forward": (
         C.c_int,
-        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_dust3r_workspace_bytes_sizes": (C.c_size_t, [C.c_int] * 6 + [C.POINTER(C.c_int), C.c_int]),
     "imcui_hip_dust3r_token_dump_floats": (C.c_size_t, [C.c_int] * 6 + [C.POINTER(C.c_int), C.c_int]),
     "imcui_hip_dust3r_forward_sizes": (
         C.c_int,
-        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+        [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_conv_gemm_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]),

@@ -46,7 +46,17 @@ typedef struct imcui_hip_s imcui_hip_t;
 int imcui_hip_create(int device, imcui_hip_t** out);
 void imcui_hip_destroy(imcui_hip_t* h);
 const char* imcui_hip_last_error(const imcui_hip_t* h);
+/* 400 since round 4: imcui_hip_dust3r_forward[_sizes] take the size of the packed buffer (a blob of another layout is rejected),
+ * the packed DUSt3R buffer ends in a format trailer, imcui_hip_set_option / _get_option exist.  (100: rounds 1-3.) */
 int imcui_hip_version(void);
+
+/* A/B switches of the kernel routing (profiling and the bitwise old-vs-new kernel tests).  The IMCUI_<NAME> environment variables
+ * are read ONCE, by imcui_hip_create; afterwards a switch changes only through this call -- set it BETWEEN forward passes, never while
+ * another thread runs a call on the same handle.  Names / values: "gemm_wreg" 0 | 1 | 2 (default 2: every eligible projection on
+ * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..7 (default see csrc/attention.hip), "lg_assign_stats"
+ * 0 | 1 (default 0: stand-alone soft-max statistics pass; 1: from the similarity GEMM's epilogue).  Unknown name: IMCUI_HIP_ERR_ARG. */
+int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value);
+int imcui_hip_get_option(imcui_hip_t* h, const char* name, int* value);
 
 /* Arithmetic mode of the matrix-core kernels (default 1):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, bitwise an fmaf chain
@@ -287,6 +297,16 @@ int imcui_hip_dust3r_layer_offsets(int enc_dim, int enc_depth, int dec_dim, int 
                                    size_t* plane_lo, size_t* scale, int* kind);
 int imcui_hip_dust3r_pack_weights(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* const* w,
                                   const float* const* b, const float* const* vec, float* packed);
+/* Format of the packed buffer (round 4).  Its CONTENT is a contract with the packer: the LayerNorm gamma / beta of every block must
+ * already be folded into the matrices that consume the normalised rows (qkv, the cross-attention projections, fc1: what
+ * imcui_hip/backend.py:dust3r_matrices does before it calls imcui_hip_dust3r_pack_weights) -- the device only normalises -- and the
+ * row sums of the folded matrices sit behind the vectors.  The buffer ends in a 64-word trailer (magic 'IMDU', format number, total
+ * size, the five configuration integers).  `packed_floats` of the forward entry points = the size of the caller's buffer: anything but
+ * imcui_hip_dust3r_packed_floats() of the configuration is refused with IMCUI_HIP_ERR_ARG (a blob cached from an older library would
+ * otherwise run with its affine parts dropped and return plausible but wrong point maps); imcui_hip_dust3r_check_packed verifies
+ * size AND trailer of a HOST copy (0 = fine) -- call it once when a cached blob is loaded. */
+int imcui_hip_dust3r_format_version(void);
+int imcui_hip_dust3r_check_packed(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed_host, size_t packed_floats);
 size_t imcui_hip_dust3r_workspace_bytes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);
 size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, int P, int H, int W);
 /* `AsymmetricCroCo3DStereo.forward(view1, view2)` for P directed pairs over NI images: images [dev, NI,3,H,W] in [0,1] (the
@@ -300,7 +320,7 @@ size_t imcui_hip_dust3r_dump_floats(int enc_dim, int enc_depth, int dec_dim, int
  * convolutions with f32 accumulation (the class of the bf16 run the reference's configuration names; since round 3 attention too: hi planes of Q / K / V, P rounded to f16).
  * The handle must be in the split mode (IMCUI_ERR_UNSUPPORTED in precision 0). */
 int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
-                             const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d, float* conf,
+                             size_t packed_floats, const float* images, int NI, int H, int W, const int* pairs, int P, int arith, float* pts3d, float* conf,
                              float* desc, float* desc_conf, float* dump, size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
 
 /* The same network on images of SEVERAL sizes.  imcui/hloc/match_dense.py:match_images and ImagePairDataset.preprocess resize
@@ -317,7 +337,7 @@ int imcui_hip_dust3r_forward(imcui_hip_t* h, int enc_dim, int enc_depth, int dec
 size_t imcui_hip_dust3r_workspace_bytes_sizes(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, const int* sizes, int P);
 size_t imcui_hip_dust3r_token_dump_floats(int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, int NI, const int* sizes, int P);
 int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, int dec_dim, int dec_depth, int desc_dim, const float* packed,
-                                   const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
+                                   size_t packed_floats, const float* images, int NI, const int* sizes, const int* pairs_host, const int* pairs, int P, int arith,
                                    float* pts3d, float* conf, float* desc, float* desc_conf, size_t* map_pixel_offsets, float* dump,
                                    size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
 

@@ -6,8 +6,6 @@
   statistics pass, and both against the oracle through the existing parity tests.
 * attention priority variants are scheduling only: bitwise equal outputs.
 """
-import os
-
 import pytest
 import torch
 
@@ -18,24 +16,9 @@ pytestmark = pytest.mark.gpu
 LSD = lightglue_state_dict(0)
 
 
-class _env:
-    def __init__(self, **kw):
-        self.kw = kw
+from imcui_hip import backend  # noqa: E402  (ctypes bindings only: importing it does not load the library)
 
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        for k, v in self.kw.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+dev = torch.device("cuda:0")  # the A/B switches live in the per-device handle: backend.option(dev, name=value)
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(300, 256, 256, False), (4800, 768, 256, True), (1000, 512, 512, False), (130, 256, 32, False),
@@ -49,9 +32,9 @@ def test_gemm_wreg_bitwise_equals_split_kernel(M, N, K, relu):
     a = torch.randn(M, K, generator=g).to(dev)
     w = torch.randn(N, K, generator=g) * (1.0 / K**0.5) + torch.arange(N).float()[:, None] * 1e-3
     b = (torch.randn(N, generator=g) * 0.1).to(dev)
-    with _env(IMCUI_GEMM_WREG=0):
+    with backend.option(dev, gemm_wreg=0):
         old = backend.linear_split_f32(a, w, b, relu).cpu()
-    with _env(IMCUI_GEMM_WREG=2):
+    with backend.option(dev, gemm_wreg=2):
         new = backend.linear_split_f32(a, w, b, relu).cpu()
     ref = a.cpu().double() @ w.double().t() + b.cpu().double()
     ref = torch.relu(ref) if relu else ref
@@ -89,9 +72,9 @@ def test_lightglue_projection_kernels_agree(dc, wc):
     off): decisions identical, token states and scores to round-off (the rotary encoding is a different sequence of fused
     multiply-adds in the two kernels; everything else is bitwise equal, see test_attention_layout_projection_planes)."""
     problems = [synthetic_matching_problem(60 + i, n, m, o) for i, (n, m, o) in enumerate(PROBLEMS)]
-    with _env(IMCUI_GEMM_WREG=0):
+    with backend.option(dev, gemm_wreg=0):
         old = _run(dc, wc, problems, dump=True)
-    with _env(IMCUI_GEMM_WREG=2):
+    with backend.option(dev, gemm_wreg=2):
         new = _run(dc, wc, problems, dump=True)
     for b, (n, m, _) in enumerate(PROBLEMS):
         for li in range(old["_layers"].shape[0]):
@@ -111,9 +94,9 @@ def test_lightglue_assignment_epilogue_stats_vs_pass(dc, wc):
     """Soft-max partials from the similarity GEMM's epilogue vs the stand-alone statistics pass: same matches, scores within
     2e-6 (the partial sums are merged in a different grouping: 128-column tiles vs 1024-column chunks)."""
     problems = [synthetic_matching_problem(70 + i, n, m, o) for i, (n, m, o) in enumerate(PROBLEMS)]
-    with _env(IMCUI_LG_ASSIGN_STATS=None):  # default: the stand-alone statistics pass
+    with backend.option(dev, lg_assign_stats=0):  # default: the stand-alone statistics pass
         a = _run(dc, wc, problems)
-    with _env(IMCUI_LG_ASSIGN_STATS="epilogue"):
+    with backend.option(dev, lg_assign_stats=1):
         b = _run(dc, wc, problems)
     for k in ("matches0", "matches1", "stop", "prune0", "prune1"):
         assert torch.equal(a[k], b[k]), k
@@ -146,7 +129,7 @@ def test_attention_layout_projection_planes(cross):
     cnt = cnt.to(dev)
     res = {}
     for mode in (0, 2):
-        with _env(IMCUI_GEMM_WREG=mode):
+        with backend.option(dev, gemm_wreg=mode):
             runs = [backend.qkv_split_f32(x, w, b, cos, sin, cnt, R, 0.18, cross) for _ in range(3)]
         torch.cuda.synchronize()
         for r in runs[1:]:
@@ -189,7 +172,7 @@ def test_attention_priority_variants_bitwise():
     v = torch.randn(S, Hh, R, 64, generator=g).to(dev)
     outs = []
     for var in (0, 1, 2, 3):
-        with _env(IMCUI_ATTN_VARIANT=var):
+        with backend.option(dev, attn_variant=var):
             outs.append(backend.attention_f32(q, k, v, cnt, True, True).cpu())
     for o in outs[1:]:
         assert torch.equal(outs[0], o)

@@ -117,7 +117,7 @@ def test_header_is_c99_and_library_binds_from_plain_c(lib, tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_smoke.c"),
                     "-o", str(exe), "-ldl"], check=True)  # fmt: skip
     out = subprocess.run([str(exe), LIB_PATH], check=True, capture_output=True, text=True).stdout
-    assert "version=100" in out and "lg_tensors=251" in out and "first=posenc.Wr.weight" in out, out
+    assert "version=400" in out and "lg_tensors=251" in out and "first=posenc.Wr.weight" in out, out
 
 
 def test_plugins_follow_the_reference_seam(lib):
@@ -304,3 +304,30 @@ def test_eloftr_upstream_checkpoint_names_round_trip():
         E.upstream_to_port_names({**up, "matcher.backbone.layer9.rbr_dense.conv.weight": torch.zeros(1)})
     with pytest.raises(KeyError, match="must use the upstream names"):
         E.to_port_names({"foo.weight": torch.zeros(1)})
+
+
+def test_lightglue_filter_threshold_is_frozen_at_init_like_the_reference():
+    """imcui/hloc/matchers/lightglue.py:50-51 copies match_threshold into upstream's conf once (`LG(**conf)`); the UI's later mutation
+    of a cached model's conf (imcui/ui/utils.py:921-922) never reaches `filter_matches`.  Default = that behaviour; the opt-in
+    conf["runtime_match_threshold"] = True re-reads the conf on every call."""
+    from imcui_hip.hloc.matchers.lightglue import LightGlue
+    from imcui_hip.synth_weights import lightglue_state_dict
+
+    seen = []
+
+    class Spy:
+        def forward(self, packed, k0, k1, d0, d1, n0, n1, s0, s1, depth, width, thr, **kw):
+            seen.append(thr)
+            return {}
+
+    z = torch.zeros(1, 4, 2), torch.zeros(1, 4, 2), torch.zeros(1, 4, 256), torch.zeros(1, 4, 256), torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+    lg = LightGlue({"match_threshold": 0.3, "state_dict": lightglue_state_dict(0)})
+    lg._impl = Spy()
+    lg.forward_batched(*z, (640, 480), (640, 480))
+    lg.conf["match_threshold"] = 0.05  # what run_matching does to a cached matcher
+    lg.forward_batched(*z, (640, 480), (640, 480))
+    assert seen == [0.3, 0.3]
+    lg.conf["runtime_match_threshold"] = True
+    lg.forward_batched(*z, (640, 480), (640, 480))
+    assert seen[-1] == 0.05
+    assert LightGlue.default_conf["runtime_match_threshold"] is False

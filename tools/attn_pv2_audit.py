@@ -1,0 +1,118 @@
+"""Audit of the reduced-product attention variants (SURVEY hard-part 1: "measure which contractions
+tolerate what; decide per-GEMM with the parity harness").
+
+attn_variant 0 = three products in both contractions (the round-1..3 kernel); 6 = K.Q^T in three products, V^T.P^T as
+(vh + vl) . f16(P) with the normaliser summed over the ROUNDED probabilities; 7 = 6 + K fragments requested one step ahead.
+
+Part 1 -- the kernel alone at the bench shape (64 sequences x 4 heads x 2048 rows): HIP-event time per launch and the largest
+error against a float64 soft-max attention, for flat rows (|q| ~ 0.5 sigma) and for peaked rows (q scaled so that a few keys
+carry the mass: the regime a trained LightGlue runs in, and the worst case for a rounded P).
+Part 2 -- the whole matcher at N = M = 2048 on the three weight sets of tests/test_gpu_lightglue.py: per-layer token-state error
+against the CPU oracle, matches (equal or audited ties), score error.
+
+    python tools/attn_pv2_audit.py > gpurun_out/.../attention_pv2.txt      (GPU box)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-matching-webui_amd"), os.path.join(ROOT, "tests")]
+import torch  # noqa: E402
+
+from imcui_hip import backend  # noqa: E402
+
+dev = torch.device("cuda:0")
+backend.set_precision(dev, 1)
+VARIANTS = [int(v) for v in os.environ.get("AUDIT_VARIANTS", "0,6,7").split(",")]
+
+# ------------------------------------------------------------------ part 1: the kernel alone
+S, Hh, R = 64, 4, 2048
+g = torch.Generator().manual_seed(0)
+k = torch.randn(S, Hh, R, 64, generator=g).to(dev)
+v = torch.randn(S, Hh, R, 64, generator=g).to(dev)
+cnt = torch.full((S,), R, dtype=torch.int32, device=dev)
+ks, vs = backend._split_planes(k), backend._split_planes(v.transpose(2, 3).contiguous())
+hd = backend.get_handle(dev)
+o = torch.zeros((S * R, Hh * 64), dtype=torch.float32, device=dev)
+print(f"# part 1: attn_split_kernel<true, VAR> alone, {S} sequences x {Hh} heads x {R} rows, head_dim 64 (the bench's launch shape)")
+for name, qscale in (("flat rows (q ~ 0.5 N(0,1): ~2000 keys carry the mass)", 0.5), ("peaked rows (q ~ 3 N(0,1): a handful of keys carry the mass)", 3.0)):
+    q = (torch.randn(S, Hh, R, 64, generator=torch.Generator().manual_seed(1)) * qscale).to(dev)
+    qs = backend._split_planes(q * 1.4426950408889634)
+    att = (torch.softmax(q[:2].double() @ k[:2].double().transpose(-1, -2), -1) @ v[:2].double()).float()
+    for cross in (0, 1):
+        for var in VARIANTS:
+            backend.set_option(dev, "attn_variant", var)
+
+            def run():
+                hd.check(hd.lib.imcui_hip_attention_f32(hd.h, backend._ptr(qs), backend._ptr(ks), backend._ptr(vs), backend._ptr(o), backend._ptr(cnt), S, Hh, R, cross, 1,
+                                                        backend._stream_ptr()), "attention")  # fmt: skip
+
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 30
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            flops = S * Hh * 2 * 2 * R * R * 64
+            line = f"  {name}  cross={cross} variant={var}: {ms * 1e3:7.1f} us / launch, {flops / ms / 1e9:6.1f} algorithmic TFLOP/s"
+            if cross == 0:
+                err = (o.view(S, R, Hh, 64)[:2].permute(0, 2, 1, 3) - att).abs().max().item()
+                line += f", max |error| vs float64 {err:.2e} (|O| max {att.abs().max().item():.2f})"
+            print(line, flush=True)
+del k, v, ks, vs, o, q, qs
+
+# ------------------------------------------------------------------ part 2: the matcher on the three weight sets
+from oracle.lightglue import LightGlueOracle  # noqa: E402
+from imcui_hip.hloc.matchers.lightglue import LightGlue  # noqa: E402
+from imcui_hip.synth_weights import lightglue_state_dict  # noqa: E402
+from parity_utils import assert_matches_equal_or_tied, synthetic_matching_problem  # noqa: E402
+
+torch.set_num_threads(min(os.cpu_count() or 1, 32))
+WEIGHTS = {"damped": lightglue_state_dict(0), "strong": lightglue_state_dict(0, damp=0.1, ln_noise=0.1, final_gain=10.0),
+           "random": lightglue_state_dict(1, structured=False)}  # fmt: skip
+IMG = torch.zeros(1, 1, 480, 640)
+problems = [synthetic_matching_problem(40, 2048, 2048, 300), synthetic_matching_problem(41, 2048, 1900, 250)]
+B = len(problems)
+k0, k1, d0, d1 = torch.zeros(B, 2048, 2), torch.zeros(B, 2048, 2), torch.zeros(B, 2048, 256), torch.zeros(B, 2048, 256)
+n0, n1 = torch.zeros(B, dtype=torch.int32), torch.zeros(B, dtype=torch.int32)
+for b, (a, c, e, f) in enumerate(problems):
+    k0[b, : len(a)], k1[b, : len(c)], d0[b, : len(a)], d1[b, : len(c)] = a, c, e, f
+    n0[b], n1[b] = len(a), len(c)
+print("# part 2: LightGlue at N = M = 2048 (depth = width = -1: all 9 layers), HIP vs the CPU oracle; layer error = max |token - oracle| / max |oracle| over the 9 layers x 2 images")
+for wname, sd in WEIGHTS.items():
+    ora = LightGlueOracle(sd, dict(depth_confidence=-1, width_confidence=-1, filter_threshold=0.1))
+    refs = [ora({"image0": IMG, "image1": IMG, "keypoints0": a[None], "keypoints1": c[None], "descriptors0": e.t()[None], "descriptors1": f.t()[None]},
+                return_intermediates=True) for (a, c, e, f) in problems]  # fmt: skip
+    model = LightGlue({"depth_confidence": -1, "width_confidence": -1, "match_threshold": 0.1, "state_dict": sd}).eval().to(dev)
+    for var in VARIANTS:
+        backend.set_option(dev, "attn_variant", var)
+        out = model.forward_batched(k0.cuda(), k1.cuda(), d0.cuda(), d1.cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480), layer_dump=True)
+        torch.cuda.synchronize()
+        dump = out.pop("_layers")
+        out = {kk: vv.cpu() for kk, vv in out.items()}
+        for b, ((a, c, e, f), ref) in enumerate(zip(problems, refs)):
+            na = len(a)
+            per_layer = []
+            for li, (r0, r1) in enumerate(ref["_layers"]):
+                errs = []
+                for s, r in enumerate((r0[0], r1[0])):
+                    got = dump[li, 2 * b + s, : r.shape[0]].cpu()
+                    errs.append((got - r).abs().max().item() / max(r.abs().max().item(), 1e-30))
+                per_layer.append(max(errs))
+            tol = 1e-4 * max(1.0, ref["_sim"].abs().max().item() / 100.0)
+            try:
+                ties = assert_matches_equal_or_tied(out["matches0"][b, :na], ref["_log_assignment"][0], ref["matches0"][0], 0.1, tol=tol, tag=f"{wname} pair {b} variant {var}",
+                                                    ind0=ref.get("_ind0"), ind1=ref.get("_ind1"))  # fmt: skip
+                mstat = f"matches equal ({ties} audited ties)"
+            except AssertionError as ex:
+                mstat = f"MATCHES DIFFER: {str(ex)[:120]}"
+            same = out["matches0"][b, :na].long() == ref["matches0"][0]
+            serr = (out["matching_scores0"][b, :na] - ref["matching_scores0"][0]).abs()[same].max().item()
+            print(f"  {wname:7s} pair {b} variant={var}: worst layer error {max(per_layer):.2e} (per layer: {' '.join(f'{x:.1e}' for x in per_layer)}); "
+                  f"{int((ref['matches0'] > -1).sum())} matches, {mstat}; max score error {serr:.2e} (bar {tol:.1e}); |sim| max {ref['_sim'].abs().max().item():.0f}", flush=True)
+backend.set_option(dev, "attn_variant", 0)

@@ -1,4 +1,8 @@
-"""Plane-level A/B of the attention-layout projection: gemm_split_kernel (IMCUI_GEMM_WREG=0) vs gemm_wreg_kernel, repeatability."""
+"""Plane-level A/B of the attention-layout projection: gemm_split_kernel (option gemm_wreg = 0) vs gemm_wreg_kernel, repeatability.
+
+The reproducer of the packed-f32 code-generation hazard of round 3 (v_pk_fma_f32 with op_sel in the rotary epilogue: wrong even
+elements in lanes 48-63, different from run to run).  tests/test_gpu_round3_kernels.py::test_attention_layout_projection_planes is the
+regression test; this script prints WHERE planes differ when it fails."""
 import os
 import sys
 
@@ -39,7 +43,7 @@ for nseq, R, cross in ((64, 2048, 0), (64, 2048, 1), (3, 256, 0)):
     cnt = torch.full((nseq,), R, dtype=torch.int32).to(dev)
     outs = {}
     for mode in ("0", "2"):
-        os.environ["IMCUI_GEMM_WREG"] = mode
+        backend.set_option(dev, "gemm_wreg", int(mode))
         runs = []
         for rep in range(3):
             q, k, v = backend.qkv_split_f32(x, w, b, cos, sin, cnt, R, 0.18, bool(cross))
