@@ -11,9 +11,12 @@ the wrapper consume it unchanged.  Every image is encoded once (upstream encodes
 
 Host-side steps (duster.py:74-108).  `global_aligner(mode=PairViewer)` (focal estimation + `cv2.solvePnPRansac`) is RANSAC
 geometry on the host in the reference and stays there (north_star): `_forward` obtains the scene through `self.aligner(output,
-device)`, by default upstream's own `dust3r.cloud_opt.global_aligner` (the `third_party/dust3r` submodule of the reference
-checkout; a clear ImportError when it is not installed -- neither the package nor cv2 exist offline).  Everything AFTER the
-aligner is restated here and needs nothing of upstream's: confidence masks -> pixel grids (`xy_grid`) -> reciprocal 3-D nearest
+device)` -- upstream's own `dust3r.cloud_opt.global_aligner` when the `third_party/dust3r` submodule of the reference checkout is
+importable, otherwise (round 4) the host-side restatement of PairViewer for one symmetrised pair, `pair_viewer.PairViewerScene`
+(Weiszfeld focal per image, relative pose from a seeded numpy PnP-RANSAC with upstream's 100 iterations / 5 px rule, masks =
+max-over-edges confidence > 3, depth maps re-projected through the recovered pinholes; parity unpinned -- neither upstream's
+package nor cv2 exist offline -- tested against ground-truth geometry in tests/test_pair_viewer_cpu.py), so `_forward` needs nothing of
+upstream's.  Everything AFTER the aligner is restated here as well: confidence masks -> pixel grids (`xy_grid`) -> reciprocal 3-D nearest
 neighbours (`find_reciprocal_matches`: two KD-trees, image-1 points whose nearest image-0 point names them back) -> the
 `np.linspace` sub-sampling to `max_keypoints` (`matches_from_scene`; tested on CPU against the brute-force restatement
 `oracle/dust3r.py: duster_matches_from_scene` with the aligner mocked).
@@ -120,15 +123,17 @@ class Duster(BaseModel):
 
     @staticmethod
     def aligner(output: dict, device):
-        """duster.py:74: `global_aligner(output, device=device, mode=GlobalAlignerMode.PairViewer)` -- upstream's package (host
-        geometry: focal estimation, cv2.solvePnPRansac).  Replaceable (tests mock it; a deployment may bind its own)."""
+        """duster.py:74: `global_aligner(output, device=device, mode=GlobalAlignerMode.PairViewer)`.  Upstream's package (host geometry:
+        focal estimation, cv2.solvePnPRansac) when it is importable -- the reference's own code then runs unchanged; otherwise the
+        host-side restatement of PairViewer for one symmetrised pair (`pair_viewer.PairViewerScene`: same focal estimator, same
+        confidence rule, a seeded numpy PnP-RANSAC in place of cv2's; parity unpinned, see its docstring), so that `_forward` stands
+        alone on a machine without third_party/dust3r.  Replaceable (tests mock it; a deployment may bind its own)."""
         try:
             from dust3r.cloud_opt import GlobalAlignerMode, global_aligner
-        except ImportError as e:
-            raise ImportError(
-                "the DUSt3R network ran on the HIP backend (see inference_output()); the pose step of imcui/hloc/matchers/duster.py:74 "
-                "(global_aligner, PairViewer) uses upstream's `dust3r` package (third_party/dust3r) and cv2, which are not installed"
-            ) from e
+        except ImportError:
+            from .pair_viewer import PairViewerScene
+
+            return PairViewerScene(output)
         return global_aligner(output, device=device, mode=GlobalAlignerMode.PairViewer)
 
     def matches_from_scene(self, imgs, masks, pts3d) -> dict:

@@ -288,8 +288,11 @@ def test_dust3r_plugin_output_structure():
     swapped = model.inference_output({"image0": i1.cuda(), "image1": i0.cuda()})
     assert torch.equal(swapped["pred1"]["pts3d"][0], out["pred1"]["pts3d"][1])
     assert torch.equal(swapped["pred2"]["conf"][1], out["pred2"]["conf"][0])
-    with pytest.raises(ImportError):
-        model({"image0": i0.cuda(), "image1": i1.cuda()})  # the host-side aligner of upstream is not installed here
+    # `_forward` stands alone since round 4: without upstream's package the aligner is the host-side PairViewer restatement
+    # (imcui_hip/hloc/matchers/pair_viewer.py); random weights give arbitrary geometry, so only the contract is checked here
+    pred = model({"image0": i0.cuda(), "image1": i1.cuda()})
+    assert set(pred) == {"keypoints0", "keypoints1"} and pred["keypoints0"].shape == pred["keypoints1"].shape and pred["keypoints0"].shape[1] == 2
+    assert len(pred["keypoints0"]) <= model.conf["max_keypoints"]
 
 
 def test_dust3r_full_model_512():
