@@ -744,9 +744,9 @@ def bench_dust3r(args, dev, rank, world):
             rec, ref = _DUST3R_CPU[ck]
             if not args.no_parity:
                 # parity of pair 0 with the oracle run timed for cpu_baseline (batch entries in make_pairs' order: (image1, image0), (image0, image1)).
-                # fp32 (3 x f16 split) = the parity mode: 5e-4 of the scene scale; fp16 (one product, bf16-class, NOT a parity mode): the 5e-3
+                # fp32 (3 x f16 split) = the parity mode: 1e-4 of the scene scale (measured 1.1e-5); fp16 (one product, bf16-class, NOT a parity mode): the 5e-3
                 # bar of tests/test_gpu_dust3r.py, which also anchors it below a bf16-autocast run of the oracle
-                bar = 5e-4 if args.arith == "fp32" else 5e-3
+                bar = 1e-4 if args.arith == "fp32" else 5e-3
                 got = model.forward_pairs(images[:2], [[1, 0], [0, 1]])
                 worst = 0.0
                 for v, key in ((0, "pred1"), (1, "pred2")):

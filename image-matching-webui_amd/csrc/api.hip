@@ -61,7 +61,7 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         const char* e;
         h->opt[OPT_GEMM_WREG] = (e = getenv("IMCUI_GEMM_WREG")) ? atoi(e) : 2;
         h->opt[OPT_WREG_PIPE] = (e = getenv("IMCUI_WREG_PIPE")) ? atoi(e) : 1;
-        h->opt[OPT_ATTN_VARIANT] = (e = getenv("IMCUI_ATTN_VARIANT")) ? atoi(e) : 0;
+        h->opt[OPT_ATTN_VARIANT] = (e = getenv("IMCUI_ATTN_VARIANT")) ? atoi(e) : 8;  // 8 = the arithmetic of 0 with the pipelined K.Q^T schedule (attention.hip)
         h->opt[OPT_LG_ASSIGN_STATS] = ((e = getenv("IMCUI_LG_ASSIGN_STATS")) && (strcmp(e, "epilogue") == 0 || atoi(e) == 1)) ? 1 : 0;
     }
     *out = h;

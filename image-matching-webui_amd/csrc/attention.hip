@@ -251,12 +251,18 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // instruction count as the packed adds it replaces), so O = sum p~_j v_j / sum p~_j is an exact weighted mean with weights perturbed
 // by at most 2^-12 relative: the error is sum_j p_j e_j (v_j - O) -- it vanishes for a peaked row (one dominant key: v_j = O) and
 // averages down like 1 / sqrt(n) for a flat one; the worst case is two equal keys with different values, 2^-13 |v_0 - v_1|.
-// Measured against the per-layer parity harness in profiles/r04_lab_attention_pv2.txt.
+// Measured against the per-layer parity harness in profiles/r04_lab_attention_pv2.txt: 13-19 % faster per launch, per-layer error
+// 0.6-1.4e-6 -> 0.8-2.1e-5 and score error 2e-5 -> 9e-5 on the "strong" weight set -- at the edge of the 1e-4 bar, so NOT the default;
+// kept as an opt-in (attn_variant 6 / 7).
+// VAR 7 = VAR 6 + VAR 8's schedule.  VAR 8 (round 4, the default since then): the arithmetic of VAR 0 bit for bit (same products, same
+// order), with the K fragments of step i + 1 requested before the MFMAs of step i (hipcc's own schedule is read -> wait -> 3 MFMAs on
+// one register quad, every LDS latency exposed), the maximum of the first S fragment taken under the MFMAs of the second, and the
+// cross-half maximum by v_permlane32_swap instead of ds_bpermute.
 template <bool L2D, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     constexpr bool SINGLE = (VAR == 4);
     constexpr bool PV2 = (VAR == 6 || VAR == 7);  // P rounded to f16, V split: two products per element pair in V^T.P^T
-    constexpr bool KPRE = (VAR == 7);             // + the K fragments of step i + 1 requested before the MFMAs of step i
+    constexpr bool KPRE = (VAR == 7 || VAR == 8);  // the K fragments of step i + 1 requested before the MFMAs of step i (8: with three products = bitwise variant 0)
     // VAR 5: the K / V^T tile double-buffered in LDS (70 KB per workgroup, still two per CU): the next tile is written into the other
     // buffer right after this tile's MFMAs, ONE workgroup barrier per key tile instead of two
     constexpr bool DBUF = (VAR == 5);
@@ -459,7 +465,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         for (int f = (KPRE && !TAIL) ? 1 : 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, s[f][r]);
-        m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        if constexpr (KPRE) {
+            // the other half-wave's maximum by v_permlane32_swap (one vector instruction) instead of ds_bpermute + lgkmcnt(0)
+            // (inline asm: hipcc 7.2 folds fmaxf(r[0], r[1]) of __builtin_amdgcn_permlane32_swap away -- it keeps the swap and drops
+            // the second result -- which left each half-wave with the LOWER half's maximum; found in the ISA before it ever ran)
+            float ma = m_t, mb = m_t;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(ma), "+v"(mb));
+            m_t = ma;
+        } else {
+            m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
+        }
         f32x2 la = {0.0f, 0.0f}, lb = {0.0f, 0.0f};
         if constexpr (!l2d) {
             // natural-log operands (building-block entry point): p * 2^14 = exp2(s*log2e - m*log2e + 14), one fma + one v_exp_f32
@@ -696,6 +711,8 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
             hipLaunchKernelGGL((attn_split_kernel<true, 6>), grid, dim3(256), 0, stream, p);
         else if (var == 7)
             hipLaunchKernelGGL((attn_split_kernel<true, 7>), grid, dim3(256), 0, stream, p);
+        else if (var == 8)
+            hipLaunchKernelGGL((attn_split_kernel<true, 8>), grid, dim3(256), 0, stream, p);
         else if (var == 5)
             hipLaunchKernelGGL((attn_split_kernel<true, 5>), grid, dim3(256), 0, stream, p);
         else if (var == 1)

@@ -171,7 +171,7 @@ def test_attention_priority_variants_bitwise():
     k = torch.randn(S, Hh, R, 64, generator=g).to(dev)
     v = torch.randn(S, Hh, R, 64, generator=g).to(dev)
     outs = []
-    for var in (0, 1, 2, 3):
+    for var in (0, 1, 2, 3, 8):  # scheduling only: wave priorities, the pipelined K.Q^T of round 4 (the default)
         with backend.option(dev, attn_variant=var):
             outs.append(backend.attention_f32(q, k, v, cnt, True, True).cpu())
     for o in outs[1:]:

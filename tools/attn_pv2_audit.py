@@ -2,7 +2,8 @@
 tolerate what; decide per-GEMM with the parity harness").
 
 attn_variant 0 = three products in both contractions (the round-1..3 kernel); 6 = K.Q^T in three products, V^T.P^T as
-(vh + vl) . f16(P) with the normaliser summed over the ROUNDED probabilities; 7 = 6 + K fragments requested one step ahead.
+(vh + vl) . f16(P) with the normaliser summed over the ROUNDED probabilities; 7 = 6 + K fragments requested one step ahead;
+8 = the arithmetic of 0 with the schedule of 7 (bitwise equal to 0).
 
 Part 1 -- the kernel alone at the bench shape (64 sequences x 4 heads x 2048 rows): HIP-event time per launch and the largest
 error against a float64 soft-max attention, for flat rows (|q| ~ 0.5 sigma) and for peaked rows (q scaled so that a few keys
@@ -23,7 +24,7 @@ from imcui_hip import backend  # noqa: E402
 
 dev = torch.device("cuda:0")
 backend.set_precision(dev, 1)
-VARIANTS = [int(v) for v in os.environ.get("AUDIT_VARIANTS", "0,6,7").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("AUDIT_VARIANTS", "0,8,6,7").split(",")]
 
 # ------------------------------------------------------------------ part 1: the kernel alone
 S, Hh, R = 64, 4, 2048
@@ -115,4 +116,4 @@ for wname, sd in WEIGHTS.items():
             serr = (out["matching_scores0"][b, :na] - ref["matching_scores0"][0]).abs()[same].max().item()
             print(f"  {wname:7s} pair {b} variant={var}: worst layer error {max(per_layer):.2e} (per layer: {' '.join(f'{x:.1e}' for x in per_layer)}); "
                   f"{int((ref['matches0'] > -1).sum())} matches, {mstat}; max score error {serr:.2e} (bar {tol:.1e}); |sim| max {ref['_sim'].abs().max().item():.0f}", flush=True)
-backend.set_option(dev, "attn_variant", 0)
+backend.set_option(dev, "attn_variant", 8)
