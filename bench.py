@@ -846,6 +846,18 @@ def bench_superglue(args, dev, rank, world):
     return None
 
 
+def _pil_luma(blob: bytes):
+    """PIL's (libjpeg's) gray decode of a JPEG file = its luma plane: what cv2.imread(IMREAD_GRAYSCALE) returns."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    im = Image.open(io.BytesIO(blob))
+    im.draft("L", im.size)
+    return np.array(im)
+
+
 def ensure_built() -> None:
     """Build libimcui_hip.so when it is missing or older than its sources (no-op otherwise).  `imcui_hip.build.build` takes an exclusive
     file lock, so the N ranks of one launch on a clean checkout compile once and the others wait."""
@@ -1003,7 +1015,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of one pair after the timed region (profiler passes)")
     ap.add_argument("--graph", action="store_true", help="splg: replay the step from a captured HIP graph (small-batch latency)")
-    ap.add_argument("--h2d", action="store_true", help="splg: the uint8 images of every step are uploaded from pinned host memory inside the timed "
+    ap.add_argument("--decode-threads", type=int, default=32, help="--h2d jpeg: host threads of the Huffman stage")
+    ap.add_argument("--h2d", nargs="?", const="raw", default=None, choices=["raw", "jpeg"],
+                    help="splg: `--h2d` / `--h2d raw`: the uint8 images of every step are uploaded from pinned host memory inside the timed "
                                                        "region (the PCIe-inclusive rate quoted in DESIGN.md; never the headline `value`)")
     ap.add_argument("--workload", default="splg", choices=["splg", "nn", "loftr", "eloftr", "dust3r", "mast3r", "superpoint", "superglue", "launchcheck"],
                     help="splg = BASELINE metric (SuperPoint+LightGlue 640x480); nn = configs[0] mutual-NN matcher on 5000 x 128-d descriptors; loftr = configs[3] LoFTR dense matcher; "
@@ -1086,7 +1100,41 @@ def bench_splg(args, dev, rank, world):
 
             run = GraphedPipeline(pipe, img0, img1)
 
-        if args.h2d:
+        if args.h2d == "jpeg":
+            # what a caller that holds JPEG FILES pays: per step the 2 B files are entropy-decoded on host threads,
+            # the luma coefficients travel over PCIe, and the pixels are reconstructed on the device (csrc/jpeg.hip: bit-exact libjpeg
+            # arithmetic), one step ahead of the compute stream on a side stream driven by a feeder thread
+            import io
+            from concurrent.futures import ThreadPoolExecutor
+
+            from PIL import Image
+
+            from imcui_hip.hloc.utils.jpeg import JpegDecoder
+
+            def to_jpeg(im):  # the synthetic scene as a colour photograph would be stored: 3 components, 4:2:0, quality 90
+                g = (im[0] * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+                buf = io.BytesIO()
+                Image.fromarray(g).convert("RGB").save(buf, "JPEG", quality=90, subsampling="4:2:0")
+                return buf.getvalue()
+
+            blobs = [to_jpeg(im) for im in img0] + [to_jpeg(im) for im in img1]
+            jdec = JpegDecoder(dev, threads=args.decode_threads)
+            side = torch.cuda.Stream(device=dev)
+            feeder = ThreadPoolExecutor(max_workers=1)
+            fstate = {"next": None}
+
+            def prepare():
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):
+                    imgs = jdec.decode_batch(blobs, True)
+                    batch = torch.stack(imgs)  # [2B,H,W] uint8 = the luma planes (what cv2.IMREAD_GRAYSCALE returns)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return batch, ev
+
+            host = None
+            fstate["next"] = feeder.submit(prepare)
+        elif args.h2d:
             # what a caller that holds decoded images in host memory pays: 2 B uint8 images per step over PCIe on a side stream, one step
             # ahead of the compute stream (two device buffers), then u8 -> f32 / 255 on the device
             host = [(im * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory() for im in (img0, img1)]
@@ -1108,7 +1156,15 @@ def bench_splg(args, dev, rank, world):
             upload(0)
 
         def step():
-            if args.h2d:
+            if args.h2d == "jpeg":
+                batch, ev = fstate["next"].result()
+                fstate["next"] = feeder.submit(prepare)  # the next step's files are decoded while this step computes
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                batch.record_stream(cur)
+                f = batch.float().div_(255.0)[:, None]
+                out = run(f[:B], f[B:])
+            elif args.h2d:
                 k = state["i"] & 1
                 state["i"] += 1
                 upload(k ^ 1)  # next step's images travel while this step computes
@@ -1144,6 +1200,11 @@ def bench_splg(args, dev, rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.h2d == "jpeg":  # the feeder is one step ahead: drain it before the parity check uses the device
+        fstate["next"].result()
+        torch.cuda.synchronize()
+        feeder.shutdown()
+        jdec.close()
     attn_ms, attn_n = backend.profile_read(dev, "attention")
     conv_ms, conv_n = backend.profile_read(dev, "conv3x3")
     gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
@@ -1199,9 +1260,10 @@ def bench_splg(args, dev, rank, world):
             "data": "synthetic",
             "config": {
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs "
-                            + ("uploaded as uint8 from pinned host memory inside the timed region (PCIe-inclusive; NOT the headline value)" if args.h2d else "resident in HBM"),
+                            + ("decoded from JPEG files inside the timed region: Huffman on host threads, coefficients over PCIe, pixels reconstructed on the device (NOT the headline value)" if args.h2d == "jpeg" else
+                               "uploaded as uint8 from pinned host memory inside the timed region (PCIe-inclusive; NOT the headline value)" if args.h2d else "resident in HBM"),
                 "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), async all-gather of match tables",
-                "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "h2d_inside_timed_region": bool(args.h2d), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
+                "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "h2d_inside_timed_region": args.h2d or False, **({"decode_threads": args.decode_threads, "jpeg_bytes_per_image": sum(len(b) for b in blobs) / len(blobs)} if args.h2d == "jpeg" else {}), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
                 "weights": "seeded random (imcui_hip/synth_weights.py), real architecture",
             },
             "roofline": {
@@ -1217,7 +1279,11 @@ def bench_splg(args, dev, rank, world):
         }  # fmt: skip
         if not args.no_parity:
             # (with --h2d the device saw the images quantised to uint8: the oracle gets the same values)
-            pa, pb = ((h.float() / 255.0).to(dev) for h in host) if args.h2d else (img0, img1)
+            if args.h2d == "jpeg":  # the device saw PIL-identical luma planes of the files: the oracle gets PIL's own decode
+                dec8 = torch.stack([torch.from_numpy(_pil_luma(b)) for b in blobs[:4] + blobs[B : B + 4]])
+                pa, pb = (dec8[:4].float() / 255.0)[:, None].to(dev), (dec8[4:].float() / 255.0)[:, None].to(dev)  # (the four pairs the parity check reads)
+            else:
+                pa, pb = ((h.float() / 255.0).to(dev) for h in host) if args.h2d else (img0, img1)
             line["parity"] = parity_splg(pipe, pa, pb, dc, wc, which=sorted({0, 1 % B, 2 % B, 3 % B}))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

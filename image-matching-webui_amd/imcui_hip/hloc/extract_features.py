@@ -5,7 +5,8 @@ per `forward_batched` call and the preprocessing on the device:
 
   * image list / skipping of already exported names: `ImageDataset.__init__` (:53-77) and `list_h5_names`
     (utils/io.py:24-37) semantics;
-  * preprocessing (`ImageDataset.__getitem__` :79-103): decode (host, PIL or cv2), gray conversion, optional
+  * preprocessing (`ImageDataset.__getitem__` :79-103): decode (baseline JPEG: Huffman on the host, pixels on the device, bit-exact
+    against libjpeg -- `read_image_device`, utils/jpeg.py; other formats: host, PIL or cv2), gray conversion, optional
     `resize_max` / `force_resize` with "cv2_area" interpolation, `/ 255` -- the arithmetic runs on the GPU
     (`backend.preprocess_area`: cv2's 8-bit RGB2GRAY fixed point + INTER_AREA decimation + float32 division);
   * images of equal preprocessed size are batched; key-points are mapped back to the original resolution with
@@ -92,6 +93,33 @@ def read_image_u8(path, grayscale: bool = False) -> np.ndarray:
     return np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy); gray conversion runs on the device
 
 
+def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> torch.Tensor:
+    """`read_image(path, grayscale)` with the result on the device: uint8 [H,W] (grayscale) or [H,W,3] RGB.
+    decode = "auto": a baseline JPEG goes through the library's decoder -- Huffman on the host, inverse DCT / up-sampling / colour on the
+    device, bit-exact against libjpeg's default path (utils/jpeg.py); with `grayscale` the result is the file's luma plane, which is
+    what the reference's `cv2.imread(IMREAD_GRAYSCALE)` returns for a JPEG.  Files that path does not take (PNG, progressive or CMYK
+    JPEG, EXIF-rotated ...) are read on the host (`read_image_u8`) and uploaded.  "host": always the host reader; "device": refuse
+    instead of falling back."""
+    if decode not in ("auto", "host", "device"):
+        raise ValueError(f"decode = {decode!r}: auto | host | device")
+    if decode != "host":
+        from .utils.jpeg import JpegUnsupported, decode_jpeg, is_jpeg
+
+        try:
+            data = Path(path).read_bytes()
+        except OSError as e:
+            raise ValueError(f"Cannot read image {path}.") from e
+        if is_jpeg(data):
+            try:
+                return decode_jpeg(data, grayscale, device)
+            except JpegUnsupported:
+                if decode == "device":
+                    raise
+        elif decode == "device":
+            raise ValueError(f"{path}: not a JPEG file (decode='device')")
+    return torch.from_numpy(read_image_u8(path, grayscale)).to(device)
+
+
 def image_names(root: Path, conf: SimpleNamespace, paths=None) -> List[str]:
     """`ImageDataset.__init__` (:53-77): glob the root or take an explicit list; every name must exist."""
     root = Path(root)
@@ -121,20 +149,20 @@ def target_size(size, conf: SimpleNamespace):
     return None
 
 
-def preprocess_on_device(img_u8: np.ndarray, conf: SimpleNamespace, device) -> torch.Tensor:
-    """uint8 [H,W] / [H,W,3] (host) -> float32 [1,1,h,w] in [0,1] on the device, following :79-99."""
+def preprocess_on_device(img_u8, conf: SimpleNamespace, device) -> torch.Tensor:
+    """uint8 [H,W] / [H,W,3] (host array or device tensor) -> float32 [1,1,h,w] in [0,1] on the device, following :79-99."""
     if not conf.grayscale:
         raise NotImplementedError("the HIP extractors take gray images (SuperPoint conf `grayscale: True`)")
     if conf.interpolation != "cv2_area":
         raise NotImplementedError(f"interpolation {conf.interpolation!r}: only cv2_area runs on the device")
-    t = torch.from_numpy(img_u8).to(device)[None]
-    h, w = img_u8.shape[:2]
+    t = (img_u8 if torch.is_tensor(img_u8) else torch.from_numpy(img_u8)).to(device)[None]
+    h, w = t.shape[1:3]
     new = target_size((w, h), conf)
     if new is None:
         new = (w, h)
     if new[0] > w or new[1] > h:
         return backend.preprocess_linear(t, new)  # resize_image :29-31: INTER_AREA becomes INTER_LINEAR as soon as a side grows
-    if new == (w, h) and img_u8.ndim == 3:
+    if new == (w, h) and t.dim() == 4:
         return backend.rgb_to_gray(t) if (h * w) % 4 == 0 else backend.preprocess_area(t, new)
     return backend.preprocess_area(t, new)
 
@@ -142,9 +170,10 @@ def preprocess_on_device(img_u8: np.ndarray, conf: SimpleNamespace, device) -> t
 @torch.no_grad()
 def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half: bool = True,
          image_list: Optional[Union[Path, Sequence[str]]] = None, feature_path: Optional[Path] = None, overwrite: bool = False,
-         model=None, batch_size: int = 32, device="cuda") -> Path:  # fmt: skip
-    """Reference signature (:174-182) + `model` (a loaded HIP extractor plugin; built from conf["model"] when None) and
-    `batch_size` (images per C-ABI call).  Returns the feature file path."""
+         model=None, batch_size: int = 32, device="cuda", decode: str = "auto") -> Path:  # fmt: skip
+    """Reference signature (:174-182) + `model` (a loaded HIP extractor plugin; built from conf["model"] when None),
+    `batch_size` (images per C-ABI call) and `decode` (`read_image_device`: "auto" = baseline JPEGs decoded on the device).  Returns
+    the feature file path."""
     pconf = SimpleNamespace(**{**DEFAULT_PREPROCESSING, **conf.get("preprocessing", {})})
     image_dir = Path(image_dir)
     names = image_names(image_dir, pconf, image_list)
@@ -199,8 +228,8 @@ def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half
                 grp["keypoints"].attrs["uncertainty"] = uncertainty
 
     for name in names:
-        img_u8 = read_image_u8(image_dir / name, pconf.grayscale)
-        original_size = np.array(img_u8.shape[:2][::-1])
+        img_u8 = read_image_device(image_dir / name, pconf.grayscale, device, decode)
+        original_size = np.array(tuple(img_u8.shape[:2][::-1]))
         img = preprocess_on_device(img_u8, pconf, device)
         key = tuple(img.shape[-2:])
         pending.setdefault(key, []).append((name, img, original_size))

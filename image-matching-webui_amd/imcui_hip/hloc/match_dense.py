@@ -25,18 +25,18 @@ import numpy as np
 import torch
 
 from .. import backend
-from .extract_features import preprocess_on_device, read_image_u8
+from .extract_features import preprocess_on_device, read_image_device, read_image_u8  # noqa: F401  (read_image_u8: re-exported for callers)
 from .match_features import names_to_pair
 from .utils.h5lite import open_h5
 
 DEFAULT_PREPROCESSING = {"grayscale": True, "resize_max": 1024, "dfactor": 8, "cache_images": False}  # ImagePairDataset.default_conf
 
 
-def preprocess_pair_image(img_u8: np.ndarray, conf: SimpleNamespace, device) -> Tuple[torch.Tensor, np.ndarray]:
-    """uint8 image (host) -> ([1,1,h,w] float32 on the device, scale (x, y) back to the original resolution)."""
+def preprocess_pair_image(img_u8, conf: SimpleNamespace, device) -> Tuple[torch.Tensor, np.ndarray]:
+    """uint8 image (host array or device tensor) -> ([1,1,h,w] float32 on the device, scale (x, y) back to the original resolution)."""
     if not conf.grayscale:
         raise NotImplementedError("the HIP dense matchers take gray images (every dense entry of the zoo sets grayscale: True)")
-    h, w = img_u8.shape[:2]
+    h, w = tuple(img_u8.shape[:2])
     area = SimpleNamespace(grayscale=True, resize_max=conf.resize_max if conf.resize_max and conf.resize_max < max(h, w) else None,
                            force_resize=False, interpolation="cv2_area")  # fmt: skip
     image = preprocess_on_device(img_u8, area, device)
@@ -56,9 +56,10 @@ def _rescale(kpts: torch.Tensor, scale: np.ndarray) -> np.ndarray:
 
 @torch.no_grad()
 def match_dense(conf: Dict, pairs: Sequence[Tuple[str, str]], image_dir: Path, match_path: Path, existing_refs: Iterable[str] = (),
-                model=None, batch_size: int = 8, device="cuda") -> Path:  # fmt: skip
-    """Reference signature (:196-202) + `model` (a loaded HIP dense matcher plugin; built from conf["model"] when None) and
-    `batch_size` (pairs per C-ABI call).  Returns the match file path."""
+                model=None, batch_size: int = 8, device="cuda", decode: str = "auto") -> Path:  # fmt: skip
+    """Reference signature (:196-202) + `model` (a loaded HIP dense matcher plugin; built from conf["model"] when None),
+    `batch_size` (pairs per C-ABI call) and `decode` (extract_features.read_image_device: "auto" = baseline JPEGs decoded on the
+    device).  Returns the match file path."""
     if model is None:
         from . import matchers
         from .utils.base_model import dynamic_load
@@ -75,7 +76,7 @@ def match_dense(conf: Dict, pairs: Sequence[Tuple[str, str]], image_dir: Path, m
         if name not in cache:
             if not pconf.cache_images and len(cache) >= 4 * batch_size:
                 cache.pop(next(iter(cache)))
-            cache[name] = preprocess_pair_image(read_image_u8(image_dir / name, pconf.grayscale), pconf, device)
+            cache[name] = preprocess_pair_image(read_image_device(image_dir / name, pconf.grayscale, device, decode), pconf, device)
         return cache[name]
 
     pending: Dict[tuple, list] = {}

@@ -147,6 +147,11 @@ SIGNATURES = {
     "imcui_hip_nn_argmax_split_workspace_bytes": (C.c_size_t, [C.c_int] * 2),
     "imcui_hip_nn_argmax_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_nn_argmax_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "imcui_hip_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "imcui_hip_jpeg_coef_count": (C.c_size_t, [C.POINTER(C.c_int)]),
+    "imcui_hip_jpeg_entropy_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "imcui_hip_jpeg_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int), C.c_int]),
+    "imcui_hip_jpeg_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_mutual_nn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "imcui_hip_mutual_nn": (
         C.c_int,

@@ -341,6 +341,29 @@ int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, i
                                    float* pts3d, float* conf, float* desc, float* desc_conf, size_t* map_pixel_offsets, float* dump,
                                    size_t dump_floats, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- baseline-JPEG decode (the step before the path) ----------------------------------------------
+ * imcui/hloc/utils/io.py:11-21 `read_image` = cv2.imread(IMREAD_GRAYSCALE | IMREAD_COLOR), called per image by
+ * imcui/hloc/extract_features.py:120-156 and match_dense.py.  Split where the format splits (csrc/jpeg.hip): the Huffman bit stream is
+ * decoded on HOST threads (imcui_hip_jpeg_info / _entropy_decode: re-entrant, no state, no handle), dequantisation + 8x8 inverse DCT +
+ * chroma up-sampling + YCbCr -> RGB run on the DEVICE (imcui_hip_jpeg_reconstruct).  The device arithmetic restates libjpeg's default
+ * path (jpeg_idct_islow, fancy up-sampling, ycc_rgb_convert) integer for integer: outputs equal PIL's / cv2's decode BIT FOR BIT
+ * (oracle/jpeg.py is pinned to PIL on every JPEG of the reference repository).
+ * info [host, 24 ints]: 0 width, 1 height, 2 components (1 | 3), 3 hmax, 4 vmax, 5 MCUs per row, 6 MCU rows, 7 restart interval,
+ * 8 EXIF orientation (1 = upright or absent; the caller applies 2..8 or keeps its host decoder), 9 + 4c .. 11 + 4c: h, v, quantisation
+ * table of component c.  Supported: SOF0 / SOF1 Huffman, 8 bit, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals,
+ * interleaved or per-component scans; everything else (progressive, arithmetic, CMYK, 12 bit, 4:4:0) returns IMCUI_HIP_ERR_UNSUPPORTED. */
+int imcui_hip_jpeg_info(const unsigned char* data, size_t n, int* info);
+/* number of int16 coefficients of all components (every component padded to whole MCUs) */
+size_t imcui_hip_jpeg_coef_count(const int* info);
+/* coef [host, imcui_hip_jpeg_coef_count() int16]: quantised DCT coefficients in natural order, [component][block row][block column][64];
+ * qt [host, 3 x 64 uint16]: the quantisation table of every component, natural order */
+int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n, short* coef, unsigned short* qt);
+size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray);
+/* coef / qt [dev]: copies of the two buffers above; info [host]; out [dev]: gray != 0 -> [H][W] uint8 = the luma plane (what
+ * cv2.IMREAD_GRAYSCALE returns for a YCbCr file), else [H][W][3] RGB (a one-component file replicated, as IMREAD_COLOR does) */
+int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, const unsigned short* qt, const int* info, int gray, unsigned char* out,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /

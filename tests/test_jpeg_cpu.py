@@ -1,0 +1,139 @@
+"""JPEG decode, host side (no GPU): the library's entropy decoder (C++, through the C ABI) and the oracle's restatement of libjpeg's
+reconstruction (oracle/jpeg.py) against PIL's decoder = libjpeg-turbo, the library family behind the reference's `cv2.imread`
+(imcui/hloc/utils/io.py:11-21) -- BIT FOR BIT, RGB and gray: this is what pins the oracle the GPU kernels are then held to."""
+import ctypes as C
+import glob
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from imcui_hip import load_library
+from oracle import jpeg as oj
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_reference_files.npz")
+
+
+def c_entropy(data: bytes):
+    lib = load_library()
+    info = (C.c_int * 24)()
+    assert lib.imcui_hip_jpeg_info(data, len(data), info) == 0
+    coef = np.zeros(lib.imcui_hip_jpeg_coef_count(info), np.int16)
+    qt = np.zeros(192, np.uint16)
+    assert lib.imcui_hip_jpeg_entropy_decode(data, len(data), coef.ctypes.data, qt.ctypes.data) == 0
+    return list(info), coef, qt
+
+
+def oracle_from_coefficients(info, coef, qt, gray):
+    W, H, nc, hmax, vmax, mx, my = info[:7]
+    comps, off = [], 0
+    for c in range(nc):
+        h, v = info[9 + 4 * c], info[10 + 4 * c]
+        n = mx * h * my * v * 64
+        comps.append(dict(h=h, v=v, coef=coef[off : off + n].reshape(my * v, mx * h, 64)))
+        off += n
+    return oj.reconstruct(W, H, comps, [qt[64 * c : 64 * c + 64].astype(np.int64) for c in range(nc)], hmax, vmax, gray)
+
+
+def pil_decode(data: bytes, gray: bool):
+    im = Image.open(io.BytesIO(data))
+    if gray:
+        im.draft("L", im.size)  # libjpeg's JCS_GRAYSCALE output: what cv2.IMREAD_GRAYSCALE returns for a JPEG
+        assert im.mode == "L"
+        return np.array(im)
+    return np.array(im.convert("RGB"))
+
+
+def encode(img, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def smooth_image(seed, h, w, channels=3):
+    g = np.random.default_rng(seed)
+    y, x = np.mgrid[:h, :w]
+    planes = [127 + 90 * np.sin(x / (7.0 + c) + g.uniform(0, 6)) * np.cos(y / (5.0 + 2 * c) + g.uniform(0, 6)) + g.normal(0, 12, (h, w)) for c in range(channels)]
+    a = np.clip(np.stack(planes, -1), 0, 255).astype(np.uint8)
+    return a[..., 0] if channels == 1 else a
+
+
+CASES = [(37, 29, "4:2:0", 85, 0), (64, 48, "4:4:4", 92, 0), (50, 33, "4:2:2", 75, 0), (41, 57, "4:2:0", 60, 3), (16, 16, "4:2:0", 30, 1), (9, 7, "4:2:2", 98, 0),
+         (8, 8, "4:4:4", 100, 0), (1, 1, "4:2:0", 90, 0), (130, 17, "4:2:0", 10, 5)]  # fmt: skip
+
+
+@pytest.mark.parametrize("w,h,sub,q,rst", CASES)
+def test_oracle_and_c_entropy_decoder_equal_pil(w, h, sub, q, rst):
+    """Every supported sampling mode, odd sizes (partial MCUs, 1 x 1), restart intervals, quality 10 .. 100: the pure-Python bit loop
+    and the C++ entropy decoder produce the same coefficients; the restated reconstruction equals PIL bit for bit."""
+    kw = dict(quality=q, subsampling=sub)
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    data = encode(smooth_image(w * 100 + h, h, w), **kw)
+    info, coef, qt = c_entropy(data)
+    assert (info[0], info[1], info[2], info[7] > 0) == (w, h, 3, rst > 0)
+    j = oj.parse(data)
+    assert np.array_equal(np.concatenate([c["coef"].reshape(-1) for c in j["comps"]]), coef)
+    for gray in (False, True):
+        want = pil_decode(data, gray)
+        assert np.array_equal(oj.decode(data, gray), want)
+        assert np.array_equal(oracle_from_coefficients(info, coef, qt, gray), want)
+
+
+def test_gray_files_and_optimised_tables():
+    """One-component files (IMREAD_COLOR replicates them) and optimised Huffman tables (code lengths up to 16 bits)."""
+    for data in (encode(smooth_image(5, 45, 70, 1), quality=80), encode(smooth_image(6, 64, 64), quality=95, optimize=True, subsampling="4:2:0")):
+        info, coef, qt = c_entropy(data)
+        for gray in (False, True):
+            assert np.array_equal(oracle_from_coefficients(info, coef, qt, gray), pil_decode(data, gray))
+
+
+def test_reference_repository_files_fixture():
+    """Six JPEG files of the reference repository (bytes + PIL's decode committed by tests/golden/make_jpeg_fixtures.py)."""
+    z = np.load(GOLD)
+    for i in range(6):
+        data = z[f"bytes{i}"].tobytes()
+        info, coef, qt = c_entropy(data)
+        assert info[8] == 1  # upright
+        assert np.array_equal(oracle_from_coefficients(info, coef, qt, False), z[f"rgb{i}"]), str(z[f"name{i}"])
+        assert np.array_equal(oracle_from_coefficients(info, coef, qt, True), z[f"gray{i}"]), str(z[f"name{i}"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_every_jpeg_of_the_reference_repository():
+    """All 155 JPEG files under /root/reference (tests/data, imcui/datasets: baseline 4:2:0), RGB and gray, against PIL."""
+    files = sorted(sum((glob.glob(f"/root/reference/**/*.{e}", recursive=True) for e in ("jpg", "jpeg", "JPG")), []))
+    assert len(files) >= 100
+    for f in files:
+        data = open(f, "rb").read()
+        info, coef, qt = c_entropy(data)
+        for gray in (False, True):
+            assert np.array_equal(oracle_from_coefficients(info, coef, qt, gray), pil_decode(data, gray)), (f, gray)
+
+
+def test_unsupported_and_damaged_files_are_refused():
+    lib = load_library()
+    info = (C.c_int * 24)()
+    prog = encode(smooth_image(1, 40, 40), quality=80, progressive=True)
+    assert lib.imcui_hip_jpeg_info(prog, len(prog), info) == -4  # IMCUI_HIP_ERR_UNSUPPORTED: the caller keeps its host decoder
+    cmyk = io.BytesIO()
+    Image.fromarray(smooth_image(2, 24, 24)).convert("CMYK").save(cmyk, "JPEG")
+    assert lib.imcui_hip_jpeg_info(cmyk.getvalue(), len(cmyk.getvalue()), info) == -4
+    png = io.BytesIO()
+    Image.fromarray(smooth_image(3, 8, 8)).save(png, "PNG")
+    assert lib.imcui_hip_jpeg_info(png.getvalue(), len(png.getvalue()), info) == -1
+    good = encode(smooth_image(4, 64, 64), quality=80)
+    cut = good[: len(good) // 2]
+    coef = np.zeros(64 * 64 * 3, np.int16)
+    qt = np.zeros(192, np.uint16)
+    assert lib.imcui_hip_jpeg_info(cut, len(cut), info) == 0  # the header is intact ...
+    assert lib.imcui_hip_jpeg_entropy_decode(cut, len(cut), coef.ctypes.data, qt.ctypes.data) in (0, -1)  # ... the scan is short: zeros are fed (libjpeg pads too) or refused, never a crash
+    # EXIF orientation is reported, not applied
+    ex = io.BytesIO()
+    im = Image.fromarray(smooth_image(7, 20, 30))
+    exif = im.getexif()
+    exif[0x0112] = 6
+    im.save(ex, "JPEG", exif=exif)
+    assert lib.imcui_hip_jpeg_info(ex.getvalue(), len(ex.getvalue()), info) == 0 and info[8] == 6
