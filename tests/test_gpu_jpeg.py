@@ -2,6 +2,7 @@
 family behind the reference's `cv2.imread` (imcui/hloc/utils/io.py:11-21): BIT-EXACT, RGB and gray (GPU box only)."""
 import io
 import os
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -99,7 +100,8 @@ def test_extract_features_from_jpeg_files_equals_the_plugin_on_pil_gray(tmp_path
     with open_h5(path, "r") as fd:
         for n in names:
             gray = pil_decode((tmp_path / n).read_bytes(), True)
-            ref = model({"image": torch.from_numpy(gray).to(DEV)[None, None].float() / 255.0})
+            # (the driver's own uint8 -> float32 step, so that both sides feed the extractor the same bits)
+            ref = model({"image": ef.preprocess_on_device(gray, SimpleNamespace(grayscale=True, resize_max=None, force_resize=False, interpolation="cv2_area"), torch.device(DEV))})
             k = np.asarray(fd[n]["keypoints"])
             assert k.shape[0] > 100 and np.array_equal(k, ref["keypoints"][0].cpu().numpy())
             assert np.array_equal(np.asarray(fd[n]["scores"]), ref["scores"][0].cpu().numpy())
