@@ -12,7 +12,7 @@ CSRC = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "..", "include"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
-SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "geometry.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
 # Per-source code-generation switches.  preprocess.hip restates host float32 arithmetic that rounds after every

@@ -364,6 +364,22 @@ size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray);
 int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, const unsigned short* qt, const int* info, int gray, unsigned char* out,
                                void* ws, size_t ws_bytes, void* stream);
 
+/* ---- batched geometric verification (the step after the path) ------------------------------------------------
+ * imcui/ui/utils.py:424-456 `proc_ransac_matches` (cv2.findHomography / findFundamentalMat per pair on the host, called twice per pair by
+ * `compute_geometry` :532-610).  An ADDITIONAL method for the reference's `ransac_zoo` ("HIP_RANSAC"), not a re-implementation of cv2's
+ * USAC samplers: plain RANSAC with local optimisation for B pairs at once, every step specified in csrc/geometry.hip and restated on the
+ * CPU in oracle/geometry.py (parity unpinned with respect to cv2).
+ * pts0 / pts1 [dev, B,N,2] float32 matched key-points in pixels (row i of pair b is one correspondence), counts [dev, B] valid rows;
+ * geometry 0 = homography (x1 ~ H x0, forward transfer error), 1 = fundamental matrix (x1^T F x0 = 0, Sampson error);
+ * reproj_threshold [px], confidence, max_iter as in the reference's call (at most 16384 hypotheses are drawn), seed: the sampler is a
+ * counter-based generator, results are a pure function of (inputs, seed).
+ * model [dev, B,9] float64 row-major (H with h33 = 1; F with unit Frobenius norm), mask [dev, B,N] uint8 inliers, info [dev, B,4] int32 =
+ * (inliers, hypotheses consumed by the sequential stopping rule, index of the winning hypothesis, ok). */
+size_t imcui_hip_ransac_workspace_bytes(int B, int N, int max_iter);
+int imcui_hip_ransac(imcui_hip_t* h, const float* pts0, const float* pts1, const int* counts, int B, int N, int geometry, double reproj_threshold,
+                     double confidence, int max_iter, unsigned long long seed, double* model, unsigned char* mask, int* info, void* ws, size_t ws_bytes,
+                     void* stream);
+
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /
