@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r03"))
+F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r04"))
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 
@@ -81,7 +81,9 @@ if os.path.exists(sqp):
     for k, v in sorted(sq.items(), key=lambda kv: -kv[1]["kernel_cycles"] * kv[1]["launches"])[:6]:
         print(f"{k[:50]:50s} mfma_busy {v['mfma_busy_frac']:.3f} wait_any {v['wait_any_frac']:.2f} wait_inst {v['wait_inst_frac']:.2f}")
 # the same SQ pass on the DUSt3R workload; its GEMM launches are grouped by grid size (= shape class: encoder / decoder, N, merged sides)
-for wl, wl_note in (("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 16 pairs per step, 3 x f16 split arithmetic)"),
+for wl, wl_note in (("loftr", "bench.py --workload loftr --steps 2 --warmup 1 (1024x1024, 4 pairs per step)"),
+                    ("eloftr", "bench.py --workload eloftr --steps 2 --warmup 1 (640x480, 8 pairs per step)"),
+                    ("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 16 pairs per step, 3 x f16 split arithmetic)"),
                     ("mast3r", "bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 (512x512: network + reciprocal matching, nn_argmax_* kernels)")):
     dsq = os.path.join(F, f"pmc_{wl}_SQ", f"{wl}_counter_collection.csv")
     if not os.path.exists(dsq):
@@ -89,7 +91,7 @@ for wl, wl_note in (("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 
     by = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(dsq)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        if k.startswith("gemm_split_kernel") or k.startswith("gemm_wreg_kernel"):
+        if k.startswith("gemm_split_kernel") or k.startswith("gemm_wreg_kernel") or (wl in ("loftr", "eloftr") and k.startswith("conv3x3_")):
             k = f"{k} grid {r['Grid_Size']}"
         by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dq = {}
@@ -134,6 +136,10 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_dust3r_512_head_unfused.json.log", f"{tag}_bench_dust3r_512_head_unfused.json.log"),
                  ("bench_dust3r_512_b8.json.log", f"{tag}_bench_dust3r_512_b8.json.log"),
                  ("stats_mast3r/mast3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_mast3r_512.csv"),
+                 ("bench_splg_attn_v0.json.log", f"{tag}_bench_splg_attn_v0.json.log"), ("bench_splg_attn_v6.json.log", f"{tag}_bench_splg_attn_v6.json.log"),
+                 ("bench_splg_attn_v7.json.log", f"{tag}_bench_splg_attn_v7.json.log"), ("bench_splg_h2d_jpeg.json.log", f"{tag}_bench_splg_h2d_jpeg.json.log"),
+                 ("lab_attention_pv2.txt", f"{tag.split('_')[0]}_lab_attention_pv2.txt"), ("lab_jpeg.txt", f"{tag.split('_')[0]}_lab_jpeg.txt"),
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
