@@ -24,6 +24,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "common.h"
 #include "imcui_hip.h"
 
@@ -79,7 +83,8 @@ struct Comp {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
     int bw = 0, bh = 0;      // blocks per row / rows of the MCU-padded plane
     int rbw = 0, rbh = 0;    // blocks that cover the component's real size (non-interleaved scans walk these)
-    size_t off = 0;          // first coefficient of the plane
+    size_t off = 0;          // first coefficient of the plane inside ONE buffer holding all components
+    short* base = nullptr;   // where the plane's coefficients go (set by the entry points)
 };
 
 struct Jpeg {
@@ -343,7 +348,7 @@ int decode_block(BitReader& br, const HuffTable& dct, const HuffTable& act, int&
 }
 
 // one scan starting at the SOS marker at `pos`; returns the offset of the next marker (after the entropy-coded data) or < 0
-long decode_scan(const unsigned char* d, size_t n, size_t pos, Jpeg& j, short* coef) {
+long decode_scan(const unsigned char* d, size_t n, size_t pos, Jpeg& j) {
     if (pos + 4 > n) return IMCUI_ERR_ARG;
     const int L = be16(d + pos + 2);
     if (L < 6 || pos + 2 + L > n) return IMCUI_ERR_ARG;
@@ -390,14 +395,14 @@ long decode_scan(const unsigned char* d, size_t n, size_t pos, Jpeg& j, short* c
                 const Comp& k = j.comp[sc[s]];
                 for (int by = 0; by < k.v; ++by)
                     for (int bx = 0; bx < k.h; ++bx) {
-                        short* blk = coef + k.off + ((size_t)(uy * k.v + by) * k.bw + (ux * k.h + bx)) * 64;
+                        short* blk = k.base + ((size_t)(uy * k.v + by) * k.bw + (ux * k.h + bx)) * 64;
                         const int rc = decode_block(br, j.dc[k.td], j.ac[k.ta], pred[sc[s]], blk);
                         if (rc != IMCUI_OK) return rc;
                     }
             }
         } else {
             const Comp& k = j.comp[sc[0]];
-            short* blk = coef + k.off + ((size_t)uy * k.bw + ux) * 64;
+            short* blk = k.base + ((size_t)uy * k.bw + ux) * 64;
             const int rc = decode_block(br, j.dc[k.td], j.ac[k.ta], pred[sc[0]], blk);
             if (rc != IMCUI_OK) return rc;
         }
@@ -437,17 +442,18 @@ extern "C" size_t imcui_hip_jpeg_coef_count(const int* info) {
     return t;
 }
 
-// coef [host]: imcui_hip_jpeg_coef_count() int16, zeroed here; qt [host]: [3][64] uint16, the quantisation table of every component
-// in natural order.  Re-entrant: decode different images on different host threads.
-extern "C" int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n, short* coef, unsigned short* qt) {
-    if (!data || !coef || !qt) return IMCUI_ERR_ARG;
+// planes[c] (c < components): destination of component c's coefficients (bw * bh * 64 int16, zeroed here); planes == nullptr: one
+// buffer `coef` with the components one behind the other
+static int entropy_decode_impl(const unsigned char* data, size_t n, short* coef, short* const* planes, unsigned short* qt) {
     Jpeg j;
     long pos;
     int rc = parse_all(data, n, j, &pos);
     if (rc != IMCUI_OK) return rc;
-    size_t total = 0;
-    for (int c = 0; c < j.nc; ++c) total += (size_t)j.comp[c].bw * j.comp[c].bh * 64;
-    memset(coef, 0, total * sizeof(short));
+    for (int c = 0; c < j.nc; ++c) {
+        j.comp[c].base = planes ? planes[c] : coef + j.comp[c].off;
+        if (!j.comp[c].base) return IMCUI_ERR_ARG;
+        memset(j.comp[c].base, 0, (size_t)j.comp[c].bw * j.comp[c].bh * 64 * sizeof(short));
+    }
     int done = 0;
     bool seen[4] = {false, false, false, false};
     while (done < j.nc) {
@@ -461,7 +467,7 @@ extern "C" int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n
                         seen[c] = true;
                         ++done;
                     }
-            const long nx = decode_scan(data, n, (size_t)pos, j, coef);
+            const long nx = decode_scan(data, n, (size_t)pos, j);
             if (nx < 0) return (int)nx;
             pos = nx;
         } else if (m == 0xD9) {
@@ -512,6 +518,37 @@ extern "C" int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n
     }
     for (int c = 0; c < 3; ++c)
         for (int k = 0; k < 64; ++k) qt[c * 64 + k] = c < j.nc ? j.qt[j.comp[c].tq][k] : 0;
+    return IMCUI_OK;
+}
+
+// coef [host]: imcui_hip_jpeg_coef_count() int16, zeroed here; qt [host]: [3][64] uint16, the quantisation table of every component
+// in natural order.  Re-entrant: decode different images on different host threads.
+extern "C" int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n, short* coef, unsigned short* qt) {
+    if (!data || !coef || !qt) return IMCUI_ERR_ARG;
+    return entropy_decode_impl(data, n, coef, nullptr, qt);
+}
+
+// `count` files on `threads` host threads of the library's own (no interpreter lock, no per-image allocation: the caller provides the
+// destinations, typically slices of ONE pinned staging buffer laid out plane-major so that the luma coefficients of a whole batch
+// cross PCIe in one transfer).  planes [3 * count]: destination of component c of file i at planes[3 * i + c] (unused components
+// may be NULL); qt [count][3 * 64]; status [count]: the per-file return code (a refused file does not stop the others).
+extern "C" int imcui_hip_jpeg_entropy_decode_batch(const unsigned char* const* data, const size_t* sizes, int count, short* const* planes, unsigned short* qt,
+                                                   int* status, int threads) {
+    if (!data || !sizes || !planes || !qt || !status || count < 0) return IMCUI_ERR_ARG;
+    if (threads < 1) threads = 1;
+    if (threads > count) threads = count > 0 ? count : 1;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= count) return;
+            status[i] = data[i] ? entropy_decode_impl(data[i], sizes[i], nullptr, planes + 3 * (size_t)i, qt + 192 * (size_t)i) : IMCUI_ERR_ARG;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
     return IMCUI_OK;
 }
 
@@ -578,12 +615,16 @@ __device__ __forceinline__ void idct8(const int* d, int* o) {
 }
 
 // A workgroup of 256 threads reconstructs 32 blocks: thread = (block, column) in pass 1 (dequantise + columns, results parked in
-// LDS), (block, row) in pass 2 (rows, range limit, one 8-byte store per row).  plane: [bh * 8][bw * 8] uint8.
+// LDS), (block, row) in pass 2 (rows, range limit, one 8-byte store per row).  plane: [bh * 8][bw * 8] uint8.  blockIdx.y = image of
+// the batch (coefficients `nblocks * 64` apart, tables 192 apart, planes `nblocks * 64` bytes apart).
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const short* __restrict__ coef, const unsigned short* __restrict__ qt, unsigned char* __restrict__ plane,
                                                         int bw, int nblocks) {
     __shared__ int ws[32][8][9];
     const int tid = threadIdx.x, lb = tid >> 3, k = tid & 7;
     const int blk = blockIdx.x * 32 + lb;
+    coef += (size_t)blockIdx.y * nblocks * 64;
+    qt += (size_t)blockIdx.y * 192;
+    plane += (size_t)blockIdx.y * nblocks * 64;
     if (blk < nblocks) {
         const short* c = coef + (size_t)blk * 64;
         int d[8], o[8];
@@ -610,10 +651,10 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const short* __restrict_
     }
 }
 
-// gray output: the luma plane cropped to the image
-__global__ __launch_bounds__(256) void jpeg_crop_kernel(const unsigned char* __restrict__ plane, int pstride, unsigned char* __restrict__ out, int W, int H) {
+// gray output: the luma plane cropped to the image (blockIdx.z = image of the batch)
+__global__ __launch_bounds__(256) void jpeg_crop_kernel(const unsigned char* __restrict__ plane, int pstride, size_t plane_bytes, unsigned char* __restrict__ out, int W, int H) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x < W && y < H) out[(size_t)y * W + x] = plane[(size_t)y * pstride + x];
+    if (x < W && y < H) out[((size_t)blockIdx.z * H + y) * W + x] = plane[(size_t)blockIdx.z * plane_bytes + (size_t)y * pstride + x];
 }
 
 // chroma sample of output pixel (x, y) by libjpeg's fancy up-sampling; cw x chh = the component's real size, (hs, vs) = (1, 1), (2, 1), (2, 2)
@@ -640,68 +681,86 @@ __device__ __forceinline__ int chroma_at(const unsigned char* __restrict__ p, in
     return (cur * 3 + 3 * r0[cx - 1] + r1[cx - 1] + 8) >> 4;
 }
 
-// RGB output [H][W][3]: up-sample + ycc_rgb_convert
-__global__ __launch_bounds__(256) void jpeg_color_kernel(const unsigned char* __restrict__ Y, int ys, const unsigned char* __restrict__ Cb,
-                                                         const unsigned char* __restrict__ Cr, int cs, int cw, int chh, int hs, int vs,
+// RGB output [H][W][3]: up-sample + ycc_rgb_convert (blockIdx.z = image of the batch)
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const unsigned char* __restrict__ Y, int ys, size_t ybytes, const unsigned char* __restrict__ Cb,
+                                                         const unsigned char* __restrict__ Cr, int cs, size_t cbytes, int cw, int chh, int hs, int vs,
                                                          unsigned char* __restrict__ out, int W, int H) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
+    Y += (size_t)blockIdx.z * ybytes;
     const int yy = Y[(size_t)y * ys + x];
     // (a one-component file as RGB: no chroma planes, cb = cr = 128 -> three equal channels)
-    const int cb = Cb ? chroma_at(Cb, cs, cw, chh, hs, vs, x, y) - 128 : 0, cr = Cr ? chroma_at(Cr, cs, cw, chh, hs, vs, x, y) - 128 : 0;
+    int cb = 0, cr = 0;
+    if (Cb) {
+        cb = chroma_at(Cb + (size_t)blockIdx.z * cbytes, cs, cw, chh, hs, vs, x, y) - 128;
+        cr = chroma_at(Cr + (size_t)blockIdx.z * cbytes, cs, cw, chh, hs, vs, x, y) - 128;
+    }
     const int r = yy + ((91881 * cr + 32768) >> 16);
     const int g = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
     const int b = yy + ((116130 * cb + 32768) >> 16);
-    unsigned char* o = out + ((size_t)y * W + x) * 3;
+    unsigned char* o = out + (((size_t)blockIdx.z * H + y) * W + x) * 3;
     o[0] = (unsigned char)clamp255(r);
     o[1] = (unsigned char)clamp255(g);
     o[2] = (unsigned char)clamp255(b);
 }
 
-extern "C" size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray) {
-    if (!info) return 0;
+extern "C" size_t imcui_hip_jpeg_workspace_bytes_batch(const int* info, int gray, int n) {
+    if (!info || n <= 0) return 0;
     size_t t = 256;
     const int nc = (gray || info[JI_NC] == 1) ? 1 : 3;
-    for (int c = 0; c < nc; ++c) t += align_up((size_t)info[JI_MX] * info[JI_COMP + 4 * c] * 8 * info[JI_MY] * info[JI_COMP + 4 * c + 1] * 8, 256);
+    for (int c = 0; c < nc; ++c) t += align_up((size_t)n * info[JI_MX] * info[JI_COMP + 4 * c] * 8 * info[JI_MY] * info[JI_COMP + 4 * c + 1] * 8, 256);
     return t;
 }
+extern "C" size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray) { return imcui_hip_jpeg_workspace_bytes_batch(info, gray, 1); }
 
-// coef [dev]: the int16 coefficients of imcui_hip_jpeg_entropy_decode; qt [dev]: its [3][64] uint16 tables; info [host];
-// out [dev]: gray != 0 -> [H][W] uint8 (the luma plane: cv2.IMREAD_GRAYSCALE), else [H][W][3] RGB (a one-component file is replicated,
-// as IMREAD_COLOR does).
-extern "C" int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, const unsigned short* qt, const int* info, int gray, unsigned char* out,
-                                          void* ws, size_t ws_bytes, void* stream_) {
-    if (!h || !coef || !qt || !info || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: null argument");
+// n files of ONE geometry (equal info records): coef_y / coef_cb / coef_cr [dev]: [n][plane coefficients] per component (the chroma
+// pointers may be NULL when gray != 0 or the files have one component), qt [dev]: [n][3 * 64] uint16, info [host]: the common record;
+// out [dev]: gray != 0 -> [n][H][W] uint8 (the luma planes: cv2.IMREAD_GRAYSCALE), else [n][H][W][3] RGB (a one-component file is
+// replicated, as IMREAD_COLOR does).  Three launches for the whole batch.
+extern "C" int imcui_hip_jpeg_reconstruct_batch(imcui_hip_t* h, const short* coef_y, const short* coef_cb, const short* coef_cr, const unsigned short* qt,
+                                                const int* info, int n, int gray, unsigned char* out, void* ws, size_t ws_bytes, void* stream_) {
+    if (!h || !coef_y || !qt || !info || !out) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: null argument");
+    if (n <= 0) return IMCUI_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const int W = info[JI_W], H = info[JI_H], nc = info[JI_NC];
-    if (W <= 0 || H <= 0 || (nc != 1 && nc != 3)) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: bad info record");
-    if (ws_bytes < imcui_hip_jpeg_workspace_bytes(info, gray) || !ws) return imcui_set_err(h, IMCUI_ERR_WS, "jpeg: workspace too small");
-    WsAlloc a(ws, ws_bytes);
+    if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || n > 65535) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: bad info record / batch of %d", n);
     const int ncd = (gray || nc == 1) ? 1 : 3;
+    if (ncd == 3 && (!coef_cb || !coef_cr)) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: RGB output needs the chroma coefficients");
+    if (ws_bytes < imcui_hip_jpeg_workspace_bytes_batch(info, gray, n) || !ws) return imcui_set_err(h, IMCUI_ERR_WS, "jpeg: workspace too small");
+    WsAlloc a(ws, ws_bytes);
+    const short* coef[3] = {coef_y, coef_cb, coef_cr};
     unsigned char* plane[3] = {nullptr, nullptr, nullptr};
-    int bw[3], bh[3];
-    size_t coff = 0;
-    for (int c = 0; c < nc; ++c) {
+    int bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+    for (int c = 0; c < ncd; ++c) {
         bw[c] = info[JI_MX] * info[JI_COMP + 4 * c];
         bh[c] = info[JI_MY] * info[JI_COMP + 4 * c + 1];
-        if (c < ncd) {
-            plane[c] = a.get<unsigned char>((size_t)bw[c] * 8 * bh[c] * 8);
-            const int nb = bw[c] * bh[c];
-            hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 31) / 32), dim3(256), 0, stream, coef + coff, qt + 64 * c, plane[c], bw[c], nb);
-        }
-        coff += (size_t)bw[c] * bh[c] * 64;
+        const int nb = bw[c] * bh[c];
+        plane[c] = a.get<unsigned char>((size_t)n * nb * 64);
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nb + 31) / 32, n), dim3(256), 0, stream, coef[c], qt + 64 * c, plane[c], bw[c], nb);
     }
-    const dim3 grid((W + 255) / 256, H);
+    const dim3 grid((W + 255) / 256, H, n);
+    const size_t ybytes = (size_t)bw[0] * bh[0] * 64;
     if (gray) {
-        hipLaunchKernelGGL(jpeg_crop_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, out, W, H);
+        hipLaunchKernelGGL(jpeg_crop_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, ybytes, out, W, H);
     } else if (nc == 1) {
-        // IMREAD_COLOR of a gray file: three equal channels (cb = cr = 128 in the colour formula)
-        hipLaunchKernelGGL(jpeg_color_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, (const unsigned char*)nullptr, (const unsigned char*)nullptr, 0, 0, 0, 0, 0, out, W, H);
+        hipLaunchKernelGGL(jpeg_color_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, ybytes, (const unsigned char*)nullptr, (const unsigned char*)nullptr, 0,
+                           (size_t)0, 0, 0, 0, 0, out, W, H);
     } else {
         const int hs = info[JI_HMAX] / info[JI_COMP + 4], vs = info[JI_VMAX] / info[JI_COMP + 5];
         const int cw = (W * info[JI_COMP + 4] + info[JI_HMAX] - 1) / info[JI_HMAX], chh = (H * info[JI_COMP + 5] + info[JI_VMAX] - 1) / info[JI_VMAX];
-        hipLaunchKernelGGL(jpeg_color_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, plane[1], plane[2], bw[1] * 8, cw, chh, hs, vs, out, W, H);
+        hipLaunchKernelGGL(jpeg_color_kernel, grid, dim3(256), 0, stream, plane[0], bw[0] * 8, ybytes, plane[1], plane[2], bw[1] * 8, (size_t)bw[1] * bh[1] * 64, cw, chh,
+                           hs, vs, out, W, H);
     }
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
+}
+
+// one file: coef [dev] = the single buffer of imcui_hip_jpeg_entropy_decode (components one behind the other), qt [dev] its [3][64] tables
+extern "C" int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, const unsigned short* qt, const int* info, int gray, unsigned char* out,
+                                          void* ws, size_t ws_bytes, void* stream_) {
+    if (!h || !coef || !info) return imcui_set_err(h, IMCUI_ERR_ARG, "jpeg: null argument");
+    const size_t ny = (size_t)info[JI_MX] * info[JI_COMP] * info[JI_MY] * info[JI_COMP + 1] * 64;
+    const size_t ncb = info[JI_NC] == 3 ? (size_t)info[JI_MX] * info[JI_COMP + 4] * info[JI_MY] * info[JI_COMP + 5] * 64 : 0;
+    const bool chroma = info[JI_NC] == 3 && !gray;
+    return imcui_hip_jpeg_reconstruct_batch(h, coef, chroma ? coef + ny : nullptr, chroma ? coef + ny + ncb : nullptr, qt, info, 1, gray, out, ws, ws_bytes, stream_);
 }

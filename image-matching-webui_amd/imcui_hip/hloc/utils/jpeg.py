@@ -2,7 +2,7 @@
 
 `read_image` of the reference (imcui/hloc/utils/io.py:11-21) is `cv2.imread`: one host decode per image.  Here the Huffman bit stream
 is decoded by the library's host routine (`imcui_hip_jpeg_entropy_decode`: re-entrant C++, called through ctypes, which releases the
-GIL -- `JpegDecoder` runs it on a thread pool) into quantised DCT coefficients, those go to the device, and dequantisation + inverse DCT
+GIL; `JpegDecoder` hands whole batches to the library's own thread pool, `imcui_hip_jpeg_entropy_decode_batch`) into quantised DCT coefficients, those go to the device, and dequantisation + inverse DCT
 + chroma up-sampling + colour conversion run there (`imcui_hip_jpeg_reconstruct`), bit-exact against libjpeg's default path (what
 cv2 / PIL run).  gray=True returns the luma plane of the file, which is what `cv2.imread(IMREAD_GRAYSCALE)` hands the extractor for a JPEG.
 
@@ -12,8 +12,6 @@ Files the device path does not take (progressive, CMYK, 4:4:0, an EXIF orientati
 from __future__ import annotations
 
 import ctypes as C
-from concurrent.futures import ThreadPoolExecutor
-
 import numpy as np
 import torch
 
@@ -81,25 +79,107 @@ def decode_jpeg(data: bytes, gray: bool, device) -> torch.Tensor:
 
 
 class JpegDecoder:
-    """Batch decode: the bit streams on `threads` host threads, the pixels on the device."""
+    """Batch decode: the bit streams on `threads` host threads OF THE LIBRARY (`imcui_hip_jpeg_entropy_decode_batch`: no interpreter
+    lock, no per-file allocation) straight into a pinned staging buffer laid out plane-major per geometry group, ONE transfer and three
+    kernel launches per group of equally shaped files (`imcui_hip_jpeg_reconstruct_batch`).  Two staging buffers alternate; a buffer is
+    rewritten only after the transfer that last read it has completed."""
 
     def __init__(self, device, threads: int = 8):
         self.device = torch.device(device)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
+        self.threads = max(1, int(threads))
+        self._stage = [None, None]
+        self._done = [None, None]
+        self._turn = 0
+
+    def _staging(self, shorts: int) -> torch.Tensor:
+        k = self._turn & 1
+        self._turn += 1
+        if self._done[k] is not None:
+            self._done[k].synchronize()  # the transfer that last read this buffer
+        if self._stage[k] is None or self._stage[k].numel() < shorts:
+            self._stage[k] = torch.empty(max(shorts, 1 << 20), dtype=torch.int16, pin_memory=True)
+        return self._stage[k], k
 
     def decode_batch(self, blobs, gray: bool):
-        """blobs: list of `bytes`; -> list of uint8 device tensors (JpegUnsupported instances for the files the device path refuses)."""
-        def host(b):
-            try:
-                return entropy_decode(b, pinned=True)
-            except JpegUnsupported as e:
-                return e
-
-        staged = list(self.pool.map(host, blobs))
-        return [s if isinstance(s, JpegUnsupported) else reconstruct(*s, gray, self.device) for s in staged]
+        """blobs: list of `bytes`; -> list of uint8 device tensors ([H,W] or [H,W,3]; views into one tensor per geometry group), with a
+        `JpegUnsupported` instance in the place of every file the device path refuses."""
+        lib = load_library()
+        dev = self.device
+        n = len(blobs)
+        results: list = [None] * n
+        infos: list = [None] * n
+        groups: dict = {}
+        for i, b in enumerate(blobs):
+            info = (C.c_int * INFO_INTS)()
+            rc = lib.imcui_hip_jpeg_info(b, len(b), info)
+            if rc != 0:
+                results[i] = JpegUnsupported(f"imcui_hip_jpeg_info: status {rc}")
+            elif info[8] != 1:
+                results[i] = JpegUnsupported(f"EXIF orientation {info[8]}: cv2.imread rotates such files; not done on the device")
+            else:
+                infos[i] = info
+                groups.setdefault(tuple(info[:8]) + tuple(info[9:21]), []).append(i)
+        if not groups:
+            return results
+        # staging layout (int16 elements): per group [Y planes of its files | Cb planes | Cr planes], then the tables of all files
+        plan, off = [], 0
+        for key, idx in groups.items():
+            info = infos[idx[0]]
+            ny = info[5] * info[9] * info[6] * info[10] * 64
+            ncb = info[5] * info[13] * info[6] * info[14] * 64 if info[2] == 3 else 0
+            plan.append((idx, info, ny, ncb, off))
+            off += len(idx) * (ny + 2 * ncb)
+        qt_off = off
+        total = off + n * 192
+        stage, slot = self._staging(total)
+        base = stage.data_ptr()
+        data_p = (C.c_char_p * n)(*[b if infos[i] is not None else None for i, b in enumerate(blobs)])
+        sizes = (C.c_size_t * n)(*[len(b) for b in blobs])
+        planes = (C.c_void_p * (3 * n))()
+        for idx, info, ny, ncb, goff in plan:
+            m = len(idx)
+            for k, i in enumerate(idx):
+                planes[3 * i] = base + 2 * (goff + k * ny)
+                if ncb:
+                    planes[3 * i + 1] = base + 2 * (goff + m * ny + k * ncb)
+                    planes[3 * i + 2] = base + 2 * (goff + m * (ny + ncb) + k * ncb)
+        status = (C.c_int * n)()
+        rc = lib.imcui_hip_jpeg_entropy_decode_batch(data_p, sizes, n, planes, base + 2 * qt_off, status, self.threads)
+        if rc != 0:
+            raise backend.ImcuiHipError(f"imcui_hip_jpeg_entropy_decode_batch failed ({rc})")
+        hd = backend.get_handle(dev)
+        qt_d = stage[qt_off:total].to(dev, non_blocking=True)
+        for idx, info, ny, ncb, goff in plan:
+            m = len(idx)
+            chroma = info[2] == 3 and not gray
+            span = m * (ny + (2 * ncb if chroma else 0))
+            coef_d = stage[goff : goff + span].to(dev, non_blocking=True)
+            W, H = info[0], info[1]
+            out = torch.empty((m, H, W) if gray else (m, H, W, 3), dtype=torch.uint8, device=dev)
+            # the tables of this group's files, in group order
+            qsel = qt_d.view(n, 192)[torch.tensor(idx, device=dev)] if m != n else qt_d.view(n, 192)
+            nbytes = lib.imcui_hip_jpeg_workspace_bytes_batch(info, int(gray), m)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            cy = coef_d.data_ptr()
+            ccb = cy + 2 * m * ny if chroma else None
+            ccr = cy + 2 * m * (ny + ncb) if chroma else None
+            with torch.cuda.device(dev):
+                rc = lib.imcui_hip_jpeg_reconstruct_batch(hd.h, cy, ccb, ccr, backend._ptr(qsel.contiguous()), info, m, int(gray), backend._ptr(out), backend._ptr(ws),
+                                                          nbytes, backend._stream_ptr())  # fmt: skip
+                hd.check(rc, "imcui_hip_jpeg_reconstruct_batch")
+            for k, i in enumerate(idx):
+                results[i] = out[k] if status[i] == 0 else JpegUnsupported(
+                    f"imcui_hip_jpeg_entropy_decode: status {status[i]} ({'unsupported JPEG variant' if status[i] == -4 else 'damaged bit stream'})")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._done[slot] = ev
+        return results
 
     def close(self):
-        self.pool.shutdown(wait=True)
+        for ev in self._done:
+            if ev is not None:
+                ev.synchronize()
+        self._stage = [None, None]
 
 
 def is_jpeg(data: bytes) -> bool:

@@ -150,7 +150,11 @@ SIGNATURES = {
     "imcui_hip_jpeg_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "imcui_hip_jpeg_coef_count": (C.c_size_t, [C.POINTER(C.c_int)]),
     "imcui_hip_jpeg_entropy_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "imcui_hip_jpeg_entropy_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "imcui_hip_jpeg_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int), C.c_int]),
+    "imcui_hip_jpeg_workspace_bytes_batch": (C.c_size_t, [C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "imcui_hip_jpeg_reconstruct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p]),
     "imcui_hip_jpeg_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_ransac_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "imcui_hip_ransac": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_ulonglong,

@@ -358,7 +358,17 @@ size_t imcui_hip_jpeg_coef_count(const int* info);
 /* coef [host, imcui_hip_jpeg_coef_count() int16]: quantised DCT coefficients in natural order, [component][block row][block column][64];
  * qt [host, 3 x 64 uint16]: the quantisation table of every component, natural order */
 int imcui_hip_jpeg_entropy_decode(const unsigned char* data, size_t n, short* coef, unsigned short* qt);
+/* `count` files on `threads` host threads OF THE LIBRARY (no interpreter lock, no per-file allocation): planes [3 * count] = where
+ * component c of file i goes (planes[3 i + c]; unused components may be NULL) -- typically slices of one pinned staging buffer laid out
+ * plane-major, so the luma coefficients of a batch cross PCIe in one transfer; qt [count][3 * 64]; status [count] per-file codes */
+int imcui_hip_jpeg_entropy_decode_batch(const unsigned char* const* data, const size_t* sizes, int count, short* const* planes, unsigned short* qt,
+                                        int* status, int threads);
 size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray);
+size_t imcui_hip_jpeg_workspace_bytes_batch(const int* info, int gray, int n);
+/* n files of ONE geometry (equal info records) in three launches: coef_y / coef_cb / coef_cr [dev, n x plane coefficients] (chroma may be
+ * NULL for gray output / one-component files), qt [dev, n x 192], out [dev]: [n,H,W] uint8 (gray) or [n,H,W,3] */
+int imcui_hip_jpeg_reconstruct_batch(imcui_hip_t* h, const short* coef_y, const short* coef_cb, const short* coef_cr, const unsigned short* qt, const int* info,
+                                     int n, int gray, unsigned char* out, void* ws, size_t ws_bytes, void* stream);
 /* coef / qt [dev]: copies of the two buffers above; info [host]; out [dev]: gray != 0 -> [H][W] uint8 = the luma plane (what
  * cv2.IMREAD_GRAYSCALE returns for a YCbCr file), else [H][W][3] RGB (a one-component file replicated, as IMREAD_COLOR does) */
 int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, const unsigned short* qt, const int* info, int gray, unsigned char* out,

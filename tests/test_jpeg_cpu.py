@@ -137,3 +137,32 @@ def test_unsupported_and_damaged_files_are_refused():
     exif[0x0112] = 6
     im.save(ex, "JPEG", exif=exif)
     assert lib.imcui_hip_jpeg_info(ex.getvalue(), len(ex.getvalue()), info) == 0 and info[8] == 6
+
+
+def test_batch_entropy_decoder_equals_the_single_file_one():
+    """`imcui_hip_jpeg_entropy_decode_batch` (the library's own host threads, per-component destinations: what `JpegDecoder` stages into
+    one pinned buffer) writes the same coefficients and tables as the single-file entry point; a refused file does not stop the others."""
+    lib = load_library()
+    blobs = [encode(smooth_image(i, 48 + 8 * (i % 3), 64 + 16 * (i % 2)), quality=70 + i, subsampling=("4:2:0", "4:2:2", "4:4:4")[i % 3]) for i in range(12)]
+    blobs += [encode(smooth_image(77, 40, 40, 1), quality=80), encode(smooth_image(1, 40, 40), quality=80, progressive=True)]
+    n = len(blobs)
+    infos = []
+    for b in blobs[:-1]:
+        info = (C.c_int * 24)()
+        assert lib.imcui_hip_jpeg_info(b, len(b), info) == 0
+        infos.append(list(info))
+    cnt = [(i[5] * i[9] * i[6] * i[10] * 64, i[5] * i[13] * i[6] * i[14] * 64 if i[2] == 3 else 0) for i in infos] + [(64, 64)]
+    bufs = [[np.full(max(c[0], 1), 7, np.int16), np.full(max(c[1], 1), 7, np.int16), np.full(max(c[1], 1), 7, np.int16)] for c in cnt]
+    planes = (C.c_void_p * (3 * n))()
+    for i in range(n):
+        planes[3 * i] = bufs[i][0].ctypes.data
+        if cnt[i][1]:
+            planes[3 * i + 1], planes[3 * i + 2] = bufs[i][1].ctypes.data, bufs[i][2].ctypes.data
+    qt = np.zeros(n * 192, np.uint16)
+    status = (C.c_int * n)()
+    assert lib.imcui_hip_jpeg_entropy_decode_batch((C.c_char_p * n)(*blobs), (C.c_size_t * n)(*[len(b) for b in blobs]), n, planes, qt.ctypes.data, status, 4) == 0
+    assert status[n - 1] == -4  # the progressive file
+    for i, b in enumerate(blobs[:-1]):
+        _, coef, q = c_entropy(b)
+        got = np.concatenate([bufs[i][0]] + ([bufs[i][1], bufs[i][2]] if cnt[i][1] else []))
+        assert status[i] == 0 and np.array_equal(got, coef) and np.array_equal(qt[192 * i : 192 * i + 192], q), i
