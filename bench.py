@@ -890,13 +890,15 @@ LEGS = {
 def legs_enabled(args) -> bool:
     """The default invocation (`python bench.py --gpus N --steps K --warmup W`, what the driver runs) carries the legs; any switch that
     turns the run into a profiler pass or an A/B leg (--no-parity, --no-cpu-baseline, --adaptive, --graph, --h2d, --precision 0, --batch,
-    another --workload) does not, and --no-legs / --legs select explicitly."""
+    another --workload, --gpus > 1) does not, and --no-legs / --legs select explicitly."""
     if args.no_legs:
         return False
     if args.legs is not None:
         return True
+    # N > 1: the scaling runs measure the headline; the legs stay off unless asked for (`--legs all`): a leg that failed on ONE rank
+    # would leave the others in a barrier and take the headline line down with it, and none of this has met an 8-GPU node yet
     return (args.workload == "splg" and not (args.no_parity or args.no_cpu_baseline or args.adaptive or args.graph or args.h2d)
-            and args.precision == 1 and args.batch_given is None)  # fmt: skip
+            and args.precision == 1 and args.batch_given is None and args.gpus == 1)  # fmt: skip
 
 
 def run_legs(args, dev, rank, world) -> dict:
