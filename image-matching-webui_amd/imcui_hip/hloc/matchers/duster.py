@@ -140,7 +140,10 @@ class Duster(BaseModel):
         """duster.py:76-108 after the aligner: `imgs` [2] arrays [H, W, 3], `masks` [2] boolean [H, W] (scene.get_masks()),
         `pts3d` [2] arrays [H, W, 3] (scene.get_pts3d()) -> {"keypoints0", "keypoints1"} in pixels (x, y) of image0 / image1."""
         masks = [np.asarray(m.cpu() if torch.is_tensor(m) else m, dtype=bool) for m in masks]
-        clouds = [np.asarray(p.detach().cpu() if torch.is_tensor(p) else p)[m] for p, m in zip(pts3d, masks)]
+        pts3d = [np.asarray(p.detach().cpu() if torch.is_tensor(p) else p) for p in pts3d]
+        # (points that are not finite cannot enter a KD-tree -- scipy raises; a confident pixel with such a point is dropped)
+        masks = [m & np.isfinite(p).all(-1) for m, p in zip(masks, pts3d)]
+        clouds = [p[m] for p, m in zip(pts3d, masks)]
         # pixel coordinates of the confident points of either image, in the order of `clouds` (xy_grid(W, H)[mask])
         pixels = [xy_grid(im.shape[1], im.shape[0])[m] for im, m in zip(imgs, masks)]
         if len(clouds[1]) == 0:

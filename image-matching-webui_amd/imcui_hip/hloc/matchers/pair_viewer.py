@@ -223,6 +223,8 @@ class PairViewerScene:
             H, W = self.imshapes[k]
             pp = torch.tensor((W / 2, H / 2))
             focal = estimate_focal_knowing_depth(pred_i[e], pp)
+            if not (np.isfinite(focal) and focal > 0):  # a point map that is not a camera's view (untrained weights): the 60-degree default
+                focal = max(H, W) / (2 * np.tan(np.deg2rad(60) / 2))
             self.focals.append(focal)
             self.pp.append(pp.numpy())
             pixels = np.mgrid[:W, :H].T.astype(np.float32)  # [H, W, 2] = (x, y)

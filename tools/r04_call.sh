@@ -1,7 +1,6 @@
 #!/bin/bash
 O=gpurun_out/final_r04; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_jpeg.py -m gpu -q -p no:cacheprovider 2>&1 | tail -4
-timeout 300 python tools/jpeg_bench.py > $O/lab_jpeg.txt 2>$O/lab_jpeg.err; cat $O/lab_jpeg.txt; tail -3 $O/lab_jpeg.err
-( timeout 300 python bench.py --h2d jpeg --no-cpu-baseline > $O/bench_splg_h2d_jpeg.json.log 2>$O/bench_splg_h2d_jpeg.err; tail -1 $O/bench_splg_h2d_jpeg.json.log | cut -c1-150; tail -3 $O/bench_splg_h2d_jpeg.err )
-( timeout 300 python bench.py --h2d raw --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | cut -c1-150 )
-( timeout 300 python bench.py --no-legs --no-cpu-baseline --no-parity 2>/dev/null | tail -1 | cut -c1-150 )
+for v in 6; do
+  IMCUI_ATTN_VARIANT=$v timeout 1200 python -m pytest tests/test_gpu_lightglue.py tests/test_gpu_real_images.py tests/test_gpu_auc_parity.py tests/test_gpu_superglue.py tests/test_gpu_vs_hf_ports.py tests/test_gpu_match_driver.py tests/test_gpu_dust3r.py -m gpu -q -p no:cacheprovider -s > $O/pytest_attn_v$v.log 2>&1
+  echo "variant $v rc $?"; grep -E "passed|failed" $O/pytest_attn_v$v.log | tail -2; grep -E "^FAILED|AssertionError" $O/pytest_attn_v$v.log | cut -c1-260 | head -30
+done
