@@ -19,6 +19,7 @@ from ... import backend
 from ...lib_loader import load_library
 
 INFO_INTS = 24
+MAX_PIXELS = 1 << 27  # 128 Mpx: a size field beyond this is a damaged or hostile header, not a photograph (the staging buffer is sized by it)
 
 
 class JpegUnsupported(ValueError):
@@ -43,6 +44,8 @@ def entropy_decode(data: bytes, pinned: bool = False):
         raise JpegUnsupported(f"imcui_hip_jpeg_info: status {rc}")
     if info[8] != 1:
         raise JpegUnsupported(f"EXIF orientation {info[8]}: cv2.imread rotates such files; not done on the device")
+    if info[0] * info[1] > MAX_PIXELS:
+        raise JpegUnsupported(f"{info[0]} x {info[1]} pixels: beyond MAX_PIXELS")
     n = lib.imcui_hip_jpeg_coef_count(info)
     coef = torch.empty(n, dtype=torch.int16, pin_memory=pinned)
     qt = torch.empty(192, dtype=torch.int16, pin_memory=pinned)
@@ -116,6 +119,8 @@ class JpegDecoder:
                 results[i] = JpegUnsupported(f"imcui_hip_jpeg_info: status {rc}")
             elif info[8] != 1:
                 results[i] = JpegUnsupported(f"EXIF orientation {info[8]}: cv2.imread rotates such files; not done on the device")
+            elif info[0] * info[1] > MAX_PIXELS:
+                results[i] = JpegUnsupported(f"{info[0]} x {info[1]} pixels: beyond MAX_PIXELS")
             else:
                 infos[i] = info
                 groups.setdefault(tuple(info[:8]) + tuple(info[9:21]), []).append(i)

@@ -166,3 +166,48 @@ def test_batch_entropy_decoder_equals_the_single_file_one():
         _, coef, q = c_entropy(b)
         got = np.concatenate([bufs[i][0]] + ([bufs[i][1], bufs[i][2]] if cnt[i][1] else []))
         assert status[i] == 0 and np.array_equal(got, coef) and np.array_equal(qt[192 * i : 192 * i + 192], q), i
+
+
+def test_mutated_files_never_overrun_or_crash():
+    """2000 mutations (byte flips, truncation, injected markers, insertions, deletions) of four valid files through the C entry points:
+    every one is either decoded or refused with a status code; the guard words behind the coefficient buffer stay untouched."""
+    lib = load_library()
+    rng = np.random.default_rng(0)
+    seeds = [encode(smooth_image(1, 40, 56), quality=80, subsampling="4:2:0"), encode(smooth_image(2, 33, 47), quality=60, subsampling="4:2:2", restart_marker_blocks=2),
+             encode(smooth_image(3, 24, 24, 1), quality=90), encode(smooth_image(4, 64, 64), quality=95, optimize=True, subsampling="4:4:4")]  # fmt: skip
+    decoded = refused = 0
+    for it in range(2000):
+        b = bytearray(seeds[it % 4])
+        mode = it % 5
+        if mode == 0:
+            for _ in range(rng.integers(1, 6)):
+                b[rng.integers(2, len(b))] = rng.integers(0, 256)
+        elif mode == 1:
+            b = b[: rng.integers(4, len(b))]
+        elif mode == 2:
+            i = rng.integers(2, len(b) - 4)
+            b[i : i + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+        elif mode == 3:
+            i = rng.integers(2, len(b))
+            b[i:i] = bytes(rng.integers(0, 256, rng.integers(1, 20)).astype(np.uint8))
+        else:
+            i = rng.integers(2, len(b) - 10)
+            del b[i : i + rng.integers(1, 10)]
+        data = bytes(b)
+        info = (C.c_int * 24)()
+        if lib.imcui_hip_jpeg_info(data, len(data), info) != 0:
+            refused += 1
+            continue
+        n = lib.imcui_hip_jpeg_coef_count(info)
+        if n > 50_000_000:  # a mutated size field: the Python layer refuses such images (MAX_PIXELS)
+            refused += 1
+            continue
+        coef = np.zeros(n + 64, np.int16)
+        coef[n:] = 12345
+        qt = np.zeros(192, np.uint16)
+        rc = lib.imcui_hip_jpeg_entropy_decode(data, len(data), coef.ctypes.data, qt.ctypes.data)
+        assert (coef[n:] == 12345).all(), "the decoder wrote past its buffer"
+        assert rc in (0, -1, -4)
+        decoded += rc == 0
+        refused += rc != 0
+    assert decoded > 200 and refused > 200
