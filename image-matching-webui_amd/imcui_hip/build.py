@@ -20,7 +20,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # gemm_wreg.hip: no SLP vectorisation -- hipcc packed the four rotary rotations of a lane into v_pk_fma_f32 / v_pk_mul_f32 with
 # op_sel swizzles and in-place destinations, and on gfx950 that sequence intermittently returned wrong even elements in lanes
 # 48-63 (found with tools/r03_diag2.py in round 3; scalar fused multiply-adds are bit-stable).
-EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"], "gemm_wreg.hip": ["-fno-slp-vectorize"]}
+# gemm.hip (round 4): the same switch for the round-2 GEMM, whose rotary epilogue (EPI_QKV, taken when gemm_wreg_ok says no) compiled to the
+# same class of in-place v_pk_fma_f32 with op_sel (16 per kernel, seen in the ISA); measured performance-neutral on one box (headline
+# 945.6 -> 950.2 pairs/s, LoFTR 100.98 -> 101.04, DUSt3R 89.98 -> 89.83), all kernel tests unchanged.
+EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"], "gemm_wreg.hip": ["-fno-slp-vectorize"], "gemm.hip": ["-fno-slp-vectorize"]}
 
 
 def _newest_source_mtime() -> float:
