@@ -27,7 +27,7 @@ EXTRA_FLAGS: dict = {"preprocess.hip": ["-ffp-contract=off"], "gemm_wreg.hip": [
 
 
 def _newest_source_mtime() -> float:
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "imcui_hip.h")]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "imcui_hip.h"), os.path.abspath(__file__)]  # (the flags live in this file)
     return max(os.path.getmtime(f) for f in files)
 
 
