@@ -25,6 +25,7 @@ DEFAULT_RANSAC_MAX_ITER = 10000
 DEFAULT_MIN_NUM_MATCHES = 4
 GEOMETRY = {"Homography": 0, "Fundamental": 1}
 _ws = backend._Workspace()
+_lock = __import__("threading").Lock()  # the workspace table is shared by the UI's worker threads (buffers are per device and stream)
 
 
 def ransac_batched(mkpts0: torch.Tensor, mkpts1: torch.Tensor, counts: Optional[torch.Tensor] = None, geometry_type: str = "Homography",
@@ -48,7 +49,8 @@ def ransac_batched(mkpts0: torch.Tensor, mkpts1: torch.Tensor, counts: Optional[
     info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
     if B > 0 and N > 0:
         nbytes = hd.lib.imcui_hip_ransac_workspace_bytes(B, N, int(max_iter))
-        ws = _ws.get(nbytes, dev)
+        with _lock:
+            ws = _ws.get(nbytes, dev)
         with torch.cuda.device(dev):
             rc = hd.lib.imcui_hip_ransac(hd.h, backend._ptr(p0), backend._ptr(p1), backend._ptr(cnt), B, N, GEOMETRY[geometry_type], float(reproj_threshold),
                                          float(confidence), int(max_iter), C.c_ulonglong(int(seed) & ((1 << 64) - 1)), backend._ptr(model), backend._ptr(mask),
