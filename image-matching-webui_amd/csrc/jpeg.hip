@@ -20,7 +20,8 @@
 // oracle/jpeg.py to PIL; tests/test_gpu_jpeg.py the kernels).  Supported: baseline / extended sequential Huffman (SOF0, SOF1), 8 bit,
 // 1 or 3 components, sampling 4:4:4, 4:2:2, 4:2:0, restart intervals, interleaved and non-interleaved scans.  Anything else
 // (progressive, arithmetic coding, CMYK, 12 bit, 4:4:0 and other sampling factors) is reported as IMCUI_ERR_UNSUPPORTED and the caller keeps
-// its host decoder for that file.  EXIF orientation is reported in the info record; the caller applies it (or falls back).
+// its host decoder for that file.  EXIF orientation is reported in the info record and applied by imcui_hip_orient_u8 (the Python layer
+// does that, as cv2.imread does).
 #include <stdlib.h>
 #include <string.h>
 
@@ -763,4 +764,36 @@ extern "C" int imcui_hip_jpeg_reconstruct(imcui_hip_t* h, const short* coef, con
     const size_t ncb = info[JI_NC] == 3 ? (size_t)info[JI_MX] * info[JI_COMP + 4] * info[JI_MY] * info[JI_COMP + 5] * 64 : 0;
     const bool chroma = info[JI_NC] == 3 && !gray;
     return imcui_hip_jpeg_reconstruct_batch(h, coef, chroma ? coef + ny : nullptr, chroma ? coef + ny + ncb : nullptr, qt, info, 1, gray, out, ws, ws_bytes, stream_);
+}
+
+// EXIF orientation (tag 0x0112, values 2..8) applied to a decoded image, as cv2.imread and PIL's ImageOps.exif_transpose do:
+// dst [H'][W'][C] with (H', W') = (H, W) for 2, 3, 4 and (W, H) for 5..8.  2 mirror, 3 rotate 180, 4 flip, 5 transpose, 6 rotate 90
+// clockwise, 7 transverse, 8 rotate 90 counter-clockwise.
+__global__ __launch_bounds__(256) void jpeg_orient_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int H, int W, int C, int ori) {
+    const int Wd = ori >= 5 ? H : W, Hd = ori >= 5 ? W : H;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= Wd || y >= Hd) return;
+    int sy, sx;
+    switch (ori) {
+        case 2: sy = y; sx = W - 1 - x; break;
+        case 3: sy = H - 1 - y; sx = W - 1 - x; break;
+        case 4: sy = H - 1 - y; sx = x; break;
+        case 5: sy = x; sx = y; break;
+        case 6: sy = H - 1 - x; sx = y; break;
+        case 7: sy = H - 1 - x; sx = W - 1 - y; break;
+        case 8: sy = x; sx = W - 1 - y; break;
+        default: sy = y; sx = x; break;
+    }
+    const unsigned char* s = src + ((size_t)sy * W + sx) * C;
+    unsigned char* d = dst + ((size_t)y * Wd + x) * C;
+    for (int c = 0; c < C; ++c) d[c] = s[c];
+}
+
+// src [dev, H,W,C] uint8 -> dst [dev]: the image in its EXIF orientation (`orientation` 1..8; 1 copies); dst holds H * W * C bytes
+extern "C" int imcui_hip_orient_u8(imcui_hip_t* h, const unsigned char* src, int H, int W, int C, int orientation, unsigned char* dst, void* stream_) {
+    if (!h || !src || !dst || H <= 0 || W <= 0 || C <= 0 || orientation < 1 || orientation > 8) return imcui_set_err(h, IMCUI_ERR_ARG, "orient: bad argument");
+    const int Wd = orientation >= 5 ? H : W, Hd = orientation >= 5 ? W : H;
+    hipLaunchKernelGGL(jpeg_orient_kernel, dim3((Wd + 255) / 256, Hd), dim3(256), 0, (hipStream_t)stream_, src, dst, H, W, C, orientation);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
 }

@@ -6,7 +6,9 @@ GIL; `JpegDecoder` hands whole batches to the library's own thread pool, `imcui_
 + chroma up-sampling + colour conversion run there (`imcui_hip_jpeg_reconstruct`), bit-exact against libjpeg's default path (what
 cv2 / PIL run).  gray=True returns the luma plane of the file, which is what `cv2.imread(IMREAD_GRAYSCALE)` hands the extractor for a JPEG.
 
-Files the device path does not take (progressive, CMYK, 4:4:0, an EXIF orientation other than upright, non-JPEG) raise
+An EXIF orientation is applied on the device after the reconstruction (`imcui_hip_orient_u8`), as cv2.imread does inside its decoder.
+
+Files the device path does not take (progressive, CMYK, 4:4:0, non-JPEG) raise
 `JpegUnsupported`; the drivers keep the host reader for those.
 """
 from __future__ import annotations
@@ -42,8 +44,6 @@ def entropy_decode(data: bytes, pinned: bool = False):
     rc = lib.imcui_hip_jpeg_info(data, len(data), info)
     if rc != 0:
         raise JpegUnsupported(f"imcui_hip_jpeg_info: status {rc}")
-    if info[8] != 1:
-        raise JpegUnsupported(f"EXIF orientation {info[8]}: cv2.imread rotates such files; not done on the device")
     if info[0] * info[1] > MAX_PIXELS:
         raise JpegUnsupported(f"{info[0]} x {info[1]} pixels: beyond MAX_PIXELS")
     n = lib.imcui_hip_jpeg_coef_count(info)
@@ -76,9 +76,23 @@ def reconstruct(info, coef: torch.Tensor, qt: torch.Tensor, gray: bool, device) 
     return out
 
 
+def apply_orientation(img: torch.Tensor, orientation: int) -> torch.Tensor:
+    """EXIF orientation 2..8 on a decoded uint8 device image [H,W] / [H,W,C], as cv2.imread / PIL's exif_transpose apply it."""
+    if orientation == 1:
+        return img
+    hd = backend.get_handle(img.device)
+    H, W = img.shape[:2]
+    Cc = img.shape[2] if img.dim() == 3 else 1
+    shape = ((W, H) if orientation >= 5 else (H, W)) + ((Cc,) if img.dim() == 3 else ())
+    out = torch.empty(shape, dtype=torch.uint8, device=img.device)
+    with torch.cuda.device(img.device):
+        hd.check(hd.lib.imcui_hip_orient_u8(hd.h, backend._ptr(img.contiguous()), H, W, Cc, int(orientation), backend._ptr(out), backend._stream_ptr()), "imcui_hip_orient_u8")
+    return out
+
+
 def decode_jpeg(data: bytes, gray: bool, device) -> torch.Tensor:
     info, coef, qt = entropy_decode(data)
-    return reconstruct(info, coef, qt, gray, device)
+    return apply_orientation(reconstruct(info, coef, qt, gray, device), info[8])
 
 
 class JpegDecoder:
@@ -111,18 +125,18 @@ class JpegDecoder:
         n = len(blobs)
         results: list = [None] * n
         infos: list = [None] * n
+        info_of: dict = {}  # file -> its EXIF orientation (the geometry key leaves it out: rotated files batch with upright ones)
         groups: dict = {}
         for i, b in enumerate(blobs):
             info = (C.c_int * INFO_INTS)()
             rc = lib.imcui_hip_jpeg_info(b, len(b), info)
             if rc != 0:
                 results[i] = JpegUnsupported(f"imcui_hip_jpeg_info: status {rc}")
-            elif info[8] != 1:
-                results[i] = JpegUnsupported(f"EXIF orientation {info[8]}: cv2.imread rotates such files; not done on the device")
             elif info[0] * info[1] > MAX_PIXELS:
                 results[i] = JpegUnsupported(f"{info[0]} x {info[1]} pixels: beyond MAX_PIXELS")
             else:
                 infos[i] = info
+                info_of[i] = info[8]
                 groups.setdefault(tuple(info[:8]) + tuple(info[9:21]), []).append(i)
         if not groups:
             return results
@@ -173,7 +187,7 @@ class JpegDecoder:
                                                           nbytes, backend._stream_ptr())  # fmt: skip
                 hd.check(rc, "imcui_hip_jpeg_reconstruct_batch")
             for k, i in enumerate(idx):
-                results[i] = out[k] if status[i] == 0 else JpegUnsupported(
+                results[i] = apply_orientation(out[k], info_of[i]) if status[i] == 0 else JpegUnsupported(
                     f"imcui_hip_jpeg_entropy_decode: status {status[i]} ({'unsupported JPEG variant' if status[i] == -4 else 'damaged bit stream'})")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))

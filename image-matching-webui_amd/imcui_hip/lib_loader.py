@@ -151,6 +151,7 @@ SIGNATURES = {
     "imcui_hip_jpeg_coef_count": (C.c_size_t, [C.POINTER(C.c_int)]),
     "imcui_hip_jpeg_entropy_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "imcui_hip_jpeg_entropy_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "imcui_hip_orient_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imcui_hip_jpeg_workspace_bytes": (C.c_size_t, [C.POINTER(C.c_int), C.c_int]),
     "imcui_hip_jpeg_workspace_bytes_batch": (C.c_size_t, [C.POINTER(C.c_int), C.c_int, C.c_int]),
     "imcui_hip_jpeg_reconstruct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -349,7 +349,7 @@ int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, i
  * path (jpeg_idct_islow, fancy up-sampling, ycc_rgb_convert) integer for integer: outputs equal PIL's / cv2's decode BIT FOR BIT
  * (oracle/jpeg.py is pinned to PIL on every JPEG of the reference repository).
  * info [host, 24 ints]: 0 width, 1 height, 2 components (1 | 3), 3 hmax, 4 vmax, 5 MCUs per row, 6 MCU rows, 7 restart interval,
- * 8 EXIF orientation (1 = upright or absent; the caller applies 2..8 or keeps its host decoder), 9 + 4c .. 11 + 4c: h, v, quantisation
+ * 8 EXIF orientation (1 = upright or absent; 2..8: imcui_hip_orient_u8 after the reconstruction), 9 + 4c .. 11 + 4c: h, v, quantisation
  * table of component c.  Supported: SOF0 / SOF1 Huffman, 8 bit, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals,
  * interleaved or per-component scans; everything else (progressive, arithmetic, CMYK, 12 bit, 4:4:0) returns IMCUI_HIP_ERR_UNSUPPORTED. */
 int imcui_hip_jpeg_info(const unsigned char* data, size_t n, int* info);
@@ -367,6 +367,9 @@ size_t imcui_hip_jpeg_workspace_bytes(const int* info, int gray);
 size_t imcui_hip_jpeg_workspace_bytes_batch(const int* info, int gray, int n);
 /* n files of ONE geometry (equal info records) in three launches: coef_y / coef_cb / coef_cr [dev, n x plane coefficients] (chroma may be
  * NULL for gray output / one-component files), qt [dev, n x 192], out [dev]: [n,H,W] uint8 (gray) or [n,H,W,3] */
+/* EXIF orientation 1..8 applied to a decoded image (cv2.imread does this inside the decoder): src [dev, H,W,C] uint8 -> dst [dev, H*W*C
+ * bytes] = [H,W,C] for 1..4, [W,H,C] for 5..8 (5 transpose, 6 rotate 90 clockwise, 7 transverse, 8 rotate 90 counter-clockwise) */
+int imcui_hip_orient_u8(imcui_hip_t* h, const unsigned char* src, int H, int W, int C, int orientation, unsigned char* dst, void* stream);
 int imcui_hip_jpeg_reconstruct_batch(imcui_hip_t* h, const short* coef_y, const short* coef_cb, const short* coef_cr, const unsigned short* qt, const int* info,
                                      int n, int gray, unsigned char* out, void* ws, size_t ws_bytes, void* stream);
 /* coef / qt [dev]: copies of the two buffers above; info [host]; out [dev]: gray != 0 -> [H][W] uint8 = the luma plane (what

@@ -267,3 +267,24 @@ def decode(data: bytes, gray: bool = False) -> np.ndarray:
     """The whole decode in Python / numpy (slow bit loop: small files)."""
     j = parse(data)
     return reconstruct(j["W"], j["H"], j["comps"], [j["qt"][c["tq"]] for c in j["comps"]], j["hmax"], j["vmax"], gray)
+
+
+def orient(img: np.ndarray, orientation: int) -> np.ndarray:
+    """EXIF orientation 1..8 applied to a decoded image, as cv2.imread does inside its decoder (pinned to PIL's ImageOps.exif_transpose
+    in tests/test_jpeg_cpu.py): 2 mirror, 3 rotate 180, 4 flip, 5 transpose, 6 rotate 90 clockwise, 7 transverse, 8 rotate 90 counter-clockwise."""
+    if orientation == 2:
+        return img[:, ::-1]
+    if orientation == 3:
+        return img[::-1, ::-1]
+    if orientation == 4:
+        return img[::-1]
+    t = np.swapaxes(img, 0, 1)
+    if orientation == 5:
+        return t
+    if orientation == 6:
+        return t[:, ::-1]
+    if orientation == 7:
+        return t[::-1, ::-1]
+    if orientation == 8:
+        return t[::-1]
+    return img

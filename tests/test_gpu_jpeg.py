@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_jpeg_cpu import CASES, GOLD, encode, pil_decode, smooth_image
+from test_jpeg_cpu import CASES, GOLD, encode, exif_jpeg, pil_decode, smooth_image
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -105,3 +105,26 @@ def test_extract_features_from_jpeg_files_equals_the_plugin_on_pil_gray(tmp_path
             k = np.asarray(fd[n]["keypoints"])
             assert k.shape[0] > 100 and np.array_equal(k, ref["keypoints"][0].cpu().numpy())
             assert np.array_equal(np.asarray(fd[n]["scores"]), ref["scores"][0].cpu().numpy())
+
+
+def test_exif_orientation_is_applied_on_the_device():
+    """cv2.imread applies the EXIF orientation inside its decoder; the device path does it after the reconstruction
+    (`imcui_hip_orient_u8`): all eight values, RGB and gray, single-file and batch entry points, against PIL's exif_transpose."""
+    from PIL import Image, ImageOps
+
+    from imcui_hip.hloc.utils.jpeg import JpegDecoder, decode_jpeg
+
+    blobs = [exif_jpeg(smooth_image(40 + o, 37, 53), o, quality=88, subsampling="4:2:0") for o in range(1, 9)]
+    dec = JpegDecoder(DEV, threads=2)
+    for gray in (False, True):
+        batch = dec.decode_batch(blobs, gray)
+        for o, data in enumerate(blobs, 1):
+            im = ImageOps.exif_transpose(Image.open(io.BytesIO(data)))
+            want = np.array(im.convert("RGB"))
+            if gray:  # the luma plane of the file in its EXIF orientation
+                from oracle.jpeg import orient
+
+                want = np.ascontiguousarray(orient(pil_decode(data, True), o))
+            assert np.array_equal(decode_jpeg(data, gray, DEV).cpu().numpy(), want), (o, gray)
+            assert np.array_equal(batch[o - 1].cpu().numpy(), want), (o, gray)
+    dec.close()

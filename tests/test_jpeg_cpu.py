@@ -130,13 +130,29 @@ def test_unsupported_and_damaged_files_are_refused():
     qt = np.zeros(192, np.uint16)
     assert lib.imcui_hip_jpeg_info(cut, len(cut), info) == 0  # the header is intact ...
     assert lib.imcui_hip_jpeg_entropy_decode(cut, len(cut), coef.ctypes.data, qt.ctypes.data) in (0, -1)  # ... the scan is short: zeros are fed (libjpeg pads too) or refused, never a crash
-    # EXIF orientation is reported, not applied
-    ex = io.BytesIO()
-    im = Image.fromarray(smooth_image(7, 20, 30))
+
+
+def exif_jpeg(img, orientation, **kw):
+    im = Image.fromarray(img)
     exif = im.getexif()
-    exif[0x0112] = 6
-    im.save(ex, "JPEG", exif=exif)
-    assert lib.imcui_hip_jpeg_info(ex.getvalue(), len(ex.getvalue()), info) == 0 and info[8] == 6
+    exif[0x0112] = orientation
+    buf = io.BytesIO()
+    im.save(buf, "JPEG", exif=exif, **kw)
+    return buf.getvalue()
+
+
+def test_exif_orientation_is_reported_and_the_restated_transform_equals_pil():
+    """The info record carries the EXIF orientation; `oracle.jpeg.orient` (what the device kernel is held to) equals PIL's
+    `ImageOps.exif_transpose` -- the transform cv2.imread applies inside its decoder -- for all eight values."""
+    from PIL import ImageOps
+
+    lib = load_library()
+    info = (C.c_int * 24)()
+    for ori in range(1, 9):
+        data = exif_jpeg(smooth_image(7 + ori, 20, 30), ori, quality=90)
+        assert lib.imcui_hip_jpeg_info(data, len(data), info) == 0 and info[8] == ori
+        want = np.array(ImageOps.exif_transpose(Image.open(io.BytesIO(data))).convert("RGB"))
+        assert np.array_equal(np.ascontiguousarray(oj.orient(pil_decode(data, False), ori)), want), ori
 
 
 def test_batch_entropy_decoder_equals_the_single_file_one():
