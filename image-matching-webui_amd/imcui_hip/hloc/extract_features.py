@@ -120,6 +120,44 @@ def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> to
     return torch.from_numpy(read_image_u8(path, grayscale)).to(device)
 
 
+def read_images_device(paths, grayscale: bool, device, decode: str = "auto", decoder=None) -> list:
+    """`read_image_device` for a list of files: the baseline JPEGs among them go through ONE `JpegDecoder.decode_batch` call (bit streams on
+    the library's host threads into pinned staging, one transfer + three launches per group of equally shaped files), everything else --
+    and every file the device path refuses -- through the host reader.  -> list of uint8 device tensors in the order of `paths`."""
+    if decode not in ("auto", "host", "device"):
+        raise ValueError(f"decode = {decode!r}: auto | host | device")
+    out: list = [None] * len(paths)
+    if decode != "host":
+        from .utils.jpeg import JpegDecoder, JpegUnsupported, is_jpeg
+
+        blobs, where = [], []
+        for i, p in enumerate(paths):
+            try:
+                data = Path(p).read_bytes()
+            except OSError as e:
+                raise ValueError(f"Cannot read image {p}.") from e
+            if is_jpeg(data):
+                blobs.append(data)
+                where.append(i)
+            elif decode == "device":
+                raise ValueError(f"{p}: not a JPEG file (decode='device')")
+        if blobs:
+            own = decoder is None
+            dec = JpegDecoder(device) if own else decoder
+            for i, r in zip(where, dec.decode_batch(blobs, grayscale)):
+                if isinstance(r, JpegUnsupported):
+                    if decode == "device":
+                        raise r
+                else:
+                    out[i] = r
+            if own:
+                dec.close()
+    for i, p in enumerate(paths):
+        if out[i] is None:
+            out[i] = torch.from_numpy(read_image_u8(p, grayscale)).to(device)
+    return out
+
+
 def image_names(root: Path, conf: SimpleNamespace, paths=None) -> List[str]:
     """`ImageDataset.__init__` (:53-77): glob the root or take an explicit list; every name must exist."""
     root = Path(root)
@@ -170,10 +208,10 @@ def preprocess_on_device(img_u8, conf: SimpleNamespace, device) -> torch.Tensor:
 @torch.no_grad()
 def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half: bool = True,
          image_list: Optional[Union[Path, Sequence[str]]] = None, feature_path: Optional[Path] = None, overwrite: bool = False,
-         model=None, batch_size: int = 32, device="cuda", decode: str = "auto") -> Path:  # fmt: skip
+         model=None, batch_size: int = 32, device="cuda", decode: str = "auto", decode_threads: int = 8) -> Path:  # fmt: skip
     """Reference signature (:174-182) + `model` (a loaded HIP extractor plugin; built from conf["model"] when None),
-    `batch_size` (images per C-ABI call) and `decode` (`read_image_device`: "auto" = baseline JPEGs decoded on the device).  Returns
-    the feature file path."""
+    `batch_size` (images per C-ABI call), `decode` (`read_images_device`: "auto" = baseline JPEGs decoded on the device, 2 x batch_size
+    files per `JpegDecoder.decode_batch` call) and `decode_threads` (host threads of the Huffman stage).  Returns the feature file path."""
     pconf = SimpleNamespace(**{**DEFAULT_PREPROCESSING, **conf.get("preprocessing", {})})
     image_dir = Path(image_dir)
     names = image_names(image_dir, pconf, image_list)
@@ -227,14 +265,23 @@ def main(conf: Dict, image_dir: Path, export_dir: Optional[Path] = None, as_half
                     grp.create_dataset(k, data=v)
                 grp["keypoints"].attrs["uncertainty"] = uncertainty
 
-    for name in names:
-        img_u8 = read_image_device(image_dir / name, pconf.grayscale, device, decode)
-        original_size = np.array(tuple(img_u8.shape[:2][::-1]))
-        img = preprocess_on_device(img_u8, pconf, device)
-        key = tuple(img.shape[-2:])
-        pending.setdefault(key, []).append((name, img, original_size))
-        if len(pending[key]) >= batch_size:
-            flush(key)
+    decoder = None
+    if decode != "host":
+        from .utils.jpeg import JpegDecoder
+
+        decoder = JpegDecoder(device, threads=decode_threads)
+    chunk = max(1, 2 * batch_size)  # files read (and, for JPEG, decoded in one batch) ahead of the extractor
+    for c0 in range(0, len(names), chunk):
+        part = names[c0 : c0 + chunk]
+        for name, img_u8 in zip(part, read_images_device([image_dir / n for n in part], pconf.grayscale, device, decode, decoder)):
+            original_size = np.array(tuple(img_u8.shape[:2][::-1]))
+            img = preprocess_on_device(img_u8, pconf, device)
+            key = tuple(img.shape[-2:])
+            pending.setdefault(key, []).append((name, img, original_size))
+            if len(pending[key]) >= batch_size:
+                flush(key)
     for key in list(pending):
         flush(key)
+    if decoder is not None:
+        decoder.close()
     return feature_path
