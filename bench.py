@@ -127,7 +127,7 @@ def cpu_baseline_dense(eloftr: bool, Hh: int, Ww: int, sd: dict, img0, img1, max
                       f"{'EfficientLoFTR' if eloftr else 'LoFTR'} oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} of {ncpu} host CPUs)"}  # fmt: skip
 
 
-def parity_splg(pipe, img0, img1, dc, wc, which=(0,)) -> dict:
+def parity_splg(pipe, img0, img1, dc, wc, which=(0,), keypoints_only=()) -> dict:
     """"parity checks run with every benchmark".  After the timed region, the pairs `which` of the bench batch go
     through the CPU oracle (the restated reference path) one by one and are compared with what the HIP pipeline returns for them:
     key-point sets equal or every difference an audited round-off tie, the matcher run on the HIP key-points gives the same stop layer
@@ -171,7 +171,26 @@ def parity_splg(pipe, img0, img1, dc, wc, which=(0,)) -> dict:
             raise AssertionError(f"bench parity: pair {pi}: matching score error {err:.2e}")
         per_pair.append({"pair": pi, "keypoints": [n0, n1], "keypoint_ties_audited": ties, "matches": int((ref["matches0"] > -1).sum()), "match_ties_audited": mt,
                          "max_score_error": err, "stop_layer": ref["stop"]})  # fmt: skip
+    # the extractor alone on further pairs of the batch (`keypoints_only`): the key-point audit is cheap, so it covers every DISTINCT scene
+    # of the batch and the JSON carries the worst tie count seen over all of them
+    extra_ties = []
+    for pi in keypoints_only:
+        ims = torch.cat([img0[pi : pi + 1], img1[pi : pi + 1]])
+        f = pipe.extractor.forward_batched(ims, want_score_map=True)
+        torch.cuda.synchronize()
+        t = 0
+        for b in range(2):
+            ref = sp({"image": ims[b : b + 1].cpu()}, spc, return_intermediates=True)
+            n = int(f["num_keypoints"][b])
+            kp, kr = f["keypoints"][b, :n].cpu(), ref["keypoints"][0]
+            flat_h, flat_r = (kp[:, 1] * W + kp[:, 0]).long(), (kr[:, 1] * W + kr[:, 0]).long()
+            t += audit_keypoint_differences(flat_h, flat_r, f["score_map"][b].cpu(), ref["_dense_scores"][0], spc, tag=f"bench pair {pi} image {b}")
+            if len(set(flat_h.tolist()) & set(flat_r.tolist())) < 0.99 * len(flat_r):
+                raise AssertionError(f"bench parity: pair {pi} image {b}: key-point sets differ ({n} vs {len(flat_r)})")
+        extra_ties.append(t)
+    kp_ties_all = [p["keypoint_ties_audited"] for p in per_pair] + extra_ties
     return {"status": "ok", "checked": f"pairs {list(which)} of the bench batch vs the CPU oracle, after the timed region", "pairs_checked": len(per_pair),
+            "keypoint_audit_pairs": len(kp_ties_all), "worst_keypoint_ties_per_pair_all": max(kp_ties_all), "keypoint_ties_audited_all": sum(kp_ties_all),
             "keypoints": per_pair[0]["keypoints"], "keypoint_ties_audited": sum(p["keypoint_ties_audited"] for p in per_pair),
             "worst_keypoint_ties_per_pair": max(p["keypoint_ties_audited"] for p in per_pair),
             "matches": per_pair[0]["matches"], "match_ties_audited": sum(p["match_ties_audited"] for p in per_pair),
@@ -1286,7 +1305,8 @@ def bench_splg(args, dev, rank, world):
                 pa, pb = (dec8[:4].float() / 255.0)[:, None].to(dev), (dec8[4:].float() / 255.0)[:, None].to(dev)  # (the four pairs the parity check reads)
             else:
                 pa, pb = ((h.float() / 255.0).to(dev) for h in host) if args.h2d else (img0, img1)
-            line["parity"] = parity_splg(pipe, pa, pb, dc, wc, which=sorted({0, 1 % B, 2 % B, 3 % B}))
+            nd = len(pa) if args.h2d == "jpeg" else (B if args.adaptive else min(B, 8))  # distinct scenes of the batch
+            line["parity"] = parity_splg(pipe, pa, pb, dc, wc, which=sorted({0, 1 % B, 2 % B, 3 % B}), keypoints_only=[i for i in range(4, min(nd, 16))])
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         return line
