@@ -490,7 +490,8 @@ extern "C" int imcui_hip_eloftr_forward_ex(imcui_hip_t* h, const float* packed, 
         g.N = S;
         g.K = 256;
         g.alpha = 0.00390625f / 0.1f;
-        g.group_rows = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;
+        static const int sim_group = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;  // (read once per process: no getenv on a launch path)
+        g.group_rows = sim_group;
         ELRUN(gemm_launch(h, g, stream));
     }
     lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);

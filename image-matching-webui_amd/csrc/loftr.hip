@@ -550,7 +550,8 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.N = S;
         g.K = 256;
         g.alpha = 0.00390625f / 0.1f;
-        g.group_rows = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;
+        static const int sim_group = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;  // (read once per process: no getenv on a launch path)
+        g.group_rows = sim_group;
         LFRUN(gemm_launch(h, g, stream));
     }
     const dim3 blk(256);
