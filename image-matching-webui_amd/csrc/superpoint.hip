@@ -98,6 +98,10 @@ __global__ __launch_bounds__(256) void sp_softmax_kernel(const float* __restrict
 // max_pool2d's implicit padding.  Every thread produces runs of 8 outputs from a register window
 // (8 + 2r LDS reads instead of 8 * (2r+1)); the LDS row stride is odd so both the row pass
 // (lanes along rows) and the column pass (lanes along columns) are bank-conflict free.
+// LDS per workgroup (round 4): the scores and ONE float temporary (the row-pass result) + the two masks as bytes; the suppressed scores
+// `where(supp_mask, 0, scores)` are formed while the row pass reads them instead of being stored.  53 KB at r = 4 (it was 105 KB with
+// five float planes), i.e. three workgroups per CU instead of one: the kernel is a chain of ten barrier-separated passes of dependent
+// LDS reads, and with one wave per SIMD nothing covered their latency.
 #define NMS_T 32
 template <int R>
 __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
@@ -105,14 +109,14 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
     extern __shared__ __attribute__((aligned(16))) char nms_smem[];
     constexpr int halo = 5 * R;
     constexpr int Rg = NMS_T + 2 * halo;
-    constexpr int RS = Rg | 1;  // odd row stride
+    constexpr int RS = Rg | 1;               // odd row stride (floats)
+    constexpr int RB = ((Rg + 3) / 4) | 1;   // row stride of the byte planes in 4-byte words, odd: lanes along rows hit distinct banks
+    constexpr int RSB = RB * 4;
     constexpr int n = Rg * RS;
-    constexpr int NCH = (Rg + 7) / 8;  // chunks of 8 along one axis
     float* S = reinterpret_cast<float*>(nms_smem);  // scores (-inf outside the image)
     float* T = S + n;                               // row-pass temporary
-    float* X = T + n;                               // pool input: mask (0/1) or suppressed scores
-    float* M = X + n;                               // max_mask (0/1)
-    float* U = M + n;                               // supp_mask (0/1)
+    unsigned char* M = reinterpret_cast<unsigned char*>(T + n);  // max_mask (0/1)
+    unsigned char* U = M + Rg * RSB;                             // supp_mask (0/1; 0 outside the image)
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * NMS_T - halo, x0 = blockIdx.x * NMS_T - halo;
@@ -128,9 +132,9 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
     // Each pool only has to be right where a later stage still reads it: pool p (1..5) is evaluated on the
     // tile plus a halo of (5 - p) R, i.e. with a margin of m = p R from the staged region (the last pool
     // exactly on the 32 x 32 core).  That halves the work of evaluating all five on the full 5R-halo region.
-    // T = max over [v-R, v+R] of src (row pass) for rows [m-R, Rg-m+R) x columns [m, Rg-m).
+    // T = max over [v-R, v+R] of src(u, v) (row pass) for rows [m-R, Rg-m+R) x columns [m, Rg-m).
     // work item = (row u, chunk of 8 columns); lanes run along u.
-    auto rowpass = [&](const float* src, auto mc) __attribute__((always_inline)) {
+    auto rowpass = [&](auto&& src, auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
         constexpr int nu = Rg - 2 * (m - R), nv = Rg - 2 * m, nch = (nv + 7) / 8;
         for (int it = tid; it < nu * nch; it += 256) {
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
 #pragma unroll
             for (int j = 0; j < 8 + 2 * R; ++j) {
                 const int v = v0 - R + j;
-                w[j] = (v < Rg) ? src[u * RS + v] : -INFINITY;
+                w[j] = (v < Rg) ? src(u, v) : -INFINITY;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -176,6 +180,10 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
         const int y = y0 + u, x = x0 + v;
         return y >= 0 && y < H && x >= 0 && x < W;
     };
+    auto score = [&](int u, int v) __attribute__((always_inline)) { return S[u * RS + v]; };
+    auto maxmask = [&](int u, int v) __attribute__((always_inline)) { return (float)M[u * RSB + v]; };
+    // supp_scores = where(supp_mask, 0, scores), -inf outside the image (S is -inf and U is 0 there)
+    auto suppscore = [&](int u, int v) __attribute__((always_inline)) { return U[u * RSB + v] ? 0.0f : S[u * RS + v]; };
     using M1 = std::integral_constant<int, 1 * R>;
     using M2 = std::integral_constant<int, 2 * R>;
     using M3 = std::integral_constant<int, 3 * R>;
@@ -183,25 +191,22 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
     using M5 = std::integral_constant<int, 5 * R>;
 
     // max_mask = scores == max_pool(scores)
-    rowpass(S, M1{});
+    rowpass(score, M1{});
     __syncthreads();
-    colpass(M1{}, [&](int u, int v, float pm) { M[u * RS + v] = (inimg(u, v) && S[u * RS + v] == pm) ? 1.0f : 0.0f; });
+    colpass(M1{}, [&](int u, int v, float pm) { M[u * RSB + v] = (inimg(u, v) && S[u * RS + v] == pm) ? 1 : 0; });
     __syncthreads();
     auto iteration = [&](auto ma, auto mb) __attribute__((always_inline)) {
-        // supp_mask = max_pool(max_mask) > 0 ; supp_scores = where(supp_mask, 0, scores)
-        rowpass(M, ma);
+        // supp_mask = max_pool(max_mask) > 0
+        rowpass(maxmask, ma);
         __syncthreads();
-        colpass(ma, [&](int u, int v, float pm) {
-            const bool supp = pm > 0.0f;
-            U[u * RS + v] = supp ? 1.0f : 0.0f;
-            X[u * RS + v] = inimg(u, v) ? (supp ? 0.0f : S[u * RS + v]) : -INFINITY;
-        });
+        colpass(ma, [&](int u, int v, float pm) { U[u * RSB + v] = (pm > 0.0f && inimg(u, v)) ? 1 : 0; });
         __syncthreads();
         // new_max_mask = supp_scores == max_pool(supp_scores) ; max_mask |= new_max_mask & ~supp_mask
-        rowpass(X, mb);
+        rowpass(suppscore, mb);
         __syncthreads();
         colpass(mb, [&](int u, int v, float pm) {
-            if (inimg(u, v) && X[u * RS + v] == pm && U[u * RS + v] == 0.0f) M[u * RS + v] = 1.0f;
+            // (not suppressed => supp_scores = scores at this pixel)
+            if (inimg(u, v) && U[u * RSB + v] == 0 && S[u * RS + v] == pm) M[u * RSB + v] = 1;
         });
         __syncthreads();
     };
@@ -211,17 +216,14 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ i
     for (int i = tid; i < NMS_T * NMS_T; i += 256) {
         const int ty = i / NMS_T, tx = i - ty * NMS_T;
         const int y = blockIdx.y * NMS_T + ty, x = blockIdx.x * NMS_T + tx;
-        if (y < H && x < W) {
-            const int j = (ty + halo) * RS + tx + halo;
-            dst[(size_t)y * W + x] = (M[j] != 0.0f) ? S[j] : 0.0f;
-        }
+        if (y < H && x < W) dst[(size_t)y * W + x] = M[(ty + halo) * RSB + tx + halo] ? S[(ty + halo) * RS + tx + halo] : 0.0f;
     }
 }
 
 template <int R>
 static void nms_launch_r(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
     constexpr int Rg = NMS_T + 10 * R;
-    constexpr size_t smem = (size_t)Rg * (Rg | 1) * 5 * sizeof(float);
+    constexpr size_t smem = (size_t)Rg * (Rg | 1) * 2 * sizeof(float) + (size_t)2 * Rg * 4 * (((Rg + 3) / 4) | 1);  // two float planes + two byte planes
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sp_nms_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     dim3 grid(cdiv(W, NMS_T), cdiv(H, NMS_T), B);
     hipLaunchKernelGGL(sp_nms_kernel<R>, grid, dim3(256), smem, stream, in, out, H, W);
