@@ -24,6 +24,11 @@ enum GemmEpi {
     // (half 1) position of the token times inv_freq[i]; inside a 32-feature half feature i < 16 pairs with i + 16), q *= alpha;
     // everything leaves as f16 hi / lo planes, q / k [seq][head][row][64], v transposed [seq][head][64][row].
     EPI_QKV_VIT = 7,
+    // NO matrix output: the similarity tile of two activation matrices (batched) is reduced while it is parked in LDS to the
+    // nearest-neighbour partials of the mutual-NN matcher -- per row (best value, its column, second best value) over the tile's
+    // 128 columns -> st_rpm / st_rpi / st_rps [batch][st_nct][st_rpitch], per column over each 64-row half -> st_cpm / st_cpi /
+    // st_cps [batch][st_nrh][st_cpitch]; ties keep the lowest index (split mode, f32 B operand; nn.hip)
+    EPI_NNSTAT = 8,
 };
 
 struct GemmP {
@@ -85,6 +90,8 @@ struct GemmP {
     int single = 0;
     float *st_rpm = nullptr, *st_rps = nullptr, *st_cpm = nullptr, *st_cps = nullptr;  // EPI_SIMSTAT partials
     int st_nct = 0, st_nrh = 0;                                                         // partial slots per row / per column
+    int *st_rpi = nullptr, *st_cpi = nullptr;                                           // EPI_NNSTAT: arg-best partials
+    long st_rpitch = 0, st_cpitch = 0;                                                  // EPI_NNSTAT: entries per partial slot (>= M rows / >= N columns)
     const float* rope_cos = nullptr;  // [rows, 32]
     const float* rope_sin = nullptr;
     int heads = 4;

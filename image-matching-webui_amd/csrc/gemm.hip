@@ -546,6 +546,107 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                     p.st_cps[o] = s;
                 }
             }
+        } else if constexpr (EPI == EPI_NNSTAT) {
+            // similarity tile of the mutual-NN matcher: never stored.  While the half is parked in LDS,
+            //  * rows: thread = (row tid & 63, 32-column segment tid >> 6) scans its 32 values in increasing column order (the 16 lanes of
+            //    a 16-byte read group sit on 16 different rows: conflict-free), the four segments of a row are folded in order by threads
+            //    0..63, which write 64 consecutive entries of each partial array;
+            //  * columns: a thread sees 8 rows (increasing) of its 4 columns, the 8 row groups are folded by threads 128..255.
+            // Every comparison is `>` or an explicit lowest-index rule, so ties resolve as a sequential first-maximum scan does.
+            // (A first version reduced a row with five xor-shuffle steps of (best, index, second) per 8 rows and wrote the row partials
+            // from one lane per half-wave: 4.75 ms per 64 pairs of 5000 x 5000 -- the dependent ds_bpermute chains, not the MFMAs.)
+            const int ctile = (cc.col0 >> 7) + PASS_C2(ps);
+            float* clb1 = st + 64 * STG_C_ROW;  // [8 row groups][128 columns] best, second, index (behind the parked half)
+            float* clb2 = clb1 + 8 * 128;
+            int* cli1 = reinterpret_cast<int*>(clb2 + 8 * 128);
+            float* rlb1 = reinterpret_cast<float*>(cli1 + 8 * 128);  // [4 segments][64 rows] best, second, index
+            float* rlb2 = rlb1 + 4 * 64;
+            int* rli1 = reinterpret_cast<int*>(rlb2 + 4 * 64);
+            {
+                const int tl = tid & 63, sg = tid >> 6;
+                const int cbase = cc.col0 + PASS_C2(ps) * 128 + sg * 32;
+                float b1 = -INFINITY, b2 = -INFINITY;
+                int i1 = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + sg * 32 + 4 * k);
+                    const float x[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = cbase + 4 * k + j;
+                        const float xv = col < cc.N ? x[j] : -INFINITY;
+                        const bool up = xv > b1;
+                        b2 = up ? b1 : fmaxf(b2, xv);
+                        i1 = up ? col : i1;
+                        b1 = up ? xv : b1;
+                    }
+                }
+                rlb1[sg * 64 + tl] = b1;
+                rlb2[sg * 64 + tl] = b2;
+                rli1[sg * 64 + tl] = i1;
+            }
+            {
+                float cb1[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cb2[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int ci1[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int tl = (tid >> 5) + 8 * it;
+                    const int row = cc.row0 + h * 64 + tl;
+                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + 4 * (tid & 31));
+                    const float x[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = (row < cc.M && f0 + j < cc.N) ? x[j] : -INFINITY;
+                        const bool up = xv > cb1[j];
+                        cb2[j] = up ? cb1[j] : fmaxf(cb2[j], xv);
+                        ci1[j] = up ? row : ci1[j];
+                        cb1[j] = up ? xv : cb1[j];
+                    }
+                }
+                *reinterpret_cast<float4*>(clb1 + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cb1[0], cb1[1], cb1[2], cb1[3]);
+                *reinterpret_cast<float4*>(clb2 + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cb2[0], cb2[1], cb2[2], cb2[3]);
+                *reinterpret_cast<int4*>(cli1 + (tid >> 5) * 128 + 4 * (tid & 31)) = make_int4(ci1[0], ci1[1], ci1[2], ci1[3]);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int row = cc.row0 + h * 64 + tid;
+                if (row < cc.M) {
+                    float b1 = rlb1[tid], b2 = rlb2[tid];
+                    int i1 = rli1[tid];
+#pragma unroll
+                    for (int sg = 1; sg < 4; ++sg) {  // increasing columns: a later segment wins only with a larger value
+                        const float ob1 = rlb1[sg * 64 + tid], ob2 = rlb2[sg * 64 + tid];
+                        const bool up = ob1 > b1;
+                        b2 = up ? fmaxf(b1, ob2) : fmaxf(b2, ob1);
+                        i1 = up ? rli1[sg * 64 + tid] : i1;
+                        b1 = up ? ob1 : b1;
+                    }
+                    const size_t o = ((size_t)cc.z * p.st_nct + ctile) * p.st_rpitch + row;
+                    p.st_rpm[o] = b1;
+                    p.st_rps[o] = b2;
+                    p.st_rpi[o] = i1;
+                }
+            } else if (tid >= 128) {
+                const int c = tid - 128;
+                const int col = cc.col0 + PASS_C2(ps) * 128 + c;
+                if (col < cc.N) {
+                    float b1 = clb1[c], b2 = clb2[c];
+                    int i1 = cli1[c];
+#pragma unroll
+                    for (int gq = 1; gq < 8; ++gq) {  // the row groups interleave (rows gq, gq + 8, ...): lowest index on equal values
+                        const float ob1 = clb1[gq * 128 + c], ob2 = clb2[gq * 128 + c];
+                        const int oi1 = cli1[gq * 128 + c];
+                        const bool up = ob1 > b1 || (ob1 == b1 && oi1 < i1);
+                        b2 = up ? fmaxf(b1, ob2) : fmaxf(b2, ob1);
+                        i1 = up ? oi1 : i1;
+                        b1 = up ? ob1 : b1;
+                    }
+                    const size_t o = ((size_t)cc.z * p.st_nrh + (cc.row0 >> 6) + h) * p.st_cpitch + col;
+                    p.st_cpm[o] = b1;
+                    p.st_cps[o] = b2;
+                    p.st_cpi[o] = i1;
+                }
+            }
         } else if (colok) {
 #pragma unroll 4
             for (int it = 0; it < 8; ++it) {
@@ -1124,6 +1225,12 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
             if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_cpm || !p.st_cps || p.bias != nullptr || (p.ldc & 3) != 0)
                 return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: EPI_SIMSTAT needs the split mode, an f32 B operand, no bias and the four partial buffers");
             hipLaunchKernelGGL((gemm_split_kernel<EPI_SIMSTAT, 0, false, 2>), dim3(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.batch), dim3(256), 0, stream, p);
+            break;
+        case EPI_NNSTAT:
+            if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_rpi || !p.st_cpm || !p.st_cps || !p.st_cpi || p.bias != nullptr || p.st_rpitch < p.M ||
+                p.st_cpitch < p.N || p.st_nct < cdiv(p.N, BN) || p.st_nrh < 2 * cdiv(p.M, BM))
+                return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: EPI_NNSTAT needs the split mode, an f32 B operand, no bias and the six partial buffers");
+            hipLaunchKernelGGL((gemm_split_kernel<EPI_NNSTAT, 0, false, 2>), dim3(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.batch), dim3(256), 0, stream, p);
             break;
         case EPI_CONV:
             if (p.conv_k > 0)

@@ -1,21 +1,38 @@
 // Mutual nearest-neighbour matcher (imcui/hloc/matchers/nearest_neighbor.py:6-66) on MI355X:
-// sim = D0 . D1^T on the f32 matrix cores, then fused row / column best-two + mutual check.
+// sim = D0 . D1^T on the matrix cores; split arithmetic: the similarity tiles are reduced to best / second-best partials in the GEMM's
+// epilogue (EPI_NNSTAT) and never stored; exact-f32 mode: materialised, then row / column best-two passes.  Then the mutual check.
 #include <math.h>
 
 #include "gemm.h"
 #include "imcui_hip.h"
 
 struct NnWs {
-    float* sim;
+    float* sim;                  // materialised path (exact-f32 mode) only
+    float *rb1, *rb2, *cb1, *cb2;  // fused path: nearest-neighbour partials of the tiles (EPI_NNSTAT)
+    int *ri1, *ci1;
     int *m0, *m1;
     float* s0;
+    int nct, nrh;
     size_t total;
     bool ok;
 };
-static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M) {
+// fused = the split arithmetic: the similarity tiles are reduced in the GEMM's epilogue and never stored (12 B per row and 128-column
+// tile + 12 B per column and 64-row half instead of 4 N M bytes written once and read twice)
+static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M, bool fused) {
     WsAlloc a(ws, bytes);
-    NnWs w;
-    w.sim = a.get<float>((size_t)B * N * M);
+    NnWs w{};
+    w.nct = cdiv(M, 128);
+    w.nrh = 2 * cdiv(N, 128);
+    if (fused) {
+        w.rb1 = a.get<float>((size_t)B * w.nct * N);
+        w.rb2 = a.get<float>((size_t)B * w.nct * N);
+        w.ri1 = a.get<int>((size_t)B * w.nct * N);
+        w.cb1 = a.get<float>((size_t)B * w.nrh * M);
+        w.cb2 = a.get<float>((size_t)B * w.nrh * M);
+        w.ci1 = a.get<int>((size_t)B * w.nrh * M);
+    } else {
+        w.sim = a.get<float>((size_t)B * N * M);
+    }
     w.m0 = a.get<int>((size_t)B * N);
     w.m1 = a.get<int>((size_t)B * M);
     w.s0 = a.get<float>((size_t)B * N);
@@ -23,8 +40,15 @@ static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M) {
     w.ok = a.ok;
     return w;
 }
+// Size that serves either arithmetic (the materialised similarity of the exact-f32 mode is the larger one) ...
 extern "C" size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M) {
-    return nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1).total;
+    const size_t a = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, false).total;
+    const size_t b = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, true).total;
+    return a > b ? a : b;
+}
+// ... and what THIS handle's arithmetic needs (precision 1: the fused path, no similarity matrix)
+extern "C" size_t imcui_hip_mutual_nn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M) {
+    return nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, h != nullptr && h->precision == 1).total;
 }
 
 // best / second best of a strided vector, one wave; ties resolve to the lowest index
@@ -83,6 +107,35 @@ __global__ __launch_bounds__(256) void nn_find_kernel(const float* __restrict__ 
     }
 }
 
+// fused path: fold the tile partials of one direction (slots in increasing index order; lowest index on ties) and apply find_nn's tests
+__global__ __launch_bounds__(256) void nn_merge_kernel(const float* __restrict__ pb1, const int* __restrict__ pi1, const float* __restrict__ pb2,
+                                                       int nslots, int n_out, float ratio2, float dist2, int use_ratio, int use_dist,
+                                                       int* __restrict__ match, float* __restrict__ score) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int i1 = 0x7fffffff;
+    for (int s = 0; s < nslots; ++s) {
+        const size_t o = ((size_t)b * nslots + s) * n_out + i;
+        const float ob1 = pb1[o], ob2 = pb2[o];
+        const int oi1 = pi1[o];
+        if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) {
+            b2 = fmaxf(b1, ob2);
+            b1 = ob1;
+            i1 = oi1;
+        } else {
+            b2 = fmaxf(b2, ob1);
+        }
+    }
+    const float d1 = 2.0f * (1.0f - b1);  // dist_nn = 2 * (1 - sim_nn)
+    bool ok = true;
+    if (use_ratio) ok = ok && (d1 <= ratio2 * (2.0f * (1.0f - b2)));
+    if (use_dist) ok = ok && (d1 <= dist2);
+    match[(size_t)b * n_out + i] = ok ? i1 : -1;
+    if (score) score[(size_t)b * n_out + i] = ok ? (b1 + 1.0f) / 2.0f : 0.0f;
+}
+
 __global__ void nn_mutual_kernel(const int* __restrict__ m0, const int* __restrict__ m1, int N, int M, int do_mutual,
                                  int* __restrict__ out) {
     const int b = blockIdx.y;
@@ -108,10 +161,11 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
         return IMCUI_OK;
     }
     if (D % 32 != 0 || !desc0 || !desc1) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn: D=%d must be a multiple of 32", D);
-    NnWs w = nn_carve(ws, ws_bytes, B, N, M);
+    const bool fused = h->precision == 1;
+    NnWs w = nn_carve(ws, ws_bytes, B, N, M, fused);
     if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "mutual_nn: workspace too small (%zu < %zu)", ws_bytes, w.total);
     GemmP g;
-    g.epi = EPI_BIAS;
+    g.epi = fused ? EPI_NNSTAT : EPI_BIAS;
     g.batch = B;
     g.A = desc0;
     g.lda = D;
@@ -122,6 +176,10 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
     g.C = w.sim;
     g.ldc = M;
     g.c_bs = (long)N * M;
+    if (fused) {
+        g.st_rpm = w.rb1, g.st_rps = w.rb2, g.st_rpi = w.ri1, g.st_rpitch = N, g.st_nct = w.nct;
+        g.st_cpm = w.cb1, g.st_cps = w.cb2, g.st_cpi = w.ci1, g.st_cpitch = M, g.st_nrh = w.nrh;
+    }
     g.M = N;
     g.N = M;
     g.K = D;
@@ -132,10 +190,17 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
     const int use_dist = distance_threshold > 0.0;
     // thresholds are squared in double (Python floats) before meeting the fp32 tensors
     const float r2 = (float)(ratio_threshold * ratio_threshold), d2 = (float)(distance_threshold * distance_threshold);
-    hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, stream, w.sim, N, M, 0, r2, d2, use_ratio, use_dist,
-                       w.m0, scores0);
-    hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, stream, w.sim, N, M, 1, r2, d2, use_ratio, use_dist,
-                       w.m1, (float*)nullptr);
+    if (fused) {
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.rb1, w.ri1, w.rb2, w.nct, N, r2, d2, use_ratio, use_dist, w.m0,
+                           scores0);
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, w.cb1, w.ci1, w.cb2, w.nrh, M, r2, d2, use_ratio, use_dist, w.m1,
+                           (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, stream, w.sim, N, M, 0, r2, d2, use_ratio, use_dist,
+                           w.m0, scores0);
+        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, stream, w.sim, N, M, 1, r2, d2, use_ratio, use_dist,
+                           w.m1, (float*)nullptr);
+    }
     hipLaunchKernelGGL(nn_mutual_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.m0, w.m1, N, M, do_mutual_check,
                        matches0);
     IMCUI_CHECK_LAUNCH(h);

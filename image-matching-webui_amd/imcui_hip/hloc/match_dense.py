@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import backend
-from .extract_features import preprocess_on_device, read_image_device, read_image_u8  # noqa: F401  (read_image_u8: re-exported for callers)
+from .extract_features import preprocess_on_device, read_image_device, read_images_device, read_image_u8  # noqa: F401  (read_image_u8: re-exported for callers)
 from .match_features import names_to_pair
 from .utils.h5lite import open_h5
 
@@ -72,10 +72,35 @@ def match_dense(conf: Dict, pairs: Sequence[Tuple[str, str]], image_dir: Path, m
     existing_refs = set(existing_refs or ())
     cache: Dict[str, Tuple[torch.Tensor, np.ndarray]] = {}
 
+    decoder = None  # one JpegDecoder (pinned staging + host threads) for the whole run
+
+    def prefetch(chunk):
+        """Read every image of `chunk` (a list of pairs) that is not cached yet through ONE `read_images_device` call: the baseline
+        JPEGs among them share a batched entropy decode, one transfer and three launches per geometry (one file per call before)."""
+        nonlocal decoder
+        need = []
+        for pr in chunk:
+            for n in pr:
+                if n not in cache and n not in need:
+                    need.append(n)
+        if not need:
+            return
+        if not pconf.cache_images:  # bounded cache: drop the oldest entries this chunk does not use
+            keep = {n for pr in chunk for n in pr}
+            for n in [n for n in cache if n not in keep]:
+                if len(cache) + len(need) <= 4 * batch_size:
+                    break
+                cache.pop(n)
+        if decode != "host" and decoder is None:
+            from .utils.jpeg import JpegDecoder
+
+            decoder = JpegDecoder(device)
+        imgs = read_images_device([image_dir / n for n in need], pconf.grayscale, device, decode, decoder)
+        for n, im in zip(need, imgs):
+            cache[n] = preprocess_pair_image(im, pconf, device)
+
     def load(name):
-        if name not in cache:
-            if not pconf.cache_images and len(cache) >= 4 * batch_size:
-                cache.pop(next(iter(cache)))
+        if name not in cache:  # (not reached after prefetch; kept for callers that extend the loop)
             cache[name] = preprocess_pair_image(read_image_device(image_dir / name, pconf.grayscale, device, decode), pconf, device)
         return cache[name]
 
@@ -97,15 +122,23 @@ def match_dense(conf: Dict, pairs: Sequence[Tuple[str, str]], image_dir: Path, m
                 grp.create_dataset("keypoints1", data=_rescale(k1, s1))
                 grp.create_dataset("scores", data=pred["scores"].cpu().numpy())
 
-    for name0, name1 in pairs:
-        im0, s0 = load(name0)
-        im1, s1 = load(name1)
-        flip = name0 in existing_refs  # refine the key-points of the query (image1) instead: call with the images exchanged
-        a, b = (im1, im0) if flip else (im0, im1)
-        key = (tuple(a.shape[-2:]), tuple(b.shape[-2:]), flip)
-        pending.setdefault(key, []).append((name0, name1, a, b, s0, s1, flip))
-        if len(pending[key]) >= batch_size:
+    pairs = list(pairs)
+    try:
+        for c0 in range(0, len(pairs), batch_size):
+            chunk = pairs[c0 : c0 + batch_size]
+            prefetch(chunk)
+            for name0, name1 in chunk:
+                im0, s0 = load(name0)
+                im1, s1 = load(name1)
+                flip = name0 in existing_refs  # refine the key-points of the query (image1) instead: call with the images exchanged
+                a, b = (im1, im0) if flip else (im0, im1)
+                key = (tuple(a.shape[-2:]), tuple(b.shape[-2:]), flip)
+                pending.setdefault(key, []).append((name0, name1, a, b, s0, s1, flip))
+                if len(pending[key]) >= batch_size:
+                    flush(key)
+        for key in list(pending):
             flush(key)
-    for key in list(pending):
-        flush(key)
+    finally:
+        if decoder is not None:
+            decoder.close()
     return match_path

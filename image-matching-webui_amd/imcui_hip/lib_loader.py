@@ -161,6 +161,7 @@ SIGNATURES = {
     "imcui_hip_ransac": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_ulonglong,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_mutual_nn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "imcui_hip_mutual_nn_workspace_bytes_for": (C.c_size_t, [C.c_void_p] + [C.c_int] * 3),
     "imcui_hip_mutual_nn": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],

@@ -394,7 +394,12 @@ int imcui_hip_ransac(imcui_hip_t* h, const float* pts0, const float* pts1, const
                      void* stream);
 
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
+/* Workspace: ..._bytes(B, N, M) serves either arithmetic of the library (the exact-f32 mode materialises the B x N x M similarity
+ * matrix: 4 B N M bytes); ..._bytes_for(h, ...) is what THIS handle needs -- in the default 3 x f16 split arithmetic the similarity
+ * tiles are reduced to (best, index, second best) partials inside the GEMM and never stored: 12 B per row and 128-column tile plus
+ * 12 B per column and 64-row half (7 MB instead of 100 MB for a 5000 x 5000 pair). */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
+size_t imcui_hip_mutual_nn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /
  * distance_threshold <= 0 mean "None"; matches0 [dev, B,N] int32, scores0 [dev, B,N]. */
 int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,

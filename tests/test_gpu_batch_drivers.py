@@ -108,12 +108,14 @@ def test_extract_then_match_from_files_equals_the_per_call_plugins(tmp_path):
     assert total > 10
 
 
-@pytest.mark.parametrize("matcher", ["loftr", "eloftr"])
-def test_dense_driver_equals_one_pair_per_call(tmp_path, matcher):
+@pytest.mark.parametrize("matcher,ext", [("loftr", "png"), ("eloftr", "png"), ("loftr", "jpg")])
+def test_dense_driver_equals_one_pair_per_call(tmp_path, matcher, ext):
     """`match_dense` on image files (imcui/hloc/match_dense.py:196-253), B pairs per C-ABI call, against the reference flow:
     one `model({"image0", "image1"})` call per pair on the same preprocessed tensors, key-points rescaled to the original
     resolution, groups `name0/name1` with keypoints0 / keypoints1 / scores.  Includes a pair that is flipped because its
-    first image is an existing reference, an image that needs the area resize, and one whose size needs the dfactor resize."""
+    first image is an existing reference, an image that needs the area resize, and one whose size needs the dfactor resize.
+    The driver reads the files of a chunk of pairs in one batched call (`read_images_device`): PNG files take the host reader, the JPEG
+    files the device decoder, whose pixels equal the host reader's bit for bit -- so the per-pair flow below (host reader) must agree."""
     from types import SimpleNamespace
 
     from PIL import Image
@@ -130,8 +132,8 @@ def test_dense_driver_equals_one_pair_per_call(tmp_path, matcher):
     for i, (hw, shift) in enumerate([((256, 320), (16, 8)), ((256, 320), (8, 24)), ((256, 320), (-16, 0)), ((512, 640), (32, 16)), ((262, 325), (16, 8))]):
         i0, i1, _ = make_shifted_pair(40 + i, hw[0], hw[1], shift, 900)
         for side, img in (("a", i0), ("b", i1)):
-            Image.fromarray((img[0, 0] * 255).round().to(torch.uint8).numpy()).save(root / f"{side}{i}.png")
-        names.append((f"a{i}.png", f"b{i}.png"))
+            Image.fromarray((img[0, 0] * 255).round().to(torch.uint8).numpy()).save(root / f"{side}{i}.{ext}", **({"quality": 95} if ext == "jpg" else {}))
+        names.append((f"a{i}.{ext}", f"b{i}.{ext}"))
     df = 32 if matcher == "eloftr" else 8
     conf = {"model": {"name": matcher, "match_threshold": 0.2, "max_keypoints": 500}, "preprocessing": {"grayscale": True, "resize_max": 320, "dfactor": df}}
     if matcher == "eloftr":
@@ -143,7 +145,7 @@ def test_dense_driver_equals_one_pair_per_call(tmp_path, matcher):
 
         sd = loftr_state_dict(0)
     model = Model({**conf["model"], "state_dict": sd}).eval().to("cuda:0")
-    existing = {"a1.png"}
+    existing = {f"a1.{ext}"}
     path = md.match_dense(conf, names, root, tmp_path / "dense.h5", existing_refs=existing, model=model, batch_size=3)
     pconf = SimpleNamespace(**{**md.DEFAULT_PREPROCESSING, **conf["preprocessing"]})
     total = 0
