@@ -2,7 +2,8 @@
 # Round evidence collector: run on the GPU box (gpurun), writes under gpurun_out/final_r04/; tools/summarize_profiles.py r04_final then
 # copies the judged summaries into profiles/.  rocprofv3 needs cwd=/tmp and TMPDIR=/tmp on this pool; counters are collected one per
 # pass (FETCH_SIZE, WRITE_SIZE, one SQ group), never together with a trace domain.
-# PART=1: bench lines + kernel tables;  PART=2: counter passes;  PART=3: A/B legs, labs, GPU test log.  (default: all)
+# PART=1: bench lines + kernel tables;  PART=2: counter passes;  PART=3: A/B legs, labs, GPU test log (default: 123);  PART=4: the driver's
+# line, the splg / nn kernel tables and the GPU test log again (after a late kernel change).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${OUT:-final_r04}
 mkdir -p $O
@@ -50,6 +51,13 @@ if [[ $P == *3* ]]; then
   ( cd $R && timeout 600 python tools/attn_pv2_audit.py > $O/lab_attention_pv2.txt 2>/dev/null; tail -2 $O/lab_attention_pv2.txt | cut -c1-120 )
   ( cd $R && timeout 300 python tools/jpeg_bench.py > $O/lab_jpeg.txt 2>/dev/null; cat $O/lab_jpeg.txt )
   ( cd $R && timeout 100 python tools/ffn_bench.py > $O/lab_ffn_phases.txt 2>&1 )
+  ( cd $R && timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log )
+  ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
+fi
+if [[ $P == *4* ]]; then  # the re-collection after the simple_nms / mutual-NN kernels changed (same commit as the rest otherwise)
+  T=900 b bench_splg --steps 20 --warmup 5
+  stats splg --steps 5 --warmup 2
+  stats nn --workload nn --steps 5 --warmup 2
   ( cd $R && timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log )
   ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 fi

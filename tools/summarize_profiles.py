@@ -136,6 +136,7 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_dust3r_512_head_unfused.json.log", f"{tag}_bench_dust3r_512_head_unfused.json.log"),
                  ("bench_dust3r_512_b8.json.log", f"{tag}_bench_dust3r_512_b8.json.log"),
                  ("stats_mast3r/mast3r_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_mast3r_512.csv"),
+                 ("stats_nn/nn_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_nn.csv"),
                  ("bench_splg_attn_v0.json.log", f"{tag}_bench_splg_attn_v0.json.log"), ("bench_splg_attn_v6.json.log", f"{tag}_bench_splg_attn_v6.json.log"),
                  ("bench_splg_attn_v7.json.log", f"{tag}_bench_splg_attn_v7.json.log"), ("bench_splg_h2d_jpeg.json.log", f"{tag}_bench_splg_h2d_jpeg.json.log"),
                  ("lab_attention_pv2.txt", f"{tag.split('_')[0]}_lab_attention_pv2.txt"), ("lab_jpeg.txt", f"{tag.split('_')[0]}_lab_jpeg.txt"),
