@@ -70,3 +70,30 @@ def test_nn_large_vs_oracle(precision):
     same = (m0.cpu().long() == ref["matches0"]).numpy()
     _audit_nn_rows(d0.numpy(), d1.numpy(), {"ratio_threshold": 0.95}, np.argwhere(~same))
     assert (s0.cpu() - ref["matching_scores0"]).abs().numpy()[same].max() < 1e-5
+
+
+def test_nn_exact_ties_resolve_to_the_lowest_index(precision):
+    """Duplicated descriptors give bit-equal similarities; `find_nn`'s arg-max on the CPU reference returns the FIRST maximum, and so must
+    every stage of the fused reduction (32-column segments, 128-column tiles, 64-row halves, the fold kernels): duplicates are placed so
+    that the tied candidates fall into different segments, different tiles and different row groups.  No audit: the matches are equal."""
+    from imcui_hip import backend
+    from oracle.mutual_nn import mutual_nn
+
+    g = torch.Generator().manual_seed(11)
+    N, M, D = 700, 900, 128
+    d0 = torch.nn.functional.normalize(torch.randn(1, D, N, generator=g), dim=1)
+    d1 = torch.nn.functional.normalize(torch.randn(1, D, M, generator=g), dim=1)
+    # columns (image-1 descriptors) duplicated across segments / tiles: j and j + 37, j + 129, j + 514 are copies of the true partner of row j
+    for j in range(0, 60):
+        d1[0, :, j] = torch.nn.functional.normalize(d0[0, :, j] + 0.05 * torch.randn(D, generator=g), dim=0)
+        for off in (37, 129, 514):
+            d1[0, :, j + 60 + off] = d1[0, :, j]
+    # rows (image-0 descriptors) duplicated across row groups / halves / tiles: the column's best row is then tied
+    for i in range(100, 140):
+        for off in (1, 8, 64, 200, 400):
+            d0[0, :, i + 40 * (1 + (off % 7)) + off] = d0[0, :, i]
+    for conf in ({"ratio_threshold": None, "distance_threshold": None, "do_mutual_check": True}, {"ratio_threshold": 0.99, "distance_threshold": None, "do_mutual_check": False}):
+        ref = mutual_nn({"descriptors0": d0, "descriptors1": d1}, conf)
+        m0, s0 = backend.mutual_nn(d0.permute(0, 2, 1).cuda(), d1.permute(0, 2, 1).cuda(), conf["ratio_threshold"], conf["distance_threshold"], conf["do_mutual_check"])
+        assert torch.equal(m0.cpu().long(), ref["matches0"].long()), (conf, (m0.cpu().long() != ref["matches0"].long()).nonzero()[:8])
+        assert (s0.cpu() - ref["matching_scores0"]).abs().max().item() < 1e-5
