@@ -61,4 +61,9 @@ if [[ $P == *4* ]]; then  # the re-collection after the simple_nms / mutual-NN k
   ( cd $R && timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log )
   ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 fi
+if [[ $P == *5* ]]; then  # counters of the mutual-NN leg (the reducing GEMM)
+  b bench_nn --workload nn
+  for c in FETCH_SIZE WRITE_SIZE; do WL="--workload nn" pmc nn_$c nn $c; done
+  WL="--workload nn" pmc nn_SQ nn $SQ
+fi
 ls $O | wc -l

@@ -47,7 +47,7 @@ json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_
                    "(traffic == compulsory bytes; it was 4.5x that before the remap)"},
           open(os.path.join(P, f"{tag}_attention_traffic.json"), "w"), indent=1)
 # LoFTR / EfficientLoFTR: HBM traffic of the GEMM-class kernels per step (same two passes on the dense workloads)
-for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench_eloftr_640x480.json.log"), ("dust3r", "bench_dust3r_512.json.log")):
+for stem, benchlog in (("loftr", "bench_loftr_1024.json.log"), ("eloftr", "bench_eloftr_640x480.json.log"), ("dust3r", "bench_dust3r_512.json.log"), ("nn", "bench_nn.json.log")):
     if not os.path.exists(os.path.join(F, f"pmc_{stem}_FETCH_SIZE", f"{stem}_counter_collection.csv")):
         continue
     lfe, lwr = agg("FETCH_SIZE", f"{stem}_FETCH_SIZE", stem), agg("WRITE_SIZE", f"{stem}_WRITE_SIZE", stem)
@@ -84,7 +84,8 @@ if os.path.exists(sqp):
 for wl, wl_note in (("loftr", "bench.py --workload loftr --steps 2 --warmup 1 (1024x1024, 4 pairs per step)"),
                     ("eloftr", "bench.py --workload eloftr --steps 2 --warmup 1 (640x480, 8 pairs per step)"),
                     ("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 16 pairs per step, 3 x f16 split arithmetic)"),
-                    ("mast3r", "bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 (512x512: network + reciprocal matching, nn_argmax_* kernels)")):
+                    ("mast3r", "bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 (512x512: network + reciprocal matching, nn_argmax_* kernels)"),
+                    ("nn", "bench.py --workload nn --steps 2 --warmup 1 (mutual-NN matcher, 5000 x 128-d descriptors, 64 pairs per step)")):
     dsq = os.path.join(F, f"pmc_{wl}_SQ", f"{wl}_counter_collection.csv")
     if not os.path.exists(dsq):
         continue
