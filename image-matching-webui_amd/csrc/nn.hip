@@ -207,6 +207,51 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
     return IMCUI_OK;
 }
 
+// ------------------------------------------------------------------ the same matcher on the reference's own layout
+// `NearestNeighbor._forward` receives descriptors0 [B, D, N] / descriptors1 [B, D, M] (one COLUMN per descriptor); the kernels above
+// want one row per descriptor.  A tiled transpose through LDS (32 x 32 tiles, 33-float rows: both sides move whole 128-byte runs) into
+// the workspace, then the call above -- torch's `permute().contiguous()` copy fetched 8 x the bytes it moved (12 % of a matcher step).
+__global__ __launch_bounds__(256) void nn_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int D, int N) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, n0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* src = in + (size_t)b * D * N;
+    float* dst = out + (size_t)b * N * D;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (d0 + r < D && n0 + tx < N) tile[r][tx] = src[(size_t)(d0 + r) * N + n0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < N && d0 + tx < D) dst[(size_t)(n0 + r) * D + d0 + tx] = tile[tx][r];
+}
+
+extern "C" size_t imcui_hip_mutual_nn_dn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M, int D) {
+    WsAlloc a(nullptr, 0);
+    a.get<float>((size_t)B * (N > 0 ? N : 1) * D);
+    a.get<float>((size_t)B * (M > 0 ? M : 1) * D);
+    return a.off + imcui_hip_mutual_nn_workspace_bytes_for(h, B, N, M);
+}
+
+extern "C" int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, const float* desc1_dm, int B, int N, int M, int D, double ratio_threshold,
+                                      double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h) return IMCUI_ERR_ARG;
+    if (B <= 0 || N <= 0) return IMCUI_OK;
+    if (M <= 0) return imcui_hip_mutual_nn(h, desc0_dn, desc1_dm, B, N, M, D, ratio_threshold, distance_threshold, do_mutual_check, matches0, scores0, ws, ws_bytes, stream_);
+    if (D <= 0 || !desc0_dn || !desc1_dm) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn_dn: null descriptors / D=%d", D);
+    WsAlloc a(ws, ws_bytes);
+    float* t0 = a.get<float>((size_t)B * N * D);
+    float* t1 = a.get<float>((size_t)B * M * D);
+    if (!ws || !a.ok) return imcui_set_err(h, IMCUI_ERR_WS, "mutual_nn_dn: workspace too small (%zu bytes)", ws_bytes);
+    hipLaunchKernelGGL(nn_transpose_kernel, dim3(cdiv(N, 32), cdiv(D, 32), B), dim3(256), 0, stream, desc0_dn, t0, D, N);
+    hipLaunchKernelGGL(nn_transpose_kernel, dim3(cdiv(M, 32), cdiv(D, 32), B), dim3(256), 0, stream, desc1_dm, t1, D, M);
+    IMCUI_CHECK_LAUNCH(h);
+    return imcui_hip_mutual_nn(h, t0, t1, B, N, M, D, ratio_threshold, distance_threshold, do_mutual_check, matches0, scores0, (char*)ws + a.off, ws_bytes - a.off,
+                               stream_);
+}
+
 // ------------------------------------------------------------------ nearest neighbour by dot product, fused (no similarity matrix)
 // idx[q] = first arg-max over n of <queries[q], db[n]>  (what `cdistMatcher(dist='dot').query` / `bruteforce_reciprocal_nns` of
 // upstream's mast3r/fast_nn.py returns for the queries -- the primitive `fast_reciprocal_NNs` iterates, imcui/hloc/matchers/

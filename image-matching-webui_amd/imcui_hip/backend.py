@@ -957,6 +957,30 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     return m0, s0
 
 
+def mutual_nn_dn(desc0_dn: torch.Tensor, desc1_dm: torch.Tensor, ratio_threshold=None, distance_threshold=None, do_mutual_check=True):
+    """`mutual_nn` on the layout `NearestNeighbor._forward` receives: desc0 [B,D,N], desc1 [B,D,M] (column per descriptor); the transpose
+    runs on the device inside the call (imcui_hip_mutual_nn_dn) -> matches0 [B,N] int32, scores0 [B,N]."""
+    dev = desc0_dn.device
+    hd = get_handle(dev)
+    lib = hd.lib
+    desc0_dn, desc1_dm = desc0_dn.contiguous().float(), desc1_dm.contiguous().float()
+    B, D, N = desc0_dn.shape
+    M = desc1_dm.shape[2]
+    m0 = torch.empty((B, N), dtype=torch.int32, device=dev)
+    s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if D % 32:
+        raise ImcuiHipError(f"descriptor dim {D} must be a multiple of 32")
+    with _nn_lock:
+        ws = _nn_ws.get(lib.imcui_hip_mutual_nn_dn_workspace_bytes_for(hd.h, B, N, M, D), dev)
+        with torch.cuda.device(dev):
+            rc = lib.imcui_hip_mutual_nn_dn(
+                hd.h, _ptr(desc0_dn), _ptr(desc1_dm), B, N, M, D, float(ratio_threshold or 0.0), float(distance_threshold or 0.0),
+                int(bool(do_mutual_check)), _ptr(m0), _ptr(s0), _ptr(ws), ws.numel(), _stream_ptr(),
+            )  # fmt: skip
+            hd.check(rc, "imcui_hip_mutual_nn_dn")
+    return m0, s0
+
+
 def nn_argmax(queries: torch.Tensor, db: torch.Tensor, return_best: bool = False, split: bool = False):
     """queries [Q,D], db [N,D] (D in 16 / 24 / 32) -> int64 [Q]: the FIRST arg-max over n of <queries[q], db[n]> (what
     `cdistMatcher(dist="dot").query` of upstream's mast3r/fast_nn.py returns; imcui/hloc/matchers/mast3r.py:68-75).

@@ -28,9 +28,9 @@ class NearestNeighbor(BaseModel):
         if d0.size(-1) == 0 or d1.size(-1) == 0:
             matches0 = torch.full(d0.shape[:2], -1, device=d0.device)
             return {"matches0": matches0, "matching_scores0": torch.zeros_like(matches0)}
-        m0, s0 = backend.mutual_nn(
-            d0.permute(0, 2, 1),
-            d1.permute(0, 2, 1),
+        m0, s0 = backend.mutual_nn_dn(  # (the [B, D, N] tensors as they come: transposed on the device inside the C call)
+            d0,
+            d1,
             self.conf["ratio_threshold"],
             self.conf["distance_threshold"],
             self.conf["do_mutual_check"],

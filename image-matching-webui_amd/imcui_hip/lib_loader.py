@@ -166,6 +166,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "imcui_hip_mutual_nn_dn_workspace_bytes_for": (C.c_size_t, [C.c_void_p] + [C.c_int] * 4),
+    "imcui_hip_mutual_nn_dn": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "imcui_hip_dual_softmax_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "imcui_hip_dual_softmax": (
         C.c_int,

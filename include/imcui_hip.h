@@ -405,6 +405,11 @@ size_t imcui_hip_mutual_nn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int
 int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,
                         double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0,
                         float* scores0, void* ws, size_t ws_bytes, void* stream);
+/* The same matcher on the layout `NearestNeighbor._forward` receives (nearest_neighbor.py:38-66): descriptors0 [dev, B,D,N], descriptors1
+ * [dev, B,D,M], one column per descriptor; transposed on the device into the workspace (tiled through LDS), then the call above. */
+size_t imcui_hip_mutual_nn_dn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M, int D);
+int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, const float* desc1_dm, int B, int N, int M, int D, double ratio_threshold,
+                           double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- dual-softmax matcher (imcui/hloc/matchers/dual_softmax.py; zoo entries disk+dualsoftmax, superpoint+dualsoftmax) */
 size_t imcui_hip_dual_softmax_workspace_bytes(int B, int C, int N, int M);
