@@ -371,8 +371,11 @@ __global__ void geo_select_kernel(const int* __restrict__ counts, int N, int K, 
             if (wm >= 1.0 - 1e-15)
                 needed = 0;
             else if (wm > 1e-300) {
-                const double it = ceil(lc / log(1.0 - wm));
-                needed = it < (double)K ? (int)(it < 0.0 ? 0.0 : it) : K;
+                // log1p: log(1.0 - wm) is 0 once wm < 2^-53 (w^8 for an inlier ratio below ~1 %), and lc / 0 = -inf used to read as
+                // "no more hypotheses needed".  A non-negative denominator or a non-finite quotient means "no bound": keep K.
+                const double den = log1p(-wm);
+                const double it = den < 0.0 ? ceil(lc / den) : (double)K;
+                needed = (it == it && it < (double)K) ? (int)(it < 0.0 ? 0.0 : it) : K;
             }
         }
     }

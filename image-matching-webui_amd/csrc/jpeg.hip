@@ -56,13 +56,16 @@ struct HuffTable {
     int mincode[17], maxcode[18], valptr[17];
     // 9-bit look-ahead: (length << 8) | symbol, 0 = longer than 9 bits
     unsigned short look[512];
-    void build() {
+    // false: the code lengths do not form a prefix code (over-subscribed: more codes of some length than the code space has left).
+    // libjpeg refuses such a table in jpeg_make_d_derived_tbl; without the test `code << (9 - l)` below indexes far past look[].
+    bool build() {
         int code = 0, k = 0;
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k;
             mincode[l] = code;
             code += bits[l];
             k += bits[l];
+            if (code > (1 << l)) return false;
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -77,6 +80,7 @@ struct HuffTable {
             }
             code <<= 1;
         }
+        return true;
     }
 };
 
@@ -91,6 +95,8 @@ struct Comp {
 struct Jpeg {
     int W = 0, H = 0, nc = 0, hmax = 1, vmax = 1, mx = 0, my = 0, rst = 0, orientation = 1, precision = 8;
     bool progressive = false, arithmetic = false, have_sof = false;
+    bool jfif = false, adobe = false;  // APP0 'JFIF' / APP14 'Adobe' seen (libjpeg's colour-space rule, finish_geometry)
+    int adobe_transform = 0;
     Comp comp[4];
     unsigned short qt[4][64];
     bool have_qt[4] = {false, false, false, false};
@@ -130,6 +136,42 @@ int exif_orientation(const unsigned char* p, size_t n) {
     return 1;
 }
 
+// one DHT segment body (possibly several tables)
+int parse_dht(const unsigned char* p, int pl, Jpeg& j) {
+    int o = 0;
+    while (o < pl) {
+        if (o + 17 > pl) return IMCUI_ERR_ARG;
+        const int tc = p[o] >> 4, th = p[o] & 15;
+        if (tc > 1 || th > 3) return IMCUI_ERR_ARG;
+        HuffTable& t = tc ? j.ac[th] : j.dc[th];
+        int cnt = 0;
+        t.bits[0] = 0;
+        for (int l = 1; l <= 16; ++l) {
+            t.bits[l] = p[o + l];
+            cnt += t.bits[l];
+        }
+        if (cnt > 256 || o + 17 + cnt > pl) return IMCUI_ERR_ARG;
+        memcpy(t.vals, p + o + 17, cnt);
+        t.present = false;
+        if (!t.build()) return IMCUI_ERR_ARG;
+        t.present = true;
+        o += 17 + cnt;
+    }
+    return IMCUI_OK;
+}
+// one DQT segment body
+int parse_dqt(const unsigned char* p, int pl, Jpeg& j) {
+    int o = 0;
+    while (o < pl) {
+        const int pq = p[o] >> 4, tq = p[o] & 15;
+        if (tq > 3 || o + 1 + (pq ? 128 : 64) > pl) return IMCUI_ERR_ARG;
+        for (int k = 0; k < 64; ++k) j.qt[tq][ZIGZAG[k]] = pq ? (unsigned short)be16(p + o + 1 + 2 * k) : p[o + 1 + k];
+        j.have_qt[tq] = true;
+        o += 1 + (pq ? 128 : 64);
+    }
+    return IMCUI_OK;
+}
+
 // parse every segment up to (not including) the first SOS; returns the offset of that SOS marker or a negative status
 long parse_headers(const unsigned char* d, size_t n, Jpeg& j) {
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return IMCUI_ERR_ARG;
@@ -165,39 +207,24 @@ long parse_headers(const unsigned char* d, size_t n, Jpeg& j) {
             }
             j.have_sof = true;
         } else if (m == 0xDB) {
-            int o = 0;
-            while (o < pl) {
-                const int pq = p[o] >> 4, tq = p[o] & 15;
-                if (tq > 3 || o + 1 + (pq ? 128 : 64) > pl) return IMCUI_ERR_ARG;
-                for (int k = 0; k < 64; ++k) j.qt[tq][ZIGZAG[k]] = pq ? (unsigned short)be16(p + o + 1 + 2 * k) : p[o + 1 + k];
-                j.have_qt[tq] = true;
-                o += 1 + (pq ? 128 : 64);
-            }
+            const int rc = parse_dqt(p, pl, j);
+            if (rc != IMCUI_OK) return rc;
         } else if (m == 0xC4) {
-            int o = 0;
-            while (o < pl) {
-                if (o + 17 > pl) return IMCUI_ERR_ARG;
-                const int tc = p[o] >> 4, th = p[o] & 15;
-                if (tc > 1 || th > 3) return IMCUI_ERR_ARG;
-                HuffTable& t = tc ? j.ac[th] : j.dc[th];
-                int cnt = 0;
-                t.bits[0] = 0;
-                for (int l = 1; l <= 16; ++l) {
-                    t.bits[l] = p[o + l];
-                    cnt += t.bits[l];
-                }
-                if (cnt > 256 || o + 17 + cnt > pl) return IMCUI_ERR_ARG;
-                memcpy(t.vals, p + o + 17, cnt);
-                t.present = true;
-                t.build();
-                o += 17 + cnt;
-            }
+            const int rc = parse_dht(p, pl, j);
+            if (rc != IMCUI_OK) return rc;
         } else if (m == 0xDD) {
             if (pl < 2) return IMCUI_ERR_ARG;
             j.rst = be16(p);
         } else if (m == 0xE1) {
             const int ori = exif_orientation(p, pl);
             if (ori != 1) j.orientation = ori;
+        } else if (m == 0xE0) {
+            if (pl >= 5 && memcmp(p, "JFIF\0", 5) == 0) j.jfif = true;
+        } else if (m == 0xEE) {
+            if (pl >= 12 && memcmp(p, "Adobe", 5) == 0) {
+                j.adobe = true;
+                j.adobe_transform = p[11];
+            }
         }
         i += L;
     }
@@ -207,6 +234,15 @@ long parse_headers(const unsigned char* d, size_t n, Jpeg& j) {
 int finish_geometry(Jpeg& j) {
     if (!j.have_sof || j.W <= 0 || j.H <= 0) return IMCUI_ERR_ARG;
     if (j.precision != 8 || (j.nc != 1 && j.nc != 3)) return IMCUI_ERR_UNSUPPORTED;
+    if (j.nc == 3 && !j.jfif) {
+        // libjpeg's default_decompress_parms: JFIF -> YCbCr; else an Adobe marker decides (transform 0 = RGB stored as is); else the
+        // component ids ('R','G','B' = RGB).  Only YCbCr frames are reconstructed here; the others go back to the host reader.
+        if (j.adobe) {
+            if (j.adobe_transform != 1) return IMCUI_ERR_UNSUPPORTED;
+        } else if (j.comp[0].id == 'R' && j.comp[1].id == 'G' && j.comp[2].id == 'B') {
+            return IMCUI_ERR_UNSUPPORTED;
+        }
+    }
     j.hmax = j.vmax = 1;
     for (int c = 0; c < j.nc; ++c) {
         if (j.comp[c].h < 1 || j.comp[c].h > 4 || j.comp[c].v < 1 || j.comp[c].v > 4) return IMCUI_ERR_ARG;
@@ -270,6 +306,7 @@ struct BitReader {
             if (!marker && pos < n) {
                 b = d[pos];
                 if (b == 0xFF) {
+                    while (pos + 2 < n && d[pos + 1] == 0xFF) ++pos;  // FF FF ..: fill bytes in front of a marker / a stuffed FF (T.81 B.1.1.2)
                     const int nx = pos + 1 < n ? d[pos + 1] : 0xD9;
                     if (nx == 0) {
                         pos += 2;
@@ -461,8 +498,11 @@ static int entropy_decode_impl(const unsigned char* data, size_t n, short* coef,
         if ((size_t)pos + 4 > n || data[pos] != 0xFF) return IMCUI_ERR_ARG;
         const int m = data[pos + 1];
         if (m == 0xDA) {
+            const int SL = be16(data + pos + 2);
+            if (SL < 6 || (size_t)pos + 2 + SL > n) return IMCUI_ERR_ARG;  // (the selectors read below lie inside the segment)
             const int ns = data[pos + 4];
-            for (int s = 0; s < ns && s < 4; ++s)
+            if (ns < 1 || ns > 4 || SL != 6 + 2 * ns) return IMCUI_ERR_ARG;
+            for (int s = 0; s < ns; ++s)
                 for (int c = 0; c < j.nc; ++c)
                     if (j.comp[c].id == data[pos + 5 + 2 * s] && !seen[c]) {
                         seen[c] = true;
@@ -478,40 +518,14 @@ static int entropy_decode_impl(const unsigned char* data, size_t n, short* coef,
             const int L = be16(data + pos + 2);
             if (L < 2 || (size_t)pos + 2 + L > n) return IMCUI_ERR_ARG;
             if (m == 0xC4 || m == 0xDB || m == 0xDD) {
-                // re-use the header parser on a two-segment buffer view: SOI is not needed, parse this segment by hand
                 const unsigned char* p = data + pos + 4;
                 const int pl = L - 2;
                 if (m == 0xDD) {
                     if (pl < 2) return IMCUI_ERR_ARG;
                     j.rst = be16(p);
-                } else if (m == 0xDB) {
-                    int o = 0;
-                    while (o < pl) {
-                        const int pq = p[o] >> 4, tq = p[o] & 15;
-                        if (tq > 3 || o + 1 + (pq ? 128 : 64) > pl) return IMCUI_ERR_ARG;
-                        for (int k = 0; k < 64; ++k) j.qt[tq][ZIGZAG[k]] = pq ? (unsigned short)be16(p + o + 1 + 2 * k) : p[o + 1 + k];
-                        j.have_qt[tq] = true;
-                        o += 1 + (pq ? 128 : 64);
-                    }
                 } else {
-                    int o = 0;
-                    while (o < pl) {
-                        if (o + 17 > pl) return IMCUI_ERR_ARG;
-                        const int tc = p[o] >> 4, th = p[o] & 15;
-                        if (tc > 1 || th > 3) return IMCUI_ERR_ARG;
-                        HuffTable& t = tc ? j.ac[th] : j.dc[th];
-                        int cnt = 0;
-                        t.bits[0] = 0;
-                        for (int l = 1; l <= 16; ++l) {
-                            t.bits[l] = p[o + l];
-                            cnt += t.bits[l];
-                        }
-                        if (cnt > 256 || o + 17 + cnt > pl) return IMCUI_ERR_ARG;
-                        memcpy(t.vals, p + o + 17, cnt);
-                        t.present = true;
-                        t.build();
-                        o += 17 + cnt;
-                    }
+                    const int rc2 = (m == 0xDB) ? parse_dqt(p, pl, j) : parse_dht(p, pl, j);
+                    if (rc2 != IMCUI_OK) return rc2;
                 }
             }
             pos += 2 + L;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void nn_find_kernel(const float* __restrict__ 
         bool ok = true;
         if (use_ratio) ok = ok && (d1 <= ratio2 * (2.0f * (1.0f - b2)));
         if (use_dist) ok = ok && (d1 <= dist2);
-        match[(size_t)b * n_out + i] = ok ? i1 : -1;
+        match[(size_t)b * n_out + i] = (ok && i1 != 0x7fffffff) ? i1 : -1;  // (an all-NaN row never updates i1: unmatched, not an out-of-range index)
         if (score) score[(size_t)b * n_out + i] = ok ? (b1 + 1.0f) / 2.0f : 0.0f;
     }
 }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float* __restrict__
     bool ok = true;
     if (use_ratio) ok = ok && (d1 <= ratio2 * (2.0f * (1.0f - b2)));
     if (use_dist) ok = ok && (d1 <= dist2);
-    match[(size_t)b * n_out + i] = ok ? i1 : -1;
+    match[(size_t)b * n_out + i] = (ok && i1 != 0x7fffffff) ? i1 : -1;  // (an all-NaN row never updates i1: unmatched, not an out-of-range index)
     if (score) score[(size_t)b * n_out + i] = ok ? (b1 + 1.0f) / 2.0f : 0.0f;
 }
 

@@ -180,7 +180,9 @@ def ransac(p0, p1, geometry: int, reproj_threshold: float, confidence: float, ma
             if wm >= 1.0 - 1e-15:
                 needed = 0
             elif wm > 1e-300:
-                it = math.ceil(lc / math.log(1.0 - wm))
+                # log1p: 1.0 - wm == 1.0 below 2^-53 (same fix as csrc/geometry.hip); no negative denominator = no bound
+                den = math.log1p(-wm)
+                it = math.ceil(lc / den) if den < 0.0 else K
                 needed = int(max(it, 0)) if it < K else K
         k += 1
     if bestk < 0 or best < m:

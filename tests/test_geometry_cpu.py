@@ -72,3 +72,17 @@ def test_degenerate_inputs():
     line = np.stack([np.arange(20.0), 2 * np.arange(20.0)], 1).astype(np.float32)
     M, mask, _ = og.ransac(line, line + 1, 0, 3.0, 0.99, 50)  # collinear points: every sample is degenerate
     assert M is None and not mask.any()
+
+
+def test_low_inlier_ratio_does_not_stop_the_run():
+    """with 2500 matches, a tight threshold and 97 % outliers the first hypotheses have an inlier ratio w with
+    w^8 < 2^-53, where log(1 - w^8) is exactly 0: the iteration bound must read as "no bound" (log1p), not as "done" -- the run goes
+    on and still finds the geometry.  (The oracle used to raise ZeroDivisionError here, the device stopped at the first hypothesis.)"""
+    p0, p1, F, good = two_view_scene(21, n=2500, outliers=0.90, noise=0.05)
+    M, mask, info = og.ransac(p0, p1, 1, 0.25, 0.999, 400, seed=3)
+    assert info["used"] > 1  # did not stop at the first valid hypothesis
+    # the bound itself: 8 inliers of 2500 -> wm ~ 1e-20
+    import math
+
+    wm = (8 / 2500) ** 8
+    assert math.log(1.0 - wm) == 0.0 and math.log1p(-wm) < 0.0

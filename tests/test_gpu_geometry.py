@@ -114,3 +114,19 @@ def test_throughput_record():
     assert bool(h["ok"].all()) and bool(f["ok"].all())
     print(f"[geometry] 64 pairs x 2048 matches, H + F, 10000 hypotheses each: {ms:.2f} ms per batch = {64 / ms * 1e3:.0f} pairs/s; "
           f"mean hypotheses consumed H {h['iterations'].float().mean().item():.0f} / F {f['iterations'].float().mean().item():.0f}")
+
+
+def test_low_inlier_ratio_equals_the_oracle():
+    """2500 matches, 90 % outliers, a tight threshold, Fundamental: the first hypotheses have w^8 below 2^-53,
+    the regime where `log(1 - w^m)` is 0.  The device's replayed stopping rule must consume the same hypotheses as the oracle's loop."""
+    from imcui_hip.geometry import ransac_batched
+
+    scenes = [two_view_scene(21, n=2500, outliers=0.90, noise=0.05), two_view_scene(22, n=2100, outliers=0.93, noise=0.05)]
+    p0, p1, counts = _batch(scenes)
+    out = ransac_batched(p0, p1, counts, "Fundamental", 0.25, 0.999, 400, seed=3)
+    torch.cuda.synchronize()
+    for b, s in enumerate(scenes):
+        M, mask, info = og.ransac(s[0], s[1], 1, 0.25, 0.999, 400, seed=3, pair_index=b)
+        assert info["used"] > 1
+        assert int(out["iterations"][b]) == info["used"], (b, int(out["iterations"][b]), info["used"])
+        assert bool(out["ok"][b]) == (M is not None)

@@ -227,3 +227,108 @@ def test_mutated_files_never_overrun_or_crash():
         decoded += rc == 0
         refused += rc != 0
     assert decoded > 200 and refused > 200
+
+
+def _segments(data: bytes):
+    """(marker, start, end) of every header segment up to and including SOS."""
+    i, out = 2, []
+    while i + 4 <= len(data):
+        assert data[i] == 0xFF
+        m, L = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        out.append((m, i, i + 2 + L))
+        if m == 0xDA:
+            break
+        i += 2 + L
+    return out
+
+
+def test_over_subscribed_huffman_tables_are_refused():
+    """a DHT whose code-length counts do not form a prefix code must be refused (libjpeg's jpeg_make_d_derived_tbl
+    test), not indexed past the 512-entry look-ahead table.  Every count byte of every table is pushed over its code space in turn."""
+    lib = load_library()
+    good = encode(smooth_image(7, 48, 48), quality=85, subsampling="4:2:0")
+    info = (C.c_int * 24)()
+    assert lib.imcui_hip_jpeg_info(good, len(good), info) == 0
+    tried = 0
+    for m, s, e in _segments(good):
+        if m != 0xC4:
+            continue
+        o = s + 4
+        while o < e:
+            cnt = sum(good[o + 1 : o + 17])
+            for l in range(1, 17):
+                for v in (255, (1 << min(l, 8)) - 1 + 1 if l <= 7 else 255):
+                    b = bytearray(good)
+                    b[o + l] = v
+                    data = bytes(b)
+                    rc = lib.imcui_hip_jpeg_info(data, len(data), info)
+                    over = sum(c << (16 - k) for k, c in enumerate(data[o + 1 : o + 17], start=1)) > (1 << 16)
+                    if over:
+                        assert rc == -1, (l, v, rc)
+                        tried += 1
+            o += 17 + cnt
+    assert tried > 50
+    # the same table arriving BETWEEN two scans (entropy_decode_impl's own segment walk): Y scan, then a bad DHT, then the Cb / Cr scans
+    img = Image.fromarray(smooth_image(8, 32, 32))
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=80, subsampling="4:4:4")
+    data = buf.getvalue()
+    bad_dht = bytes([0xFF, 0xC4, 0x00, 0x14, 0x00, 3] + [0] * 15 + [1])  # three codes of length 1
+    sos = [s for m, s, _ in _segments(data) if m == 0xDA][0]
+    broken = data[:sos] + bad_dht + data[sos:]
+    assert lib.imcui_hip_jpeg_info(broken, len(broken), info) == -1
+
+
+def test_sos_truncation_and_fill_bytes():
+    """a file cut right behind an SOS marker is refused without reading past its end, and FF FF .. fill bytes in
+    front of a restart marker are skipped like libjpeg skips them (the coefficients stay those of the clean file)."""
+    lib = load_library()
+    good = encode(smooth_image(9, 40, 56), quality=80, subsampling="4:2:0", restart_marker_blocks=2)
+    sos = [s for m, s, _ in _segments(good) if m == 0xDA][0]
+    info = (C.c_int * 24)()
+    assert lib.imcui_hip_jpeg_info(good, len(good), info) == 0
+    n = lib.imcui_hip_jpeg_coef_count(info)
+    for cut in range(sos + 2, sos + 14):
+        data = good[:cut]
+        coef = np.zeros(n, np.int16)
+        qt = np.zeros(192, np.uint16)
+        # (exact-size bytes object: an over-read would be caught by the allocator's red zone under ASan; here the status is what is checked)
+        assert lib.imcui_hip_jpeg_entropy_decode(data, len(data), coef.ctypes.data, qt.ctypes.data) in (-1, 0)
+    _, ref, _ = c_entropy(good)
+    rst = good.index(b"\xff\xd0", sos)
+    padded = good[:rst] + b"\xff\xff\xff" + good[rst:]
+    _, got, _ = c_entropy(padded)
+    assert np.array_equal(ref, got)
+    assert np.array_equal(pil_decode(padded, True), pil_decode(good, True))
+
+
+def test_rgb_stored_jpegs_are_left_to_the_host_reader():
+    """three-component frames that libjpeg does NOT treat as YCbCr -- an Adobe APP14 marker with transform 0, or
+    component ids 'R' 'G' 'B' without JFIF / Adobe markers -- are reported unsupported (the drivers then use the host decoder)."""
+    lib = load_library()
+    good = encode(smooth_image(11, 32, 32), quality=90, subsampling="4:4:4")
+    info = (C.c_int * 24)()
+    segs = _segments(good)
+    app0 = [(s, e) for m, s, e in segs if m == 0xE0]
+    assert app0, "PIL writes a JFIF header"
+    s0, e0 = app0[0]
+    no_jfif = good[:s0] + good[e0:]
+    assert lib.imcui_hip_jpeg_info(no_jfif, len(no_jfif), info) == 0  # ids 1, 2, 3 without markers: YCbCr (libjpeg's guess as well)
+    adobe = lambda t: bytes([0xFF, 0xEE, 0x00, 0x0E]) + b"Adobe" + bytes([0, 100, 0, 0, 0, 0, t])
+    for t, want in ((0, -4), (1, 0), (2, -4)):
+        data = good[:s0] + adobe(t) + good[e0:]
+        assert lib.imcui_hip_jpeg_info(data, len(data), info) == want, t
+    with_jfif_and_adobe0 = good[:e0] + adobe(0) + good[e0:]
+    assert lib.imcui_hip_jpeg_info(with_jfif_and_adobe0, len(with_jfif_and_adobe0), info) == 0  # JFIF wins, as in libjpeg
+    # component ids R, G, B (SOF0 and SOS selectors)
+    b = bytearray(no_jfif)
+    for m, s, e in _segments(no_jfif):
+        if m == 0xC0:
+            for c, ch in enumerate(b"RGB"):
+                b[s + 4 + 6 + 3 * c] = ch
+        if m == 0xDA:
+            for c, ch in enumerate(b"RGB"):
+                b[s + 5 + 2 * c] = ch
+    data = bytes(b)
+    assert lib.imcui_hip_jpeg_info(data, len(data), info) == -4
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)))[..., 0], np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[..., 0])  # (PIL agrees it is RGB: it opens)
