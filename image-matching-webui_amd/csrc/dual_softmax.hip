@@ -1,23 +1,37 @@
 // Dual-softmax matcher (imcui/hloc/matchers/dual_softmax.py:8-41) on MI355X: L2-normalise the descriptors,
-// sim = D0^T D1 * inv_temperature on the matrix cores (materialised: 16.8 MB per 2048 x 2048 pair),
-// P = softmax over rows x softmax over columns, match (i, j) when P is both its row and its column maximum
-// and exceeds the threshold.  Everything after the GEMM is HBM-bound passes over sim.
+// sim = D0^T D1 * inv_temperature on the matrix cores, P = softmax over rows x softmax over columns, match (i, j) when P is both its
+// row and its column maximum and exceeds the threshold.
+// Round 5: descriptors of up to 256 channels (every zoo entry: DISK 128, SuperPoint 256) run on the matrix-free two-pass kernel of
+// simred.hip -- sim is never stored.  Wider descriptors keep the round-1 form: sim materialised (16.8 MB per 2048 x 2048 pair), then
+// HBM-bound passes over it.
 #include <math.h>
 
 #include "gemm.h"
 #include "imcui_hip.h"
+#include "simred.h"
 
 struct DsWs {
     float *a, *b, *sim, *rmax, *rsum, *cmax, *csum, *rbest, *cbest;
+    int* bestj;
+    SimDsWs ds;
     size_t total;
     bool ok;
 };
+// channel count the descriptors are padded to: the widths the persistent kernel takes (64 / 128 / 256), else a multiple of 32
+static int ds_pad(int C) { return C <= 64 ? 64 : C <= 128 ? 128 : C <= 256 ? 256 : (int)align_up((size_t)C, 32); }
 static DsWs ds_carve(void* ws, size_t bytes, int B, int Cp, int N, int M) {
     WsAlloc al(ws, bytes);
     DsWs w;
     w.a = al.get<float>((size_t)B * N * Cp);
     w.b = al.get<float>((size_t)B * M * Cp);
-    w.sim = al.get<float>((size_t)B * N * M);
+    w.sim = nullptr;
+    w.bestj = nullptr;
+    if (simred_ok(Cp)) {
+        simred_ds_carve(al, B, N, M, Cp, w.ds);
+        w.bestj = al.get<int>((size_t)B * N);
+    } else {
+        w.sim = al.get<float>((size_t)B * N * M);
+    }
     w.rmax = al.get<float>((size_t)B * N);
     w.rsum = al.get<float>((size_t)B * N);
     w.rbest = al.get<float>((size_t)B * N);
@@ -29,8 +43,7 @@ static DsWs ds_carve(void* ws, size_t bytes, int B, int Cp, int N, int M) {
     return w;
 }
 extern "C" size_t imcui_hip_dual_softmax_workspace_bytes(int B, int C, int N, int M) {
-    const int Cp = (int)align_up((size_t)(C > 0 ? C : 1), 32);
-    return ds_carve(nullptr, 0, B > 0 ? B : 1, Cp, N > 0 ? N : 1, M > 0 ? M : 1).total;
+    return ds_carve(nullptr, 0, B > 0 ? B : 1, ds_pad(C > 0 ? C : 1), N > 0 ? N : 1, M > 0 ? M : 1).total;
 }
 
 // [B, C, n] channels-first -> [B, n, Cp] rows, divided by the L2 norm over C (dual_softmax.py:20-22), zero padded to Cp
@@ -186,6 +199,20 @@ __global__ __launch_bounds__(256) void ds_decide_kernel(const float* __restrict_
     }
 }
 
+// matrix-free path: the row best (value, column) and the column bests come from simred.hip, which saw the columns in REVERSED order (the
+// reference keeps the LAST qualifying column of a row, the kernel reports the first column attaining the row maximum)
+__global__ void ds_decide2_kernel(const float* __restrict__ best, const int* __restrict__ bestj, const float* __restrict__ cbest, int N, int M, float thr,
+                                  int* __restrict__ matches0, float* __restrict__ scores0) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float v = best[(size_t)b * N + i];
+    const int jr = bestj[(size_t)b * N + i];
+    const bool ok = jr >= 0 && jr < M && v > thr && v == cbest[(size_t)b * M + jr];
+    matches0[(size_t)b * N + i] = ok ? M - 1 - jr : -1;
+    scores0[(size_t)b * N + i] = ok ? v : 0.0f;
+}
+
 extern "C" int imcui_hip_dual_softmax(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int C, int N, int M,
                                       double threshold, double inv_temperature, int normalize, int* matches0, float* scores0,
                                       void* ws, size_t ws_bytes, void* stream_) {
@@ -198,12 +225,21 @@ extern "C" int imcui_hip_dual_softmax(imcui_hip_t* h, const float* desc0, const 
         return IMCUI_OK;
     }
     if (!desc0 || !desc1 || !ws) return imcui_set_err(h, IMCUI_ERR_ARG, "dual_softmax: null argument");
-    const int Cp = (int)align_up((size_t)C, 32);
+    const int Cp = ds_pad(C);
     const DsWs w = ds_carve(ws, ws_bytes, B, Cp, N, M);
     if (!w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "dual_softmax: workspace too small (%zu < %zu bytes)", ws_bytes, w.total);
     const dim3 blk(256);
     hipLaunchKernelGGL(ds_prep_kernel, dim3(cdiv(N, 256), B), blk, 0, stream, desc0, w.a, C, Cp, N, normalize);
     hipLaunchKernelGGL(ds_prep_kernel, dim3(cdiv(M, 256), B), blk, 0, stream, desc1, w.b, C, Cp, M, normalize);
+    if (simred_ok(Cp)) {
+        // descriptors1 enter in reversed row order (negative row stride from the last row): first-in-reversed = last-in-original
+        const int rc = simred_dual_softmax(h, w.ds, w.a, Cp, (long)N * Cp, w.b + (size_t)(M - 1) * Cp, -(long)Cp, (long)M * Cp, B, N, M, Cp, (float)inv_temperature,
+                                           (float)threshold, w.rmax, w.rsum, w.cmax, w.csum, w.rbest, w.bestj, w.cbest, stream);
+        if (rc != IMCUI_OK) return rc;
+        hipLaunchKernelGGL(ds_decide2_kernel, dim3(cdiv(N, 256), B), blk, 0, stream, w.rbest, w.bestj, w.cbest, N, M, (float)threshold, matches0, scores0);
+        IMCUI_CHECK_LAUNCH(h);
+        return IMCUI_OK;
+    }
     GemmP g;
     g.epi = EPI_BIAS;
     g.batch = B;

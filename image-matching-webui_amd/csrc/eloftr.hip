@@ -26,6 +26,7 @@
 #include "gemm.h"
 #include "imcui_hip.h"
 #include "loftr_kernels.h"
+#include "simred.h"
 
 // ------------------------------------------------------------------ layer table
 enum {
@@ -159,9 +160,10 @@ extern "C" int imcui_hip_eloftr_pack_weights(const float* conv0_w, const float* 
 struct ElWs {
     float *s0, *s1a, *x1, *s2a, *s2b, *x2, *s3a, *s3b, *fc;
     float *qa, *ka, *q, *k, *v, *att, *o, *up, *hb, *ob;
-    float *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *rp0, *rp1, *mconf;
+    float *rmax, *rsum, *cmax, *csum, *best, *cbest, *mconf;
+    SimDsWs ds;  // the matrix-free dual-softmax (simred.hip): packed coarse features, partials, tile flags
     float *f8, *u4, *a4, *b4, *r4, *u2, *a2, *b2, *r2, *win;
-    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *rpj;
+    int *bestj, *flag, *mb, *mi, *mj, *nmatch;
     size_t total;
     bool ok;
 };
@@ -194,18 +196,13 @@ static ElWs el_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int 
     w.up = a.get<float>(p8 * 256);
     w.hb = a.get<float>(p8 * 512);
     w.ob = a.get<float>(p8 * 256);
-    w.sim = a.get<float>((size_t)B * L0 * L1);
+    simred_ds_carve(a, B, (int)L0, (int)L1, 256, w.ds);
     w.rmax = a.get<float>(cap);
     w.rsum = a.get<float>(cap);
     w.cmax = a.get<float>(cap1);
     w.csum = a.get<float>(cap1);
     w.best = a.get<float>(cap);
     w.cbest = a.get<float>(cap1);
-    w.pc0 = a.get<float>(cap1 * lf2_nbd((int)L0));
-    w.pc1 = a.get<float>(cap1 * lf2_nbd((int)L0));
-    w.rp0 = a.get<float>(cap * lf2_nch((int)L1));
-    w.rp1 = a.get<float>(cap * lf2_nch((int)L1));
-    w.rpj = a.get<int>(cap * lf2_nch((int)L1));
     w.mconf = a.get<float>(cap);
     w.f8 = a.get<float>(p8 * 256);
     w.u4 = a.get<float>(p4 * 256);
@@ -234,7 +231,7 @@ extern "C" size_t imcui_hip_eloftr_workspace_bytes(int B, int H0, int W0, int H1
 
 // byte offsets of workspace buffers, for the parity tests (every per-image buffer: the B images of side 0, then side 1):
 // 0 = backbone 1/2 features [.,H/2,W/2,64], 1 = 1/4 features [.,128], 2 = coarse features after the transformer [., L, 256],
-// 3 = sim [B, L0, L1], 4 = fused 1/2 map R [.,H/2,W/2,64], 5 = fine windows (debug_windows only)
+// 3 = (the similarity matrix until round 4: it no longer exists), 4 = fused 1/2 map R [.,H/2,W/2,64], 5 = fine windows (debug_windows only)
 extern "C" size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1) {
     ElWs w = el_carve((void*)256, (size_t)-1 >> 1, B, H0, W0, H1, W1, 1);
     const char* base = (const char*)256;
@@ -242,7 +239,7 @@ extern "C" size_t imcui_hip_eloftr_debug_offset(int which, int B, int H0, int W0
         case 0: return (const char*)w.x1 - base;
         case 1: return (const char*)w.x2 - base;
         case 2: return (const char*)w.fc - base;
-        case 3: return (const char*)w.sim - base;
+        case 3: return 0;
         case 4: return (const char*)w.r2 - base;
         case 5: return (const char*)w.win - base;
         default: return 0;
@@ -472,29 +469,10 @@ extern "C" int imcui_hip_eloftr_forward_ex(imcui_hip_t* h, const float* packed, 
     }
     IMCUI_CHECK_LAUNCH(h);
 
-    // ---- dual soft-max coarse matching (LoFTR kernels)
-    {
-        GemmP g;  // sim = (f0 / 16) . (f1 / 16)^T / 0.1
-        g.epi = EPI_BIAS;
-        g.batch = B;
-        g.A = w.fc;
-        g.lda = 256;
-        g.a_bs = (long)L * 256;
-        g.W = w.fc + tok1 * 256;
-        g.ldw = 256;
-        g.w_bs = (long)S * 256;
-        g.C = w.sim;
-        g.ldc = S;
-        g.c_bs = (long)L * S;
-        g.M = L;
-        g.N = S;
-        g.K = 256;
-        g.alpha = 0.00390625f / 0.1f;
-        static const int sim_group = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;  // (read once per process: no getenv on a launch path)
-        g.group_rows = sim_group;
-        ELRUN(gemm_launch(h, g, stream));
-    }
-    lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
+    // ---- dual soft-max coarse matching: sim = (f0 / 16) . (f1 / 16)^T / 0.1 is never stored (simred.hip: statistics pass, then the
+    // confidences of the tiles that can exceed the threshold)
+    ELRUN(simred_dual_softmax(h, w.ds, w.fc, 256, (long)L * 256, w.fc + tok1 * 256, 256, (long)S * 256, B, L, S, 256, 0.00390625f / 0.1f, (float)match_threshold,
+                              w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream));
     hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, S, wcs[0], hcs[0], wcs[1], hcs[1], 2,
                        (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi, w.mj,

@@ -17,6 +17,7 @@
 #include "gemm.h"
 #include "imcui_hip.h"
 #include "loftr_kernels.h"
+#include "simred.h"
 
 // ------------------------------------------------------------------ layer table
 enum {
@@ -178,9 +179,10 @@ extern "C" int imcui_hip_loftr_pack_weights(const float* conv1_w, const float* c
 // ------------------------------------------------------------------ workspace
 struct LfWs {
     float *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *fc, *up3, *x2o, *y2, *x2out, *up2, *x1o, *y1, *ff;
-    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *sim, *rmax, *rsum, *cmax, *csum, *best, *cbest, *pc0, *pc1, *rp0, *rp1;
+    float *q, *k, *v, *att, *m, *hb, *ob, *kvpart, *kv, *rmax, *rsum, *cmax, *csum, *best, *cbest;
+    SimDsWs ds;  // the matrix-free dual-softmax (simred.hip): packed coarse features, partials, tile flags
     float *X, *CG, *CW, *F, *fq, *fk, *fv, *fatt, *fm, *fh, *fo, *mconf;
-    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2, *rpj;
+    int *bestj, *flag, *mb, *mi, *mj, *nmatch, *cnt2;
     size_t total;
     bool ok;
 };
@@ -224,19 +226,13 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int 
     const size_t nchunk = ((L0 > L1 ? L0 : L1) + LA_CHUNK - 1) / LA_CHUNK;
     w.kvpart = a.get<float>((size_t)2 * B * 8 * nchunk * (32 * 32 + 32));
     w.kv = a.get<float>((size_t)2 * B * 8 * (32 * 32 + 32));
-    w.sim = a.get<float>((size_t)B * L0 * L1);
+    simred_ds_carve(a, B, (int)L0, (int)L1, 256, w.ds);
     w.rmax = a.get<float>(cap);
     w.rsum = a.get<float>(cap);
     w.cmax = a.get<float>(cap1);
     w.csum = a.get<float>(cap1);
     w.best = a.get<float>(cap);
     w.cbest = a.get<float>(cap1);
-    const size_t ncp = (size_t)(lf2_nbd((int)L0) > LF_RCH ? lf2_nbd((int)L0) : LF_RCH);  // column partials: row bands (two-pass) or row chunks (four-pass)
-    w.pc0 = a.get<float>(cap1 * ncp);
-    w.pc1 = a.get<float>(cap1 * ncp);
-    w.rp0 = a.get<float>(cap * lf2_nch((int)L1));
-    w.rp1 = a.get<float>(cap * lf2_nch((int)L1));
-    w.rpj = a.get<int>(cap * lf2_nch((int)L1));
     w.X = a.get<float>(2 * cap * 25 * 256);
     w.CG = a.get<float>(2 * cap * 256);
     w.CW = a.get<float>(2 * cap * 128);
@@ -263,14 +259,14 @@ static LfWs lf_carve(void* ws, size_t bytes, int B, int H0, int W0, int H1, int 
 extern "C" size_t imcui_hip_loftr_workspace_bytes(int B, int H0, int W0, int H1, int W1) { return lf_carve(nullptr, 0, B, H0, W0, H1, W1).total; }
 
 // byte offsets of a few workspace buffers, for the parity tests: 0 = coarse features after the transformer
-// [B*L0 + B*L1, 256], 1 = fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 = sim [B, L0, L1], 3 = fine windows F
+// [B*L0 + B*L1, 256], 1 = fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 = (the similarity matrix until round 4: gone), 3 = fine windows F
 extern "C" size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1) {
     LfWs w = lf_carve((void*)256, (size_t)-1 >> 1, B, H0, W0, H1, W1);
     const char* base = (const char*)256;
     switch (which) {
         case 0: return (const char*)w.fc - base;
         case 1: return (const char*)w.ff - base;
-        case 2: return (const char*)w.sim - base;
+        case 2: return 0;
         case 3: return (const char*)w.F - base;
         default: return 0;
     }
@@ -532,43 +528,13 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     }
     IMCUI_CHECK_LAUNCH(h);
 
-    // ---- a15: dual-softmax coarse matching
-    {
-        GemmP g;  // sim = (f0 / 16) . (f1 / 16)^T / 0.1
-        g.epi = EPI_BIAS;
-        g.batch = B;
-        g.A = w.fc;
-        g.lda = 256;
-        g.a_bs = (long)L * 256;
-        g.W = w.fc + tok1 * 256;
-        g.ldw = 256;
-        g.w_bs = (long)S * 256;
-        g.C = w.sim;
-        g.ldc = S;
-        g.c_bs = (long)L * S;
-        g.M = L;
-        g.N = S;
-        g.K = 256;
-        g.alpha = 0.00390625f / 0.1f;
-        static const int sim_group = getenv("IMCUI_SIM_GROUP") ? atoi(getenv("IMCUI_SIM_GROUP")) : 8;  // (read once per process: no getenv on a launch path)
-        g.group_rows = sim_group;
-        LFRUN(gemm_launch(h, g, stream));
-    }
+    // ---- a15: dual-softmax coarse matching.  sim = (f0 / 16) . (f1 / 16)^T / 0.1 [B, L, S] -- 1 GiB per 1024 x 1024 pair -- is never
+    // stored: simred.hip computes it tile by tile twice, once for the soft-max statistics of both directions and once
+    // more, only where a confidence can exceed the threshold, for conf = softmax_i * softmax_j, its row maxima (first column) and its
+    // column maxima.  (Rounds 2-4 wrote the matrix and read it back two to four times: 51.6 GB of HBM traffic per 16-pair step.)
+    LFRUN(simred_dual_softmax(h, w.ds, w.fc, 256, (long)L * 256, w.fc + tok1 * 256, 256, (long)S * 256, B, L, S, 256, 0.00390625f / 0.1f, (float)match_threshold,
+                              w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream));
     const dim3 blk(256);
-    static const bool four_pass = getenv("IMCUI_LF_MATCH_4PASS") != nullptr;  // A/B switch: the round-1 form that reads sim four times
-    if (!four_pass) {
-        lf_dual_softmax2_launch(w.sim, B, L, S, w.rp0, w.rp1, w.rpj, w.pc0, w.pc1, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj, w.cbest, stream);
-    } else {
-        const dim3 rg(cdiv(L, 4), B);
-        hipLaunchKernelGGL(lf_rowstat_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum);
-        const dim3 cgz(cdiv(S, 64), B, LF_RCH), cg1(cdiv(S, 256), B);
-        hipLaunchKernelGGL(lf_colstat_kernel, cgz, blk, 0, stream, w.sim, L, S, w.pc0, w.pc1);
-        hipLaunchKernelGGL(lf_colstat_combine_kernel, cg1, blk, 0, stream, w.pc0, w.pc1, S, w.cmax, w.csum);
-        // conf = softmax(sim, dim=1) * softmax(sim, dim=2): dim 1 runs over i (columns stats), dim 2 over j (row stats)
-        hipLaunchKernelGGL(lf_rowbest_kernel, rg, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.best, w.bestj);
-        hipLaunchKernelGGL(lf_colbest_kernel, cgz, blk, 0, stream, w.sim, L, S, w.rmax, w.rsum, w.cmax, w.csum, w.pc0);
-        hipLaunchKernelGGL(lf_colmax_combine_kernel, cg1, blk, 0, stream, w.pc0, S, w.cbest);
-    }
     hipLaunchKernelGGL(lf_decide_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.best, w.bestj, w.cbest, L, S, wcs[0], hcs[0], wcs[1], hcs[1],
                        2, (float)match_threshold, w.flag, (long)cap);
     hipLaunchKernelGGL(lf_compact_kernel, dim3(1), dim3(1024), 0, stream, w.flag, w.best, w.bestj, L, (long)cap, cap, w.mb, w.mi,

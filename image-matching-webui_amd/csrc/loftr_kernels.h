@@ -280,412 +280,10 @@ __global__ __launch_bounds__(256) void lf_la_apply_kernel(const float* __restric
     }
 }
 
-// ------------------------------------------------------------------ dual-softmax coarse matching on sim [B, L, S]
-// row / column statistics (max, sum of exp) -> conf(i,j) = softmax_col(i,j) * softmax_row(i,j)
-__global__ __launch_bounds__(256) void lf_rowstat_kernel(const float* __restrict__ sim, int L, int S,
-                                                         float* __restrict__ rmax, float* __restrict__ rsum) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= L) return;
-    const float* row = sim + ((size_t)b * L + i) * S;
-    // 8 independent loads per trip, folded in the original order (a one-load-per-trip walk is latency bound)
-    float m = -INFINITY;
-    for (int j = lane; j < S; j += 512) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (j + 64 * u < S) ? row[j + 64 * u] : -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
-    }
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int j = lane; j < S; j += 512) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (j + 64 * u < S) ? row[j + 64 * u] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (j + 64 * u < S) s += __expf(v[u] - m);
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-        rmax[(size_t)b * L + i] = m;
-        rsum[(size_t)b * L + i] = s;
-    }
-}
-// column pass, split over LF_RCH row chunks (blockIdx.z): partial (max, sum) per chunk, combined in a
-// fixed order by lf_colstat_combine_kernel
-#define LF_RCH 32
-__global__ __launch_bounds__(256) void lf_colstat_kernel(const float* __restrict__ sim, int L, int S,
-                                                         float* __restrict__ pmax, float* __restrict__ psum) {
-    __shared__ float sm[4][64], ss[4][64];
-    const int b = blockIdx.y, ch = blockIdx.z;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    const int rows = (L + LF_RCH - 1) / LF_RCH;
-    const int i0 = ch * rows, i1 = min(L, i0 + rows);
-    const float* base = sim + (size_t)b * L * S;
-    float m = -INFINITY;
-    if (j < S)
-        for (int i = i0 + g; i < i1; i += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < i1) ? base[(size_t)(i + 4 * u) * S + j] : -INFINITY;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
-        }
-    sm[g][c] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
-    float s = 0.0f;
-    if (j < S && m > -INFINITY)
-        for (int i = i0 + g; i < i1; i += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (i + 4 * u < i1) ? base[(size_t)(i + 4 * u) * S + j] : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + 4 * u < i1) s += __expf(v[u] - m);
-        }
-    ss[g][c] = s;
-    __syncthreads();
-    if (g == 0 && j < S) {
-        pmax[((size_t)b * LF_RCH + ch) * S + j] = m;
-        psum[((size_t)b * LF_RCH + ch) * S + j] = ss[0][c] + ss[1][c] + ss[2][c] + ss[3][c];
-    }
-}
-__global__ void lf_colstat_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int S,
-                                          float* __restrict__ cmax, float* __restrict__ csum) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= S) return;
-    float m = -INFINITY;
-    for (int ch = 0; ch < LF_RCH; ++ch) m = fmaxf(m, pmax[((size_t)b * LF_RCH + ch) * S + j]);
-    float s = 0.0f;
-    for (int ch = 0; ch < LF_RCH; ++ch) {
-        const float pm = pmax[((size_t)b * LF_RCH + ch) * S + j];
-        if (pm > -INFINITY) s += psum[((size_t)b * LF_RCH + ch) * S + j] * __expf(pm - m);
-    }
-    cmax[(size_t)b * S + j] = m;
-    csum[(size_t)b * S + j] = s;
-}
-// conf = softmax(sim, dim=1)[i,j] * softmax(sim, dim=2)[i,j]   (dim 1 = over i / L, dim 2 = over j / S)
-// The four passes over the 1.07 GB matrix evaluate one or two exponentials (and here two divisions) per element: with
-// the library expf and IEEE division they were VALU-bound at 2.3 - 3.2 TB/s.  Arguments are s - max <= 0, so the
-// hardware 2^x (v_exp_f32 of x * log2 e) and v_rcp_f32 (1 ulp each, ~1e-6 relative on conf) are used instead; every
-// pass calls this one function, so the mutual-maximum equality tests stay bit-consistent.
-__device__ __forceinline__ float lf_conf(float s, float cm, float cs, float rm, float rs) {
-    return (__expf(s - cm) * __builtin_amdgcn_rcpf(cs)) * (__expf(s - rm) * __builtin_amdgcn_rcpf(rs));
-}
-// per row: max_j conf and the first j attaining it
-__global__ __launch_bounds__(256) void lf_rowbest_kernel(const float* __restrict__ sim, int L, int S,
-                                                         const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                         const float* __restrict__ cmax, const float* __restrict__ csum,
-                                                         float* __restrict__ best, int* __restrict__ bestj) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= L) return;
-    const float* row = sim + ((size_t)b * L + i) * S;
-    const float rm = rmax[(size_t)b * L + i], rs = rsum[(size_t)b * L + i];
-    float bv = -1.0f;
-    int bj = 0x7fffffff;
-    for (int j0 = lane; j0 < S; j0 += 512) {
-        float sv[8], cm[8], cs[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = min(j0 + 64 * u, S - 1);
-            sv[u] = row[j];
-            cm[u] = cmax[(size_t)b * S + j];
-            cs[u] = csum[(size_t)b * S + j];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = j0 + 64 * u;
-            if (j < S) {
-                const float v = lf_conf(sv[u], cm[u], cs[u], rm, rs);
-                if (v > bv) {
-                    bv = v;
-                    bj = j;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oj = __shfl_xor(bj, o, 64);
-        if (ov > bv || (ov == bv && oj < bj)) {
-            bv = ov;
-            bj = oj;
-        }
-    }
-    if (lane == 0) {
-        best[(size_t)b * L + i] = bv;
-        bestj[(size_t)b * L + i] = bj;
-    }
-}
-// per column: max_i conf, split over LF_RCH row chunks (partials), then lf_colmax_combine_kernel
-__global__ __launch_bounds__(256) void lf_colbest_kernel(const float* __restrict__ sim, int L, int S,
-                                                         const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                         const float* __restrict__ cmax, const float* __restrict__ csum,
-                                                         float* __restrict__ pbest) {
-    __shared__ float sv[4][64];
-    const int b = blockIdx.y, ch = blockIdx.z;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
-    const int rows = (L + LF_RCH - 1) / LF_RCH;
-    const int i0 = ch * rows, i1 = min(L, i0 + rows);
-    const float* base = sim + (size_t)b * L * S;
-    float bv = -1.0f;
-    if (j < S) {
-        const float cm = cmax[(size_t)b * S + j], cs = csum[(size_t)b * S + j];
-        for (int ia = i0 + g; ia < i1; ia += 32) {
-            float sv8[8], rm8[8], rs8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(ia + 4 * u, i1 - 1);
-                sv8[u] = base[(size_t)i * S + j];
-                rm8[u] = rmax[(size_t)b * L + i];
-                rs8[u] = rsum[(size_t)b * L + i];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (ia + 4 * u < i1) bv = fmaxf(bv, lf_conf(sv8[u], cm, cs, rm8[u], rs8[u]));
-        }
-    }
-    sv[g][c] = bv;
-    __syncthreads();
-    if (g == 0 && j < S) pbest[((size_t)b * LF_RCH + ch) * S + j] = fmaxf(fmaxf(sv[0][c], sv[1][c]), fmaxf(sv[2][c], sv[3][c]));
-}
-__global__ void lf_colmax_combine_kernel(const float* __restrict__ pbest, int S, float* __restrict__ cbest) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= S) return;
-    float m = -1.0f;
-    for (int ch = 0; ch < LF_RCH; ++ch) m = fmaxf(m, pbest[((size_t)b * LF_RCH + ch) * S + j]);
-    cbest[(size_t)b * S + j] = m;
-}
-// ------------------------------------------------------------------ fused two-pass form of the dual soft-max (round 2)
-// The four kernels above read the matrix four times (row stats, column stats, row best, column best).  These two read
-// it twice: a workgroup owns a band of LF2_ROWS rows x LF2_COLS columns (wave w: 16 rows, a lane: 4 x float4 = 16
-// columns of every row) and produces BOTH the row statistics of its column chunk (exact max, then sum, inside the
-// chunk) and the column statistics of its row band (online (max, sum) over the wave's 16 rows, four waves combined in
-// LDS); small combine kernels merge the partials in a fixed order (chunks / bands ascending), so results do not depend
-// on scheduling.  The second pass evaluates conf ONCE per element and derives the row maximum (first column attaining
-// it) and the column maximum from that one value, so the mutual-maximum equality test compares identical numbers.
-#define LF2_ROWS 64
-#define LF2_COLS 1024
-__global__ __launch_bounds__(256) void lf_stats2_kernel(const float* __restrict__ sim, int L, int S, int nch, int nbd,
-                                                        float* __restrict__ rpm, float* __restrict__ rps,
-                                                        float* __restrict__ cpm, float* __restrict__ cps) {
-    __shared__ float lm[4][LF2_COLS], ls[4][LF2_COLS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ch = blockIdx.x, bd = blockIdx.y, b = blockIdx.z;
-    const int c0 = ch * LF2_COLS, i0 = bd * LF2_ROWS + wv * 16;
-    const float* base = sim + (size_t)b * L * S;
-    const bool vec = (S & 3) == 0;
-    float cm[16], cs[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        cm[e] = -INFINITY;
-        cs[e] = 0.0f;
-    }
-    for (int r = 0; r < 16; ++r) {
-        const int i = i0 + r;
-        if (i >= L) break;
-        const float* row = base + (size_t)i * S;
-        float x[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = c0 + k * 256 + lane * 4;
-            if (vec && j + 3 < S) {
-                const float4 t = *reinterpret_cast<const float4*>(row + j);
-                x[4 * k] = t.x, x[4 * k + 1] = t.y, x[4 * k + 2] = t.z, x[4 * k + 3] = t.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[4 * k + e] = (j + e < S) ? row[j + e] : -INFINITY;
-            }
-        }
-        float m = x[0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) m = fmaxf(m, x[e]);
-        m = wave_max(m);
-        float s = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float ex = (x[e] > -INFINITY) ? __expf(x[e] - m) : 0.0f;
-            s += ex;
-            // column (max, sum) over the rows seen so far
-            const float mn = fmaxf(cm[e], x[e]);
-            if (mn > -INFINITY) cs[e] = cs[e] * __expf(cm[e] - mn) + ((x[e] > -INFINITY) ? __expf(x[e] - mn) : 0.0f);
-            cm[e] = mn;
-        }
-        s = wave_sum(s);
-        if (lane == 0) {
-            rpm[((size_t)b * nch + ch) * L + i] = m;
-            rps[((size_t)b * nch + ch) * L + i] = s;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            lm[wv][k * 256 + lane * 4 + e] = cm[4 * k + e];
-            ls[wv][k * 256 + lane * 4 + e] = cs[4 * k + e];
-        }
-    __syncthreads();
-    for (int c = threadIdx.x; c < LF2_COLS; c += 256) {
-        const int j = c0 + c;
-        if (j >= S) continue;
-        const float m = fmaxf(fmaxf(lm[0][c], lm[1][c]), fmaxf(lm[2][c], lm[3][c]));
-        float s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-            if (lm[w][c] > -INFINITY) s += ls[w][c] * __expf(lm[w][c] - m);
-        cpm[((size_t)b * nbd + bd) * S + j] = m;
-        cps[((size_t)b * nbd + bd) * S + j] = s;
-    }
-}
-// merge `np` partial (max, sum) pairs per item in ascending partial order: out[b][t] over pm/ps [b][np][n]
-__global__ void lf_stat_combine_kernel(const float* __restrict__ pm, const float* __restrict__ ps, int np, int n,
-                                       float* __restrict__ om, float* __restrict__ os) {
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float m = -INFINITY;
-    for (int p = 0; p < np; ++p) m = fmaxf(m, pm[((size_t)b * np + p) * n + t]);
-    float s = 0.0f;
-    for (int p = 0; p < np; ++p) {
-        const float q = pm[((size_t)b * np + p) * n + t];
-        if (q > -INFINITY) s += ps[((size_t)b * np + p) * n + t] * __expf(q - m);
-    }
-    om[(size_t)b * n + t] = m;
-    os[(size_t)b * n + t] = s;
-}
-__global__ __launch_bounds__(256) void lf_best2_kernel(const float* __restrict__ sim, int L, int S, int nch, int nbd,
-                                                       const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                       const float* __restrict__ cmax, const float* __restrict__ csum,
-                                                       float* __restrict__ rpv, int* __restrict__ rpj, float* __restrict__ cpv) {
-    __shared__ float lb[4][LF2_COLS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ch = blockIdx.x, bd = blockIdx.y, b = blockIdx.z;
-    const int c0 = ch * LF2_COLS, i0 = bd * LF2_ROWS + wv * 16;
-    const float* base = sim + (size_t)b * L * S;
-    const bool vec = (S & 3) == 0;
-    float cm[16], ci[16], cb[16];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = min(c0 + k * 256 + lane * 4 + e, S - 1);
-            cm[4 * k + e] = cmax[(size_t)b * S + j];
-            ci[4 * k + e] = __builtin_amdgcn_rcpf(csum[(size_t)b * S + j]);
-            cb[4 * k + e] = -1.0f;
-        }
-    for (int r = 0; r < 16; ++r) {
-        const int i = i0 + r;
-        if (i >= L) break;
-        const float* row = base + (size_t)i * S;
-        const float rm = rmax[(size_t)b * L + i], ri = __builtin_amdgcn_rcpf(rsum[(size_t)b * L + i]);
-        float x[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = c0 + k * 256 + lane * 4;
-            if (vec && j + 3 < S) {
-                const float4 t = *reinterpret_cast<const float4*>(row + j);
-                x[4 * k] = t.x, x[4 * k + 1] = t.y, x[4 * k + 2] = t.z, x[4 * k + 3] = t.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[4 * k + e] = (j + e < S) ? row[j + e] : -INFINITY;
-            }
-        }
-        float bv = -1.0f;
-        int bj = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = c0 + k * 256 + lane * 4 + e;
-                // conf = softmax over i (column statistics) * softmax over j (row statistics); x = -inf past the edge -> 0
-                const float v = (__expf(x[4 * k + e] - cm[4 * k + e]) * ci[4 * k + e]) * (__expf(x[4 * k + e] - rm) * ri);
-                if (j < S) {
-                    if (v > bv) {  // j ascends within a lane: the first maximum is kept
-                        bv = v;
-                        bj = j;
-                    }
-                    cb[4 * k + e] = fmaxf(cb[4 * k + e], v);
-                }
-            }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oj = __shfl_xor(bj, o, 64);
-            if (ov > bv || (ov == bv && oj < bj)) {
-                bv = ov;
-                bj = oj;
-            }
-        }
-        if (lane == 0) {
-            rpv[((size_t)b * nch + ch) * L + i] = bv;
-            rpj[((size_t)b * nch + ch) * L + i] = bj;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lb[wv][k * 256 + lane * 4 + e] = cb[4 * k + e];
-    __syncthreads();
-    for (int c = threadIdx.x; c < LF2_COLS; c += 256) {
-        const int j = c0 + c;
-        if (j < S) cpv[((size_t)b * nbd + bd) * S + j] = fmaxf(fmaxf(lb[0][c], lb[1][c]), fmaxf(lb[2][c], lb[3][c]));
-    }
-}
-// row best over the column chunks (ascending: a later chunk wins only with a strictly larger value = first column attaining
-// the maximum) and column best over the row bands
-__global__ void lf_rowbest_combine_kernel(const float* __restrict__ rpv, const int* __restrict__ rpj, int nch, int L,
-                                          float* __restrict__ best, int* __restrict__ bestj) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
-    float bv = -1.0f;
-    int bj = 0x7fffffff;
-    for (int c = 0; c < nch; ++c) {
-        const float v = rpv[((size_t)b * nch + c) * L + i];
-        if (v > bv) {
-            bv = v;
-            bj = rpj[((size_t)b * nch + c) * L + i];
-        }
-    }
-    best[(size_t)b * L + i] = bv;
-    bestj[(size_t)b * L + i] = bj;
-}
-__global__ void lf_colbest_combine_kernel(const float* __restrict__ cpv, int nbd, int S, float* __restrict__ cbest) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= S) return;
-    float m = -1.0f;
-    for (int p = 0; p < nbd; ++p) m = fmaxf(m, cpv[((size_t)b * nbd + p) * S + j]);
-    cbest[(size_t)b * S + j] = m;
-}
-
-// host: the two passes + combines.  rp0 / rp1 / rpj: [B][nch][L] row partials, cp0 / cp1: [B][nbd][S] column partials
-// (nch = ceil(S / LF2_COLS), nbd = ceil(L / LF2_ROWS)).  Outputs: best / bestj [B][L], cbest [B][S] (and the statistics).
-static inline int lf2_nch(int S) { return (S + LF2_COLS - 1) / LF2_COLS; }
-static inline int lf2_nbd(int L) { return (L + LF2_ROWS - 1) / LF2_ROWS; }
-static inline void lf_dual_softmax2_launch(const float* sim, int B, int L, int S, float* rp0, float* rp1, int* rpj, float* cp0, float* cp1,
-                                           float* rmax, float* rsum, float* cmax, float* csum, float* best, int* bestj, float* cbest,
-                                           hipStream_t stream) {
-    const int nch = lf2_nch(S), nbd = lf2_nbd(L);
-    const dim3 grid(nch, nbd, B), blk(256);
-    hipLaunchKernelGGL(lf_stats2_kernel, grid, blk, 0, stream, sim, L, S, nch, nbd, rp0, rp1, cp0, cp1);
-    hipLaunchKernelGGL(lf_stat_combine_kernel, dim3((L + 255) / 256, B), blk, 0, stream, rp0, rp1, nch, L, rmax, rsum);
-    hipLaunchKernelGGL(lf_stat_combine_kernel, dim3((S + 255) / 256, B), blk, 0, stream, cp0, cp1, nbd, S, cmax, csum);
-    hipLaunchKernelGGL(lf_best2_kernel, grid, blk, 0, stream, sim, L, S, nch, nbd, rmax, rsum, cmax, csum, rp0, rpj, cp0);
-    hipLaunchKernelGGL(lf_rowbest_combine_kernel, dim3((L + 255) / 256, B), blk, 0, stream, rp0, rpj, nch, L, best, bestj);
-    hipLaunchKernelGGL(lf_colbest_combine_kernel, dim3((S + 255) / 256, B), blk, 0, stream, cp0, nbd, S, cbest);
-}
+// ------------------------------------------------------------------ dual-softmax coarse matching
+// conf(i, j) = softmax over i (column statistics) * softmax over j (row statistics) of sim = (f0 / 16) . (f1 / 16)^T / 0.1; the row
+// best (first column attaining it) and the column best come from simred.hip, which never stores sim (rounds 1-4 materialised it and
+// read it back in four, then two passes: lf_rowstat / lf_colstat / lf_rowbest / lf_colbest, lf_stats2 / lf_best2 -- removed in round 5).
 
 // per row decision: conf > thr, border, mutual; flag[b*L+i] = 1/0
 __global__ void lf_decide_kernel(const float* __restrict__ best, const int* __restrict__ bestj,
@@ -696,6 +294,10 @@ __global__ void lf_decide_kernel(const float* __restrict__ best, const int* __re
     const int b = (int)(t / L), i = (int)(t - (long)b * L);
     const int j = bestj[t];
     const float v = best[t];
+    if (j < 0 || j >= S) {  // a row none of whose tiles was evaluated (no confidence of it can exceed the threshold): no match
+        flag[t] = 0;
+        return;
+    }
     const int y0 = i / w0c, x0 = i - y0 * w0c, y1 = j / w1c, x1 = j - y1 * w1c;
     bool ok = v > thr && v == cbest[(size_t)b * S + j];
     ok = ok && y0 >= bd && y0 < h0c - bd && x0 >= bd && x0 < w0c - bd && y1 >= bd && y1 < h1c - bd && x1 >= bd && x1 < w1c - bd;

@@ -5,9 +5,11 @@
 
 #include "gemm.h"
 #include "imcui_hip.h"
+#include "simred.h"
 
 struct NnWs {
-    float* sim;                  // materialised path (exact-f32 mode) only
+    uint4 *pk0, *pk1;            // round 5: the descriptors as MFMA fragments (simred_pack), D in {64, 128, 256}
+    float* sim;                  // materialised path (exact-f32 mode, other descriptor widths) only
     float *rb1, *rb2, *cb1, *cb2;  // fused path: nearest-neighbour partials of the tiles (EPI_NNSTAT)
     int *ri1, *ci1;
     int *m0, *m1;
@@ -18,11 +20,16 @@ struct NnWs {
 };
 // fused = the split arithmetic: the similarity tiles are reduced in the GEMM's epilogue and never stored (12 B per row and 128-column
 // tile + 12 B per column and 64-row half instead of 4 N M bytes written once and read twice)
-static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M, bool fused) {
+// D > 0: room for the packed descriptors of the persistent kernel (round 5) as well; D = 0: the round-4 layouts only
+static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M, bool fused, int D) {
     WsAlloc a(ws, bytes);
     NnWs w{};
     w.nct = cdiv(M, 128);
     w.nrh = 2 * cdiv(N, 128);
+    if (D > 0 && simred_ok(D)) {
+        w.pk0 = a.get<uint4>((size_t)B * simred_packed_uint4(N, D));
+        w.pk1 = a.get<uint4>((size_t)B * simred_packed_uint4(M, D));
+    }
     if (fused) {
         w.rb1 = a.get<float>((size_t)B * w.nct * N);
         w.rb2 = a.get<float>((size_t)B * w.nct * N);
@@ -40,15 +47,23 @@ static NnWs nn_carve(void* ws, size_t bytes, int B, int N, int M, bool fused) {
     w.ok = a.ok;
     return w;
 }
+// The entry points without a descriptor width size the workspace for D = 256, the widest the persistent kernel takes.
 // Size that serves either arithmetic (the materialised similarity of the exact-f32 mode is the larger one) ...
 extern "C" size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M) {
-    const size_t a = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, false).total;
-    const size_t b = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, true).total;
+    const size_t a = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, false, 256).total;
+    const size_t b = nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, true, 256).total;
     return a > b ? a : b;
 }
-// ... and what THIS handle's arithmetic needs (precision 1: the fused path, no similarity matrix)
+// does this call run on the persistent kernel?  (either arithmetic; the tile paths keep every other descriptor width)
+static bool nn_persistent(const imcui_hip_s* h, int D) { return h != nullptr && h->opt[OPT_SIMRED] != 0 && simred_ok(D); }
+// ... and what THIS handle's arithmetic needs (precision 1: no similarity matrix)
 extern "C" size_t imcui_hip_mutual_nn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M) {
-    return nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, h != nullptr && h->precision == 1).total;
+    if (h == nullptr || h->precision != 1) return imcui_hip_mutual_nn_workspace_bytes(B, N, M);  // (exact-f32 mode: the width decides the path at call time)
+    return nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, h != nullptr && (h->precision == 1 || h->opt[OPT_SIMRED] != 0), 256).total;
+}
+// ... for descriptors of width D (round 5)
+extern "C" size_t imcui_hip_mutual_nn_workspace_bytes_d(imcui_hip_t* h, int B, int N, int M, int D) {
+    return nn_carve(nullptr, 0, B, N > 0 ? N : 1, M > 0 ? M : 1, h != nullptr && (h->precision == 1 || nn_persistent(h, D)), D).total;
 }
 
 // best / second best of a strided vector, one wave; ties resolve to the lowest index
@@ -148,6 +163,85 @@ __global__ void nn_mutual_kernel(const int* __restrict__ m0, const int* __restri
     out[(size_t)b * N + i] = m;
 }
 
+// descriptors given by strides: element (row, k) of batch b at d[b * bs + row * ldr + k * ldk]  ([B, N, D]: ldr = D, ldk = 1; the
+// reference's [B, D, N]: ldr = 1, ldk = N -- only the persistent path takes that one)
+static int nn_forward(imcui_hip_t* h, const float* desc0, long ldr0, long ldk0, long bs0, const float* desc1, long ldr1, long ldk1, long bs1, int B, int N, int M,
+                      int D, double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes,
+                      hipStream_t stream) {
+    const bool persistent = nn_persistent(h, D);
+    const bool fused = h->precision == 1 || persistent;
+    NnWs w = nn_carve(ws, ws_bytes, B, N, M, fused, persistent ? D : 0);
+    if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "mutual_nn: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    int nslot_r = w.nct, nslot_c = w.nrh;
+    if (persistent) {
+        // round 5: both descriptor sets packed once into MFMA fragments, then ONE launch of the persistent similarity-and-reduce kernel
+        // (simred.hip): row results in registers across the column tiles, column partials per 128-row block
+        if (h->precision == 1 && h->range_flag && ldk0 == 1 && ldk1 == 1) {
+            for (int z = 0; z < B; ++z) {
+                imcui_range_check(h, desc0 + (size_t)z * bs0, N, D, ldr0, nullptr, 0, stream);
+                imcui_range_check(h, desc1 + (size_t)z * bs1, M, D, ldr1, nullptr, 0, stream);
+            }
+        }
+        simred_pack(h, desc0, ldr0, ldk0, bs0, N, D, B, nullptr, 0, w.pk0, stream);
+        simred_pack(h, desc1, ldr1, ldk1, bs1, M, D, B, nullptr, 0, w.pk1, stream);
+        SimRedP p;
+        p.mode = SR_NN;
+        p.Ap = w.pk0, p.Bp = w.pk1;
+        p.ap_bs = (long)simred_packed_uint4(N, D), p.bp_bs = (long)simred_packed_uint4(M, D);
+        p.M = N, p.N = M, p.K = D, p.batch = B;
+        p.nchunk = simred_chunks(B, N, M);  // (<= nct: the row partial arrays above have a slot per column tile)
+        p.r0 = w.rb1, p.r1 = w.rb2, p.ri = w.ri1, p.r_pitch = N;
+        p.c0 = w.cb1, p.c1 = w.cb2, p.ci = w.ci1, p.c_pitch = M;
+        const int rc = simred_launch(h, p, stream);
+        if (rc != IMCUI_OK) return rc;
+        nslot_r = p.nchunk;
+        nslot_c = cdiv(N, 128);
+    } else {
+        if (ldk0 != 1 || ldk1 != 1) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn: the tile path needs row-major descriptors");
+        GemmP g;
+        g.epi = fused ? EPI_NNSTAT : EPI_BIAS;
+        g.batch = B;
+        g.A = desc0;
+        g.lda = ldr0;
+        g.a_bs = bs0;
+        g.W = desc1;
+        g.ldw = ldr1;
+        g.w_bs = bs1;
+        g.C = w.sim;
+        g.ldc = M;
+        g.c_bs = (long)N * M;
+        if (fused) {
+            g.st_rpm = w.rb1, g.st_rps = w.rb2, g.st_rpi = w.ri1, g.st_rpitch = N, g.st_nct = w.nct;
+            g.st_cpm = w.cb1, g.st_cps = w.cb2, g.st_cpi = w.ci1, g.st_cpitch = M, g.st_nrh = w.nrh;
+        }
+        g.M = N;
+        g.N = M;
+        g.K = D;
+        const int rc = gemm_launch(h, g, stream);
+        if (rc != IMCUI_OK) return rc;
+    }
+    // a single neighbour cannot pass a ratio test (nearest_neighbor.py:50-51)
+    const int use_ratio = (ratio_threshold > 0.0) && N > 1 && M > 1;
+    const int use_dist = distance_threshold > 0.0;
+    // thresholds are squared in double (Python floats) before meeting the fp32 tensors
+    const float r2 = (float)(ratio_threshold * ratio_threshold), d2 = (float)(distance_threshold * distance_threshold);
+    if (fused) {
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.rb1, w.ri1, w.rb2, nslot_r, N, r2, d2, use_ratio, use_dist, w.m0,
+                           scores0);
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, w.cb1, w.ci1, w.cb2, nslot_c, M, r2, d2, use_ratio, use_dist, w.m1,
+                           (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, stream, w.sim, N, M, 0, r2, d2, use_ratio, use_dist,
+                           w.m0, scores0);
+        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, stream, w.sim, N, M, 1, r2, d2, use_ratio, use_dist,
+                           w.m1, (float*)nullptr);
+    }
+    hipLaunchKernelGGL(nn_mutual_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.m0, w.m1, N, M, do_mutual_check,
+                       matches0);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
 extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,
                                    double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0,
                                    float* scores0, void* ws, size_t ws_bytes, void* stream_) {
@@ -161,50 +255,8 @@ extern "C" int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const flo
         return IMCUI_OK;
     }
     if (D % 32 != 0 || !desc0 || !desc1) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn: D=%d must be a multiple of 32", D);
-    const bool fused = h->precision == 1;
-    NnWs w = nn_carve(ws, ws_bytes, B, N, M, fused);
-    if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "mutual_nn: workspace too small (%zu < %zu)", ws_bytes, w.total);
-    GemmP g;
-    g.epi = fused ? EPI_NNSTAT : EPI_BIAS;
-    g.batch = B;
-    g.A = desc0;
-    g.lda = D;
-    g.a_bs = (long)N * D;
-    g.W = desc1;
-    g.ldw = D;
-    g.w_bs = (long)M * D;
-    g.C = w.sim;
-    g.ldc = M;
-    g.c_bs = (long)N * M;
-    if (fused) {
-        g.st_rpm = w.rb1, g.st_rps = w.rb2, g.st_rpi = w.ri1, g.st_rpitch = N, g.st_nct = w.nct;
-        g.st_cpm = w.cb1, g.st_cps = w.cb2, g.st_cpi = w.ci1, g.st_cpitch = M, g.st_nrh = w.nrh;
-    }
-    g.M = N;
-    g.N = M;
-    g.K = D;
-    int rc = gemm_launch(h, g, stream);
-    if (rc != IMCUI_OK) return rc;
-    // a single neighbour cannot pass a ratio test (nearest_neighbor.py:50-51)
-    const int use_ratio = (ratio_threshold > 0.0) && N > 1 && M > 1;
-    const int use_dist = distance_threshold > 0.0;
-    // thresholds are squared in double (Python floats) before meeting the fp32 tensors
-    const float r2 = (float)(ratio_threshold * ratio_threshold), d2 = (float)(distance_threshold * distance_threshold);
-    if (fused) {
-        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.rb1, w.ri1, w.rb2, w.nct, N, r2, d2, use_ratio, use_dist, w.m0,
-                           scores0);
-        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, w.cb1, w.ci1, w.cb2, w.nrh, M, r2, d2, use_ratio, use_dist, w.m1,
-                           (float*)nullptr);
-    } else {
-        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, stream, w.sim, N, M, 0, r2, d2, use_ratio, use_dist,
-                           w.m0, scores0);
-        hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(M, 4), B), dim3(256), 0, stream, w.sim, N, M, 1, r2, d2, use_ratio, use_dist,
-                           w.m1, (float*)nullptr);
-    }
-    hipLaunchKernelGGL(nn_mutual_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.m0, w.m1, N, M, do_mutual_check,
-                       matches0);
-    IMCUI_CHECK_LAUNCH(h);
-    return IMCUI_OK;
+    return nn_forward(h, desc0, D, 1, (long)N * D, desc1, D, 1, (long)M * D, B, N, M, D, ratio_threshold, distance_threshold, do_mutual_check, matches0, scores0, ws,
+                      ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------ the same matcher on the reference's own layout
@@ -227,10 +279,11 @@ __global__ __launch_bounds__(256) void nn_transpose_kernel(const float* __restri
 }
 
 extern "C" size_t imcui_hip_mutual_nn_dn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M, int D) {
+    if (nn_persistent(h, D)) return imcui_hip_mutual_nn_workspace_bytes_d(h, B, N, M, D);  // packed straight from [B, D, N]: no transposed copy
     WsAlloc a(nullptr, 0);
     a.get<float>((size_t)B * (N > 0 ? N : 1) * D);
     a.get<float>((size_t)B * (M > 0 ? M : 1) * D);
-    return a.off + imcui_hip_mutual_nn_workspace_bytes_for(h, B, N, M);
+    return a.off + imcui_hip_mutual_nn_workspace_bytes_d(h, B, N, M, D);
 }
 
 extern "C" int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, const float* desc1_dm, int B, int N, int M, int D, double ratio_threshold,
@@ -241,6 +294,10 @@ extern "C" int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, con
     if (B <= 0 || N <= 0) return IMCUI_OK;
     if (M <= 0) return imcui_hip_mutual_nn(h, desc0_dn, desc1_dm, B, N, M, D, ratio_threshold, distance_threshold, do_mutual_check, matches0, scores0, ws, ws_bytes, stream_);
     if (D <= 0 || !desc0_dn || !desc1_dm) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn_dn: null descriptors / D=%d", D);
+    if (!matches0 || !scores0) return imcui_set_err(h, IMCUI_ERR_ARG, "mutual_nn_dn: null output");
+    if (nn_persistent(h, D))  // the fragment packer reads the [D, N] layout directly (lanes run along N: coalesced)
+        return nn_forward(h, desc0_dn, 1, N, (long)N * D, desc1_dm, 1, M, (long)M * D, B, N, M, D, ratio_threshold, distance_threshold, do_mutual_check, matches0,
+                          scores0, ws, ws_bytes, stream);
     WsAlloc a(ws, ws_bytes);
     float* t0 = a.get<float>((size_t)B * N * D);
     float* t1 = a.get<float>((size_t)B * M * D);

@@ -1,0 +1,758 @@
+// Similarity-and-reduce on the matrix cores (simred.h): sim = alpha * A . B^T is computed 128 x 128 tile by tile and reduced on the spot.
+//
+// Why not the tile GEMM with a reducing epilogue (gemm.hip, EPI_NNSTAT / EPI_SIMSTAT; rounds 3-4)?  With K = 128 .. 256 a tile kernel
+// spends its life in prologues and epilogues: both operands fetched from HBM / L2 per tile and split into f16 planes on the fly
+// (the A panel 40 .. 128 times), four to eight k-tiles, then the epilogue -- 0.21 .. 0.31 of the matrix pipe, 4.5 x over-fetch.  Here:
+//   * both operands are split ONCE by a packing pass into ready-to-use MFMA fragments ([32 rows][16 k] blocks, 16 bytes per lane and
+//     piece): no vector work on either operand inside the loop;
+//   * a workgroup OWNS 128 rows of A for its whole life: wave w holds the fragments of rows 32 w .. 32 w + 31 in registers (64 .. 128
+//     VGPRs), fetched once;
+//   * the B fragments of the column tiles STREAM through a two-slot LDS ring (16 KiB = two k-steps of a 128-column tile per stage,
+//     one barrier per stage, requested two stages ahead): the pipeline never drains between tiles;
+//   * accumulators hold sim^T (B fragment = MFMA A operand): a lane owns ONE row i of sim and 16 columns per fragment, so everything
+//     per ROW is lane-local and is carried in registers across all column tiles (no row partials, no merge for the rows of a chunk);
+//   * per COLUMN the tile is parked in LDS 64 columns at a time and scanned by (column, row range) threads; one partial per column and
+//     128-row block goes to memory (12 bytes per column and row block instead of 4 bytes per element).
+// Product order per accumulator (b_hi a_lo, b_lo a_hi, b_hi a_hi; k ascending) is that of gemm_split_kernel, so a similarity has
+// the bits the tile GEMM gave it.
+#include <math.h>
+#include <stdio.h>
+
+#include "simred.h"
+
+#define SR_PLD 68       // floats per parked row of 64 columns (+ 4: the 16-byte stores of 8 consecutive rows hit 32 different banks)
+#define SR_SLOT_U4 1024  // uint4 per ring slot: 4 column fragments x 2 k-steps x 2 pieces x 64 lanes
+#define SR_MAXLIST 2048  // tiles per chunk when tiles are selected by flags
+
+__device__ __forceinline__ float sr_lg_score(float s, float rm, float rl, float cm, float cl, float l0, float l1) {
+    return (((s - rm) - rl) + ((s - cm) - cl)) + (l0 + l1);  // the reference's association (lightglue_assign.h)
+}
+
+// ------------------------------------------------------------------ packing
+// grid (fragments, 1, batch), 4 waves: wave w packs k-steps w, w + 4, ...; lane (lo, hi) owns row 32 f + lo, k = 16 ks + 8 hi .. + 7
+template <bool F32>
+__global__ __launch_bounds__(256) void simred_pack_kernel(const float* __restrict__ X, long ldr, long ldk, long xbs, int rows, const int* __restrict__ cnt,
+                                                          int cnt_stride, int KS, uint4* __restrict__ out, long obs) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lo = lane & 31, hi = lane >> 5;
+    const int f = blockIdx.x, b = blockIdx.z;
+    const int nrow = cnt ? min(cnt[(size_t)b * cnt_stride], rows) : rows;
+    const int row = f * 32 + lo;
+    const float* src = X + (size_t)b * xbs + (size_t)row * ldr;
+    uint4* dst = out + (size_t)b * obs + (size_t)f * KS * 128 + lane;
+    for (int ks = wid; ks < KS; ks += 4) {
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (row < nrow) {
+            const int k0 = 16 * ks + 8 * hi;
+            if (ldk == 1 && (ldr & 3) == 0) {
+                va = *reinterpret_cast<const float4*>(src + k0);
+                vb = *reinterpret_cast<const float4*>(src + k0 + 4);
+            } else {
+                va = make_float4(src[(size_t)k0 * ldk], src[(size_t)(k0 + 1) * ldk], src[(size_t)(k0 + 2) * ldk], src[(size_t)(k0 + 3) * ldk]);
+                vb = make_float4(src[(size_t)(k0 + 4) * ldk], src[(size_t)(k0 + 5) * ldk], src[(size_t)(k0 + 6) * ldk], src[(size_t)(k0 + 7) * ldk]);
+            }
+        }
+        uint4 p0, p1;
+        if constexpr (F32) {
+            p0 = __builtin_bit_cast(uint4, va);
+            p1 = __builtin_bit_cast(uint4, vb);
+        } else {
+            split8(va, vb, p0, p1);  // the same split the tile GEMM applies while staging (hi toward zero, lo nearest)
+        }
+        dst[(size_t)ks * 128] = p0;
+        dst[(size_t)ks * 128 + 64] = p1;
+    }
+}
+
+void simred_pack(imcui_hip_s* h, const float* X, long ldr, long ldk, long xbs, int rows, int K, int batch, const int* cnt, int cnt_stride, uint4* out,
+                 hipStream_t stream) {
+    const int nfrag = (rows + SR_TILE - 1) / SR_TILE * (SR_TILE / 32);
+    const long obs = (long)simred_packed_uint4(rows, K);
+    const dim3 grid(nfrag, 1, batch);
+    if (h->precision == 1)
+        hipLaunchKernelGGL(simred_pack_kernel<false>, grid, dim3(256), 0, stream, X, ldr, ldk, xbs, rows, cnt, cnt_stride, K / 16, out, obs);
+    else
+        hipLaunchKernelGGL(simred_pack_kernel<true>, grid, dim3(256), 0, stream, X, ldr, ldk, xbs, rows, cnt, cnt_stride, K / 16, out, obs);
+}
+
+// ------------------------------------------------------------------ the kernel
+// KS = K / 16.  WN = 1: 256 threads, wave w owns rows 32 w x all 128 columns of a tile (64 accumulators), two workgroups per CU;
+// WN = 2 (K = 256: 128 VGPRs of A fragments): 512 threads, wave (wm, wn) owns rows 32 wm x columns 64 wn .. 64 wn + 63, one per CU.
+template <int KS, int WN, int MODE, bool F32>
+__global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
+    constexpr int NTH = 256 * WN, NW = 4 * WN, NF = 4 / WN, KT = KS / 2, PPW = 16 / NW;
+    constexpr int NPART = NTH / 64, RPP = SR_TILE / NPART;  // column scan: parts of RPP rows
+    static_assert(KT >= 2, "at least two stages per tile");
+    extern __shared__ uint4 sr_smem[];
+    uint4* ring = sr_smem;                                              // 2 slots
+    float* park = reinterpret_cast<float*>(sr_smem + 2 * SR_SLOT_U4);   // [128 rows][SR_PLD]
+    float* sc0 = park + SR_TILE * SR_PLD;                               // [NPART][64] scan partials
+    float* sc1 = sc0 + NPART * 64;
+    int* sci = reinterpret_cast<int*>(sc1 + NPART * 64);
+    float* ctab = reinterpret_cast<float*>(sci + NPART * 64);           // [3][128] column constants of the tile (pass 2)
+    unsigned short* tlist = reinterpret_cast<unsigned short*>(ctab + 3 * SR_TILE);
+    __shared__ int s_ntl;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wm = wid & 3, wn = wid >> 2;
+    const int nrb = (p.M + SR_TILE - 1) / SR_TILE, nct_s = (p.N + SR_TILE - 1) / SR_TILE;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int rb = t % nrb;
+    t /= nrb;
+    const int chunk = t % p.nchunk, b = t / p.nchunk;
+    const int Mb = p.mcnt ? min(p.mcnt[(size_t)b * p.cnt_stride], p.M) : p.M;
+    const int Nb = p.ncnt ? min(p.ncnt[(size_t)b * p.cnt_stride], p.N) : p.N;
+    if (rb * SR_TILE >= Mb) return;
+    const int rowsv = min(SR_TILE, Mb - rb * SR_TILE);  // live rows of the block
+    const int tpc = (nct_s + p.nchunk - 1) / p.nchunk;
+    const int ct0 = chunk * tpc, ct1 = min(ct0 + tpc, (Nb + SR_TILE - 1) / SR_TILE);
+
+    // ---- the tiles of this workgroup
+    int ntl;
+    const bool listed = (MODE == SR_DSBEST) && p.flags != nullptr;
+    if (listed) {
+        if (wid == 0) {
+            const unsigned char* fl = p.flags + ((size_t)b * nrb + rb) * nct_s;
+            int n = 0;
+            for (int c0 = ct0; c0 < ct1; c0 += 64) {
+                const int c = c0 + lane;
+                const bool f = c < ct1 && fl[c] != 0;
+                const unsigned long long bal = __ballot(f);
+                if (f) tlist[n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)c;
+                n += __popcll(bal);
+            }
+            if (lane == 0) s_ntl = n;
+        }
+        __syncthreads();
+        ntl = s_ntl;
+    } else {
+        ntl = max(ct1 - ct0, 0);
+    }
+    auto tile_at = [&](int i) -> int { return listed ? (int)tlist[i] : ct0 + i; };
+
+    // ---- A fragments of the wave's 32 rows: registers, for the life of the workgroup
+    uint4 a0[KS], a1[KS];
+    {
+        const uint4* ap = p.Ap + (size_t)b * p.ap_bs + ((size_t)(rb * 4 + wm) * KS) * 128 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a0[ks] = ap[ks * 128];
+            a1[ks] = ap[ks * 128 + 64];
+        }
+    }
+    // ---- B stages: piece pc = wid * PPW + u of a stage = fragment pc >> 2, (k-step, piece) pc & 3.  Everything but the lane offset is
+    // wave-uniform and is kept scalar (readfirstlane tells the compiler so): one 32-bit lane offset against a scalar base per load,
+    // instead of a 64-bit vector address per (piece, stage of a tile) hoisted out of the loop
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const uint4* bpb = p.Bp + (size_t)b * p.bp_bs + ((size_t)((wid_s * PPW) >> 2) * KS) * 128 + ((wid_s * PPW) & 3) * 64;
+    // (named registers, not an array: a register array that is only copied global -> LDS is turned into a private-memory copy by hipcc)
+    uint4 br0, br1, br2, br3;
+    auto load_stage = [&](int ct, int kslice) __attribute__((always_inline)) {
+        const uint4* src = bpb + ((size_t)ct * 4 * KS + kslice * 2) * 128;  // scalar
+        br0 = src[lane];
+        br1 = src[lane + 64];
+        if constexpr (PPW == 4) {
+            br2 = src[lane + 128];
+            br3 = src[lane + 192];
+        }
+    };
+    auto store_stage = [&](int slot) __attribute__((always_inline)) {
+        uint4* d = ring + slot * SR_SLOT_U4 + (wid * PPW) * 64 + lane;
+        d[0] = br0;
+        d[64] = br1;
+        if constexpr (PPW == 4) {
+            d[128] = br2;
+            d[192] = br3;
+        }
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+    // ---- per-row running state (lane = row wm * 32 + lo, its columns 4 hi .. of every 8)
+    const int rowl = wm * 32 + lo, rowg = rb * SR_TILE + rowl;
+    float q0 = -INFINITY, q1 = (MODE == SR_NN) ? -INFINITY : 0.0f;  // NN: best, second; LSE: max, sum; BEST: best value
+    int qi = 0x7fffffff;
+    if (MODE == SR_DSBEST) q0 = -1.0f;
+    float rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;  // pass 2: row constants
+    if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
+        const size_t ro = (size_t)b * p.r_pitch + min(rowg, Mb - 1);
+        rc0 = p.rmax[ro];
+        rc1 = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.rsum[ro]) : p.rsum[ro];
+        if (MODE == SR_LGBEST) rc2 = p.l0[(size_t)b * p.l0_bs + min(rowg, Mb - 1)];
+    }
+
+    const int S = ntl * KT;
+    if (S > 0) {
+        load_stage(tile_at(0), 0);
+        store_stage(0);
+        load_stage(tile_at(0), 1);  // KT >= 2: stage 1 is in tile 0
+    }
+    __syncthreads();
+
+    for (int ti = 0; ti < ntl; ++ti) {
+        const int ct = tile_at(ti);
+        const int ctn = (ti + 1 < ntl) ? tile_at(ti + 1) : ct;
+        if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
+            // column constants of the tile (read in the epilogue, >= 1 barrier from here; the previous tile's readers are past its last barrier)
+            if (tid < SR_TILE) {
+                const int j = min(ct * SR_TILE + tid, Nb - 1);
+                const size_t co = (size_t)b * p.c_pitch + j;
+                ctab[tid] = p.cmax[co];
+                ctab[SR_TILE + tid] = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.csum[co]) : p.csum[co];
+                if (MODE == SR_LGBEST) ctab[2 * SR_TILE + tid] = p.l1[(size_t)b * p.l1_bs + j];
+            }
+        }
+#pragma unroll
+        for (int kslice = 0; kslice < KT; ++kslice) {
+            const int s = ti * KT + kslice;
+            const int slot = kslice & 1;  // (KT is even)
+            if (s + 1 < S) store_stage(slot ^ 1);
+            if (s + 2 < S) {
+                if (kslice + 2 < KT)
+                    load_stage(ct, kslice + 2);
+                else
+                    load_stage(ctn, kslice + 2 - KT);
+            }
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+                const int ks = kslice * 2 + ksl;
+                uint4 b0[NF], b1[NF];
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int nf = wn * NF + n;
+                    b0[n] = ring[slot * SR_SLOT_U4 + (nf * 4 + ksl * 2) * 64 + lane];
+                    b1[n] = ring[slot * SR_SLOT_U4 + (nf * 4 + ksl * 2 + 1) * 64 + lane];
+                }
+                if constexpr (!F32) {
+                    // pieces = f16 hi / lo planes; per accumulator: b_hi a_lo, b_lo a_hi, b_hi a_hi (gemm_split_kernel's order), the NF
+                    // accumulators interleaved so consecutive matrix instructions are independent
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a1[ks], acc[n]);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b1[n], a0[ks], acc[n]);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a0[ks], acc[n]);
+                } else {
+                    // pieces = the lane's two k-quads; step j pairs k = 16 ks + j (lanes hi = 0) with k = 16 ks + 8 + j (hi = 1)
+                    const float4 fa0 = __builtin_bit_cast(float4, a0[ks]), fa1 = __builtin_bit_cast(float4, a1[ks]);
+                    const float av[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) {
+                            const float4 fb = __builtin_bit_cast(float4, j < 4 ? b0[n] : b1[n]);
+                            const float bv4[4] = {fb.x, fb.y, fb.z, fb.w};
+                            acc[n] = mfma32(bv4[j & 3], av[j], acc[n]);
+                        }
+                }
+                // one k-step's fragments live at a time (the co-resident wave covers the LDS latency); without the fence hipcc hoists the
+                // reads of both k-steps of a stage (+ 32 VGPRs) and then spills the A fragments
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kslice + 1 < KT) __syncthreads();
+        }
+
+        // ================================================================ epilogue of tile ct
+        // The thread index is laundered through an empty asm so that the epilogue's address arithmetic is recomputed per tile (a few
+        // dozen instructions) instead of being hoisted out of the tile loop and carried -- 60 VGPRs of it -- across the MFMA loop.
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        const int elo = etid & 31, ehi = (etid >> 5) & 1, erowl = ((etid >> 6) & 3) * 32 + elo;
+        // (1) per row, from the accumulators: lane = row rowl, columns jb + 32 n + 8 q + e; the value to park replaces the accumulator
+        const int jb = ct * SR_TILE + wn * (NF * 32) + 4 * ehi;
+        float tmax = -INFINITY;
+        const float q0old = q0;
+        int tc = -1;  // column of the row's new best inside this tile (relative to jb), -1: the best did not move
+        // (ONE instance of this code: a variant without the column mask for the tiles that lie inside the matrix was tried twice -- as a
+        // second copy of the masking part and as a second copy of the whole epilogue -- and both made hipcc spill: the accumulators are
+        // rewritten in place and two variants of that meeting in one control-flow join keep both register sets alive)
+        const int jlim = Nb - jb;  // column c of the lane's list is live when c < jlim
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float cm4[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f}, cl4[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
+                    const int jl = wn * (NF * 32) + 4 * ehi + n * 32 + 8 * q;
+                    const float4 t0 = *reinterpret_cast<const float4*>(ctab + jl), t1 = *reinterpret_cast<const float4*>(ctab + SR_TILE + jl);
+                    cm4[0] = t0.x, cm4[1] = t0.y, cm4[2] = t0.z, cm4[3] = t0.w;
+                    cs4[0] = t1.x, cs4[1] = t1.y, cs4[2] = t1.z, cs4[3] = t1.w;
+                    if (MODE == SR_LGBEST) {
+                        const float4 t2 = *reinterpret_cast<const float4*>(ctab + 2 * SR_TILE + jl);
+                        cl4[0] = t2.x, cl4[1] = t2.y, cl4[2] = t2.z, cl4[3] = t2.w;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const bool valid = n * 32 + 8 * q + e < jlim;
+                    const float x = acc[n][r] * p.alpha;
+                    if constexpr (MODE == SR_NN) {
+                        const float xv = valid ? x : -INFINITY;
+                        q1 = __builtin_amdgcn_fmed3f(q0, q1, xv);  // second best of {best, second, x} (second <= best)
+                        q0 = fmaxf(q0, xv);
+                        acc[n][r] = xv;
+                    } else if constexpr (MODE == SR_LSE) {
+                        const float xv = valid ? x : -INFINITY;
+                        tmax = fmaxf(tmax, xv);
+                        acc[n][r] = xv;
+                    } else if constexpr (MODE == SR_DSBEST) {
+                        // conf = softmax over i (column statistics) * softmax over j (row statistics), evaluated ONCE per element
+                        const float v = valid ? (__expf(x - cm4[e]) * cs4[e]) * (__expf(x - rc0) * rc1) : -1.0f;
+                        tmax = fmaxf(tmax, v);
+                        acc[n][r] = v;
+                    } else {
+                        const float v = valid ? sr_lg_score(x, rc0, rc1, cm4[e], cs4[e], rc2, cl4[e]) : -INFINITY;
+                        tmax = fmaxf(tmax, v);
+                        acc[n][r] = v;
+                    }
+                }
+                // one group of four columns at a time: left alone, hipcc's scheduler starts all 64 elements at once (every temporary of
+                // every element live together) and the kernel spills
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if constexpr (MODE == SR_NN) {
+            // (q0 is the row's best including this tile: if it moved, its first column in the tile is found by equality, walking downwards)
+            float tm = acc[0][0];
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tm = fmaxf(tm, acc[n][r]);
+#pragma unroll
+            for (int n = NF - 1; n >= 0; --n)
+#pragma unroll
+                for (int r = 15; r >= 0; --r) tc = (acc[n][r] == tm) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
+            qi = tm > q0old ? jb + tc : qi;
+        }
+        if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
+            // the row's best of this tile is a maximum tree over the finished values; its FIRST column is found by equality, walking the
+            // columns downwards (the last hit is the lowest column) -- no chain through the running best while the values are formed
+#pragma unroll
+            for (int n = NF - 1; n >= 0; --n)
+#pragma unroll
+                for (int r = 15; r >= 0; --r) tc = (acc[n][r] == tmax) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
+            const bool up = tmax > q0;  // tiles ascend: a later tile wins only with a larger value
+            qi = up ? jb + tc : qi;
+            q0 = up ? tmax : q0;
+        }
+        if constexpr (MODE == SR_LSE) {
+            // online (max, sum): the reference moves once per tile
+            const float mn = fmaxf(q0, tmax);
+            const float mref = (mn == -INFINITY) ? 0.0f : mn;
+            float sum = q1 * __expf(q0 - mref);  // q0 = -inf: 0
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += __expf(acc[n][r] - mref);
+            q1 = sum;
+            q0 = mn;
+        }
+        // (2) per column: park 64 columns of the tile ([row][column], all 128 rows), scan them by (column, row range) threads
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (WN == 1 || wn == h) {
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const int n = (WN == 1) ? 2 * h + nn : nn;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(park + erowl * SR_PLD + nn * 32 + 8 * q + 4 * ehi) =
+                            make_float4(acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]);
+                }
+            }
+            __syncthreads();
+            {
+                const int jl = etid & 63, part = etid >> 6;
+                const int r0 = part * RPP, r1 = min(r0 + RPP, rowsv);
+                const float* col = park + jl;
+                if constexpr (MODE == SR_NN) {
+                    float b1 = -INFINITY, b2 = -INFINITY;
+                    int i1 = 0x7fffffff;
+#pragma unroll 4
+                    for (int r = r0; r < r1; ++r) {
+                        const float xv = col[r * SR_PLD];
+                        const bool up = xv > b1;  // rows ascend: first maximum
+                        b2 = __builtin_amdgcn_fmed3f(b1, b2, xv);
+                        i1 = up ? rb * SR_TILE + r : i1;
+                        b1 = fmaxf(b1, xv);
+                    }
+                    sc0[part * 64 + jl] = b1;
+                    sc1[part * 64 + jl] = b2;
+                    sci[part * 64 + jl] = i1;
+                } else if constexpr (MODE == SR_LSE) {
+                    float m = -INFINITY;
+#pragma unroll 4
+                    for (int r = r0; r < r1; ++r) m = fmaxf(m, col[r * SR_PLD]);
+                    float sum = 0.0f;
+                    const float mref = (m == -INFINITY) ? 0.0f : m;
+#pragma unroll 4
+                    for (int r = r0; r < r1; ++r) sum += __expf(col[r * SR_PLD] - mref);
+                    sc0[part * 64 + jl] = m;
+                    sc1[part * 64 + jl] = sum;
+                } else if constexpr (MODE == SR_DSBEST) {
+                    float m = -1.0f;
+#pragma unroll 4
+                    for (int r = r0; r < r1; ++r) m = fmaxf(m, col[r * SR_PLD]);
+                    sc0[part * 64 + jl] = m;
+                } else {
+                    float bv = -INFINITY;
+                    int bi = 0x7fffffff;
+#pragma unroll 4
+                    for (int r = r0; r < r1; ++r) {
+                        const float v = col[r * SR_PLD];
+                        const bool up = v > bv;
+                        bi = up ? rb * SR_TILE + r : bi;
+                        bv = up ? v : bv;
+                    }
+                    sc0[part * 64 + jl] = bv;
+                    sci[part * 64 + jl] = bi;
+                }
+            }
+            __syncthreads();
+            if (etid < 64) {
+                const int tid = etid;  // (shadows the kernel's: the laundered copy)
+                const int j = ct * SR_TILE + 64 * h + tid;
+                if (j < Nb) {
+                    const size_t o = ((size_t)b * nrb + rb) * p.c_pitch + j;
+                    if constexpr (MODE == SR_NN) {
+                        float b1 = sc0[tid], b2 = sc1[tid];
+                        int i1 = sci[tid];
+#pragma unroll
+                        for (int pt = 1; pt < NPART; ++pt) {  // ascending row ranges: a later range wins only with a larger value
+                            const float ob1 = sc0[pt * 64 + tid], ob2 = sc1[pt * 64 + tid];
+                            const bool up = ob1 > b1;
+                            b2 = up ? fmaxf(b1, ob2) : fmaxf(b2, ob1);
+                            i1 = up ? sci[pt * 64 + tid] : i1;
+                            b1 = up ? ob1 : b1;
+                        }
+                        p.c0[o] = b1;
+                        p.c1[o] = b2;
+                        p.ci[o] = i1;
+                    } else if constexpr (MODE == SR_LSE) {
+                        float m = sc0[tid];
+#pragma unroll
+                        for (int pt = 1; pt < NPART; ++pt) m = fmaxf(m, sc0[pt * 64 + tid]);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int pt = 0; pt < NPART; ++pt) {
+                            const float pm = sc0[pt * 64 + tid];
+                            if (pm > -INFINITY) sum += sc1[pt * 64 + tid] * __expf(pm - m);
+                        }
+                        p.c0[o] = m;
+                        p.c1[o] = sum;
+                    } else if constexpr (MODE == SR_DSBEST) {
+                        float m = sc0[tid];
+#pragma unroll
+                        for (int pt = 1; pt < NPART; ++pt) m = fmaxf(m, sc0[pt * 64 + tid]);
+                        p.c0[o] = m;
+                    } else {
+                        float bv = sc0[tid];
+                        int bi = sci[tid];
+#pragma unroll
+                        for (int pt = 1; pt < NPART; ++pt) {
+                            const float ov = sc0[pt * 64 + tid];
+                            const bool up = ov > bv;
+                            bi = up ? sci[pt * 64 + tid] : bi;
+                            bv = up ? ov : bv;
+                        }
+                        p.c0[o] = bv;
+                        p.ci[o] = bi;
+                    }
+                }
+            }
+            // (the next parking round / the next tile's stores are behind the barrier that follows)
+            if (h == 0) __syncthreads();
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        __syncthreads();
+    }
+
+    // ================================================================ rows: fold the two half-waves (columns 4 hi), then the column halves
+    {
+        const float o0 = __shfl_xor(q0, 32, 64), o1 = __shfl_xor(q1, 32, 64);
+        const int oi = __shfl_xor(qi, 32, 64);
+        if constexpr (MODE == SR_NN) {
+            const bool up = o0 > q0 || (o0 == q0 && oi < qi);  // interleaved column sets: lowest index on equal values
+            q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
+            qi = up ? oi : qi;
+            q0 = up ? o0 : q0;
+        } else if constexpr (MODE == SR_LSE) {
+            const float m = fmaxf(q0, o0);
+            const float mref = (m == -INFINITY) ? 0.0f : m;
+            q1 = q1 * __expf(q0 - mref) + o1 * __expf(o0 - mref);
+            q0 = m;
+        } else {
+            const bool up = o0 > q0 || (o0 == q0 && oi < qi);
+            qi = up ? oi : qi;
+            q0 = up ? o0 : q0;
+        }
+    }
+    if constexpr (WN == 2) {
+        float* xr = park;  // (every scan of the loop is behind its last barrier)
+        if (wn == 1 && hi == 0) {
+            xr[rowl * 4 + 0] = q0;
+            xr[rowl * 4 + 1] = q1;
+            reinterpret_cast<int*>(xr)[rowl * 4 + 2] = qi;
+        }
+        __syncthreads();
+        if (wn == 0 && hi == 0) {
+            const float o0 = xr[rowl * 4 + 0], o1 = xr[rowl * 4 + 1];
+            const int oi = reinterpret_cast<int*>(xr)[rowl * 4 + 2];
+            if constexpr (MODE == SR_NN) {
+                const bool up = o0 > q0 || (o0 == q0 && oi < qi);
+                q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
+                qi = up ? oi : qi;
+                q0 = up ? o0 : q0;
+            } else if constexpr (MODE == SR_LSE) {
+                const float m = fmaxf(q0, o0);
+                const float mref = (m == -INFINITY) ? 0.0f : m;
+                q1 = q1 * __expf(q0 - mref) + o1 * __expf(o0 - mref);
+                q0 = m;
+            } else {
+                const bool up = o0 > q0 || (o0 == q0 && oi < qi);
+                qi = up ? oi : qi;
+                q0 = up ? o0 : q0;
+            }
+        }
+    }
+    if (wn == 0 && hi == 0 && rowl < rowsv) {
+        const size_t o = ((size_t)b * p.nchunk + chunk) * p.r_pitch + rowg;
+        p.r0[o] = q0;
+        if (MODE == SR_NN || MODE == SR_LSE) p.r1[o] = q1;
+        if (MODE != SR_LSE) p.ri[o] = qi;
+    }
+}
+
+// ------------------------------------------------------------------ launch
+#define SR_LDS_BYTES(WN) (2 * SR_SLOT_U4 * 16 + SR_TILE * SR_PLD * 4 + 3 * (4 * (WN)) * 64 * 4 + 3 * SR_TILE * 4 + SR_MAXLIST * 2)
+
+// column chunks per row block: enough workgroups for two rounds of the 256 CUs of the target part (a function of the sizes alone, so
+// that a workspace carved without a handle and the launch agree)
+int simred_chunks(int batch, int M, int N) {
+    const int nrb = (M + SR_TILE - 1) / SR_TILE, nct = (N + SR_TILE - 1) / SR_TILE;
+    int nchunk = (512 + batch * nrb - 1) / (batch * nrb);
+    if (nchunk > nct) nchunk = nct;
+    if (nchunk < 1) nchunk = 1;
+    while ((nct + nchunk - 1) / nchunk > SR_MAXLIST) ++nchunk;
+    return nchunk;
+}
+
+template <int KS, int WN, int MODE, bool F32>
+static int sr_launch_one(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in (once per instantiation)
+    constexpr int lds = SR_LDS_BYTES(WN);
+    auto kern = simred_kernel<KS, WN, MODE, F32>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return imcui_set_err(h, IMCUI_ERR_HIP, "simred: cannot reserve %d bytes of LDS", lds);
+        attr_set = true;
+    }
+    const int nrb = (p.M + SR_TILE - 1) / SR_TILE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.batch * p.nchunk * nrb)), dim3(256 * WN), lds, stream, p);
+    return IMCUI_OK;
+}
+template <int MODE, bool F32>
+static int sr_launch_k(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
+    switch (p.K) {
+        case 64: return sr_launch_one<4, 1, MODE, F32>(h, p, stream);
+        case 128: return sr_launch_one<8, 1, MODE, F32>(h, p, stream);
+        case 256: return sr_launch_one<16, 2, MODE, F32>(h, p, stream);
+        default: return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "simred: K=%d (64, 128 or 256)", p.K);
+    }
+}
+template <bool F32>
+static int sr_launch_m(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
+    switch (p.mode) {
+        case SR_NN: return sr_launch_k<SR_NN, F32>(h, p, stream);
+        case SR_LSE: return sr_launch_k<SR_LSE, F32>(h, p, stream);
+        case SR_DSBEST: return sr_launch_k<SR_DSBEST, F32>(h, p, stream);
+        case SR_LGBEST: return sr_launch_k<SR_LGBEST, F32>(h, p, stream);
+        default: return imcui_set_err(h, IMCUI_ERR_ARG, "simred: bad mode %d", p.mode);
+    }
+}
+
+int simred_launch(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
+    if (p.batch <= 0 || p.M <= 0 || p.N <= 0) return IMCUI_OK;
+    if (!p.Ap || !p.Bp || !p.r0 || !p.c0 || p.nchunk < 1 || p.r_pitch < p.M || p.c_pitch < p.N)
+        return imcui_set_err(h, IMCUI_ERR_ARG, "simred: null operand / output or pitch below the matrix size");
+    const int nct = (p.N + SR_TILE - 1) / SR_TILE;
+    if ((nct + p.nchunk - 1) / p.nchunk > SR_MAXLIST) return imcui_set_err(h, IMCUI_ERR_ARG, "simred: more than %d column tiles per chunk", SR_MAXLIST);
+    if ((p.mode == SR_DSBEST || p.mode == SR_LGBEST) && (!p.rmax || !p.rsum || !p.cmax || !p.csum || (p.mode == SR_LGBEST && (!p.l0 || !p.l1))))
+        return imcui_set_err(h, IMCUI_ERR_ARG, "simred: pass 2 needs the statistics of pass 1");
+    imcui_prof_begin(h, PROF_GEMM, stream);
+    const int rc = (h->precision == 1) ? sr_launch_m<false>(h, p, stream) : sr_launch_m<true>(h, p, stream);
+    imcui_prof_end(h, PROF_GEMM, stream);
+    if (rc != IMCUI_OK) return rc;
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ dual-softmax coarse matching on top of it
+// merge `np` partial (max, sum) pairs per item in ascending partial order: out[b][t] over pm / ps [b][np][n]
+__global__ void sr_lse_merge_kernel(const float* __restrict__ pm, const float* __restrict__ ps, int np, int n, float* __restrict__ om, float* __restrict__ os) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float m = -INFINITY;
+    for (int q = 0; q < np; ++q) m = fmaxf(m, pm[((size_t)b * np + q) * n + t]);
+    float s = 0.0f;
+    for (int q = 0; q < np; ++q) {
+        const float v = pm[((size_t)b * np + q) * n + t];
+        if (v > -INFINITY) s += ps[((size_t)b * np + q) * n + t] * __expf(v - m);
+    }
+    om[(size_t)b * n + t] = m;
+    os[(size_t)b * n + t] = s;
+}
+// Which tiles can hold a confidence above thr?  conf(i, j) <= min(p_col, p_row); inside tile (rb, ct) every x(i, j) <= cpm[rb][j] (the
+// column maximum over the block's rows, from pass 1), so an entry above the threshold needs, for its column j,
+//   exp(cpm[rb][j] - cmax[j]) / csum[j] > thr   and   exp(cpm[rb][j] - min_i (rmax[i] + log rsum[i])) > thr    (i over the block's rows).
+// Evaluated with a 2 % margin (the approximate exp / reciprocal of pass 2 are ~1e-6 relative).  grid (nct, nrb, B), 128 threads.
+__global__ __launch_bounds__(128) void sr_ds_flag_kernel(const float* __restrict__ cpm, const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                         const float* __restrict__ cmax, const float* __restrict__ csum, int L, int S, int nrb, int nct, float thr,
+                                                         unsigned char* __restrict__ flags) {
+    __shared__ float red[2];
+    __shared__ int any[2];
+    const int ct = blockIdx.x, rb = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int i = rb * SR_TILE + tid;
+    float lse = INFINITY;
+    if (i < L) lse = rmax[(size_t)b * L + i] + logf(rsum[(size_t)b * L + i]);
+    lse = -wave_max(-lse);
+    if ((tid & 63) == 0) red[tid >> 6] = lse;
+    __syncthreads();
+    const float minr = fminf(red[0], red[1]);
+    const int j = ct * SR_TILE + tid;
+    bool f = false;
+    if (j < S) {
+        const float v = cpm[((size_t)b * nrb + rb) * S + j];
+        const float t = 0.98f * thr;
+        f = t <= 0.0f || (expf(v - cmax[(size_t)b * S + j]) > t * csum[(size_t)b * S + j] && expf(v - minr) > t);
+    }
+    const unsigned long long bal = __ballot(f);
+    if ((tid & 63) == 0) any[tid >> 6] = bal != 0ull;
+    __syncthreads();
+    if (tid == 0) flags[((size_t)b * nrb + rb) * nct + ct] = (any[0] | any[1]) ? 1 : 0;
+}
+// row best over the column chunks (ascending: a later chunk wins only with a strictly larger value = first column attaining the maximum)
+__global__ void sr_rowbest_merge_kernel(const float* __restrict__ rpv, const int* __restrict__ rpj, int nch, int L, float* __restrict__ best, int* __restrict__ bestj) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    float bv = -1.0f;
+    int bj = 0x7fffffff;
+    for (int c = 0; c < nch; ++c) {
+        const float v = rpv[((size_t)b * nch + c) * L + i];
+        if (v > bv) {
+            bv = v;
+            bj = rpj[((size_t)b * nch + c) * L + i];
+        }
+    }
+    best[(size_t)b * L + i] = bv;
+    bestj[(size_t)b * L + i] = bj;
+}
+// column best over the row blocks whose tile was evaluated
+__global__ void sr_colbest_merge_kernel(const float* __restrict__ cpv, const unsigned char* __restrict__ flags, int nrb, int nct, int S, float* __restrict__ cbest) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    const int ct = j / SR_TILE;
+    float m = -1.0f;
+    for (int q = 0; q < nrb; ++q)
+        if (flags[((size_t)b * nrb + q) * nct + ct]) m = fmaxf(m, cpv[((size_t)b * nrb + q) * S + j]);
+    cbest[(size_t)b * S + j] = m;
+}
+
+void simred_ds_carve(WsAlloc& a, int B, int L, int S, int K, SimDsWs& w) {
+    w.nrb = (L + SR_TILE - 1) / SR_TILE;
+    w.nct = (S + SR_TILE - 1) / SR_TILE;
+    w.nchunk = simred_chunks(B, L, S);
+    w.ap = a.get<uint4>((size_t)B * simred_packed_uint4(L, K));
+    w.bp = a.get<uint4>((size_t)B * simred_packed_uint4(S, K));
+    w.rp0 = a.get<float>((size_t)B * w.nchunk * L);
+    w.rp1 = a.get<float>((size_t)B * w.nchunk * L);
+    w.rpj = a.get<int>((size_t)B * w.nchunk * L);
+    w.cp0 = a.get<float>((size_t)B * w.nrb * S);
+    w.cp1 = a.get<float>((size_t)B * w.nrb * S);
+    w.flags = a.get<unsigned char>((size_t)B * w.nrb * w.nct);
+}
+
+int simred_dual_softmax(imcui_hip_s* h, const SimDsWs& w, const float* fa, long lda, long a_bs, const float* fb, long ldb, long b_bs, int B, int L, int S, int K,
+                        float alpha, float thr, float* rmax, float* rsum, float* cmax, float* csum, float* best, int* bestj, float* cbest, hipStream_t stream) {
+    if (!simred_ok(K)) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "dual-softmax: feature width %d (64, 128 or 256)", K);
+    if (h->precision == 1 && h->range_flag) {  // opt-in debugging aid: scan the f32 operands that are about to be split (a negative row stride = rows in reverse)
+        for (int z = 0; z < B; ++z) {
+            imcui_range_check(h, fa + (size_t)z * a_bs + (lda < 0 ? (long)(L - 1) * lda : 0), L, K, lda < 0 ? -lda : lda, nullptr, 0, stream);
+            imcui_range_check(h, fb + (size_t)z * b_bs + (ldb < 0 ? (long)(S - 1) * ldb : 0), S, K, ldb < 0 ? -ldb : ldb, nullptr, 0, stream);
+        }
+    }
+    simred_pack(h, fa, lda, 1, a_bs, L, K, B, nullptr, 0, w.ap, stream);
+    simred_pack(h, fb, ldb, 1, b_bs, S, K, B, nullptr, 0, w.bp, stream);
+    SimRedP p;
+    p.mode = SR_LSE;
+    p.Ap = w.ap, p.Bp = w.bp;
+    p.ap_bs = (long)simred_packed_uint4(L, K), p.bp_bs = (long)simred_packed_uint4(S, K);
+    p.M = L, p.N = S, p.K = K, p.batch = B;
+    p.alpha = alpha;
+    p.nchunk = w.nchunk;
+    p.r0 = w.rp0, p.r1 = w.rp1, p.ri = w.rpj, p.r_pitch = L;
+    p.c0 = w.cp0, p.c1 = w.cp1, p.c_pitch = S;
+    int rc = simred_launch(h, p, stream);
+    if (rc != IMCUI_OK) return rc;
+    const dim3 blk(256);
+    hipLaunchKernelGGL(sr_lse_merge_kernel, dim3((L + 255) / 256, B), blk, 0, stream, w.rp0, w.rp1, w.nchunk, L, rmax, rsum);
+    hipLaunchKernelGGL(sr_lse_merge_kernel, dim3((S + 255) / 256, B), blk, 0, stream, w.cp0, w.cp1, w.nrb, S, cmax, csum);
+    hipLaunchKernelGGL(sr_ds_flag_kernel, dim3(w.nct, w.nrb, B), dim3(128), 0, stream, w.cp0, rmax, rsum, cmax, csum, L, S, w.nrb, w.nct, thr, w.flags);
+    p.mode = SR_DSBEST;
+    p.rmax = rmax, p.rsum = rsum, p.cmax = cmax, p.csum = csum;
+    p.flags = w.flags;
+    rc = simred_launch(h, p, stream);
+    if (rc != IMCUI_OK) return rc;
+    hipLaunchKernelGGL(sr_rowbest_merge_kernel, dim3((L + 255) / 256, B), blk, 0, stream, w.rp0, w.rpj, w.nchunk, L, best, bestj);
+    hipLaunchKernelGGL(sr_colbest_merge_kernel, dim3((S + 255) / 256, B), blk, 0, stream, w.cp0, w.flags, w.nrb, w.nct, S, cbest);
+    IMCUI_CHECK_LAUNCH(h);
+    return IMCUI_OK;
+}
+
+// ------------------------------------------------------------------ test hook (tests/test_gpu_simred.py): ONE launch on raw matrices
+// A [batch][M][K], Bm [batch][N][K] f32 (device); mcnt / ncnt [batch] device-side sizes or null; nchunk 0 = simred_chunks().
+// Row outputs [batch][nchunk][M], column outputs [batch][ceil(M / 128)][N]; which of them a mode writes: SimRedP (simred.h).
+extern "C" int imcui_hip_simred_chunks(int batch, int M, int N) { return simred_chunks(batch, M, N); }
+extern "C" size_t imcui_hip_simred_debug_workspace_bytes(int batch, int M, int N, int K) {
+    WsAlloc a(nullptr, 0);
+    a.get<uint4>((size_t)batch * simred_packed_uint4(M, K));
+    a.get<uint4>((size_t)batch * simred_packed_uint4(N, K));
+    return a.off;
+}
+extern "C" int imcui_hip_simred_debug(imcui_hip_s* h, int mode, const float* A, const float* Bm, int batch, int M, int N, int K, const int* mcnt, const int* ncnt,
+                                      float alpha, int nchunk, float* r0, float* r1, int* ri, float* c0, float* c1, int* ci, const float* rmax, const float* rsum,
+                                      const float* cmax, const float* csum, const float* l0, const float* l1, const unsigned char* flags, void* ws, size_t ws_bytes,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h || !A || !Bm) return IMCUI_ERR_ARG;
+    if (!simred_ok(K)) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "simred: K=%d (64, 128 or 256)", K);
+    WsAlloc a(ws, ws_bytes);
+    uint4* ap = a.get<uint4>((size_t)batch * simred_packed_uint4(M, K));
+    uint4* bp = a.get<uint4>((size_t)batch * simred_packed_uint4(N, K));
+    if (!ws || !a.ok) return imcui_set_err(h, IMCUI_ERR_WS, "simred: workspace too small (%zu bytes)", ws_bytes);
+    simred_pack(h, A, K, 1, (long)M * K, M, K, batch, mcnt, 1, ap, stream);
+    simred_pack(h, Bm, K, 1, (long)N * K, N, K, batch, ncnt, 1, bp, stream);
+    SimRedP p;
+    p.mode = mode;
+    p.Ap = ap, p.Bp = bp;
+    p.ap_bs = (long)simred_packed_uint4(M, K), p.bp_bs = (long)simred_packed_uint4(N, K);
+    p.M = M, p.N = N, p.K = K, p.batch = batch;
+    p.mcnt = mcnt, p.ncnt = ncnt, p.cnt_stride = 1;
+    p.alpha = alpha;
+    p.nchunk = nchunk > 0 ? nchunk : simred_chunks(batch, M, N);
+    p.r0 = r0, p.r1 = r1, p.ri = ri, p.r_pitch = M;
+    p.c0 = c0, p.c1 = c1, p.ci = ci, p.c_pitch = N;
+    p.rmax = rmax, p.rsum = rsum, p.cmax = cmax, p.csum = csum;
+    p.l0 = l0, p.l1 = l1, p.l0_bs = M, p.l1_bs = N;
+    p.flags = flags;
+    return simred_launch(h, p, stream);
+}

@@ -946,7 +946,7 @@ def mutual_nn(desc0_nd: torch.Tensor, desc1_md: torch.Tensor, ratio_threshold=No
     if D % 32:
         raise ImcuiHipError(f"descriptor dim {D} must be a multiple of 32")
     with _nn_lock:
-        ws = _nn_ws.get(lib.imcui_hip_mutual_nn_workspace_bytes_for(hd.h, B, N, M), dev)  # (split arithmetic: partials only, no similarity matrix)
+        ws = _nn_ws.get(lib.imcui_hip_mutual_nn_workspace_bytes_d(hd.h, B, N, M, D), dev)  # (no similarity matrix for D = 64 / 128 / 256 or the split arithmetic)
         with torch.cuda.device(dev):
             rc = lib.imcui_hip_mutual_nn(
                 hd.h, _ptr(desc0_nd), _ptr(desc1_md), B, N, M, D, float(ratio_threshold or 0.0),

@@ -162,6 +162,13 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_mutual_nn_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "imcui_hip_mutual_nn_workspace_bytes_for": (C.c_size_t, [C.c_void_p] + [C.c_int] * 3),
+    "imcui_hip_mutual_nn_workspace_bytes_d": (C.c_size_t, [C.c_void_p] + [C.c_int] * 4),
+    "imcui_hip_simred_chunks": (C.c_int, [C.c_int] * 3),
+    "imcui_hip_simred_debug_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "imcui_hip_simred_debug": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_float, C.c_int] + [C.c_void_p] * 13 + [C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
     "imcui_hip_mutual_nn": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],

@@ -394,22 +394,40 @@ int imcui_hip_ransac(imcui_hip_t* h, const float* pts0, const float* pts1, const
                      void* stream);
 
 /* ---- mutual nearest neighbour (row a12) --------------------------------------------------- */
-/* Workspace: ..._bytes(B, N, M) serves either arithmetic of the library (the exact-f32 mode materialises the B x N x M similarity
- * matrix: 4 B N M bytes); ..._bytes_for(h, ...) is what THIS handle needs -- in the default 3 x f16 split arithmetic the similarity
- * tiles are reduced to (best, index, second best) partials inside the GEMM and never stored: 12 B per row and 128-column tile plus
- * 12 B per column and 64-row half (7 MB instead of 100 MB for a 5000 x 5000 pair). */
+/* Round 5: descriptors of width 64 / 128 / 256 (SIFT, DISK, SuperPoint ...) run on the persistent similarity-and-reduce kernel
+ * (csrc/simred.hip) in EITHER arithmetic: both sets are packed once into matrix-core fragments (4 bytes per element), a workgroup keeps
+ * 128 descriptors of image 0 in registers and streams image 1 past them; per row (best, index, second best) live in registers, per
+ * column and 128-row block 12 bytes go to memory.  The similarity matrix never exists.  Other widths keep the round-4 paths: the tile
+ * GEMM with the reducing epilogue (3 x f16 split) or the materialised B x N x M matrix (exact f32: 4 B N M bytes).
+ * Workspace: ..._bytes(B, N, M) serves every path (sized for D <= 256); ..._bytes_for(h, ...) what THIS handle needs for D <= 256;
+ * ..._bytes_d(h, ..., D) what this handle needs for descriptors of width D. */
 size_t imcui_hip_mutual_nn_workspace_bytes(int B, int N, int M);
 size_t imcui_hip_mutual_nn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M);
+size_t imcui_hip_mutual_nn_workspace_bytes_d(imcui_hip_t* h, int B, int N, int M, int D);
 /* desc0 [dev, B,N,D], desc1 [dev, B,M,D] row per descriptor (D % 32 == 0); ratio_threshold /
  * distance_threshold <= 0 mean "None"; matches0 [dev, B,N] int32, scores0 [dev, B,N]. */
 int imcui_hip_mutual_nn(imcui_hip_t* h, const float* desc0, const float* desc1, int B, int N, int M, int D,
                         double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0,
                         float* scores0, void* ws, size_t ws_bytes, void* stream);
 /* The same matcher on the layout `NearestNeighbor._forward` receives (nearest_neighbor.py:38-66): descriptors0 [dev, B,D,N], descriptors1
- * [dev, B,D,M], one column per descriptor; transposed on the device into the workspace (tiled through LDS), then the call above. */
+ * [dev, B,D,M], one column per descriptor.  D = 64 / 128 / 256: the fragment packer reads that layout directly (no transposed copy);
+ * other widths: transposed on the device into the workspace (tiled through LDS), then the call above. */
 size_t imcui_hip_mutual_nn_dn_workspace_bytes_for(imcui_hip_t* h, int B, int N, int M, int D);
 int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, const float* desc1_dm, int B, int N, int M, int D, double ratio_threshold,
                            double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- test hook: ONE launch of the similarity-and-reduce kernel (csrc/simred.hip) on raw matrices (tests/test_gpu_simred.py) ----
+ * sim[b] = alpha * A[b] . Bm[b]^T is reduced, never stored.  A [dev, batch,M,K], Bm [dev, batch,N,K] f32, K in {64, 128, 256}; mcnt / ncnt
+ * [dev, batch] live rows / columns per batch or NULL.  mode 0: nearest neighbours (best, first index, second best); 1: soft-max statistics
+ * (max, sum exp); 2: dual-softmax confidence, row best + first column, column best (needs rmax / rsum / cmax / csum, optional tile flags
+ * [batch][ceil(M/128)][ceil(N/128)]); 3: LightGlue's log assignment, row best + first column, column best + first row (rsum / csum = LOG
+ * sums, l0 [batch,M], l1 [batch,N]).  Row outputs r0 / r1 / ri [batch][nchunk][M] (nchunk 0: imcui_hip_simred_chunks), column outputs
+ * c0 / c1 / ci [batch][ceil(M/128)][N]. */
+int imcui_hip_simred_chunks(int batch, int M, int N);
+size_t imcui_hip_simred_debug_workspace_bytes(int batch, int M, int N, int K);
+int imcui_hip_simred_debug(imcui_hip_t* h, int mode, const float* A, const float* Bm, int batch, int M, int N, int K, const int* mcnt, const int* ncnt, float alpha,
+                           int nchunk, float* r0, float* r1, int* ri, float* c0, float* c1, int* ci, const float* rmax, const float* rsum, const float* cmax,
+                           const float* csum, const float* l0, const float* l1, const unsigned char* flags, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- dual-softmax matcher (imcui/hloc/matchers/dual_softmax.py; zoo entries disk+dualsoftmax, superpoint+dualsoftmax) */
 size_t imcui_hip_dual_softmax_workspace_bytes(int B, int C, int N, int M);
