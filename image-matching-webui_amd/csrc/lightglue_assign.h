@@ -220,16 +220,18 @@ __global__ __launch_bounds__(256) void lg_best2_kernel(const float* __restrict__
 
 // rows (blockIdx.z = 0): best over the column chunks -> max0, m0; columns (1): best over the row bands -> m1.  Ascending
 // order, a later partial wins only with a strictly larger value = the first index attaining the maximum (torch.max)
+// rgran / cgran: columns per row-partial slot / rows per column-partial slot (round 5: the slots of simred.hip are chunks of column tiles and
+// 128-row blocks)
 __global__ __launch_bounds__(256) void lg_best_merge_kernel(const float* __restrict__ rpv, const int* __restrict__ rpj,
                                                             const float* __restrict__ cpv, const int* __restrict__ cpi,
-                                                            const int* __restrict__ cnt, int R, int nch, int nbd,
+                                                            const int* __restrict__ cnt, int R, int nch, int nbd, int rgran, int cgran,
                                                             float* __restrict__ max0, int* __restrict__ m0, int* __restrict__ m1) {
     const int b = blockIdx.y, cols = blockIdx.z;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int n0 = cnt[2 * b], n1 = cnt[2 * b + 1];
     if (t >= (cols ? n1 : n0) || n0 <= 0 || n1 <= 0) return;
     if (!cols) {
-        const int np = (n1 + LG2_COLS - 1) / LG2_COLS;
+        const int np = (n1 + rgran - 1) / rgran;
         float bv = -INFINITY;
         int bj = 0x7fffffff;
         for (int q = 0; q < np; ++q) {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void lg_best_merge_kernel(const float* __restr
         max0[(size_t)b * R + t] = bv;
         m0[(size_t)b * R + t] = bj < n1 ? bj : 0;  // only a row of NaN scores leaves no maximum: keep the index inside the pair
     } else {
-        const int np = (n0 + LG2_ROWS - 1) / LG2_ROWS;
+        const int np = (n0 + cgran - 1) / cgran;
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int q = 0; q < np; ++q) {

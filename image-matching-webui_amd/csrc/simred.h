@@ -46,6 +46,7 @@ struct SimRedP {
     long l0_bs = 0, l1_bs = 0;
     // SR_DSBEST: [batch][ceil(M / 128)][ceil(N / 128)] tile flags (0 = no entry of the tile can exceed the threshold: skipped), or nullptr
     const unsigned char* flags = nullptr;
+    int dbg = 0;  // lab switch (IMCUI_SR_DBG, read once): bit 0 = skip the per-column part of the epilogue, bit 1 = skip the per-row part (WRONG results: timing only)
 };
 
 // pack `rows` x K floats (element (r, k) of batch b at X[b * xbs + r * ldr + k * ldk]) into the fragment order above.

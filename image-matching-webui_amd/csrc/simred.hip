@@ -7,8 +7,10 @@
 //     piece): no vector work on either operand inside the loop;
 //   * a workgroup OWNS 128 rows of A for its whole life: wave w holds the fragments of rows 32 w .. 32 w + 31 in registers (64 .. 128
 //     VGPRs), fetched once;
-//   * the B fragments of the column tiles STREAM through a two-slot LDS ring (16 KiB = two k-steps of a 128-column tile per stage,
-//     one barrier per stage, requested two stages ahead): the pipeline never drains between tiles;
+//   * the B fragments of the column tiles STREAM through a four-slot LDS ring (16 KiB = two k-steps of a 128-column tile per stage, one
+//     barrier per stage), brought in by LDS-DMA (`global_load_lds_dwordx4`: no registers, no VALU) THREE stages ahead: the pipeline never
+//     drains between tiles and a request has three stages of matrix work to come back from L2 / the Infinity Cache (the first version
+//     went through registers one stage ahead and ran at the latency of a load per stage: 0.29 of the matrix pipe);
 //   * accumulators hold sim^T (B fragment = MFMA A operand): a lane owns ONE row i of sim and 16 columns per fragment, so everything
 //     per ROW is lane-local and is carried in registers across all column tiles (no row partials, no merge for the rows of a chunk);
 //   * per COLUMN the tile is parked in LDS 64 columns at a time and scanned by (column, row range) threads; one partial per column and
@@ -17,11 +19,13 @@
 // the bits the tile GEMM gave it.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "simred.h"
 
-#define SR_PLD 68       // floats per parked row of 64 columns (+ 4: the 16-byte stores of 8 consecutive rows hit 32 different banks)
+#define SR_PLD 132      // floats per parked COLUMN of 128 rows (+ 4: the 16-byte reads of four adjacent columns x four row groups hit 64 different banks)
 #define SR_SLOT_U4 1024  // uint4 per ring slot: 4 column fragments x 2 k-steps x 2 pieces x 64 lanes
+#define SR_NSLOT 4        // ring slots: the stage being multiplied + three in flight
 #define SR_MAXLIST 2048  // tiles per chunk when tiles are selected by flags
 
 __device__ __forceinline__ float sr_lg_score(float s, float rm, float rl, float cm, float cl, float l0, float l1) {
@@ -80,15 +84,12 @@ void simred_pack(imcui_hip_s* h, const float* X, long ldr, long ldk, long xbs, i
 template <int KS, int WN, int MODE, bool F32>
 __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     constexpr int NTH = 256 * WN, NW = 4 * WN, NF = 4 / WN, KT = KS / 2, PPW = 16 / NW;
-    constexpr int NPART = NTH / 64, RPP = SR_TILE / NPART;  // column scan: parts of RPP rows
+    static_assert(WN == 2, "the column scan maps 512 threads onto 128 columns x 4 row groups");
     static_assert(KT >= 2, "at least two stages per tile");
     extern __shared__ uint4 sr_smem[];
-    uint4* ring = sr_smem;                                              // 2 slots
-    float* park = reinterpret_cast<float*>(sr_smem + 2 * SR_SLOT_U4);   // [128 rows][SR_PLD]
-    float* sc0 = park + SR_TILE * SR_PLD;                               // [NPART][64] scan partials
-    float* sc1 = sc0 + NPART * 64;
-    int* sci = reinterpret_cast<int*>(sc1 + NPART * 64);
-    float* ctab = reinterpret_cast<float*>(sci + NPART * 64);           // [3][128] column constants of the tile (pass 2)
+    uint4* ring = sr_smem;                                                     // SR_NSLOT slots
+    float* park = reinterpret_cast<float*>(sr_smem + SR_NSLOT * SR_SLOT_U4);   // [128 columns][SR_PLD]
+    float* ctab = park + SR_TILE * SR_PLD;                                      // [3][128] column constants of the tile (pass 2)
     unsigned short* tlist = reinterpret_cast<unsigned short*>(ctab + 3 * SR_TILE);
     __shared__ int s_ntl;
 
@@ -144,26 +145,46 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     // instead of a 64-bit vector address per (piece, stage of a tile) hoisted out of the loop
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);
     const uint4* bpb = p.Bp + (size_t)b * p.bp_bs + ((size_t)((wid_s * PPW) >> 2) * KS) * 128 + ((wid_s * PPW) & 3) * 64;
-    // (named registers, not an array: a register array that is only copied global -> LDS is turned into a private-memory copy by hipcc)
-    uint4 br0, br1, br2, br3;
-    auto load_stage = [&](int ct, int kslice) __attribute__((always_inline)) {
-        const uint4* src = bpb + ((size_t)ct * 4 * KS + kslice * 2) * 128;  // scalar
-        br0 = src[lane];
-        br1 = src[lane + 64];
-        if constexpr (PPW == 4) {
-            br2 = src[lane + 128];
-            br3 = src[lane + 192];
-        }
+    // LDS-DMA: one instruction moves 1 KiB (16 bytes per lane) from the lanes' global addresses to M0 + 16 lane; issued from inline asm
+    // (M0 saved / restored around it) because a DMA the compiler can see makes it drain vmcnt to 0 in front of every LDS read -- the
+    // three-stage lead is the point.  The waits are placed by hand below (sr_wait_dma).
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)ring) + (unsigned)(wid_s * PPW) * 1024u;
+    auto dma_stage = [&](int ct, int kslice, int slot) __attribute__((always_inline)) {
+        const uint4* src = bpb + ((size_t)ct * 4 * KS + kslice * 2) * 128 + lane;  // (scalar base + lane)
+        const unsigned dst = ring_lds + (unsigned)slot * (SR_SLOT_U4 * 16u);
+        unsigned keep;
+        if constexpr (PPW == 2)
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "v"(src + 64), "s"(dst), "s"(dst + 1024u)
+                         : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                         "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "v"(src + 64), "v"(src + 128), "v"(src + 192), "s"(dst), "s"(dst + 1024u), "s"(dst + 2048u), "s"(dst + 3072u)
+                         : "memory");
     };
-    auto store_stage = [&](int slot) __attribute__((always_inline)) {
-        uint4* d = ring + slot * SR_SLOT_U4 + (wid * PPW) * 64 + lane;
-        d[0] = br0;
-        d[64] = br1;
-        if constexpr (PPW == 4) {
-            d[128] = br2;
-            d[192] = br3;
-        }
+    // wait until at most `stages` of this wave's DMA stages are outstanding (requests retire in order; the stores of an epilogue may sit
+    // between them -- they only make the wait longer, never shorter than needed)
+    auto wait_dma = [&](int stages) __attribute__((always_inline)) {
+        if (stages >= 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (stages == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    constexpr int LKT = (KT == 2) ? 1 : (KT == 4) ? 2 : 3;  // log2(KT)
+    static_assert((1 << LKT) == KT, "KS is 4, 8 or 16");
 
     f32x16 acc[NF];
 #pragma unroll
@@ -185,16 +206,13 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     }
 
     const int S = ntl * KT;
-    if (S > 0) {
-        load_stage(tile_at(0), 0);
-        store_stage(0);
-        load_stage(tile_at(0), 1);  // KT >= 2: stage 1 is in tile 0
-    }
+    // stages 0 .. 2 on their way; stage 0 landed (everywhere: the barrier) before the loop starts
+    for (int g = 0; g < 3 && g < S; ++g) dma_stage(tile_at(g >> LKT), g & (KT - 1), g);
+    wait_dma(S >= 3 ? 2 : S >= 2 ? 1 : 0);
     __syncthreads();
 
     for (int ti = 0; ti < ntl; ++ti) {
         const int ct = tile_at(ti);
-        const int ctn = (ti + 1 < ntl) ? tile_at(ti + 1) : ct;
         if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
             // column constants of the tile (read in the epilogue, >= 1 barrier from here; the previous tile's readers are past its last barrier)
             if (tid < SR_TILE) {
@@ -208,14 +226,9 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
 #pragma unroll
         for (int kslice = 0; kslice < KT; ++kslice) {
             const int s = ti * KT + kslice;
-            const int slot = kslice & 1;  // (KT is even)
-            if (s + 1 < S) store_stage(slot ^ 1);
-            if (s + 2 < S) {
-                if (kslice + 2 < KT)
-                    load_stage(ct, kslice + 2);
-                else
-                    load_stage(ctn, kslice + 2 - KT);
-            }
+            const int slot = (KT >= SR_NSLOT) ? (kslice & (SR_NSLOT - 1)) : (s & (SR_NSLOT - 1));
+            // stage s + 3 into the slot stage s - 1 was multiplied from (every wave is past the barrier that ended it)
+            if (s + 3 < S) dma_stage(tile_at((s + 3) >> LKT), (kslice + 3) & (KT - 1), (slot + 3) & (SR_NSLOT - 1));
 #pragma unroll
             for (int ksl = 0; ksl < 2; ++ksl) {
                 const int ks = kslice * 2 + ksl;
@@ -248,11 +261,12 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                             acc[n] = mfma32(bv4[j & 3], av[j], acc[n]);
                         }
                 }
-                // one k-step's fragments live at a time (the co-resident wave covers the LDS latency); without the fence hipcc hoists the
-                // reads of both k-steps of a stage (+ 32 VGPRs) and then spills the A fragments
-                __builtin_amdgcn_sched_barrier(0);
             }
-            if (kslice + 1 < KT) __syncthreads();
+            if (kslice + 1 < KT) {
+                // stage s + 1 of THIS wave has landed (two younger stages may still be in flight); the barrier makes it everybody's
+                wait_dma(s + 3 < S ? 2 : s + 2 < S ? 1 : 0);
+                __syncthreads();
+            }
         }
 
         // ================================================================ epilogue of tile ct
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         // second copy of the masking part and as a second copy of the whole epilogue -- and both made hipcc spill: the accumulators are
         // rewritten in place and two variants of that meeting in one control-flow join keep both register sets alive)
         const int jlim = Nb - jb;  // column c of the lane's list is live when c < jlim
+        if (!(p.dbg & 2))
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
@@ -350,126 +365,117 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
             q1 = sum;
             q0 = mn;
         }
-        // (2) per column: park 64 columns of the tile ([row][column], all 128 rows), scan them by (column, row range) threads
+        // (2) per column: the whole tile is parked COLUMN-major ([column][row], 132-float rows) and every column is reduced by FOUR adjacent
+        // lanes: thread (column jl = t >> 2, part = t & 3) reads rows 64 hh + 16 part + 4 k .. + 3 (hh < 2, k < 4) as eight conflict-free
+        // 16-byte reads -- 32 values, no loop, no dependent LDS latency -- reduces them in registers, and the four parts are folded with two
+        // DPP quad exchanges; lane part 0 stores.  One parking round and two barriers per tile.  (The first version parked row-major, 64
+        // columns at a time, scanned with (column, 16-row range) threads in a loop and folded the eight ranges through LDS by 64 threads
+        // while the other seven waves waited: 42 % of the LoFTR statistics launch, measured with IMCUI_SR_DBG.)
+        if (!(p.dbg & 1)) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (WN == 1 || wn == h) {
+            for (int n = 0; n < NF; ++n)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
-                    const int n = (WN == 1) ? 2 * h + nn : nn;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(park + erowl * SR_PLD + nn * 32 + 8 * q + 4 * ehi) =
-                            make_float4(acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]);
-                }
-            }
+                for (int r = 0; r < 16; ++r)
+                    park[(wn * (NF * 32) + n * 32 + 8 * (r >> 2) + (r & 3) + 4 * ehi) * SR_PLD + erowl] = acc[n][r];
             __syncthreads();
             {
-                const int jl = etid & 63, part = etid >> 6;
-                const int r0 = part * RPP, r1 = min(r0 + RPP, rowsv);
-                const float* col = park + jl;
-                if constexpr (MODE == SR_NN) {
-                    float b1 = -INFINITY, b2 = -INFINITY;
-                    int i1 = 0x7fffffff;
-#pragma unroll 4
-                    for (int r = r0; r < r1; ++r) {
-                        const float xv = col[r * SR_PLD];
-                        const bool up = xv > b1;  // rows ascend: first maximum
-                        b2 = __builtin_amdgcn_fmed3f(b1, b2, xv);
-                        i1 = up ? rb * SR_TILE + r : i1;
-                        b1 = fmaxf(b1, xv);
+                const int jl = etid >> 2, part = etid & 3;
+                const float4* col = reinterpret_cast<const float4*>(park + jl * SR_PLD + 16 * part);
+                float v[32];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 t4 = col[16 * hh + k];  // rows 64 hh + 16 part + 4 k .. + 3
+                        v[16 * hh + 4 * k + 0] = t4.x, v[16 * hh + 4 * k + 1] = t4.y, v[16 * hh + 4 * k + 2] = t4.z, v[16 * hh + 4 * k + 3] = t4.w;
                     }
-                    sc0[part * 64 + jl] = b1;
-                    sc1[part * 64 + jl] = b2;
-                    sci[part * 64 + jl] = i1;
-                } else if constexpr (MODE == SR_LSE) {
-                    float m = -INFINITY;
-#pragma unroll 4
-                    for (int r = r0; r < r1; ++r) m = fmaxf(m, col[r * SR_PLD]);
-                    float sum = 0.0f;
-                    const float mref = (m == -INFINITY) ? 0.0f : m;
-#pragma unroll 4
-                    for (int r = r0; r < r1; ++r) sum += __expf(col[r * SR_PLD] - mref);
-                    sc0[part * 64 + jl] = m;
-                    sc1[part * 64 + jl] = sum;
-                } else if constexpr (MODE == SR_DSBEST) {
-                    float m = -1.0f;
-#pragma unroll 4
-                    for (int r = r0; r < r1; ++r) m = fmaxf(m, col[r * SR_PLD]);
-                    sc0[part * 64 + jl] = m;
-                } else {
-                    float bv = -INFINITY;
-                    int bi = 0x7fffffff;
-#pragma unroll 4
-                    for (int r = r0; r < r1; ++r) {
-                        const float v = col[r * SR_PLD];
-                        const bool up = v > bv;
-                        bi = up ? rb * SR_TILE + r : bi;
-                        bv = up ? v : bv;
-                    }
-                    sc0[part * 64 + jl] = bv;
-                    sci[part * 64 + jl] = bi;
+                constexpr float NEUTRAL = (MODE == SR_DSBEST) ? -1.0f : -INFINITY;
+                if (rowsv < SR_TILE) {  // (the last row block of a matrix: rows past its end are neutral)
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) v[u] = (64 * (u >> 4) + 16 * part + (u & 15) < rowsv) ? v[u] : NEUTRAL;
                 }
-            }
-            __syncthreads();
-            if (etid < 64) {
-                const int tid = etid;  // (shadows the kernel's: the laundered copy)
-                const int j = ct * SR_TILE + 64 * h + tid;
-                if (j < Nb) {
-                    const size_t o = ((size_t)b * nrb + rb) * p.c_pitch + j;
+                // element u of the list is row 64 (u >> 4) + 16 part + (u & 15): ascending in u
+                float tm = v[0];
+#pragma unroll
+                for (int u = 1; u < 32; ++u) tm = fmaxf(tm, v[u]);
+                const int j = ct * SR_TILE + jl;
+                const size_t o = ((size_t)b * nrb + rb) * p.c_pitch + j;
+                const int rbase = rb * SR_TILE + 16 * part;
+                if constexpr (MODE == SR_NN || MODE == SR_LGBEST) {
+                    // first row attaining the maximum: equality, walking downwards (the last hit is the lowest row)
+                    int ti = 0x7fffffff - rbase;
+#pragma unroll
+                    for (int u = 31; u >= 0; --u) ti = (v[u] == tm) ? 64 * (u >> 4) + (u & 15) : ti;
+                    ti += rbase;
+                    float b2 = -INFINITY;
                     if constexpr (MODE == SR_NN) {
-                        float b1 = sc0[tid], b2 = sc1[tid];
-                        int i1 = sci[tid];
+                        // second best = the maximum of the list with ONE occurrence of the best removed: the running pair over the values
+                        float b1 = -INFINITY;
 #pragma unroll
-                        for (int pt = 1; pt < NPART; ++pt) {  // ascending row ranges: a later range wins only with a larger value
-                            const float ob1 = sc0[pt * 64 + tid], ob2 = sc1[pt * 64 + tid];
-                            const bool up = ob1 > b1;
-                            b2 = up ? fmaxf(b1, ob2) : fmaxf(b2, ob1);
-                            i1 = up ? sci[pt * 64 + tid] : i1;
-                            b1 = up ? ob1 : b1;
+                        for (int u = 0; u < 32; ++u) {
+                            b2 = __builtin_amdgcn_fmed3f(b1, b2, v[u]);
+                            b1 = fmaxf(b1, v[u]);
                         }
-                        p.c0[o] = b1;
-                        p.c1[o] = b2;
-                        p.ci[o] = i1;
-                    } else if constexpr (MODE == SR_LSE) {
-                        float m = sc0[tid];
-#pragma unroll
-                        for (int pt = 1; pt < NPART; ++pt) m = fmaxf(m, sc0[pt * 64 + tid]);
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int pt = 0; pt < NPART; ++pt) {
-                            const float pm = sc0[pt * 64 + tid];
-                            if (pm > -INFINITY) sum += sc1[pt * 64 + tid] * __expf(pm - m);
-                        }
-                        p.c0[o] = m;
-                        p.c1[o] = sum;
-                    } else if constexpr (MODE == SR_DSBEST) {
-                        float m = sc0[tid];
-#pragma unroll
-                        for (int pt = 1; pt < NPART; ++pt) m = fmaxf(m, sc0[pt * 64 + tid]);
-                        p.c0[o] = m;
-                    } else {
-                        float bv = sc0[tid];
-                        int bi = sci[tid];
-#pragma unroll
-                        for (int pt = 1; pt < NPART; ++pt) {
-                            const float ov = sc0[pt * 64 + tid];
-                            const bool up = ov > bv;
-                            bi = up ? sci[pt * 64 + tid] : bi;
-                            bv = up ? ov : bv;
-                        }
-                        p.c0[o] = bv;
-                        p.ci[o] = bi;
                     }
+                    // fold the four parts (interleaved row sets): larger value, lowest row on equal values
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int ctrl = st == 0 ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]: lane ^ 1, lane ^ 2
+                        const float om = __builtin_bit_cast(float, st == 0 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0xB1, 0xF, 0xF, true)
+                                                                          : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0x4E, 0xF, 0xF, true));
+                        const int oi = st == 0 ? __builtin_amdgcn_mov_dpp(ti, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(ti, 0x4E, 0xF, 0xF, true);
+                        const float o2 = __builtin_bit_cast(float, st == 0 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b2), 0xB1, 0xF, 0xF, true)
+                                                                          : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b2), 0x4E, 0xF, 0xF, true));
+                        (void)ctrl;
+                        const bool up = om > tm || (om == tm && oi < ti);
+                        if (MODE == SR_NN) b2 = up ? fmaxf(tm, o2) : fmaxf(b2, om);
+                        ti = up ? oi : ti;
+                        tm = up ? om : tm;
+                    }
+                    if (part == 0 && j < Nb) {
+                        p.c0[o] = tm;
+                        if (MODE == SR_NN) p.c1[o] = b2;
+                        p.ci[o] = ti;
+                    }
+                } else if constexpr (MODE == SR_LSE) {
+                    const float mref = (tm == -INFINITY) ? 0.0f : tm;
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) sum += __expf(v[u] - mref);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const float om = __builtin_bit_cast(float, st == 0 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0xB1, 0xF, 0xF, true)
+                                                                          : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0x4E, 0xF, 0xF, true));
+                        const float os = __builtin_bit_cast(float, st == 0 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sum), 0xB1, 0xF, 0xF, true)
+                                                                          : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sum), 0x4E, 0xF, 0xF, true));
+                        const float mm = fmaxf(tm, om);
+                        const float mr = (mm == -INFINITY) ? 0.0f : mm;
+                        sum = sum * __expf(tm - mr) + os * __expf(om - mr);  // (both lanes of a pair evaluate the same expression on swapped operands:
+                        tm = mm;                                             //  the sum is commutative in exact arithmetic only -- lane `part 0` decides)
+                    }
+                    if (part == 0 && j < Nb) {
+                        p.c0[o] = tm;
+                        p.c1[o] = sum;
+                    }
+                } else {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const float om = __builtin_bit_cast(float, st == 0 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0xB1, 0xF, 0xF, true)
+                                                                          : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, tm), 0x4E, 0xF, 0xF, true));
+                        tm = fmaxf(tm, om);
+                    }
+                    if (part == 0 && j < Nb) p.c0[o] = tm;
                 }
             }
-            // (the next parking round / the next tile's stores are behind the barrier that follows)
-            if (h == 0) __syncthreads();
         }
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+        {
+            const int s = ti * KT + KT - 1;
+            wait_dma(s + 3 < S ? 2 : s + 2 < S ? 1 : 0);
+        }
         __syncthreads();
     }
 
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
 }
 
 // ------------------------------------------------------------------ launch
-#define SR_LDS_BYTES(WN) (2 * SR_SLOT_U4 * 16 + SR_TILE * SR_PLD * 4 + 3 * (4 * (WN)) * 64 * 4 + 3 * SR_TILE * 4 + SR_MAXLIST * 2)
+#define SR_LDS_BYTES(WN) (SR_NSLOT * SR_SLOT_U4 * 16 + SR_TILE * SR_PLD * 4 + 3 * SR_TILE * 4 + SR_MAXLIST * 2)
 
 // column chunks per row block: enough workgroups for two rounds of the 256 CUs of the target part (a function of the sizes alone, so
 // that a workspace carved without a handle and the launch agree)
@@ -560,8 +566,10 @@ static int sr_launch_one(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
 template <int MODE, bool F32>
 static int sr_launch_k(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
     switch (p.K) {
-        case 64: return sr_launch_one<4, 1, MODE, F32>(h, p, stream);
-        case 128: return sr_launch_one<8, 1, MODE, F32>(h, p, stream);
+        // (512 threads, one workgroup per CU, for every width: the four-slot ring + the parked tile are 110 KB of LDS; the 256-thread
+        // geometry WN = 1 -- two workgroups per CU, register transport -- was the first version for K <= 128 and stays instantiable)
+        case 64: return sr_launch_one<4, 2, MODE, F32>(h, p, stream);
+        case 128: return sr_launch_one<8, 2, MODE, F32>(h, p, stream);
         case 256: return sr_launch_one<16, 2, MODE, F32>(h, p, stream);
         default: return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "simred: K=%d (64, 128 or 256)", p.K);
     }
@@ -585,8 +593,11 @@ int simred_launch(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
     if ((nct + p.nchunk - 1) / p.nchunk > SR_MAXLIST) return imcui_set_err(h, IMCUI_ERR_ARG, "simred: more than %d column tiles per chunk", SR_MAXLIST);
     if ((p.mode == SR_DSBEST || p.mode == SR_LGBEST) && (!p.rmax || !p.rsum || !p.cmax || !p.csum || (p.mode == SR_LGBEST && (!p.l0 || !p.l1))))
         return imcui_set_err(h, IMCUI_ERR_ARG, "simred: pass 2 needs the statistics of pass 1");
+    static const int dbg = getenv("IMCUI_SR_DBG") ? atoi(getenv("IMCUI_SR_DBG")) : 0;  // (lab switch, read once per process)
+    SimRedP q = p;
+    q.dbg = dbg;
     imcui_prof_begin(h, PROF_GEMM, stream);
-    const int rc = (h->precision == 1) ? sr_launch_m<false>(h, p, stream) : sr_launch_m<true>(h, p, stream);
+    const int rc = (h->precision == 1) ? sr_launch_m<false>(h, q, stream) : sr_launch_m<true>(h, q, stream);
     imcui_prof_end(h, PROF_GEMM, stream);
     if (rc != IMCUI_OK) return rc;
     IMCUI_CHECK_LAUNCH(h);

@@ -130,8 +130,9 @@ def test_dual_softmax_confidence(precision, K, B, M, N):
         out, nch = run(DSBEST, a.to(DEV), b.to(DEV), alpha=1.3, nchunk=nchunk, stats=stats)
         rv = out["r0"].double().max(1).values
         cv = out["c0"].double().max(1).values
-        assert (rv - conf.max(2).values).abs().max() < 1e-4  # (the parity bar; |sim| reaches ~60 here, so 1e-6 relative on a similarity is ~1e-4 on exp)
-        assert (cv - conf.max(1).values).abs().max() < 1e-4
+        # |sim| reaches ~60 here: fp32 round-off of a similarity (1e-6 relative) is 6e-5 in each of the two exponents of a confidence near 1
+        assert (rv - conf.max(2).values).abs().max() < 2.5e-4
+        assert (cv - conf.max(1).values).abs().max() < 2.5e-4
         # first column attaining the row maximum: the chunk that holds the maximum reports it
         v, k = out["r0"].double(), out["ri"].long()
         bj = torch.where(v == rv[:, None], k, torch.full_like(k, BIG)).min(1).values
@@ -139,7 +140,7 @@ def test_dual_softmax_confidence(precision, K, B, M, N):
         bad = bj != want
         if bad.any():
             top2 = conf.topk(min(2, N), 2).values
-            assert ((top2[..., 0] - top2[..., -1])[bad] < 1e-4).all()
+            assert ((top2[..., 0] - top2[..., -1])[bad] < 2.5e-4).all()
         # mutual maxima compare IDENTICAL numbers: where the double-precision matrix has a clear mutual maximum the device's row best equals its column best
         mut = (conf == conf.max(2, keepdim=True).values) & (conf == conf.max(1, keepdim=True).values) & (conf > 0.05)
         bb, ii, jj = torch.nonzero(mut, as_tuple=True)
@@ -173,7 +174,7 @@ def test_dual_softmax_tile_flags():
                 assert (part["r0"][bb, 0, rows] == -1).all() and (part["ri"][bb, 0, rows] == BIG).all()
                 continue
             sub = conf[bb, rows][:, cols]
-            assert (part["r0"][bb, 0, rows] - sub.max(1).values).abs().max() < 1e-4
+            assert (part["r0"][bb, 0, rows] - sub.max(1).values).abs().max() < 2.5e-4
             for ct in range(nct):
                 cc = slice(ct * 128, min(N, ct * 128 + 128))
                 if flags[bb, rb, ct]:
@@ -236,16 +237,16 @@ def test_repeatable_and_equal_to_the_tile_gemm_path():
         d0 = torch.nn.functional.normalize(torch.randn(2, n, d, generator=g), dim=2).to(dev)
         d1 = torch.nn.functional.normalize(torch.randn(2, m, d, generator=g), dim=2).to(dev)
         with backend.option(dev, simred=1):
-            m_new, s_new = backend.mutual_nn(d0, d1, 0.9, None, True)
-            m_again, s_again = backend.mutual_nn(d0, d1, 0.9, None, True)
-            m_dn, s_dn = backend.mutual_nn_dn(d0.permute(0, 2, 1).contiguous(), d1.permute(0, 2, 1).contiguous(), 0.9, None, True)
+            m_new, s_new = backend.mutual_nn(d0, d1, 0.999, None, True)
+            m_again, s_again = backend.mutual_nn(d0, d1, 0.999, None, True)
+            m_dn, s_dn = backend.mutual_nn_dn(d0.permute(0, 2, 1).contiguous(), d1.permute(0, 2, 1).contiguous(), 0.999, None, True)
         with backend.option(dev, simred=0):
-            m_old, s_old = backend.mutual_nn(d0, d1, 0.9, None, True)
+            m_old, s_old = backend.mutual_nn(d0, d1, 0.999, None, True)
         assert torch.equal(m_new, m_again) and torch.equal(s_new, s_again)
         assert torch.equal(m_new, m_dn) and torch.equal(s_new, s_dn)
         assert torch.equal(m_new, m_old), (n, m, d, (m_new != m_old).sum().item())
         assert torch.equal(s_new, s_old), (n, m, d, (s_new - s_old).abs().max().item())
-        assert (m_new > -1).sum() > 0
+        assert (m_new > -1).sum() > 20, (m_new > -1).sum()  # (mutual neighbours that pass the 0.999 ratio test exist: the comparison is not vacuous)
 
 
 def test_nan_descriptors_do_not_index_out_of_range():
