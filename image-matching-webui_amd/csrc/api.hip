@@ -24,7 +24,7 @@ int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...) {
 // an older layout is rejected instead of running with its LayerNorm affine parts dropped); imcui_hip_set_option / _get_option.
 extern "C" int imcui_hip_version(void) { return 400; }
 
-static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "lg_assign_stats", "simred"};
+static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "simred"};
 static int opt_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_NCNT; ++i)
@@ -62,7 +62,6 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         h->opt[OPT_GEMM_WREG] = (e = getenv("IMCUI_GEMM_WREG")) ? atoi(e) : 2;
         h->opt[OPT_WREG_PIPE] = (e = getenv("IMCUI_WREG_PIPE")) ? atoi(e) : 1;
         h->opt[OPT_ATTN_VARIANT] = (e = getenv("IMCUI_ATTN_VARIANT")) ? atoi(e) : 8;  // 8 = the arithmetic of 0 with the pipelined K.Q^T schedule (attention.hip)
-        h->opt[OPT_LG_ASSIGN_STATS] = ((e = getenv("IMCUI_LG_ASSIGN_STATS")) && (strcmp(e, "epilogue") == 0 || atoi(e) == 1)) ? 1 : 0;
         h->opt[OPT_SIMRED] = (e = getenv("IMCUI_SIMRED")) ? atoi(e) : 1;
     }
     *out = h;

@@ -149,8 +149,7 @@ enum {
     OPT_GEMM_WREG = 0,     // IMCUI_GEMM_WREG: 0 = projections on gemm_split_kernel, 1 = attention-layout projections on gemm_wreg_kernel, 2 (default) = every eligible launch
     OPT_WREG_PIPE,         // IMCUI_WREG_PIPE: 0 = rolled K loop, 1 (default) = three rotating register sets
     OPT_ATTN_VARIANT,      // IMCUI_ATTN_VARIANT: 0 .. 8, default 8, see attention.hip
-    OPT_LG_ASSIGN_STATS,   // IMCUI_LG_ASSIGN_STATS: 0 (default) = stand-alone statistics pass, 1 (`epilogue`) = soft-max partials from the similarity GEMM's epilogue
-    OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM paths (A/B; mutual-NN, LightGlue)
+    OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
     OPT_NCNT
 };
 

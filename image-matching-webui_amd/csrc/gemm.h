@@ -13,10 +13,7 @@ enum GemmEpi {
     EPI_QKV = 3,    // LightGlue SelfBlock: bias, RoPE on q/k, q *= alpha, head-major split
     EPI_CROSS = 4,  // LightGlue CrossBlock: [qk | v] = bias, qk *= alpha, head-major split
     EPI_CONV = 5,   // C = act(acc + bias + resid): act 0 none / 1 ReLU / 2 LeakyReLU(0.01) / 3 GELU (erf)
-    // C = acc (similarity matrix of two activation matrices, batched) AND, from the same parked tile, the soft-max partials of
-    // the assignment: per row (max, sum exp) over the tile's 128 columns -> st_rpm / st_rps [batch][N/128][ldc], per column over
-    // each 64-row half -> st_cpm / st_cps [batch][M/64][ldc]  (split mode, f32 B operand; LightGlue's log-assignment, a11)
-    EPI_SIMSTAT = 6,
+    // (6 was EPI_SIMSTAT, rounds 3-4: the similarity stored AND reduced to soft-max partials -- replaced by simred.hip, which stores nothing)
     // ViT blocks of the DUSt3R / MASt3R networks (gemm_wreg_kernel only): the output features are `heads` x 64 wide blocks of
     // q / k / v in that order starting at block `role0` (0: q, 1: k, 2: v -- self attention [q | k | v]: role0 = 0, N = 3 C; the
     // cross-attention key / value projection [k | v]: role0 = 1, N = 2 C; its query projection: role0 = 0, N = C).  q and k get
@@ -88,7 +85,7 @@ struct GemmP {
     // 1: ONE f16 product per element pair (hi planes only, f32 accumulate) instead of the three of the split arithmetic: 11-bit
     // operands, the class of a bf16 / fp16 autocast run.  EPI_CONV with pre-split weight planes only.
     int single = 0;
-    float *st_rpm = nullptr, *st_rps = nullptr, *st_cpm = nullptr, *st_cps = nullptr;  // EPI_SIMSTAT partials
+    float *st_rpm = nullptr, *st_rps = nullptr, *st_cpm = nullptr, *st_cps = nullptr;  // EPI_NNSTAT partials: best / second best
     int st_nct = 0, st_nrh = 0;                                                         // partial slots per row / per column
     int *st_rpi = nullptr, *st_cpi = nullptr;                                           // EPI_NNSTAT: arg-best partials
     long st_rpitch = 0, st_cpitch = 0;                                                  // EPI_NNSTAT: entries per partial slot (>= M rows / >= N columns)

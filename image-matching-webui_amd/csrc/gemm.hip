@@ -480,73 +480,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmP& p, const TileC
                     }
         }
         __syncthreads();
-        if constexpr (EPI == EPI_SIMSTAT) {
-            // similarity tile: store it, and reduce it to soft-max partials while it is in LDS.  A row of the half is held by
-            // the 32 lanes of one half-wave (4 columns each): row (max, sum exp) by five xor-shuffles; a thread sees 8 rows of
-            // its 4 columns: online (max, sum) per column, the 8 row groups combined through LDS in group order.
-            float cm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-            const int ctile = (cc.col0 >> 7) + PASS_C2(ps);
-#pragma unroll 2
-            for (int it = 0; it < 8; ++it) {
-                const int tl = (tid >> 5) + 8 * it;
-                const int row = cc.row0 + h * 64 + tl;
-                if (row < cc.M) {  // uniform over the half-wave
-                    const float4 t4 = *reinterpret_cast<const float4*>(st + tl * STG_C_ROW + 4 * (tid & 31));
-                    if (full)
-                        *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + f0) = t4;
-                    else if (colok) {
-                        const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (f0 + j < cc.N) C[(size_t)row * p.ldc + f0 + j] = tv[j];
-                    }
-                    float x[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (f0 + j >= cc.N) x[j] = -INFINITY;
-                    float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                    float s = 0.0f;  // m is finite: the tile holds at least one valid column
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        s += (x[j] > -INFINITY) ? __expf(x[j] - m) : 0.0f;
-                        const float mn = fmaxf(cm[j], x[j]);
-                        if (mn > -INFINITY) cs[j] = cs[j] * __expf(cm[j] - mn) + ((x[j] > -INFINITY) ? __expf(x[j] - mn) : 0.0f);
-                        cm[j] = mn;
-                    }
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                    if ((tid & 31) == 0) {
-                        const size_t o = ((size_t)cc.z * p.st_nct + ctile) * p.ldc + row;
-                        p.st_rpm[o] = m;
-                        p.st_rps[o] = s;
-                    }
-                }
-            }
-            float* clm = st + 64 * STG_C_ROW;  // [8 row groups][128 columns] max, then sums (behind the parked half)
-            float* cls = clm + 8 * 128;
-            *reinterpret_cast<float4*>(clm + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cm[0], cm[1], cm[2], cm[3]);
-            *reinterpret_cast<float4*>(cls + (tid >> 5) * 128 + 4 * (tid & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-            __syncthreads();
-            if (tid < 128) {
-                const int col = cc.col0 + PASS_C2(ps) * 128 + tid;
-                if (col < cc.N) {
-                    float m = clm[tid];
-#pragma unroll
-                    for (int gq = 1; gq < 8; ++gq) m = fmaxf(m, clm[gq * 128 + tid]);
-                    float s = 0.0f;
-#pragma unroll
-                    for (int gq = 0; gq < 8; ++gq) {
-                        const float q = clm[gq * 128 + tid];
-                        if (q > -INFINITY) s += cls[gq * 128 + tid] * __expf(q - m);
-                    }
-                    const size_t o = ((size_t)cc.z * p.st_nrh + (cc.row0 >> 6) + h) * p.ldc + col;
-                    p.st_cpm[o] = m;
-                    p.st_cps[o] = s;
-                }
-            }
-        } else if constexpr (EPI == EPI_NNSTAT) {
+        if constexpr (EPI == EPI_NNSTAT) {
             // similarity tile of the mutual-NN matcher: never stored.  While the half is parked in LDS,
             //  * rows: thread = (row tid & 63, 32-column segment tid >> 6) scans its 32 values in increasing column order (the 16 lanes of
             //    a 16-byte read group sit on 16 different rows: conflict-free), the four segments of a row are folded in order by threads
@@ -1221,11 +1155,6 @@ int gemm_launch(imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
         case EPI_CROSS: launch_one<EPI_CROSS>(p, split, stream); break;
         case EPI_QKV_VIT:
             return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "gemm: EPI_QKV_VIT is implemented by gemm_wreg_kernel only (split mode, pre-split weights, N %% (64 heads) == 0)");
-        case EPI_SIMSTAT:
-            if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_cpm || !p.st_cps || p.bias != nullptr || (p.ldc & 3) != 0)
-                return imcui_set_err(h, IMCUI_ERR_ARG, "gemm: EPI_SIMSTAT needs the split mode, an f32 B operand, no bias and the four partial buffers");
-            hipLaunchKernelGGL((gemm_split_kernel<EPI_SIMSTAT, 0, false, 2>), dim3(cdiv(p.M, BM) * cdiv(p.N, BN), 1, p.batch), dim3(256), 0, stream, p);
-            break;
         case EPI_NNSTAT:
             if (!split || p.Wh != nullptr || !p.st_rpm || !p.st_rps || !p.st_rpi || !p.st_cpm || !p.st_cps || !p.st_cpi || p.bias != nullptr || p.st_rpitch < p.M ||
                 p.st_cpitch < p.N || p.st_nct < cdiv(p.N, BN) || p.st_nrh < 2 * cdiv(p.M, BM))

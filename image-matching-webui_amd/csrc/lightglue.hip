@@ -246,9 +246,9 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
 
 // ------------------------------------------------------------------ workspace
 struct LgWs {
-    float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls, *sim;
+    float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls;
     float *rmax, *rls, *cmax, *cls, *max0, *ms0;
-    float *rpm, *rps, *cpm, *cps;  // assignment partials: rows [B][R/128][R], columns [B][R/64][R] (lightglue_assign.h)
+    float *rpm, *rps, *cpm, *cps;  // assignment partials of simred.hip: rows [B][column chunks][R], columns [B][R/128][R]
     int *rpj, *cpi;
     uint4 *pk0, *pk1;  // round 5: the matching descriptors as MFMA fragments (simred_pack)
     int *cntA, *cntB, *active, *ind, *indt, *pos, *prune, *m0, *m1, *valid0, *norig, *pflag;
@@ -275,7 +275,6 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.mtch = a.get<float>(rows);
     w.md = a.get<float>(rows * 256);
     w.ls = a.get<float>(rows);
-    w.sim = a.get<float>((size_t)B * R * R);
     w.pk0 = a.get<uint4>((size_t)B * simred_packed_uint4(R, 256));
     w.pk1 = a.get<uint4>((size_t)B * simred_packed_uint4(R, 256));
     w.rmax = a.get<float>((size_t)B * R);
@@ -286,10 +285,10 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.ms0 = a.get<float>((size_t)B * R);
     w.rpm = a.get<float>((size_t)B * (R / 128) * R);
     w.rps = a.get<float>((size_t)B * (R / 128) * R);
-    w.cpm = a.get<float>((size_t)B * (R / 64) * R);
-    w.cps = a.get<float>((size_t)B * (R / 64) * R);
+    w.cpm = a.get<float>((size_t)B * (R / 128) * R);
+    w.cps = a.get<float>((size_t)B * (R / 128) * R);
     w.rpj = a.get<int>((size_t)B * (R / 128) * R);
-    w.cpi = a.get<int>((size_t)B * (R / 64) * R);
+    w.cpi = a.get<int>((size_t)B * (R / 128) * R);
     w.cntA = a.get<int>(2 * B);
     w.cntB = a.get<int>(2 * B);
     w.active = a.get<int>(B);
@@ -964,7 +963,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
     }
     hipLaunchKernelGGL(lg_match_logit_kernel, rowgrid, blk, 0, stream, w.x, P + l.wmatch, P + l.bmatch, stop, cnt_cur, R,
                        w.ls);
-    if (h->opt[OPT_SIMRED] != 0) {
+    {
         // Round 5: sim[b] = md0[b] . md1[b]^T is never stored (simred.hip).  Pass 1: soft-max statistics of both directions (rows carried in
         // registers across the column tiles, columns per 128-row block); pass 2: the same tiles again, the log assignment ONCE per element,
         // row best (first column) and column best (first row).  Both descriptor sets are split into MFMA fragments once, by the packer.
@@ -990,48 +989,6 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
         sp.l0 = w.ls, sp.l1 = w.ls + R, sp.l0_bs = sp.l1_bs = (long)2 * R;
         LGRUN(simred_launch(h, sp, stream));
         hipLaunchKernelGGL(lg_best_merge_kernel, mg, blk, 0, stream, w.rpm, w.rpj, w.cpm, w.cpi, cnt_cur, R, nchunk, nrb, tpc * 128, 128, w.max0, w.m0, w.m1);
-    } else {
-        // sim[b] = md0[b] . md1[b]^T, then the soft-max partials in one pass over the matrix (default) or from the GEMM's own epilogue
-        // (IMCUI_LG_ASSIGN_STATS=epilogue, split mode: one read of the matrix less, but the 128 v_exp_f32 per thread make the
-        // matrix-pipe-bound GEMM 320 us longer where the HBM-bound pass costs 260 us -- measured 928 vs 931 pairs/s, profiles/r03),
-        // then ONE pass for both arg-maxes (lightglue_assign.h)
-        const bool epi_stats = split && h->opt[OPT_LG_ASSIGN_STATS] == 1;  // imcui_hip_set_option(h, "lg_assign_stats", 1)
-        const int nrp = R / 128, ncp = R / 64, nch = (R + LG2_COLS - 1) / LG2_COLS, nbd = R / LG2_ROWS;
-        {
-            GemmP g;
-            g.epi = epi_stats ? EPI_SIMSTAT : EPI_BIAS;
-            g.batch = B;
-            g.A = w.md;
-            g.lda = 256;
-            g.a_bs = (long)2 * R * 256;
-            g.W = w.md + (size_t)R * 256;
-            g.ldw = 256;
-            g.w_bs = (long)2 * R * 256;
-            g.C = w.sim;
-            g.ldc = R;
-            g.c_bs = (long)R * R;
-            g.M = R;
-            g.N = R;
-            g.K = 256;
-            g.mcnt = cnt_cur;
-            g.ncnt = cnt_cur + 1;
-            g.cnt_stride = 2;
-            g.st_rpm = w.rpm;
-            g.st_rps = w.rps;
-            g.st_cpm = w.cpm;
-            g.st_cps = w.cps;
-            g.st_nct = nrp;
-            g.st_nrh = ncp;
-            LGRUN(gemm_launch(h, g, stream));
-        }
-        const dim3 tg(nch, nbd, B), mg(cdiv(R, 256), B, 2);
-        if (!epi_stats) hipLaunchKernelGGL(lg_stats2_kernel, tg, blk, 0, stream, w.sim, cnt_cur, R, nrp, ncp, w.rpm, w.rps, w.cpm, w.cps);
-        hipLaunchKernelGGL(lg_stat_merge_kernel, mg, blk, 0, stream, w.rpm, w.rps, w.cpm, w.cps, cnt_cur, R, nrp, ncp, epi_stats ? 128 : LG2_COLS, 64,
-                           epi_stats ? 128 : 64, w.rmax, w.rls, w.cmax, w.cls);
-        // the best-partials reuse the statistic partial buffers (values) next to their index arrays
-        hipLaunchKernelGGL(lg_best2_kernel, tg, blk, 0, stream, w.sim, cnt_cur, R, nch, nbd, w.rmax, w.rls, w.cmax, w.cls, w.ls, w.rpm, w.rpj, w.cpm,
-                           w.cpi);
-        hipLaunchKernelGGL(lg_best_merge_kernel, mg, blk, 0, stream, w.rpm, w.rpj, w.cpm, w.cpi, cnt_cur, R, nch, nbd, LG2_COLS, LG2_ROWS, w.max0, w.m0, w.m1);
     }
     hipLaunchKernelGGL(lg_filter_kernel, dim3(B), blk, 0, stream, cnt_cur, w.norig, R, ncap, w.m0, w.m1, w.max0, w.ind,
                        w.prune, w.ms0, w.valid0, filt_f, matches0, matches1, mscores0, mscores1, prune0, prune1);

@@ -53,8 +53,9 @@ int imcui_hip_version(void);
 /* A/B switches of the kernel routing (profiling and the bitwise old-vs-new kernel tests).  The IMCUI_<NAME> environment variables
  * are read ONCE, by imcui_hip_create; afterwards a switch changes only through this call -- set it BETWEEN forward passes, never while
  * another thread runs a call on the same handle.  Names / values: "gemm_wreg" 0 | 1 | 2 (default 2: every eligible projection on
- * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..8 (default 8 = the three-product arithmetic of 0, bit for bit, with a pipelined schedule; 6 / 7 = the two-product P.V, NOT fp32-grade, csrc/attention.hip), "lg_assign_stats"
- * 0 | 1 (default 0: stand-alone soft-max statistics pass; 1: from the similarity GEMM's epilogue).  Unknown name: IMCUI_HIP_ERR_ARG. */
+ * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..8 (default 8 = the three-product arithmetic of 0, bit for bit, with a pipelined schedule; 6 / 7 = the two-product P.V, NOT fp32-grade, csrc/attention.hip), "simred"
+ * 1 | 0 (default 1: the mutual-NN matcher on the persistent similarity-and-reduce kernel; 0: the round-4 tile GEMM with the reducing
+ * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256).  Unknown name: IMCUI_HIP_ERR_ARG. */
 int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value);
 int imcui_hip_get_option(imcui_hip_t* h, const char* name, int* value);
 

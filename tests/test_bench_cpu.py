@@ -28,9 +28,36 @@ def test_which_invocations_carry_the_legs():
 
 
 def test_leg_table_covers_every_other_baseline_config():
-    assert set(bench.LEGS) == {"nn", "superpoint", "loftr_1024", "dust3r_512", "dust3r_512_fp16"}
-    assert {w for w, _ in bench.LEGS.values()} == {"nn", "superpoint", "loftr", "dust3r"}
+    # configs[0], [1], [3], [4] (+ its bf16-class arithmetic), the reference's own operating points of configs[2] (default adaptive conf; one pair
+    # per call through the plugin seam) and the f-row matchers
+    assert set(bench.LEGS) == {"splg_adaptive", "splg_b1_seam", "nn", "superpoint", "loftr_1024", "dust3r_512", "dust3r_512_fp16", "eloftr_640x480", "mast3r_512",
+                               "superglue"}  # fmt: skip
+    assert {w for w, _ in bench.LEGS.values()} == {"splg", "seam", "nn", "superpoint", "loftr", "eloftr", "dust3r", "mast3r", "superglue"}
     assert bench.LEGS["dust3r_512"][1]["arith"] == "fp32" and bench.LEGS["dust3r_512_fp16"][1]["arith"] == "fp16"
+    assert bench.LEGS["splg_adaptive"][1]["adaptive"] is True
+
+
+def test_compact_line_fits_the_drivers_tail():
+    """The ONE stdout line must fit the 8 KB tail the driver keeps, with every leg's value in it: a full-size record (long config strings, per-pair
+    parity lists, verbose samples, ten legs) is reduced to well under 8 KB and keeps the contract's keys."""
+    import json
+
+    leg = {"metric": "m" * 80, "value": 123.456, "unit": "pairs/s", "n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": 12.5, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" + "x" * 200, "data": "synthetic", "config": {"workload": "w" * 600, "pairs_per_step_per_gpu": 16},
+           "roofline": {"kernel": "k" * 200, "bound": "mfma", "achieved": 321.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.1284, "traffic": 1.07e9, "traffic_source": "t" * 300,
+                        "note": "n" * 300}, "cpu_baseline": {"value": 0.2, "unit": "pairs/s", "cores": 32, "kind": "port", "sample": "s" * 500, "table": {str(i): i for i in range(20)}},
+           "parity": {"status": "ok", "checked": "c" * 300, "max_score_error": 2.9e-5, "per_pair": [{"pair": i, "x": "y" * 50} for i in range(8)]}, "status": "ok", "leg_wall_s": 12.3}  # fmt: skip
+    full = {**leg, "kernel_time_ms_per_step": {"attention": 26.9, "conv3x3": 17.4, "gemm": 18.9}, "workloads": {f"leg{i}": dict(leg) for i in range(10)}}
+    full["workloads"]["broken"] = {"status": "failed", "error": "RuntimeError: " + "e" * 500, "traceback": "t" * 1500}
+    c = bench.compact_line(full)
+    text = json.dumps(c)
+    assert len(text) < 7000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
+              "cpu_baseline"):  # fmt: skip
+        assert k in c, k
+    assert c["roofline"]["frac"] == 0.1284 and c["cpu_baseline"]["cores"] == 32 and c["parity"]["status"] == "ok"
+    assert len(c["legs"]) == 11 and c["legs"]["leg3"]["value"] == 123.456 and c["legs"]["leg3"]["frac"] == 0.1284 and c["legs"]["leg3"]["parity"] == "ok"
+    assert c["legs"]["leg3"]["cpu"] == 0.2 and c["legs"]["broken"]["status"] == "failed"
 
 
 def test_ensure_built_is_a_no_op_on_a_fresh_library_and_guard_on_one_rank():

@@ -2,8 +2,8 @@
 
 * gemm_wreg_kernel (weights in registers) must be BITWISE equal to gemm_split_kernel: same K order, same three products per
   k-step, same epilogue expressions -- so every parity statement made for the old kernel carries over.
-* LightGlue assignment: the soft-max partials of the similarity GEMM's epilogue (EPI_SIMSTAT) against the stand-alone
-  statistics pass, and both against the oracle through the existing parity tests.
+* (LightGlue's assignment ran on a materialised similarity here, with its statistics from a stand-alone pass or from the GEMM's epilogue;
+  round 5 replaced both by the matrix-free kernel of csrc/simred.hip: tests/test_gpu_simred.py, tests/test_gpu_lightglue.py.)
 * attention priority variants are scheduling only: bitwise equal outputs.
 """
 import pytest
@@ -87,22 +87,6 @@ def test_lightglue_projection_kernels_agree(dc, wc):
         assert torch.equal(old[k], new[k]), k
     for k in ("matching_scores0", "matching_scores1"):
         assert (old[k] - new[k]).abs().max().item() < 2e-5, k
-
-
-@pytest.mark.parametrize("dc,wc", [(-1, -1), (0.95, 0.99)])
-def test_lightglue_assignment_epilogue_stats_vs_pass(dc, wc):
-    """Soft-max partials from the similarity GEMM's epilogue vs the stand-alone statistics pass: same matches, scores within
-    2e-6 (the partial sums are merged in a different grouping: 128-column tiles vs 1024-column chunks)."""
-    problems = [synthetic_matching_problem(70 + i, n, m, o) for i, (n, m, o) in enumerate(PROBLEMS)]
-    with backend.option(dev, lg_assign_stats=0):  # default: the stand-alone statistics pass
-        a = _run(dc, wc, problems)
-    with backend.option(dev, lg_assign_stats=1):
-        b = _run(dc, wc, problems)
-    for k in ("matches0", "matches1", "stop", "prune0", "prune1"):
-        assert torch.equal(a[k], b[k]), k
-    assert (a["matches0"] > -1).sum() > 100
-    for k in ("matching_scores0", "matching_scores1"):
-        assert (a[k] - b[k]).abs().max().item() < 2e-6, k
 
 
 @pytest.mark.parametrize("cross", [False, True])
