@@ -1461,7 +1461,8 @@ def bench_splg(args, dev, rank, world):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32",
+            "dtype": ("f32 via 3xf16 split MFMA, f32 accumulate" + ("" if backend.get_option(dev, "attn_variant_cross") < 0 else
+                      "; P.V of LightGlue's cross blocks in two products (audited per block: layer error <= 7.1e-6, score error <= 4.7e-5, profiles/r05_lab_attention_mix.txt)")) if split else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs "

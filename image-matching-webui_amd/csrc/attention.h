@@ -20,5 +20,8 @@ struct AttnP {
     int log2_domain = 0;
     // 1 (split mode + log2_domain only): one f16 product per element pair, hi planes only (DUSt3R's opt-in single-product arithmetic)
     int single = 0;
+    // >= 0: kernel variant for THIS launch (split mode, log2 domain) instead of the handle's "attn_variant" -- LightGlue routes its self and
+    // cross blocks / a subset of its layers separately ("attn_variant_self", "attn_variant_cross", "attn_mix_layers": round 5)
+    int variant = -1;
 };
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);

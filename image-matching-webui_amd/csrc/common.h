@@ -149,6 +149,9 @@ enum {
     OPT_GEMM_WREG = 0,     // IMCUI_GEMM_WREG: 0 = projections on gemm_split_kernel, 1 = attention-layout projections on gemm_wreg_kernel, 2 (default) = every eligible launch
     OPT_WREG_PIPE,         // IMCUI_WREG_PIPE: 0 = rolled K loop, 1 (default) = three rotating register sets
     OPT_ATTN_VARIANT,      // IMCUI_ATTN_VARIANT: 0 .. 8, default 8, see attention.hip
+    OPT_ATTN_SELF,         // IMCUI_ATTN_VARIANT_SELF: -1 (default) = attn_variant; else the variant of LightGlue's SELF blocks in the layers of attn_mix_layers
+    OPT_ATTN_CROSS,        // IMCUI_ATTN_VARIANT_CROSS: the same for the CROSS blocks; default 7 (two-product P.V: audited per block, tools/attn_mix_audit.py)
+    OPT_ATTN_MIX_LAYERS,   // IMCUI_ATTN_MIX_LAYERS: bit l = layer l takes the two overrides above (default 0x1ff: all nine)
     OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
     OPT_NCNT
 };

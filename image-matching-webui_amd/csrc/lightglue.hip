@@ -869,6 +869,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.rows_per_seq = R;
             a.cross = 0;
             a.log2_domain = 1;
+            if (h->opt[OPT_ATTN_SELF] >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = h->opt[OPT_ATTN_SELF];  // (per-block arithmetic mix: audit tool)
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.s2sp, o.b2s));
         }
@@ -904,6 +905,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.rows_per_seq = R;
             a.cross = 1;
             a.log2_domain = 1;
+            if (h->opt[OPT_ATTN_CROSS] >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = h->opt[OPT_ATTN_CROSS];
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.s2cp, o.b2c));
         }

@@ -1042,13 +1042,21 @@ def lib_version() -> int:
 
 
 def set_option(device: torch.device, name: str, value: int) -> int:
-    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "simred"); returns
+    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "simred"); returns
     the previous value.  The IMCUI_* environment variables of the same names are only read when the handle is created."""
     hd = get_handle(device)
     old = C.c_int(0)
     hd.check(hd.lib.imcui_hip_get_option(hd.h, name.encode(), C.byref(old)), "get_option")
     hd.check(hd.lib.imcui_hip_set_option(hd.h, name.encode(), int(value)), "set_option")
     return old.value
+
+
+def get_option(device: torch.device, name: str) -> int:
+    """Current value of a routing switch (imcui_hip_get_option)."""
+    hd = get_handle(device)
+    val = C.c_int(0)
+    hd.check(hd.lib.imcui_hip_get_option(hd.h, name.encode(), C.byref(val)), "get_option")
+    return val.value
 
 
 class option:

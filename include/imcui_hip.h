@@ -53,7 +53,10 @@ int imcui_hip_version(void);
 /* A/B switches of the kernel routing (profiling and the bitwise old-vs-new kernel tests).  The IMCUI_<NAME> environment variables
  * are read ONCE, by imcui_hip_create; afterwards a switch changes only through this call -- set it BETWEEN forward passes, never while
  * another thread runs a call on the same handle.  Names / values: "gemm_wreg" 0 | 1 | 2 (default 2: every eligible projection on
- * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..8 (default 8 = the three-product arithmetic of 0, bit for bit, with a pipelined schedule; 6 / 7 = the two-product P.V, NOT fp32-grade, csrc/attention.hip), "simred"
+ * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..8 (default 8 = the three-product arithmetic of 0, bit for bit, with a pipelined schedule; 6 / 7 = the two-product P.V, NOT fp32-grade, csrc/attention.hip),
+ * "attn_variant_self" / "attn_variant_cross" (-1 = attn_variant; else the variant of LightGlue's self / cross blocks in the layers whose bit is set in
+ * "attn_mix_layers", default 0x1ff.  Round 5 default: cross 7 -- the two-product P.V in the CROSS blocks only, audited per block: layer error <= 7.1e-6 and
+ * score error <= 4.7e-5 at N = M = 2048 on three weight sets, half the parity bar; -1 restores three products everywhere), "simred"
  * 1 | 0 (default 1: the mutual-NN matcher on the persistent similarity-and-reduce kernel; 0: the round-4 tile GEMM with the reducing
  * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256).  Unknown name: IMCUI_HIP_ERR_ARG. */
 int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value);
