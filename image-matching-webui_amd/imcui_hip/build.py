@@ -12,7 +12,7 @@ CSRC = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "..", "include"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
-SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "geometry.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "simred.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "png.hip", "geometry.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "simred.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
 # Per-source code-generation switches.  preprocess.hip restates host float32 arithmetic that rounds after every
@@ -89,7 +89,7 @@ def _build_locked(verbose: bool) -> None:
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB_PATH + f".tmp{os.getpid()}"
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", tmp]  # (-lz: the PNG path inflates on host threads with the system zlib)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

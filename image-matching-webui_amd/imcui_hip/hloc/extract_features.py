@@ -97,8 +97,9 @@ def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> to
     """`read_image(path, grayscale)` with the result on the device: uint8 [H,W] (grayscale) or [H,W,3] RGB.
     decode = "auto": a baseline JPEG goes through the library's decoder -- Huffman on the host, inverse DCT / up-sampling / colour on the
     device, bit-exact against libjpeg's default path (utils/jpeg.py); with `grayscale` the result is the file's luma plane, which is
-    what the reference's `cv2.imread(IMREAD_GRAYSCALE)` returns for a JPEG.  Files that path does not take (PNG, progressive or CMYK
-    JPEG, EXIF-rotated ...) are read on the host (`read_image_u8`) and uploaded.  "host": always the host reader; "device": refuse
+    what the reference's `cv2.imread(IMREAD_GRAYSCALE)` returns for a JPEG.  A PNG (8-bit, not interlaced: every PNG of the reference repository)
+    is inflated on the host and un-filtered on the device (utils/png.py), bit-exact.  Files neither path takes (progressive or CMYK JPEG,
+    interlaced or 16-bit PNG, other formats) are read on the host (`read_image_u8`) and uploaded.  "host": always the host reader; "device": refuse
     instead of falling back."""
     if decode not in ("auto", "host", "device"):
         raise ValueError(f"decode = {decode!r}: auto | host | device")
@@ -109,15 +110,31 @@ def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> to
             data = Path(path).read_bytes()
         except OSError as e:
             raise ValueError(f"Cannot read image {path}.") from e
+        from .utils.png import PngUnsupported, decode_png, is_png
+
         if is_jpeg(data):
             try:
                 return decode_jpeg(data, grayscale, device)
             except JpegUnsupported:
                 if decode == "device":
                     raise
+        elif is_png(data):
+            try:
+                return _png_as_read_image(decode_png(data, device), grayscale)
+            except PngUnsupported:
+                if decode == "device":
+                    raise
         elif decode == "device":
-            raise ValueError(f"{path}: not a JPEG file (decode='device')")
+            raise ValueError(f"{path}: neither a JPEG nor a PNG file (decode='device')")
     return torch.from_numpy(read_image_u8(path, grayscale)).to(device)
+
+
+def _png_as_read_image(t: torch.Tensor, grayscale: bool) -> torch.Tensor:
+    """The device PNG decoder's output in `read_image_u8`'s convention: gray files stay [H,W] for `grayscale`, are replicated to three channels
+    otherwise (IMREAD_COLOR); colour files stay RGB either way (their gray conversion runs on the device in the caller, as for the host reader)."""
+    if t.dim() == 2 and not grayscale:
+        return t[:, :, None].expand(-1, -1, 3).contiguous()
+    return t
 
 
 def read_images_device(paths, grayscale: bool, device, decode: str = "auto", decoder=None) -> list:
@@ -129,8 +146,9 @@ def read_images_device(paths, grayscale: bool, device, decode: str = "auto", dec
     out: list = [None] * len(paths)
     if decode != "host":
         from .utils.jpeg import JpegDecoder, JpegUnsupported, is_jpeg
+        from .utils.png import PngDecoder, PngUnsupported, is_png
 
-        blobs, where = [], []
+        blobs, where, pblobs, pwhere = [], [], [], []
         for i, p in enumerate(paths):
             try:
                 data = Path(p).read_bytes()
@@ -139,8 +157,20 @@ def read_images_device(paths, grayscale: bool, device, decode: str = "auto", dec
             if is_jpeg(data):
                 blobs.append(data)
                 where.append(i)
+            elif is_png(data):
+                pblobs.append(data)
+                pwhere.append(i)
             elif decode == "device":
-                raise ValueError(f"{p}: not a JPEG file (decode='device')")
+                raise ValueError(f"{p}: neither a JPEG nor a PNG file (decode='device')")
+        if pblobs:  # PNG: zlib on the library's host threads, the scan-line filters undone on the device (utils/png.py)
+            pdec = PngDecoder(device)
+            for i, r in zip(pwhere, pdec.decode_batch(pblobs)):
+                if isinstance(r, PngUnsupported):
+                    if decode == "device":
+                        raise r
+                else:
+                    out[i] = _png_as_read_image(r, grayscale)
+            pdec.close()
         if blobs:
             own = decoder is None
             dec = JpegDecoder(device) if own else decoder

@@ -157,6 +157,12 @@ SIGNATURES = {
     "imcui_hip_jpeg_reconstruct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                    C.c_size_t, C.c_void_p]),
     "imcui_hip_jpeg_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "imcui_hip_png_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "imcui_hip_png_raw_bytes": (C.c_size_t, [C.POINTER(C.c_int)]),
+    "imcui_hip_png_inflate": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "imcui_hip_png_inflate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "imcui_hip_png_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "imcui_hip_png_reconstruct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "imcui_hip_ransac_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "imcui_hip_ransac": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_ulonglong,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -420,6 +420,24 @@ size_t imcui_hip_mutual_nn_dn_workspace_bytes_for(imcui_hip_t* h, int B, int N, 
 int imcui_hip_mutual_nn_dn(imcui_hip_t* h, const float* desc0_dn, const float* desc1_dm, int B, int N, int M, int D, double ratio_threshold,
                            double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- PNG decode (row f-3; `read_image` = cv2.imread, imcui/hloc/utils/io.py:11-21; the reference's WxBS / EVD fixtures are PNG) ----
+ * Host: chunk walk + zlib inflate of the IDAT stream into the FILTERED scan lines (re-entrant; the batch call runs on the library's own host
+ * threads into caller-provided, typically pinned, staging).  Device: the scan-line filters undone as a wavefront (one workgroup per image,
+ * one thread per row) and the pixels written as the host reader returns them: [H][W] for gray / gray + alpha files, [H][W][3] RGB for RGB /
+ * RGBA / palette files (alpha dropped).  Bit-exact (checker: PIL).  8-bit, non-interlaced files; everything else: IMCUI_HIP_ERR_UNSUPPORTED
+ * (the caller keeps its host reader).  info: 8 ints = width, height, colour type, samples per pixel, decoded channels (1 | 3), bytes per
+ * pixel, palette entries, 0. */
+int imcui_hip_png_info(const unsigned char* data, size_t n, int* info);
+size_t imcui_hip_png_raw_bytes(const int* info);
+int imcui_hip_png_inflate(const unsigned char* data, size_t n, unsigned char* raw, size_t raw_bytes, unsigned char* palette);
+int imcui_hip_png_inflate_batch(const unsigned char* const* data, const size_t* sizes, int count, unsigned char* const* raw, const size_t* raw_bytes,
+                                unsigned char* palettes, int* status, int threads);
+size_t imcui_hip_png_workspace_bytes(const int* infos, int count);
+/* raw [dev] + raw_offsets [host]: scan lines of file i at raw + raw_offsets[i]; infos [host, count x 8]; palettes [dev, count x 768] or NULL;
+ * out [dev] + out_offsets [host]: the decoded image of file i. */
+int imcui_hip_png_reconstruct_batch(imcui_hip_t* h, const unsigned char* raw, const size_t* raw_offsets, const int* infos, const unsigned char* palettes, int count,
+                                    unsigned char* out, const size_t* out_offsets, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- test hook: ONE launch of the similarity-and-reduce kernel (csrc/simred.hip) on raw matrices (tests/test_gpu_simred.py) ----
  * sim[b] = alpha * A[b] . Bm[b]^T is reduced, never stored.  A [dev, batch,M,K], Bm [dev, batch,N,K] f32, K in {64, 128, 256}; mcnt / ncnt
  * [dev, batch] live rows / columns per batch or NULL.  mode 0: nearest neighbours (best, first index, second best); 1: soft-max statistics
