@@ -33,10 +33,20 @@ def load_pairs():
 
     z = np.load(os.path.join(HERE, "golden", "evd_pairs.npz"))
     names = [str(n) for n in z["names"]]
-    dec = lambda k: torch.from_numpy(np.asarray(Image.open(io.BytesIO(z[k].tobytes()))).astype(np.float32) / 255.0)  # noqa: E731
-    img0 = torch.stack([dec(f"img0_{i}") for i in range(len(names))])[:, None]
-    img1 = torch.stack([dec(f"img1_{i}") for i in range(len(names))])[:, None]
-    return names, img0, img1, z["homographies"]
+    # Round 5: the PNG bytes of the 32 images go through the DEVICE decode path (zlib on the library's host threads, scan-line filters on the
+    # device: imcui_hip/hloc/utils/png.py), the way the batch drivers read the reference's EVD / WxBS files; PIL decodes them too and
+    # the two must agree bit for bit before anything else is compared.
+    from imcui_hip.hloc.utils.png import PngDecoder
+
+    blobs = [z[f"img{s}_{i}"].tobytes() for s in (0, 1) for i in range(len(names))]
+    dec = PngDecoder("cuda:0", threads=8)
+    dev_imgs = dec.decode_batch(blobs)
+    dec.close()
+    for b, t in zip(blobs, dev_imgs):
+        assert isinstance(t, torch.Tensor) and np.array_equal(t.cpu().numpy(), np.asarray(Image.open(io.BytesIO(b)))), "device PNG decode != PIL"
+    imgs = torch.stack([t.cpu() for t in dev_imgs]).float() / 255.0
+    n = len(names)
+    return names, imgs[:n, None], imgs[n:, None], z["homographies"]
 
 
 def _run_and_check(img0, img1, hgt, lgc, names, need_matches):
