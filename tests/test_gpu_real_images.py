@@ -124,3 +124,51 @@ def test_real_texture_known_homography_auc(precision):
     auc = _run_and_check(a, b, hm.numpy().astype(np.float64), dict(depth_confidence=-1.0, width_confidence=-1.0, match_threshold=0.1),
                          [names[i] for i in pick], need_matches=200)  # fmt: skip
     assert auc[2] > 0.3, f"AUC@10 {auc}: the warped real-image pairs should be matchable"
+
+
+def test_hip_ransac_against_a_textbook_ransac_on_real_textures():
+    """`HIP_RANSAC` (csrc/geometry.hip) is its own, fully specified RANSAC, not cv2's USAC_MAGSAC, and its oracle
+    restates its own specification.  This records how it relates to "a" reference RANSAC: the 16 real EVD images warped by seeded mild homographies,
+    matched by the HIP pipeline, then verified (a) on the device by `ransac_batched` and (b) by the seeded textbook numpy DLT-RANSAC of
+    tests/geometry_utils.py on the SAME matches: corner errors against the ground truth, AUC@{3, 5, 10 px} of both printed; they must agree to a
+    few hundredths (both estimate one homography from the same inliers; sampling differs)."""
+    from imcui_hip.geometry import ransac_batched
+    from imcui_hip.pipeline import SuperPointLightGluePipeline
+    from imcui_hip.synth import random_homography, warp_image
+
+    names, img0, _, _ = load_pairs()
+    g = torch.Generator().manual_seed(11)
+    a = img0
+    hm = torch.stack([random_homography(g, H, W) for _ in names])
+    b = torch.cat([warp_image(a[i : i + 1], hm[i]) for i in range(len(names))]).clamp_(0, 1)
+    b = (b * 255).round() / 255
+    pipe = SuperPointLightGluePipeline({**SPC, "state_dict": superpoint_state_dict(0)},
+                                       {"depth_confidence": -1.0, "width_confidence": -1.0, "match_threshold": 0.1, "state_dict": lightglue_state_dict(0)}).eval().to("cuda:0")  # fmt: skip
+    out = pipe(a.cuda(), b.cuda())
+    B = len(names)
+    nmax = int(max(int((out["matches0"][i] > -1).sum()) for i in range(B)))
+    p0, p1 = torch.zeros(B, max(nmax, 4), 2, device="cuda:0"), torch.zeros(B, max(nmax, 4), 2, device="cuda:0")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    for i in range(B):
+        n0 = int(out["num_keypoints0"][i])
+        m = out["matches0"][i, :n0].long()
+        v = m > -1
+        k0, k1 = out["keypoints0"][i, :n0][v], out["keypoints1"][i][m[v]]
+        p0[i, : len(k0)], p1[i, : len(k1)], cnt[i] = k0, k1, len(k0)
+    res = ransac_batched(p0, p1, cnt, "Homography", 3.0, 0.9999, 2000, seed=1)
+    torch.cuda.synchronize()
+    e_dev, e_np, used = [], [], []
+    for i in range(B):
+        n = int(cnt[i])
+        if n < 8:
+            continue
+        hgt = hm[i].numpy().astype(np.float64)
+        e_dev.append(float(corner_error(res["model"][i].cpu().numpy(), hgt, W, H)) if bool(res["ok"][i]) else float("inf"))
+        hn, _ = ransac_homography(p0[i, :n].cpu().numpy().astype(np.float64), p1[i, :n].cpu().numpy().astype(np.float64), thresh=3.0, iters=2000, seed=i)
+        e_np.append(float(corner_error(hn, hgt, W, H)) if hn is not None else float("inf"))
+        used.append(n)
+    auc_dev, auc_np = error_auc(e_dev), error_auc(e_np)
+    print(f"[ransac] {len(used)} warped real-texture pairs, matches/pair {used}: AUC@3/5/10 HIP_RANSAC {auc_dev}, numpy DLT-RANSAC {auc_np}; "
+          f"median corner error {np.median(e_dev):.3f} vs {np.median(e_np):.3f} px")
+    assert len(used) >= 12
+    assert all(abs(x - y) <= 0.1 for x, y in zip(auc_dev, auc_np)), (auc_dev, auc_np)

@@ -125,3 +125,76 @@ def test_coarse_matching_border_and_mutual_maximum():
     inner = mask[0].reshape(L, L).diagonal().nonzero()[:, 0]
     assert torch.equal(cm["i_ids"], inner) and torch.equal(cm["j_ids"], inner) and (cm["mconf"] > 0.99).all()
     assert torch.equal(cm["mkpts0_c"], torch.stack([inner % w, inner // w], 1) * 8.0)
+
+
+def test_backbone_against_a_module_tree_written_from_the_published_layer_list():
+    """the FPN of the LoFTR oracle had no independent cross-check.  `ResNetFPN_8_2` is re-expressed here as a plain
+    `torch.nn` module tree from kornia's published layer list (feature/loftr/backbone/resnet_fpn.py: conv1 7x7/2 -> 128, three stages of two
+    BasicBlocks 128 / 196 / 256 with 1x1 down-sample branches, 1x1 lateral convolutions, x2 bilinear up-sampling with align_corners=True, and the
+    conv3x3 - BN - LeakyReLU - conv3x3 merge blocks), with kornia's attribute names -- so loading the seeded state dict with strict=True checks the
+    key set and shapes, and the forward pass checks the wiring the functional oracle restates (strides, paddings, which sum feeds which block)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    def conv3x3(i, o, s=1):
+        return nn.Conv2d(i, o, 3, s, 1, bias=False)
+
+    def conv1x1(i, o, s=1):
+        return nn.Conv2d(i, o, 1, s, 0, bias=False)
+
+    class BasicBlock(nn.Module):
+        def __init__(self, i, o, stride):
+            super().__init__()
+            self.conv1, self.conv2 = conv3x3(i, o, stride), conv3x3(o, o)
+            self.bn1, self.bn2 = nn.BatchNorm2d(o), nn.BatchNorm2d(o)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = None if stride == 1 else nn.Sequential(conv1x1(i, o, stride), nn.BatchNorm2d(o))
+
+        def forward(self, x):
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.bn2(self.conv2(y))
+            if self.downsample is not None:
+                x = self.downsample(x)
+            return self.relu(x + y)
+
+    class ResNetFPN82(nn.Module):
+        def __init__(self, initial=128, dims=(128, 196, 256)):
+            super().__init__()
+            self.conv1 = nn.Conv2d(1, initial, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(initial)
+            self.relu = nn.ReLU(inplace=True)
+            self.layer1 = nn.Sequential(BasicBlock(initial, dims[0], 1), BasicBlock(dims[0], dims[0], 1))
+            self.layer2 = nn.Sequential(BasicBlock(dims[0], dims[1], 2), BasicBlock(dims[1], dims[1], 1))
+            self.layer3 = nn.Sequential(BasicBlock(dims[1], dims[2], 2), BasicBlock(dims[2], dims[2], 1))
+            self.layer3_outconv = conv1x1(dims[2], dims[2])
+            self.layer2_outconv = conv1x1(dims[1], dims[2])
+            self.layer2_outconv2 = nn.Sequential(conv3x3(dims[2], dims[2]), nn.BatchNorm2d(dims[2]), nn.LeakyReLU(), conv3x3(dims[2], dims[1]))
+            self.layer1_outconv = conv1x1(dims[0], dims[1])
+            self.layer1_outconv2 = nn.Sequential(conv3x3(dims[1], dims[1]), nn.BatchNorm2d(dims[1]), nn.LeakyReLU(), conv3x3(dims[1], dims[0]))
+
+        def forward(self, x):
+            x0 = self.relu(self.bn1(self.conv1(x)))
+            x1 = self.layer1(x0)
+            x2 = self.layer2(x1)
+            x3 = self.layer3(x2)
+            x3_out = self.layer3_outconv(x3)
+            x3_out_2x = F.interpolate(x3_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+            x2_out = self.layer2_outconv2(self.layer2_outconv(x2) + x3_out_2x)
+            x2_out_2x = F.interpolate(x2_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+            x1_out = self.layer1_outconv2(self.layer1_outconv(x1) + x2_out_2x)
+            return x3_out, x1_out
+
+    sd = loftr_state_dict(0)
+    net = ResNetFPN82().eval()
+    missing = net.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert sum(p.numel() for p in net.parameters()) == sum(v.numel() for k, v in sd.items() if k.startswith("backbone.") and "running" not in k and "num_batches" not in k)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 1, 96, 128, generator=g)
+    ora = LoFTROracle(sd)
+    with torch.no_grad():
+        c_mod, f_mod = net(x)
+        c_ora, f_ora = ora.backbone(x)
+    assert c_mod.shape == (2, 256, 12, 16) and f_mod.shape == (2, 128, 48, 64)
+    assert (c_mod - c_ora).abs().max() <= 1e-5 * c_ora.abs().max()
+    assert (f_mod - f_ora).abs().max() <= 1e-5 * f_ora.abs().max()
