@@ -813,22 +813,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
 }
 
 // IMCUI_CONV_TALL: 0 = the 8-row kernel everywhere, 1 (default) = 16-row tiles for the fused first layer, 2 = also for plain layers
-// whose Cout is not a multiple of 128 (read per process).  Measured (profiles/r03_lab_conv_tall.txt): SuperPoint's convolutions 18.38 ms
+// whose Cout is not a multiple of 128 (handle option "conv_tall").  Measured (profiles/r03_lab_conv_tall.txt): SuperPoint's convolutions 18.38 ms
 // per 128 images with 0, 17.60 with 1, 17.94 with 2 -- the plain layers LOSE with 16-channel stages (64-byte pieces of the 256-byte
 // pixel rows per stage, and no registers left to prefetch the next patch across the taps), the fused layer, whose patch is computed
 // from an LDS image tile, gains 10 %.
-static int conv_tall_mode() {
-    static const int mode = [] {
-        const char* e = getenv("IMCUI_CONV_TALL");
-        return e ? atoi(e) : 1;
-    }();
-    return mode;
-}
-
-static bool conv_narrow_env() {  // (read once per process, like IMCUI_CONV_TALL)
-    static const bool on = getenv("IMCUI_CONV_NARROW") != nullptr;
-    return on;
-}
+// (both switches live in the handle since round 5 -- imcui_hip_set_option "conv_tall" / "conv_narrow", environment read once by imcui_hip_create)
+static inline int conv_tall_mode(const imcui_hip_s* h) { return h->opt[OPT_CONV_TALL]; }
+static inline bool conv_narrow_env(const imcui_hip_s* h) { return h->opt[OPT_CONV_NARROW] != 0; }
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
@@ -840,7 +831,7 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (pool && resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: residual input and fused pooling are exclusive");
     if (resid2 && !resid) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: a second residual map needs the first");
     if (head && (Cout != 128 || pool || resid || (relu & 3) != 1 || cout_live != Cout || !head->w || !head->b || !head->pts || !head->conf ||
-                 conv_narrow_env()))
+                 conv_narrow_env(h)))
         return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: the fused point-map head needs a 128-channel ReLU layer without pooling / residual");
     if (!head && !out) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: null output");
     if (Cin % 32 != 0 || Cout % 64 != 0)
@@ -848,9 +839,9 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
     const int tiles_x = cdiv(W, STW);
     // 128 output channels per workgroup when the layer has them (fewer LDS fragment reads and barriers per MFMA)
-    static const bool narrow_only = getenv("IMCUI_CONV_NARROW") != nullptr;  // A/B switch
+    const bool narrow_only = conv_narrow_env(h);  // A/B switch
     const bool wide = (Cout % 128 == 0) && !narrow_only;
-    if (!wide && cout_live == Cout && conv_tall_mode() >= 2) {  // 64-channel layers: 16-row tiles (same LDS-read ratio as the wide kernel)
+    if (!wide && cout_live == Cout && conv_tall_mode(h) >= 2) {  // 64-channel layers: 16-row tiles (same LDS-read ratio as the wide kernel)
         const int tiles_t = cdiv(H, TTH);
         const long nwg_t = (long)tiles_x * tiles_t * (Cout / 64) * B;
         if (nwg_t <= 0) return IMCUI_OK;
@@ -892,7 +883,7 @@ int conv1ab_fused_split_launch(imcui_hip_s* h, const float* image, const float* 
                                const unsigned short* wh, const unsigned short* wl, const float* wscale, const float* bias,
                                float* out, int B, int H, int W, int pool, hipStream_t stream) {
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv1ab: pooled layer needs even H,W (%dx%d)", H, W);
-    const bool tall = conv_tall_mode() >= 1;
+    const bool tall = conv_tall_mode(h) >= 1;
     const int tiles_x = cdiv(W, STW), tiles_y = cdiv(H, tall ? TTH : STH);
     const long nwg = (long)tiles_x * tiles_y * B;
     if (nwg <= 0) return IMCUI_OK;
