@@ -540,9 +540,22 @@ __global__ void geo_okflag_kernel(const int* __restrict__ info, int* __restrict_
     }
 }
 
+// between two local-optimisation rounds: the chosen model's inlier count becomes the count to beat, the refit's counter starts from zero
+__global__ void geo_next_round_kernel(const int* __restrict__ info, int* __restrict__ ninl1, int* __restrict__ ninl2, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        ninl1[b] = info[4 * b + 0];
+        ninl2[b] = 0;
+    }
+}
+
 }  // namespace
 
 #define GEO_MAX_HYP 16384
+// least-squares refits on the current inliers, each kept when it has at least as many inliers as the model it came from (round 5: three rounds;
+// the single refit of round 4 measured a median corner error of 7.7 px where a textbook RANSAC with two refits reached 4.6 px on the same matches,
+// tests/test_gpu_real_images.py)
+#define GEO_REFIT_ROUNDS 3
 
 extern "C" size_t imcui_hip_ransac_workspace_bytes(int B, int N, int max_iter) {
     if (B <= 0 || N <= 0 || max_iter <= 0) return 0;
@@ -570,9 +583,12 @@ extern "C" int imcui_hip_ransac(imcui_hip_t* h, const float* pts0, const float* 
     hipLaunchKernelGGL(geo_select_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, counts, N, K, m, confidence, w.cnt, w.models, model, info, B);
     hipLaunchKernelGGL(geo_okflag_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, info, w.okflag, w.ninl1, w.ninl2, B);
     hipLaunchKernelGGL(geo_mask_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, pts0, pts1, counts, N, geometry, thr2, model, w.okflag, mask, w.ninl1);
-    hipLaunchKernelGGL(geo_refit_kernel, dim3(B), dim3(256), 0, stream, pts0, pts1, counts, N, geometry, mask, w.okflag, w.refit, w.refit_ok);
-    hipLaunchKernelGGL(geo_mask_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, pts0, pts1, counts, N, geometry, thr2, w.refit, w.refit_ok, w.mask2, w.ninl2);
-    hipLaunchKernelGGL(geo_choose_kernel, dim3(B), dim3(256), 0, stream, N, model, mask, info, w.refit, w.mask2, w.ninl2, w.refit_ok, w.ninl1);
+    for (int round = 0; round < GEO_REFIT_ROUNDS; ++round) {
+        if (round > 0) hipLaunchKernelGGL(geo_next_round_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, info, w.ninl1, w.ninl2, B);
+        hipLaunchKernelGGL(geo_refit_kernel, dim3(B), dim3(256), 0, stream, pts0, pts1, counts, N, geometry, mask, w.okflag, w.refit, w.refit_ok);
+        hipLaunchKernelGGL(geo_mask_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, pts0, pts1, counts, N, geometry, thr2, w.refit, w.refit_ok, w.mask2, w.ninl2);
+        hipLaunchKernelGGL(geo_choose_kernel, dim3(B), dim3(256), 0, stream, N, model, mask, info, w.refit, w.mask2, w.ninl2, w.refit_ok, w.ninl1);
+    }
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;
 }

@@ -155,6 +155,9 @@ def refit(p0, p1, mask, geometry):
     return normalise_model(M, geometry)
 
 
+REFIT_ROUNDS = 3
+
+
 def ransac(p0, p1, geometry: int, reproj_threshold: float, confidence: float, max_iter: int, seed: int = 0, pair_index: int = 0, return_counts: bool = False):
     """One pair.  -> (model 3x3 float64 or None, mask [n] bool, info dict(inliers, used, best_k))."""
     n = len(p0)
@@ -189,8 +192,10 @@ def ransac(p0, p1, geometry: int, reproj_threshold: float, confidence: float, ma
         return none
     M = models[bestk]
     mask = errors2(M, p0, p1, geometry) < thr2
-    M2 = refit(p0, p1, mask, geometry)
-    if M2 is not None:
+    for _ in range(REFIT_ROUNDS):  # local optimisation: least-squares refits on the current inliers (csrc/geometry.hip: GEO_REFIT_ROUNDS)
+        M2 = refit(p0, p1, mask, geometry)
+        if M2 is None:
+            continue
         mask2 = errors2(M2, p0, p1, geometry) < thr2
         if mask2.sum() >= mask.sum():
             M, mask = M2, mask2
