@@ -301,9 +301,8 @@ def best_cpu_threads() -> int:
 def bench_nn(args, dev, rank, world):
     """configs[0] (the plumbing config): mutual nearest-neighbour matcher on SIFT-like descriptors -- 5000 x 128-d RootSIFT-style rows
     per image, the matcher zoo's `NN-mutual` conf (imcui/hloc/matchers/nearest_neighbor.py:38-66: ratio test
-    off, distance threshold off, mutual check).  One step = B independent pairs through imcui_hip_mutual_nn.  Split arithmetic (default):
-    the [5000 x 5000] similarity tiles are reduced inside the GEMM and never stored -- priced against the MFMA peak; exact-f32 mode: the
-    matrix is written and read twice per pair -- HBM-bound, priced against the 8 TB/s peak."""
+    off, distance threshold off, mutual check).  One step = B independent pairs through imcui_hip_mutual_nn_dn.  The [5000 x 5000] similarity
+    tiles are reduced inside the persistent kernel of csrc/simred.hip and never stored, in either arithmetic -- priced against the MFMA peak."""
     from imcui_hip import backend
     from imcui_hip.hloc.matchers.nearest_neighbor import NearestNeighbor
 
@@ -355,24 +354,17 @@ def bench_nn(args, dev, rank, world):
         dt = float(t.item())
     if rank == 0:
         split = args.precision == 1
-        if split:
-            # the similarity tiles are reduced to (best, index, second best) partials inside the GEMM and never stored: what is left of
-            # the HBM traffic is the descriptors and 24 B of partials per row / column and tile -- the launch is bound by the matrix pipe
-            gf = 2.0 * N * N * D / 1e9  # algorithmic GFLOP per pair (the similarity products)
-            ach = gf * 1e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
-            roof = {"kernel": "gemm_split_kernel<EPI_NNSTAT> (similarity tiles reduced to nearest-neighbour partials in the epilogue, never stored)", "bound": "mfma",
-                    "achieved": ach, "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TF, "traffic": None, "executed_tflops": 3.0 * ach,
-                    "algorithmic_gflop_per_pair": gf, "launches_per_step": gemm_n / max(args.steps, 1), "kernel_ms_per_step": gemm_ms / max(args.steps, 1),
-                    "note": "achieved = algorithmic TFLOP of the similarity products / GEMM kernel time (HIP events inside the timed loop); K = 128 gives a tile only four "
-                            "k-steps between its prologue and the reducing epilogue"}  # fmt: skip
-        else:
-            # exact-f32 mode: the similarity matrix is materialised -- descriptors read (2 x N x D x 4), similarity written once and read
-            # twice (row pass, column pass), match tables written
-            alg = 2 * N * D * 4 + 3 * N * N * 4 + 4 * N * 4
-            achieved = alg * B * args.steps / (gpu_ms * 1e-3) / 1e9
-            roof = {"kernel": "nn similarity GEMM + nn_find / nn_mutual passes", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_pair": alg,
-                    "note": "achieved = algorithmic bytes of a pair (similarity written once, read twice) / stream time (HIP events over the timed region)"}  # fmt: skip
+        # Round 5, either arithmetic: both descriptor sets are packed once into MFMA fragments and ONE persistent launch (csrc/simred.hip) reduces
+        # the similarity tiles to (best, index, second best) on the spot -- rows in registers across the column tiles, columns per 128-row block;
+        # the matrix is never stored.  HBM traffic = the descriptors (+ their packed copies) and 12 B per column and row block: matrix-pipe bound.
+        gf = 2.0 * N * N * D / 1e9  # algorithmic GFLOP per pair (the similarity products)
+        ach = gf * 1e9 * B * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
+        peak = PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF
+        roof = {"kernel": "simred_kernel<K/16 = 8, mode NN> (persistent similarity-and-reduce: A rows in registers, B by LDS-DMA through a four-slot ring)", "bound": "mfma",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "executed_tflops": (3.0 if split else 1.0) * ach,
+                "algorithmic_gflop_per_pair": gf, "launches_per_step": gemm_n / max(args.steps, 1), "kernel_ms_per_step": gemm_ms / max(args.steps, 1),
+                "note": "achieved = algorithmic TFLOP of the similarity products / kernel time (HIP events inside the timed loop); K = 128 leaves four "
+                        "two-k-step stages between two tile epilogues (per row 32 values / lane, per column a 128 x 128 tile parked in LDS)"}  # fmt: skip
         line = {
             "metric": "image-pairs/sec mutual nearest-neighbour matcher (5000 x 128-d descriptors)", "value": world * B * args.steps / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -1225,7 +1217,9 @@ def bench_seam(args, dev, rank, world):
 
     if world > 1:
         raise LegSkipped("the seam leg is a single-GPU latency figure")
-    ext = SuperPoint({"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)}).eval().to(dev)
+    spc = {"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)}
+    exts = {False: SuperPoint(dict(spc)).eval().to(dev), True: SuperPoint({**spc, "hip_graph": True}).eval().to(dev)}
+    ext = exts[False]
     npairs = 8
     img0, img1, _ = make_pair_batch(4321, npairs, H, W, distinct=npairs)
     img0, img1 = img0.to(dev), img1.to(dev)
@@ -1246,8 +1240,12 @@ def bench_seam(args, dev, rank, world):
 
     res = {}
     with torch.no_grad():
-        for tag, (dc, wc) in (("fixed_work", (-1.0, -1.0)), ("reference_default_adaptive", (0.95, 0.99))):
-            matcher = LightGlue({"depth_confidence": dc, "width_confidence": wc, "match_threshold": 0.1, "state_dict": lightglue_state_dict(0)}).eval().to(dev)
+        # eager launches (the drop-in default) and the plugins' opt-in `hip_graph` conf (the same calls replayed from HIP graphs captured per
+        # image shape / key-point capacity: outputs identical, tests/test_gpu_plugin_graph.py)
+        for tag, (dc, wc), graphed in (("fixed_work", (-1.0, -1.0), False), ("reference_default_adaptive", (0.95, 0.99), False),
+                                       ("fixed_work_hip_graph", (-1.0, -1.0), True), ("reference_default_adaptive_hip_graph", (0.95, 0.99), True)):  # fmt: skip
+            ext = exts[graphed]
+            matcher = LightGlue({"depth_confidence": dc, "width_confidence": wc, "match_threshold": 0.1, "state_dict": lightglue_state_dict(0), "hip_graph": graphed}).eval().to(dev)
 
             def one(i):
                 f0, f1 = extract(img0[i : i + 1]), extract(img1[i : i + 1])
@@ -1268,8 +1266,8 @@ def bench_seam(args, dev, rank, world):
     return {"metric": "image-pairs/sec @640x480 SuperPoint+LightGlue through the plugin seam, one pair per call (the reference's call pattern)",
             "value": fw["pairs_per_s"], "unit": "pairs/s", "n_gpus": 1, "steps": fw["pairs_timed"], "warmup": min(args.warmup, 3) + 1, "ms_per_step": fw["ms_per_pair"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "configs[2] at the reference's call granularity: SuperPoint._forward x 2 + LightGlue._forward + .cpu() of every output per pair, eager launches, "
-                                   "8 distinct synthetic 640x480 scenes in turn", "pairs_per_step_per_gpu": 1},
+            "config": {"workload": "configs[2] at the reference's call granularity: SuperPoint._forward x 2 + LightGlue._forward + .cpu() of every output per pair, eager launches "
+                                   "(value) and the plugins' opt-in hip_graph conf (seam.*_hip_graph), 8 distinct synthetic 640x480 scenes in turn", "pairs_per_step_per_gpu": 1},
             "roofline": {"bound": "launch/latency", "achieved": None, "peak": None, "unit": None, "frac": None,
                          "note": "one pair does not fill the chip: ~250 launches of a few microseconds each and three host round trips; no roofline fraction is claimed"},
             "seam": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in res.items()}}  # fmt: skip

@@ -22,6 +22,9 @@ class SuperPoint(BaseModel):
         "max_keypoints": -1,
         "remove_borders": 4,
         "fix_sampling": False,
+        # opt-in (not a reference key): replay the extractor from a captured HIP graph per (image shape, conf) -- the reference calls
+        # `_forward` with ONE image at a time (extract_features.py:166-170), ~70 launches of a few microseconds; outputs are unchanged
+        "hip_graph": False,
     }
     required_inputs = ["image"]
     detection_noise = 2.0
@@ -51,7 +54,7 @@ class SuperPoint(BaseModel):
         capacity overflow (status bit 1: `max_keypoints = -1` sizes the outputs by the NMS bound, which only exactly tied
         scores of flat images can exceed) is retried with room for every pixel, any other non-zero status raises.
         -> (outputs, counts).  Used by `_forward` and by the batched extraction driver."""
-        out = self.forward_batched(image)
+        out = self._forward_graphed(image) if self.conf.get("hip_graph", False) else self.forward_batched(image)
         *counts, status = torch.cat([out["num_keypoints"], out["status"]]).tolist()
         if status & 2:
             out = self._impl.forward(self.packed, self._gray(image), self.conf, kcap=image.shape[-2] * image.shape[-1])
@@ -59,6 +62,24 @@ class SuperPoint(BaseModel):
         if status:
             raise backend.ImcuiHipError(f"SuperPoint key-point selection failed (status {status})")
         return out, counts
+
+    def _forward_graphed(self, image: torch.Tensor) -> dict:
+        """`forward_batched` replayed from a HIP graph captured for this (shape, conf); outputs are CLONED out of the graph's static buffers (the
+        next call -- the pair's second image -- overwrites them).  Falls back to eager launches if the capture fails."""
+        from ...pipeline import GraphedCall
+
+        c = self.conf
+        key = (tuple(image.shape), str(image.device), c["nms_radius"], c["max_keypoints"], c["keypoint_threshold"], c["remove_borders"], c.get("fix_sampling", False))
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key not in cache:
+            try:
+                cache[key] = GraphedCall(lambda img: self.forward_batched(img), image)
+            except Exception:  # noqa: BLE001 -- capture is an optimisation: keep working without it
+                cache[key] = None
+        g = cache[key]
+        if g is None:
+            return self.forward_batched(image)
+        return {k: v.clone() for k, v in g(image).items()}
 
     def _forward(self, data):
         # ragged lists are the reference contract

@@ -41,6 +41,9 @@ class LightGlue(BaseModel):
         # cached LightGlue keeps the threshold it was first loaded with.  False (default) = exactly that; True = re-read
         # conf["match_threshold"] on every call (what the UI's slider intends).  VERDICT round 3, weak 5.
         "runtime_match_threshold": False,
+        # opt-in (not a reference key): one pair per `_forward` (the reference's call pattern, match_features.py:204-240) replayed from a HIP
+        # graph captured per key-point capacity (a multiple of 128) and image size; outputs are unchanged
+        "hip_graph": False,
     }
     PRUNING_KEYPOINT_THRESHOLDS = {"cpu": -1, "mps": -1, "cuda": 1024, "flash": 1536}
     required_inputs = [
@@ -84,6 +87,45 @@ class LightGlue(BaseModel):
             scales_oris=scales_oris,
         )  # fmt: skip
 
+    def _forward_graphed(self, kpts0, kpts1, desc0, desc1, n0, n1, size0, size1) -> dict:
+        """One pair through a HIP graph captured for the key-point CAPACITY (max(m, n) rounded up to 128): the inputs are copied into zero-padded
+        static buffers, the counts say how many rows are live (the kernels are launched for the capacity, dead tiles exit), the outputs are
+        sliced back to (m, n) and cloned.  Falls back to eager launches if the capture fails."""
+        from ...pipeline import GraphedCall
+
+        c = self.conf
+        m, n = kpts0.shape[1], kpts1.shape[1]
+        cap = max(128, (max(m, n) + 127) // 128 * 128)
+        thr = float(c["match_threshold"]) if c.get("runtime_match_threshold", False) else self._filter_threshold
+        key = (cap, size0, size1, str(kpts0.device), c["depth_confidence"], c["width_confidence"], thr, str(c.get("pruning_device", "cpu")))
+        cache = self.__dict__.setdefault("_graphs", {})
+        dev = kpts0.device
+
+        def pad(t, width):
+            out = torch.zeros((1, cap, width), dtype=torch.float32, device=dev)
+            out[:, : t.shape[1]] = t
+            return out
+
+        ins = (pad(kpts0, 2), pad(kpts1, 2), pad(desc0, desc0.shape[-1]), pad(desc1, desc1.shape[-1]), n0, n1)
+        if key not in cache:
+            try:
+                cache[key] = GraphedCall(lambda a, b, d, e, p, q: self.forward_batched(a, b, d, e, p, q, size0, size1), *ins)
+            except Exception:  # noqa: BLE001 -- capture is an optimisation: keep working without it
+                cache[key] = None
+        g = cache[key]
+        if g is None:
+            return self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1)
+        out = g(*ins)
+        res = {}
+        for k, v in out.items():
+            if k in ("matches0", "matching_scores0", "prune0"):
+                res[k] = v[:, :m].clone()
+            elif k in ("matches1", "matching_scores1", "prune1"):
+                res[k] = v[:, :n].clone()
+            else:
+                res[k] = v.clone()
+        return res
+
     def _forward(self, data):
         kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
         desc0 = data["descriptors0"].permute(0, 2, 1)
@@ -98,7 +140,10 @@ class LightGlue(BaseModel):
         so = None
         if self.add_scale_ori:  # imcui/hloc/matchers/lightglue.py:62-73 forwards them when the extractor provides them
             so = tuple(data[k] for k in ("scales0", "oris0", "scales1", "oris1"))
-        out = self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, scales_oris=so)
+        if self.conf.get("hip_graph", False) and B == 1 and so is None:
+            out = self._forward_graphed(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1)
+        else:
+            out = self.forward_batched(kpts0, kpts1, desc0, desc1, n0, n1, size0, size1, scales_oris=so)
         m0, m1 = out["matches0"].long(), out["matches1"].long()
         ms0, ms1 = out["matching_scores0"], out["matching_scores1"]
         matches, mscores = [], []

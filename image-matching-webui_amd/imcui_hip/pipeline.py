@@ -109,6 +109,36 @@ class GraphedPipeline:
         return self.out
 
 
+class GraphedCall:
+    """A function of fixed-shape device tensors captured in a HIP graph: `GraphedCall(fn, *example_inputs)` warms `fn` up, captures ONE call on
+    static copies of the inputs and replays it on every `__call__` (inputs are copied into the static buffers first).  Used by the plugins'
+    opt-in `conf["hip_graph"]` (one image / one pair per `_forward`: the reference's call pattern is launch-bound, ~250 launches of a few
+    microseconds).  `fn` must not synchronise with the host and must return a dict of tensors; the returned tensors are the graph's static
+    outputs -- the caller slices and CLONES what it keeps."""
+
+    def __init__(self, fn, *inputs: torch.Tensor, warmup: int = 2):
+        dev = inputs[0].device
+        self.fn = fn
+        self.static_in = [t.clone() for t in inputs]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the capture: workspaces reach their final size
+            for _ in range(warmup):
+                fn(*self.static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn(*self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, *inputs: torch.Tensor) -> dict:
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t)
+        self.graph.replay()
+        return self.out
+
+
 def match_table(out: dict) -> torch.Tensor:
     """Fixed-stride per-pair record for the multi-GPU all-gather:
     int32 [B, 3 + 2*K]: n0, n1, stop, matches0[K], bit-cast matching_scores0[K]."""

@@ -10,9 +10,21 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r04"))
+F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r05"))
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+# every summary carries the commit the collection ran at (tools/collect_profiles.sh writes it into <out>/HEAD: VERDICT round 4, item 2 iv)
+HEAD = open(os.path.join(F, "HEAD")).read().strip() if os.path.exists(os.path.join(F, "HEAD")) else "unknown"
+_dump = json.dump
+
+
+def _stamped(obj, fh, **kw):
+    if isinstance(obj, dict):
+        obj = {"head": HEAD, **obj}
+    return _dump(obj, fh, **kw)
+
+
+json.dump = _stamped
 
 
 def agg(counter, sub=None, stem="splg", name=None):
@@ -141,7 +153,10 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_splg_attn_v0.json.log", f"{tag}_bench_splg_attn_v0.json.log"), ("bench_splg_attn_v6.json.log", f"{tag}_bench_splg_attn_v6.json.log"),
                  ("bench_splg_attn_v7.json.log", f"{tag}_bench_splg_attn_v7.json.log"), ("bench_splg_h2d_jpeg.json.log", f"{tag}_bench_splg_h2d_jpeg.json.log"),
                  ("lab_attention_pv2.txt", f"{tag.split('_')[0]}_lab_attention_pv2.txt"), ("lab_jpeg.txt", f"{tag.split('_')[0]}_lab_jpeg.txt"),
-                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"),
+                 ("pytest_gpu.log", f"{tag}_pytest_gpu.log"), ("bench_splg.err", f"{tag}_bench_splg.detail.log"),
+                 ("lab_attention_mix.txt", f"{tag.split('_')[0]}_lab_attention_mix.txt"), ("bench_splg_attn_cross_off.json.log", f"{tag}_bench_splg_attn_cross_off.json.log"),
+                 ("bench_nn_simred_off.json.log", f"{tag}_bench_nn_simred_off.json.log"), ("lab_simred_parts.txt", f"{tag.split('_')[0]}_lab_simred_parts.txt"),
+                 ("bench_splg_adaptive_b1_graph.json.log", f"{tag}_bench_splg_adaptive_b1_graph.json.log"),
                  ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
