@@ -19,7 +19,7 @@
 // Results are BIT-EXACT against PIL on every JPEG of the reference repository (tests/test_jpeg_cpu.py pins the restatement
 // oracle/jpeg.py to PIL; tests/test_gpu_jpeg.py the kernels).  Supported: baseline / extended sequential Huffman (SOF0, SOF1), 8 bit,
 // 1 or 3 components, sampling 4:4:4, 4:2:2, 4:2:0, restart intervals, interleaved and non-interleaved scans.  Anything else
-// (progressive, arithmetic coding, CMYK, 12 bit, 4:4:0 and other sampling factors) is reported as IMCUI_ERR_UNSUPPORTED and the caller keeps
+// (arithmetic coding, CMYK, 12 bit, 4:4:0 and other sampling factors; progressive files are taken since round 5) is reported as IMCUI_ERR_UNSUPPORTED and the caller keeps
 // its host decoder for that file.  EXIF orientation is reported in the info record and applied by imcui_hip_orient_u8 (the Python layer
 // does that, as cv2.imread does).
 #include <stdlib.h>
@@ -193,7 +193,7 @@ long parse_headers(const unsigned char* d, size_t n, Jpeg& j) {
             if (pl < 6) return IMCUI_ERR_ARG;
             j.progressive = (m == 0xC2 || m == 0xC6 || m == 0xCA || m == 0xCE);
             j.arithmetic = m >= 0xC9;
-            if (m != 0xC0 && m != 0xC1) return IMCUI_ERR_UNSUPPORTED;  // lossless / differential / progressive / arithmetic
+            if (m != 0xC0 && m != 0xC1 && m != 0xC2) return IMCUI_ERR_UNSUPPORTED;  // lossless / differential / arithmetic coding (SOF2 = progressive Huffman: round 5)
             j.precision = p[0];
             j.H = be16(p + 1);
             j.W = be16(p + 3);
@@ -385,6 +385,133 @@ int decode_block(BitReader& br, const HuffTable& dct, const HuffTable& act, int&
     return IMCUI_OK;
 }
 
+// ---- progressive frames (SOF2; ITU T.81 Annex G, the procedure of libjpeg's jdphuff.c): a scan codes a band Ss .. Se of the zig-zag
+// sequence at bit position Al; DC scans (Ss = 0) may interleave components, AC scans code one component block by block with end-of-band
+// runs; a refinement scan (Ah > 0) adds one bit to what earlier scans left.  The coefficient planes accumulate over the scans; once
+// the last scan is in they hold exactly what a sequential file would have, and the device reconstruction is the same.
+// `first` = the offset of the entropy-coded data; returns the offset of the next marker or < 0.
+long decode_scan_progressive(const unsigned char* d, size_t n, size_t first, Jpeg& j, const int* sc, int ns, int Ss, int Se, int Ah, int Al) {
+    if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1)) return IMCUI_ERR_ARG;
+    if (Ah != 0 && Ah != Al + 1) return IMCUI_ERR_ARG;  // successive approximation adds one bit per pass
+    for (int s = 0; s < ns; ++s) {
+        const Comp& k = j.comp[sc[s]];
+        if (Ss == 0 ? (Ah == 0 && !j.dc[k.td].present) : !j.ac[k.ta].present) return IMCUI_ERR_ARG;
+    }
+    BitReader br(d, n, first);
+    int pred[4] = {0, 0, 0, 0};
+    unsigned eobrun = 0;
+    const bool inter = ns > 1;
+    const int units_x = inter ? j.mx : j.comp[sc[0]].rbw, units_y = inter ? j.my : j.comp[sc[0]].rbh;
+    const long total = (long)units_x * units_y;
+    int rst_left = j.rst, next_rst = 0;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    for (long u = 0; u < total; ++u) {
+        if (j.rst && rst_left == 0) {
+            br.reset();
+            size_t q = br.pos;
+            while (q + 1 < n && !(d[q] == 0xFF && d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7)) {
+                if (d[q] == 0xFF && d[q + 1] != 0 && d[q + 1] != 0xFF) return IMCUI_ERR_ARG;
+                ++q;
+            }
+            if (q + 1 >= n || d[q + 1] != 0xD0 + next_rst) return IMCUI_ERR_ARG;
+            br.pos = q + 2;
+            next_rst = (next_rst + 1) & 7;
+            rst_left = j.rst;
+            pred[0] = pred[1] = pred[2] = pred[3] = 0;
+            eobrun = 0;
+        }
+        const int ux = (int)(u % units_x), uy = (int)(u / units_x);
+        if (Ss == 0) {
+            // ---- DC: first pass = the sequential DC difference, shifted; refinement = one raw bit per block
+            for (int s = 0; s < ns; ++s) {
+                const Comp& k = j.comp[sc[s]];
+                const int nby = inter ? k.v : 1, nbx = inter ? k.h : 1;
+                for (int by = 0; by < nby; ++by)
+                    for (int bx = 0; bx < nbx; ++bx) {
+                        short* blk = inter ? k.base + ((size_t)(uy * k.v + by) * k.bw + (ux * k.h + bx)) * 64 : k.base + ((size_t)uy * k.bw + ux) * 64;
+                        if (Ah == 0) {
+                            const int t = huff_decode(br, j.dc[k.td]);
+                            if (t < 0 || t > 15) return IMCUI_ERR_ARG;
+                            if (t) pred[sc[s]] += extend(br.get(t), t);
+                            blk[0] = (short)(pred[sc[s]] * p1);
+                        } else if (br.get(1)) {
+                            blk[0] = (short)(blk[0] | p1);
+                        }
+                    }
+            }
+        } else {
+            const Comp& kc = j.comp[sc[0]];
+            short* blk = kc.base + ((size_t)uy * kc.bw + ux) * 64;
+            const HuffTable& act = j.ac[kc.ta];
+            if (Ah == 0) {
+                // ---- AC first pass: (run, size) symbols inside the band; size 0 with run < 15 opens an end-of-band run
+                if (eobrun > 0) {
+                    --eobrun;
+                } else {
+                    for (int k = Ss; k <= Se; ++k) {
+                        const int rs = huff_decode(br, act);
+                        if (rs < 0) return IMCUI_ERR_ARG;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz) {
+                            k += r;
+                            if (k > 63) return IMCUI_ERR_ARG;
+                            blk[ZIGZAG[k]] = (short)(extend(br.get(sz), sz) * p1);
+                        } else if (r == 15) {
+                            k += 15;
+                        } else {
+                            eobrun = 1u << r;
+                            if (r) eobrun += (unsigned)br.get(r);
+                            --eobrun;  // this block is the first of the run
+                            break;
+                        }
+                    }
+                }
+            } else {
+                // ---- AC refinement: every coefficient that is already non-zero receives one correction bit as the walk passes it; a new
+                // coefficient (+-1 << Al) lands after `r` still-zero positions
+                int k = Ss;
+                if (eobrun == 0) {
+                    for (; k <= Se; ++k) {
+                        const int rs = huff_decode(br, act);
+                        if (rs < 0) return IMCUI_ERR_ARG;
+                        int r = rs >> 4;
+                        const int sz = rs & 15;
+                        int val = 0;
+                        if (sz) {
+                            val = br.get(1) ? p1 : m1;  // (size must be 1 here; libjpeg warns and carries on for anything else)
+                        } else if (r != 15) {
+                            eobrun = 1u << r;
+                            if (r) eobrun += (unsigned)br.get(r);
+                            break;  // the rest of this block is handled by the end-of-band branch below
+                        }
+                        do {
+                            short* cp = blk + ZIGZAG[k];
+                            if (*cp != 0) {
+                                if (br.get(1) && (*cp & p1) == 0) *cp = (short)(*cp + (*cp >= 0 ? p1 : m1));
+                            } else if (--r < 0) {
+                                break;
+                            }
+                            ++k;
+                        } while (k <= Se);
+                        if (val && k <= 63) blk[ZIGZAG[k]] = (short)val;
+                    }
+                }
+                if (eobrun > 0) {
+                    for (; k <= Se; ++k) {
+                        short* cp = blk + ZIGZAG[k];
+                        if (*cp != 0 && br.get(1) && (*cp & p1) == 0) *cp = (short)(*cp + (*cp >= 0 ? p1 : m1));
+                    }
+                    --eobrun;
+                }
+            }
+        }
+        if (j.rst) --rst_left;
+    }
+    size_t q = br.pos;
+    while (q + 1 < n && !(d[q] == 0xFF && d[q + 1] != 0 && d[q + 1] != 0xFF && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) ++q;
+    return (long)q;
+}
+
 // one scan starting at the SOS marker at `pos`; returns the offset of the next marker (after the entropy-coded data) or < 0
 long decode_scan(const unsigned char* d, size_t n, size_t pos, Jpeg& j) {
     if (pos + 4 > n) return IMCUI_ERR_ARG;
@@ -401,11 +528,12 @@ long decode_scan(const unsigned char* d, size_t n, size_t pos, Jpeg& j) {
         sc[s] = c;
         j.comp[c].td = p[2 + 2 * s] >> 4;
         j.comp[c].ta = p[2 + 2 * s] & 15;
-        if (j.comp[c].td > 3 || j.comp[c].ta > 3 || !j.dc[j.comp[c].td].present || !j.ac[j.comp[c].ta].present || !j.have_qt[j.comp[c].tq])
-            return IMCUI_ERR_ARG;
+        if (j.comp[c].td > 3 || j.comp[c].ta > 3 || !j.have_qt[j.comp[c].tq]) return IMCUI_ERR_ARG;
+        if (!j.progressive && (!j.dc[j.comp[c].td].present || !j.ac[j.comp[c].ta].present)) return IMCUI_ERR_ARG;
     }
     const unsigned char* tail = p + 1 + 2 * ns;
-    if (tail[0] != 0 || tail[1] != 63 || tail[2] != 0) return IMCUI_ERR_UNSUPPORTED;  // spectral selection / approximation = progressive
+    if (j.progressive) return decode_scan_progressive(d, n, pos + 2 + L, j, sc, ns, tail[0], tail[1], tail[2] >> 4, tail[2] & 15);
+    if (tail[0] != 0 || tail[1] != 63 || tail[2] != 0) return IMCUI_ERR_ARG;  // a sequential frame codes whole blocks
     BitReader br(d, n, pos + 2 + L);
     int pred[4] = {0, 0, 0, 0};
     const bool inter = ns > 1;
@@ -494,8 +622,12 @@ static int entropy_decode_impl(const unsigned char* data, size_t n, short* coef,
     }
     int done = 0;
     bool seen[4] = {false, false, false, false};
-    while (done < j.nc) {
-        if ((size_t)pos + 4 > n || data[pos] != 0xFF) return IMCUI_ERR_ARG;
+    // sequential: until every component has been coded; progressive: every scan up to EOI (each adds a band or a bit)
+    while (done < j.nc || j.progressive) {
+        if ((size_t)pos + 4 > n || data[pos] != 0xFF) {
+            if (j.progressive && (size_t)pos + 2 <= n && data[pos] == 0xFF && data[pos + 1] == 0xD9 && done == j.nc) break;
+            return IMCUI_ERR_ARG;
+        }
         const int m = data[pos + 1];
         if (m == 0xDA) {
             const int SL = be16(data + pos + 2);
@@ -512,6 +644,7 @@ static int entropy_decode_impl(const unsigned char* data, size_t n, short* coef,
             if (nx < 0) return (int)nx;
             pos = nx;
         } else if (m == 0xD9) {
+            if (j.progressive && done == j.nc) break;  // the last scan is in
             return IMCUI_ERR_ARG;  // EOI before every component was coded
         } else {
             // tables between scans (DHT / DQT / DRI): parse the one segment

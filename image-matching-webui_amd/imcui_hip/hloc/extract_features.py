@@ -98,7 +98,7 @@ def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> to
     decode = "auto": a baseline JPEG goes through the library's decoder -- Huffman on the host, inverse DCT / up-sampling / colour on the
     device, bit-exact against libjpeg's default path (utils/jpeg.py); with `grayscale` the result is the file's luma plane, which is
     what the reference's `cv2.imread(IMREAD_GRAYSCALE)` returns for a JPEG.  A PNG (8-bit, not interlaced: every PNG of the reference repository)
-    is inflated on the host and un-filtered on the device (utils/png.py), bit-exact.  Files neither path takes (progressive or CMYK JPEG,
+    is inflated on the host and un-filtered on the device (utils/png.py), bit-exact.  Files neither path takes (arithmetic-coded or CMYK JPEG,
     interlaced or 16-bit PNG, other formats) are read on the host (`read_image_u8`) and uploaded.  "host": always the host reader; "device": refuse
     instead of falling back."""
     if decode not in ("auto", "host", "device"):

@@ -8,7 +8,7 @@ cv2 / PIL run).  gray=True returns the luma plane of the file, which is what `cv
 
 An EXIF orientation is applied on the device after the reconstruction (`imcui_hip_orient_u8`), as cv2.imread does inside its decoder.
 
-Files the device path does not take (progressive, CMYK, 4:4:0, non-JPEG) raise
+Files the device path does not take (arithmetic-coded, CMYK, 4:4:0, non-JPEG; progressive Huffman files ARE taken since round 5) raise
 `JpegUnsupported`; the drivers keep the host reader for those.
 """
 from __future__ import annotations

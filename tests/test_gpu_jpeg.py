@@ -57,7 +57,8 @@ def test_batch_of_640x480_files_twice_bitwise_and_refusals(tmp_path):
     from imcui_hip.hloc.utils.jpeg import JpegDecoder, JpegUnsupported
 
     blobs = [encode(smooth_image(100 + i, 480, 640), quality=70 + i % 25, subsampling=("4:2:0", "4:2:2", "4:4:4")[i % 3]) for i in range(32)]
-    prog = encode(smooth_image(1, 40, 40), quality=80, progressive=True)
+    # (progressive Huffman files decode on the device since round 5; a frame announced as arithmetic-coded stands for the refused kind)
+    prog = encode(smooth_image(1, 40, 40), quality=80, progressive=True).replace(b"\xff\xc2", b"\xff\xca", 1)
     dec = JpegDecoder(DEV, threads=8)
     a = dec.decode_batch(blobs + [prog], True)
     b = dec.decode_batch(blobs + [prog], True)
@@ -65,17 +66,41 @@ def test_batch_of_640x480_files_twice_bitwise_and_refusals(tmp_path):
     assert isinstance(a[-1], JpegUnsupported) and isinstance(b[-1], JpegUnsupported)
     for i, (x, y) in enumerate(zip(a[:-1], b[:-1])):
         assert torch.equal(x, y) and np.array_equal(x.cpu().numpy(), pil_decode(blobs[i], True))
-    # the drivers' reader: baseline JPEG on the device, a progressive one and a PNG through the host reader
+    # the drivers' reader: JPEG (baseline and progressive) and PNG on the device, a CMYK JPEG through the host reader
     (tmp_path / "a.jpg").write_bytes(blobs[0])
-    (tmp_path / "p.jpg").write_bytes(prog)
     from PIL import Image
 
+    cmyk = io.BytesIO()
+    Image.fromarray(smooth_image(2, 40, 40)).convert("CMYK").save(cmyk, "JPEG")
+    (tmp_path / "p.jpg").write_bytes(cmyk.getvalue())
     Image.fromarray(smooth_image(9, 30, 50)).save(tmp_path / "c.png")
     assert np.array_equal(read_image_device(tmp_path / "a.jpg", True, DEV).cpu().numpy(), pil_decode(blobs[0], True))
     assert read_image_device(tmp_path / "p.jpg", False, DEV).shape == (40, 40, 3)
     assert read_image_device(tmp_path / "c.png", False, DEV).shape == (30, 50, 3)
     with pytest.raises(JpegUnsupported):
         read_image_device(tmp_path / "p.jpg", True, DEV, decode="device")
+
+
+@pytest.mark.parametrize("w,h,sub,q,rst", [(64, 64, "4:2:0", 80, 0), (123, 77, "4:2:2", 75, 0), (200, 150, "4:2:0", 60, 3), (640, 480, "4:2:0", 90, 0), (641, 479, "4:4:4", 92, 5)])
+def test_device_decode_of_progressive_files_equals_pil(w, h, sub, q, rst):
+    """Progressive Huffman files (SOF2, libjpeg's standard ten-scan script with spectral selection and successive approximation; round 5): the host
+    stage accumulates the scans into the coefficient planes of the equivalent sequential file, the device reconstruction is the same -- bit-exact
+    against PIL, RGB and gray, alone and in a batch next to baseline files."""
+    from imcui_hip.hloc.utils.jpeg import JpegDecoder, decode_jpeg
+
+    kw = dict(quality=q, subsampling=sub, progressive=True)
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    data = encode(smooth_image(w + 3 * h, h, w), **kw)
+    assert b"\xff\xc2" in data[:1200]
+    for gray in (False, True):
+        assert np.array_equal(decode_jpeg(data, gray, DEV).cpu().numpy(), pil_decode(data, gray)), gray
+    base = encode(smooth_image(w + 3 * h, h, w), quality=q, subsampling=sub)
+    dec = JpegDecoder(DEV, threads=4)
+    outs = dec.decode_batch([base, data, base, data], False)
+    dec.close()
+    for b, o in zip([base, data, base, data], outs):
+        assert np.array_equal(o.cpu().numpy(), pil_decode(b, False))
 
 
 def test_extract_features_from_jpeg_files_equals_the_plugin_on_pil_gray(tmp_path):

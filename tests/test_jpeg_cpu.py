@@ -117,7 +117,9 @@ def test_unsupported_and_damaged_files_are_refused():
     lib = load_library()
     info = (C.c_int * 24)()
     prog = encode(smooth_image(1, 40, 40), quality=80, progressive=True)
-    assert lib.imcui_hip_jpeg_info(prog, len(prog), info) == -4  # IMCUI_HIP_ERR_UNSUPPORTED: the caller keeps its host decoder
+    assert lib.imcui_hip_jpeg_info(prog, len(prog), info) == 0  # progressive Huffman files are taken since round 5 (test below)
+    arith = prog.replace(b"\xff\xc2", b"\xff\xca", 1)  # the same frame header announced as arithmetic-coded progressive
+    assert lib.imcui_hip_jpeg_info(arith, len(arith), info) == -4  # IMCUI_HIP_ERR_UNSUPPORTED: the caller keeps its host decoder
     cmyk = io.BytesIO()
     Image.fromarray(smooth_image(2, 24, 24)).convert("CMYK").save(cmyk, "JPEG")
     assert lib.imcui_hip_jpeg_info(cmyk.getvalue(), len(cmyk.getvalue()), info) == -4
@@ -160,7 +162,7 @@ def test_batch_entropy_decoder_equals_the_single_file_one():
     one pinned buffer) writes the same coefficients and tables as the single-file entry point; a refused file does not stop the others."""
     lib = load_library()
     blobs = [encode(smooth_image(i, 48 + 8 * (i % 3), 64 + 16 * (i % 2)), quality=70 + i, subsampling=("4:2:0", "4:2:2", "4:4:4")[i % 3]) for i in range(12)]
-    blobs += [encode(smooth_image(77, 40, 40, 1), quality=80), encode(smooth_image(1, 40, 40), quality=80, progressive=True)]
+    blobs += [encode(smooth_image(77, 40, 40, 1), quality=80), encode(smooth_image(1, 40, 40), quality=80, progressive=True).replace(b"\xff\xc2", b"\xff\xca", 1)]
     n = len(blobs)
     infos = []
     for b in blobs[:-1]:
@@ -177,7 +179,7 @@ def test_batch_entropy_decoder_equals_the_single_file_one():
     qt = np.zeros(n * 192, np.uint16)
     status = (C.c_int * n)()
     assert lib.imcui_hip_jpeg_entropy_decode_batch((C.c_char_p * n)(*blobs), (C.c_size_t * n)(*[len(b) for b in blobs]), n, planes, qt.ctypes.data, status, 4) == 0
-    assert status[n - 1] == -4  # the progressive file
+    assert status[n - 1] == -4  # the file announced as arithmetic-coded: refused before anything is written
     for i, b in enumerate(blobs[:-1]):
         _, coef, q = c_entropy(b)
         got = np.concatenate([bufs[i][0]] + ([bufs[i][1], bufs[i][2]] if cnt[i][1] else []))
@@ -332,3 +334,62 @@ def test_rgb_stored_jpegs_are_left_to_the_host_reader():
     data = bytes(b)
     assert lib.imcui_hip_jpeg_info(data, len(data), info) == -4
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)))[..., 0], np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[..., 0])  # (PIL agrees it is RGB: it opens)
+
+
+@pytest.mark.parametrize("w,h,sub,q,rst,opt", [(64, 64, "4:2:0", 80, 0, False), (57, 43, "4:2:0", 90, 0, False), (123, 77, "4:2:2", 75, 0, True), (40, 56, "4:4:4", 95, 0, False),
+                                               (200, 150, "4:2:0", 60, 3, False), (33, 47, "4:2:2", 85, 2, True), (16, 16, "4:4:4", 50, 0, False), (641, 479, "4:2:0", 90, 0, True)])
+def test_progressive_files_equal_pil(w, h, sub, q, rst, opt):
+    """Round 5 (missing 4): progressive Huffman files (SOF2) -- spectral selection, successive approximation, end-of-band runs,
+    DC / AC refinement scans, restart intervals, optimised tables -- decode to the coefficients of the equivalent sequential file: the restated
+    reconstruction of them equals PIL bit for bit, RGB and gray.  (PIL writes libjpeg's standard 10-scan script.)"""
+    kw = dict(quality=q, subsampling=sub, progressive=True, optimize=opt)
+    if rst:
+        kw["restart_marker_blocks"] = rst
+    data = encode(smooth_image(w + h, h, w), **kw)
+    assert b"\xff\xc2" in data[:1200]
+    info, coef, qt = c_entropy(data)
+    for gray in (False, True):
+        assert np.array_equal(oracle_from_coefficients(info, coef, qt, gray), pil_decode(data, gray)), gray
+    gdata = encode(smooth_image(5, h, w, 1), quality=q, progressive=True)
+    info, coef, qt = c_entropy(gdata)
+    assert np.array_equal(oracle_from_coefficients(info, coef, qt, True), pil_decode(gdata, True))
+
+
+def test_mutated_progressive_files_never_overrun_or_crash():
+    lib = load_library()
+    rng = np.random.default_rng(1)
+    seeds = [encode(smooth_image(31, 40, 56), quality=80, subsampling="4:2:0", progressive=True), encode(smooth_image(32, 33, 47), quality=60, subsampling="4:2:2", progressive=True,
+             restart_marker_blocks=2), encode(smooth_image(33, 24, 24, 1), quality=90, progressive=True)]  # fmt: skip
+    decoded = refused = 0
+    for it in range(1500):
+        b = bytearray(seeds[it % 3])
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rng.integers(1, 6)):
+                b[rng.integers(2, len(b))] = rng.integers(0, 256)
+        elif mode == 1:
+            b = b[: rng.integers(4, len(b))]
+        elif mode == 2:
+            i = rng.integers(2, len(b) - 4)
+            b[i : i + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+        else:
+            i = rng.integers(2, len(b) - 10)
+            del b[i : i + rng.integers(1, 10)]
+        data = bytes(b)
+        info = (C.c_int * 24)()
+        if lib.imcui_hip_jpeg_info(data, len(data), info) != 0:
+            refused += 1
+            continue
+        n = lib.imcui_hip_jpeg_coef_count(info)
+        if n > 50_000_000:
+            refused += 1
+            continue
+        coef = np.zeros(n + 64, np.int16)
+        coef[n:] = 12345
+        qt = np.zeros(192, np.uint16)
+        rc = lib.imcui_hip_jpeg_entropy_decode(data, len(data), coef.ctypes.data, qt.ctypes.data)
+        assert (coef[n:] == 12345).all(), "the decoder wrote past its buffer"
+        assert rc in (0, -1, -4)
+        decoded += rc == 0
+        refused += rc != 0
+    assert decoded > 100 and refused > 200, (decoded, refused)
