@@ -355,7 +355,8 @@ int imcui_hip_dust3r_forward_sizes(imcui_hip_t* h, int enc_dim, int enc_depth, i
  * info [host, 24 ints]: 0 width, 1 height, 2 components (1 | 3), 3 hmax, 4 vmax, 5 MCUs per row, 6 MCU rows, 7 restart interval,
  * 8 EXIF orientation (1 = upright or absent; 2..8: imcui_hip_orient_u8 after the reconstruction), 9 + 4c .. 11 + 4c: h, v, quantisation
  * table of component c.  Supported: SOF0 / SOF1 Huffman, 8 bit, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals,
- * interleaved or per-component scans; everything else (progressive, arithmetic, CMYK, 12 bit, 4:4:0) returns IMCUI_HIP_ERR_UNSUPPORTED. */
+ * interleaved or per-component scans, and -- round 5 -- progressive Huffman frames (SOF2: every scan up to EOI is accumulated into the same
+ * coefficient planes); everything else (arithmetic coding, CMYK, 12 bit, 4:4:0) returns IMCUI_HIP_ERR_UNSUPPORTED. */
 int imcui_hip_jpeg_info(const unsigned char* data, size_t n, int* info);
 /* number of int16 coefficients of all components (every component padded to whole MCUs) */
 size_t imcui_hip_jpeg_coef_count(const int* info);
