@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const float* __restrict__
     int i1 = 0x7fffffff;
     for (int s = 0; s < nslots; ++s) {
         const size_t o = ((size_t)b * nslots + s) * n_out + i;
-        const float ob1 = pb1[o], ob2 = pb2[o];
+        const float ob1 = pb1[o], ob2 = pb2 ? pb2[o] : -INFINITY;  // (no second best without a ratio test: SR_NN1)
         const int oi1 = pi1[o];
         if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) {
             b2 = fmaxf(b1, ob2);
@@ -169,6 +169,8 @@ static int nn_forward(imcui_hip_t* h, const float* desc0, long ldr0, long ldk0, 
                       int D, double ratio_threshold, double distance_threshold, int do_mutual_check, int* matches0, float* scores0, void* ws, size_t ws_bytes,
                       hipStream_t stream) {
     const bool persistent = nn_persistent(h, D);
+    // a single neighbour cannot pass a ratio test (nearest_neighbor.py:50-51)
+    const int use_ratio = (ratio_threshold > 0.0) && N > 1 && M > 1;
     const bool fused = h->precision == 1 || persistent;
     NnWs w = nn_carve(ws, ws_bytes, B, N, M, fused, persistent ? D : 0);
     if (!ws || !w.ok) return imcui_set_err(h, IMCUI_ERR_WS, "mutual_nn: workspace too small (%zu < %zu)", ws_bytes, w.total);
@@ -185,7 +187,7 @@ static int nn_forward(imcui_hip_t* h, const float* desc0, long ldr0, long ldk0, 
         simred_pack(h, desc0, ldr0, ldk0, bs0, N, D, B, nullptr, 0, w.pk0, stream);
         simred_pack(h, desc1, ldr1, ldk1, bs1, M, D, B, nullptr, 0, w.pk1, stream);
         SimRedP p;
-        p.mode = SR_NN;
+        p.mode = use_ratio ? SR_NN : SR_NN1;  // the second best is only read by the ratio test
         p.Ap = w.pk0, p.Bp = w.pk1;
         p.ap_bs = (long)simred_packed_uint4(N, D), p.bp_bs = (long)simred_packed_uint4(M, D);
         p.M = N, p.N = M, p.K = D, p.batch = B;
@@ -220,15 +222,13 @@ static int nn_forward(imcui_hip_t* h, const float* desc0, long ldr0, long ldk0, 
         const int rc = gemm_launch(h, g, stream);
         if (rc != IMCUI_OK) return rc;
     }
-    // a single neighbour cannot pass a ratio test (nearest_neighbor.py:50-51)
-    const int use_ratio = (ratio_threshold > 0.0) && N > 1 && M > 1;
     const int use_dist = distance_threshold > 0.0;
     // thresholds are squared in double (Python floats) before meeting the fp32 tensors
     const float r2 = (float)(ratio_threshold * ratio_threshold), d2 = (float)(distance_threshold * distance_threshold);
     if (fused) {
-        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.rb1, w.ri1, w.rb2, nslot_r, N, r2, d2, use_ratio, use_dist, w.m0,
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(N, 256), B), dim3(256), 0, stream, w.rb1, w.ri1, use_ratio || !persistent ? w.rb2 : nullptr, nslot_r, N, r2, d2, use_ratio, use_dist, w.m0,
                            scores0);
-        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, w.cb1, w.ci1, w.cb2, nslot_c, M, r2, d2, use_ratio, use_dist, w.m1,
+        hipLaunchKernelGGL(nn_merge_kernel, dim3(cdiv(M, 256), B), dim3(256), 0, stream, w.cb1, w.ci1, use_ratio || !persistent ? w.cb2 : nullptr, nslot_c, M, r2, d2, use_ratio, use_dist, w.m1,
                            (float*)nullptr);
     } else {
         hipLaunchKernelGGL(nn_find_kernel, dim3(cdiv(N, 4), B), dim3(256), 0, stream, w.sim, N, M, 0, r2, d2, use_ratio, use_dist,

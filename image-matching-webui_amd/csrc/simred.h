@@ -13,6 +13,7 @@ enum SimRedMode {
     SR_LSE = 1,     // per row / per column: max and sum exp(x - max)            (pass 1 of every soft-max based matcher)
     SR_DSBEST = 2,  // conf = softmax_col(x) * softmax_row(x): per row best (value, first column), per column best value   (pass 2, LoFTR family)
     SR_LGBEST = 3,  // LightGlue's log assignment: per row best (value, first column), per column best (value, first row)   (pass 2)
+    SR_NN1 = 4,     // SR_NN without the second best (find_nn without a ratio test): r1 / c1 are not written
 };
 
 #define SR_TILE 128  // rows per workgroup block and columns per tile
@@ -28,7 +29,7 @@ struct SimRedP {
     const int* mcnt = nullptr;           // rows of batch b = mcnt[b * cnt_stride] (device), nullptr: M
     const int* ncnt = nullptr;
     int cnt_stride = 0;
-    float alpha = 1.0f;
+    float alpha = 1.0f;  // > 0; the nearest-neighbour modes take 1
     int nchunk = 1;  // column chunks per row block (fills the chip when batch * M / 128 is small); row outputs have one slot per chunk
     // row outputs, slot (b, chunk): value arrays [batch][nchunk][r_pitch]
     float* r0 = nullptr;  // NN: best      LSE: max   BEST: best value
@@ -46,7 +47,7 @@ struct SimRedP {
     long l0_bs = 0, l1_bs = 0;
     // SR_DSBEST: [batch][ceil(M / 128)][ceil(N / 128)] tile flags (0 = no entry of the tile can exceed the threshold: skipped), or nullptr
     const unsigned char* flags = nullptr;
-    int dbg = 0;  // lab switch (IMCUI_SR_DBG, read once): bit 0 = skip the per-column part of the epilogue, bit 1 = skip the per-row part (WRONG results: timing only)
+    int dbg = 0;  // lab switch (IMCUI_SR_DBG, read once): bit 0 = skip the per-column part of the epilogue, bit 1 = skip the per-row part (both: WRONG results, timing only), bit 2 = the two column halves half a tile apart (results unchanged; slower: simred.hip)
 };
 
 // pack `rows` x K floats (element (r, k) of batch b at X[b * xbs + r * ldr + k * ldk]) into the fragment order above.

@@ -84,6 +84,8 @@ void simred_pack(imcui_hip_s* h, const float* X, long ldr, long ldk, long xbs, i
 template <int KS, int WN, int MODE, bool F32>
 __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     constexpr int NTH = 256 * WN, NW = 4 * WN, NF = 4 / WN, KT = KS / 2, PPW = 16 / NW;
+    constexpr bool ISNN = MODE == SR_NN || MODE == SR_NN1;  // SR_NN1: no second best (find_nn without a ratio test)
+    constexpr bool PREMASK = ISNN || MODE == SR_LSE;       // columns past the matrix are set to -inf in the accumulators, before the epilogue
     static_assert(WN == 2, "the column scan maps 512 threads onto 128 columns x 4 row groups");
     static_assert(KT >= 2, "at least two stages per tile");
     extern __shared__ uint4 sr_smem[];
@@ -187,14 +189,15 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     static_assert((1 << LKT) == KT, "KS is 4, 8 or 16");
 
     f32x16 acc[NF];
+    f32x16 zero16;
 #pragma unroll
-    for (int n = 0; n < NF; ++n)
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    for (int n = 0; n < NF; ++n) acc[n] = zero16;
 
     // ---- per-row running state (lane = row wm * 32 + lo, its columns 4 hi .. of every 8)
     const int rowl = wm * 32 + lo, rowg = rb * SR_TILE + rowl;
-    float q0 = -INFINITY, q1 = (MODE == SR_NN) ? -INFINITY : 0.0f;  // NN: best, second; LSE: max, sum; BEST: best value
+    float q0 = -INFINITY, q1 = ISNN ? -INFINITY : 0.0f;  // NN: best, second; LSE: max, sum; BEST: best value
     int qi = 0x7fffffff;
     if (MODE == SR_DSBEST) q0 = -1.0f;
     float rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;  // pass 2: row constants
@@ -211,16 +214,32 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     wait_dma(S >= 3 ? 2 : S >= 2 ? 1 : 0);
     __syncthreads();
 
+    // ---- lab switch (IMCUI_SR_DBG bit 2; OFF by default, a measured negative result): the two column halves HALF A TILE APART.  A tile is KT
+    // matrix intervals + two reducing intervals (per row + parking | per column), each closed by a workgroup barrier.  In step, the two
+    // waves of a SIMD (same wm, wn = 0 / 1) both multiply, then both reduce, and the matrix pipe idles through every epilogue.  Nothing in
+    // the loop couples the halves except the barriers (a wave's DMA pieces are the fragments of its own half, the parked tile is scanned
+    // by the half that parked it, the column constants are per half), so the wn = 1 waves can simply enter the loop `lag` barriers later
+    // and the wn = 0 waves pass `lag` barriers after it: while one wave of a SIMD reduces, the other multiplies.  Measured (MI355X, round
+    // 5): K = 128 nearest neighbours 1.68 -> 1.79 ms, LightGlue's assignment pass 0.56 -> 0.67 ms, the K = 256 statistics pass 7.21 ->
+    // 7.00 ms.  The loop is not bound by issue slots but by the LDS pipe (every B fragment is read by the four row waves: 64 KB per stage
+    // = 512 of a stage's 768 matrix cycles, + 128 KB per parked tile) and by the barriers; apart, every barrier waits for the slower of a
+    // matrix and a reducing interval and the two kinds of LDS traffic collide.
+    const int lag = (p.dbg & 4) ? (KT + 2) / 2 : 0;
+    if (__builtin_amdgcn_readfirstlane(wn) == 1)
+        for (int g = 0; g < lag; ++g) __builtin_amdgcn_s_barrier();
+
     for (int ti = 0; ti < ntl; ++ti) {
         const int ct = tile_at(ti);
         if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
             // column constants of the tile (read in the epilogue, >= 1 barrier from here; the previous tile's readers are past its last barrier)
-            if (tid < SR_TILE) {
-                const int j = min(ct * SR_TILE + tid, Nb - 1);
+            // (each column half loads -- and later reads -- its own 64 entries: the halves are not at the same tile, see `lag`)
+            if ((tid & 255) < SR_TILE / 2) {
+                const int jl = wn * (SR_TILE / 2) + (tid & 255);
+                const int j = min(ct * SR_TILE + jl, Nb - 1);
                 const size_t co = (size_t)b * p.c_pitch + j;
-                ctab[tid] = p.cmax[co];
-                ctab[SR_TILE + tid] = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.csum[co]) : p.csum[co];
-                if (MODE == SR_LGBEST) ctab[2 * SR_TILE + tid] = p.l1[(size_t)b * p.l1_bs + j];
+                ctab[jl] = p.cmax[co];
+                ctab[SR_TILE + jl] = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.csum[co]) : p.csum[co];
+                if (MODE == SR_LGBEST) ctab[2 * SR_TILE + jl] = p.l1[(size_t)b * p.l1_bs + j];
             }
         }
 #pragma unroll
@@ -242,8 +261,9 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 if constexpr (!F32) {
                     // pieces = f16 hi / lo planes; per accumulator: b_hi a_lo, b_lo a_hi, b_hi a_hi (gemm_split_kernel's order), the NF
                     // accumulators interleaved so consecutive matrix instructions are independent
+                    // (the first product of a tile takes a constant-zero C operand: the accumulators are never cleared by vector moves)
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a1[ks], acc[n]);
+                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a1[ks], ks == 0 ? zero16 : acc[n]);
 #pragma unroll
                     for (int n = 0; n < NF; ++n) acc[n] = mfma16(b1[n], a0[ks], acc[n]);
 #pragma unroll
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                         for (int n = 0; n < NF; ++n) {
                             const float4 fb = __builtin_bit_cast(float4, j < 4 ? b0[n] : b1[n]);
                             const float bv4[4] = {fb.x, fb.y, fb.z, fb.w};
-                            acc[n] = mfma32(bv4[j & 3], av[j], acc[n]);
+                            acc[n] = mfma32(bv4[j & 3], av[j], (ks == 0 && j == 0) ? zero16 : acc[n]);
                         }
                 }
             }
@@ -266,6 +286,8 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 // stage s + 1 of THIS wave has landed (two younger stages may still be in flight); the barrier makes it everybody's
                 wait_dma(s + 3 < S ? 2 : s + 2 < S ? 1 : 0);
                 __syncthreads();
+            } else if (lag) {
+                __builtin_amdgcn_s_barrier();  // (closes the last matrix interval: the reducing intervals line up with the other half's matrix intervals)
             }
         }
 
@@ -284,6 +306,16 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         // second copy of the masking part and as a second copy of the whole epilogue -- and both made hipcc spill: the accumulators are
         // rewritten in place and two variants of that meeting in one control-flow join keep both register sets alive)
         const int jlim = Nb - jb;  // column c of the lane's list is live when c < jlim
+        if constexpr (PREMASK) {
+            // only the last column tile of a matrix has dead columns: they are set to -inf IN PLACE, in a block of its own, so the common
+            // tile pays neither the compare nor the select per element (a second copy of the epilogue for it made hipcc spill: see above)
+            if (__builtin_amdgcn_readfirstlane(Nb - ct * SR_TILE) < SR_TILE) {
+#pragma unroll
+                for (int n = 0; n < NF; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][r] = (n * 32 + 8 * (r >> 2) + (r & 3) < jlim) ? acc[n][r] : -INFINITY;
+            }
+        }
         if (!(p.dbg & 2))
 #pragma unroll
         for (int n = 0; n < NF; ++n)
@@ -304,14 +336,16 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * q + e;
                     const bool valid = n * 32 + 8 * q + e < jlim;
-                    const float x = acc[n][r] * p.alpha;
-                    if constexpr (MODE == SR_NN) {
-                        const float xv = valid ? x : -INFINITY;
-                        q1 = __builtin_amdgcn_fmed3f(q0, q1, xv);  // second best of {best, second, x} (second <= best)
-                        q0 = fmaxf(q0, xv);
-                        acc[n][r] = xv;
+                    const float x = PREMASK ? 0.0f : acc[n][r] * p.alpha;
+                    (void)valid, (void)x;
+                    if constexpr (ISNN) {
+                        // (alpha is 1 for the nearest-neighbour modes: simred_launch refuses anything else; dead columns are -inf already)
+                        if constexpr (MODE == SR_NN) {
+                            q1 = __builtin_amdgcn_fmed3f(q0, q1, acc[n][r]);  // second best of {best, second, x} (second <= best)
+                            q0 = fmaxf(q0, acc[n][r]);
+                        }
                     } else if constexpr (MODE == SR_LSE) {
-                        const float xv = valid ? x : -INFINITY;
+                        const float xv = acc[n][r] * p.alpha;  // (alpha > 0: a dead column stays -inf)
                         tmax = fmaxf(tmax, xv);
                         acc[n][r] = xv;
                     } else if constexpr (MODE == SR_DSBEST) {
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 // every element live together) and the kernel spills
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if constexpr (MODE == SR_NN) {
+        if constexpr (ISNN) {
             // (q0 is the row's best including this tile: if it moved, its first column in the tile is found by equality, walking downwards)
             float tm = acc[0][0];
 #pragma unroll
@@ -341,6 +375,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
 #pragma unroll
                 for (int r = 15; r >= 0; --r) tc = (acc[n][r] == tm) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
             qi = tm > q0old ? jb + tc : qi;
+            if (MODE == SR_NN1) q0 = fmaxf(q0old, tm);
         }
         if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
             // the row's best of this tile is a maximum tree over the finished values; its FIRST column is found by equality, walking the
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 const int j = ct * SR_TILE + jl;
                 const size_t o = ((size_t)b * nrb + rb) * p.c_pitch + j;
                 const int rbase = rb * SR_TILE + 16 * part;
-                if constexpr (MODE == SR_NN || MODE == SR_LGBEST) {
+                if constexpr (ISNN || MODE == SR_LGBEST) {
                     // first row attaining the maximum: equality, walking downwards (the last hit is the lowest row)
                     int ti = 0x7fffffff - rbase;
 #pragma unroll
@@ -429,6 +464,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                         (void)ctrl;
                         const bool up = om > tm || (om == tm && oi < ti);
                         if (MODE == SR_NN) b2 = up ? fmaxf(tm, o2) : fmaxf(b2, om);
+                        (void)o2;
                         ti = up ? oi : ti;
                         tm = up ? om : tm;
                     }
@@ -468,10 +504,6 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 }
             }
         }
-#pragma unroll
-        for (int n = 0; n < NF; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
         {
             const int s = ti * KT + KT - 1;
             wait_dma(s + 3 < S ? 2 : s + 2 < S ? 1 : 0);
@@ -479,11 +511,15 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         __syncthreads();
     }
 
+    if (__builtin_amdgcn_readfirstlane(wn) == 0)
+        for (int g = 0; g < lag; ++g) __builtin_amdgcn_s_barrier();
+    __syncthreads();  // (both halves out of the loop: the parked tiles are dead, `park` carries the row exchange below)
+
     // ================================================================ rows: fold the two half-waves (columns 4 hi), then the column halves
     {
         const float o0 = __shfl_xor(q0, 32, 64), o1 = __shfl_xor(q1, 32, 64);
         const int oi = __shfl_xor(qi, 32, 64);
-        if constexpr (MODE == SR_NN) {
+        if constexpr (ISNN) {
             const bool up = o0 > q0 || (o0 == q0 && oi < qi);  // interleaved column sets: lowest index on equal values
             q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
             qi = up ? oi : qi;
@@ -510,7 +546,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         if (wn == 0 && hi == 0) {
             const float o0 = xr[rowl * 4 + 0], o1 = xr[rowl * 4 + 1];
             const int oi = reinterpret_cast<int*>(xr)[rowl * 4 + 2];
-            if constexpr (MODE == SR_NN) {
+            if constexpr (ISNN) {
                 const bool up = o0 > q0 || (o0 == q0 && oi < qi);
                 q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
                 qi = up ? oi : qi;
@@ -578,6 +614,7 @@ template <bool F32>
 static int sr_launch_m(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
     switch (p.mode) {
         case SR_NN: return sr_launch_k<SR_NN, F32>(h, p, stream);
+        case SR_NN1: return sr_launch_k<SR_NN1, F32>(h, p, stream);
         case SR_LSE: return sr_launch_k<SR_LSE, F32>(h, p, stream);
         case SR_DSBEST: return sr_launch_k<SR_DSBEST, F32>(h, p, stream);
         case SR_LGBEST: return sr_launch_k<SR_LGBEST, F32>(h, p, stream);
@@ -593,6 +630,8 @@ int simred_launch(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
     if ((nct + p.nchunk - 1) / p.nchunk > SR_MAXLIST) return imcui_set_err(h, IMCUI_ERR_ARG, "simred: more than %d column tiles per chunk", SR_MAXLIST);
     if ((p.mode == SR_DSBEST || p.mode == SR_LGBEST) && (!p.rmax || !p.rsum || !p.cmax || !p.csum || (p.mode == SR_LGBEST && (!p.l0 || !p.l1))))
         return imcui_set_err(h, IMCUI_ERR_ARG, "simred: pass 2 needs the statistics of pass 1");
+    if ((p.mode == SR_NN || p.mode == SR_NN1) && p.alpha != 1.0f) return imcui_set_err(h, IMCUI_ERR_ARG, "simred: the nearest-neighbour modes take alpha = 1");
+    if (!(p.alpha > 0.0f)) return imcui_set_err(h, IMCUI_ERR_ARG, "simred: alpha must be positive");
     static const int dbg = getenv("IMCUI_SR_DBG") ? atoi(getenv("IMCUI_SR_DBG")) : 0;  // (lab switch, read once per process)
     SimRedP q = p;
     q.dbg = dbg;

@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-NN, LSE, DSBEST, LGBEST = 0, 1, 2, 3
+NN, LSE, DSBEST, LGBEST, NN1 = 0, 1, 2, 3, 4
 BIG = 0x7FFFFFFF
 
 
@@ -111,6 +111,25 @@ def test_nearest_neighbours(precision, K, B, M, N):
             first = (s2 == best[:, None]).double().argmax(1)
             s2.scatter_(1, first[:, None], -np.inf)
             assert (s2.max(1).values - top2.values[..., 1]).abs().max() < 2e-5, name
+
+
+@pytest.mark.parametrize("K", [64, 128, 256])
+@pytest.mark.parametrize("B,M,N", SHAPES)
+def test_nearest_neighbours_without_second_best(precision, K, B, M, N):
+    """SR_NN1 (find_nn without a ratio test) = SR_NN's best values and first indices, bit for bit; the second-best slots stay untouched."""
+    a, b = problem(5 * K + M + N, B, M, N, K)
+    a[:, ::7] = a[:, :1].clone()  # ties between rows (and so between columns' candidates): the FIRST index must win in both modes
+    nchunk = min(2, (N + 127) // 128)
+    full, _ = run(NN, a.to(DEV), b.to(DEV), nchunk=nchunk)
+    one, _ = run(NN1, a.to(DEV), b.to(DEV), nchunk=nchunk)
+    nct = (N + 127) // 128
+    tpc = (nct + nchunk - 1) // nchunk
+    live = [c for c in range(nchunk) if c * tpc < nct]
+    for key in ("r0", "ri"):
+        assert torch.equal(full[key][:, live], one[key][:, live]), key
+    for key in ("c0", "ci"):
+        assert torch.equal(full[key], one[key]), key
+    assert torch.isnan(one["r1"]).all() and torch.isnan(one["c1"]).all()
 
 
 def _dual_softmax_conf(ref):
