@@ -155,6 +155,7 @@ enum {
     OPT_CONV_TALL,         // IMCUI_CONV_TALL: 0 = 8-row conv tiles everywhere, 1 (default) = 16-row tiles for SuperPoint's fused first layer, 2 = also for plain 64-channel layers
     OPT_CONV_NARROW,       // IMCUI_CONV_NARROW: 1 = 64-output-channel tiles also where 128 fit (A/B)
     OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
+    OPT_FFN_TILE,          // IMCUI_FFN_TILE: tokens per workgroup of the fused FFN: 0 (default) = by token count (128 / 64 / 32: the largest that fills the CUs), or 128 / 64 / 32 (bitwise equal results)
     OPT_NCNT
 };
 

@@ -21,6 +21,13 @@
 //   store    through LDS so that every global store / residual load is a full 1 KB row.
 //
 // Occupancy: one workgroup of 512 threads per CU (2 waves per SIMD, 256 VGPRs each), 136 KB of LDS.
+//
+// Token tile (round 5): MT = 4 token fragments = 128 tokens per workgroup is the throughput geometry (every weight fragment a wave pulls
+// from L2 feeds 12 matrix instructions).  With few tokens it leaves the chip empty -- ONE pair of 2048 key-points is 32 workgroups on 256
+// CUs, and a workgroup's 128-token pass is 57 us whatever the grid: a third of the one-pair step.  MT = 2 / 1 (64 / 32 tokens per
+// workgroup, same thread roles, same LDS addresses with the unused token blocks left empty) spread the same tokens over 2 x / 4 x the
+// CUs; ffn_launch picks the largest tile that still gives every CU a workgroup.  A token's arithmetic does not depend on the tile it
+// rides in: the three geometries are bitwise equal.
 #include "ffn.h"
 
 #include <stdlib.h>
@@ -32,14 +39,15 @@
 
 __device__ __forceinline__ float ffn_gelu(float y) { return gelu_poly(y); }  // common.h
 
-template <int VAR, int ACT>
+template <int VAR, int ACT, int MT>
 __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
+    constexpr int TOK = 32 * MT;  // tokens per workgroup
     extern __shared__ uint4 ffn_smem[];
     char* sm = reinterpret_cast<char*>(ffn_smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * 128;
+    const int row0 = blockIdx.x * TOK;
     if (row0 >= p.M) return;
     if (p.rows_per_seq > 0) {
         const int seq = row0 / p.rows_per_seq;
@@ -51,17 +59,18 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     if (p.dbg != nullptr && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = (long long)wall_clock64();
     FFN_STAMP(0)
     // ================================================================== GEMM 1: H^T[512][128] = W1 * [x | ctx]^T
-    f32x16 acc[2][4];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
 
     // staging: thread -> k-octet g (8 consecutive k of the 32-wide tile) of token srow
     const int srow = tid >> 2, g = tid & 3;
-    const int grow = min(row0 + srow, p.M - 1);
+    const bool stager = MT == 4 || srow < TOK;  // (a smaller tile is staged by the first 4 * TOK threads)
+    const int grow = min(row0 + min(srow, TOK - 1), p.M - 1);
     const float* px = p.x + (size_t)grow * 256 + g * 8;
     const float* pc = p.ctx + (size_t)grow * 256 + g * 8;
     // granule of fragment (ks = g >> 1, token block srow >> 5): half g & 1, position (srow & 31) ^ 2g (gemm.hip's swizzle)
@@ -71,14 +80,18 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     f32x4 a0, a1;
     auto issue = [&](int kt) __attribute__((always_inline)) {
         const float* q = kt < 8 ? px + kt * 32 : pc + (kt - 8) * 32;
-        a0 = *reinterpret_cast<const f32x4*>(q);
-        a1 = *reinterpret_cast<const f32x4*>(q + 4);
+        if (stager) {
+            a0 = *reinterpret_cast<const f32x4*>(q);
+            a1 = *reinterpret_cast<const f32x4*>(q + 4);
+        }
     };
     auto store = [&](int stg) __attribute__((always_inline)) {
         uint4 h, l;
-        split8(__builtin_bit_cast(float4, a0), __builtin_bit_cast(float4, a1), h, l);
-        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo) = h;
-        *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo) = l;
+        if (stager) {
+            split8(__builtin_bit_cast(float4, a0), __builtin_bit_cast(float4, a1), h, l);
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo) = h;
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo) = l;
+        }
     };
     uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step
     auto loadw = [&](int s, uint4(&w)[2][2]) __attribute__((always_inline)) {
@@ -90,9 +103,9 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     };
     auto kstep = [&](int stg, int ks, uint4(&w)[2][2]) __attribute__((always_inline)) {
         const int apos = (hi * 32 + (lo ^ (2 * (2 * ks + hi)))) * 16;
-        uint4 ah[4], al[4];
+        uint4 ah[MT], al[MT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const int fo = stg * 16384 + (ks * 4 + m) * 1024 + apos;
             ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
             al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 acc[n][m] = mfma16(w[n][0], al[m], acc[n][m]);
                 acc[n][m] = mfma16(w[n][1], ah[m], acc[n][m]);
                 acc[n][m] = mfma16(w[n][0], ah[m], acc[n][m]);
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
         for (int q = 0; q < 4; ++q) {
             const float4 b4 = p.b1 ? *reinterpret_cast<const float4*>(p.b1 + 64 * wid + 32 * n + 8 * q + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 acc[n][m][4 * q + 0] = acc[n][m][4 * q + 0] * s1 + b4.x;
                 acc[n][m][4 * q + 1] = acc[n][m][4 * q + 1] * s1 + b4.y;
                 acc[n][m][4 * q + 2] = acc[n][m][4 * q + 2] * s1 + b4.z;
@@ -177,9 +190,9 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             }
         }
     if constexpr (ACT == 0) {
-    float mean[4], rstd[4];
+    float mean[MT], rstd[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         float s = 0.0f;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -190,14 +203,14 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s += stat[w * 128 + 32 * m + lo];
         mean[m] = s * (1.0f / 512.0f);
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         float s = 0.0f;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         float s = 0.0f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) s += stat2[w * 128 + 32 * m + lo];
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + f0);
             const float4 e4 = *reinterpret_cast<const float4*>(p.beta + f0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 acc[n][m][4 * q + 0] = ffn_gelu(acc[n][m][4 * q + 0] * rstd[m] * g4.x + e4.x);
                 acc[n][m][4 * q + 1] = ffn_gelu(acc[n][m][4 * q + 1] * rstd[m] * g4.y + e4.y);
                 acc[n][m][4 * q + 2] = ffn_gelu(acc[n][m][4 * q + 2] * rstd[m] * g4.z + e4.z);
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[n][m][r];
@@ -259,14 +272,14 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     // register-tight LayerNorm / GELU section above
     asm volatile("" : "+v"(lane2), "+v"(wid2));
     const int lo2 = lane2 & 31, hi2 = lane2 >> 5;
-    f32x16 acc2[4];
+    f32x16 acc2[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[m][r] = 0.0f;
     const uint4* w2h = reinterpret_cast<const uint4*>(p.w2h) + ((size_t)wid2 * 32) * 64 + lane2;
     const uint4* w2l = reinterpret_cast<const uint4*>(p.w2l) + ((size_t)wid2 * 32) * 64 + lane2;
-    float4 res[16];  // residual rows in the order of the final row-major store, requested before the last MFMA loop
+    float4 res[4 * MT];  // residual rows in the order of the final row-major store, requested before the last MFMA loop
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
         if (ph == 1) {
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 const float4 v0 = make_float4(acc[ph][m][8 * ks + 0], acc[ph][m][8 * ks + 1], acc[ph][m][8 * ks + 2], acc[ph][m][8 * ks + 3]);
                 const float4 v1 = make_float4(acc[ph][m][8 * ks + 4], acc[ph][m][8 * ks + 5], acc[ph][m][8 * ks + 6], acc[ph][m][8 * ks + 7]);
                 uint4 h, l;
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             // the hidden accumulators are dead: 64 registers take the residual rows (whole 1 KB rows per wave) while
             // the MFMAs run, so the store phase has no load latency in it
 #pragma unroll
-            for (int pass = 0; pass < 16; ++pass)
+            for (int pass = 0; pass < 4 * MT; ++pass)
                 res[pass] = *reinterpret_cast<const float4*>(p.x + (size_t)min(row0 + pass * 8 + wid2, p.M - 1) * 256 + lane2 * 4);
         }
         uint4 wq[2][2];  // [k-step parity][plane], two k-steps ahead
@@ -311,15 +324,15 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
                     wq[u][0] = w2h[(size_t)gk * 64];
                     wq[u][1] = w2l[(size_t)gk * 64];
                 }
-                uint4 gh[4], gl[4];
+                uint4 gh[MT], gl[MT];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     const int off = (kk >> 1) * 16384 + lane2 * 16 + ((u * 4 + m) * 2) * 1024;
                     gh[m] = *reinterpret_cast<const uint4*>(sm + off);
                     gl[m] = *reinterpret_cast<const uint4*>(sm + off + 1024);
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     acc2[m] = mfma16(wh, gl[m], acc2[m]);
                     acc2[m] = mfma16(wl, gh[m], acc2[m]);
                     acc2[m] = mfma16(wh, gh[m], acc2[m]);
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
         const int f0 = 32 * wid2 + 8 * q + 4 * hi2;
         const float4 b4 = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             float4 v;
             v.x = acc2[m][4 * q + 0] * s2 + b4.x;
             v.y = acc2[m][4 * q + 1] * s2 + b4.y;
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
+    for (int pass = 0; pass < 4 * MT; ++pass) {
         const int row = pass * 8 + wid2;
         const int gr = row0 + row;
         if (gr < p.M) {  // wave-uniform: a wave owns the whole row
@@ -380,10 +393,17 @@ int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
     if (p.M <= 0) return IMCUI_OK;
     static const int variant = getenv("IMCUI_FFN_VARIANT") ? atoi(getenv("IMCUI_FFN_VARIANT")) : 1;
     typedef void (*kern_t)(FfnP);
-    static const kern_t kerns[2][4] = {{lg_ffn_kernel<0, 0>, lg_ffn_kernel<0, 1>, lg_ffn_kernel<0, 2>, lg_ffn_kernel<0, 3>},
-                                       {lg_ffn_kernel<1, 0>, lg_ffn_kernel<1, 1>, lg_ffn_kernel<1, 2>, lg_ffn_kernel<1, 3>}};
-    static bool attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};  // > 64 KB of dynamic LDS needs the opt-in
-    const int v = variant != 0, a = p.act;
+    // [token tile: 128 (rolled loop), 128, 64, 32][act]
+    static const kern_t kerns[4][4] = {{lg_ffn_kernel<0, 0, 4>, lg_ffn_kernel<0, 1, 4>, lg_ffn_kernel<0, 2, 4>, lg_ffn_kernel<0, 3, 4>},
+                                       {lg_ffn_kernel<1, 0, 4>, lg_ffn_kernel<1, 1, 4>, lg_ffn_kernel<1, 2, 4>, lg_ffn_kernel<1, 3, 4>},
+                                       {lg_ffn_kernel<1, 0, 2>, lg_ffn_kernel<1, 1, 2>, lg_ffn_kernel<1, 2, 2>, lg_ffn_kernel<1, 3, 2>},
+                                       {lg_ffn_kernel<1, 0, 1>, lg_ffn_kernel<1, 1, 1>, lg_ffn_kernel<1, 2, 1>, lg_ffn_kernel<1, 3, 1>}};
+    static bool attr_set[4][4] = {};  // > 64 KB of dynamic LDS needs the opt-in
+    // token tile: the largest of 128 / 64 / 32 that still gives each of the 256 CUs a workgroup (option ffn_tile forces one)
+    int tok = h->opt[OPT_FFN_TILE];
+    if (tok != 128 && tok != 64 && tok != 32) tok = p.M > 256 * 64 ? 128 : p.M > 256 * 32 ? 64 : 32;
+    if (p.dbg) tok = 128;  // (the lab's stamp buffer has a slot per 128 tokens)
+    const int v = tok == 128 ? (variant != 0) : tok == 64 ? 2 : 3, a = p.act;
     if (!attr_set[v][a]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v][a]), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
             return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
@@ -394,7 +414,7 @@ int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
         imcui_range_check(h, p.ctx, p.M, 256, 256, p.cnt, p.rows_per_seq, stream);
     }
     imcui_prof_begin(h, PROF_GEMM, stream);
-    hipLaunchKernelGGL(kerns[v][a], dim3((p.M + 127) / 128), dim3(512), FFN_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kerns[v][a], dim3((p.M + tok - 1) / tok), dim3(512), FFN_LDS_BYTES, stream, p);
     imcui_prof_end(h, PROF_GEMM, stream);
     IMCUI_CHECK_LAUNCH(h);
     return IMCUI_OK;

@@ -317,6 +317,37 @@ def test_fused_ffn_relu_mode_vs_fp64():
     assert (out.double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
 
 
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+@pytest.mark.parametrize("M", [37, 2400, 4096])
+def test_fused_ffn_token_tiles_are_bitwise_equal(act, M):
+    """The fused FFN's 128 / 64 / 32-token workgroup tiles (option `ffn_tile`; picked by token count otherwise, so that a single pair
+    still fills the CUs) run the same arithmetic per token: bitwise equal outputs, for every activation mode and a ragged last tile."""
+    from imcui_hip import backend
+
+    backend.set_precision(_dev(), 1)
+    g = torch.Generator().manual_seed(act * 1000 + M)
+    x = torch.randn(M, 256, generator=g)
+    ctx = torch.randn(M, 256, generator=g) * 0.8
+    w1 = torch.randn(512, 512, generator=g) / 512 ** 0.5
+    w2 = torch.randn(256, 512, generator=g) / 512 ** 0.5
+    b1, b2 = torch.randn(512, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    nf = 512 if act == 0 else 256
+    gamma, beta = 1.0 + 0.3 * torch.randn(nf, generator=g), 0.2 * torch.randn(nf, generator=g)
+    if act == 1:
+        ffn = backend.FusedFFN(w1, b1, None, None, w2, b2, _dev())
+    elif act == 0:
+        ffn = backend.FusedFFN(w1, b1, gamma, beta, w2, b2, _dev())
+    else:
+        ffn = backend.FusedFFN(w1, torch.zeros(512), gamma, beta, w2, torch.zeros(256), _dev(), act=act)
+    outs = {}
+    for tile in (128, 64, 32, 0):
+        with backend.option(_dev(), ffn_tile=tile):
+            outs[tile] = ffn(x.to(_dev()), ctx.to(_dev())).cpu()
+    assert torch.isfinite(outs[128]).all()
+    for tile in (64, 32, 0):
+        assert torch.equal(outs[tile], outs[128]), tile
+
+
 @pytest.mark.parametrize("act,M", [(2, 4800), (3, 2400), (3, 16384)])
 def test_fused_ffn_post_layernorm_modes_vs_fp64(act, M):
     """act 2 / 3: x + LayerNorm(fc2(act(fc1([x | message])))) -- the coarse MLPs of EfficientLoFTR (LeakyReLU) and LoFTR
