@@ -24,7 +24,7 @@ int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...) {
 // an older layout is rejected instead of running with its LayerNorm affine parts dropped); imcui_hip_set_option / _get_option.
 extern "C" int imcui_hip_version(void) { return 400; }
 
-static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "conv_tall", "conv_narrow", "simred", "ffn_tile"};
+static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "conv_tall", "conv_narrow", "simred", "ffn_tile", "wreg_tile"};
 static int opt_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_NCNT; ++i)
@@ -64,6 +64,7 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         h->opt[OPT_ATTN_VARIANT] = (e = getenv("IMCUI_ATTN_VARIANT")) ? atoi(e) : 8;  // 8 = the arithmetic of 0 with the pipelined K.Q^T schedule (attention.hip)
         h->opt[OPT_SIMRED] = (e = getenv("IMCUI_SIMRED")) ? atoi(e) : 1;
         h->opt[OPT_FFN_TILE] = (e = getenv("IMCUI_FFN_TILE")) ? atoi(e) : 0;
+        h->opt[OPT_WREG_TILE] = (e = getenv("IMCUI_WREG_TILE")) ? atoi(e) : 0;
         h->opt[OPT_CONV_TALL] = (e = getenv("IMCUI_CONV_TALL")) ? atoi(e) : 1;
         h->opt[OPT_CONV_NARROW] = getenv("IMCUI_CONV_NARROW") != nullptr ? 1 : 0;
         h->opt[OPT_ATTN_SELF] = (e = getenv("IMCUI_ATTN_VARIANT_SELF")) ? atoi(e) : -1;

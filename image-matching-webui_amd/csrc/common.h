@@ -156,6 +156,7 @@ enum {
     OPT_CONV_NARROW,       // IMCUI_CONV_NARROW: 1 = 64-output-channel tiles also where 128 fit (A/B)
     OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
     OPT_FFN_TILE,          // IMCUI_FFN_TILE: tokens per workgroup of the fused FFN: 0 (default) = by token count (128 / 64 / 32: the largest that fills the CUs), or 128 / 64 / 32 (bitwise equal results)
+    OPT_WREG_TILE,         // IMCUI_WREG_TILE: the same for the weights-in-registers projection GEMM (LightGlue's q / k / v, cross and plain-bias launches)
     OPT_NCNT
 };
 

@@ -13,7 +13,7 @@ struct TileCtx {
 };
 
 // returns false when the workgroup has nothing to do
-__device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int bn = BN) {
+__device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int bn = BN, int bm = BM) {
     c.z = blockIdx.z;
     c.M = p.mcnt ? p.mcnt[c.z * p.cnt_stride] : p.M;
     c.N = p.ncnt ? p.ncnt[c.z * p.cnt_stride] : p.N;
@@ -31,7 +31,7 @@ __device__ __forceinline__ bool gemm_tile_setup(const GemmP& p, TileCtx& c, int 
         c.row0 = (g * p.group_rows + t % rows) * BM;
         c.col0 = (t / rows) * bn;
     } else {
-        c.row0 = (tile / ncol) * BM;
+        c.row0 = (tile / ncol) * bm;  // (only this branch takes a row tile other than BM: gemm_wreg's small-batch tiles)
         c.col0 = (tile % ncol) * bn;
     }
     if (c.row0 >= c.M || c.col0 >= c.N) return false;

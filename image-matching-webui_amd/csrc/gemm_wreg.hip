@@ -42,7 +42,10 @@ __device__ __forceinline__ void wr_wave_fence() {
 // PIPE: the K loop with the weight fragments requested TWO k-steps ahead in three rotating register sets (the schedule of the fused
 // FFN's first GEMM, ffn.hip VAR 1: vmcnt retires in order, so an activation tile gets exactly the lead of the weights requested after
 // it); unrolled over three K tiles so that the set of a k-step is static.  PIPE = false keeps the rolled loop, one k-step ahead.
-template <int EPI, bool SINGLE, bool PIPE = true>
+// MT: token fragments per workgroup (4 = 128 tokens, the throughput geometry; 2 / 1 = 64 / 32 tokens for launches with so few tokens
+// that 128-token tiles leave most CUs idle -- one LightGlue pair is 32 row tiles.  Same thread roles and LDS addresses, the unused token
+// blocks stay empty; a token's arithmetic does not depend on the tile it rides in: bitwise equal).
+template <int EPI, bool SINGLE, bool PIPE = true, int MT = 4>
 __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     __shared__ uint4 smem[(4 * WR_WAVE_LDS) / 16];  // main loop: two 16 KB activation stages; epilogue: 4 x 9 KB wave staging
     char* sm = reinterpret_cast<char*>(smem);
@@ -50,46 +53,55 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     const int lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     TileCtx c;
-    if (!gemm_tile_setup(p, c, WR_BN)) return;
+    if (!gemm_tile_setup(p, c, WR_BN, 32 * MT)) return;
     const float* A = p.A + (size_t)c.z * p.a_bs;
     const float wsc = p.wscale ? p.wscale[c.wsel] : 1.0f;
     const int nkt = p.K >> 5, nks = p.K >> 4;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.0f;
 
     // ---- activation staging: thread -> k-octet g (8 consecutive k of the 32-wide tile) of rows tid >> 2 and + 64
     const int g = tid & 3;
     const int rl0 = tid >> 2, rl1 = 64 + (tid >> 2);
+    const bool st0 = MT >= 2 || rl0 < 32, st1 = MT == 4;  // which of its two rows a thread stages
     const int wo0 = (((g >> 1) * 4 + (rl0 >> 5)) * 64 + (g & 1) * 32 + ((rl0 & 31) ^ (2 * g))) * 16;
     const int wo1 = (((g >> 1) * 4 + (rl1 >> 5)) * 64 + (g & 1) * 32 + ((rl1 & 31) ^ (2 * g))) * 16;
-    const float* pa0 = A + (size_t)min(c.row0 + rl0, c.M - 1) * p.lda + g * 8;
-    const float* pa1 = A + (size_t)min(c.row0 + rl1, c.M - 1) * p.lda + g * 8;
+    const float* pa0 = A + (size_t)min(c.row0 + (st0 ? rl0 : 0), c.M - 1) * p.lda + g * 8;
+    const float* pa1 = A + (size_t)min(c.row0 + (st1 ? rl1 : 0), c.M - 1) * p.lda + g * 8;
     f32x4 xa0, xb0, xa1, xb1;
     auto issue = [&](int kt) __attribute__((always_inline)) {
-        xa0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32);
-        xb0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32 + 4);
-        xa1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32);
-        xb1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32 + 4);
+        if (st0) {
+            xa0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32);
+            xb0 = *reinterpret_cast<const f32x4*>(pa0 + kt * 32 + 4);
+        }
+        if (st1) {
+            xa1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32);
+            xb1 = *reinterpret_cast<const f32x4*>(pa1 + kt * 32 + 4);
+        }
     };
     auto store = [&](int stg) __attribute__((always_inline)) {
         uint4 h, l;
         if constexpr (SINGLE) {  // one product: the nearest f16 of either operand (common.h)
-            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = half8_rtn(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0));
-            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = half8_rtn(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1));
+            if (st0) *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = half8_rtn(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0));
+            if (st1) *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = half8_rtn(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1));
             return;
         }
-        split8(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0), h, l);
-        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = h;
-        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo0) = l;
-        split8(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1), h, l);
-        *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = h;
-        if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo1) = l;
+        if (st0) {
+            split8(__builtin_bit_cast(float4, xa0), __builtin_bit_cast(float4, xb0), h, l);
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo0) = h;
+            if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo0) = l;
+        }
+        if (st1) {
+            split8(__builtin_bit_cast(float4, xa1), __builtin_bit_cast(float4, xb1), h, l);
+            *reinterpret_cast<uint4*>(sm + stg * 16384 + wo1) = h;
+            if constexpr (!SINGLE) *reinterpret_cast<uint4*>(sm + stg * 16384 + 8192 + wo1) = l;
+        }
     };
     // ---- weights: fragments (nf, ks) of the planes [ceil(N/32)][K/16][64 lanes][8 halves] at ((nf * nks) + ks) * 64 + lane.
     // Buffer loads: two wave-uniform descriptors (hi / lo plane of the selected weight set), one 32-bit lane offset per feature
@@ -123,10 +135,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         // two halves of two token fragments each: 16 instead of 32 fragment registers live (the pipelined loop needs them for
         // its third weight set)
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
-            uint4 ah[2], al[2];
+        for (int mh = 0; mh < (MT + 1) / 2; ++mh) {
+            constexpr int MH = MT >= 2 ? 2 : 1;  // token fragments per half
+            uint4 ah[MH], al[MH];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MH; ++m) {
                 const int fo = stg * 16384 + (ks * 4 + 2 * mh + m) * 1024 + apos;
                 ah[m] = *reinterpret_cast<const uint4*>(sm + fo);
                 if constexpr (!SINGLE) al[m] = *reinterpret_cast<const uint4*>(sm + fo + 8192);
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MH; ++m) {
                     // weight fragment = MFMA A operand (rows = features), activations = B (columns = tokens)
                     if constexpr (!SINGLE) {
                         acc[n][2 * mh + m] = mfma16(w[n][0], al[m], acc[n][2 * mh + m]);
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                 }
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 float4 tc[4][2], ts[4][2];
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {  // tables of this step's tokens, requested before the tile is parked
@@ -335,10 +348,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
             };
             if (rope) load_tables(0, tc[0], ts[0]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 park_rows(m);
                 wr_wave_fence();
-                if (rope && m + 1 < 4) load_tables(m + 1, tc[(m + 1) & 1], ts[(m + 1) & 1]);
+                if (rope && m + 1 < MT) load_tables(m + 1, tc[(m + 1) & 1], ts[(m + 1) & 1]);
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int tl = pass * 8 + (lane >> 3);
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         } else {
             // V^T [seq][head][64][rows]: park [feature][32 tokens], read 8 consecutive tokens of one feature per lane
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -415,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lrs != nullptr) s4 = *reinterpret_cast<const float4*>(lrs + f0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             park_rows(m);
             wr_wave_fence();
 #pragma unroll
@@ -489,6 +502,22 @@ bool gemm_wreg_ok(const imcui_hip_s* h, const GemmP& p) {
     return p.epi == EPI_BIAS || p.epi == EPI_RELU || p.epi == EPI_RESID || p.epi == EPI_CONV;
 }
 
+// small-batch row tiles (LightGlue's attention-layout projections and plain-bias launches): the largest of 128 / 64 / 32 tokens that
+// still gives every CU a workgroup
+template <int EPI, int MT>
+static void wreg_launch_small(const GemmP& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gemm_wreg_kernel<EPI, false, true, MT>), dim3(cdiv(p.M, 32 * MT) * cdiv(p.N, WR_BN), 1, 1), dim3(256), 0, stream, p);
+}
+static int wreg_tile_tokens(const imcui_hip_s* h, const GemmP& p) {
+    if (p.epi != EPI_QKV && p.epi != EPI_CROSS && p.epi != EPI_BIAS) return 128;
+    if (p.single || p.group_rows > 1 || (h && h->opt[OPT_WREG_PIPE] == 0)) return 128;
+    const int forced = h ? h->opt[OPT_WREG_TILE] : 0;
+    if (forced == 128 || forced == 64 || forced == 32) return forced;
+    const long ncol = cdiv(p.N, WR_BN);
+    if ((long)cdiv(p.M, 128) * ncol >= 256) return 128;
+    if ((long)cdiv(p.M, 64) * ncol >= 256) return 64;
+    return 32;
+}
 template <bool PIPE>
 static void wreg_launch(const GemmP& p, hipStream_t stream) {
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, WR_BN), 1, 1);
@@ -507,6 +536,16 @@ static void wreg_launch(const GemmP& p, hipStream_t stream) {
     }
 }
 void gemm_wreg_launch(const imcui_hip_s* h, const GemmP& p, hipStream_t stream) {
+    const int tok = wreg_tile_tokens(h, p);
+    if (tok != 128) {
+        if (p.epi == EPI_QKV)
+            tok == 64 ? wreg_launch_small<EPI_QKV, 2>(p, stream) : wreg_launch_small<EPI_QKV, 1>(p, stream);
+        else if (p.epi == EPI_CROSS)
+            tok == 64 ? wreg_launch_small<EPI_CROSS, 2>(p, stream) : wreg_launch_small<EPI_CROSS, 1>(p, stream);
+        else
+            tok == 64 ? wreg_launch_small<EPI_BIAS, 2>(p, stream) : wreg_launch_small<EPI_BIAS, 1>(p, stream);
+        return;
+    }
     if (h && h->opt[OPT_WREG_PIPE] == 0)  // A/B switch: 0 = the rolled K loop
         wreg_launch<false>(p, stream);
     else

@@ -58,7 +58,9 @@ int imcui_hip_version(void);
  * "attn_mix_layers", default 0x1ff.  Round 5 default: cross 7 -- the two-product P.V in the CROSS blocks only, audited per block: layer error <= 7.1e-6 and
  * score error <= 4.7e-5 at N = M = 2048 on three weight sets, half the parity bar; -1 restores three products everywhere), "simred"
  * 1 | 0 (default 1: the mutual-NN matcher on the persistent similarity-and-reduce kernel; 0: the round-4 tile GEMM with the reducing
- * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256).  Unknown name: IMCUI_HIP_ERR_ARG. */
+ * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256), "ffn_tile" 0 | 128 | 64 | 32 (tokens per workgroup of the
+ * fused FFN; default 0 = by token count, the largest tile that still gives every CU a workgroup; bitwise equal results), "conv_tall"
+ * 0 | 1 | 2 and "conv_narrow" 0 | 1 (convolution tile shapes).  Unknown name: IMCUI_HIP_ERR_ARG. */
 int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value);
 int imcui_hip_get_option(imcui_hip_t* h, const char* name, int* value);
 
@@ -444,7 +446,8 @@ int imcui_hip_png_reconstruct_batch(imcui_hip_t* h, const unsigned char* raw, co
  * [dev, batch] live rows / columns per batch or NULL.  mode 0: nearest neighbours (best, first index, second best); 1: soft-max statistics
  * (max, sum exp); 2: dual-softmax confidence, row best + first column, column best (needs rmax / rsum / cmax / csum, optional tile flags
  * [batch][ceil(M/128)][ceil(N/128)]); 3: LightGlue's log assignment, row best + first column, column best + first row (rsum / csum = LOG
- * sums, l0 [batch,M], l1 [batch,N]).  Row outputs r0 / r1 / ri [batch][nchunk][M] (nchunk 0: imcui_hip_simred_chunks), column outputs
+ * sums, l0 [batch,M], l1 [batch,N]); 4: mode 0 without the second best (r1 / c1 untouched: find_nn without a ratio test).  alpha > 0, and 1
+ * for the nearest-neighbour modes.  Row outputs r0 / r1 / ri [batch][nchunk][M] (nchunk 0: imcui_hip_simred_chunks), column outputs
  * c0 / c1 / ci [batch][ceil(M/128)][N]. */
 int imcui_hip_simred_chunks(int batch, int M, int N);
 size_t imcui_hip_simred_debug_workspace_bytes(int batch, int M, int N, int K);

@@ -143,6 +143,52 @@ def test_attention_layout_projection_planes(cross):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
 
 
+@pytest.mark.parametrize("cross", [False, True])
+def test_projection_token_tiles_are_bitwise_equal(cross):
+    """The weights-in-registers projection GEMM picks 128 / 64 / 32-token workgroup tiles by token count (option `wreg_tile`; one
+    LightGlue pair no longer leaves two thirds of the CUs idle): every plane bitwise equal across the tiles, ragged counts included."""
+    backend.set_precision(dev, 1)
+    nseq, R = 6, 2048
+    g = torch.Generator().manual_seed(23 + cross)
+    x = torch.randn(nseq * R, 256, generator=g).to(dev)
+    N = 512 if cross else 768
+    w = torch.randn(N, 256, generator=g) / 16.0
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    ang = torch.rand(nseq * R, 32, generator=g) * 6.28
+    cos, sin = torch.cos(ang).to(dev), torch.sin(ang).to(dev)
+    cnt = torch.tensor([R, 1000, 0, 77, R, 1900], dtype=torch.int32).to(dev)
+    res = {}
+    for tile in (128, 64, 32, 0):
+        with backend.option(dev, gemm_wreg=2, wreg_tile=tile):
+            res[tile] = [t.clone() for t in backend.qkv_split_f32(x, w, b, cos, sin, cnt, R, 0.18, cross)]
+        torch.cuda.synchronize()
+    cn = cnt.cpu().tolist()
+    for tile in (64, 32, 0):
+        for i, (a, c) in enumerate(zip(res[128], res[tile])):
+            # a tile is skipped when its first row is past the sequence's count, so the written rows past the count depend on the tile: live rows only
+            if a.shape[-1] == 64:  # [2 planes, seq, head, R, 64]
+                for z, n in enumerate(cn):
+                    assert torch.equal(a[:, z, :, :n], c[:, z, :, :n]), (tile, i, z)
+            else:  # V^T [2 planes, seq, head, 64, R]
+                for z, n in enumerate(cn):
+                    assert torch.equal(a[:, z, :, :, :n], c[:, z, :, :, :n]), (tile, i, z)
+
+
+@pytest.mark.parametrize("M,N", [(300, 256), (4096, 768), (9000, 256)])
+def test_plain_projection_token_tiles_are_bitwise_equal(M, N):
+    backend.set_precision(dev, 1)
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, 256, generator=g).to(dev)
+    w = torch.randn(N, 256, generator=g) / 16.0
+    b = (torch.randn(N, generator=g) * 0.1).to(dev)
+    outs = {}
+    for tile in (128, 64, 32, 0):
+        with backend.option(dev, gemm_wreg=2, wreg_tile=tile):
+            outs[tile] = backend.linear_split_f32(a, w, b, False).cpu()
+    for tile in (64, 32, 0):
+        assert torch.equal(outs[tile], outs[128]), tile
+
+
 def test_attention_priority_variants_bitwise():
     from imcui_hip import backend
 
