@@ -66,7 +66,7 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         h->opt[OPT_FFN_TILE] = (e = getenv("IMCUI_FFN_TILE")) ? atoi(e) : 0;
         h->opt[OPT_WREG_TILE] = (e = getenv("IMCUI_WREG_TILE")) ? atoi(e) : 0;
         h->opt[OPT_CONV_TALL] = (e = getenv("IMCUI_CONV_TALL")) ? atoi(e) : 1;
-        h->opt[OPT_CONV_NARROW] = getenv("IMCUI_CONV_NARROW") != nullptr ? 1 : 0;
+        h->opt[OPT_CONV_NARROW] = (e = getenv("IMCUI_CONV_NARROW")) ? atoi(e) : 0;
         h->opt[OPT_ATTN_SELF] = (e = getenv("IMCUI_ATTN_VARIANT_SELF")) ? atoi(e) : -1;
         // Round 5: LightGlue's CROSS blocks run the audited two-product P.V (variant 7) by default -- layer error <= 7.1e-6 and score error <= 4.7e-5 on the
         // three weight sets at N = M = 2048 (half the parity bar; profiles/r05_lab_attention_mix.txt), + 2.7 % end to end; the self blocks keep three

@@ -153,7 +153,7 @@ enum {
     OPT_ATTN_CROSS,        // IMCUI_ATTN_VARIANT_CROSS: the same for the CROSS blocks; default 7 (two-product P.V: audited per block, tools/attn_mix_audit.py)
     OPT_ATTN_MIX_LAYERS,   // IMCUI_ATTN_MIX_LAYERS: bit l = layer l takes the two overrides above (default 0x1ff: all nine)
     OPT_CONV_TALL,         // IMCUI_CONV_TALL: 0 = 8-row conv tiles everywhere, 1 (default) = 16-row tiles for SuperPoint's fused first layer, 2 = also for plain 64-channel layers
-    OPT_CONV_NARROW,       // IMCUI_CONV_NARROW: 1 = 64-output-channel tiles also where 128 fit (A/B)
+    OPT_CONV_NARROW,       // IMCUI_CONV_NARROW: 0 (default) = 64-output-channel tiles where the 128-channel tiling gives fewer than 256 workgroups; 1 = wherever 128 fit too; 2 = never (A/B)
     OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
     OPT_FFN_TILE,          // IMCUI_FFN_TILE: tokens per workgroup of the fused FFN: 0 (default) = by token count (128 / 64 / 32: the largest that fills the CUs), or 128 / 64 / 32 (bitwise equal results)
     OPT_WREG_TILE,         // IMCUI_WREG_TILE: the same for the weights-in-registers projection GEMM (LightGlue's q / k / v, cross and plain-bias launches)

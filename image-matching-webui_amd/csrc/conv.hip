@@ -819,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tall_kernel(const float* __res
 // from an LDS image tile, gains 10 %.
 // (both switches live in the handle since round 5 -- imcui_hip_set_option "conv_tall" / "conv_narrow", environment read once by imcui_hip_create)
 static inline int conv_tall_mode(const imcui_hip_s* h) { return h->opt[OPT_CONV_TALL]; }
-static inline bool conv_narrow_env(const imcui_hip_s* h) { return h->opt[OPT_CONV_NARROW] != 0; }
+static inline bool conv_narrow_env(const imcui_hip_s* h) { return h->opt[OPT_CONV_NARROW] == 1; }
 
 int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* wh, const unsigned short* wl,
                          const float* wscale, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
@@ -839,7 +839,10 @@ int conv3x3_split_launch(imcui_hip_s* h, const float* in, const unsigned short* 
     if (pool && ((H | W) & 1)) return imcui_set_err(h, IMCUI_ERR_ARG, "conv3x3: pooled layer needs even H,W (%dx%d)", H, W);
     const int tiles_x = cdiv(W, STW);
     // 128 output channels per workgroup when the layer has them (fewer LDS fragment reads and barriers per MFMA)
-    const bool narrow_only = conv_narrow_env(h);  // A/B switch
+    bool narrow_only = conv_narrow_env(h);  // A/B switch
+    // few pixels (a single pair: 24 .. 75 tiles per image at 1/8 .. 1/4 resolution): 64-channel tiles double the workgroups while the
+    // 128-channel tiling leaves CUs empty (option conv_narrow: 0 = this rule, 1 = always, 2 = never; same arithmetic per output)
+    if (h->opt[OPT_CONV_NARROW] == 0 && !head && Cout % 128 == 0 && (long)tiles_x * cdiv(H, STH) * (Cout / 128) * B < 256) narrow_only = true;
     const bool wide = (Cout % 128 == 0) && !narrow_only;
     if (!wide && cout_live == Cout && conv_tall_mode(h) >= 2) {  // 64-channel layers: 16-row tiles (same LDS-read ratio as the wide kernel)
         const int tiles_t = cdiv(H, TTH);

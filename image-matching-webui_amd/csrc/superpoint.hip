@@ -386,14 +386,34 @@ __global__ __launch_bounds__(1024) void sp_topk_kernel(const unsigned long long*
             if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> (8 * byte)) & 0xFF)], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int kk = s_k, d = 255;
-            for (; d > 0; --d) {
-                if (hist[d] >= kk) break;
-                kk -= hist[d];
+        // the digit of the k-th key: walk the bins downwards until the running count reaches k.  One wave does it in parallel (lane l owns
+        // bins 255 - 4 l .. 252 - 4 l, inclusive scan over the lanes, the first lane that reaches k finishes inside its four bins); one
+        // thread walking 255 dependent LDS reads, eight times, was most of this kernel's 84 us
+        if (tid < 64) {
+            const int d0 = 255 - 4 * tid;
+            const int h0 = hist[d0], h1 = hist[d0 - 1], h2 = hist[d0 - 2], h3 = hist[d0 - 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int inc = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(inc, o, 64);
+                if (tid >= o) inc += up;
             }
-            s_prefix = prefix | ((unsigned long long)d << (8 * byte));
-            s_k = kk;
+            const int kk = s_k;
+            const unsigned long long reach = __ballot(inc >= kk);
+            const int L = reach ? __ffsll((long long)reach) - 1 : 63;  // (never empty: at least k keys carry the prefix; 63 = bin 0 all the same)
+            if (tid == L) {
+                int k2 = kk - (inc - mine), d;
+                if (h0 >= k2)
+                    d = d0;
+                else if (h0 + h1 >= k2)
+                    d = d0 - 1, k2 -= h0;
+                else if (h0 + h1 + h2 >= k2)
+                    d = d0 - 2, k2 -= h0 + h1;
+                else
+                    d = d0 - 3, k2 -= h0 + h1 + h2;  // (lane 63: bin 0 takes what is left, as the sequential walk did)
+                s_prefix = prefix | ((unsigned long long)d << (8 * byte));
+                s_k = k2;
+            }
         }
         __syncthreads();
     }
@@ -425,9 +445,19 @@ __global__ __launch_bounds__(1024) void sp_topk_kernel(const unsigned long long*
                     sel[hi2] = a;
                 }
             }
-            __syncthreads();
+            // pair i of a stage with stride <= 64 lies inside elements [128 w, 128 w + 127] of the wave w that handles it: such stages only
+            // need the wave's own LDS traffic to have landed.  A workgroup barrier is needed around the stages that cross waves
+            // (stride > 64): 10 of the 66 stages of a 2048-key sort
+            const int next = (stride > 1) ? (stride >> 1) : size;  // stride of the following stage
+            if (stride > 64 || next > 64) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
+    __syncthreads();
     for (int i = tid; i < k; i += 1024) {
         const unsigned long long key = sel[i];
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);

@@ -71,6 +71,24 @@ def test_conv3x3_f32(B, H, W, Cin, Cout, pool, precision):
     assert _rel(out, ref) < (2e-6 if precision == 0 else 4e-6)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [(2, 60, 80, 128, 128, False), (1, 120, 160, 64, 128, True), (2, 60, 80, 128, 256, False), (8, 120, 160, 128, 128, False)])
+def test_conv3x3_channel_tiles_are_bitwise_equal(B, H, W, Cin, Cout, pool):
+    """A launch whose 128-output-channel tiling gives fewer than 256 workgroups runs 64-channel tiles instead (a single pair's
+    SuperPoint layers at 1/4 and 1/8 resolution; option `conv_narrow`: 0 = that rule, 1 = always, 2 = never): same arithmetic per output."""
+    from imcui_hip import backend
+
+    backend.set_precision(_dev(), 1)
+    g = torch.Generator().manual_seed(H + W + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).to(_dev())
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    outs = {}
+    for mode in (2, 1, 0):
+        with backend.option(_dev(), conv_narrow=mode):
+            outs[mode] = backend.conv3x3_f32(x, w, b, relu=True, pool=pool).cpu()
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_f32(cross, precision):
     from imcui_hip import backend
