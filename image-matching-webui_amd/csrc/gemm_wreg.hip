@@ -502,14 +502,14 @@ bool gemm_wreg_ok(const imcui_hip_s* h, const GemmP& p) {
     return p.epi == EPI_BIAS || p.epi == EPI_RELU || p.epi == EPI_RESID || p.epi == EPI_CONV;
 }
 
-// small-batch row tiles (LightGlue's attention-layout projections and plain-bias launches): the largest of 128 / 64 / 32 tokens that
+// small-batch row tiles (LightGlue's attention-layout projections, plain-bias and activation-epilogue launches): the largest of 128 / 64 / 32 tokens that
 // still gives every CU a workgroup
 template <int EPI, int MT>
 static void wreg_launch_small(const GemmP& p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_wreg_kernel<EPI, false, true, MT>), dim3(cdiv(p.M, 32 * MT) * cdiv(p.N, WR_BN), 1, 1), dim3(256), 0, stream, p);
 }
 static int wreg_tile_tokens(const imcui_hip_s* h, const GemmP& p) {
-    if (p.epi != EPI_QKV && p.epi != EPI_CROSS && p.epi != EPI_BIAS) return 128;
+    if (p.epi != EPI_QKV && p.epi != EPI_CROSS && p.epi != EPI_BIAS && p.epi != EPI_CONV) return 128;
     if (p.single || p.group_rows > 1 || (h && h->opt[OPT_WREG_PIPE] == 0)) return 128;
     const int forced = h ? h->opt[OPT_WREG_TILE] : 0;
     if (forced == 128 || forced == 64 || forced == 32) return forced;
@@ -542,6 +542,8 @@ void gemm_wreg_launch(const imcui_hip_s* h, const GemmP& p, hipStream_t stream) 
             tok == 64 ? wreg_launch_small<EPI_QKV, 2>(p, stream) : wreg_launch_small<EPI_QKV, 1>(p, stream);
         else if (p.epi == EPI_CROSS)
             tok == 64 ? wreg_launch_small<EPI_CROSS, 2>(p, stream) : wreg_launch_small<EPI_CROSS, 1>(p, stream);
+        else if (p.epi == EPI_CONV)  // (EfficientLoFTR's projections on 300-token aggregated grids)
+            tok == 64 ? wreg_launch_small<EPI_CONV, 2>(p, stream) : wreg_launch_small<EPI_CONV, 1>(p, stream);
         else
             tok == 64 ? wreg_launch_small<EPI_BIAS, 2>(p, stream) : wreg_launch_small<EPI_BIAS, 1>(p, stream);
         return;

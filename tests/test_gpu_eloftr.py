@@ -119,6 +119,29 @@ def test_eloftr_1024(precision):
     print(f"ELoFTR 1024x1024: {n} matches")
 
 
+def test_eloftr_small_launch_tiles_are_bitwise_equal():
+    """The 64- / 32-token tiles that the projection GEMM (`wreg_tile`) and the fused MLP (`ffn_tile`) pick for launches with few tokens
+    (the aggregated 1/32 grids) run the same arithmetic per token: forcing 128-token tiles changes no output bit."""
+    from imcui_hip import backend
+    from imcui_hip.hloc.matchers.eloftr import ELoFTR
+
+    dev = torch.device("cuda:0")
+    pairs = [make_shifted_pair(31 + b, 160, 224, ((16, 8), (-8, 24))[b], n_blobs=300) for b in range(2)]
+    img0 = torch.cat([p[0] for p in pairs], 0).contiguous().cuda()
+    img1 = torch.cat([p[1] for p in pairs], 0).contiguous().cuda()
+    model = ELoFTR({"match_threshold": 0.2, "max_keypoints": None, "state_dict": SD}).eval().to(dev)
+    outs = []
+    for tile in (128, 0):
+        with backend.option(dev, wreg_tile=tile, ffn_tile=tile):
+            o = model.forward_batched(img0, img1)
+            torch.cuda.synchronize()
+            n = int(o["num_matches"][0])
+            outs.append({k: o[k][:n].cpu().clone() for k in ("keypoints0", "keypoints1", "confidence", "batch_indexes")})
+    assert len(outs[0]["confidence"]) > 50
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_eloftr_no_matches():
     """A threshold nothing passes: empty outputs, no fine stage work, no error."""
     from imcui_hip.hloc.matchers.eloftr import ELoFTR
