@@ -47,7 +47,7 @@ struct SimRedP {
     long l0_bs = 0, l1_bs = 0;
     // SR_DSBEST: [batch][ceil(M / 128)][ceil(N / 128)] tile flags (0 = no entry of the tile can exceed the threshold: skipped), or nullptr
     const unsigned char* flags = nullptr;
-    int dbg = 0;  // lab switch (IMCUI_SR_DBG, read once): bit 0 = skip the per-column part of the epilogue, bit 1 = skip the per-row part (both: WRONG results, timing only), bit 2 = the two column halves half a tile apart (results unchanged; slower: simred.hip)
+    int dbg = 0;  // lab switch (IMCUI_SR_DBG, read once): bit 0 = skip the per-column part of the epilogue, bit 1 = skip the per-row part (both: WRONG results, timing only), bit 2 = the two column halves half a tile apart (results unchanged; slower: simred.hip), bit 3 = 32-row wave tiles at every width (results unchanged; A/B of the 64-row tiles of K <= 128)
 };
 
 // pack `rows` x K floats (element (r, k) of batch b at X[b * xbs + r * ldr + k * ldk]) into the fragment order above.

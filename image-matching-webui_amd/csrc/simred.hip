@@ -79,14 +79,17 @@ void simred_pack(imcui_hip_s* h, const float* X, long ldr, long ldk, long xbs, i
 }
 
 // ------------------------------------------------------------------ the kernel
-// KS = K / 16.  WN = 1: 256 threads, wave w owns rows 32 w x all 128 columns of a tile (64 accumulators), two workgroups per CU;
-// WN = 2 (K = 256: 128 VGPRs of A fragments): 512 threads, wave (wm, wn) owns rows 32 wm x columns 64 wn .. 64 wn + 63, one per CU.
+// KS = K / 16.  512 threads = 8 waves, one workgroup per CU.  WN = column groups of waves:
+//   WN = 2: wave (wm < 4, wn < 2) owns rows 32 wm .. + 31 x columns 64 wn .. + 63 of a tile (1 x 2 accumulator fragments; every width);
+//   WN = 4 (K <= 128: the A fragments of 64 rows are 64 .. 128 VGPRs): wave (wm < 2, wn < 4) owns rows 64 wm .. + 63 x columns 32 wn ..
+//           + 31 (2 x 1 fragments): a streamed fragment is read from LDS by TWO waves instead of four -- half the LDS traffic per matrix
+//           instruction, which is what the loop waits for.
 template <int KS, int WN, int MODE, bool F32>
-__global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
-    constexpr int NTH = 256 * WN, NW = 4 * WN, NF = 4 / WN, KT = KS / 2, PPW = 16 / NW;
+__global__ __launch_bounds__(512, 2) void simred_kernel(SimRedP p) {
+    constexpr int NW = 8, NWM = NW / WN, RF = 4 / NWM, NF = 4 / WN, KT = KS / 2, PPW = 16 / NW;
     constexpr bool ISNN = MODE == SR_NN || MODE == SR_NN1;  // SR_NN1: no second best (find_nn without a ratio test)
     constexpr bool PREMASK = ISNN || MODE == SR_LSE;       // columns past the matrix are set to -inf in the accumulators, before the epilogue
-    static_assert(WN == 2, "the column scan maps 512 threads onto 128 columns x 4 row groups");
+    static_assert(WN == 2 || WN == 4, "column groups of waves");
     static_assert(KT >= 2, "at least two stages per tile");
     extern __shared__ uint4 sr_smem[];
     uint4* ring = sr_smem;                                                     // SR_NSLOT slots
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     __shared__ int s_ntl;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int wm = wid & 3, wn = wid >> 2;
+    const int wm = wid % NWM, wn = wid / NWM;
     const int nrb = (p.M + SR_TILE - 1) / SR_TILE, nct_s = (p.N + SR_TILE - 1) / SR_TILE;
     int t = xcd_remap(blockIdx.x, gridDim.x);
     const int rb = t % nrb;
@@ -132,14 +135,15 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     }
     auto tile_at = [&](int i) -> int { return listed ? (int)tlist[i] : ct0 + i; };
 
-    // ---- A fragments of the wave's 32 rows: registers, for the life of the workgroup
-    uint4 a0[KS], a1[KS];
-    {
-        const uint4* ap = p.Ap + (size_t)b * p.ap_bs + ((size_t)(rb * 4 + wm) * KS) * 128 + lane;
+    // ---- A fragments of the wave's 32 RF rows: registers, for the life of the workgroup
+    uint4 a0[RF][KS], a1[RF][KS];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        const uint4* ap = p.Ap + (size_t)b * p.ap_bs + ((size_t)(rb * 4 + wm * RF + f) * KS) * 128 + lane;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            a0[ks] = ap[ks * 128];
-            a1[ks] = ap[ks * 128 + 64];
+            a0[f][ks] = ap[ks * 128];
+            a1[f][ks] = ap[ks * 128 + 64];
         }
     }
     // ---- B stages: piece pc = wid * PPW + u of a stage = fragment pc >> 2, (k-step, piece) pc & 3.  Everything but the lane offset is
@@ -188,24 +192,33 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     constexpr int LKT = (KT == 2) ? 1 : (KT == 4) ? 2 : 3;  // log2(KT)
     static_assert((1 << LKT) == KT, "KS is 4, 8 or 16");
 
-    f32x16 acc[NF];
+    f32x16 acc[RF][NF];
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
 #pragma unroll
-    for (int n = 0; n < NF; ++n) acc[n] = zero16;
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[f][n] = zero16;
 
-    // ---- per-row running state (lane = row wm * 32 + lo, its columns 4 hi .. of every 8)
-    const int rowl = wm * 32 + lo, rowg = rb * SR_TILE + rowl;
-    float q0 = -INFINITY, q1 = ISNN ? -INFINITY : 0.0f;  // NN: best, second; LSE: max, sum; BEST: best value
-    int qi = 0x7fffffff;
-    if (MODE == SR_DSBEST) q0 = -1.0f;
-    float rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;  // pass 2: row constants
-    if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
-        const size_t ro = (size_t)b * p.r_pitch + min(rowg, Mb - 1);
-        rc0 = p.rmax[ro];
-        rc1 = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.rsum[ro]) : p.rsum[ro];
-        if (MODE == SR_LGBEST) rc2 = p.l0[(size_t)b * p.l0_bs + min(rowg, Mb - 1)];
+    // ---- per-row running state (lane = rows (wm RF + f) * 32 + lo, their columns 4 hi .. of every 8)
+    const int rowl0 = wm * RF * 32 + lo, rowg0 = rb * SR_TILE + rowl0;  // fragment f: + 32 f
+    float q0[RF], q1[RF];  // NN: best, second; LSE: max, sum; BEST: best value
+    int qi[RF];
+    float rc0[RF], rc1[RF], rc2[RF];  // pass 2: row constants
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        q0[f] = (MODE == SR_DSBEST) ? -1.0f : -INFINITY;
+        q1[f] = ISNN ? -INFINITY : 0.0f;
+        qi[f] = 0x7fffffff;
+        rc0[f] = rc1[f] = rc2[f] = 0.0f;
+        if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
+            const int rg = min(rowg0 + 32 * f, Mb - 1);
+            const size_t ro = (size_t)b * p.r_pitch + rg;
+            rc0[f] = p.rmax[ro];
+            rc1[f] = (MODE == SR_DSBEST) ? __builtin_amdgcn_rcpf(p.rsum[ro]) : p.rsum[ro];
+            if (MODE == SR_LGBEST) rc2[f] = p.l0[(size_t)b * p.l0_bs + rg];
+        }
     }
 
     const int S = ntl * KT;
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
     // 7.00 ms.  The loop is not bound by issue slots but by the LDS pipe (every B fragment is read by the four row waves: 64 KB per stage
     // = 512 of a stage's 768 matrix cycles, + 128 KB per parked tile) and by the barriers; apart, every barrier waits for the slower of a
     // matrix and a reducing interval and the two kinds of LDS traffic collide.
-    const int lag = (p.dbg & 4) ? (KT + 2) / 2 : 0;
+    const int lag = (WN == 2 && (p.dbg & 4)) ? (KT + 2) / 2 : 0;
     if (__builtin_amdgcn_readfirstlane(wn) == 1)
         for (int g = 0; g < lag; ++g) __builtin_amdgcn_s_barrier();
 
@@ -233,8 +246,8 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
             // column constants of the tile (read in the epilogue, >= 1 barrier from here; the previous tile's readers are past its last barrier)
             // (each column half loads -- and later reads -- its own 64 entries: the halves are not at the same tile, see `lag`)
-            if ((tid & 255) < SR_TILE / 2) {
-                const int jl = wn * (SR_TILE / 2) + (tid & 255);
+            if (wm * 64 + lane < NF * 32) {  // (the first threads of every column group: its own NF * 32 entries)
+                const int jl = wn * (NF * 32) + wm * 64 + lane;
                 const int j = min(ct * SR_TILE + jl, Nb - 1);
                 const size_t co = (size_t)b * p.c_pitch + j;
                 ctab[jl] = p.cmax[co];
@@ -263,22 +276,31 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                     // accumulators interleaved so consecutive matrix instructions are independent
                     // (the first product of a tile takes a constant-zero C operand: the accumulators are never cleared by vector moves)
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a1[ks], ks == 0 ? zero16 : acc[n]);
+                    for (int f = 0; f < RF; ++f)
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b1[n], a0[ks], acc[n]);
+                        for (int n = 0; n < NF; ++n) acc[f][n] = mfma16(b0[n], a1[f][ks], ks == 0 ? zero16 : acc[f][n]);
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) acc[n] = mfma16(b0[n], a0[ks], acc[n]);
+                    for (int f = 0; f < RF; ++f)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) acc[f][n] = mfma16(b1[n], a0[f][ks], acc[f][n]);
+#pragma unroll
+                    for (int f = 0; f < RF; ++f)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) acc[f][n] = mfma16(b0[n], a0[f][ks], acc[f][n]);
                 } else {
                     // pieces = the lane's two k-quads; step j pairs k = 16 ks + j (lanes hi = 0) with k = 16 ks + 8 + j (hi = 1)
-                    const float4 fa0 = __builtin_bit_cast(float4, a0[ks]), fa1 = __builtin_bit_cast(float4, a1[ks]);
-                    const float av[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
 #pragma unroll
-                        for (int n = 0; n < NF; ++n) {
-                            const float4 fb = __builtin_bit_cast(float4, j < 4 ? b0[n] : b1[n]);
-                            const float bv4[4] = {fb.x, fb.y, fb.z, fb.w};
-                            acc[n] = mfma32(bv4[j & 3], av[j], (ks == 0 && j == 0) ? zero16 : acc[n]);
+                        for (int f = 0; f < RF; ++f) {
+                            const float4 fa = __builtin_bit_cast(float4, j < 4 ? a0[f][ks] : a1[f][ks]);
+                            const float av4[4] = {fa.x, fa.y, fa.z, fa.w};
+#pragma unroll
+                            for (int n = 0; n < NF; ++n) {
+                                const float4 fb = __builtin_bit_cast(float4, j < 4 ? b0[n] : b1[n]);
+                                const float bv4[4] = {fb.x, fb.y, fb.z, fb.w};
+                                acc[f][n] = mfma32(bv4[j & 3], av4[j & 3], (ks == 0 && j == 0) ? zero16 : acc[f][n]);
+                            }
                         }
                 }
             }
@@ -296,12 +318,9 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         // dozen instructions) instead of being hoisted out of the tile loop and carried -- 60 VGPRs of it -- across the MFMA loop.
         int etid = tid;
         asm volatile("" : "+v"(etid));
-        const int elo = etid & 31, ehi = (etid >> 5) & 1, erowl = ((etid >> 6) & 3) * 32 + elo;
-        // (1) per row, from the accumulators: lane = row rowl, columns jb + 32 n + 8 q + e; the value to park replaces the accumulator
+        const int elo = etid & 31, ehi = (etid >> 5) & 1, erowl0 = (((etid >> 6) % NWM) * RF) * 32 + elo;  // row of fragment f: + 32 f
+        // (1) per row, from the accumulators: lane = rows rowl0 + 32 f, columns jb + 32 n + 8 q + e; the value to park replaces the accumulator
         const int jb = ct * SR_TILE + wn * (NF * 32) + 4 * ehi;
-        float tmax = -INFINITY;
-        const float q0old = q0;
-        int tc = -1;  // column of the row's new best inside this tile (relative to jb), -1: the best did not move
         // (ONE instance of this code: a variant without the column mask for the tiles that lie inside the matrix was tried twice -- as a
         // second copy of the masking part and as a second copy of the whole epilogue -- and both made hipcc spill: the accumulators are
         // rewritten in place and two variants of that meeting in one control-flow join keep both register sets alive)
@@ -311,12 +330,19 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
             // tile pays neither the compare nor the select per element (a second copy of the epilogue for it made hipcc spill: see above)
             if (__builtin_amdgcn_readfirstlane(Nb - ct * SR_TILE) < SR_TILE) {
 #pragma unroll
-                for (int n = 0; n < NF; ++n)
+                for (int f = 0; f < RF; ++f)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[n][r] = (n * 32 + 8 * (r >> 2) + (r & 3) < jlim) ? acc[n][r] : -INFINITY;
+                    for (int n = 0; n < NF; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[f][n][r] = (n * 32 + 8 * (r >> 2) + (r & 3) < jlim) ? acc[f][n][r] : -INFINITY;
             }
         }
         if (!(p.dbg & 2))
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+        float tmax = -INFINITY;
+        const float q0old = q0[f];
+        int tc = -1;  // column of the row's new best inside this tile (relative to jb), -1: the best did not move
 #pragma unroll
         for (int n = 0; n < NF; ++n)
 #pragma unroll
@@ -336,27 +362,27 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * q + e;
                     const bool valid = n * 32 + 8 * q + e < jlim;
-                    const float x = PREMASK ? 0.0f : acc[n][r] * p.alpha;
+                    const float x = PREMASK ? 0.0f : acc[f][n][r] * p.alpha;
                     (void)valid, (void)x;
                     if constexpr (ISNN) {
                         // (alpha is 1 for the nearest-neighbour modes: simred_launch refuses anything else; dead columns are -inf already)
                         if constexpr (MODE == SR_NN) {
-                            q1 = __builtin_amdgcn_fmed3f(q0, q1, acc[n][r]);  // second best of {best, second, x} (second <= best)
-                            q0 = fmaxf(q0, acc[n][r]);
+                            q1[f] = __builtin_amdgcn_fmed3f(q0[f], q1[f], acc[f][n][r]);  // second best of {best, second, x} (second <= best)
+                            q0[f] = fmaxf(q0[f], acc[f][n][r]);
                         }
                     } else if constexpr (MODE == SR_LSE) {
-                        const float xv = acc[n][r] * p.alpha;  // (alpha > 0: a dead column stays -inf)
+                        const float xv = acc[f][n][r] * p.alpha;  // (alpha > 0: a dead column stays -inf)
                         tmax = fmaxf(tmax, xv);
-                        acc[n][r] = xv;
+                        acc[f][n][r] = xv;
                     } else if constexpr (MODE == SR_DSBEST) {
                         // conf = softmax over i (column statistics) * softmax over j (row statistics), evaluated ONCE per element
-                        const float v = valid ? (__expf(x - cm4[e]) * cs4[e]) * (__expf(x - rc0) * rc1) : -1.0f;
+                        const float v = valid ? (__expf(x - cm4[e]) * cs4[e]) * (__expf(x - rc0[f]) * rc1[f]) : -1.0f;
                         tmax = fmaxf(tmax, v);
-                        acc[n][r] = v;
+                        acc[f][n][r] = v;
                     } else {
-                        const float v = valid ? sr_lg_score(x, rc0, rc1, cm4[e], cs4[e], rc2, cl4[e]) : -INFINITY;
+                        const float v = valid ? sr_lg_score(x, rc0[f], rc1[f], cm4[e], cs4[e], rc2[f], cl4[e]) : -INFINITY;
                         tmax = fmaxf(tmax, v);
-                        acc[n][r] = v;
+                        acc[f][n][r] = v;
                     }
                 }
                 // one group of four columns at a time: left alone, hipcc's scheduler starts all 64 elements at once (every temporary of
@@ -365,17 +391,17 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
             }
         if constexpr (ISNN) {
             // (q0 is the row's best including this tile: if it moved, its first column in the tile is found by equality, walking downwards)
-            float tm = acc[0][0];
+            float tm = acc[f][0][0];
 #pragma unroll
             for (int n = 0; n < NF; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tm = fmaxf(tm, acc[n][r]);
+                for (int r = 0; r < 16; ++r) tm = fmaxf(tm, acc[f][n][r]);
 #pragma unroll
             for (int n = NF - 1; n >= 0; --n)
 #pragma unroll
-                for (int r = 15; r >= 0; --r) tc = (acc[n][r] == tm) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
-            qi = tm > q0old ? jb + tc : qi;
-            if (MODE == SR_NN1) q0 = fmaxf(q0old, tm);
+                for (int r = 15; r >= 0; --r) tc = (acc[f][n][r] == tm) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
+            qi[f] = tm > q0old ? jb + tc : qi[f];
+            if (MODE == SR_NN1) q0[f] = fmaxf(q0old, tm);
         }
         if constexpr (MODE == SR_DSBEST || MODE == SR_LGBEST) {
             // the row's best of this tile is a maximum tree over the finished values; its FIRST column is found by equality, walking the
@@ -383,23 +409,24 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
 #pragma unroll
             for (int n = NF - 1; n >= 0; --n)
 #pragma unroll
-                for (int r = 15; r >= 0; --r) tc = (acc[n][r] == tmax) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
-            const bool up = tmax > q0;  // tiles ascend: a later tile wins only with a larger value
-            qi = up ? jb + tc : qi;
-            q0 = up ? tmax : q0;
+                for (int r = 15; r >= 0; --r) tc = (acc[f][n][r] == tmax) ? n * 32 + 8 * (r >> 2) + (r & 3) : tc;
+            const bool up = tmax > q0[f];  // tiles ascend: a later tile wins only with a larger value
+            qi[f] = up ? jb + tc : qi[f];
+            q0[f] = up ? tmax : q0[f];
         }
         if constexpr (MODE == SR_LSE) {
             // online (max, sum): the reference moves once per tile
-            const float mn = fmaxf(q0, tmax);
+            const float mn = fmaxf(q0[f], tmax);
             const float mref = (mn == -INFINITY) ? 0.0f : mn;
-            float sum = q1 * __expf(q0 - mref);  // q0 = -inf: 0
+            float sum = q1[f] * __expf(q0[f] - mref);  // q0 = -inf: 0
 #pragma unroll
             for (int n = 0; n < NF; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sum += __expf(acc[n][r] - mref);
-            q1 = sum;
-            q0 = mn;
+                for (int r = 0; r < 16; ++r) sum += __expf(acc[f][n][r] - mref);
+            q1[f] = sum;
+            q0[f] = mn;
         }
+        }  // (row fragment f)
         // (2) per column: the whole tile is parked COLUMN-major ([column][row], 132-float rows) and every column is reduced by FOUR adjacent
         // lanes: thread (column jl = t >> 2, part = t & 3) reads rows 64 hh + 16 part + 4 k .. + 3 (hh < 2, k < 4) as eight conflict-free
         // 16-byte reads -- 32 values, no loop, no dependent LDS latency -- reduces them in registers, and the four parts are folded with two
@@ -408,10 +435,12 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         // while the other seven waves waited: 42 % of the LoFTR statistics launch, measured with IMCUI_SR_DBG.)
         if (!(p.dbg & 1)) {
 #pragma unroll
-            for (int n = 0; n < NF; ++n)
+            for (int f = 0; f < RF; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    park[(wn * (NF * 32) + n * 32 + 8 * (r >> 2) + (r & 3) + 4 * ehi) * SR_PLD + erowl] = acc[n][r];
+                for (int n = 0; n < NF; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        park[(wn * (NF * 32) + n * 32 + 8 * (r >> 2) + (r & 3) + 4 * ehi) * SR_PLD + erowl0 + 32 * f] = acc[f][n][r];
             __syncthreads();
             {
                 const int jl = etid >> 2, part = etid & 3;
@@ -515,59 +544,58 @@ __global__ __launch_bounds__(256 * WN, 2) void simred_kernel(SimRedP p) {
         for (int g = 0; g < lag; ++g) __builtin_amdgcn_s_barrier();
     __syncthreads();  // (both halves out of the loop: the parked tiles are dead, `park` carries the row exchange below)
 
-    // ================================================================ rows: fold the two half-waves (columns 4 hi), then the column halves
-    {
-        const float o0 = __shfl_xor(q0, 32, 64), o1 = __shfl_xor(q1, 32, 64);
-        const int oi = __shfl_xor(qi, 32, 64);
+    // ================================================================ rows: fold the two half-waves (columns 4 hi), then the WN column groups
+    // (one partial against another: interleaved / ascending column sets -- lowest index on equal values)
+    auto fold = [&](float& a0_, float& a1_, int& ai_, float o0, float o1, int oi) __attribute__((always_inline)) {
         if constexpr (ISNN) {
-            const bool up = o0 > q0 || (o0 == q0 && oi < qi);  // interleaved column sets: lowest index on equal values
-            q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
-            qi = up ? oi : qi;
-            q0 = up ? o0 : q0;
+            const bool up = o0 > a0_ || (o0 == a0_ && oi < ai_);
+            a1_ = up ? fmaxf(a0_, o1) : fmaxf(a1_, o0);
+            ai_ = up ? oi : ai_;
+            a0_ = up ? o0 : a0_;
         } else if constexpr (MODE == SR_LSE) {
-            const float m = fmaxf(q0, o0);
+            const float m = fmaxf(a0_, o0);
             const float mref = (m == -INFINITY) ? 0.0f : m;
-            q1 = q1 * __expf(q0 - mref) + o1 * __expf(o0 - mref);
-            q0 = m;
+            a1_ = a1_ * __expf(a0_ - mref) + o1 * __expf(o0 - mref);
+            a0_ = m;
         } else {
-            const bool up = o0 > q0 || (o0 == q0 && oi < qi);
-            qi = up ? oi : qi;
-            q0 = up ? o0 : q0;
+            const bool up = o0 > a0_ || (o0 == a0_ && oi < ai_);
+            ai_ = up ? oi : ai_;
+            a0_ = up ? o0 : a0_;
         }
-    }
-    if constexpr (WN == 2) {
-        float* xr = park;  // (every scan of the loop is behind its last barrier)
-        if (wn == 1 && hi == 0) {
-            xr[rowl * 4 + 0] = q0;
-            xr[rowl * 4 + 1] = q1;
-            reinterpret_cast<int*>(xr)[rowl * 4 + 2] = qi;
+    };
+#pragma unroll
+    for (int f = 0; f < RF; ++f) fold(q0[f], q1[f], qi[f], __shfl_xor(q0[f], 32, 64), __shfl_xor(q1[f], 32, 64), __shfl_xor(qi[f], 32, 64));
+    {
+        float* xr = park;  // [WN - 1][128 rows][4]  (every scan of the loop is behind its last barrier)
+        if (wn > 0 && hi == 0) {
+#pragma unroll
+            for (int f = 0; f < RF; ++f) {
+                const int o = ((wn - 1) * SR_TILE + rowl0 + 32 * f) * 4;
+                xr[o + 0] = q0[f];
+                xr[o + 1] = q1[f];
+                reinterpret_cast<int*>(xr)[o + 2] = qi[f];
+            }
         }
         __syncthreads();
         if (wn == 0 && hi == 0) {
-            const float o0 = xr[rowl * 4 + 0], o1 = xr[rowl * 4 + 1];
-            const int oi = reinterpret_cast<int*>(xr)[rowl * 4 + 2];
-            if constexpr (ISNN) {
-                const bool up = o0 > q0 || (o0 == q0 && oi < qi);
-                q1 = up ? fmaxf(q0, o1) : fmaxf(q1, o0);
-                qi = up ? oi : qi;
-                q0 = up ? o0 : q0;
-            } else if constexpr (MODE == SR_LSE) {
-                const float m = fmaxf(q0, o0);
-                const float mref = (m == -INFINITY) ? 0.0f : m;
-                q1 = q1 * __expf(q0 - mref) + o1 * __expf(o0 - mref);
-                q0 = m;
-            } else {
-                const bool up = o0 > q0 || (o0 == q0 && oi < qi);
-                qi = up ? oi : qi;
-                q0 = up ? o0 : q0;
-            }
+#pragma unroll
+            for (int f = 0; f < RF; ++f)
+#pragma unroll
+                for (int g = 1; g < WN; ++g) {  // ascending column groups
+                    const int o = ((g - 1) * SR_TILE + rowl0 + 32 * f) * 4;
+                    fold(q0[f], q1[f], qi[f], xr[o + 0], xr[o + 1], reinterpret_cast<int*>(xr)[o + 2]);
+                }
         }
     }
-    if (wn == 0 && hi == 0 && rowl < rowsv) {
-        const size_t o = ((size_t)b * p.nchunk + chunk) * p.r_pitch + rowg;
-        p.r0[o] = q0;
-        if (MODE == SR_NN || MODE == SR_LSE) p.r1[o] = q1;
-        if (MODE != SR_LSE) p.ri[o] = qi;
+    if (wn == 0 && hi == 0) {
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+            if (rowl0 + 32 * f < rowsv) {
+                const size_t o = ((size_t)b * p.nchunk + chunk) * p.r_pitch + rowg0 + 32 * f;
+                p.r0[o] = q0[f];
+                if (MODE == SR_NN || MODE == SR_LSE) p.r1[o] = q1[f];
+                if (MODE != SR_LSE) p.ri[o] = qi[f];
+            }
     }
 }
 
@@ -596,7 +624,7 @@ static int sr_launch_one(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nrb = (p.M + SR_TILE - 1) / SR_TILE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.batch * p.nchunk * nrb)), dim3(256 * WN), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.batch * p.nchunk * nrb)), dim3(512), lds, stream, p);
     return IMCUI_OK;
 }
 template <int MODE, bool F32>
@@ -604,8 +632,9 @@ static int sr_launch_k(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
     switch (p.K) {
         // (512 threads, one workgroup per CU, for every width: the four-slot ring + the parked tile are 110 KB of LDS; the 256-thread
         // geometry WN = 1 -- two workgroups per CU, register transport -- was the first version for K <= 128 and stays instantiable)
-        case 64: return sr_launch_one<4, 2, MODE, F32>(h, p, stream);
-        case 128: return sr_launch_one<8, 2, MODE, F32>(h, p, stream);
+        // (K <= 128: 64-row wave tiles, half the LDS reads per matrix instruction; IMCUI_SR_DBG bit 3 = the 32-row geometry everywhere, A/B)
+        case 64: return (p.dbg & 8) ? sr_launch_one<4, 2, MODE, F32>(h, p, stream) : sr_launch_one<4, 4, MODE, F32>(h, p, stream);
+        case 128: return (p.dbg & 8) ? sr_launch_one<8, 2, MODE, F32>(h, p, stream) : sr_launch_one<8, 4, MODE, F32>(h, p, stream);
         case 256: return sr_launch_one<16, 2, MODE, F32>(h, p, stream);
         default: return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "simred: K=%d (64, 128 or 256)", p.K);
     }
