@@ -1042,7 +1042,7 @@ def lib_version() -> int:
 
 
 def set_option(device: torch.device, name: str, value: int) -> int:
-    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "simred", "ffn_tile"); returns
+    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "simred", "ffn_tile", "wreg_tile", "conv_tall", "conv_narrow"); returns
     the previous value.  The IMCUI_* environment variables of the same names are only read when the handle is created."""
     hd = get_handle(device)
     old = C.c_int(0)

@@ -58,8 +58,8 @@ int imcui_hip_version(void);
  * "attn_mix_layers", default 0x1ff.  Round 5 default: cross 7 -- the two-product P.V in the CROSS blocks only, audited per block: layer error <= 7.1e-6 and
  * score error <= 4.7e-5 at N = M = 2048 on three weight sets, half the parity bar; -1 restores three products everywhere), "simred"
  * 1 | 0 (default 1: the mutual-NN matcher on the persistent similarity-and-reduce kernel; 0: the round-4 tile GEMM with the reducing
- * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256), "ffn_tile" 0 | 128 | 64 | 32 (tokens per workgroup of the
- * fused FFN; default 0 = by token count, the largest tile that still gives every CU a workgroup; bitwise equal results), "conv_tall"
+ * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256), "ffn_tile" / "wreg_tile" 0 | 128 | 64 | 32 (tokens per workgroup of the
+ * fused FFN / of the weights-in-registers projection GEMM; default 0 = by token count, the largest tile that still gives every CU a workgroup; bitwise equal results), "conv_tall"
  * 0 | 1 | 2 and "conv_narrow" 0 | 1 | 2 (convolution tile shapes; conv_narrow 0 = 64-channel tiles where 128-channel tiles would give fewer than 256
  * workgroups, 1 = always, 2 = never).  Unknown name: IMCUI_HIP_ERR_ARG. */
 int imcui_hip_set_option(imcui_hip_t* h, const char* name, int value);
