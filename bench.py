@@ -190,6 +190,8 @@ def parity_splg(pipe, img0, img1, dc, wc, which=(0,), keypoints_only=()) -> dict
         extra_ties.append(t)
     kp_ties_all = [p["keypoint_ties_audited"] for p in per_pair] + extra_ties
     return {"status": "ok", "checked": f"pairs {list(which)} of the bench batch vs the CPU oracle, after the timed region", "pairs_checked": len(per_pair),
+            "score_bar": 1e-4, "weights": "synth_weights seed 0, the shaped ('damped') LightGlue set",
+            "out_of_bar_stress_case": "tests/test_gpu_lightglue.py also runs an unshaped 'random' weight set (|similarity| ~ 2000) held to 5e-4 on scores: a stress case ABOVE the 1e-4 bar, not a parity claim",
             "keypoint_audit_pairs": len(kp_ties_all), "worst_keypoint_ties_per_pair_all": max(kp_ties_all), "keypoint_ties_audited_all": sum(kp_ties_all),
             "keypoints": per_pair[0]["keypoints"], "keypoint_ties_audited": sum(p["keypoint_ties_audited"] for p in per_pair),
             "worst_keypoint_ties_per_pair": max(p["keypoint_ties_audited"] for p in per_pair),
@@ -837,6 +839,7 @@ def bench_superglue(args, dev, rank, world):
     gemm_ms, _ = backend.profile_read(dev, "gemm")
     backend.profile_enable(dev, False)
     # the optimal transport alone: the same step without Sinkhorn rounds (outside the timed region)
+    pipe.matcher.conf["runtime_match_threshold"] = True  # the plugin freezes its conf at _init like the reference; this leg re-reads it
     pipe.matcher.conf["sinkhorn_iterations"] = 0
     pipe(img0, img1)
     dt0, _ = timed(max(2, args.steps // 2))
@@ -1066,6 +1069,30 @@ def launchcheck(args) -> None:
         dist.destroy_process_group()
 
 
+ATTENTION_SOURCES = ("image-matching-webui_amd/csrc/attention.hip", "image-matching-webui_amd/csrc/attention.h", "image-matching-webui_amd/csrc/gemm_wreg.hip")  # what decides the attention kernel's HBM traffic (kernel, launch geometry, the plane layout its producer writes)
+
+
+def sources_sha16(paths=ATTENTION_SOURCES) -> dict:
+    """sha256 prefixes of the kernel sources: tools/summarize_profiles.py records them beside the PMC traffic it writes, bench.py compares them
+    with the tree that runs (the GPU box has no .git, so a commit id cannot be checked there; file contents can)."""
+    import hashlib
+
+    out = {}
+    for rel in paths:
+        try:
+            out[rel] = hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
+        except OSError:
+            out[rel] = None
+    return out
+
+
+def _cross_variant(dev) -> int:
+    """The attention variant LightGlue's cross blocks run (csrc/lightglue.hip): option attn_variant_cross, whose default -2 means 7 (two-product P.V)
+    while attn_variant is the default kernel 8 and "follow attn_variant" otherwise; -1 = follow attn_variant."""
+    cv, av = backend.get_option(dev, "attn_variant_cross"), backend.get_option(dev, "attn_variant")
+    return (7 if av == 8 else -1) if cv == -2 else cv
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1152,6 +1179,7 @@ def compact_line(line: dict) -> dict:
         out = {k: (_short(r[k], 80) if k == "kernel" else r[k]) for k in keep if k in r}
         if r.get("traffic_source"):
             out["traffic_source"] = "committed PMC passes under profiles/ (not this run)"
+            out["traffic_head"], out["traffic_stale"] = r.get("traffic_head"), r.get("traffic_stale")  # commit of the passes; kernel sources changed since ([] = none)
         return out
 
     def cpu(c):
@@ -1437,7 +1465,7 @@ def bench_splg(args, dev, rank, world):
         executed = achieved * (17.18 / 15.03) * (3.0 if split else 1.0) if achieved is not None else None
         # HBM-side bytes per attention launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, separate runs, FETCH doubled per MI355X_MICROARCH.md); scales with the batch
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_head, traffic_stale = None, None, None, None
         import glob
 
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_attention_traffic.json")))  # newest round's PMC passes
@@ -1448,6 +1476,13 @@ def bench_splg(args, dev, rank, world):
             traffic = tj["traffic_bytes_per_launch"] * B / tj["batch_pairs"]
             traffic_source = (f"NOT measured in this run: {os.path.relpath(tpath, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at "
                               f"{tj['batch_pairs']} pairs per step, committed), scaled to {B} pairs per step")
+            # the commit the counters were taken at + whether the kernel's sources changed since
+            traffic_head = str(tj.get("head", ""))
+            rec = tj.get("sources_sha16")
+            traffic_stale = None if not rec else sorted(k for k, v in sources_sha16(tuple(rec)).items() if v != rec[k])
+            if traffic_stale:
+                print(f"[bench] WARNING: roofline.traffic was collected at {traffic_head} and {traffic_stale} changed since: re-run the PMC passes "
+                      "(tools/collect_profiles.sh, tools/summarize_profiles.py)", file=sys.stderr)
         line = {
             "metric": "image-pairs/sec @640x480 SuperPoint+LightGlue",
             "value": pairs / dt,
@@ -1459,7 +1494,7 @@ def bench_splg(args, dev, rank, world):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 via 3xf16 split MFMA, f32 accumulate" + ("" if backend.get_option(dev, "attn_variant_cross") < 0 else
+            "dtype": ("f32 via 3xf16 split MFMA, f32 accumulate" + ("" if _cross_variant(dev) < 0 else
                       "; P.V of LightGlue's cross blocks in two products (audited per block: layer error <= 7.1e-6, score error <= 4.7e-5, profiles/r05_lab_attention_mix.txt)")) if split else "f32",
             "data": "synthetic",
             "config": {
@@ -1473,6 +1508,7 @@ def bench_splg(args, dev, rank, world):
             "roofline": {
                 "kernel": "attn_split_kernel (3xf16 split MFMA flash attention)" if split else "attn_kernel (f32 MFMA flash attention)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak if achieved is not None else None, "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_head": traffic_head, "traffic_stale": traffic_stale,  # commit of the PMC passes; attention sources changed since ([] = none, None = not recorded)
                 "executed_tflops": executed, "executed_frac": executed / peak if executed is not None else None,
                 "executed_frac_of_sustained_peak": (executed / SUSTAINED_F16_MFMA_TF) if split and executed is not None else None,
                 **({"note": "adaptive depth / width: the work per launch is data dependent, no roofline fraction is claimed"} if args.adaptive else {}),

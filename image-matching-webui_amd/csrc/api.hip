@@ -70,8 +70,9 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         h->opt[OPT_ATTN_SELF] = (e = getenv("IMCUI_ATTN_VARIANT_SELF")) ? atoi(e) : -1;
         // Round 5: LightGlue's CROSS blocks run the audited two-product P.V (variant 7) by default -- layer error <= 7.1e-6 and score error <= 4.7e-5 on the
         // three weight sets at N = M = 2048 (half the parity bar; profiles/r05_lab_attention_mix.txt), + 2.7 % end to end; the self blocks keep three
-        // products (2.1e-5 / 9.6e-5 there: rejected).  -1 here restores three products everywhere.
-        h->opt[OPT_ATTN_CROSS] = (e = getenv("IMCUI_ATTN_VARIANT_CROSS")) ? atoi(e) : 7;
+        // products (2.1e-5 / 9.6e-5 there: rejected).  -1 here restores three products everywhere.  The default is -2 = "7 while attn_variant is
+        // its default (8)": an explicit attn_variant (the A/B and parity workflows that set that option alone) governs every block again.
+        h->opt[OPT_ATTN_CROSS] = (e = getenv("IMCUI_ATTN_VARIANT_CROSS")) ? atoi(e) : -2;
         h->opt[OPT_ATTN_MIX_LAYERS] = (e = getenv("IMCUI_ATTN_MIX_LAYERS")) ? (int)strtol(e, nullptr, 0) : 0x1ff;
     }
     *out = h;

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -131,6 +133,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// More than 64 KB of dynamic LDS needs `hipFuncAttributeMaxDynamicSharedMemorySize`, and the attribute belongs to the CURRENT device's copy of
+// the kernel: a process that drives several GPUs has to opt in on each of them.  `done` = one bit per device ordinal, one word per kernel
+// instantiation (a static of the launcher); two threads racing on the same bit both set the attribute, which is harmless.
+static inline bool imcui_lds_optin(std::atomic<unsigned long long>& done, const void* kernel, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -150,7 +164,7 @@ enum {
     OPT_WREG_PIPE,         // IMCUI_WREG_PIPE: 0 = rolled K loop, 1 (default) = three rotating register sets
     OPT_ATTN_VARIANT,      // IMCUI_ATTN_VARIANT: 0 .. 8, default 8, see attention.hip
     OPT_ATTN_SELF,         // IMCUI_ATTN_VARIANT_SELF: -1 (default) = attn_variant; else the variant of LightGlue's SELF blocks in the layers of attn_mix_layers
-    OPT_ATTN_CROSS,        // IMCUI_ATTN_VARIANT_CROSS: the same for the CROSS blocks; default 7 (two-product P.V: audited per block, tools/attn_mix_audit.py)
+    OPT_ATTN_CROSS,        // IMCUI_ATTN_VARIANT_CROSS: the same for the CROSS blocks; default -2 = 7 (two-product P.V: audited per block, tools/attn_mix_audit.py) while attn_variant is 8, else attn_variant
     OPT_ATTN_MIX_LAYERS,   // IMCUI_ATTN_MIX_LAYERS: bit l = layer l takes the two overrides above (default 0x1ff: all nine)
     OPT_CONV_TALL,         // IMCUI_CONV_TALL: 0 = 8-row conv tiles everywhere, 1 (default) = 16-row tiles for SuperPoint's fused first layer, 2 = also for plain 64-channel layers
     OPT_CONV_NARROW,       // IMCUI_CONV_NARROW: 0 (default) = 64-output-channel tiles where the 128-channel tiling gives fewer than 256 workgroups; 1 = wherever 128 fit too; 2 = never (A/B)

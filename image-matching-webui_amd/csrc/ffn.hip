@@ -398,17 +398,14 @@ int ffn_launch(imcui_hip_s* h, const FfnP& p, hipStream_t stream) {
                                        {lg_ffn_kernel<1, 0, 4>, lg_ffn_kernel<1, 1, 4>, lg_ffn_kernel<1, 2, 4>, lg_ffn_kernel<1, 3, 4>},
                                        {lg_ffn_kernel<1, 0, 2>, lg_ffn_kernel<1, 1, 2>, lg_ffn_kernel<1, 2, 2>, lg_ffn_kernel<1, 3, 2>},
                                        {lg_ffn_kernel<1, 0, 1>, lg_ffn_kernel<1, 1, 1>, lg_ffn_kernel<1, 2, 1>, lg_ffn_kernel<1, 3, 1>}};
-    static bool attr_set[4][4] = {};  // > 64 KB of dynamic LDS needs the opt-in
+    static std::atomic<unsigned long long> optin[4][4];  // > 64 KB of dynamic LDS: once per instantiation AND device (common.h)
     // token tile: the largest of 128 / 64 / 32 that still gives each of the 256 CUs a workgroup (option ffn_tile forces one)
     int tok = h->opt[OPT_FFN_TILE];
     if (tok != 128 && tok != 64 && tok != 32) tok = p.M > 256 * 64 ? 128 : p.M > 256 * 32 ? 64 : 32;
     if (p.dbg) tok = 128;  // (the lab's stamp buffer has a slot per 128 tokens)
     const int v = tok == 128 ? (variant != 0) : tok == 64 ? 2 : 3, a = p.act;
-    if (!attr_set[v][a]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[v][a]), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS_BYTES) != hipSuccess)
-            return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
-        attr_set[v][a] = true;
-    }
+    if (!imcui_lds_optin(optin[v][a], reinterpret_cast<const void*>(kerns[v][a]), FFN_LDS_BYTES))
+        return imcui_set_err(h, IMCUI_ERR_HIP, "ffn: cannot reserve %d bytes of LDS", FFN_LDS_BYTES);
     if (h->range_flag) {
         imcui_range_check(h, p.x, p.M, 256, 256, p.cnt, p.rows_per_seq, stream);
         imcui_range_check(h, p.ctx, p.M, 256, 256, p.cnt, p.rows_per_seq, stream);

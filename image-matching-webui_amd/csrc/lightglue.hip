@@ -905,7 +905,10 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.rows_per_seq = R;
             a.cross = 1;
             a.log2_domain = 1;
-            if (h->opt[OPT_ATTN_CROSS] >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = h->opt[OPT_ATTN_CROSS];
+            {   // -2 (default) = the audited two-product P.V (7) while attn_variant is the default kernel (8), otherwise attn_variant governs; -1 = attn_variant
+                const int cv = h->opt[OPT_ATTN_CROSS] == -2 ? (h->opt[OPT_ATTN_VARIANT] == 8 ? 7 : -1) : h->opt[OPT_ATTN_CROSS];
+                if (cv >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = cv;
+            }
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1c, o.s1c, o.b1c, o.gc, o.bc, o.w2c, o.s2c, o.s2cp, o.b2c));
         }

@@ -12,7 +12,8 @@
 //     to the row below through a double-buffered LDS word.  W + rows steps per strip of <= 1024 rows instead of W x H dependent steps.
 // Byte work with integer arithmetic: HBM / latency bound, nothing here wants a matrix core.  Bit-exact by construction (the filters are
 // exact modulo-256 arithmetic); the checker is PIL (tests/test_png_cpu.py, tests/test_gpu_png.py).
-// Not taken (the caller keeps its host reader): interlaced files, bit depths other than 8.
+// Not taken (the caller keeps its host reader): interlaced files, bit depths other than 8, files with an eXIf orientation other than 1.
+// Chunk CRCs are not verified (zlib's adler32 over the pixel stream is).
 #include <string.h>
 #include <zlib.h>
 
@@ -39,6 +40,26 @@ struct Png {
     unsigned char pal[768];
     std::vector<std::pair<const unsigned char*, size_t>> idat;
 };
+
+// Orientation (tag 0x0112) of an eXIf chunk body = a TIFF header + IFD0; 1 when absent or unreadable.  cv2.imread and PIL's
+// `exif_transpose` rotate / mirror by it; the device path does not, so anything but 1 is handed back to the host reader.
+int exif_orientation(const unsigned char* b, size_t n) {
+    if (n < 8) return 1;
+    const bool le = b[0] == 'I' && b[1] == 'I';
+    if (!le && !(b[0] == 'M' && b[1] == 'M')) return 1;
+    auto u16 = [&](size_t o) -> unsigned { return le ? (b[o] | (b[o + 1] << 8)) : ((b[o] << 8) | b[o + 1]); };
+    auto u32 = [&](size_t o) -> unsigned { return le ? (u16(o) | (u16(o + 2) << 16)) : ((u16(o) << 16) | u16(o + 2)); };
+    if (u16(2) != 42) return 1;
+    const size_t ifd = u32(4);
+    if (ifd + 2 > n) return 1;
+    const unsigned cnt = u16(ifd);
+    for (unsigned e = 0; e < cnt; ++e) {
+        const size_t o = ifd + 2 + 12 * (size_t)e;
+        if (o + 12 > n) return 1;
+        if (u16(o) == 0x0112) return u16(o + 2) == 3 ? (int)u16(o + 8) : 1;
+    }
+    return 1;
+}
 
 inline unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3]; }
 
@@ -71,6 +92,9 @@ int png_parse(const unsigned char* d, size_t n, Png& p, bool want_idat) {
             if (len % 3 != 0 || len > 768) return IMCUI_ERR_ARG;
             memcpy(p.pal, body, len);
             p.npal = (int)(len / 3);
+        } else if (memcmp(type, "eXIf", 4) == 0) {
+            const int o = exif_orientation(body, len);
+            if (o != 1 && o >= 0 && o <= 8) return IMCUI_ERR_UNSUPPORTED;  // rotated / mirrored on load by cv2 and PIL: the host reader
         } else if (memcmp(type, "IDAT", 4) == 0) {
             have_idat = true;
             if (want_idat) p.idat.emplace_back(body, len);
@@ -110,15 +134,19 @@ int png_inflate_one(const unsigned char* d, size_t n, unsigned char* raw, size_t
         z.next_in = const_cast<unsigned char*>(p.idat[k].first);
         z.avail_in = (uInt)p.idat[k].second;
         while (z.avail_in > 0 && zr != Z_STREAM_END) {
+            // Once the image is full a valid stream still has its trailer (adler32) to consume, possibly across an IDAT boundary: it gets a
+            // scratch to write into and is refused only if it actually produces a byte there, or stops making progress.
+            unsigned char spill[32];
             const size_t room = need - done;
-            z.next_out = raw + done;
-            z.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
-            const uInt before = z.avail_out;
+            z.next_out = room > 0 ? raw + done : spill;
+            z.avail_out = room > 0 ? (uInt)(room > 0x40000000u ? 0x40000000u : room) : (uInt)sizeof spill;
+            const uInt before_out = z.avail_out, before_in = z.avail_in;
             zr = inflate(&z, Z_NO_FLUSH);
-            done += before - z.avail_out;
+            const uInt produced = before_out - z.avail_out;
+            if (room > 0) done += produced;
             if (zr != Z_OK && zr != Z_STREAM_END) break;
-            if (before == 0 && zr == Z_OK) {  // more data than the image holds
-                zr = Z_DATA_ERROR;
+            if ((room == 0 && produced > 0) || (produced == 0 && z.avail_in == before_in && zr == Z_OK)) {
+                zr = Z_DATA_ERROR;  // more data than the image holds / no progress
                 break;
             }
         }

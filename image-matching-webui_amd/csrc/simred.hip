@@ -619,14 +619,10 @@ int simred_chunks(int batch, int M, int N) {
 
 template <int KS, int WN, int MODE, bool F32>
 static int sr_launch_one(imcui_hip_s* h, const SimRedP& p, hipStream_t stream) {
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in (once per instantiation)
+    static std::atomic<unsigned long long> optin{0};  // > 64 KB of dynamic LDS: once per instantiation AND device (common.h)
     constexpr int lds = SR_LDS_BYTES(WN);
     auto kern = simred_kernel<KS, WN, MODE, F32>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return imcui_set_err(h, IMCUI_ERR_HIP, "simred: cannot reserve %d bytes of LDS", lds);
-        attr_set = true;
-    }
+    if (!imcui_lds_optin(optin, reinterpret_cast<const void*>(kern), lds)) return imcui_set_err(h, IMCUI_ERR_HIP, "simred: cannot reserve %d bytes of LDS", lds);
     const int nrb = (p.M + SR_TILE - 1) / SR_TILE;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.batch * p.nchunk * nrb)), dim3(512), lds, stream, p);
     return IMCUI_OK;

@@ -18,9 +18,9 @@ per `forward_batched` call and the preprocessing on the device:
 A resize that GROWS a side runs cv2.INTER_LINEAR like the reference (`resize_image` :29-31), also on the device
 (`backend.preprocess_linear`); `superpoint_max` (force_resize to 640 x 480) therefore accepts images of any size.
 
-Difference from the reference, on the host side of the boundary: colour images are decoded as RGB and reduced to gray with
-cv2's `cvtColor` fixed-point formula (the reference lets `cv2.imread(IMREAD_GRAYSCALE)` do it inside the decoder, which uses
-the same 8-bit kernel for JPEG / PNG colour files).
+Gray of a colour FILE (`cv2.imread(IMREAD_GRAYSCALE)` converts inside the decoder): JPEG = the file's luma plane (device decoder) and
+PNG = libpng's `(9797 R + 19234 G + 3737 B) >> 15` (`_png_as_read_image`); a host reader without cv2 (PIL) hands back RGB and the device
+kernel applies `cvtColor`'s fixed-point formula, as the UI path (`extract`, :158-161) does with its RGB input.
 """
 from __future__ import annotations
 
@@ -56,8 +56,9 @@ def read_image_u8(path, grayscale: bool = False) -> np.ndarray:
     cv2 (when installed) with the reference's own flags -- IMREAD_GRAYSCALE / IMREAD_COLOR: the decoder applies the EXIF
     orientation, reduces 16-bit files to 8 bits and drops alpha, and for `grayscale` hands back ITS gray (libjpeg's luma for
     JPEG), exactly what the reference feeds the extractor.  Without cv2, PIL reproduces those conversions: EXIF transpose,
-    16-bit -> 8-bit by dropping the low byte (cv2's 1/256 scaling), palette / alpha / CMYK -> RGB; gray is then left to the
-    device kernel (cv2's RGB2GRAY fixed point), which is what the UI path (`extract`, :158-161) does with its RGB input."""
+    16-bit -> 8-bit by dropping the low byte (cv2's 1/256 scaling), palette / alpha / CMYK -> RGB; the gray of a colour PNG is libpng's
+    (what cv2's PNG reader returns, `_png_as_read_image`), the gray of other colour files is left to the device kernel (cv2's RGB2GRAY
+    fixed point), which is what the UI path (`extract`, :158-161) does with its RGB input."""
     try:
         import cv2
     except ImportError:
@@ -76,6 +77,7 @@ def read_image_u8(path, grayscale: bool = False) -> np.ndarray:
         im.load()
     except Exception as e:  # noqa: BLE001
         raise ValueError(f"Cannot read image {path}.") from e
+    is_png = (im.format or "").upper() == "PNG"  # (the transposed copy below has no format)
     im = ImageOps.exif_transpose(im)
     if im.mode in ("I;16", "I;16B", "I;16L", "I"):
         arr = np.asarray(im).astype(np.int64)
@@ -90,7 +92,11 @@ def read_image_u8(path, grayscale: bool = False) -> np.ndarray:
         return arr if grayscale else np.repeat(arr[:, :, None], 3, axis=2)
     if im.mode != "RGB":
         im = im.convert("RGB")  # palette, RGBA (alpha dropped), CMYK
-    return np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy); gray conversion runs on the device
+    arr = np.array(im, dtype=np.uint8)  # a writable copy (torch.from_numpy)
+    if grayscale and is_png:  # cv2's PNG reader converts inside libpng (see `_png_as_read_image`): the same gray as the device decoder's
+        c = arr.astype(np.int32)
+        return ((9797 * c[..., 0] + 19234 * c[..., 1] + 3737 * c[..., 2]) >> 15).astype(np.uint8)
+    return arr  # other colour files: gray conversion runs on the device
 
 
 def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> torch.Tensor:
@@ -130,10 +136,18 @@ def read_image_device(path, grayscale: bool, device, decode: str = "auto") -> to
 
 
 def _png_as_read_image(t: torch.Tensor, grayscale: bool) -> torch.Tensor:
-    """The device PNG decoder's output in `read_image_u8`'s convention: gray files stay [H,W] for `grayscale`, are replicated to three channels
-    otherwise (IMREAD_COLOR); colour files stay RGB either way (their gray conversion runs on the device in the caller, as for the host reader)."""
+    """The device PNG decoder's output as `cv2.imread` hands the file back: gray files stay [H,W] for `grayscale` and are replicated to three
+    channels otherwise (IMREAD_COLOR); colour files stay RGB for IMREAD_COLOR and, for IMREAD_GRAYSCALE, are reduced to gray the way OpenCV's
+    PNG reader does it -- INSIDE libpng (`png_set_rgb_to_gray(png_ptr, 1, 0.299, 0.587)`, grfmt_png.cpp), not with `cvtColor`:
+    libpng turns the two weights into 15-bit integers by truncation (29900 * 32768 / 100000 = 9797, 58700 * 32768 / 100000 = 19234, blue =
+    32768 - both = 3737) and TRUNCATES the sum, `(9797 R + 19234 G + 3737 B) >> 15` (`png_do_rgb_to_gray`, the 8-bit branch without gamma tables;
+    R = G = B passes through, which the formula gives by itself since the weights sum to 2^15).  `cvtColor`'s 9798 / 19235 / 3735 with rounding
+    differs from it by one level on many pixels."""
     if t.dim() == 2 and not grayscale:
         return t[:, :, None].expand(-1, -1, 3).contiguous()
+    if t.dim() == 3 and grayscale:
+        c = t.to(torch.int32)
+        return ((9797 * c[..., 0] + 19234 * c[..., 1] + 3737 * c[..., 2]) >> 15).to(torch.uint8)
     return t
 
 

@@ -7,6 +7,8 @@ runtime conf is re-read on every call like `self.net(data, self.conf)` (:57).  T
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 from ... import backend
@@ -74,7 +76,8 @@ class SuperPoint(BaseModel):
         if key not in cache:
             try:
                 cache[key] = GraphedCall(lambda img: self.forward_batched(img), image)
-            except Exception:  # noqa: BLE001 -- capture is an optimisation: keep working without it
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation: keep working without it, but say so (once per key)
+                warnings.warn(f"SuperPoint hip_graph: capture failed for {key[:2]}, running eager launches instead ({type(e).__name__}: {e})", RuntimeWarning, stacklevel=2)
                 cache[key] = None
         g = cache[key]
         if g is None:

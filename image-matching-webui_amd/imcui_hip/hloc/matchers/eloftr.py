@@ -135,6 +135,10 @@ class ELoFTR(BaseModel):
         "model_type": "full",
         "precision": "fp32",
     }
+    # The reference writes match_threshold into upstream's config when the model is BUILT (`cfg["match_coarse"]["thr"] = conf["match_threshold"]`,
+    # imcui/hloc/matchers/eloftr.py:51-52), and picks the arithmetic there too (:43-47,63-64): the UI's later mutation of a cached model's
+    # conf (imcui/ui/utils.py:921-922) reaches neither.  False (default) = exactly that; True = re-read conf["match_threshold"] on every
+    # call (what the slider intends).  Not a reference key: read with conf.get("runtime_match_threshold", False), default_conf stays the reference's.
     required_inputs = ["image0", "image1"]
 
     def _init(self, conf):
@@ -142,6 +146,8 @@ class ELoFTR(BaseModel):
             raise NotImplementedError("the HIP EfficientLoFTR computes the 'full' model (model_type 'opt' changes the coarse matching rule; not restated)")
         if conf.get("precision", "fp32") not in ("fp32", "fp16", "mp"):
             raise ValueError(f"precision {conf.get('precision')!r}: one of 'fp32', 'mp', 'fp16' (imcui/hloc/matchers/eloftr.py:32-33)")
+        self._match_threshold = float(conf["match_threshold"])  # frozen here, like `cfg["match_coarse"]["thr"]` (see default_conf)
+        self._arith = 0 if conf.get("precision", "fp32") == "fp32" else 1  # `_default_cfg["mp"]` / `.half()` are applied once, in `_init`
         sd = resolve_state_dict(conf, "eloftr")
         if "state_dict" in sd and isinstance(sd["state_dict"], dict):
             sd = sd["state_dict"]
@@ -152,8 +158,12 @@ class ELoFTR(BaseModel):
 
     def forward_batched(self, image0: torch.Tensor, image1: torch.Tensor, debug_windows: bool = False) -> dict:
         """Upstream forward(image0, image1) on a batch: fixed-capacity outputs, no host sync."""
-        arith = 0 if self.conf.get("precision", "fp32") == "fp32" else 1  # read per call: conf is mutable at run time
-        return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], debug_windows, arith)
+        return self._impl.forward(self.packed, image0, image1, self.match_threshold(), debug_windows, self._arith)
+
+    def match_threshold(self) -> float:
+        """The coarse-matching threshold of this call: the value the model was built with, or conf's current one under the opt-in."""
+        c = self.conf
+        return float(c["match_threshold"]) if c.get("runtime_match_threshold", False) else self._match_threshold
 
     def forward_pairs(self, image0: torch.Tensor, image1: torch.Tensor) -> list:
         """`_forward` on B pairs at once (the batched dense driver): the per-pair dictionaries the wrapper would return for

@@ -11,6 +11,8 @@ upstream LightGlue.forward, CPU-path semantics) runs in libimcui_hip (imcui_hip_
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 
 from ... import backend
@@ -110,7 +112,8 @@ class LightGlue(BaseModel):
         if key not in cache:
             try:
                 cache[key] = GraphedCall(lambda a, b, d, e, p, q: self.forward_batched(a, b, d, e, p, q, size0, size1), *ins)
-            except Exception:  # noqa: BLE001 -- capture is an optimisation: keep working without it
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation: keep working without it, but say so (once per key)
+                warnings.warn(f"LightGlue hip_graph: capture failed for {key[:2]}, running eager launches instead ({type(e).__name__}: {e})", RuntimeWarning, stacklevel=2)
                 cache[key] = None
         g = cache[key]
         if g is None:

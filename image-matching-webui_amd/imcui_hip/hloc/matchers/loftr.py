@@ -5,8 +5,10 @@ Drop-in for imcui/hloc/matchers/loftr.py: module name `loftr`, same `default_con
 before the net ("we refine kpts in image0", :42-51), the top-k matches by confidence are kept with
 `argsort(descending)[:k]` (:58-65), key names are swapped back and `confidence` is renamed `scores`
 (:67-70).  The model itself (kornia.feature.LoFTR.forward, :54) runs in libimcui_hip
-(imcui_hip_loftr_forward).  Weights: kornia's `outdoor` checkpoint state dict (or the MINIMA variant,
-which sets temp_bug_fix, :27-36), given as conf["state_dict"] / conf["weights_path"].
+(imcui_hip_loftr_forward).  Weights: conf["state_dict"] / conf["weights_path"] (kornia's `loftr_outdoor.ckpt`, or any LoFTR state dict with its names);
+without either, the zoo's default entry (`weights: "outdoor"`, configs/matchers.py:249-256) resolves like the reference's
+`LoFTR_(pretrained="outdoor")`: kornia when importable, else kornia's URL through the torch-hub cache (`kornia_pretrained`); a
+`minima` model name (:27-36, sets temp_bug_fix) comes from `loftr/<model_name>` of the model repository like the reference's.
 
 image0 and image1 may have different sizes (`minima_loftr`, configs/matchers.py:283, keeps each image's aspect ratio).
 """
@@ -19,6 +21,28 @@ from ..utils.base_model import BaseModel
 from ..utils.weights import resolve_state_dict
 
 
+# kornia.feature.loftr.loftr `urls` (the files `LoFTR(pretrained=...)` fetches with torch.hub.load_state_dict_from_url); kornia is not
+# a dependency of this package, so its download is restated: same URL, same torch-hub cache file, same `["state_dict"]` container
+KORNIA_LOFTR_URLS = {
+    "outdoor": "http://cmp.felk.cvut.cz/~mishkdmy/models/loftr_outdoor.ckpt",
+    "indoor_new": "http://cmp.felk.cvut.cz/~mishkdmy/models/loftr_indoor_ds_new.ckpt",
+    "indoor": "http://cmp.felk.cvut.cz/~mishkdmy/models/loftr_indoor.ckpt",
+}
+
+
+def kornia_pretrained(weights: str) -> dict:
+    """What `kornia.feature.LoFTR(pretrained=weights)` loads (imcui/hloc/matchers/loftr.py:37): kornia itself when it is installed,
+    otherwise its URL through torch.hub (a file already in `$TORCH_HOME/hub/checkpoints/` -- where kornia's own download leaves it --
+    is used without touching the network)."""
+    try:
+        from kornia.feature import LoFTR as KorniaLoFTR
+
+        return KorniaLoFTR(pretrained=weights).state_dict()
+    except ImportError:
+        pass
+    return torch.hub.load_state_dict_from_url(KORNIA_LOFTR_URLS[weights], map_location="cpu")
+
+
 class LoFTR(BaseModel):
     default_conf = {
         "weights": "outdoor",
@@ -26,23 +50,48 @@ class LoFTR(BaseModel):
         "sinkhorn_iterations": 20,
         "max_keypoints": -1,
     }
+    # The reference writes match_threshold into kornia's config when the model is BUILT (`cfg["match_coarse"]["thr"] = conf["match_threshold"]`,
+    # imcui/hloc/matchers/loftr.py:21-24; `CoarseMatching.__init__` keeps `self.thr`), so the UI's later `matcher.conf["match_threshold"] = ...`
+    # on a cached model (imcui/ui/utils.py:921-922) never reaches the coarse matching.  False (default) = exactly that; True = re-read
+    # conf["match_threshold"] on every call (what the slider intends).  Not a reference key: read with conf.get("runtime_match_threshold", False), default_conf stays the reference's.
     required_inputs = ["image0", "image1"]
 
     def _init(self, conf):
+        self._match_threshold = float(conf["match_threshold"])  # frozen here, like `cfg["match_coarse"]["thr"]` (see default_conf)
         model_name = conf.get("model_name", None)
-        self.temp_bug_fix = model_name is not None and "minima" in model_name
+        minima = model_name is not None and "minima" in model_name
+        # temp_bug_fix: the MINIMA checkpoint (loftr.py:27-28) and kornia's own rule for its re-trained indoor weights
+        # (`LoFTR.__init__`: `if pretrained == "indoor_new": config["coarse"]["temp_bug_fix"] = True`)
+        self.temp_bug_fix = minima or conf["weights"] == "indoor_new"
+        fallback = None
         if conf.get("state_dict") is None and not conf.get("weights_path"):
-            conf = {**conf, "model_name": model_name or f"loftr_{conf['weights']}.ckpt"}
-        sd = resolve_state_dict(conf, "loftr")
-        if "state_dict" in sd and isinstance(sd["state_dict"], dict):
-            sd = sd["state_dict"]
+            if minima:  # loftr.py:29-33: `loftr/<model_name>` of the model repository
+                conf = {**conf, "model_name": model_name}
+            else:  # loftr.py:37: `LoFTR_(pretrained=conf["weights"])` -- kornia downloads its own file; the model repository has none
+                if conf["weights"] not in KORNIA_LOFTR_URLS:
+                    raise ValueError(f"weights {conf['weights']!r}: kornia's LoFTR knows {sorted(KORNIA_LOFTR_URLS)}")
+                weights = conf["weights"]
+
+                def fallback():
+                    try:
+                        return kornia_pretrained(weights)
+                    except Exception as e:  # noqa: BLE001
+                        raise RuntimeError(f"kornia_pretrained({weights!r}) = {KORNIA_LOFTR_URLS[weights]}: {type(e).__name__}: {e}") from e
+
+                conf = {**conf, "model_name": f"loftr_{conf['weights']}.ckpt"}  # last resort only (not a file the reference uses)
+        sd = resolve_state_dict(conf, "loftr", fallback=fallback)
         self.conf.pop("state_dict", None)
         self.register_buffer("packed", backend.pack_loftr(sd), persistent=False)
         self._impl = backend.LoFTRHIP()
 
     def forward_batched(self, image0: torch.Tensor, image1: torch.Tensor) -> dict:
         """kornia LoFTR.forward(image0, image1) on a batch: fixed-capacity outputs, no host sync."""
-        return self._impl.forward(self.packed, image0, image1, self.conf["match_threshold"], self.temp_bug_fix)
+        return self._impl.forward(self.packed, image0, image1, self.match_threshold(), self.temp_bug_fix)
+
+    def match_threshold(self) -> float:
+        """The coarse-matching threshold of this call: the value the model was built with, or conf's current one under the opt-in."""
+        c = self.conf
+        return float(c["match_threshold"]) if c.get("runtime_match_threshold", False) else self._match_threshold
 
     def forward_pairs(self, image0: torch.Tensor, image1: torch.Tensor) -> list:
         """`_forward` on B pairs at once (the batched dense driver): the per-pair dictionaries the wrapper would return for

@@ -21,6 +21,10 @@ class SuperGlue(BaseModel):
         "sinkhorn_iterations": 100,
         "match_threshold": 0.2,
     }
+    # The reference hands its conf to upstream once (`self.net = SG(conf)`, imcui/hloc/matchers/superglue.py:37; upstream's
+    # `self.config = {**self.default_config, **config}` is a copy), so sinkhorn_iterations and match_threshold are those of `_init`: the
+    # UI's later `matcher.conf["match_threshold"] = ...` on a cached model (imcui/ui/utils.py:921-922) changes nothing.  False (default)
+    # = exactly that; True = re-read both on every call (what the slider intends).  Not a reference key: read with conf.get("runtime_match_threshold", False), default_conf stays the reference's.
     required_inputs = [
         "image0",
         "keypoints0",
@@ -33,6 +37,7 @@ class SuperGlue(BaseModel):
     ]
 
     def _init(self, conf):
+        self._frozen = (int(conf["sinkhorn_iterations"]), float(conf["match_threshold"]))  # upstream's config copy (see default_conf)
         sd = resolve_state_dict(conf, "superglue")
         conf.pop("state_dict", None)
         self.conf.pop("state_dict", None)
@@ -42,11 +47,9 @@ class SuperGlue(BaseModel):
     def forward_batched(self, kpts0, kpts1, scores0, scores1, desc0, desc1, n0, n1, size0, size1) -> dict:
         """Row-per-point descriptors [B,N,256]; n0/n1 [B] int32 valid counts; sizes (W, H).
         Fixed-stride int32 outputs, no host synchronisation."""
-        c = self.conf  # read on every call: the UI mutates match_threshold at run time (imcui/ui/utils.py:921-922)
-        return self._impl.forward(
-            self.packed, kpts0, kpts1, scores0, scores1, desc0, desc1, n0, n1, size0, size1,
-            c["sinkhorn_iterations"], c["match_threshold"],
-        )  # fmt: skip
+        c = self.conf
+        iters, thr = (int(c["sinkhorn_iterations"]), float(c["match_threshold"])) if c.get("runtime_match_threshold", False) else self._frozen
+        return self._impl.forward(self.packed, kpts0, kpts1, scores0, scores1, desc0, desc1, n0, n1, size0, size1, iters, thr)
 
     def _forward(self, data):
         kpts0, kpts1 = data["keypoints0"], data["keypoints1"]

@@ -3,8 +3,9 @@ interpreter lock) into pinned staging, ONE transfer, the scan-line filters undon
 
 Replaces, for the batch drivers, the PNG half of `read_image` = `cv2.imread` (imcui/hloc/utils/io.py:11-21): the reference's own evaluation
 images (imcui/datasets/wxbs_benchmark/**.png) are PNG.  Output = what `extract_features.read_image_u8` returns for the file: [H,W] for gray
-(and gray + alpha) files, [H,W,3] RGB for RGB / RGBA / palette files (alpha dropped).  Bit-exact; the checker is PIL.  Interlaced files
-and bit depths other than 8 raise `PngUnsupported` (the caller keeps its host reader)."""
+(and gray + alpha) files, [H,W,3] RGB for RGB / RGBA / palette files (alpha dropped).  Bit-exact; the checker is PIL.  Interlaced files,
+bit depths other than 8 and files whose eXIf chunk asks for a rotation / mirror (cv2.imread and PIL apply it on load) raise `PngUnsupported`
+(the caller keeps its host reader)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -91,30 +92,40 @@ class PngDecoder:
         rc = lib.imcui_hip_png_inflate_batch(data_p, sizes, m, raws, rbytes, base + pal_off, status, self.threads)
         if rc != 0:
             raise backend.ImcuiHipError(f"imcui_hip_png_inflate_batch failed ({rc})")
+        for k, i in enumerate(live):
+            if status[k] != 0:
+                results[i] = PngUnsupported(f"imcui_hip_png_inflate: status {status[k]} (damaged stream)")
+        good = [k for k in range(m) if status[k] == 0]  # a refused file's staging is uninitialised: it gets no device job
+        if not good:
+            return results
+        g = len(good)
         hd = backend.get_handle(dev)
         staged = stage[:total].to(dev, non_blocking=True)
-        out_sizes = [infos[i][0] * infos[i][1] * infos[i][4] for i in live]
+        out_sizes = [infos[live[k]][0] * infos[live[k]][1] * infos[live[k]][4] for k in good]
         out_off, off = [], 0
         for s in out_sizes:
             out_off.append(off)
             off += (s + 255) // 256 * 256
         out = torch.empty(max(off, 1), dtype=torch.uint8, device=dev)
-        info_flat = (C.c_int * (INFO_INTS * m))()
-        for k, i in enumerate(live):
-            for q in range(INFO_INTS):
-                info_flat[k * INFO_INTS + q] = infos[i][q]
-        nbytes = lib.imcui_hip_png_workspace_bytes(info_flat, m)
+        info_flat = (C.c_int * (INFO_INTS * g))()
+        for q, k in enumerate(good):
+            for w in range(INFO_INTS):
+                info_flat[q * INFO_INTS + w] = infos[live[k]][w]
+        nbytes = lib.imcui_hip_png_workspace_bytes(info_flat, g)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        # palettes are indexed by job: compact the live files' palette slots the same way the jobs are
+        pal_ptr = staged.data_ptr() + pal_off
+        if g != m:
+            pal = staged[pal_off : pal_off + 768 * m].view(m, 768)[torch.tensor(good, device=dev)].contiguous()
+            pal_ptr = pal.data_ptr()
         with torch.cuda.device(dev):
-            rc = lib.imcui_hip_png_reconstruct_batch(hd.h, backend._ptr(staged), (C.c_size_t * m)(*raw_off), info_flat, staged.data_ptr() + pal_off, m, backend._ptr(out),
-                                                     (C.c_size_t * m)(*out_off), backend._ptr(ws), nbytes, backend._stream_ptr())  # fmt: skip
+            rc = lib.imcui_hip_png_reconstruct_batch(hd.h, backend._ptr(staged), (C.c_size_t * g)(*[raw_off[k] for k in good]), info_flat, pal_ptr, g, backend._ptr(out),
+                                                     (C.c_size_t * g)(*out_off), backend._ptr(ws), nbytes, backend._stream_ptr())  # fmt: skip
             hd.check(rc, "imcui_hip_png_reconstruct_batch")
-        for k, i in enumerate(live):
-            if status[k] != 0:
-                results[i] = PngUnsupported(f"imcui_hip_png_inflate: status {status[k]} (damaged stream)")
-                continue
+        for q, k in enumerate(good):
+            i = live[k]
             W, H, ch = infos[i][0], infos[i][1], infos[i][4]
-            t = out[out_off[k] : out_off[k] + out_sizes[k]]
+            t = out[out_off[q] : out_off[q] + out_sizes[q]]
             results[i] = t.view(H, W) if ch == 1 else t.view(H, W, 3)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))

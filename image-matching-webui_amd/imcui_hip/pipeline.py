@@ -120,15 +120,20 @@ class GraphedCall:
         dev = inputs[0].device
         self.fn = fn
         self.static_in = [t.clone() for t in inputs]
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):  # warm-up off the capture: workspaces reach their final size
+        # The graph's OWN stream, for the warm-up and for the capture: the C ABI's scratch is one buffer per (device, stream)
+        # (`backend._Workspace`) and a buffer handed out during a capture is pinned, so every graph pins a workspace of its own, sized by its
+        # own warm-up -- a later graph of a larger capacity (LightGlue 2048 key-points after 1024, a bigger SuperPoint image) no longer asks
+        # a pinned buffer to grow (torch.cuda.graph's default capture stream is shared by all graphs of the process), and the warm-up leaves no
+        # second buffer behind under a throw-away stream's key.  ADVICE round 5.
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):  # warm-up off the capture: workspaces reach their final size
             for _ in range(warmup):
                 fn(*self.static_in)
-        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             self.out = fn(*self.static_in)
 
     @torch.no_grad()

@@ -86,3 +86,15 @@ def decode(data: bytes) -> np.ndarray:
         full[: len(pal)] = pal
         return full[px[:, :, 0]]
     return px[:, :, :3].copy()
+
+
+def libpng_rgb_to_gray(rgb: np.ndarray) -> np.ndarray:
+    """Gray of a colour PNG as `cv2.imread(path, IMREAD_GRAYSCALE)` returns it (`read_image(path, grayscale=True)`,
+    imcui/hloc/utils/io.py:11-21): OpenCV's PNG reader asks libpng for it, `png_set_rgb_to_gray(png_ptr, 1, 0.299, 0.587)`
+    (modules/imgcodecs/src/grfmt_png.cpp).  libpng (pngrtran.c): `png_set_rgb_to_gray_fixed` scales the weights given in 1/100000 to
+    15 bits by integer division -- 29900 * 32768 / 100000 = 9797, 58700 * 32768 / 100000 = 19234, blue = 32768 - 9797 - 19234 = 3737 --
+    and `png_do_rgb_to_gray` (8-bit samples, no gamma tables: OpenCV sets no gamma) writes `(rc*r + gc*g + bc*b) >> 15`, the "historical
+    approach which simply truncates"; pixels with r == g == b are copied (the formula gives the same, the weights sum to 2^15).
+    Parity unpinned here (cv2 is not in the image); tests/test_png_cpu.py pins it to cv2.imread wherever cv2 is installed."""
+    c = np.asarray(rgb).astype(np.int64)
+    return ((9797 * c[..., 0] + 19234 * c[..., 1] + 3737 * c[..., 2]) >> 15).astype(np.uint8)

@@ -48,3 +48,48 @@ def test_plugins_replayed_from_graphs_equal_eager_launches(dc, wc):
         assert torch.equal(t, snap)
     assert len(m_g._graphs) >= 1 and all(v is not None for v in m_g._graphs.values()), "the capture fell back to eager launches"
     assert len(ext_g._graphs) == 1 and all(v is not None for v in ext_g._graphs.values())
+
+
+def test_graphs_of_growing_capacity_each_own_their_workspace():
+    """a second graph of the same plugin that needs a LARGER workspace (LightGlue capacity 1024 after 256, a bigger SuperPoint
+    image after a small one) must capture -- not fall back to eager launches because the first graph pinned the shared capture stream's
+    scratch -- and all graphs must keep replaying correctly afterwards, in any order."""
+    import warnings
+
+    from imcui_hip.hloc.extractors.superpoint import SuperPoint
+    from imcui_hip.hloc.matchers.lightglue import LightGlue
+
+    lsd, ssd = lightglue_state_dict(0), superpoint_state_dict(0)
+    lgc = {"depth_confidence": -1.0, "width_confidence": -1.0, "match_threshold": 0.1, "state_dict": lsd}
+    m_e, m_g = LightGlue(dict(lgc)).eval().to(DEV), LightGlue({**lgc, "hip_graph": True}).eval().to(DEV)
+    g = torch.Generator().manual_seed(5)
+
+    def pair(n):
+        k0, k1 = torch.rand(1, n, 2, generator=g) * torch.tensor([640.0, 480.0]), torch.rand(1, n, 2, generator=g) * torch.tensor([640.0, 480.0])
+        d0, d1 = torch.nn.functional.normalize(torch.randn(1, 256, n, generator=g), dim=1), torch.nn.functional.normalize(torch.randn(1, 256, n, generator=g), dim=1)
+        img = torch.zeros(1, 1, 480, 640)
+        return {k: v.to(DEV) for k, v in {"image0": img, "image1": img, "keypoints0": k0, "keypoints1": k1, "scores0": torch.rand(1, n, generator=g),
+                                          "scores1": torch.rand(1, n, generator=g), "descriptors0": d0, "descriptors1": d1}.items()}  # fmt: skip
+
+    pairs = [pair(n) for n in (200, 900, 1900, 250, 1000)]  # capacities 256, 1024, 1920, 256, 1024
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a capture that falls back warns: that is a failure here
+        with torch.no_grad():
+            for rnd in range(2):
+                for d in pairs:
+                    pe, pg = m_e(d), m_g(d)
+                    for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                        assert torch.equal(pe[k], pg[k]), (rnd, d["keypoints0"].shape, k)
+    assert len(m_g._graphs) == 3 and all(v is not None for v in m_g._graphs.values())
+    spc = {"nms_radius": 3, "max_keypoints": 512, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": ssd}
+    ext_e, ext_g = SuperPoint(dict(spc)).eval().to(DEV), SuperPoint({**spc, "hip_graph": True}).eval().to(DEV)
+    imgs = [make_pair_batch(80 + i, 1, h, w)[0].to(DEV) for i, (h, w) in enumerate(((120, 160), (480, 640), (240, 320), (120, 160)))]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            for rnd in range(2):
+                for im in imgs:
+                    a, b = ext_e({"image": im}), ext_g({"image": im})
+                    for k in ("keypoints", "scores", "descriptors"):
+                        assert torch.equal(a[k][0], b[k][0]), (rnd, tuple(im.shape), k)
+    assert len(ext_g._graphs) == 3 and all(v is not None for v in ext_g._graphs.values())

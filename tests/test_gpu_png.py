@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.png import libpng_rgb_to_gray
 from test_png_cpu import encode, pil_pixels, reference_files, synthetic_files, texture
 
 pytestmark = pytest.mark.gpu
@@ -79,6 +80,9 @@ def test_drivers_read_png_files_on_the_device(tmp_path):
         for p, got in zip(paths, batch):
             want = read_image_u8(p, gray)
             if p.suffix == ".png":
+                if gray:  # cv2.imread(IMREAD_GRAYSCALE): gray files as stored, colour files through libpng's rgb_to_gray (oracle/png.py)
+                    rgb = read_image_u8(p, False)
+                    assert want.ndim == 2 and np.array_equal(want, libpng_rgb_to_gray(rgb)), p.name
                 assert np.array_equal(got.cpu().numpy(), want), (p.name, gray)
                 assert np.array_equal(read_image_device(p, gray, torch.device(DEV), decode="device").cpu().numpy(), want), (p.name, gray)
             else:

@@ -92,8 +92,13 @@ def test_superglue_plugin_contract_and_empty():
     assert torch.equal(pred["matches0"].cpu(), ref["matches0"])
     assert torch.equal(pred["matches1"].cpu(), ref["matches1"])
     assert (pred["matching_scores0"].cpu() - ref["matching_scores0"]).abs().max().item() < 1e-4
-    # the UI mutates the threshold on the live model (imcui/ui/utils.py:921-922)
+    # the UI mutates the threshold on the live model (imcui/ui/utils.py:921-922): like the reference's `SG(conf)` copy, nothing changes ...
     model.conf["match_threshold"] = 0.9
+    with torch.no_grad():
+        same = model(data)
+    assert torch.equal(same["matches0"], pred["matches0"]) and torch.equal(same["matching_scores0"], pred["matching_scores0"])
+    # ... unless the plugin's opt-in says the conf is to be re-read on every call
+    model.conf["runtime_match_threshold"] = True
     with torch.no_grad():
         strict = model(data)
     ref9 = _oracle(SuperGlueOracle(SSD, {"sinkhorn_iterations": 20, "match_threshold": 0.9}), p)

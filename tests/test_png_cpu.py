@@ -204,3 +204,96 @@ def test_batch_inflate_equals_single_file_calls():
     assert rc == 0 and list(status)[:-1] == [0] * (n - 1) and status[n - 1] == -1
     for d, b in zip(files[:-1], bufs):
         assert np.array_equal(b, c_inflate(d)[1])
+
+
+def _chunks(data: bytes):
+    i, out = 8, []
+    while i + 12 <= len(data):
+        n = struct.unpack(">I", data[i : i + 4])[0]
+        out.append((data[i + 4 : i + 8], data[i + 8 : i + 8 + n]))
+        i += 12 + n
+    return out
+
+
+def _assemble(chunks) -> bytes:
+    return b"\x89PNG\r\n\x1a\n" + b"".join(struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b)) for t, b in chunks)
+
+
+def test_zlib_trailer_split_across_idat_chunks_is_a_valid_file():
+    """the adler32 trailer may straddle an IDAT boundary (libpng writes fixed-size IDATs, so this happens in the wild); with
+    the image already full, inflate is legally mid-trailer.  Every split position of the stream's last 6 bytes decodes; a stream that
+    holds MORE pixel data than the header promises is still refused; so is a corrupted trailer."""
+    lib = load_library()
+    arr = texture(21, 33, 47, 3)
+    good = encode(arr, "RGB")
+    ch = _chunks(good)
+    z = b"".join(b for t, b in ch if t == b"IDAT")
+    head = [c for c in ch if c[0] not in (b"IDAT", b"IEND")]
+    nb = 33 * (47 * 3 + 1)
+    for cut in range(1, 7):
+        for pieces in ([z[:-cut], z[-cut:]], [z[: len(z) // 2], z[len(z) // 2 : -cut], z[-cut:-1], z[-1:]], [z[:-cut], b"", z[-cut:]]):
+            data = _assemble(head + [(b"IDAT", p) for p in pieces] + [(b"IEND", b"")])
+            assert np.array_equal(pil_pixels(data), arr)
+            raw = np.zeros(nb + 16, np.uint8)
+            raw[nb:] = 0xA5
+            assert lib.imcui_hip_png_inflate(data, len(data), raw.ctypes.data, nb, None) == 0, (cut, [len(p) for p in pieces])
+            assert (raw[nb:] == 0xA5).all()
+            assert np.array_equal(op.decode(data), arr)
+    raw = np.zeros(nb, np.uint8)
+    bad = _assemble(head + [(b"IDAT", z[:-4]), (b"IDAT", bytes([z[-4] ^ 1]) + z[-3:]), (b"IEND", b"")])
+    assert lib.imcui_hip_png_inflate(bad, len(bad), raw.ctypes.data, nb, None) == -1  # adler32 mismatch
+    shorter = _with_ihdr(good, H=32)  # the stream now holds one scan line more than the image
+    raw = np.zeros(32 * (47 * 3 + 1) + 16, np.uint8)
+    raw[-16:] = 0xA5
+    assert lib.imcui_hip_png_inflate(shorter, len(shorter), raw.ctypes.data, len(raw) - 16, None) == -1
+    assert (raw[-16:] == 0xA5).all()
+
+
+def _exif(orientation: int, big_endian: bool) -> bytes:
+    e = ">" if big_endian else "<"
+    return (b"MM\x00*" if big_endian else b"II*\x00") + struct.pack(e + "I", 8) + struct.pack(e + "H", 1) + struct.pack(e + "HHIHH", 0x0112, 3, 1, orientation, 0) + struct.pack(e + "I", 0)
+
+
+def test_exif_orientation_is_left_to_the_host_reader():
+    """cv2.imread and PIL's exif_transpose rotate / mirror a PNG by its eXIf orientation; the device path does not, so it refuses such
+    files (status -4: the caller keeps its host reader) and takes orientation 1 / a chunk without the tag."""
+    lib = load_library()
+    info = (C.c_int * 8)()
+    good = encode(texture(22, 24, 36, 3), "RGB")
+    ch = _chunks(good)
+    for be in (False, True):
+        for o in range(1, 9):
+            data = _assemble(ch[:1] + [(b"eXIf", _exif(o, be))] + ch[1:])
+            assert np.array_equal(pil_pixels(data), pil_pixels(good))  # a valid file either way (PIL decodes the stored pixels)
+            assert lib.imcui_hip_png_info(data, len(data), info) == (0 if o == 1 else -4), (be, o)
+    for body in (b"", b"II*\x00\x08\x00\x00\x00\x00\x00", b"garbage!", _exif(3, False)[:12]):
+        data = _assemble(ch[:1] + [(b"eXIf", body)] + ch[1:])
+        assert lib.imcui_hip_png_info(data, len(data), info) == 0  # no readable orientation = 1, like the readers
+
+
+def test_gray_of_a_colour_png_is_libpngs(tmp_path):
+    """`read_image(path, grayscale=True)` on a colour PNG = cv2.imread(IMREAD_GRAYSCALE) = libpng's truncating 15-bit formula, not cvtColor's
+    (oracle/png.py: libpng_rgb_to_gray).  The host reader returns it (with cv2, or restated on top of PIL); pinned to cv2 where installed."""
+    from imcui_hip.hloc.extract_features import read_image_u8
+    from oracle.preprocess import rgb_to_gray_u8
+
+    rgb = texture(23, 50, 70, 3)
+    rgb[:5] = rgb[:5, :, :1]  # some r == g == b pixels: passed through
+    want = op.libpng_rgb_to_gray(rgb)
+    assert np.array_equal(want[:5], rgb[:5, :, 0])
+    n_diff = int((want != rgb_to_gray_u8(rgb)).sum())
+    assert 0 < n_diff and np.abs(want.astype(int) - rgb_to_gray_u8(rgb).astype(int)).max() == 1  # one level, on many pixels
+    for name, data in (("c.png", encode(rgb, "RGB")), ("a.png", encode(np.dstack([rgb, rgb[..., :1]]), "RGBA"))):
+        p = tmp_path / name
+        p.write_bytes(data)
+        assert np.array_equal(read_image_u8(p, True), want), name
+        assert np.array_equal(read_image_u8(p, False), rgb), name
+    pal = Image.fromarray(rgb).quantize(64)
+    pal.save(tmp_path / "q.png")
+    assert np.array_equal(read_image_u8(tmp_path / "q.png", True), op.libpng_rgb_to_gray(np.array(pal.convert("RGB"))))
+    g = tmp_path / "g.png"
+    g.write_bytes(encode(rgb[..., 0], "L"))
+    assert np.array_equal(read_image_u8(g, True), rgb[..., 0])
+    cv2 = pytest.importorskip("cv2")  # the pin: OpenCV's own reader on the same files
+    for name in ("c.png", "a.png", "q.png", "g.png"):
+        assert np.array_equal(cv2.imread(str(tmp_path / name), cv2.IMREAD_GRAYSCALE), read_image_u8(tmp_path / name, True)), name

@@ -51,7 +51,10 @@ json.dump({"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 
           open(os.path.join(P, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 akey = next(k for k in out if k.startswith("attn_split_kernel"))
 a = out[akey]
-json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_pairs": B,
+sys.path.insert(0, ROOT)
+from bench import sources_sha16  # noqa: E402  (hashes of the attention kernel's sources: bench.py flags a later change as `traffic_stale`)
+
+json.dump({"kernel": akey, "source": f"profiles/{tag}_pmc_traffic.json", "batch_pairs": B, "sources_sha16": sources_sha16(),
            "fetch_bytes_per_launch": a["fetch_bytes_per_launch"], "write_bytes_per_launch": a["write_bytes_per_launch"],
            "traffic_bytes_per_launch": a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"],
            "algorithmic_bytes_per_launch": 16777216 * B,
