@@ -1089,6 +1089,8 @@ def sources_sha16(paths=ATTENTION_SOURCES) -> dict:
 def _cross_variant(dev) -> int:
     """The attention variant LightGlue's cross blocks run (csrc/lightglue.hip): option attn_variant_cross, whose default -2 means 7 (two-product P.V)
     while attn_variant is the default kernel 8 and "follow attn_variant" otherwise; -1 = follow attn_variant."""
+    from imcui_hip import backend
+
     cv, av = backend.get_option(dev, "attn_variant_cross"), backend.get_option(dev, "attn_variant")
     return (7 if av == 8 else -1) if cv == -2 else cv
 

@@ -411,3 +411,25 @@ extern "C" int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const flo
     a.log2_domain = log2_domain;
     return attention_launch(h, a, (hipStream_t)stream);
 }
+extern "C" size_t imcui_hip_attention_mx_scratch_bytes(int S, int heads, int rows) { return (S > 0 && heads > 0 && rows > 0) ? attn_v6_bytes(S, heads, rows) : 0; }
+extern "C" int imcui_hip_attention_mx_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S, int heads, int rows, int cross,
+                                          void* scratch, size_t scratch_bytes, void* stream) {
+    if (!h || !Q || !K || !V || !O || !cnt || !scratch) return imcui_set_err(h, IMCUI_ERR_ARG, "attention (variant 9): null argument");
+    if (h->precision != 1) return imcui_set_err(h, IMCUI_ERR_UNSUPPORTED, "attention variant 9 belongs to the split arithmetic (imcui_hip_set_precision(h, 1))");
+    if (rows % 128 != 0 || (heads * S) % 8 != 0) return imcui_set_err(h, IMCUI_ERR_ARG, "attention (variant 9): rows %% 128 and (heads * S) %% 8 must be 0");
+    if (scratch_bytes < attn_v6_bytes(S, heads, rows)) return imcui_set_err(h, IMCUI_ERR_WS, "attention (variant 9): scratch of %zu bytes needed", attn_v6_bytes(S, heads, rows));
+    AttnP a;
+    a.Q = Q;
+    a.K = K;
+    a.V = V;
+    a.O = O;
+    a.cnt = cnt;
+    a.nseq = S;
+    a.heads = heads;
+    a.rows_per_seq = rows;
+    a.cross = cross;
+    a.log2_domain = 1;
+    a.variant = 9;
+    a.V6 = (unsigned char*)scratch;
+    return attention_launch(h, a, (hipStream_t)stream);
+}

@@ -23,5 +23,13 @@ struct AttnP {
     // >= 0: kernel variant for THIS launch (split mode, log2 domain) instead of the handle's "attn_variant" -- LightGlue routes its self and
     // cross blocks / a subset of its layers separately ("attn_variant_self", "attn_variant_cross", "attn_mix_layers": round 5)
     int variant = -1;
+    // variant 9 (attention_mx.hip): the fp6 planes of V^T, ATTN_V6_TILE_BYTES per (sequence, head, 64-key tile) -- caller-provided scratch of
+    // attn_v6_bytes(nseq, heads, rows_per_seq) bytes, filled by the launch itself from the f16 planes of V (v6_ready = 1: the producer of V
+    // already wrote it).  nullptr: variant 9 is not available for this launch and falls back to variant 8.
+    unsigned char* V6 = nullptr;
+    int v6_ready = 0;
 };
+#define ATTN_V6_TILE_BYTES 6400  // hi6 [128 slots][16 B] + [128][8 B], lo6 likewise, 256 scale bytes
+static inline size_t attn_v6_bytes(int nseq, int heads, int rows_per_seq) { return (size_t)nseq * heads * (rows_per_seq / 64) * ATTN_V6_TILE_BYTES; }
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);
+int attention_mx_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);  // attention_mx.hip

@@ -704,8 +704,12 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     dim3 grid((p.rows_per_seq / 128) * p.heads * p.nseq);
     imcui_prof_begin(h, PROF_ATTN, stream);
     if (h->precision == 1 && p.log2_domain) {
-        const int var = p.variant >= 0 ? p.variant : h->opt[OPT_ATTN_VARIANT];  // imcui_hip_set_option(h, "attn_variant", v)
-        if (p.single)
+        int var = p.variant >= 0 ? p.variant : h->opt[OPT_ATTN_VARIANT];  // imcui_hip_set_option(h, "attn_variant", v)
+        if (var == 9 && (p.V6 == nullptr || p.single)) var = 8;  // (callers without the fp6 scratch: SuperGlue, DUSt3R, the C-ABI block)
+        if (var == 9) {
+            const int rc = attention_mx_launch(h, p, stream);
+            if (rc != IMCUI_OK) return rc;
+        } else if (p.single)
             hipLaunchKernelGGL((attn_split_kernel<true, 4>), grid, dim3(256), 0, stream, p);
         else if (var == 6)
             hipLaunchKernelGGL((attn_split_kernel<true, 6>), grid, dim3(256), 0, stream, p);

@@ -22,6 +22,22 @@
 #include "gemm_tile.h"
 
 #define WR_BN 256
+// tools/wreg_lab.hip compiles this file with WR_LAB: a device word of switches that knock out parts of the kernel (timing experiments: what the
+// launch waits for).  In the product build the word is the constant 0 and every test below folds away.
+#ifdef WR_LAB
+__device__ int wr_lab_flags = 0;
+#define WR_FLAGS (__builtin_amdgcn_readfirstlane(wr_lab_flags))
+#else
+#define WR_FLAGS 0
+#endif
+#define WR_F_NOSTORE 1   // no global stores in the epilogue
+#define WR_F_ONETILE 2   // one K tile instead of K / 32
+#define WR_F_NOEPI 4     // return after the main loop
+#define WR_F_NOWLOAD 8   // weights loaded for the first two k-steps only (registers re-used)
+#define WR_F_NOXLOAD 16  // activations loaded / staged for the first tile only
+// bits 8..15: the workgroups of the SECOND dispatch round (ids [ncu, 2 ncu): the second resident workgroup of every CU) start this many
+// ~0.5 us later, so that the two workgroups of a CU run their matrix loop / their epilogue in opposite phases
+#define WR_F_STAGGER(f) (((f) >> 8) & 255)
 #define WR_STG_ROW 68    // floats per parked [token][64 features] row (272 B: conflict-free 16-byte writes)
 #define WR_STG_TROW 36   // floats per parked [feature][32 tokens] row (144 B)
 #define WR_WAVE_LDS 9216  // staging bytes per wave (32 x 68 x 4 = 8704; 64 x 36 x 4 = 9216)
@@ -56,7 +72,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     if (!gemm_tile_setup(p, c, WR_BN, 32 * MT)) return;
     const float* A = p.A + (size_t)c.z * p.a_bs;
     const float wsc = p.wscale ? p.wscale[c.wsel] : 1.0f;
-    const int nkt = p.K >> 5, nks = p.K >> 4;
+    const int labf = WR_FLAGS;
+    if (WR_F_STAGGER(labf) != 0 && (int)blockIdx.x >= p.st_nct && (int)blockIdx.x < 2 * p.st_nct)  // (lab: st_nct carries the CU count)
+        for (int i = 0; i < WR_F_STAGGER(labf); ++i) __builtin_amdgcn_s_sleep(16);
+    const int nkt = (labf & WR_F_ONETILE) ? 1 : p.K >> 5, nks = 2 * nkt;
 
     f32x16 acc[2][MT];
 #pragma unroll
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int nf = min((c.col0 >> 5) + 2 * wid + n, nfr - 1);
-        wof[n] = (unsigned)((nf * nks) * 64 + lane) * 16u;
+        wof[n] = (unsigned)((nf * (p.K >> 4)) * 64 + lane) * 16u;
     }
     uint4 wc[2][2], wn[2][2];  // [feature fragment][plane] of the current / next k-step (rolled loop)
     auto loadw = [&](int s, uint4(&w)[2][2]) __attribute__((always_inline)) {
@@ -173,15 +192,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
 #define WR_TILE(KT, WA, WB, WC)                                  \
     {                                                            \
         const int kt_ = (KT), stg_ = kt_ & 1, s_ = 2 * kt_;      \
-        if (s_ + 2 < nks) loadw(s_ + 2, WC);                     \
+        if (s_ + 2 < nks && !(labf & WR_F_NOWLOAD)) loadw(s_ + 2, WC); \
         __builtin_amdgcn_sched_barrier(0);                       \
         kstep(stg_, 0, WA);                                      \
         __builtin_amdgcn_sched_barrier(0);                       \
-        if (kt_ + 1 < nkt) {                                     \
+        if (kt_ + 1 < nkt && !(labf & WR_F_NOXLOAD)) {           \
             store(stg_ ^ 1);                                     \
             if (kt_ + 2 < nkt) issue(kt_ + 2);                   \
         }                                                        \
-        if (s_ + 3 < nks) loadw(s_ + 3, WA);                     \
+        if (s_ + 3 < nks && !(labf & WR_F_NOWLOAD)) loadw(s_ + 3, WA); \
         __builtin_amdgcn_sched_barrier(0);                       \
         kstep(stg_, 1, WB);                                      \
         __syncthreads();                                         \
@@ -222,6 +241,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     float* st = reinterpret_cast<float*>(sm + wid * WR_WAVE_LDS);
     const int fw0 = c.col0 + 64 * wid;  // first feature of this wave
     if (fw0 >= c.N) return;            // (no workgroup barrier below)
+    if (labf & WR_F_NOEPI) {
+        if (acc[0][0][0] == 12345.678f) p.C[0] = acc[1][MT - 1][3];  // (keeps the accumulators alive)
+        return;
+    }
+    const bool do_store = !(labf & WR_F_NOSTORE);
     // LayerNorm folded into this layer: per-feature row sums of the (gamma-folded) weights, per-token (mean, rstd) of the raw input
     const float* lrs = nullptr;
     if constexpr (EPI == EPI_QKV_VIT || EPI == EPI_CONV) {
@@ -323,8 +347,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                     uint4 hv, lv;
                     split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
                     unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * R + i0 + 32 * m + tl) * 64 + d0;
-                    *reinterpret_cast<uint4*>(o) = hv;
-                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    if (do_store) {
+                        *reinterpret_cast<uint4*>(o) = hv;
+                        *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    }
                 }
                 wr_wave_fence();
             }
@@ -382,8 +408,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                     uint4 hv, lv;
                     split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hv, lv);
                     unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * R + i0 + 32 * m + tl) * 64 + d0;
-                    *reinterpret_cast<uint4*>(o) = hv;
-                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    if (do_store) {
+                        *reinterpret_cast<uint4*>(o) = hv;
+                        *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    }
                 }
                 wr_wave_fence();
             }
@@ -412,8 +440,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                     uint4 hv, lv;
                     split8(make_float4(va.x + bd, va.y + bd, va.z + bd, va.w + bd), make_float4(vb.x + bd, vb.y + bd, vb.z + bd, vb.w + bd), hv, lv);
                     unsigned short* o = d16 + (((size_t)c.seq * p.heads + hd) * 64 + d) * R + i0 + 32 * m + tk;
-                    *reinterpret_cast<uint4*>(o) = hv;
-                    *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    if (do_store) {
+                        *reinterpret_cast<uint4*>(o) = hv;
+                        *reinterpret_cast<uint4*>(o + p.plane_halves) = lv;
+                    }
                 }
                 wr_wave_fence();
             }
@@ -474,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
                         v[2] += o4.z;
                         v[3] += o4.w;
                     }
-                    *reinterpret_cast<float4*>(dstp) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (do_store) *reinterpret_cast<float4*>(dstp) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
             wr_wave_fence();

@@ -1415,6 +1415,23 @@ def attention_f32(q, k, v, cnt, cross=False, log2_domain=False):
     return o
 
 
+def attention_mx_f32(q, k, v, cnt, cross=False):
+    """`attention_f32(..., log2_domain=True)` in attention variant 9 (csrc/attention_mx.hip: P.V as one f16 product + two block-scaled fp6
+    correction products); split arithmetic only."""
+    hd = get_handle(q.device)
+    S, Hh, R, d = q.shape
+    assert d == 64
+    q = _split_planes(q.float() * 1.4426950408889634)
+    k, v = _split_planes(k.float()), _split_planes(v.float().transpose(2, 3).contiguous())
+    o = torch.zeros((S * R, Hh * 64), dtype=torch.float32, device=q.device)
+    cnt = cnt.to(torch.int32).contiguous()
+    nbytes = hd.lib.imcui_hip_attention_mx_scratch_bytes(S, Hh, R)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        hd.check(hd.lib.imcui_hip_attention_mx_f32(hd.h, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(cnt), S, Hh, R, int(cross), _ptr(scratch), nbytes, _stream_ptr()), "attention (variant 9)")
+    return o
+
+
 def simple_nms(scores: torch.Tensor, radius: int) -> torch.Tensor:
     hd = get_handle(scores.device)
     scores = scores.contiguous().float()

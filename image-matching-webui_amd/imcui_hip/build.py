@@ -12,7 +12,7 @@ CSRC = os.path.normpath(os.path.join(PKG_DIR, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "..", "include"))
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libimcui_hip.so")
-SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "png.hip", "geometry.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "simred.hip", "conv.hip", "attention.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "jpeg.hip", "png.hip", "geometry.hip", "gemm.hip", "gemm_wreg.hip", "ffn.hip", "simred.hip", "conv.hip", "attention.hip", "attention_mx.hip", "superpoint.hip", "lightglue.hip", "superglue.hip", "nn.hip", "dual_softmax.hip", "loftr.hip", "eloftr.hip", "dust3r.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}"]
 # Per-source code-generation switches.  preprocess.hip restates host float32 arithmetic that rounds after every
@@ -38,7 +38,7 @@ def needs_build() -> bool:
 # MFMA kernels whose register budget is part of the design: a build that spills them to scratch is rejected (two
 # experimental builds of the split GEMM that spilled -- 128-VGPR and 168-VGPR-with-20-B-scratch variants -- were
 # slower AND failed the parity / determinism tests on the GPU; hipcc is not to be trusted with spills around them).
-NO_SPILL_KERNELS = ("simred_kernel", "gemm_split_kernel", "gemm_wreg_kernel", "gemm_kernel", "attn_split_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_tall_kernel", "conv3x3_kernel", "lg_ffn_kernel")
+NO_SPILL_KERNELS = ("simred_kernel", "gemm_split_kernel", "gemm_wreg_kernel", "gemm_kernel", "attn_split_kernel", "attn_mx_kernel", "attn_kernel", "conv3x3_split_kernel", "conv3x3_tall_kernel", "conv3x3_kernel", "lg_ffn_kernel")
 
 
 def _check_no_spills(src: str, remarks: str) -> None:

@@ -193,6 +193,8 @@ SIGNATURES = {
     "imcui_hip_conv3x3_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imcui_hip_conv3x3_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 7 + [C.c_void_p]),
     "imcui_hip_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
+    "imcui_hip_attention_mx_scratch_bytes": (C.c_size_t, [C.c_int] * 3),
+    "imcui_hip_attention_mx_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 

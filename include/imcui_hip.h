@@ -582,6 +582,13 @@ int imcui_hip_conv_gemm_f32(imcui_hip_t* h, const float* in_nhwc, const float* w
  * SuperGlue layers do: one v_exp_f32 per probability, no multiply); 0: natural-log operands. */
 int imcui_hip_attention_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,
                             int heads, int rows, int cross, int log2_domain, void* stream);
+/* The same block in attention variant 9 (round 6; split mode, log2 domain only: what LightGlue's layers run when option "attn_variant" = 9):
+ * K.Q^T in three f16 products, P.V as one f16 product + two block-scaled fp6 correction products (csrc/attention_mx.hip).  Operands as
+ * for imcui_hip_attention_f32 in mode 1 (pre-split planes; the lo plane of V^T is read once, to build the fp6 planes); `scratch` [dev,
+ * imcui_hip_attention_mx_scratch_bytes(S, heads, rows)] receives the fp6 planes of V^T. */
+size_t imcui_hip_attention_mx_scratch_bytes(int S, int heads, int rows);
+int imcui_hip_attention_mx_f32(imcui_hip_t* h, const float* Q, const float* K, const float* V, float* O, const int* cnt, int S,
+                               int heads, int rows, int cross, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }
