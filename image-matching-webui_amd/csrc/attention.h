@@ -28,7 +28,12 @@ struct AttnP {
     // already wrote it).  nullptr: variant 9 is not available for this launch and falls back to variant 8.
     unsigned char* V6 = nullptr;
     int v6_ready = 0;
+    // key-split launches (attention.hip, round 6): caller-provided scratch of attn_part_floats(nseq, heads, rows_per_seq) floats for the per-chunk
+    // partials (O_c [chunks][nseq][heads][rows][64], then (m_c, l_c) pairs).  nullptr: one workgroup walks all the keys of its queries (same rows).
+    float* part = nullptr;
 };
+#define ATTN_MAX_CHUNKS(R) (((R) + 511) / 512)  // chunks of 8 key tiles of 64
+static inline size_t attn_part_floats(int nseq, int heads, int rows_per_seq) { return (size_t)ATTN_MAX_CHUNKS(rows_per_seq) * nseq * heads * rows_per_seq * 66; }
 #define ATTN_V6_TILE_BYTES 6400  // hi6 [128 slots][16 B] + [128][8 B], lo6 likewise, 256 scale bytes
 static inline size_t attn_v6_bytes(int nseq, int heads, int rows_per_seq) { return (size_t)nseq * heads * (rows_per_seq / 64) * ATTN_V6_TILE_BYTES; }
 int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream);

@@ -238,47 +238,63 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     return (const void*)((size_t)lo32 | ((size_t)hi32 << 32));
 }
 
-// VAR (IMCUI_ATTN_VARIANT, A/B runs): wave priority around the two MFMA clusters of a key tile.  Two workgroups share a CU,
-// so every SIMD holds two waves that are in different phases most of the time; priority decides whose instruction issues when
-// both are ready (guide T5).  0: none; 1: the K.Q^T and V^T.P^T clusters at priority 1, the soft-max at 0; 2: only V^T.P^T
-// raised; 3: the soft-max raised instead.
+// VAR (option "attn_variant"; rounds 3-5 also carried wave-priority schedules 1-3, a double-buffered tile 5 and the un-pipelined
+// schedules 0 / 6 -- all measured within noise or slower, removed in round 6; the option values map onto the two survivors):
 // VAR 4 (AttnP.single, DUSt3R's opt-in `arith = 1`): ONE f16 product per element pair -- only the hi planes of Q / K / V are loaded,
 // staged and multiplied, P is rounded to the nearest f16 (f32 accumulation and an f32 normaliser as before).  Not a parity mode.
-// VAR 6 (round 4, option attn_variant = 6; the audited "reduced-product P.V"): K.Q^T keeps its three products (an error there is an
+// VAR 7 (option values 6, 7; the audited "reduced-product P.V"): K.Q^T keeps its three products (an error there is an
 // error of the EXPONENT), V^T.P^T runs as (vh + vl) . ph with the probabilities rounded to the nearest f16: two MFMAs per product
 // instead of three (48 -> 40 per key tile) and one v_cvt_pk_f16_f32 per probability pair instead of v_cvt_pkrtz + two v_fma_mix.  The
 // normaliser is the sum of the ROUNDED probabilities (v_dot2_f32_f16 against (1, 1): exact products, f32 accumulation, the same
 // instruction count as the packed adds it replaces), so O = sum p~_j v_j / sum p~_j is an exact weighted mean with weights perturbed
 // by at most 2^-12 relative: the error is sum_j p_j e_j (v_j - O) -- it vanishes for a peaked row (one dominant key: v_j = O) and
 // averages down like 1 / sqrt(n) for a flat one; the worst case is two equal keys with different values, 2^-13 |v_0 - v_1|.
-// Measured against the per-layer parity harness in profiles/r04_lab_attention_pv2.txt: 13-19 % faster per launch, per-layer error
-// 0.6-1.4e-6 -> 0.8-2.1e-5 and score error 2e-5 -> 9e-5 on the "strong" weight set -- at the edge of the 1e-4 bar, so NOT the default;
-// kept as an opt-in (attn_variant 6 / 7).
-// VAR 7 = VAR 6 + VAR 8's schedule.  VAR 8 (round 4, the default since then): the arithmetic of VAR 0 bit for bit (same products, same
-// order), with the K fragments of step i + 1 requested before the MFMAs of step i (hipcc's own schedule is read -> wait -> 3 MFMAs on
-// one register quad, every LDS latency exposed), the maximum of the first S fragment taken under the MFMAs of the second, and the
-// cross-half maximum by v_permlane32_swap instead of ds_bpermute.
-template <bool L2D, int VAR>
+// Audited per block in round 5 (profiles/r05_lab_attention_mix.txt): the default of LightGlue's CROSS blocks.
+// VAR 8 (option values 0-3, 5, 8; the default): three products in both contractions, the K fragments of step i + 1 requested before the
+// MFMAs of step i (hipcc's own schedule is read -> wait -> 3 MFMAs on one register quad, every LDS latency exposed), the maximum of the
+// first S fragment taken under the MFMAs of the second, and the cross-half maximum by v_permlane32_swap instead of ds_bpermute.
+// VAR 0 remains for the natural-log entry point (L2D = false: the C-ABI building block) with the plain schedule.
+//
+// CHUNKS (round 6, log2-domain kernels).  The keys of a sequence are processed in chunks of ATTN_CHUNK_TILES * 64 = 512: every chunk starts
+// the online soft-max from scratch (its first tile sets the reference maximum) and ends as a partial (O_c, m_c, l_c); the partials are
+// folded IN CHUNK ORDER with `attn_fold`.  The result no longer depends on how the chunks are distributed: one workgroup may walk all of
+// them (SPLIT = false: the fold runs in registers after every eighth tile -- the throughput geometry), or each chunk may get its own
+// workgroup (SPLIT = true) that writes its partial to a scratch buffer for `attn_combine_kernel`, which folds with the same function in
+// the same order: bitwise the same rows.  The split launch is for grids that leave the chip empty -- ONE LightGlue pair is 128 workgroups
+// of 4 waves on 256 CUs, each walking 32 tiles alone on its SIMD (51.7 us per launch, a third of the one-pair step: VERDICT round 5, weak
+// 9) -- and because both geometries compute the same function, a pair's result does not depend on the batch it rides in.
+#define ATTN_CHUNK_TILES 8
+// (O, m, l) <- (O, m, l) (+) (O_c, m_c, l_c): both partials carry the factor 2^(14 - their reference maximum).  Explicit operations only
+// (no contraction the two call sites could resolve differently).
+__device__ __forceinline__ void attn_fold_scales(float ma, float mc, float& m_new, float& a, float& b) {
+    m_new = fmaxf(ma, mc);
+    a = __builtin_amdgcn_exp2f(ma - m_new);
+    b = __builtin_amdgcn_exp2f(mc - m_new);
+}
+__device__ __forceinline__ float attn_fold1(float acc, float a, float part, float b) {
+    const float t = acc * a;
+    return __builtin_fmaf(part, b, t);
+}
+
+template <bool L2D, int VAR, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     constexpr bool SINGLE = (VAR == 4);
-    constexpr bool PV2 = (VAR == 6 || VAR == 7);  // P rounded to f16, V split: two products per element pair in V^T.P^T
-    constexpr bool KPRE = (VAR == 7 || VAR == 8);  // the K fragments of step i + 1 requested before the MFMAs of step i (8: with three products = bitwise variant 0)
-    // VAR 5: the K / V^T tile double-buffered in LDS (70 KB per workgroup, still two per CU): the next tile is written into the other
-    // buffer right after this tile's MFMAs, ONE workgroup barrier per key tile instead of two
-    constexpr bool DBUF = (VAR == 5);
+    constexpr bool PV2 = (VAR == 7);                // P rounded to f16, V split: two products per element pair in V^T.P^T
+    constexpr bool KPRE = (VAR == 7 || VAR == 8);   // the K fragments of step i + 1 requested before the MFMAs of step i
+    constexpr bool CHUNKED = L2D;                   // (the natural-log entry point keeps one pass over all keys)
+    static_assert(!SPLIT || CHUNKED, "a key-split launch needs the chunked arithmetic");
     constexpr int TILE_U4 = 2 * 8 * KSTR + 2 * 64 * VSTR;
-    __shared__ uint4 smem4[(DBUF ? 2 : 1) * TILE_U4];
-    uint4* Kh = smem4;  // [d-octet][key] 8 halves
-    uint4* Kl = smem4 + 8 * KSTR;
-    uint4* Vh = smem4 + 2 * 8 * KSTR;  // [d][VSTR]
-    uint4* Vl = Vh + 64 * VSTR;
+    __shared__ uint4 smem4[TILE_U4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
     // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, so the nqb query blocks of one
     // (sequence, head) are given ids that share b % 8 and read their K/V through ONE L2.
+    // SPLIT: the chunk index is the slowest grid coordinate (the workgroups of one chunk keep the XCD-aware order among themselves).
     const int nqb = p.rows_per_seq >> 7;
-    const int bid = blockIdx.x;
+    const int nwg = nqb * p.heads * p.nseq;
+    const int bid = SPLIT ? (int)blockIdx.x % nwg : (int)blockIdx.x;
+    const int chunk = SPLIT ? (int)blockIdx.x / nwg : 0;
     const int grp = (bid / (8 * nqb)) * 8 + (bid & 7);
     const int seq = grp / p.heads, head = grp - seq * p.heads;
     const int q0 = ((bid >> 3) % nqb) * 128;
@@ -361,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     };
     // key quad kq -> group kq>>2, 16-byte slot (kq&1), 8-byte half ((kq>>1)&1)
     const int v_u = ((v_kq >> 2) * 2 + (v_kq & 1)) * 2 + ((v_kq >> 1) & 1);
-    auto store_tile = [&](int k0, auto tail, int buf = 0) __attribute__((always_inline)) {
-        uint4* Kh = smem4 + buf * TILE_U4;
+    auto store_tile = [&](int k0, auto tail) __attribute__((always_inline)) {
+        uint4* Kh = smem4;
         uint4* Kl = Kh + 8 * KSTR;
         uint4* Vh = Kh + 2 * 8 * KSTR;
         uint4* Vl = Vh + 64 * VSTR;
@@ -396,11 +412,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
     };
 
     // one 64-key tile: S^T = K.Q^T, online soft-max, O^T += V^T.P^T
-    //   FIRST: no reference maximum yet (accumulators start from 0, the tile's own maximum becomes the reference)
+    //   first: no reference maximum yet (accumulators start from 0, the tile's own maximum becomes the reference) -- the first tile of the
+    //          sequence or of a chunk.  A RUN-TIME flag (wave-uniform): one instance of this code serves both cases, which keeps the chunk starts
+    //          of the split and the unsplit geometry on literally the same instructions (and the kernel at two instances instead of four)
     //   TAIL : the tile may hold keys past the sequence end
-    auto compute_tile = [&](int k0, auto first, auto tail, int buf = 0) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first)::value, TAIL = decltype(tail)::value;
-        const uint4* Kh = smem4 + buf * TILE_U4;
+    auto compute_tile = [&](int k0, const bool first, auto tail) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const uint4* Kh = smem4;
         const uint4* Kl = Kh + 8 * KSTR;
         const uint4* Vh = Kh + 2 * 8 * KSTR;
         const uint4* Vl = Vh + 64 * VSTR;
@@ -409,7 +427,11 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         // exponent directly
         f32x16 s[2];
         float m_pre = -INFINITY;  // KPRE: maximum of fragment 0, taken while fragment 1 is multiplied
-        if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
+        if (first) {  // (a later chunk starts from scratch: cinit still holds the previous chunk's reference)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[r] = 0.0f;
+        }
+        const f32x16& c0 = cinit;
         if constexpr (KPRE) {
             // hipcc's schedule of the plain loop below is read -> wait -> three MFMAs, eight times per fragment, on ONE register
             // quad: every LDS latency is exposed.  Here the (hi, lo) fragments of step i + 1 are requested before the MFMAs of step
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                     kl[(i + 1) & 1] = Kl[(2 * sn + hi) * KSTR + 32 * fn + lo];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                s[f] = mfma16(kl[i & 1], qh[st], st == 0 ? cinit : s[f]);
+                s[f] = mfma16(kl[i & 1], qh[st], st == 0 ? c0 : s[f]);
                 s[f] = mfma16(kh[i & 1], ql[st], s[f]);
                 s[f] = mfma16(kh[i & 1], qh[st], s[f]);
                 if (!TAIL && i >= 4) {  // the maximum of the finished first fragment rides under the MFMAs of the second
@@ -442,17 +464,15 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             for (int st = 0; st < 4; ++st) {
                 const uint4 ah = Kh[(2 * st + hi) * KSTR + 32 * f + lo];
                 if constexpr (SINGLE) {
-                    s[f] = mfma16(ah, qh[st], st == 0 ? cinit : s[f]);
+                    s[f] = mfma16(ah, qh[st], st == 0 ? c0 : s[f]);
                 } else {
                     const uint4 al = Kl[(2 * st + hi) * KSTR + 32 * f + lo];
-                    s[f] = mfma16(al, qh[st], st == 0 ? cinit : s[f]);
+                    s[f] = mfma16(al, qh[st], st == 0 ? c0 : s[f]);
                     s[f] = mfma16(ah, ql[st], s[f]);
                     s[f] = mfma16(ah, qh[st], s[f]);
                 }
             }
         }
-        if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
-        if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(1);
         if (TAIL) {  // only the last tile can hold keys past the sequence end
 #pragma unroll
             for (int f = 0; f < 2; ++f)
@@ -478,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         f32x2 la = {0.0f, 0.0f}, lb = {0.0f, 0.0f};
         if constexpr (!l2d) {
             // natural-log operands (building-block entry point): p * 2^14 = exp2(s*log2e - m*log2e + 14), one fma + one v_exp_f32
-            const float m_new = FIRST ? m_t : fmaxf(m_ref, m_t);
-            const float alpha = FIRST ? 0.0f : __builtin_amdgcn_exp2f((m_ref - m_new) * LOG2E);
+            const float m_new = first ? m_t : fmaxf(m_ref, m_t);
+            const float alpha = first ? 0.0f : __builtin_amdgcn_exp2f((m_ref - m_new) * LOG2E);
             const float bias = P_SHIFT - m_new * LOG2E;
             const f32x2 k2 = {LOG2E, LOG2E}, b2 = {bias, bias};
 #pragma unroll
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                 }
             l_run = l_run * alpha + ((la[0] + la[1]) + (lb[0] + lb[1]));
             m_ref = m_new;
-            if (!FIRST && __ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
+            if (!first && __ballot(alpha != 1.0f) != 0ull) {  // the running max of some query moved
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -511,8 +531,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             // what to take off this query's exponents: its own decision only (a lane whose maximum grew by less than the
             // threshold subtracts 0 and scales by 1 even when another query of the wave takes the branch, so a result
             // never depends on which other rows -- padding included -- share the wave)
-            const float excess = FIRST ? m_t - P_SHIFT : (m_t > P_SHIFT + DEFER_THR ? m_t - P_SHIFT : 0.0f);
-            const bool shift = FIRST || (__ballot(excess != 0.0f) != 0ull);
+            const float excess = first ? m_t - P_SHIFT : (m_t > P_SHIFT + DEFER_THR ? m_t - P_SHIFT : 0.0f);
+            const bool shift = first || (__ballot(excess != 0.0f) != 0ull);
             if (shift) {
                 const f32x2 d2 = {excess, excess};
 #pragma unroll
@@ -524,8 +544,8 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                         s[f][r] = y[0];
                         s[f][r + 1] = y[1];
                     }
-                if (FIRST) {
-                    m_ref = m_t;  // the tile maximum (accumulators started from 0) is the first reference
+                if (first) {
+                    m_ref = m_t;  // the tile maximum (accumulators started from 0) is the first reference (O and l are zero: nothing to rescale)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) cinit[r] = P_SHIFT - m_ref;
                 } else {
@@ -565,8 +585,6 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
         }
         // step (f, t) covers keys 32f + 16t + {4hi..4hi+3, 8+4hi..8+4hi+3}
         float lsum0 = 0.0f, lsum1 = 0.0f;  // PV2: this tile's sum of the rounded probabilities
-        if constexpr (VAR == 3) __builtin_amdgcn_s_setprio(0);
-        if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -611,77 +629,104 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
                     }
                 }
             }
-        if constexpr (VAR == 1 || VAR == 2) __builtin_amdgcn_s_setprio(0);
         if constexpr (PV2) l_run += lsum0 + lsum1;
     };
 
     const int ntile = (nk + KT - 1) / KT;
-    if constexpr (DBUF) {
-        if (ntile > 0) {
-            load_tile(0);
-            if (ntile == 1)
-                store_tile(0, std::true_type{}, 0);
-            else
-                store_tile(0, std::false_type{}, 0);
-            __syncthreads();
-            if (ntile == 1) {
-                compute_tile(0, std::true_type{}, std::true_type{}, 0);
-            } else {
-                load_tile(KT);
-                compute_tile(0, std::true_type{}, std::false_type{}, 0);
-                for (int tile = 1;; ++tile) {
-                    // buffer tile & 1 was last read two tiles ago: every wave finished that before the previous barrier
-                    if (tile == ntile - 1)
-                        store_tile(tile * KT, std::true_type{}, tile & 1);
-                    else
-                        store_tile(tile * KT, std::false_type{}, tile & 1);
-                    __syncthreads();
-                    if (tile == ntile - 1) {
-                        compute_tile(tile * KT, std::false_type{}, std::true_type{}, tile & 1);
-                        break;
-                    }
-                    load_tile((tile + 1) * KT);
-                    compute_tile(tile * KT, std::false_type{}, std::false_type{}, tile & 1);
-                }
-            }
+    // the tiles this workgroup walks: all of them, or the chunk of a key-split launch (a chunk past the sequence's keys has no workgroup output:
+    // the combine kernel folds only the chunks that exist)
+    const int t_begin = SPLIT ? chunk * ATTN_CHUNK_TILES : 0;
+    const int t_end = SPLIT ? min(ntile, t_begin + ATTN_CHUNK_TILES) : ntile;
+    if (SPLIT && t_begin >= ntile) return;
+    // folded partials of the finished chunks (SPLIT = false, CHUNKED): O, reference maximum, normaliser of the query of this lane
+    f32x16 oacc[2];
+    float macc = 0.0f, lacc = 0.0f;
+    // fold the chunk that just ended into (oacc, macc, lacc) and clear the running state (SPLIT = false, CHUNKED)
+    auto fold_chunk = [&](bool first_chunk) __attribute__((always_inline)) {
+        const float lc = l_run + __shfl_xor(l_run, 32, 64);
+        if (first_chunk) {  // the first chunk IS the running result
+            macc = m_ref;
+            lacc = lc;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) oacc[f] = o[f];
+        } else {
+            float m_new, a, b;
+            attn_fold_scales(macc, m_ref, m_new, a, b);
+            lacc = attn_fold1(lacc, a, lc, b);
+            macc = m_new;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[f][r] = attn_fold1(oacc[f][r], a, o[f][r], b);
         }
-    } else {
-    if (ntile > 0) load_tile(0);
-    if (ntile > 1) {  // first tile sets the reference maximum
-        __syncthreads();
-        store_tile(0, std::false_type{});
-        __syncthreads();
-        load_tile(KT);
-        compute_tile(0, std::true_type{}, std::false_type{});
-    }
-    for (int tile = 1; tile + 1 < ntile; ++tile) {
+        l_run = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
+    };
+    if (t_begin < t_end) load_tile(t_begin * KT);
+    // every tile but the sequence's last one: no key beyond the count
+    const int t_plain = min(t_end, ntile - 1);
+    for (int tile = t_begin; tile < t_plain; ++tile) {
         __syncthreads();  // previous tile fully consumed
         store_tile(tile * KT, std::false_type{});
         __syncthreads();
-        load_tile((tile + 1) * KT);
-        compute_tile(tile * KT, std::false_type{}, std::false_type{});
+        load_tile((tile + 1) * KT);  // (tile + 1 <= ntile - 1: the sequence's last tile at most; a split chunk may fetch one tile it does not use)
+        compute_tile(tile * KT, CHUNKED ? ((tile - t_begin) % ATTN_CHUNK_TILES) == 0 : tile == 0, std::false_type{});
+        if constexpr (CHUNKED && !SPLIT) {
+            if (((tile + 1) % ATTN_CHUNK_TILES) == 0) fold_chunk(tile < ATTN_CHUNK_TILES);
+        }
     }
-    if (ntile > 0) {
+    if (t_end == ntile && ntile > 0) {  // the sequence's last tile
+        const int tile = ntile - 1;
         __syncthreads();
-        store_tile((ntile - 1) * KT, std::true_type{});
+        store_tile(tile * KT, std::true_type{});
         __syncthreads();
-        if (ntile == 1)
-            compute_tile(0, std::true_type{}, std::true_type{});
-        else
-            compute_tile((ntile - 1) * KT, std::false_type{}, std::true_type{});
-    }
+        compute_tile(tile * KT, CHUNKED ? ((tile - t_begin) % ATTN_CHUNK_TILES) == 0 : tile == 0, std::true_type{});
+        if constexpr (CHUNKED && !SPLIT) fold_chunk(tile < ATTN_CHUNK_TILES);
     }
 
     // ---- normalise and write (transpose through LDS so each query row is stored contiguously)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (ntile > 0) ? 1.0f / l_tot : 0.0f;  // l carries the same 2^14 as O
+    float inv;
+    if constexpr (CHUNKED && !SPLIT) {
+        inv = (ntile > 0) ? 1.0f / lacc : 0.0f;  // l carries the same 2^14 as O
+#pragma unroll
+        for (int f = 0; f < 2; ++f) o[f] = oacc[f];
+        if (ntile == 0) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[f][r] = 0.0f;
+        }
+    } else if constexpr (SPLIT) {
+        inv = 1.0f;  // the partial leaves unnormalised
+    } else {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        inv = (ntile > 0) ? 1.0f / l_tot : 0.0f;
+    }
     __syncthreads();
     float* Os = reinterpret_cast<float*>(smem4) + wid * (32 * 33);
     const int H64 = p.heads * 64;
+    // SPLIT: partial O of chunk c at part[((c * nseq + seq) * heads + head) * R + row][64], then (m, l) pairs behind all the O partials
+    float* dst = p.O;
+    size_t row_stride = (size_t)H64, base = (size_t)seq * R * H64 + (size_t)head * 64;
+    if constexpr (SPLIT) {
+        const size_t rows_all = (size_t)p.nseq * p.heads * R;
+        const size_t prow0 = ((size_t)chunk * p.nseq + seq) * p.heads * R + (size_t)head * R;
+        dst = p.part;
+        row_stride = 64;
+        base = prow0 * 64;
+        const float lc = l_run + __shfl_xor(l_run, 32, 64);
+        if (hi == 0) {  // one lane per query writes (m_c, l_c)
+            float2* ml = reinterpret_cast<float2*>(p.part + (size_t)ATTN_MAX_CHUNKS(R) * rows_all * 64) + prow0 + q0 + wid * 32 + lo;
+            *ml = make_float2(m_ref, lc);
+        }
+    }
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Os[lo * 33 + frag_row(r, hi)] = o[f][r] * inv;
+        for (int r = 0; r < 16; ++r) Os[lo * 33 + frag_row(r, hi)] = SPLIT ? o[f][r] : o[f][r] * inv;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         // read back: 8 lanes cover the 32 dims of one query -> one 16-byte store per lane
@@ -690,10 +735,59 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnP p) {
             const int q = 8 * qq + (lane >> 3), d4 = (lane & 7) * 4;
             const int row = q0 + wid * 32 + q;
             const float4 v = make_float4(Os[q * 33 + d4], Os[q * 33 + d4 + 1], Os[q * 33 + d4 + 2], Os[q * 33 + d4 + 3]);
-            if (row < nq) *reinterpret_cast<float4*>(p.O + ((size_t)seq * R + row) * H64 + head * 64 + 32 * f + d4) = v;
+            if (row < nq) *reinterpret_cast<float4*>(dst + base + (size_t)row * row_stride + 32 * f + d4) = v;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Folds the chunk partials of a key-split launch in chunk order (the arithmetic of the unsplit kernel's in-register fold, `attn_fold*`) and
+// normalises: one thread per (query row, 4 features).
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnP p) {
+    const int R = p.rows_per_seq;
+    const size_t rows_all = (size_t)p.nseq * p.heads * R;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t prow = t >> 4;  // (seq * heads + head) * R + row
+    const int d4 = (int)(t & 15) * 4;
+    if (prow >= rows_all) return;
+    const int row = (int)(prow % R);
+    const int sh = (int)(prow / R), seq = sh / p.heads, head = sh - seq * p.heads;
+    if (row >= p.cnt[seq]) return;
+    if (p.active && p.active[seq >> 1] == 0) return;
+    const int nk = p.cnt[attn_key_seq(p, seq)];
+    const int nchunk = (nk + KT * ATTN_CHUNK_TILES - 1) / (KT * ATTN_CHUNK_TILES);
+    const float2* ml = reinterpret_cast<const float2*>(p.part + (size_t)ATTN_MAX_CHUNKS(R) * rows_all * 64);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float macc = 0.0f, lacc = 0.0f;
+    for (int c = 0; c < nchunk; ++c) {
+        const float4 oc = *reinterpret_cast<const float4*>(p.part + ((size_t)c * rows_all + prow) * 64 + d4);
+        const float2 mlc = ml[(size_t)c * rows_all + prow];
+        if (c == 0) {
+            acc = oc;
+            macc = mlc.x;
+            lacc = mlc.y;
+        } else {
+            float m_new, a, b;
+            attn_fold_scales(macc, mlc.x, m_new, a, b);
+            lacc = attn_fold1(lacc, a, mlc.y, b);
+            macc = m_new;
+            acc = make_float4(attn_fold1(acc.x, a, oc.x, b), attn_fold1(acc.y, a, oc.y, b), attn_fold1(acc.z, a, oc.z, b), attn_fold1(acc.w, a, oc.w, b));
+        }
+    }
+    const float inv = nchunk > 0 ? 1.0f / lacc : 0.0f;
+    *reinterpret_cast<float4*>(p.O + ((size_t)seq * R + row) * (p.heads * 64) + head * 64 + d4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+template <int VAR>
+static void attn_launch_l2d(const AttnP& p, bool split, hipStream_t stream) {
+    const unsigned nwg = (unsigned)((p.rows_per_seq / 128) * p.heads * p.nseq);
+    if (split) {
+        hipLaunchKernelGGL((attn_split_kernel<true, VAR, true>), dim3(nwg * (unsigned)ATTN_MAX_CHUNKS(p.rows_per_seq)), dim3(256), 0, stream, p);
+        const size_t threads = (size_t)p.nseq * p.heads * p.rows_per_seq * 16;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((attn_split_kernel<true, VAR, false>), dim3(nwg), dim3(256), 0, stream, p);
     }
 }
 
@@ -706,29 +800,21 @@ int attention_launch(imcui_hip_s* h, const AttnP& p, hipStream_t stream) {
     if (h->precision == 1 && p.log2_domain) {
         int var = p.variant >= 0 ? p.variant : h->opt[OPT_ATTN_VARIANT];  // imcui_hip_set_option(h, "attn_variant", v)
         if (var == 9 && (p.V6 == nullptr || p.single)) var = 8;  // (callers without the fp6 scratch: SuperGlue, DUSt3R, the C-ABI block)
+        // key-split launch: the grid leaves the chip empty (fewer than two workgroups per CU), there is more than one chunk to split and the
+        // caller provided the scratch; option attn_split: 0 never, 1 (default) by this rule, 2 whenever there is scratch (tests).  Same rows either way.
+        const int rule = h->opt[OPT_ATTN_SPLIT];
+        const bool split = p.part != nullptr && p.rows_per_seq > KT * ATTN_CHUNK_TILES && rule != 0 && ((long)grid.x < 2L * h->num_cu || rule == 2);
         if (var == 9) {
             const int rc = attention_mx_launch(h, p, stream);
             if (rc != IMCUI_OK) return rc;
         } else if (p.single)
-            hipLaunchKernelGGL((attn_split_kernel<true, 4>), grid, dim3(256), 0, stream, p);
-        else if (var == 6)
-            hipLaunchKernelGGL((attn_split_kernel<true, 6>), grid, dim3(256), 0, stream, p);
-        else if (var == 7)
-            hipLaunchKernelGGL((attn_split_kernel<true, 7>), grid, dim3(256), 0, stream, p);
-        else if (var == 8)
-            hipLaunchKernelGGL((attn_split_kernel<true, 8>), grid, dim3(256), 0, stream, p);
-        else if (var == 5)
-            hipLaunchKernelGGL((attn_split_kernel<true, 5>), grid, dim3(256), 0, stream, p);
-        else if (var == 1)
-            hipLaunchKernelGGL((attn_split_kernel<true, 1>), grid, dim3(256), 0, stream, p);
-        else if (var == 2)
-            hipLaunchKernelGGL((attn_split_kernel<true, 2>), grid, dim3(256), 0, stream, p);
-        else if (var == 3)
-            hipLaunchKernelGGL((attn_split_kernel<true, 3>), grid, dim3(256), 0, stream, p);
+            attn_launch_l2d<4>(p, split, stream);
+        else if (var == 6 || var == 7)
+            attn_launch_l2d<7>(p, split, stream);
         else
-            hipLaunchKernelGGL((attn_split_kernel<true, 0>), grid, dim3(256), 0, stream, p);
+            attn_launch_l2d<8>(p, split, stream);
     } else if (h->precision == 1)
-        hipLaunchKernelGGL((attn_split_kernel<false, 0>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_split_kernel<false, 0, false>), grid, dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, stream, p);
     imcui_prof_end(h, PROF_ATTN, stream);

@@ -171,6 +171,7 @@ enum {
     OPT_SIMRED,            // IMCUI_SIMRED: 1 (default) = similarities reduced by the persistent kernel of simred.hip, 0 = the round-4 tile GEMM with the reducing epilogue (A/B; mutual-NN only)
     OPT_FFN_TILE,          // IMCUI_FFN_TILE: tokens per workgroup of the fused FFN: 0 (default) = by token count (128 / 64 / 32: the largest that fills the CUs), or 128 / 64 / 32 (bitwise equal results)
     OPT_WREG_TILE,         // IMCUI_WREG_TILE: the same for the weights-in-registers projection GEMM (LightGlue's q / k / v, cross and plain-bias launches)
+    OPT_ATTN_SPLIT,        // IMCUI_ATTN_SPLIT: key-split attention launches: 0 never, 1 (default) when the grid has fewer than two workgroups per CU, 2 whenever the caller gave scratch (bitwise equal rows)
     OPT_NCNT
 };
 

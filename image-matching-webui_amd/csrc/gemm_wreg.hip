@@ -35,6 +35,8 @@ __device__ int wr_lab_flags = 0;
 #define WR_F_NOEPI 4     // return after the main loop
 #define WR_F_NOWLOAD 8   // weights loaded for the first two k-steps only (registers re-used)
 #define WR_F_NOXLOAD 16  // activations loaded / staged for the first tile only
+#define WR_F_NOSTORE_V 32   // no global stores in the V^T panels only (64-byte row segments)
+#define WR_F_NOSTORE_QK 64  // no global stores in the q / k panels only (whole 128-byte plane rows)
 // bits 8..15: the workgroups of the SECOND dispatch round (ids [ncu, 2 ncu): the second resident workgroup of every CU) start this many
 // ~0.5 us later, so that the two workgroups of a CU run their matrix loop / their epilogue in opposite phases
 #define WR_F_STAGGER(f) (((f) >> 8) & 255)
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
     const float* A = p.A + (size_t)c.z * p.a_bs;
     const float wsc = p.wscale ? p.wscale[c.wsel] : 1.0f;
     const int labf = WR_FLAGS;
-    if (WR_F_STAGGER(labf) != 0 && (int)blockIdx.x >= p.st_nct && (int)blockIdx.x < 2 * p.st_nct)  // (lab: st_nct carries the CU count)
-        for (int i = 0; i < WR_F_STAGGER(labf); ++i) __builtin_amdgcn_s_sleep(16);
+    if (WR_F_STAGGER(labf) != 0 && (int)blockIdx.x >= p.st_nct && (int)blockIdx.x < 4 * p.st_nct)  // (lab: st_nct carries the CU count)
+        for (int i = 0; i < WR_F_STAGGER(labf) * ((int)blockIdx.x / p.st_nct); ++i) __builtin_amdgcn_s_sleep(16);
     const int nkt = (labf & WR_F_ONETILE) ? 1 : p.K >> 5, nks = 2 * nkt;
 
     f32x16 acc[2][MT];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
         if (acc[0][0][0] == 12345.678f) p.C[0] = acc[1][MT - 1][3];  // (keeps the accumulators alive)
         return;
     }
-    const bool do_store = !(labf & WR_F_NOSTORE);
+    bool do_store = !(labf & WR_F_NOSTORE);
     // LayerNorm folded into this layer: per-feature row sums of the (gamma-folded) weights, per-token (mean, rstd) of the raw input
     const float* lrs = nullptr;
     if constexpr (EPI == EPI_QKV_VIT || EPI == EPI_CONV) {
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wreg_kernel(GemmP p) {
             scale = (t == 0);
         }
         unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        if ((labf & WR_F_NOSTORE_V) && vt) do_store = false;
+        if ((labf & WR_F_NOSTORE_QK) && !vt) do_store = false;
         const int R = p.rows_per_seq;
         const int i0 = c.row0 - c.seq * R;
         if (EPI == EPI_QKV_VIT && !vt) {

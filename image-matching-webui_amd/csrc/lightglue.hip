@@ -248,6 +248,7 @@ extern "C" int imcui_hip_lightglue_pack_weights(const float* const* t, float* pa
 struct LgWs {
     float *x, *xt, *ctx, *hbuf, *q, *k, *v, *cs, *sn, *cst, *snt, *conf, *mtch, *md, *ls;
     unsigned char* v6;  // attention variant 9: fp6 planes of V^T (attention_mx.hip)
+    float* apart;       // key-split attention launches of small batches: per-chunk partials (attention.hip), nullptr for large batches
     float *rmax, *rls, *cmax, *cls, *max0, *ms0;
     float *rpm, *rps, *cpm, *cps;  // assignment partials of simred.hip: rows [B][column chunks][R], columns [B][R/128][R]
     int *rpj, *cpi;
@@ -269,6 +270,9 @@ static LgWs lg_carve(void* ws, size_t bytes, int B, int R) {
     w.k = a.get<float>(rows * 256);
     w.v = a.get<float>(rows * 256);
     w.v6 = a.get<unsigned char>(attn_v6_bytes(2 * B, LG_HEADS, R));
+    // (a grid of fewer than two workgroups per CU splits its keys over workgroups: at most 1024 workgroups covers every part with <= 512 CUs)
+    const bool small_grid = (long)(R / 128) * LG_HEADS * 2 * B < 1024 && R > 512;
+    w.apart = small_grid ? a.get<float>(attn_part_floats(2 * B, LG_HEADS, R)) : nullptr;
     w.cs = a.get<float>(rows * 32);
     w.sn = a.get<float>(rows * 32);
     w.cst = a.get<float>(rows * 32);
@@ -872,6 +876,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.cross = 0;
             a.log2_domain = 1;
             a.V6 = w.v6;
+            a.part = w.apart;
             if (h->opt[OPT_ATTN_SELF] >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = h->opt[OPT_ATTN_SELF];  // (per-block arithmetic mix: audit tool)
             LGRUN(attention_launch(h, a, stream));
             LGRUN(ffn(w.ctx, o.w1s, o.s1s, o.b1s, o.gs, o.bs, o.w2s, o.s2s, o.s2sp, o.b2s));
@@ -909,6 +914,7 @@ extern "C" int imcui_hip_lightglue_forward(imcui_hip_t* h, const float* packed, 
             a.cross = 1;
             a.log2_domain = 1;
             a.V6 = w.v6;
+            a.part = w.apart;
             {   // -2 (default) = the audited two-product P.V (7) while attn_variant is the default kernel (8), otherwise attn_variant governs; -1 = attn_variant
                 const int cv = h->opt[OPT_ATTN_CROSS] == -2 ? (h->opt[OPT_ATTN_VARIANT] == 8 ? 7 : -1) : h->opt[OPT_ATTN_CROSS];
                 if (cv >= 0 && ((h->opt[OPT_ATTN_MIX_LAYERS] >> layer) & 1)) a.variant = cv;

@@ -398,3 +398,50 @@ def test_all_keypoints_conf_is_graph_capturable():
         assert torch.equal(out[k][0, :n0], eager[k][0, :n0]), k
     assert torch.equal(out["stop"], eager["stop"])
     assert n0 > 100
+
+
+def test_pair_alone_equals_pair_in_a_batch_bitwise():
+    """one pair per call runs its attention as a KEY-SPLIT launch (a chunk of 512 keys per workgroup + a combine
+    kernel; csrc/attention.hip) so that a lone pair fills the chip; a batch keeps one workgroup per query block.  Both geometries evaluate
+    the same chunked soft-max with the same fold, so every token state of every layer, every match and every score of a pair must be
+    BITWISE the same alone (split), alone with the split switched off, and inside a batch of six (unsplit) -- with ragged counts whose
+    last chunks are partial or missing."""
+    from imcui_hip import backend
+
+    dev = torch.device("cuda:0")
+    backend.set_precision(dev, 1)
+    sd = WEIGHTS["strong"]
+    problems = [synthetic_matching_problem(60, 2048, 1900, 250), synthetic_matching_problem(61, 600, 2048, 100), synthetic_matching_problem(62, 1500, 1025, 200),
+                synthetic_matching_problem(63, 2048, 2048, 300), synthetic_matching_problem(64, 513, 700, 50), synthetic_matching_problem(65, 1300, 1800, 150)]  # fmt: skip
+    model = _model(-1, -1, sd=sd)
+
+    def run(ps, cap):
+        k0, k1, d0, d1 = torch.zeros(len(ps), cap, 2), torch.zeros(len(ps), cap, 2), torch.zeros(len(ps), cap, 256), torch.zeros(len(ps), cap, 256)
+        n0, n1 = torch.zeros(len(ps), dtype=torch.int32), torch.zeros(len(ps), dtype=torch.int32)
+        for b, (a, c, e, f) in enumerate(ps):
+            k0[b, : len(a)], k1[b, : len(c)], d0[b, : len(a)], d1[b, : len(c)] = a, c, e, f
+            n0[b], n1[b] = len(a), len(c)
+        out = model.forward_batched(k0.cuda(), k1.cuda(), d0.cuda(), d1.cuda(), n0.cuda(), n1.cuda(), (640, 480), (640, 480), layer_dump=True)
+        torch.cuda.synchronize()
+        return {k: v.cpu() for k, v in out.items()}
+
+    batch = run(problems, 2048)
+    assert backend.get_option(dev, "attn_split") == 1
+    for b, pr in enumerate(problems):
+        alone = run([pr], 2048)
+        with backend.option(dev, attn_split=0):
+            alone_unsplit = run([pr], 2048)
+        na, nc = len(pr[0]), len(pr[1])
+        for other, tag in ((alone_unsplit, "split vs unsplit, alone"), (batch, "alone (split) vs in the batch")):
+            ob = 0 if other is alone_unsplit else b
+            for li in range(9):
+                for s, n in ((0, na), (1, nc)):
+                    assert torch.equal(alone["_layers"][li, s, :n], other["_layers"][li, 2 * ob + s, :n]), (tag, b, li, s)
+            assert torch.equal(alone["matches0"][0, :na], other["matches0"][ob, :na]) and torch.equal(alone["matches1"][0, :nc], other["matches1"][ob, :nc]), (tag, b)
+            if other is alone_unsplit:
+                assert torch.equal(alone["matching_scores0"][0, :na], other["matching_scores0"][ob, :na]), (tag, b)
+            else:
+                # the ASSIGNMENT's soft-max statistics are reduced in column chunks whose number follows the batch size (simred_chunks: enough
+                # workgroups to fill the chip), so the log-sum-exp of a row is associated differently alone and in a batch: last-bit differences
+                # of the scores (the matches above are equal); everything upstream -- every token state -- is bitwise equal
+                assert (alone["matching_scores0"][0, :na] - other["matching_scores0"][ob, :na]).abs().max().item() < 2e-6, (tag, b)

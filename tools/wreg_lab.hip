@@ -41,6 +41,41 @@ static float run(const GemmP& p, int flags, int tile, int reps = 10) {
     return ms * 1000.f / reps;
 }
 
+// ---- how fast can 805 MB be WRITTEN at all?  Pure store kernels in the epilogue's three patterns.
+//  0: every wave instruction writes 1 KB contiguous (the q / k planes: 8 token rows x 128 B, consecutive)
+//  1: every wave instruction writes 16 segments of 64 B, 4 KB apart (the V^T planes: 16 feature rows x 4 lanes x 16 B, row pitch R halves)
+//  2: every wave instruction writes 8 segments of 128 B, 4 KB apart (V^T with whole lines)
+template <int PAT>
+__global__ __launch_bounds__(256) void store_kernel(uint4* out, size_t n16, int iters) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint4 v = make_uint4(lane, wave, 3u, 4u);
+    for (int it = 0; it < iters; ++it) {
+        size_t idx;
+        if (PAT == 0) idx = (wave * iters + it) * 64 + lane;
+        else if (PAT == 1) idx = ((wave * iters + it) >> 6) * 16384 + (size_t)(lane >> 2) * 256 + (((wave * iters + it) & 63) * 4) + (lane & 3);  // 16 rows of a 64-row block, 4 KB pitch
+        else idx = ((wave * iters + it) >> 5) * 8192 + (size_t)(lane >> 3) * 256 + (((wave * iters + it) & 31) * 8) + (lane & 7);
+        if (idx < n16) out[idx] = v;
+    }
+}
+template <int PAT>
+static void store_rate(const char* name, uint4* buf, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    const int iters = 64;
+    const int blocks = (int)(n16 / 64 / iters / 4);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((store_kernel<PAT>), dim3(blocks), dim3(256), 0, 0, buf, n16, iters);
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((store_kernel<PAT>), dim3(blocks), dim3(256), 0, 0, buf, n16, iters);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("store pattern %-58s %7.1f us per %zu MB  = %.2f TB/s\n", name, ms / 5 * 1000.f, bytes >> 20, (double)bytes / (ms / 5 * 1e-3) / 1e12);
+}
+
 int main(int argc, char** argv) {
     const int pairs = argc > 1 ? atoi(argv[1]) : 64;
     const int R = 2048, S = 2 * pairs, K = 256;
@@ -87,6 +122,9 @@ int main(int argc, char** argv) {
         std::vector<int> c(S, R);
         CK(hipMemcpy(cnt, c.data(), S * 4, hipMemcpyHostToDevice));
     }
+    store_rate<0>("1 KB contiguous per wave instruction (q / k planes)", reinterpret_cast<uint4*>(Q), plane * 4);
+    store_rate<1>("16 x 64 B, 4 KB apart (V^T planes today)", reinterpret_cast<uint4*>(Q), plane * 4);
+    store_rate<2>("8 x 128 B, 4 KB apart (V^T planes, whole lines)", reinterpret_cast<uint4*>(Q), plane * 4);
     GemmP g;
     g.A = A;
     g.lda = K;
@@ -121,6 +159,8 @@ int main(int argc, char** argv) {
         {"no weight stream, no activation stream, full epilogue", WR_F_NOWLOAD | WR_F_NOXLOAD},
         {"no streams, no epilogue (the bare matrix loop)", WR_F_NOWLOAD | WR_F_NOXLOAD | WR_F_NOEPI},
         {"weights + activations streamed, no epilogue", WR_F_NOEPI},
+        {"no stores in the V^T panels (64-byte segments)", WR_F_NOSTORE_V},
+        {"no stores in the q / k panels (128-byte rows)", WR_F_NOSTORE_QK},
     };
     for (int pass = 0; pass < 2; ++pass) {
         g.epi = pass == 0 ? EPI_QKV : EPI_CROSS;
@@ -134,7 +174,8 @@ int main(int argc, char** argv) {
             printf("%-62s %8.1f us   (%.0f TF/s executed, %.2f TB/s of compulsory traffic)\n", r.name, us, gf / us * 1e3, (mbw + mbr) / us);
         }
         printf("token tile 64 (twice the workgroups), full kernel:%*s %8.1f us\n", 13, "", run(g, 0, 64));
-        for (int d : {2, 4, 8, 12, 16, 24, 32, 48}) printf("second-round workgroups start %2d x ~0.5 us late:%*s %8.1f us\n", d, 14, "", run(g, d << 8, 128));
+        for (int tile : {128, 64, 32})
+            for (int d : {0, 4, 16, 40}) printf("token tile %3d, later dispatch rounds start %2d x ~0.5 us x round late:%*s %8.1f us\n", tile, d, 3, "", run(g, d << 8, tile));
         printf("\n");
     }
     return 0;
