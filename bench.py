@@ -942,7 +942,7 @@ LEGS = {
     "dust3r_512": ("dust3r", {"batch": 32, "arith": "fp32", "size": None}),  # 8 / 16 / 32 = 86.4 / 90.4 / 92.4
     "dust3r_512_fp16": ("dust3r", {"batch": 32, "arith": "fp16", "size": None}),
     # SURVEY section 8 f-rows: the other matchers of the zoo that run on this backend
-    "eloftr_640x480": ("eloftr", {"batch": 8, "size": None}),
+    "eloftr_640x480": ("eloftr", {"batch": 32, "size": None}),  # (8 pairs = 600 workgroups of the fused MLP = 2.3 rounds of the chip: 498 pairs/s; 16: 561; 32: 593)
     "mast3r_512": ("mast3r", {"batch": 16, "arith": "fp32", "size": None}),
     "superglue": ("superglue", {"batch": 64}),
 }
@@ -1100,7 +1100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 64; loftr: 16, eloftr: 8, dust3r: 32, mast3r: 16)")
+    ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default 64; loftr: 16, eloftr: 32, dust3r: 32, mast3r: 16)")
     ap.add_argument("--adaptive", action="store_true", help="reference defaults depth 0.95 / width 0.99 (data dependent work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of one pair after the timed region (profiler passes)")
@@ -1127,7 +1127,7 @@ def main():
     args = ap.parse_args()
     args.batch_given = args.batch
     if args.batch is None:
-        args.batch = 16 if args.workload == "loftr" else 8 if args.workload == "eloftr" else 32 if args.workload == "dust3r" else 16 if args.workload == "mast3r" else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels; dust3r 8 / 16 / 32: 86.5 / 90.5 / 92.7 pairs/s)
+        args.batch = 16 if args.workload == "loftr" else 32 if args.workload == "eloftr" else 32 if args.workload == "dust3r" else 16 if args.workload == "mast3r" else 64  # pairs per step and GPU (64: +2.5 % over 32, same kernels; dust3r 8 / 16 / 32: 86.5 / 90.5 / 92.7 pairs/s)
 
     ensure_built()  # a clean checkout / an N-rank launch builds libimcui_hip.so once, under a file lock
     if args.workload == "launchcheck":

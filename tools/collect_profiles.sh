@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round evidence collector: run on the GPU box (gpurun), writes under gpurun_out/final_r05/; tools/summarize_profiles.py r05_final then
+# Round evidence collector: run on the GPU box (gpurun), writes under gpurun_out/final_r06/; tools/summarize_profiles.py r06_final then
 # copies the judged summaries into profiles/ (each stamped with the commit in <out>/HEAD).  rocprofv3 needs cwd=/tmp and TMPDIR=/tmp on
 # this pool; counters are collected one per pass (FETCH_SIZE, WRITE_SIZE, one SQ group), never together with a trace domain.
 #   HEAD=<commit>  the commit of the snapshot (no .git on the box: pass `HEAD=$(git rev-parse --short HEAD)` on the gpurun command line)
@@ -7,7 +7,7 @@
 #   PART=2: counter passes (FETCH_SIZE / WRITE_SIZE / SQ) of splg, loftr, eloftr, dust3r, nn -- each at its leg's batch size
 #   PART=3: A/B legs, labs, the full GPU test log, smoke          (default: 123)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/${OUT:-final_r05}
+O=$R/gpurun_out/${OUT:-final_r06}
 mkdir -p $O
 echo "${HEAD:-unknown}" > $O/HEAD
 P=${PART:-123}
@@ -28,6 +28,7 @@ if [[ $P == *1* ]]; then
   stats loftr --workload loftr --steps 5 --warmup 2
   stats eloftr --workload eloftr --steps 3 --warmup 1
   stats dust3r --workload dust3r --steps 3 --warmup 1
+  stats splg_b1 --batch 1 --steps 30 --warmup 3
 fi
 if [[ $P == *2* ]]; then
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -45,6 +46,11 @@ if [[ $P == *2* ]]; then
 fi
 if [[ $P == *3* ]]; then
   IMCUI_ATTN_VARIANT_CROSS=-1 b bench_splg_attn_cross_off --no-cpu-baseline --no-parity --no-legs   # three products everywhere (the round-4 arithmetic)
+  IMCUI_ATTN_VARIANT=9 b bench_splg_attn_v9 --no-cpu-baseline --no-legs                              # round 6: P.V corrections on fp6 MFMA in every block (opt-in)
+  IMCUI_ATTN_SPLIT=0 b bench_splg_b1_nosplit --batch 1 --steps 30 --warmup 3 --no-cpu-baseline --no-legs --no-parity   # one pair per step without the key-split launch
+  b bench_eloftr_640x480_b8 --workload eloftr --batch 8 --no-legs --no-cpu-baseline                   # (round 5's batch)
+  ( cd $R && timeout 120 tools/mx_lab > $O/lab_mx_mfma.txt 2>&1; tail -8 $O/lab_mx_mfma.txt )
+  ( cd $R && AUDIT_REDUCED=9 timeout 900 python tools/attn_mix_audit.py > $O/lab_attention_mx_mix.txt 2>/dev/null; tail -9 $O/lab_attention_mx_mix.txt | cut -c1-200 )
   IMCUI_SIMRED=0 b bench_nn_simred_off --workload nn --no-legs --no-cpu-baseline                     # the round-4 tile GEMM with the reducing epilogue
   b bench_splg_h2d --h2d raw --no-cpu-baseline --no-legs
   b bench_splg_h2d_jpeg --h2d jpeg --no-cpu-baseline --no-legs

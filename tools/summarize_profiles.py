@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r05"))
+F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r06"))
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 # every summary carries the commit the collection ran at (tools/collect_profiles.sh writes it into <out>/HEAD: VERDICT round 4, item 2 iv)
@@ -97,7 +97,7 @@ if os.path.exists(sqp):
         print(f"{k[:50]:50s} mfma_busy {v['mfma_busy_frac']:.3f} wait_any {v['wait_any_frac']:.2f} wait_inst {v['wait_inst_frac']:.2f}")
 # the same SQ pass on the DUSt3R workload; its GEMM launches are grouped by grid size (= shape class: encoder / decoder, N, merged sides)
 for wl, wl_note in (("loftr", "bench.py --workload loftr --steps 2 --warmup 1 (1024x1024, 4 pairs per step)"),
-                    ("eloftr", "bench.py --workload eloftr --steps 2 --warmup 1 (640x480, 8 pairs per step)"),
+                    ("eloftr", "bench.py --workload eloftr --steps 2 --warmup 1 (640x480, 32 pairs per step)"),
                     ("dust3r", "bench.py --workload dust3r --steps 2 --warmup 1 (512x512, 16 pairs per step, 3 x f16 split arithmetic)"),
                     ("mast3r", "bench.py --workload mast3r --batch 2 --steps 1 --warmup 1 (512x512: network + reciprocal matching, nn_argmax_* kernels)"),
                     ("nn", "bench.py --workload nn --steps 2 --warmup 1 (mutual-NN matcher, 5000 x 128-d descriptors, 64 pairs per step)")):
@@ -160,7 +160,11 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("lab_attention_mix.txt", f"{tag.split('_')[0]}_lab_attention_mix.txt"), ("bench_splg_attn_cross_off.json.log", f"{tag}_bench_splg_attn_cross_off.json.log"),
                  ("bench_nn_simred_off.json.log", f"{tag}_bench_nn_simred_off.json.log"), ("lab_simred_parts.txt", f"{tag.split('_')[0]}_lab_simred_parts.txt"),
                  ("bench_splg_adaptive_b1_graph.json.log", f"{tag}_bench_splg_adaptive_b1_graph.json.log"),
-                 ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt")]:
+                 ("lab_ffn_phases.txt", f"{tag}_lab_ffn_phases.txt"),
+                 ("bench_splg_attn_v9.json.log", f"{tag}_bench_splg_attn_v9.json.log"), ("bench_splg_b1_nosplit.json.log", f"{tag}_bench_splg_b1_nosplit.json.log"),
+                 ("bench_eloftr_640x480_b8.json.log", f"{tag}_bench_eloftr_640x480_b8.json.log"), ("lab_mx_mfma.txt", f"{tag.split('_')[0]}_lab_mx_mfma.txt"),
+                 ("lab_attention_mx_mix.txt", f"{tag.split('_')[0]}_lab_attention_mx_mix.txt"),
+                 ("stats_splg_b1/splg_b1_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg_b1.csv")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
     shutil.copy(os.path.join(F, src), os.path.join(P, dst))
