@@ -53,10 +53,14 @@ int imcui_hip_version(void);
 /* A/B switches of the kernel routing (profiling and the bitwise old-vs-new kernel tests).  The IMCUI_<NAME> environment variables
  * are read ONCE, by imcui_hip_create; afterwards a switch changes only through this call -- set it BETWEEN forward passes, never while
  * another thread runs a call on the same handle.  Names / values: "gemm_wreg" 0 | 1 | 2 (default 2: every eligible projection on
- * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 0..8 (default 8 = the three-product arithmetic of 0, bit for bit, with a pipelined schedule; 6 / 7 = the two-product P.V, NOT fp32-grade, csrc/attention.hip),
+ * the weights-in-registers GEMM), "wreg_pipe" 0 | 1 (default 1), "attn_variant" 8 (default: three f16 products in both contractions; the retired schedules 0 .. 3 and 5 map onto it) | 7 (the two-product P.V; 6 maps
+ * onto it; NOT fp32-grade on its own) | 9 (round 6, opt-in: P.V corrections on the block-scaled fp6 matrix instruction, csrc/attention_mx.hip; callers without the
+ * fp6 scratch -- SuperGlue, DUSt3R -- fall back to 8), "attn_split" 0 | 1 | 2 (key-split attention launches, csrc/attention.hip: 0 never, 1 = default: when the grid
+ * has fewer than two workgroups per CU -- one pair per call --, 2 whenever the caller gave scratch; the geometries are bitwise equal),
  * "attn_variant_self" / "attn_variant_cross" (-1 = attn_variant; else the variant of LightGlue's self / cross blocks in the layers whose bit is set in
- * "attn_mix_layers", default 0x1ff.  Round 5 default: cross 7 -- the two-product P.V in the CROSS blocks only, audited per block: layer error <= 7.1e-6 and
- * score error <= 4.7e-5 at N = M = 2048 on three weight sets, half the parity bar; -1 restores three products everywhere), "simred"
+ * "attn_mix_layers", default 0x1ff.  Default cross = -2: variant 7 -- the two-product P.V in the CROSS blocks only, audited per block: layer error <= 7.1e-6 and
+ * score error <= 4.7e-5 at N = M = 2048 on three weight sets, half the parity bar -- WHILE "attn_variant" is left at 8; an explicit "attn_variant" governs every
+ * block; -1 restores three products everywhere), "simred"
  * 1 | 0 (default 1: the mutual-NN matcher on the persistent similarity-and-reduce kernel; 0: the round-4 tile GEMM with the reducing
  * epilogue, kept for A/B and for descriptor widths other than 64 / 128 / 256), "ffn_tile" / "wreg_tile" 0 | 128 | 64 | 32 (tokens per workgroup of the
  * fused FFN / of the weights-in-registers projection GEMM; default 0 = by token count, the largest tile that still gives every CU a workgroup; bitwise equal results), "conv_tall"
