@@ -72,6 +72,21 @@ def q_mx(x, fmt, block=32):
     return out[..., :k] if pad else out
 
 
+def q_i8(x, block=0, levels=127):
+    """Symmetric integer quantisation along the last axis: one f32 scale per row (block = 0) or per `block` elements, `levels` steps to the maximum
+    (v_mfma_i32_32x32x32_i8: i32 accumulation, the scales applied when the i32 sums are folded into the f32 accumulator)."""
+    *lead, k = x.shape
+    if block:
+        pad = (-k) % block
+        xb = (F.pad(x, (0, pad)) if pad else x).reshape(*lead, -1, block)
+    else:
+        xb = x.reshape(*lead, 1, k)
+    amax = xb.abs().amax(-1, keepdim=True)
+    scale = torch.where(amax > 0, amax / levels, torch.ones_like(amax))
+    out = (torch.round(xb / scale).clamp(-levels, levels) * scale).reshape(*lead, -1)
+    return out[..., :k]
+
+
 def f16_rtn(x):
     return x.to(torch.float32).to(torch.float16).to(D)
 
@@ -118,6 +133,12 @@ def product(x, y, mode, xsplit=split_act, ysplit=split_act):
     elif mode.startswith("mx:"):  # mx:<format of the copies of the hi planes>:<format of the lo planes>
         _, fh, fl = mode.split(":")
         r = xh @ yt(yh) + q_mx(xh, fh) @ yt(q_mx(yl, fl)) + q_mx(xl, fl) @ yt(q_mx(yh, fh))
+    elif mode.startswith("i8:"):  # i8:<block along K of the scales, 0 = one scale per row>: both correction products on int8 operands
+        blk = int(mode.split(":")[1])
+        r = xh @ yt(yh) + q_i8(xh, blk) @ yt(q_i8(yl, blk)) + q_i8(xl, blk) @ yt(q_i8(yh, blk))
+    elif mode.startswith("i8lo:"):  # only the lo planes on int8, their partners stay f16 (not an instruction: what the lo planes alone cost)
+        blk = int(mode.split(":")[1])
+        r = xh @ yt(yh) + xh @ yt(q_i8(yl, blk)) + q_i8(xl, blk) @ yt(yh)
     elif mode.startswith("pvfix:"):  # attention's P with CONSTANT scales (2^13 for P, 2^2 for P - ph) instead of one scale per 32 keys; V block-scaled
         _, fh, fl = mode.split(":")
         r = xh @ yt(yh) + (q_elem(x.to(torch.float32).to(D) / 8192.0, fh) * 8192.0) @ yt(q_mx(yl, fl)) + (q_elem(xl / 4.0, fl) * 4.0) @ yt(q_mx(yh, fh))
