@@ -36,6 +36,16 @@ for p in (ROOT, os.path.join(ROOT, "image-matching-webui_amd")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# Hardware check of the N > 1 code path on a ONE-GPU box (tests/test_gpu_rccl_single_rank.py): under `torch.distributed.run --nproc-per-node 1`
+# with IMCUI_BENCH_DIST1=1 a single rank initialises RCCL and runs every barrier / all-gather / max-over-ranks reduction the multi-GPU launch
+# runs.  Not set by the driver: a plain `python bench.py` (no WORLD_SIZE) never takes this path.
+FORCE_DIST = os.environ.get("IMCUI_BENCH_DIST1") == "1" and os.environ.get("WORLD_SIZE") == "1"
+
+
+def dist_on(world: int) -> bool:
+    """True when this process is part of a torch.distributed job (N > 1, or the forced single-rank check above)."""
+    return world > 1 or FORCE_DIST
+
 H, W, MAXK = 480, 640, 2048
 SP_GF_PER_IMAGE = 52.10          # SURVEY.md section 8d
 LG_GF_PER_LAYER_PAIR = 25.23     # @N=M=2048, shared cross similarity
@@ -332,7 +342,7 @@ def bench_nn(args, dev, rank, world):
     if not ranks_agree(failed is None, world, dev):
         raise LegSkipped(f"set-up failed on a rank: {failed!r}")
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -343,14 +353,14 @@ def bench_nn(args, dev, rank, world):
         out = step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
     gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
     backend.profile_enable(dev, False)
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -372,7 +382,7 @@ def bench_nn(args, dev, rank, world):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if args.precision == 1 else "f32", "data": "synthetic",
             "config": {"workload": "configs[0] (matcher half): NN-mutual on 5000 x 128-d RootSIFT-like descriptors per image, resident in HBM",
-                       "pairs_per_step_per_gpu": B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), no collective",
+                       "pairs_per_step_per_gpu": B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if dist_on(world) else 1}), no collective",
                        "matches_pair0": int((out["matches0"][0] > -1).sum())},
             "roofline": roof,
         }  # fmt: skip
@@ -423,7 +433,7 @@ def bench_superpoint(args, dev, rank, world):
     if not ranks_agree(failed is None, world, dev):
         raise LegSkipped(f"set-up failed on a rank: {failed!r}")
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     backend.profile_enable(dev, True)
     torch.cuda.synchronize()
@@ -431,12 +441,12 @@ def bench_superpoint(args, dev, rank, world):
     for _ in range(args.steps):
         out = model.forward_batched(img)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     dt = time.perf_counter() - t0
     conv_ms, conv_n = backend.profile_read(dev, "conv3x3")
     backend.profile_enable(dev, False)
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -494,11 +504,11 @@ def bench_loftr(args, dev, rank, world):
         img0 = base[..., 0:Hh, 0:Ww].contiguous().repeat(B, 1, 1, 1).to(dev)
         img1 = base[..., 8 : Hh + 8, 16 : Ww + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
         cap = B * (Hh // 8) * (Ww // 8)
-        gather = TableGather(world, cap + 1, 6, torch.float32, dev)
+        gather = TableGather(world, cap + 1, 6, torch.float32, dev, force=FORCE_DIST)
 
         def step():
             out = model.forward_batched(img0, img1)
-            if world > 1:  # fixed-capacity match table of this rank's pairs: rows (x0, y0, x1, y1, conf, pair), last row = count
+            if dist_on(world):  # fixed-capacity match table of this rank's pairs: rows (x0, y0, x1, y1, conf, pair), last row = count
                 rows = torch.cat([out["keypoints0"], out["keypoints1"], out["confidence"][:, None], out["batch_indexes"].float()[:, None]], 1)
                 gather(torch.cat([rows, out["num_matches"].float().expand(1, 6)], 0))
             return out
@@ -513,7 +523,7 @@ def bench_loftr(args, dev, rank, world):
         raise LegSkipped(f"set-up failed on a rank: {failed!r}")
     gather.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     backend.profile_enable(dev, True)
     t0 = time.perf_counter()
@@ -521,14 +531,14 @@ def bench_loftr(args, dev, rank, world):
         out = step()
     gather.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     dt = time.perf_counter() - t0
     gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
     conv_ms, conv_n = backend.profile_read(dev, "conv3x3")  # the 3x3 stride-1 convolutions run on the patch-staging kernel
     gemm_ms, gemm_n = gemm_ms + conv_ms, gemm_n + conv_n
     backend.profile_enable(dev, False)
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -549,6 +559,19 @@ def bench_loftr(args, dev, rank, world):
         if eloftr:  # per 640x480 pair: 2 x (53.8 backbone + 35.5 fine fusion) + 30.2 transformer MLPs GMAC, 5.9 GMAC coarse sim
             a2 = Hh * Ww / (640.0 * 480.0)
             tf_pair = 0.4176 * a2 + 0.0118 * a2 * a2
+        fine_stage = None
+        if not eloftr:
+            # The last FPN stage (layer1_outconv + layer1_outconv2 at 1/2 resolution, 0.626 TF of the 2.55 TF per 1024^2 pair) is evaluated on the 5x5
+            # windows of the matches when that is cheaper (option loftr_fine_sparse, csrc/loftr.hip): the roofline line then counts the work
+            # that was EXECUTED (98.5 MFLOP per match instead of the dense maps), not the nominal dense figure.
+            mode, nmatch_all = model._impl.last_fine_mode(dev)
+            dense_tf = 2 * (Hh // 2) * (Ww // 2) * 2.0 * (128 * 196 + 9 * 196 * 196 + 9 * 196 * 128) / 1e12
+            win_tf = max(nmatch_all, 0) / B * 2 * 2.0 * (81 * 128 * 196 + 49 * 9 * 196 * 196 + 25 * 9 * 196 * 128) / 1e12
+            fine_stage = {"mode": "windows of the matches" if mode == 1 else "dense maps", "matches_per_step": nmatch_all, "option_loftr_fine_sparse": backend.get_option(dev, "loftr_fine_sparse"),
+                          "dense_tflop_per_pair": dense_tf, "executed_tflop_per_pair": win_tf if mode == 1 else dense_tf,
+                          "note": "data dependent: the synthetic pair of this leg yields few matches; the dense evaluation is what `--fine-dense` (option 0) times"}  # fmt: skip
+            if mode == 1:
+                tf_pair += win_tf - dense_tf
         split = args.precision == 1
         line = {
             "metric": "image-pairs/sec EfficientLoFTR dense matcher" if eloftr else "image-pairs/sec LoFTR dense matcher", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
@@ -556,7 +579,7 @@ def bench_loftr(args, dev, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 via 3xf16 split MFMA, f32 accumulate" if split else "f32", "data": "synthetic",
             "config": {"workload": (f"EfficientLoFTR (RepVGG 8-1 + 4 x aggregated self / cross attention + two-stage fine matching) on synthetic {Ww}x{Hh} pairs resident in HBM" if eloftr else
                                     f"configs[3]: LoFTR (ResNetFPN_8_2 + 8 coarse + 2 fine linear-attention layers) on synthetic {Ww}x{Hh} pairs resident in HBM"),
-                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]),
+                       "pairs_per_step_per_gpu": B, "matches": int(out["num_matches"][0]), **({"fine_stage": fine_stage} if fine_stage else {}),
                        "weights": "seeded random (imcui_hip/synth_weights.py), " + ("EfficientLoFTR architecture (transformers port names)" if eloftr else "kornia LoFTR architecture")},
             "roofline": {"kernel": "conv3x3_split_kernel + gemm_split_kernel + lg_ffn_kernel (matrix class: 3x3 convolutions, strided / 1x1 convolutions as implicit GEMM, projections, fused MLPs)" if split else "gemm_kernel", "bound": "mfma",
                          "achieved": tf_pair * B * args.steps / (gemm_ms * 1e-3) if gemm_ms else 0.0, "peak": PEAK_F16_MFMA_TF if split else PEAK_F32_MFMA_TF,
@@ -694,14 +717,14 @@ def bench_dust3r(args, dev, rank, world):
     if not ranks_agree(failed is None, world, dev):
         raise LegSkipped(f"set-up failed on a rank: {failed!r}")
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     backend.profile_enable(dev, True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     dt = time.perf_counter() - t0
     cls_ms = {k: backend.profile_read(dev, k) for k in ("gemm", "conv3x3", "attention")}
@@ -714,7 +737,7 @@ def bench_dust3r(args, dev, rank, world):
             model.forward_pairs(images, pairs)
         torch.cuda.synchronize()
         net_ms = (time.perf_counter() - t1) / 3 * 1e3
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -809,24 +832,24 @@ def bench_superglue(args, dev, rank, world):
     img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=min(B, 4))
     img0, img1 = img0.to(dev), img1.to(dev)
 
-    gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev)
+    gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev, force=FORCE_DIST)
 
     def step():
         out = pipe(img0, img1)
-        if world > 1:  # the one exchange step of the path: all-gather of the match tables
+        if dist_on(world):  # the one exchange step of the path: all-gather of the match tables
             gather(match_table(out))
         return out
 
     def timed(steps):
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
         gather.finish()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on(world):
             dist.barrier()
         return time.perf_counter() - t0, out
 
@@ -844,7 +867,7 @@ def bench_superglue(args, dev, rank, world):
     pipe(img0, img1)
     dt0, _ = timed(max(2, args.steps // 2))
     dt0 *= args.steps / max(2, args.steps // 2)
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -922,7 +945,7 @@ def ensure_built() -> None:
 def ranks_agree(ok: bool, world: int, dev) -> bool:
     """True when EVERY rank reports ok.  The legs call it after set-up and warm-up, before their barrier-bracketed timed loop, so a
     rank that failed (out of memory, a missing file) makes all ranks skip the leg together instead of leaving the others in a barrier."""
-    if world == 1:
+    if not dist_on(world):
         return ok
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -990,7 +1013,7 @@ def run_legs(args, dev, rank, world) -> dict:
         except LegSkipped as e:
             line = {"status": "skipped", "reason": str(e)}
         except Exception as e:  # noqa: BLE001 -- the headline line must survive a broken leg; the entry says what happened
-            if world > 1:
+            if dist_on(world):
                 raise  # ranks may be out of step with each other: no way to continue the collectives safely
             line = {"status": "failed", "error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
         if line is not None:
@@ -1124,6 +1147,7 @@ def main():
     ap.add_argument("--legs", default=None, help="comma-separated legs to run after the workload and attach as \"workloads\" (" + ", ".join(LEGS) + "; `all`); default: all of "
                                                  "them on the plain headline invocation, none otherwise")
     ap.add_argument("--no-legs", action="store_true", help="headline line only")
+    ap.add_argument("--fine-dense", action="store_true", help="loftr: the last FPN stage as dense maps whatever the match count (option loftr_fine_sparse = 0; A/B)")
     args = ap.parse_args()
     args.batch_given = args.batch
     if args.batch is None:
@@ -1139,14 +1163,18 @@ def main():
         raise SystemExit("bench.py needs the MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on(world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        if rank == 0:
+            print(f"[bench] RCCL process group up: {world} rank(s), backend {dist.get_backend()}", file=sys.stderr, flush=True)
 
     from imcui_hip import backend
 
     backend.set_precision(dev, args.precision)
+    if args.fine_dense:
+        backend.set_option(dev, "loftr_fine_sparse", 0)
     fn = {"splg": bench_splg, "loftr": bench_loftr, "eloftr": bench_loftr, "dust3r": bench_dust3r, "mast3r": bench_dust3r, "superpoint": bench_superpoint,
           "superglue": bench_superglue, "nn": bench_nn}[args.workload]  # fmt: skip
     line = fn(args, dev, rank, world)
@@ -1160,7 +1188,7 @@ def main():
         # first (`python bench.py 2> detail.log`; profiles/ keeps both).
         print("[bench detail] " + json.dumps(line), file=sys.stderr, flush=True)
         print(json.dumps(compact_line(line)), flush=True)
-    if world > 1:
+    if dist_on(world):
         dist.destroy_process_group()
 
 
@@ -1245,7 +1273,7 @@ def bench_seam(args, dev, rank, world):
     from imcui_hip.synth import make_pair_batch
     from imcui_hip.synth_weights import lightglue_state_dict, superpoint_state_dict  # seeded weights only
 
-    if world > 1:
+    if dist_on(world):
         raise LegSkipped("the seam leg is a single-GPU latency figure")
     spc = {"nms_radius": 3, "max_keypoints": MAXK, "keypoint_threshold": 0.005, "remove_borders": 4, "state_dict": superpoint_state_dict(0)}
     exts = {False: SuperPoint(dict(spc)).eval().to(dev), True: SuperPoint({**spc, "hip_graph": True}).eval().to(dev)}
@@ -1325,7 +1353,7 @@ def bench_splg(args, dev, rank, world):
         distinct = B if args.adaptive else min(B, 8)
         img0, img1, _ = make_pair_batch(1234 + rank, B, H, W, distinct=distinct)
         img0, img1 = img0.to(dev), img1.to(dev)
-        gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev)
+        gather = TableGather(world, B, 3 + 2 * MAXK, torch.int32, dev, force=FORCE_DIST)
 
         run = pipe
         if args.graph:
@@ -1407,7 +1435,7 @@ def bench_splg(args, dev, rank, world):
                 free[k].record(torch.cuda.current_stream(dev))
             else:
                 out = run(img0, img1)
-            if world > 1:
+            if dist_on(world):
                 gather(match_table(out))
             return out
 
@@ -1420,7 +1448,7 @@ def bench_splg(args, dev, rank, world):
     if not ranks_agree(failed is None, world, dev):
         raise LegSkipped(f"set-up failed on a rank: {failed!r}")
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     backend.profile_enable(dev, True)
     torch.cuda.synchronize()
@@ -1429,7 +1457,7 @@ def bench_splg(args, dev, rank, world):
         out = step()
     gather.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on(world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -1442,7 +1470,7 @@ def bench_splg(args, dev, rank, world):
     conv_ms, conv_n = backend.profile_read(dev, "conv3x3")
     gemm_ms, gemm_n = backend.profile_read(dev, "gemm")
     backend.profile_enable(dev, False)
-    if world > 1:
+    if dist_on(world):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -1503,7 +1531,7 @@ def bench_splg(args, dev, rank, world):
                 "workload": "configs[2]: SuperPoint(max 2048 kpts, nms 3)+LightGlue(9 layers) on synthetic 640x480 pairs "
                             + ("decoded from JPEG files inside the timed region: Huffman on host threads, coefficients over PCIe, pixels reconstructed on the device (NOT the headline value)" if args.h2d == "jpeg" else
                                "uploaded as uint8 from pinned host memory inside the timed region (PCIe-inclusive; NOT the headline value)" if args.h2d else "resident in HBM"),
-                "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if world > 1 else 1}), async all-gather of match tables",
+                "pairs_per_step_per_gpu": B, "global_pairs_per_step": world * B, "parallelism": f"pairs sharded over {world} rank(s) (RCCL world size {dist.get_world_size() if dist_on(world) else 1}), async all-gather of match tables",
                 "lightglue_adaptive": bool(args.adaptive), "hip_graph": bool(args.graph), "h2d_inside_timed_region": args.h2d or False, **({"decode_threads": args.decode_threads, "jpeg_bytes_per_image": sum(len(b) for b in blobs) / len(blobs)} if args.h2d == "jpeg" else {}), "mean_keypoints": [nk0, nk1], "mean_stop_layer": stop,
                 "weights": "seeded random (imcui_hip/synth_weights.py), real architecture",
             },

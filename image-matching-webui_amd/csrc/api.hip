@@ -24,7 +24,7 @@ int imcui_set_err(imcui_hip_s* h, int code, const char* fmt, ...) {
 // an older layout is rejected instead of running with its LayerNorm affine parts dropped); imcui_hip_set_option / _get_option.
 extern "C" int imcui_hip_version(void) { return 400; }
 
-static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "conv_tall", "conv_narrow", "simred", "ffn_tile", "wreg_tile", "attn_split"};
+static const char* const OPT_NAMES[OPT_NCNT] = {"gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "conv_tall", "conv_narrow", "simred", "ffn_tile", "wreg_tile", "attn_split", "loftr_fine_sparse"};
 static int opt_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < OPT_NCNT; ++i)
@@ -74,6 +74,7 @@ extern "C" int imcui_hip_create(int device, imcui_hip_t** out) {
         // its default (8)": an explicit attn_variant (the A/B and parity workflows that set that option alone) governs every block again.
         h->opt[OPT_ATTN_CROSS] = (e = getenv("IMCUI_ATTN_VARIANT_CROSS")) ? atoi(e) : -2;
         h->opt[OPT_ATTN_SPLIT] = (e = getenv("IMCUI_ATTN_SPLIT")) ? atoi(e) : 1;
+        h->opt[OPT_LOFTR_FINE_SPARSE] = (e = getenv("IMCUI_LOFTR_FINE_SPARSE")) ? atoi(e) : 1;
         h->opt[OPT_ATTN_MIX_LAYERS] = (e = getenv("IMCUI_ATTN_MIX_LAYERS")) ? (int)strtol(e, nullptr, 0) : 0x1ff;
     }
     *out = h;

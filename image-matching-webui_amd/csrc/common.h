@@ -172,6 +172,7 @@ enum {
     OPT_FFN_TILE,          // IMCUI_FFN_TILE: tokens per workgroup of the fused FFN: 0 (default) = by token count (128 / 64 / 32: the largest that fills the CUs), or 128 / 64 / 32 (bitwise equal results)
     OPT_WREG_TILE,         // IMCUI_WREG_TILE: the same for the weights-in-registers projection GEMM (LightGlue's q / k / v, cross and plain-bias launches)
     OPT_ATTN_SPLIT,        // IMCUI_ATTN_SPLIT: key-split attention launches: 0 never, 1 (default) when the grid has fewer than two workgroups per CU, 2 whenever the caller gave scratch (bitwise equal rows)
+    OPT_LOFTR_FINE_SPARSE, // IMCUI_LOFTR_FINE_SPARSE: LoFTR's last FPN stage (the 1/2-resolution fine map): 0 = dense maps, 1 (default) = on the 5x5 windows of the matches when that is cheaper (one 4-byte read-back of the match count), 2 = always on the windows
     OPT_NCNT
 };
 
@@ -194,6 +195,8 @@ struct imcui_hip_s {
     // f32 activation beyond the f16 range (|x| > 65504: the hi part saturates, the product is no longer fp32-grade), bit 1 = NaN / Inf
     int* range_flag;
     int opt[OPT_NCNT];  // A/B switches (above)
+    int loftr_fine_mode;  // how the last imcui_hip_loftr_forward evaluated the last FPN stage: 0 dense maps, 1 on the windows of the matches (bench.py reports it)
+    int loftr_fine_matches;  // the match count that call read back (-1: no read-back)
 };
 // scan `rows` x `cols` f32 values (row stride ld; rows of sequence s beyond cnt[s] are padding and skipped) into h->range_flag
 void imcui_range_check(imcui_hip_s* h, const float* x, long rows, int cols, long ld, const int* cnt, int rows_per_seq, hipStream_t s);

@@ -272,6 +272,12 @@ extern "C" size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0,
     }
 }
 
+extern "C" int imcui_hip_loftr_last_fine_mode(imcui_hip_t* h, int* matches) {
+    if (!h) return IMCUI_ERR_ARG;
+    if (matches) *matches = h->loftr_fine_matches;
+    return h->loftr_fine_mode;
+}
+
 __global__ void lf_counts_kernel(const int* nmatch, int* cnt2) {
     cnt2[0] = *nmatch;       // rows of the per-match GEMMs
     cnt2[1] = *nmatch * 25;  // rows of the per-window-token GEMMs
@@ -429,14 +435,28 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     }
     LFRUN(conv(LF_OUT2B_0, w.x2o, w.y2, 4, 256, 3, 1, nullptr, 2));
     LFRUN(conv(LF_OUT2B_3, w.y2, w.x2out, 4, 256, 3, 1, nullptr, 0));
-    if (upf) {
-        LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.x2out, 0, true));
-    } else {
-        upsample(w.x2out, w.up2, 4, CP);
-        LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.up2, 0));
+    // The last FPN stage (1/2 resolution: layer1_outconv + layer1_outconv2 -> the 128-channel fine map `ff`) is only ever read through the
+    // 5x5 windows of the matched cells.  Option loftr_fine_sparse (default 1): it is deferred until the matches are known and evaluated on
+    // the windows alone when that is the cheaper way (few matches; `sparse_fine_stage` below); 0 = always the dense maps, here, as before.
+    auto dense_fine_stage = [&]() -> int {
+        if (upf) {
+            LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.x2out, 0, true));
+        } else {
+            upsample(w.x2out, w.up2, 4, CP);
+            LFRUN(conv(LF_OUT1, w.x1, w.x1o, 2, 128, 1, 1, w.up2, 0));
+        }
+        LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, 2, CP, 3, 1, nullptr, 2));
+        LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, 2, CP, 3, 1, nullptr, 0));
+        return IMCUI_OK;
+    };
+    h->loftr_fine_mode = 0;
+    h->loftr_fine_matches = -1;
+    bool fine_deferred = h->opt[OPT_LOFTR_FINE_SPARSE] != 0;
+    if (fine_deferred) {  // (a stream that is being captured into a graph cannot be waited for: dense)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fine_deferred = false;
     }
-    LFRUN(conv(LF_OUT1B_0, w.x1o, w.y1, 2, CP, 3, 1, nullptr, 2));
-    LFRUN(conv(LF_OUT1B_3, w.y1, w.ff, 2, CP, 3, 1, nullptr, 0));
+    if (!fine_deferred) LFRUN(dense_fine_stage());
 
     // ---- a14: positional encoding + coarse LocalFeatureTransformer (linear attention)
     const size_t tok1 = (size_t)B * L;  // first token row of side 1
@@ -543,8 +563,84 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     IMCUI_CHECK_LAUNCH(h);
 
     // ---- a16: fine level on the 5x5 windows of the matches
-    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap, H0 / 2, W0 / 2,
-                       hcs[0], wcs[0], H1 / 2, W1 / 2, hcs[1], wcs[1], 4, w.X, w.CG);
+    bool sparse_done = false;
+    if (fine_deferred) {
+        // the number of matches decides (one 4-byte read-back: the only host round trip of the forward pass)
+        int nm = 0;
+        if (hipMemcpyAsync(&nm, w.nmatch, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return imcui_set_err(h, IMCUI_ERR_HIP, "loftr: reading the match count back failed");
+        h->loftr_fine_matches = nm;
+        const size_t p2 = (size_t)B * (npx(0, 2) + npx(1, 2));
+        // cost model (multiply-adds; the window path runs on the implicit GEMM at about 0.6 of the dense kernels' rate -- option value 2
+        // takes the windows whatever the count): per window of one side 81 x 128 x 256 + 49 x 2304 x 256 + 25 x 2304 x 128, per dense pixel
+        // 128 x 256 + 9 x 224 x (224 + 128)
+        const double sparse_cost = (double)nm * 2.0 * (81.0 * 128 * 256 + 49.0 * 2304 * 256 + 25.0 * 2304 * 128) / 0.6;
+        const double dense_cost = (double)p2 * (128.0 * 256 + 9.0 * 224 * (224 + 128));
+        const long wcap_chunk = (long)min((size_t)32768, p2 / 81);  // windows per chunk: the dense stage's idle buffers hold them
+        if (nm == 0) {
+            sparse_done = true;  // nothing reads the fine map
+        } else if ((h->opt[OPT_LOFTR_FINE_SPARSE] == 2 || sparse_cost < dense_cost) && wcap_chunk >= 1) {
+            float* G = w.up2;                                           // [chunk, 81, 128]
+            float* T = w.x1o;                                           // [chunk, 81, CP]
+            float* Y1 = w.y1;                                           // [chunk, 49, CP]
+            unsigned char* V = reinterpret_cast<unsigned char*>(w.ff);  // [chunk, 81]
+            for (int s = 0; s < 2; ++s) {
+                const int hf = Hs[s] / 2, wf = Ws[s] / 2;
+                const float* x1s = w.x1 + (s ? (size_t)B * npx(0, 2) * 128 : 0);
+                const float* x2s = w.x2out + (s ? (size_t)B * npx(0, 4) * CP : 0);
+                for (long m0 = 0; m0 < nm; m0 += wcap_chunk) {
+                    const int n = (int)min(wcap_chunk, (long)nm - m0);
+                    hipLaunchKernelGGL(lf_win_gather_kernel, dim3(n), blk, 0, stream, x1s, x2s, w.mb, s ? w.mj : w.mi, (int)m0, n, hf, wf, wcs[s], 4, CP, G, T, V);
+                    IMCUI_CHECK_LAUNCH(h);
+                    const unsigned mgrid = (unsigned)min((long)n * 81 / 4 + 1, (long)8192);
+                    {  // layer1_outconv (1x1) + the gathered up-sampled residual, in place
+                        GemmP g;
+                        wts(g, LF_OUT1);
+                        g.epi = EPI_CONV;
+                        g.A = G;
+                        g.lda = 128;
+                        g.M = n * 81;
+                        g.C = T;
+                        g.ldc = g.N;
+                        g.resid = T;
+                        g.ldr = g.N;
+                        g.act = 0;
+                        LFRUN(gemm_launch(h, g, stream));
+                        hipLaunchKernelGGL(lf_win_mask_kernel, dim3(mgrid), blk, 0, stream, T, V, n, 9, 0, (long)CP, CP);
+                    }
+                    auto wconv = [&](int li, const float* in, int side_in, float* out, long ldc, int act) -> int {
+                        GemmP g;
+                        wts(g, li);
+                        g.epi = EPI_CONV;
+                        g.A = in;
+                        g.conv_k = 3;
+                        g.conv_stride = 1;
+                        g.conv_pad = 0;
+                        g.conv_hin = g.conv_win = side_in;
+                        g.conv_hout = g.conv_wout = side_in - 2;
+                        g.conv_cin = CP;
+                        g.M = n * (side_in - 2) * (side_in - 2);
+                        g.C = out;
+                        g.ldc = ldc;
+                        g.act = act;
+                        return gemm_launch(h, g, stream);
+                    };
+                    LFRUN(wconv(LF_OUT1B_0, T, 9, Y1, CP, 2));
+                    hipLaunchKernelGGL(lf_win_mask_kernel, dim3(mgrid), blk, 0, stream, Y1, V, n, 7, 1, (long)CP, CP);
+                    float* Xs = w.X + ((size_t)s * cap + m0) * 25 * 256;  // the window rows of these matches: [25][fine 128 | coarse 128]
+                    LFRUN(wconv(LF_OUT1B_3, Y1, 7, Xs, 256, 0));
+                    hipLaunchKernelGGL(lf_win_mask_kernel, dim3(mgrid), blk, 0, stream, Xs, V, n, 5, 2, (long)256, 128);
+                    IMCUI_CHECK_LAUNCH(h);
+                }
+            }
+            sparse_done = true;
+            h->loftr_fine_mode = 1;
+        } else {
+            LFRUN(dense_fine_stage());
+        }
+    }
+    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, sparse_done ? (const float*)nullptr : w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap,
+                       H0 / 2, W0 / 2, hcs[0], wcs[0], H1 / 2, W1 / 2, hcs[1], wcs[1], 4, w.X, w.CG);
     auto lin_b = [&](int li, const float* A, long lda, const float* A2, float* C, long side_rows_cap, int relu, int per_token,
                      int side0, int nsides, bool with_bias) -> int {
         // rows of side s start at s * side_rows_cap; valid rows = nmatch (* 25)

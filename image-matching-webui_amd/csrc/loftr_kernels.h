@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void lf_fine_gather_kernel(const float* __rest
     const float* fc = feat_c + (side ? (size_t)B * hc0 * wc0 * 256 : 0) + (size_t)b * hc * wc * 256;
     const int cy = cell / wc, cx = cell - cy * wc;
     const size_t wrow0 = ((size_t)side * cap + m) * 25;
-    for (int ww = threadIdx.x >> 6; ww < 25; ww += 4) {
+    for (int ww = threadIdx.x >> 6; feat_f != nullptr && ww < 25; ww += 4) {  // (feat_f null: the windows come from the match-sparse FPN stage below)
         const int fy = cy * stride + ww / 5 - 2, fx = cx * stride + ww % 5 - 2;
         float2 v = make_float2(0.f, 0.f);
         if (fy >= 0 && fy < hf && fx >= 0 && fx < wf) v = *reinterpret_cast<const float2*>(ff + ((size_t)fy * wf + fx) * 128 + lane * 2);
@@ -368,6 +368,74 @@ __global__ __launch_bounds__(256) void lf_fine_gather_kernel(const float* __rest
     if (threadIdx.x < 64) {
         const float4 c = *reinterpret_cast<const float4*>(fc + (size_t)cell * 256 + lane * 4);
         *reinterpret_cast<float4*>(CG + ((size_t)side * cap + m) * 256 + lane * 4) = c;
+    }
+}
+// ------------------------------------------------------------------ match-sparse last FPN stage (round 6)
+// Only the 5x5 windows (1/2 resolution, stride 4, zero padding 2) around the matched coarse cells of the 128-channel fine map are ever read
+// (lf_fine_gather_kernel).  That map is layer1_outconv2(layer1_outconv(x1) + up2(x2out)) -- a 1x1 and two 3x3 convolutions over the whole 1/2
+// resolution grid, a quarter of the 1024 x 1024 step.  With few matches it is cheaper to evaluate the three layers on the 9x9 input neighbourhood
+// of every window: gather -> 1x1 (GEMM, the up-sampled residual gathered beside it) -> 3x3 valid 9x9 -> 7x7 -> 3x3 valid 7x7 -> 5x5 (implicit GEMM
+// over the windows as tiny images).  A position outside the image is ZERO at every level, as the dense layers' zero padding and unfold's padding make it.
+// One block per window of one side: x1 [imgs, hf, wf, 128] -> G [n, 81, 128]; up2 (align_corners = True, ATen's formula and order, as the GEMM
+// epilogue evaluates it) of x2q [imgs, hf / 2, wf / 2, CQ] -> T [n, 81, CQ]; V [n, 81] = 1 inside the image.
+__global__ __launch_bounds__(256) void lf_win_gather_kernel(const float* __restrict__ x1, const float* __restrict__ x2q, const int* __restrict__ mb,
+                                                            const int* __restrict__ cells, int m0, int n, int hf, int wf, int wc, int stride, int CQ,
+                                                            float* __restrict__ G, float* __restrict__ T, unsigned char* __restrict__ V) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int m = m0 + i;
+    const int b = mb[m], cell = cells[m];
+    const int cy = cell / wc, cx = cell - cy * wc;
+    const int y00 = cy * stride - 4, x00 = cx * stride - 4;
+    const int hq = hf >> 1, wq = wf >> 1;
+    const float sy = (float)(hq - 1) / (float)(hf - 1), sx = (float)(wq - 1) / (float)(wf - 1);
+    const float* xb = x1 + (size_t)b * hf * wf * 128;
+    const float* qb = x2q + (size_t)b * hq * wq * CQ;
+    if (threadIdx.x < 81) {
+        const int y = y00 + threadIdx.x / 9, x = x00 + threadIdx.x % 9;
+        V[(size_t)i * 81 + threadIdx.x] = (y >= 0 && y < hf && x >= 0 && x < wf) ? 1 : 0;
+    }
+    const int c1 = 128 >> 2, c2 = CQ >> 2;
+    for (int e = threadIdx.x; e < 81 * c1; e += 256) {
+        const int p = e / c1, c4 = e - p * c1;
+        const int y = y00 + p / 9, x = x00 + p % 9;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < hf && x >= 0 && x < wf) v = *reinterpret_cast<const float4*>(xb + ((size_t)y * wf + x) * 128 + c4 * 4);
+        *reinterpret_cast<float4*>(G + ((size_t)i * 81 + p) * 128 + c4 * 4) = v;
+    }
+    for (int e = threadIdx.x; e < 81 * c2; e += 256) {
+        const int p = e / c2, c4 = e - p * c2;
+        const int oy = y00 + p / 9, ox = x00 + p % 9;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy >= 0 && oy < hf && ox >= 0 && ox < wf) {
+            const float fy = sy * (float)oy, fx = sx * (float)ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = min(y0 + 1, hq - 1), x1i = min(x0 + 1, wq - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+            const float* base = qb + c4 * 4;
+            const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * wq + x0) * CQ);
+            const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * wq + x1i) * CQ);
+            const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * wq + x0) * CQ);
+            const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * wq + x1i) * CQ);
+            o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        }
+        *reinterpret_cast<float4*>(T + ((size_t)i * 81 + p) * CQ + c4 * 4) = o;
+    }
+}
+// rows of a window level (side x side positions, the interior of the 9x9 grid at offset off) that lie outside the image are set to zero:
+// buf [n * side * side rows][ld floats], the first nch channels of a row
+__global__ __launch_bounds__(256) void lf_win_mask_kernel(float* __restrict__ buf, const unsigned char* __restrict__ V, int n, int side, int off, long ld, int nch) {
+    const int lane = threadIdx.x & 63;
+    const long nrow = (long)n * side * side;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < nrow; r += (long)gridDim.x * 4) {
+        const long i = r / (side * side);
+        const int p = (int)(r - i * side * side);
+        const int py = p / side + off, px = p % side + off;
+        if (V[i * 81 + py * 9 + px]) continue;  // (wave-uniform)
+        for (int c = lane * 4; c < nch; c += 256) *reinterpret_cast<float4*>(buf + r * ld + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 // broadcast the projected coarse feature CW [2*cap, 128] into columns 128..255 of every window row

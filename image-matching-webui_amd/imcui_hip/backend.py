@@ -477,6 +477,14 @@ class LoFTRHIP:
                 hd.check(rc, "imcui_hip_loftr_forward")
         return {"keypoints0": kp0, "keypoints1": kp1, "confidence": conf, "batch_indexes": bidx, "num_matches": nm}
 
+    @staticmethod
+    def last_fine_mode(dev) -> tuple:
+        """(mode, matches) of the last forward on this device's handle (imcui_hip_loftr_last_fine_mode): mode 0 = the last FPN stage as dense
+        maps, 1 = on the 5x5 windows of the matches; matches = the count read back for that decision (-1: none)."""
+        hd = get_handle(dev)
+        m = C.c_int(-1)
+        return int(hd.lib.imcui_hip_loftr_last_fine_mode(hd.h, C.byref(m))), m.value
+
     def debug_buffer(self, which: int, shape) -> torch.Tensor:
         """Workspace buffer `which` of the last forward (imcui_hip_loftr_debug_offset) viewed as float32 `shape`."""
         lib = load_library()
@@ -1042,7 +1050,7 @@ def lib_version() -> int:
 
 
 def set_option(device: torch.device, name: str, value: int) -> int:
-    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "simred", "ffn_tile", "wreg_tile", "conv_tall", "conv_narrow"); returns
+    """A/B switch of the kernel routing (imcui_hip_set_option: "gemm_wreg", "wreg_pipe", "attn_variant", "attn_variant_self", "attn_variant_cross", "attn_mix_layers", "simred", "ffn_tile", "wreg_tile", "conv_tall", "conv_narrow", "attn_split", "loftr_fine_sparse"); returns
     the previous value.  The IMCUI_* environment variables of the same names are only read when the handle is created."""
     hd = get_handle(device)
     old = C.c_int(0)

@@ -30,18 +30,20 @@ class TableGather:
     collective on its own communication stream behind the producing kernels, so the compute stream goes straight on to
     the next batch; two receive buffers alternate and a buffer is only reused after the collective that last wrote it
     has completed.  `bench.py` (every workload that has a table) and `gather_match_tables` / `run_sharded` below all go
-    through this class; with world == 1 it hands the local table back."""
+    through this class; with world == 1 it hands the local table back (`force` keeps the collective even then: the
+    single-rank RCCL check on a one-GPU box, tests/test_gpu_rccl_single_rank.py)."""
 
-    def __init__(self, world: int, rows: int, stride: int, dtype, device, group=None):
+    def __init__(self, world: int, rows: int, stride: int, dtype, device, group=None, force: bool = False):
         self.world, self.group = world, group
-        self.bufs = [torch.empty((world * rows, stride), dtype=dtype, device=device) for _ in range(2)] if world > 1 else []
+        self.on = world > 1 or force
+        self.bufs = [torch.empty((world * rows, stride), dtype=dtype, device=device) for _ in range(2)] if self.on else []
         self.work = [None, None]
         self.i = 0
 
     def __call__(self, table: torch.Tensor) -> torch.Tensor:
         """Start the gather of this step's table; returns the receive buffer (valid after `finish()` or after the
         second following call)."""
-        if self.world == 1:
+        if not self.on:
             return table
         j = self.i & 1
         if self.work[j] is not None:

@@ -104,6 +104,7 @@ SIGNATURES = {
         [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_double, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p],
     ),
     "imcui_hip_loftr_debug_offset": (C.c_size_t, [C.c_int] * 6),
+    "imcui_hip_loftr_last_fine_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "imcui_hip_eloftr_packed_floats": (C.c_size_t, []),
     "imcui_hip_eloftr_num_layers": (C.c_int, []),
     "imcui_hip_eloftr_layer_shape": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -221,6 +221,15 @@ int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, const float* im
                             float* keypoints1, float* confidence, int* batch_indexes, int* num_matches, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* The last FPN stage (1/2 resolution: layer1_outconv + layer1_outconv2, kornia ResNetFPN_8_2 behind loftr.py:54) produces the fine map that is
+ * only ever read through the 5x5 windows of the matched cells.  Option "loftr_fine_sparse" (imcui_hip_set_option; default 1): the stage is
+ * deferred until the matches are known and evaluated on those windows alone when that is cheaper than the dense maps -- for that decision
+ * imcui_hip_loftr_forward reads the 4-byte match count back and SYNCHRONISES THE STREAM ONCE per call (not while the stream is being captured
+ * into a graph: dense then); 2 = always on the windows, 0 = dense maps, no read-back (the call does not synchronise).  Same matches either way;
+ * window features agree to round-off (tests/test_gpu_loftr.py).  Returns how the last forward on this handle did it: 0 dense, 1 windows;
+ * *matches (may be NULL) = the count it read back, -1 without a read-back. */
+int imcui_hip_loftr_last_fine_mode(imcui_hip_t* h, int* matches);
+
 /* byte offset inside the LoFTR workspace of: 0 coarse features after the transformer [B*L0 + B*L1, 256] (side 0 first),
  * 1 fine features [B*H0/2*W0/2 + B*H1/2*W1/2, 128], 2 sim [B,L0,L1], 3 fine windows [2,B*L0,25,128]  (parity tests) */
 size_t imcui_hip_loftr_debug_offset(int which, int B, int H0, int W0, int H1, int W1);

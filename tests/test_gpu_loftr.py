@@ -63,6 +63,7 @@ def _feature_tolerance() -> float:
 
 def _loftr_case(h, w, B, sd, thr, min_matches, hw1=None):
     """`hw1`: size of the second image when it differs from (h, w)."""
+    from imcui_hip import backend
     from imcui_hip.hloc.matchers.loftr import LoFTR
 
     torch.set_num_threads(16)
@@ -71,9 +72,30 @@ def _loftr_case(h, w, B, sd, thr, min_matches, hw1=None):
     img0 = torch.cat([p[0][..., :h, :w] for p in pairs], 0).contiguous()
     img1 = torch.cat([p[1][..., :h1, :w1] for p in pairs], 0).contiguous()
     model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to("cuda:0")
-    out = model.forward_batched(img0.cuda(), img1.cuda())
-    torch.cuda.synchronize()
+    dev = torch.device("cuda:0")
+    # the last FPN stage has two evaluations (option loftr_fine_sparse): on the 5x5 windows of the matches alone (2: always; the default 1
+    # picks by match count) and as dense 1/2-resolution maps (0).  Both run here: same matches, the window features of the two within the
+    # feature tolerance of each other, the refined key-points of BOTH within the bar of the oracle's; the dense run is the last one, so the
+    # fine feature map checked below is its map.
+    with backend.option(dev, loftr_fine_sparse=2):
+        out_s = model.forward_batched(img0.cuda(), img1.cuda())
+        torch.cuda.synchronize()
+        ns = int(out_s["num_matches"][0])
+        capw = B * (h // 8) * (w // 8)
+        Fs = model._impl.debug_buffer(3, (2 * capw * 25, 128))
+        Fs = torch.cat([Fs[: ns * 25], Fs[capw * 25 : capw * 25 + ns * 25]]).cpu()
+        kp1_s = out_s["keypoints1"][:ns].cpu()
+    with backend.option(dev, loftr_fine_sparse=0):
+        out = model.forward_batched(img0.cuda(), img1.cuda())
+        torch.cuda.synchronize()
     n = int(out["num_matches"][0])
+    assert ns == n and torch.equal(out_s["keypoints0"][:n], out["keypoints0"][:n]) and torch.equal(out_s["batch_indexes"][:n], out["batch_indexes"][:n])
+    if n:
+        Fd = model._impl.debug_buffer(3, (2 * capw * 25, 128))
+        Fd = torch.cat([Fd[: n * 25], Fd[capw * 25 : capw * 25 + n * 25]]).cpu()
+        ew = (Fs - Fd).abs().max().item() / Fd.abs().max().item()
+        print(f"[parity] LoFTR {w}x{h} B={B}: fine windows after the fine transformer, window evaluation vs dense maps: {ew:.2e} relative ({n} matches)")
+        assert ew < 1e-4, ew
     hc, wc = h // 8, w // 8
     L, S = hc * wc, (h1 // 8) * (w1 // 8)
     ora = LoFTROracle(sd, {"match_threshold": thr, "max_keypoints": None})
@@ -100,8 +122,10 @@ def _loftr_case(h, w, B, sd, thr, min_matches, hw1=None):
         # sub-pixel expectation over a 5 x 5 soft-max of fine features: 1e-4 relative on the features moves it by ~1e-4 * 2 px * the
         # logit range; 1e-3 px is the measured class (printed), the old bar was 2e-3
         ek = (out["keypoints1"][:n].cpu() - ref["keypoints1"]).abs().max().item()
-        print(f"[parity] LoFTR {w}x{h}: refined key-points of image 1 within {ek:.2e} px")
+        eks = (kp1_s - ref["keypoints1"]).abs().max().item()
+        print(f"[parity] LoFTR {w}x{h}: refined key-points of image 1 within {ek:.2e} px (dense fine maps), {eks:.2e} px (fine stage on the windows)")
         assert ek < 1e-3, ek
+        assert eks < 1e-3, eks
     return n
 
 
