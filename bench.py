@@ -572,6 +572,19 @@ def bench_loftr(args, dev, rank, world):
                           "note": "data dependent: the synthetic pair of this leg yields few matches; the dense evaluation is what `--fine-dense` (option 0) times"}  # fmt: skip
             if mode == 1:
                 tf_pair += win_tf - dense_tf
+                # the same step with the dense maps (option 0), timed right here: what this leg reported until round 5 and what a pair with
+                # thousands of matches costs (break-even ~3000 matches per 1024^2 pair: profiles/r06_lab_loftr_fine.txt)
+                with backend.option(dev, loftr_fine_sparse=0):
+                    step()
+                    torch.cuda.synchronize()
+                    td = time.perf_counter()
+                    for _ in range(max(2, args.steps // 2)):
+                        step()
+                    gather.finish()
+                    torch.cuda.synchronize()
+                    td = (time.perf_counter() - td) / max(2, args.steps // 2)
+                fine_stage["dense_maps_pairs_per_s"] = B / td
+                fine_stage["dense_maps_ms_per_step"] = td * 1e3
         split = args.precision == 1
         line = {
             "metric": "image-pairs/sec EfficientLoFTR dense matcher" if eloftr else "image-pairs/sec LoFTR dense matcher", "value": world * B * args.steps / dt, "unit": "pairs/s", "n_gpus": world,
@@ -1240,6 +1253,9 @@ def compact_line(line: dict) -> dict:
                 e[k] = v[k]
         if (v.get("config") or {}).get("mean_stop_layer") is not None:
             e["mean_stop_layer"] = v["config"]["mean_stop_layer"]
+        fs = (v.get("config") or {}).get("fine_stage")
+        if isinstance(fs, dict):  # LoFTR: how the last FPN stage ran (data dependent) and the dense-map figure measured beside it
+            e["fine_stage"] = {k: fs[k] for k in ("mode", "matches_per_step", "dense_maps_pairs_per_s") if k in fs}
         return {k: x for k, x in e.items() if x is not None}
 
     out = {}

@@ -307,36 +307,50 @@ __global__ __launch_bounds__(512, 2) void lg_ffn_kernel(FfnP p) {
             for (int pass = 0; pass < 4 * MT; ++pass)
                 res[pass] = *reinterpret_cast<const float4*>(p.x + (size_t)min(row0 + pass * 8 + wid2, p.M - 1) * 256 + lane2 * 4);
         }
-        uint4 wq[2][2];  // [k-step parity][plane], two k-steps ahead
+        // W2 fragments: FOUR k-steps in flight in four register sets (round 6; was two).  A k-step of this GEMM is 12 MFMAs = 384 matrix cycles against
+        // 24 in GEMM 1, so "two ahead" gave a fragment 0.4 us to come back from L2 where GEMM 1's get 0.8 us -- and this loop ran at 0.46 of the pipe
+        // against GEMM 1's 0.63 (tools/ffn_bench.py).  The loop is unrolled over the four sets (static register names, no copies).
+        uint4 wq[4][2];  // [k-step & 3][plane]
+        auto wload = [&](int q, uint4(&w)[2]) __attribute__((always_inline)) {
+            const int gk = (q >> 1) * 4 + ph * 2 + (q & 1);
+            w[0] = w2h[(size_t)gk * 64];
+            w[1] = w2l[(size_t)gk * 64];
+        };
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int gk = ph * 2 + u;
-            wq[u][0] = w2h[(size_t)gk * 64];
-            wq[u][1] = w2l[(size_t)gk * 64];
-        }
+        for (int u = 0; u < 4; ++u) wload(u, wq[u]);
+        // Fragment reads placed by hand (round 6) -- the hi plane of a k-step is requested at its top and lands under its first product (which reads
+        // the lo plane), the lo plane of the NEXT k-step goes into the registers that product has just released and lands under the other two;
+        // the MFMAs of a k-step go product by product across the MT accumulators (order pinned with sched_barrier).  hipcc's own schedule of the
+        // plain loop was ds_read_b128 -> s_waitcnt lgkmcnt(0) -> MFMA on ONE register quad, eight exposed LDS latencies per 12 MFMAs.  No extra
+        // registers (a second set of hi fragments made hipcc spill six hidden activations in the LayerNorm section).  Per accumulator the
+        // products and k-steps keep their order: bitwise equal.
+        uint4 gh[MT], gl[MT];
+        // fragment m of k-step q of this half (the layout the hand-over above wrote)
+        auto goff = [&](int q, int m) __attribute__((always_inline)) { return (q >> 1) * 16384 + lane2 * 16 + (((q & 1) * 4 + m) * 2) * 1024; };
+#pragma unroll
+        for (int m = 0; m < MT; ++m) gl[m] = *reinterpret_cast<const uint4*>(sm + goff(0, m) + 1024);
 #pragma unroll 1
-        for (int kk = 0; kk < 16; kk += 2) {
+        for (int kk = 0; kk < 16; kk += 4) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const uint4 wh = wq[u][0], wl = wq[u][1];
-                if (kk + 2 < 16) {
-                    const int gk = ((kk + 2) >> 1) * 4 + ph * 2 + u;
-                    wq[u][0] = w2h[(size_t)gk * 64];
-                    wq[u][1] = w2l[(size_t)gk * 64];
-                }
-                uint4 gh[MT], gl[MT];
+            for (int u = 0; u < 4; ++u) {
+                const int q = kk + u;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int off = (kk >> 1) * 16384 + lane2 * 16 + ((u * 4 + m) * 2) * 1024;
-                    gh[m] = *reinterpret_cast<const uint4*>(sm + off);
-                    gl[m] = *reinterpret_cast<const uint4*>(sm + off + 1024);
-                }
+                for (int m = 0; m < MT; ++m) gh[m] = *reinterpret_cast<const uint4*>(sm + goff(q, m));  // lands under the first product
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc2[m] = mfma16(wh, gl[m], acc2[m]);
-                    acc2[m] = mfma16(wl, gh[m], acc2[m]);
-                    acc2[m] = mfma16(wh, gh[m], acc2[m]);
+                for (int m = 0; m < MT; ++m) acc2[m] = mfma16(wq[u][0], gl[m], acc2[m]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < 16) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) gl[m] = *reinterpret_cast<const uint4*>(sm + goff(q + 1, m) + 1024);  // lands under the other two
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc2[m] = mfma16(wq[u][1], gh[m], acc2[m]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc2[m] = mfma16(wq[u][0], gh[m], acc2[m]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 4 < 16) wload(q + 4, wq[u]);  // (this k-step's MFMAs have been issued: its set is free)
             }
         }
     }
