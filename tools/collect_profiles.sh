@@ -7,7 +7,7 @@
 #   PART=2: counter passes (FETCH_SIZE / WRITE_SIZE / SQ) of splg, loftr, eloftr, dust3r, nn -- each at its leg's batch size
 #   PART=3: A/B legs, labs, the full GPU test log, smoke          (default: 123)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/${OUT:-final_r06}
+O=$R/gpurun_out/${OUT:-final2_r06}
 mkdir -p $O
 echo "${HEAD:-unknown}" > $O/HEAD
 P=${PART:-123}
@@ -23,6 +23,7 @@ if [[ $P == *1* ]]; then
   b bench_eloftr_640x480 --workload eloftr --no-legs --no-cpu-baseline
   b bench_dust3r_512 --workload dust3r --no-legs --no-cpu-baseline
   b bench_loftr_640x480 --workload loftr --size 480 640 --no-legs --no-cpu-baseline
+  b bench_loftr_1024_fine_dense --workload loftr --fine-dense --no-legs --no-cpu-baseline   # round 6: the last FPN stage as dense maps (option loftr_fine_sparse = 0)
   stats splg --steps 5 --warmup 2
   stats nn --workload nn --steps 5 --warmup 2
   stats loftr --workload loftr --steps 5 --warmup 2
@@ -61,6 +62,8 @@ if [[ $P == *3* ]]; then
   ( cd $R && timeout 900 python tools/attn_mix_audit.py > $O/lab_attention_mix.txt 2>/dev/null; tail -9 $O/lab_attention_mix.txt | cut -c1-200 )
   ( cd $R && for dbg in 0 1 3; do echo "== IMCUI_SR_DBG=$dbg (bit 0: no per-column part, bit 1: no per-row part; WRONG results, timing only)"; for wl in nn loftr; do IMCUI_SR_DBG=$dbg timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sr_${wl}_$dbg -o sr -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-legs > /dev/null 2>&1 < /dev/null; python3 tools/top_kernels.py $O/stats_sr_${wl}_$dbg 30 | grep simred_kernel; done; done ) > $O/lab_simred_parts.txt 2>&1
   ( cd $R && timeout 300 python tools/jpeg_bench.py > $O/lab_jpeg.txt 2>/dev/null; tail -4 $O/lab_jpeg.txt )
+  ( cd $R && timeout 600 python tools/loftr_fine_lab.py > $O/lab_loftr_fine.txt 2>/dev/null; tail -10 $O/lab_loftr_fine.txt )   # round 6: window vs dense evaluation of LoFTR's last FPN stage by match count
+  ( cd $R && timeout 200 python tools/ffn_bench.py 262144 20 > $O/lab_ffn_phases.txt 2>/dev/null; tail -8 $O/lab_ffn_phases.txt )
   ( cd $R && timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -s > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log )
   ( cd $R && timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 )
 fi

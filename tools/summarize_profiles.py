@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final_r06"))
+F = os.path.join(ROOT, "gpurun_out", os.environ.get("OUT", "final2_r06"))
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 # every summary carries the commit the collection ran at (tools/collect_profiles.sh writes it into <out>/HEAD: VERDICT round 4, item 2 iv)
@@ -164,6 +164,7 @@ for src, dst in [("bench_splg.json.log", f"{tag}_bench_splg.json.log"), ("bench_
                  ("bench_splg_attn_v9.json.log", f"{tag}_bench_splg_attn_v9.json.log"), ("bench_splg_b1_nosplit.json.log", f"{tag}_bench_splg_b1_nosplit.json.log"),
                  ("bench_eloftr_640x480_b8.json.log", f"{tag}_bench_eloftr_640x480_b8.json.log"), ("lab_mx_mfma.txt", f"{tag.split('_')[0]}_lab_mx_mfma.txt"),
                  ("lab_attention_mx_mix.txt", f"{tag.split('_')[0]}_lab_attention_mx_mix.txt"),
+                 ("bench_loftr_1024_fine_dense.json.log", f"{tag}_bench_loftr_1024_fine_dense.json.log"), ("lab_loftr_fine.txt", f"{tag}_lab_loftr_fine.txt"),
                  ("stats_splg_b1/splg_b1_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats_splg_b1.csv")]:
     if not os.path.exists(os.path.join(F, src)):
         continue
