@@ -564,17 +564,19 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
 
     // ---- a16: fine level on the 5x5 windows of the matches
     bool sparse_done = false;
+    int gcap = cap;  // grid size (matches) of the fine-level launches: the capacity, or the count once it has been read back
     if (fine_deferred) {
         // the number of matches decides (one 4-byte read-back: the only host round trip of the forward pass)
         int nm = 0;
         if (hipMemcpyAsync(&nm, w.nmatch, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
             return imcui_set_err(h, IMCUI_ERR_HIP, "loftr: reading the match count back failed");
         h->loftr_fine_matches = nm;
+        gcap = max(1, min(nm, cap));  // (the fine level below launches for the matches that exist instead of B * L0 mostly empty workgroups)
         const size_t p2 = (size_t)B * (npx(0, 2) + npx(1, 2));
-        // cost model (multiply-adds; the window path runs on the implicit GEMM at about 0.6 of the dense kernels' rate -- option value 2
-        // takes the windows whatever the count): per window of one side 81 x 128 x 256 + 49 x 2304 x 256 + 25 x 2304 x 128, per dense pixel
-        // 128 x 256 + 9 x 224 x (224 + 128)
-        const double sparse_cost = (double)nm * 2.0 * (81.0 * 128 * 256 + 49.0 * 2304 * 256 + 25.0 * 2304 * 128) / 0.6;
+        // cost model (multiply-adds; the window path runs on the implicit GEMM at about 0.75 of the dense kernels' rate: measured break-even
+        // ~3700 matches per 1024 x 1024 pair, profiles/r06_lab_loftr_fine.txt -- option value 2 takes the windows whatever the count): per
+        // window of one side 81 x 128 x 256 + 49 x 2304 x 256 + 25 x 2304 x 128, per dense pixel 128 x 256 + 9 x 224 x (224 + 128)
+        const double sparse_cost = (double)nm * 2.0 * (81.0 * 128 * 256 + 49.0 * 2304 * 256 + 25.0 * 2304 * 128) / 0.75;
         const double dense_cost = (double)p2 * (128.0 * 256 + 9.0 * 224 * (224 + 128));
         const long wcap_chunk = (long)min((size_t)32768, p2 / 81);  // windows per chunk: the dense stage's idle buffers hold them
         if (nm == 0) {
@@ -639,7 +641,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
             LFRUN(dense_fine_stage());
         }
     }
-    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(cap, 2), blk, 0, stream, sparse_done ? (const float*)nullptr : w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap,
+    hipLaunchKernelGGL(lf_fine_gather_kernel, dim3(gcap, 2), blk, 0, stream, sparse_done ? (const float*)nullptr : w.ff, w.fc, w.mb, w.mi, w.mj, w.nmatch, B, cap,
                        H0 / 2, W0 / 2, hcs[0], wcs[0], H1 / 2, W1 / 2, hcs[1], wcs[1], 4, w.X, w.CG);
     auto lin_b = [&](int li, const float* A, long lda, const float* A2, float* C, long side_rows_cap, int relu, int per_token,
                      int side0, int nsides, bool with_bias) -> int {
@@ -661,13 +663,13 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         g.C = C + (size_t)side0 * side_rows_cap * g.N;
         g.ldc = g.N;
         g.c_bs = side_rows_cap * g.N;
-        g.M = (int)side_rows_cap;
+        g.M = (int)min(side_rows_cap, (long)gcap * (per_token ? 25 : 1));  // rows launched (the live count is read on the device: mcnt)
         g.mcnt = w.cnt2 + (per_token ? 1 : 0);
         g.cnt_stride = 0;
         return gemm_launch(h, g, stream);
     };
     LFRUN(lin_b(LF_DOWN, w.CG, 256, nullptr, w.CW, cap, 0, 0, 0, 2, true));
-    hipLaunchKernelGGL(lf_fine_fill_kernel, dim3(cap, 2), blk, 0, stream, w.CW, w.nmatch, cap, w.X);
+    hipLaunchKernelGGL(lf_fine_fill_kernel, dim3(gcap, 2), blk, 0, stream, w.CW, w.nmatch, cap, w.X);
     const long wcap = (long)cap * 25;
     LFRUN(lin_b(LF_MERGEF, w.X, 256, nullptr, w.F, wcap, 0, 1, 0, 2, true));
     auto fine_layer = [&](int layer, int side0, int nsides, int cross) -> int {
@@ -677,7 +679,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
         if ((r = lin_b(base + 0, w.F, 128, nullptr, w.fq, wcap, 0, 1, side0, nsides, false))) return r;
         if ((r = lin_b(base + 1, w.F, 128, nullptr, w.fk, wcap, 0, 1, src0, nsides, false))) return r;
         if ((r = lin_b(base + 2, w.F, 128, nullptr, w.fv, wcap, 0, 1, src0, nsides, false))) return r;
-        hipLaunchKernelGGL(lf_la_window_kernel, dim3(cap, nsides), blk, 0, stream, w.fq, w.fk, w.fv, w.nmatch, cap, side0, cross,
+        hipLaunchKernelGGL(lf_la_window_kernel, dim3(gcap, nsides), blk, 0, stream, w.fq, w.fk, w.fv, w.nmatch, cap, side0, cross,
                            w.fatt);
         if ((r = lin_b(base + 3, w.fatt, 128, nullptr, w.fm, wcap, 0, 1, side0, nsides, false))) return r;
         const int nl = 32 + layer * 4;
@@ -699,7 +701,7 @@ extern "C" int imcui_hip_loftr_forward(imcui_hip_t* h, const float* packed, cons
     LFRUN(fine_layer(1, 0, 1, 1));  // cross: window0 <- (window0, window1)
     LFRUN(fine_layer(1, 1, 1, 1));  //        window1 <- (window1, updated window0)
     // kornia: scale = hw0_i[0] / hw0_c[0] (= 8) for BOTH images' coarse key-points, fine offsets scaled by hw0_i[0] / hw0_f[0] (= 2)
-    hipLaunchKernelGGL(lf_fine_match_kernel, dim3(cdiv(cap, 4)), blk, 0, stream, w.F, w.mi, w.mj, w.nmatch, cap, wcs[0], wcs[1],
+    hipLaunchKernelGGL(lf_fine_match_kernel, dim3(cdiv(gcap, 4)), blk, 0, stream, w.F, w.mi, w.mj, w.nmatch, cap, wcs[0], wcs[1],
                        (float)H0 / (float)hcs[0], (float)H0 / (float)(H0 / 2), keypoints0, keypoints1);
     hipMemcpyAsync(confidence, w.mconf, (size_t)cap * sizeof(float), hipMemcpyDeviceToDevice, stream);
     hipLaunchKernelGGL(lf_copy_int_kernel, dim3(cdiv(cap, 256)), blk, 0, stream, w.mb, batch_indexes, cap);

@@ -1,6 +1,7 @@
 """Lab (round 6): where the window evaluation of LoFTR's last FPN stage stops paying.  1024 x 1024 pairs, the match count driven by the coarse
 threshold (synthetic weights: the dual soft-max is diffuse, so a lower threshold admits more mutual matches); per threshold the step time with
-option loftr_fine_sparse = 0 (dense maps), 2 (always on the windows) and 1 (the cost model of csrc/loftr.hip picks).
+option loftr_fine_sparse = 0 (dense maps, no read-back of the match count: capacity-sized fine-level grids), 2 (always on the windows) and 1
+(the cost model of csrc/loftr.hip picks; with the count read back the fine level launches for the matches that exist, whichever way the stage runs).
     python tools/loftr_fine_lab.py > profiles/r06_lab_loftr_fine.txt"""
 import os
 import sys
@@ -23,7 +24,7 @@ img1 = base[..., 8 : H + 8, 16 : W + 16].contiguous().repeat(B, 1, 1, 1).to(dev)
 sd = loftr_state_dict(0)
 print(f"# LoFTR {W}x{H}, {B} pairs per step, 3 x f16 split arithmetic; ms per step (HIP events over 5 steps after 2 warm-ups)")
 print(f"# {'threshold':>10s} {'matches/pair':>12s} {'dense':>9s} {'windows':>9s} {'auto':>9s}  auto took")
-for thr in (0.2, 0.05, 0.01, 0.003, 0.001, 0.0003, 0.0001, 0.00003, 0.00001):
+for thr in (0.2, 0.05, 0.01, 0.003, 0.001, 0.0003, 0.0001, 0.00003, 0.00001, 0.000005, 0.000002):
     model = LoFTR({"match_threshold": thr, "max_keypoints": None, "state_dict": sd}).eval().to(dev)
     row, nm, took = [], 0, ""
     for opt in (0, 2, 1):
